@@ -1,0 +1,226 @@
+/* woltka_hip.h — C ABI of libwoltka_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the `woltka classify` hot path.  The
+ * reference (qiyunzhu/woltka v0.1.7, pure Python) has no FFI of its own; the
+ * boundary below is what a ctypes binding added to the reference would call in
+ * place of the per-read Python loops.  Each entry point cites the reference
+ * code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ * -----------
+ *  - Plain C: opaque context, plain pointers + sizes, no torch/C++ types.
+ *  - Every function returns 0 on success, <0 on error (WK_E_*); the message is
+ *    available from wk_last_error().  The library never falls back to a CPU
+ *    path: without a usable HIP device wk_create() fails.
+ *  - The caller owns all host buffers; they need to stay valid only for the
+ *    duration of the call.  The library owns all device memory.
+ *  - Strings never cross the boundary.  The host interns every subject /
+ *    taxon / gene name into an int32 *feature id*.  Ids [0, n_nodes) are the
+ *    nodes of the classification hierarchy numbered in DFS pre-order (root is
+ *    0, parent id < child id); ids >= n_nodes are names that are not part of
+ *    the hierarchy (woltka/tree.py: "taxon not in tree").
+ *  - A *read* is one (query, mate) unit yielded by the reference's alignment
+ *    parsers (woltka/align.py:328-333); its candidates are a CSR segment.
+ *
+ * Count keys
+ * ----------
+ * Counts are exact integers.  A read that contributes 1/k to each of k
+ * candidates (woltka/classify.py:167-170) increments the counter of the key
+ * (job, k, group, feature) by one; the host reconstitutes sum_k n_k / k as an
+ * exact rational before rounding (woltka/util.py:323-354).  Key layout
+ * (uint64): [63:61] job | [60:49] k (1..4095) | [48:28] group | [27:0] feature.
+ */
+#ifndef WOLTKA_HIP_H
+#define WOLTKA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WK_ABI_VERSION 1
+
+/* error codes */
+#define WK_OK 0
+#define WK_E_HIP (-1)      /* HIP runtime error (no device, OOM, launch failure) */
+#define WK_E_ARG (-2)      /* invalid argument */
+#define WK_E_STATE (-3)    /* required table not uploaded */
+#define WK_E_CAPACITY (-4) /* count table / output buffer too small */
+#define WK_E_RANGE (-5)    /* value does not fit the key layout (k > 4095, ...) */
+
+/* key layout */
+#define WK_KEY_FEATURE_BITS 28
+#define WK_KEY_GROUP_BITS 21
+#define WK_KEY_K_BITS 12
+#define WK_KEY_JOB_BITS 3
+#define WK_MAX_JOBS 8
+#define WK_MAX_K 4095
+#define WK_FEATURE_UNASSIGNED 0x0FFFFFFF /* 'Unassigned', workflow.py:1038-1039 */
+#define WK_MAX_FEATURE 0x0FFFFFFE
+
+/* assignment modes: which reference assigner a job reproduces */
+#define WK_MODE_NONE 0 /* classify.assign_none  (classify.py:32-51)  */
+#define WK_MODE_FREE 1 /* classify.assign_free  (classify.py:54-78)  */
+#define WK_MODE_RANK 2 /* classify.assign_rank  (classify.py:81-127) */
+
+/* job flags */
+#define WK_F_UNIQ 1u       /* --uniq       */
+#define WK_F_ABOVE 2u      /* --above      (classify.py:119-123) */
+#define WK_F_SUBOK 4u      /* --subok      (classify.py:75)      */
+#define WK_F_UNASSIGNED 8u /* --unassigned (workflow.py:1038-1039) */
+
+/* values written to the optional per-read assignment output */
+#define WK_ASSIGN_NONE (-1)  /* read not assigned (None)                     */
+#define WK_ASSIGN_MULTI (-2) /* read split over several features (a list)    */
+#define WK_ASSIGN_EMPTY (-3) /* read has no candidates (skipped altogether)  */
+
+typedef struct wk_ctx wk_ctx;
+
+/* One classification job = one rank of `--rank a,b,c` evaluated in the same
+ * pass over the records (the reference loops `for rank in ranks`,
+ * workflow.py:333-335). */
+typedef struct wk_job {
+    int32_t mode;       /* WK_MODE_*                                          */
+    int32_t rank_slot;  /* WK_MODE_RANK: slot filled by wk_build_rank_table   */
+    uint32_t flags;     /* WK_F_*                                             */
+    uint32_t _pad;
+    double major;       /* majority threshold as fraction (major/100), 0=off;
+                           compared in fp64 exactly as classify.py:317        */
+} wk_job;
+
+typedef struct wk_stats {
+    int64_t n_reads;      /* reads with >= 1 candidate ("Number of sequences
+                             classified", workflow.py:305,344)                */
+    int64_t n_records;    /* candidate records consumed                       */
+    int64_t n_pairs;      /* ordinal: read-gene matches emitted               */
+    int64_t table_used;   /* distinct count keys currently in the table       */
+} wk_stats;
+
+/* ---- life cycle -------------------------------------------------------- */
+int wk_abi_version(void);
+/* Create a context on HIP device `device`.  Fails (WK_E_HIP) without a GPU. */
+int wk_create(int device, wk_ctx** out);
+void wk_destroy(wk_ctx* ctx);
+const char* wk_last_error(const wk_ctx* ctx); /* ctx may be NULL */
+int wk_device_name(const wk_ctx* ctx, char* buf, size_t cap);
+int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
+/* Tuning knobs: "lds_slots" (LDS front-cache slots per workgroup, power of two
+ * in [64, 8192]), "use_lds" (0/1). Results never depend on them. */
+int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
+
+/* ---- static state ------------------------------------------------------ */
+/* Flattened hierarchy (replaces the `tree`/`rankdic` dicts produced by
+ * workflow.build_hierarchy, workflow.py:698-815, after tree.fill_root,
+ * tree.py:302-388).  Nodes are in DFS pre-order: parent[0] == 0 is the root,
+ * parent[v] < v otherwise; last[v] is the largest id in v's subtree;
+ * rank_code[v] is the host's integer code of rankdic[v] (0 = no rank). */
+int wk_set_tree(wk_ctx* ctx, const int32_t* parent, const int32_t* last,
+                const int32_t* rank_code, int32_t n_nodes);
+
+/* tree.find_rank (tree.py:467-510) for every node at once: fills slot `slot`
+ * with anc[v] = first node on the path v -> root (v itself first) whose
+ * rank_code equals `rank_code`, or -1.  Device kernel. */
+int wk_build_rank_table(wk_ctx* ctx, int32_t slot, int32_t rank_code);
+/* Download a rank table (testing / read-map output). `out` has n_nodes slots. */
+int wk_get_rank_table(wk_ctx* ctx, int32_t slot, int32_t* out);
+
+/* Gene coordinate tables (replaces the `coords` dict of encoded int64 queues
+ * built by ordinal.load_gene_coords / encode_genes, ordinal.py:338-473).
+ * Genome g owns genes [genome_off[g], genome_off[g+1]), sorted by start0.
+ * start0 = min(beg,end)-1, end = max(beg,end) (ordinal.py:459-465).
+ * gene_feature[i] is the feature id reported for gene i. */
+int wk_set_genes(wk_ctx* ctx, const int32_t* genome_off, int32_t n_genomes,
+                 const int32_t* start0, const int32_t* end,
+                 const int32_t* gene_feature, int32_t n_genes);
+
+/* ---- count table ------------------------------------------------------- */
+/* (Re)allocate the device count table with at least `min_slots` slots and
+ * clear it.  Must be called before the first classify call. */
+int wk_counts_reserve(wk_ctx* ctx, int64_t min_slots);
+int wk_counts_clear(wk_ctx* ctx);
+/* Copy all (key, count) pairs to the host. Returns WK_E_CAPACITY and sets *n
+ * to the required size if cap is too small. Order is unspecified. */
+int wk_counts_fetch(wk_ctx* ctx, uint64_t* keys, int64_t* counts, int64_t cap,
+                    int64_t* n);
+
+/* ---- per-chunk work ---------------------------------------------------- */
+/* Stage one packed chunk of plain-mapper output in HBM (replaces the
+ * (qryque, subque) lists yielded by align.plain_mapper, align.py:47-115).
+ *   subj[n_records]   candidate feature id per alignment record
+ *   qoff[n_reads + 1] CSR offsets of each read's records (int32: one staged
+ *                     chunk holds < 2^31 records; larger inputs are chunked)
+ *   group[n_reads]    optional stratum/sample slot per read, -1 = read is not
+ *                     in the strata map and is skipped (classify.py:239);
+ *                     NULL = group 0 for every read
+ * `subj_is_set` != 0 promises that no read lists the same subject twice (the
+ * reference's per-read sets, align.py:309); otherwise the device removes
+ * duplicates itself. */
+int wk_chunk_stage(wk_ctx* ctx, const int32_t* subj, const int32_t* qoff,
+                   int64_t n_reads, const int32_t* group, int subj_is_set);
+
+/* Run `n_jobs` classification jobs over the staged chunk and add the results
+ * to the count table (replaces workflow.assign_readmap, workflow.py:941-1058:
+ * assigner -> counter -> sum_dict).  May be called repeatedly on one staged
+ * chunk.  `out_assign`, if not NULL, receives n_jobs * n_reads int32
+ * (job-major): feature id, or WK_ASSIGN_*. */
+int wk_classify_staged(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
+                       int32_t* out_assign);
+
+/* Convenience: stage + classify in one call from host buffers. */
+int wk_classify_chunk(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
+                      const int32_t* subj, const int32_t* qoff,
+                      int64_t n_reads, const int32_t* group, int subj_is_set,
+                      int32_t* out_assign);
+
+/* Stage one chunk of ordinal-mapper input (replaces the qrys/lens/begs/ends
+ * arrays + sub2idx of ordinal.ordinal_mapper, ordinal.py:204-237).
+ *   genome[n_hits]  index into the gene tables, -1 = genome without genes
+ *   beg/end[n_hits] 0-based start, exclusive end (align.py:382-398)
+ *   len[n_hits]     alignment length; rel = ceil(len * th) in fp64
+ *                   (ordinal.py:281)
+ *   hoff[n_reads+1] CSR offsets: hits of each read (query, mate)
+ *   group[n_reads]  as above, may be NULL */
+int wk_ordinal_stage(wk_ctx* ctx, const int32_t* genome, const int32_t* beg,
+                     const int32_t* end, const uint32_t* len, int64_t n_hits,
+                     const int32_t* hoff, int64_t n_reads,
+                     const int32_t* group, double th);
+
+/* Match every staged hit against the genes of its genome (replaces
+ * ordinal.flush_chunk + match_read_gene / _quart, ordinal.py:243-335,
+ * 476-582, 650-811) and leave the per-read gene sets staged as the current
+ * classify chunk (subjects = gene feature ids), ready for
+ * wk_classify_staged().  A hit (rs, re, rel) matches gene (gs, ge) iff
+ * min(ge, re) - max(gs, rs) >= rel (ordinal.py:555,580). */
+int wk_ordinal_match(wk_ctx* ctx);
+
+/* Download the staged classify chunk (testing / read-map output): the
+ * candidate lists as currently staged (after wk_ordinal_match: gene feature
+ * ids per read, duplicates possible when several hits of a read match the same
+ * gene).  Pass NULL buffers to query sizes. */
+int wk_chunk_download(wk_ctx* ctx, int32_t* subj, int64_t subj_cap,
+                      int32_t* qoff, int64_t qoff_cap, int64_t* n_records,
+                      int64_t* n_reads);
+
+int wk_get_stats(wk_ctx* ctx, wk_stats* out);
+int wk_reset_stats(wk_ctx* ctx);
+
+/* ---- measurement ------------------------------------------------------- */
+/* HIP-event timing on the context's own stream (the stream every kernel of
+ * this library is launched on).  wk_timer_begin/end bracket a region;
+ * wk_timer_ms returns the elapsed GPU time of the last closed region.
+ * wk_last_kernel_ms returns the duration of the most recent launch of the
+ * named kernel family ("classify", "match_count", "match_write", "scan",
+ * "rank_table", "compact"), measured with events around that launch; event
+ * recording around individual kernels is enabled by wk_profile_kernels(1). */
+int wk_timer_begin(wk_ctx* ctx);
+int wk_timer_end(wk_ctx* ctx);
+int wk_timer_ms(wk_ctx* ctx, double* ms);
+int wk_profile_kernels(wk_ctx* ctx, int enable);
+int wk_last_kernel_ms(wk_ctx* ctx, const char* family, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WOLTKA_HIP_H */

@@ -1,0 +1,350 @@
+"""ctypes binding of ``libwoltka_hip.so`` (C ABI in ``include/woltka_hip.h``).
+
+This is the only route from the Python host layer to the device.  There is no
+CPU fallback: if the shared library is missing, or no HIP device is usable,
+the functions here raise ``RuntimeError`` — they never compute on the host.
+"""
+import ctypes as C
+import os
+from fractions import Fraction
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libwoltka_hip.so')
+
+# constants mirrored from include/woltka_hip.h
+ABI_VERSION = 1
+OK, E_HIP, E_ARG, E_STATE, E_CAPACITY, E_RANGE = 0, -1, -2, -3, -4, -5
+KEY_FEATURE_BITS, KEY_GROUP_BITS, KEY_K_BITS, KEY_JOB_BITS = 28, 21, 12, 3
+MAX_JOBS, MAX_K = 8, 4095
+FEATURE_UNASSIGNED, MAX_FEATURE = 0x0FFFFFFF, 0x0FFFFFFE
+MODE_NONE, MODE_FREE, MODE_RANK = 0, 1, 2
+F_UNIQ, F_ABOVE, F_SUBOK, F_UNASSIGNED = 1, 2, 4, 8
+ASSIGN_NONE, ASSIGN_MULTI, ASSIGN_EMPTY = -1, -2, -3
+MAX_RANK_SLOTS = MAX_JOBS * 4
+
+# every symbol the header declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    'wk_abi_version', 'wk_create', 'wk_destroy', 'wk_last_error',
+    'wk_device_name', 'wk_sync', 'wk_set_option', 'wk_set_tree',
+    'wk_build_rank_table', 'wk_get_rank_table', 'wk_set_genes',
+    'wk_counts_reserve', 'wk_counts_clear', 'wk_counts_fetch',
+    'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
+    'wk_ordinal_stage', 'wk_ordinal_match', 'wk_chunk_download',
+    'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
+    'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms')
+
+
+class Job(C.Structure):
+    """``struct wk_job``."""
+    _fields_ = [('mode', C.c_int32), ('rank_slot', C.c_int32),
+                ('flags', C.c_uint32), ('_pad', C.c_uint32),
+                ('major', C.c_double)]
+
+
+class Stats(C.Structure):
+    """``struct wk_stats``."""
+    _fields_ = [('n_reads', C.c_int64), ('n_records', C.c_int64),
+                ('n_pairs', C.c_int64), ('table_used', C.c_int64)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load the in-tree shared library and declare its prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `python -c "import '
+            '__graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950). '
+            'There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    i32p, i64p, u32p, u64p = (C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64))
+    proto = {
+        'wk_abi_version': (C.c_int, []),
+        'wk_create': (C.c_int, [C.c_int, C.POINTER(p)]),
+        'wk_destroy': (None, [p]),
+        'wk_last_error': (C.c_char_p, [p]),
+        'wk_device_name': (C.c_int, [p, C.c_char_p, C.c_size_t]),
+        'wk_sync': (C.c_int, [p]),
+        'wk_set_option': (C.c_int, [p, C.c_char_p, C.c_int64]),
+        'wk_set_tree': (C.c_int, [p, i32p, i32p, i32p, C.c_int32]),
+        'wk_build_rank_table': (C.c_int, [p, C.c_int32, C.c_int32]),
+        'wk_get_rank_table': (C.c_int, [p, C.c_int32, i32p]),
+        'wk_set_genes': (C.c_int, [p, i32p, C.c_int32, i32p, i32p, i32p,
+                                   C.c_int32]),
+        'wk_counts_reserve': (C.c_int, [p, C.c_int64]),
+        'wk_counts_clear': (C.c_int, [p]),
+        'wk_counts_fetch': (C.c_int, [p, u64p, i64p, C.c_int64, i64p]),
+        'wk_chunk_stage': (C.c_int, [p, i32p, i32p, C.c_int64, i32p,
+                                     C.c_int]),
+        'wk_classify_staged': (C.c_int, [p, C.POINTER(Job), C.c_int32, i32p]),
+        'wk_classify_chunk': (C.c_int, [p, C.POINTER(Job), C.c_int32, i32p,
+                                        i32p, C.c_int64, i32p, C.c_int,
+                                        i32p]),
+        'wk_ordinal_stage': (C.c_int, [p, i32p, i32p, i32p, u32p, C.c_int64,
+                                       i32p, C.c_int64, i32p, C.c_double]),
+        'wk_ordinal_match': (C.c_int, [p]),
+        'wk_chunk_download': (C.c_int, [p, i32p, C.c_int64, i32p, C.c_int64,
+                                        i64p, i64p]),
+        'wk_get_stats': (C.c_int, [p, C.POINTER(Stats)]),
+        'wk_reset_stats': (C.c_int, [p]),
+        'wk_timer_begin': (C.c_int, [p]),
+        'wk_timer_end': (C.c_int, [p]),
+        'wk_timer_ms': (C.c_int, [p, C.POINTER(C.c_double)]),
+        'wk_profile_kernels': (C.c_int, [p, C.c_int]),
+        'wk_last_kernel_ms': (C.c_int, [p, C.c_char_p,
+                                        C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in proto.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wk_abi_version() != ABI_VERSION:
+        raise RuntimeError('libwoltka_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def _arr(a, dtype):
+    """Contiguous array of the given dtype (no copy when already so)."""
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+def decode_keys(keys):
+    """Split packed count keys into (job, k, group, feature) arrays."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    feat = (keys & np.uint64((1 << KEY_FEATURE_BITS) - 1)).astype(np.int64)
+    grp = ((keys >> np.uint64(KEY_FEATURE_BITS)) &
+           np.uint64((1 << KEY_GROUP_BITS) - 1)).astype(np.int64)
+    k = ((keys >> np.uint64(KEY_FEATURE_BITS + KEY_GROUP_BITS)) &
+         np.uint64((1 << KEY_K_BITS) - 1)).astype(np.int64)
+    job = (keys >> np.uint64(61)).astype(np.int64)
+    return job, k, grp, feat
+
+
+class Context:
+    """One device context (one per GPU; use from one thread at a time)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.wk_create(int(device), C.byref(h))
+        if rc != OK:
+            msg = self._lib.wk_last_error(None).decode()
+            raise RuntimeError(f'wk_create(device={device}) failed: {msg}')
+        self._h = h
+        self.device = device
+        self.n_nodes = 0
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self._lib.wk_last_error(self._h).decode()
+        if rc in (E_ARG, E_RANGE):
+            raise ValueError(msg)
+        if rc == E_CAPACITY:
+            raise OverflowError(msg)
+        raise RuntimeError(msg)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.wk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self._lib.wk_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        self._check(self._lib.wk_sync(self._h))
+
+    def set_option(self, name, value):
+        self._check(self._lib.wk_set_option(self._h, name.encode(),
+                                            int(value)))
+
+    # -- static state -----------------------------------------------------
+    def set_tree(self, parent, last, rank_code):
+        parent, last, rank_code = (_arr(parent, np.int32),
+                                   _arr(last, np.int32),
+                                   _arr(rank_code, np.int32))
+        n = parent.size
+        if last.size != n or rank_code.size != n:
+            raise ValueError('tree arrays differ in length')
+        self._check(self._lib.wk_set_tree(
+            self._h, _ptr(parent, C.c_int32), _ptr(last, C.c_int32),
+            _ptr(rank_code, C.c_int32), n))
+        self.n_nodes = n
+
+    def build_rank_table(self, slot, rank_code):
+        self._check(self._lib.wk_build_rank_table(self._h, slot, rank_code))
+
+    def get_rank_table(self, slot):
+        out = np.empty(self.n_nodes, dtype=np.int32)
+        self._check(self._lib.wk_get_rank_table(self._h, slot,
+                                                _ptr(out, C.c_int32)))
+        return out
+
+    def set_genes(self, genome_off, start0, end, gene_feature):
+        genome_off = _arr(genome_off, np.int32)
+        start0, end, gene_feature = (_arr(start0, np.int32),
+                                     _arr(end, np.int32),
+                                     _arr(gene_feature, np.int32))
+        self._check(self._lib.wk_set_genes(
+            self._h, _ptr(genome_off, C.c_int32), genome_off.size - 1,
+            _ptr(start0, C.c_int32), _ptr(end, C.c_int32),
+            _ptr(gene_feature, C.c_int32), start0.size))
+
+    # -- counts -----------------------------------------------------------
+    def counts_reserve(self, min_slots):
+        self._check(self._lib.wk_counts_reserve(self._h, int(min_slots)))
+
+    def counts_clear(self):
+        self._check(self._lib.wk_counts_clear(self._h))
+
+    def counts_fetch(self):
+        """Return (keys uint64[], counts int64[]) of the device count table."""
+        n = C.c_int64(0)
+        rc = self._lib.wk_counts_fetch(self._h, None, None, 0, C.byref(n))
+        if rc == OK and n.value == 0:
+            return np.empty(0, np.uint64), np.empty(0, np.int64)
+        if rc not in (OK, E_CAPACITY):
+            self._check(rc)
+        keys = np.empty(n.value, dtype=np.uint64)
+        vals = np.empty(n.value, dtype=np.int64)
+        self._check(self._lib.wk_counts_fetch(
+            self._h, _ptr(keys, C.c_uint64), _ptr(vals, C.c_int64), n.value,
+            C.byref(n)))
+        return keys[:n.value], vals[:n.value]
+
+    # -- classify ---------------------------------------------------------
+    @staticmethod
+    def _jobs(jobs):
+        arr = (Job * len(jobs))()
+        for i, j in enumerate(jobs):
+            arr[i] = j
+        return arr
+
+    def chunk_stage(self, subj, qoff, group=None, subj_is_set=False):
+        subj, qoff = _arr(subj, np.int32), _arr(qoff, np.int32)
+        n_reads = qoff.size - 1
+        if group is not None:
+            group = _arr(group, np.int32)
+            if group.size != n_reads:
+                raise ValueError('group must have one entry per read')
+        self._check(self._lib.wk_chunk_stage(
+            self._h, _ptr(subj, C.c_int32), _ptr(qoff, C.c_int32), n_reads,
+            _ptr(group, C.c_int32), int(bool(subj_is_set))))
+        self._n_reads = n_reads
+
+    def classify_staged(self, jobs, want_assign=False):
+        out = None
+        if want_assign:
+            out = np.empty((len(jobs), self._n_reads), dtype=np.int32)
+        self._check(self._lib.wk_classify_staged(
+            self._h, self._jobs(jobs), len(jobs), _ptr(out, C.c_int32)))
+        return out
+
+    def classify_chunk(self, jobs, subj, qoff, group=None, subj_is_set=False,
+                       want_assign=False):
+        self.chunk_stage(subj, qoff, group, subj_is_set)
+        return self.classify_staged(jobs, want_assign)
+
+    # -- ordinal ----------------------------------------------------------
+    def ordinal_stage(self, genome, beg, end, length, hoff, th, group=None):
+        genome, beg, end = (_arr(genome, np.int32), _arr(beg, np.int32),
+                            _arr(end, np.int32))
+        length, hoff = _arr(length, np.uint32), _arr(hoff, np.int32)
+        n_hits, n_reads = genome.size, hoff.size - 1
+        if not (beg.size == end.size == length.size == n_hits):
+            raise ValueError('hit arrays differ in length')
+        if group is not None:
+            group = _arr(group, np.int32)
+        self._check(self._lib.wk_ordinal_stage(
+            self._h, _ptr(genome, C.c_int32), _ptr(beg, C.c_int32),
+            _ptr(end, C.c_int32), _ptr(length, C.c_uint32), n_hits,
+            _ptr(hoff, C.c_int32), n_reads, _ptr(group, C.c_int32),
+            float(th)))
+        self._n_reads = n_reads
+
+    def ordinal_match(self):
+        self._check(self._lib.wk_ordinal_match(self._h))
+
+    def chunk_download(self):
+        """Return (subj int32[], qoff int32[]) of the staged classify chunk."""
+        nrec, nrd = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.wk_chunk_download(
+            self._h, None, 0, None, 0, C.byref(nrec), C.byref(nrd)))
+        subj = np.empty(nrec.value, dtype=np.int32)
+        qoff = np.empty(nrd.value + 1, dtype=np.int32)
+        self._check(self._lib.wk_chunk_download(
+            self._h, _ptr(subj, C.c_int32), subj.size, _ptr(qoff, C.c_int32),
+            qoff.size, C.byref(nrec), C.byref(nrd)))
+        return subj, qoff
+
+    # -- stats / timing ---------------------------------------------------
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.wk_get_stats(self._h, C.byref(s)))
+        return {'n_reads': s.n_reads, 'n_records': s.n_records,
+                'n_pairs': s.n_pairs, 'table_used': s.table_used}
+
+    def reset_stats(self):
+        self._check(self._lib.wk_reset_stats(self._h))
+
+    def timer_begin(self):
+        self._check(self._lib.wk_timer_begin(self._h))
+
+    def timer_end(self):
+        self._check(self._lib.wk_timer_end(self._h))
+
+    def timer_ms(self):
+        ms = C.c_double(0)
+        self._check(self._lib.wk_timer_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def profile_kernels(self, enable=True):
+        self._check(self._lib.wk_profile_kernels(self._h, int(enable)))
+
+    def last_kernel_ms(self, family):
+        ms = C.c_double(0)
+        self._check(self._lib.wk_last_kernel_ms(self._h, family.encode(),
+                                                C.byref(ms)))
+        return ms.value
+
+
+def counts_to_fractions(keys, vals):
+    """Fold (job, k, group, feature) -> n into {(job, group, feature):
+    Fraction} = sum_k n_k / k  (exact; woltka/classify.py:167-170)."""
+    job, k, grp, feat = decode_keys(keys)
+    res = {}
+    for j, kk, g, f, n in zip(job.tolist(), k.tolist(), grp.tolist(),
+                              feat.tolist(), np.asarray(vals).tolist()):
+        key = (j, g, f)
+        res[key] = res.get(key, 0) + Fraction(n, kk)
+    return res

@@ -1,0 +1,213 @@
+// wk_ordinal.hpp — coord-match ("ordinal") read <-> gene interval overlap.
+//
+// Reproduces ordinal.flush_chunk + match_read_gene / match_read_gene_quart
+// (woltka/ordinal.py:243-335, 476-582, 650-811).  All three reference
+// matchers decide the same predicate (ordinal.py:555, 580, 644-645):
+//
+//     hit (rs, re, rel) matches gene (gs, ge)
+//         <=>  min(ge, re) - max(gs, rs) >= rel,        rel = ceil(len * th) >= 1
+//
+// The reference evaluates it with a sweep over a merged, sorted queue of all
+// gene and read end points per genome, which needs the reads sorted per chunk.
+// Here the genes of a genome are sorted once by start (and carry a running
+// maximum of their ends); each hit then needs one binary search plus a short
+// backward scan in cache-resident tables, so reads are never sorted and their
+// records are touched exactly once per pass.
+#pragma once
+#include "wk_device.hpp"
+
+namespace wk {
+
+constexpr int kMatchThreads = 256;
+constexpr int kMatchItems = 4;
+constexpr int kMatchTile = kMatchThreads * kMatchItems;
+
+struct MatchArgs {
+    // per hit
+    const int32_t* genome;
+    const int32_t* beg;
+    const int32_t* end;
+    const uint32_t* len;
+    int64_t n_hits;
+    double th;
+    // gene tables
+    const int32_t* genome_off;  // [n_genomes + 1]
+    const int32_t* gstart;      // [n_genes] start0, ascending per genome
+    const int32_t* gend;        // [n_genes]
+    const int32_t* gpmax;       // [n_genes] running max of gend inside the genome
+    const int32_t* gfeat;       // [n_genes] feature id
+    int32_t n_genomes;
+};
+
+// rel = ceil(len * th) evaluated in fp64 exactly like numpy does in
+// ordinal.py:281 (uint32 -> float64 is exact, one IEEE multiply, ceil).
+__device__ __forceinline__ int64_t effective_len(uint32_t len, double th) {
+    return (int64_t)ceil((double)len * th);
+}
+
+// Visit every gene matching the hit, calling f(gene_index).
+template <typename F>
+__device__ __forceinline__ void for_each_match(const MatchArgs& a, int64_t h, F&& f) {
+    const int32_t g = a.genome[h];
+    const uint32_t len = a.len[h];
+    if (g < 0 || g >= a.n_genomes || len == 0) return;  // ordinal.py:231, 294-297
+    const int64_t rs = a.beg[h];
+    const int64_t re = a.end[h];
+    const int64_t rel = effective_len(len, a.th);
+    const int32_t lo = a.genome_off[g];
+    const int32_t hi = a.genome_off[g + 1];
+    // a matching gene starts at or before re - rel ...
+    const int64_t max_start = re - rel;
+    int32_t l = lo, r = hi;
+    while (l < r) {  // upper bound: first gene with start0 > max_start
+        const int32_t m = l + ((r - l) >> 1);
+        if ((int64_t)a.gstart[m] <= max_start)
+            l = m + 1;
+        else
+            r = m;
+    }
+    // ... and ends at or after rs + rel
+    const int64_t min_end = rs + rel;
+    for (int32_t j = l - 1; j >= lo; --j) {
+        if ((int64_t)a.gpmax[j] < min_end) break;  // nothing at or before j reaches the hit
+        const int64_t gs = a.gstart[j];
+        const int64_t ge = a.gend[j];
+        const int64_t ov = (ge < re ? ge : re) - (gs > rs ? gs : rs);
+        if (ov >= rel) f(j);
+    }
+}
+
+// Pass 1: number of matching genes per hit + per-tile totals.
+__global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
+                                                                    int32_t* __restrict__ cnt,
+                                                                    unsigned long long* __restrict__ tile_sum) {
+    __shared__ unsigned long long wsum[kMatchThreads / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kMatchTile;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int it = 0; it < kMatchItems; ++it) {
+        const int64_t h = base + it * kMatchThreads + threadIdx.x;
+        if (h < a.n_hits) {
+            int32_t c = 0;
+            for_each_match(a, h, [&](int32_t) { c += 1; });
+            cnt[h] = c;
+            mine += (unsigned long long)c;
+        }
+    }
+    mine = wave_sum(mine);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int w = 0; w < kMatchThreads / kWave; ++w) s += wsum[w];
+        tile_sum[blockIdx.x] = s;
+    }
+}
+
+// Exclusive scan of the tile totals (single workgroup, serial over chunks of
+// blockDim; n_tiles is n_hits / 1024 so this is tiny).
+__global__ void __launch_bounds__(1024) tile_scan_kernel(const unsigned long long* __restrict__ tile_sum,
+                                                         unsigned long long* __restrict__ tile_off,
+                                                         int64_t n_tiles,
+                                                         unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long buf[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const unsigned long long v = (i < n_tiles) ? tile_sum[i] : 0ull;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        // Hillis-Steele inclusive scan in LDS
+        for (int off = 1; off < (int)blockDim.x; off <<= 1) {
+            unsigned long long add = (threadIdx.x >= (unsigned)off) ? buf[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const unsigned long long incl = buf[threadIdx.x];
+        if (i < n_tiles) tile_off[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// Pass 2: exclusive offsets per hit (tile-local scan + tile offset) and the
+// matched gene feature ids.
+__global__ void __launch_bounds__(kMatchThreads) match_write_kernel(MatchArgs a,
+                                                                    const int32_t* __restrict__ cnt,
+                                                                    const unsigned long long* __restrict__ tile_off,
+                                                                    int32_t* __restrict__ poff,
+                                                                    int32_t* __restrict__ pairs) {
+    __shared__ int32_t scan[kMatchTile];
+    const int64_t base = (int64_t)blockIdx.x * kMatchTile;
+    // load counts of the tile (hit order = LDS order)
+#pragma unroll
+    for (int it = 0; it < kMatchItems; ++it) {
+        const int idx = it * kMatchThreads + threadIdx.x;
+        const int64_t h = base + idx;
+        scan[idx] = (h < a.n_hits) ? cnt[h] : 0;
+    }
+    __syncthreads();
+    // each thread serially scans kMatchItems consecutive entries, then the
+    // per-thread totals are scanned across the workgroup
+    __shared__ int32_t tsum[kMatchThreads];
+    {
+        int32_t s = 0;
+        const int b = threadIdx.x * kMatchItems;
+#pragma unroll
+        for (int k = 0; k < kMatchItems; ++k) {
+            const int32_t v = scan[b + k];
+            scan[b + k] = s;
+            s += v;
+        }
+        tsum[threadIdx.x] = s;
+    }
+    __syncthreads();
+    for (int off = 1; off < kMatchThreads; off <<= 1) {
+        int32_t add = (threadIdx.x >= (unsigned)off) ? tsum[threadIdx.x - off] : 0;
+        __syncthreads();
+        tsum[threadIdx.x] += add;
+        __syncthreads();
+    }
+    {
+        const int b = threadIdx.x * kMatchItems;
+        const int32_t pre = (threadIdx.x == 0) ? 0 : tsum[threadIdx.x - 1];
+#pragma unroll
+        for (int k = 0; k < kMatchItems; ++k) scan[b + k] += pre;
+    }
+    __syncthreads();
+    const int64_t toff = (int64_t)tile_off[blockIdx.x];
+#pragma unroll
+    for (int it = 0; it < kMatchItems; ++it) {
+        const int idx = it * kMatchThreads + threadIdx.x;
+        const int64_t h = base + idx;
+        if (h < a.n_hits) {
+            const int64_t o = toff + scan[idx];
+            poff[h] = (int32_t)o;
+            if (cnt[h] > 0) {
+                int64_t w = o;
+                for_each_match(a, h, [&](int32_t j) { pairs[w++] = a.gfeat[j]; });
+            }
+        }
+    }
+}
+
+// Per-read gene offsets: the hits of a read are contiguous, so the genes of a
+// read are the concatenation of its hits' genes (union taken later by the
+// classify kernel's duplicate removal; ordinal.py:331-332 builds a set).
+__global__ void __launch_bounds__(256) read_offsets_kernel(const int32_t* __restrict__ hoff,
+                                                           const int32_t* __restrict__ poff,
+                                                           int64_t n_reads, int64_t n_hits,
+                                                           const unsigned long long* __restrict__ total,
+                                                           int32_t* __restrict__ qoff) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    const int32_t h = hoff[r];
+    qoff[r] = (h >= n_hits) ? (int32_t)(*total) : poff[h];
+}
+
+}  // namespace wk

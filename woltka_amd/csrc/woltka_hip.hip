@@ -1,0 +1,732 @@
+// woltka_hip.hip — C-ABI implementation of include/woltka_hip.h for gfx950.
+// Host-side resource management + kernel launches.  No CPU compute path: every
+// entry point that does work launches HIP kernels on the context's stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/woltka_hip.h"
+#include "wk_classify.hpp"
+#include "wk_device.hpp"
+#include "wk_ordinal.hpp"
+
+using namespace wk;
+
+namespace {
+
+thread_local std::string g_last_error;  // for calls without a context
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 4 + 256;  // headroom against re-allocation churn
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+            if (e != hipSuccess) {
+                p = nullptr;
+                return e;
+            }
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct KernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool valid = false;
+};
+
+}  // namespace
+
+struct wk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+
+    // hierarchy
+    DevBuf nodes, rank_code;
+    int32_t n_nodes = 0;
+    DevBuf rank_tab[WK_MAX_JOBS * 4];
+    bool rank_tab_valid[WK_MAX_JOBS * 4] = {};
+
+    // genes
+    DevBuf genome_off, gstart, gend, gpmax, gfeat;
+    int32_t n_genomes = 0, n_genes = 0;
+
+    // count table
+    DevBuf tkeys, tvals;
+    uint64_t slots = 0;
+
+    // staged classify chunk
+    DevBuf c_subj, c_qoff, c_group;
+    const int32_t* cur_subj = nullptr;  // points into c_subj or o_pairs
+    const int32_t* cur_qoff = nullptr;
+    int64_t n_reads = 0, n_records = 0;
+    bool has_group = false, subj_is_set = false, chunk_valid = false;
+
+    // staged ordinal chunk
+    DevBuf o_genome, o_beg, o_end, o_len, o_hoff, o_cnt, o_poff, o_pairs, o_qoff, o_tile_sum, o_tile_off;
+    int64_t n_hits = 0, o_reads = 0;
+    double th = 0.8;
+    bool ord_valid = false;
+
+    // misc device scalars: [0]=err(int) [1]=reads [2]=records [3]=total pairs [4]=compact counter
+    DevBuf scalars;
+    DevBuf assign_out, fetch_k, fetch_v;
+    int64_t stat_pairs = 0;
+
+    // timing
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool timer_closed = false;
+    bool profile = false;
+    std::map<std::string, KernelTimer> ktimers;
+
+    int lds_slots = 4096;  // LDS front-cache slots per workgroup (16 B each)
+    int use_lds = 1;
+};
+
+namespace {
+
+int fail(wk_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail((ctx), WK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+};
+
+unsigned long long* scalar_u64(wk_ctx* c, int idx) { return c->scalars.as<unsigned long long>() + idx; }
+int* scalar_err(wk_ctx* c) { return c->scalars.as<int>(); }
+
+KernelTimer* ktimer_begin(wk_ctx* c, const char* family) {
+    if (!c->profile) return nullptr;
+    KernelTimer& t = c->ktimers[family];
+    if (!t.a) {
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return nullptr;
+    }
+    t.valid = false;
+    (void)hipEventRecord(t.a, c->stream);
+    return &t;
+}
+void ktimer_end(wk_ctx* c, KernelTimer* t) {
+    if (!t) return;
+    (void)hipEventRecord(t->b, c->stream);
+    t->valid = true;
+}
+
+int check_device_errors(wk_ctx* c) {
+    int e = 0;
+    HIP_TRY(c, hipMemcpyAsync(&e, scalar_err(c), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (e == 0) return WK_OK;
+    HIP_TRY(c, hipMemsetAsync(scalar_err(c), 0, sizeof(int), c->stream));
+    if (e & kErrTableFull) return fail(c, WK_E_CAPACITY, "count table is full (%llu slots); call wk_counts_reserve with more slots", (unsigned long long)c->slots);
+    if (e & kErrKRange) return fail(c, WK_E_RANGE, "a read has more than %d candidate features", WK_MAX_K);
+    if (e & kErrFeatureRange) return fail(c, WK_E_RANGE, "feature id outside [0, %d]", WK_MAX_FEATURE);
+    if (e & kErrGroupRange) return fail(c, WK_E_RANGE, "group id outside [0, %d)", 1 << WK_KEY_GROUP_BITS);
+    if (e & kErrPairOverflow) return fail(c, WK_E_RANGE, "more than 2^31 read-gene pairs in one chunk");
+    return fail(c, WK_E_HIP, "unknown device error flag %d", e);
+}
+
+int upload(wk_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    HIP_TRY(c, b.reserve(bytes ? bytes : 1));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return WK_OK;
+}
+
+int grid_for(int64_t n, int threads, int max_blocks) {
+    int64_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+__global__ void __launch_bounds__(256) table_count_kernel(const unsigned long long* __restrict__ keys,
+                                                          uint64_t slots, unsigned long long* __restrict__ n) {
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x)
+        mine += (keys[i] != kEmptyKey) ? 1ull : 0ull;
+    mine = wave_sum(mine);
+    if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(n, mine);
+}
+
+__global__ void __launch_bounds__(256) table_compact_kernel(const unsigned long long* __restrict__ keys,
+                                                            const unsigned long long* __restrict__ vals,
+                                                            uint64_t slots, unsigned long long* __restrict__ cursor,
+                                                            unsigned long long* __restrict__ out_k,
+                                                            long long* __restrict__ out_v) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (slots + stride - 1) / stride;
+    const int lane = threadIdx.x & (kWave - 1);
+    for (uint64_t it = 0; it < rounds; ++it) {  // wave-uniform trip count: ballots see all lanes
+        const uint64_t i = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned long long k = (i < slots) ? keys[i] : kEmptyKey;
+        const bool live = (k != kEmptyKey);
+        const unsigned long long m = __ballot(live);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0, kWave);
+        if (live) {
+            const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            out_k[pos] = k;
+            out_v[pos] = (long long)vals[i];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int wk_abi_version(void) { return WK_ABI_VERSION; }
+
+const char* wk_last_error(const wk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int wk_create(int device, wk_ctx** out) {
+    if (!out) return fail(nullptr, WK_E_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, WK_E_HIP, "no HIP device available (%s); libwoltka_hip has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, WK_E_ARG, "device %d out of range [0,%d)", device, ndev);
+    wk_ctx* c = new (std::nothrow) wk_ctx();
+    if (!c) return fail(nullptr, WK_E_HIP, "out of host memory");
+    c->device = device;
+    DeviceGuard guard(device);
+    if ((e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
+        (e = c->scalars.reserve(64)) != hipSuccess ||
+        (e = hipMemsetAsync(c->scalars.p, 0, 64, c->stream)) != hipSuccess) {
+        int rc = fail(nullptr, WK_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+        wk_destroy(c);
+        return rc;
+    }
+    // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = c;
+    return WK_OK;
+}
+
+void wk_destroy(wk_ctx* c) {
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat,
+                      &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
+                      &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_poff, &c->o_pairs, &c->o_qoff,
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->assign_out, &c->fetch_k, &c->fetch_v};
+    for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : c->rank_tab) b.release();
+    for (auto& kv : c->ktimers) {
+        if (kv.second.a) (void)hipEventDestroy(kv.second.a);
+        if (kv.second.b) (void)hipEventDestroy(kv.second.b);
+    }
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int wk_device_name(const wk_ctx* c, char* buf, size_t cap) {
+    if (!c || !buf || cap == 0) return WK_E_ARG;
+    snprintf(buf, cap, "%s (%s, %d CUs)", c->prop.name, c->prop.gcnArchName, c->prop.multiProcessorCount);
+    return WK_OK;
+}
+
+int wk_sync(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WK_OK;
+}
+
+int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return WK_E_ARG;
+    if (!strcmp(name, "lds_slots")) {
+        if (value < 64 || value > 8192 || (value & (value - 1))) return fail(c, WK_E_ARG, "lds_slots must be a power of two in [64, 8192]");
+        c->lds_slots = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "use_lds")) {
+        c->use_lds = value ? 1 : 0;
+        return WK_OK;
+    }
+    return fail(c, WK_E_ARG, "unknown option '%s'", name);
+}
+
+// ---- static state ----------------------------------------------------------
+
+int wk_set_tree(wk_ctx* c, const int32_t* parent, const int32_t* last, const int32_t* rank_code, int32_t n) {
+    if (!c) return WK_E_ARG;
+    if (n < 0 || (n > 0 && (!parent || !last || !rank_code))) return fail(c, WK_E_ARG, "bad tree arguments");
+    if ((int64_t)n > (int64_t)WK_MAX_FEATURE) return fail(c, WK_E_RANGE, "too many hierarchy nodes");
+    DeviceGuard guard(c->device);
+    for (int32_t v = 0; v < n; ++v) {  // validate the pre-order contract the kernels rely on
+        const bool ok = (v == 0) ? (parent[0] == 0) : (parent[v] >= 0 && parent[v] < v);
+        if (!ok || last[v] < v || last[v] >= n) return fail(c, WK_E_ARG, "node %d violates the pre-order contract (parent %d, last %d)", v, parent[v], last[v]);
+    }
+    std::vector<Node> packed((size_t)n);
+    for (int32_t v = 0; v < n; ++v) packed[v] = Node{parent[v], last[v]};
+    int rc;
+    if ((rc = upload(c, c->nodes, packed.data(), (size_t)n * sizeof(Node)))) return rc;
+    if ((rc = upload(c, c->rank_code, rank_code, (size_t)n * sizeof(int32_t)))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `packed` is about to go out of scope
+    c->n_nodes = n;
+    for (bool& v : c->rank_tab_valid) v = false;
+    return WK_OK;
+}
+
+int wk_build_rank_table(wk_ctx* c, int32_t slot, int32_t code) {
+    if (!c) return WK_E_ARG;
+    if (slot < 0 || slot >= (int)(sizeof c->rank_tab / sizeof c->rank_tab[0])) return fail(c, WK_E_ARG, "rank slot %d out of range", slot);
+    if (c->n_nodes <= 0) return fail(c, WK_E_STATE, "no hierarchy uploaded (wk_set_tree)");
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, c->rank_tab[slot].reserve((size_t)c->n_nodes * sizeof(int32_t)));
+    KernelTimer* kt = ktimer_begin(c, "rank_table");
+    hipLaunchKernelGGL(rank_table_kernel, dim3((c->n_nodes + 255) / 256), dim3(256), 0, c->stream,
+                       c->nodes.as<Node>(), c->rank_code.as<int32_t>(), c->n_nodes, code,
+                       c->rank_tab[slot].as<int32_t>());
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    c->rank_tab_valid[slot] = true;
+    return WK_OK;
+}
+
+int wk_get_rank_table(wk_ctx* c, int32_t slot, int32_t* out) {
+    if (!c || !out) return WK_E_ARG;
+    if (slot < 0 || slot >= (int)(sizeof c->rank_tab / sizeof c->rank_tab[0]) || !c->rank_tab_valid[slot])
+        return fail(c, WK_E_STATE, "rank slot %d has not been built", slot);
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipMemcpyAsync(out, c->rank_tab[slot].p, (size_t)c->n_nodes * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WK_OK;
+}
+
+int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const int32_t* start0,
+                 const int32_t* end, const int32_t* gene_feature, int32_t n_genes) {
+    if (!c) return WK_E_ARG;
+    if (n_genomes < 0 || n_genes < 0 || !genome_off || (n_genes > 0 && (!start0 || !end || !gene_feature)))
+        return fail(c, WK_E_ARG, "bad gene table arguments");
+    if (genome_off[0] != 0 || genome_off[n_genomes] != n_genes) return fail(c, WK_E_ARG, "genome_off must run from 0 to n_genes");
+    // running maximum of gene ends per genome (prunes the backward scan)
+    std::vector<int32_t> pmax((size_t)n_genes);
+    for (int32_t g = 0; g < n_genomes; ++g) {
+        if (genome_off[g + 1] < genome_off[g]) return fail(c, WK_E_ARG, "genome_off is not monotone at genome %d", g);
+        int32_t m = INT32_MIN;
+        for (int32_t i = genome_off[g]; i < genome_off[g + 1]; ++i) {
+            if (i > genome_off[g] && start0[i] < start0[i - 1]) return fail(c, WK_E_ARG, "genes of genome %d are not sorted by start", g);
+            if (end[i] < start0[i]) return fail(c, WK_E_ARG, "gene %d has end < start", i);
+            if (gene_feature[i] < 0 || gene_feature[i] > WK_MAX_FEATURE) return fail(c, WK_E_RANGE, "gene feature id out of range");
+            m = end[i] > m ? end[i] : m;
+            pmax[i] = m;
+        }
+    }
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = upload(c, c->genome_off, genome_off, ((size_t)n_genomes + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->gstart, start0, (size_t)n_genes * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->gend, end, (size_t)n_genes * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->gpmax, pmax.data(), (size_t)n_genes * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->gfeat, gene_feature, (size_t)n_genes * sizeof(int32_t)))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_genomes = n_genomes;
+    c->n_genes = n_genes;
+    return WK_OK;
+}
+
+// ---- count table -------------------------------------------------------------
+
+int wk_counts_clear(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved");
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipMemsetAsync(c->tkeys.p, 0xFF, c->slots * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->tvals.p, 0, c->slots * sizeof(uint64_t), c->stream));
+    return WK_OK;
+}
+
+int wk_counts_reserve(wk_ctx* c, int64_t min_slots) {
+    if (!c) return WK_E_ARG;
+    if (min_slots < 1) min_slots = 1;
+    uint64_t s = 1024;
+    while (s < (uint64_t)min_slots) s <<= 1;
+    DeviceGuard guard(c->device);
+    if (s != c->slots) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->tkeys.release();
+        c->tvals.release();
+        HIP_TRY(c, c->tkeys.reserve(s * sizeof(uint64_t)));
+        HIP_TRY(c, c->tvals.reserve(s * sizeof(uint64_t)));
+        c->slots = s;
+    }
+    return wk_counts_clear(c);
+}
+
+int wk_counts_fetch(wk_ctx* c, uint64_t* keys, int64_t* counts, int64_t cap, int64_t* n) {
+    if (!c || !n) return WK_E_ARG;
+    if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved");
+    DeviceGuard guard(c->device);
+    int rc = check_device_errors(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 4), 0, sizeof(unsigned long long), c->stream));
+    const int blocks = grid_for((int64_t)c->slots, 256, 2048);
+    hipLaunchKernelGGL(table_count_kernel, dim3(blocks), dim3(256), 0, c->stream, c->tkeys.as<unsigned long long>(),
+                       c->slots, scalar_u64(c, 4));
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long used = 0;
+    HIP_TRY(c, hipMemcpyAsync(&used, scalar_u64(c, 4), sizeof used, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n = (int64_t)used;
+    if ((int64_t)used > cap || (used && (!keys || !counts))) return fail(c, WK_E_CAPACITY, "output capacity %lld < %llu entries", (long long)cap, used);
+    if (used == 0) return WK_OK;
+    HIP_TRY(c, c->fetch_k.reserve(used * sizeof(uint64_t)));
+    HIP_TRY(c, c->fetch_v.reserve(used * sizeof(int64_t)));
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 4), 0, sizeof(unsigned long long), c->stream));
+    KernelTimer* kt = ktimer_begin(c, "compact");
+    hipLaunchKernelGGL(table_compact_kernel, dim3(blocks), dim3(256), 0, c->stream, c->tkeys.as<unsigned long long>(),
+                       c->tvals.as<unsigned long long>(), c->slots, scalar_u64(c, 4),
+                       c->fetch_k.as<unsigned long long>(), c->fetch_v.as<long long>());
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(keys, c->fetch_k.p, used * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(counts, c->fetch_v.p, used * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WK_OK;
+}
+
+// ---- classify ----------------------------------------------------------------
+
+int wk_chunk_stage(wk_ctx* c, const int32_t* subj, const int32_t* qoff, int64_t n_reads, const int32_t* group,
+                   int subj_is_set) {
+    if (!c) return WK_E_ARG;
+    if (n_reads < 0 || !qoff) return fail(c, WK_E_ARG, "bad chunk arguments");
+    const int64_t n_rec = qoff[n_reads];
+    if (qoff[0] != 0 || n_rec < 0 || (n_rec > 0 && !subj)) return fail(c, WK_E_ARG, "qoff must start at 0 and end at n_records");
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = upload(c, c->c_subj, subj, (size_t)n_rec * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->c_qoff, qoff, ((size_t)n_reads + 1) * sizeof(int32_t)))) return rc;
+    if (group && (rc = upload(c, c->c_group, group, (size_t)n_reads * sizeof(int32_t)))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffers are only valid during the call
+    c->cur_subj = c->c_subj.as<int32_t>();
+    c->cur_qoff = c->c_qoff.as<int32_t>();
+    c->n_reads = n_reads;
+    c->n_records = n_rec;
+    c->has_group = group != nullptr;
+    c->subj_is_set = subj_is_set != 0;
+    c->chunk_valid = true;
+    return WK_OK;
+}
+
+int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* out_assign) {
+    if (!c) return WK_E_ARG;
+    if (!jobs || n_jobs < 1 || n_jobs > WK_MAX_JOBS) return fail(c, WK_E_ARG, "n_jobs must be in [1,%d]", WK_MAX_JOBS);
+    if (!c->chunk_valid) return fail(c, WK_E_STATE, "no chunk staged");
+    if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
+    DeviceGuard guard(c->device);
+
+    ClassifyArgs a{};
+    a.subj = c->cur_subj;
+    a.qoff = c->cur_qoff;
+    a.group = c->has_group ? c->c_group.as<int32_t>() : nullptr;
+    a.n_reads = c->n_reads;
+    a.nodes = c->n_nodes ? c->nodes.as<Node>() : nullptr;
+    a.n_nodes = c->n_nodes;
+    a.n_jobs = n_jobs;
+    a.subj_is_set = c->subj_is_set ? 1 : 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const wk_job& jb = jobs[j];
+        JobDev d{};
+        d.mode = jb.mode;
+        d.flags = jb.flags;
+        d.major = jb.major;
+        d.anc = nullptr;
+        if (jb.mode == WK_MODE_FREE || jb.mode == WK_MODE_RANK) {
+            if (c->n_nodes <= 0) return fail(c, WK_E_STATE, "job %d needs a hierarchy (wk_set_tree)", j);
+        } else if (jb.mode != WK_MODE_NONE) {
+            return fail(c, WK_E_ARG, "job %d: unknown mode %d", j, jb.mode);
+        }
+        if (jb.mode == WK_MODE_RANK) {
+            if (jb.rank_slot < 0 || jb.rank_slot >= (int)(sizeof c->rank_tab / sizeof c->rank_tab[0]) || !c->rank_tab_valid[jb.rank_slot])
+                return fail(c, WK_E_STATE, "job %d: rank slot %d has not been built", j, jb.rank_slot);
+            d.anc = c->rank_tab[jb.rank_slot].as<int32_t>();
+            if (jb.major < 0.0 || jb.major > 1.0) return fail(c, WK_E_ARG, "job %d: major must be a fraction in [0,1]", j);
+        }
+        a.jobs[j] = d;
+    }
+    if (out_assign) {
+        HIP_TRY(c, c->assign_out.reserve((size_t)n_jobs * (size_t)(c->n_reads ? c->n_reads : 1) * sizeof(int32_t)));
+        a.out_assign = c->assign_out.as<int32_t>();
+    }
+    a.stat_reads = scalar_u64(c, 1);
+    a.stat_records = scalar_u64(c, 2);
+    a.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
+
+    if (c->n_reads > 0) {
+        const int threads = 256;
+        // ~8 resident workgroups per CU; each keeps its own LDS front cache
+        const int blocks = grid_for(c->n_reads, threads, c->prop.multiProcessorCount * 8);
+        KernelTimer* kt = ktimer_begin(c, "classify");
+        if (c->use_lds) {
+            const size_t lds = (size_t)c->lds_slots * 16;
+            hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(threads), lds, c->stream, a, (uint32_t)c->lds_slots);
+        } else {
+            hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks), dim3(threads), 0, c->stream, a, 0u);
+        }
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (out_assign) {
+        HIP_TRY(c, hipMemcpyAsync(out_assign, c->assign_out.p, (size_t)n_jobs * (size_t)c->n_reads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return WK_OK;
+}
+
+int wk_classify_chunk(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, const int32_t* subj, const int32_t* qoff,
+                      int64_t n_reads, const int32_t* group, int subj_is_set, int32_t* out_assign) {
+    int rc = wk_chunk_stage(c, subj, qoff, n_reads, group, subj_is_set);
+    if (rc) return rc;
+    return wk_classify_staged(c, jobs, n_jobs, out_assign);
+}
+
+// ---- ordinal -------------------------------------------------------------------
+
+int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const int32_t* end, const uint32_t* len,
+                     int64_t n_hits, const int32_t* hoff, int64_t n_reads, const int32_t* group, double th) {
+    if (!c) return WK_E_ARG;
+    if (n_hits < 0 || n_reads < 0 || !hoff || (n_hits > 0 && (!genome || !beg || !end || !len)))
+        return fail(c, WK_E_ARG, "bad ordinal chunk arguments");
+    if (n_hits >= (1ll << 31)) return fail(c, WK_E_RANGE, "more than 2^31 hits in one chunk");
+    if (hoff[0] != 0 || hoff[n_reads] != n_hits) return fail(c, WK_E_ARG, "hoff must run from 0 to n_hits");
+    if (!(th > 0.0)) return fail(c, WK_E_ARG, "overlap threshold must be positive");
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = upload(c, c->o_genome, genome, (size_t)n_hits * 4))) return rc;
+    if ((rc = upload(c, c->o_beg, beg, (size_t)n_hits * 4))) return rc;
+    if ((rc = upload(c, c->o_end, end, (size_t)n_hits * 4))) return rc;
+    if ((rc = upload(c, c->o_len, len, (size_t)n_hits * 4))) return rc;
+    if ((rc = upload(c, c->o_hoff, hoff, ((size_t)n_reads + 1) * 4))) return rc;
+    if (group && (rc = upload(c, c->c_group, group, (size_t)n_reads * 4))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_hits = n_hits;
+    c->o_reads = n_reads;
+    c->th = th;
+    c->has_group = group != nullptr;
+    c->ord_valid = true;
+    c->chunk_valid = false;
+    return WK_OK;
+}
+
+int wk_ordinal_match(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    if (!c->ord_valid) return fail(c, WK_E_STATE, "no ordinal chunk staged");
+    if (c->genome_off.p == nullptr) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
+    DeviceGuard guard(c->device);
+    const int64_t n_hits = c->n_hits;
+    const int64_t n_tiles = (n_hits + kMatchTile - 1) / kMatchTile;
+    HIP_TRY(c, c->o_cnt.reserve((size_t)(n_hits ? n_hits : 1) * 4));
+    HIP_TRY(c, c->o_poff.reserve((size_t)(n_hits ? n_hits : 1) * 4));
+    HIP_TRY(c, c->o_tile_sum.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
+    HIP_TRY(c, c->o_tile_off.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
+    HIP_TRY(c, c->o_qoff.reserve(((size_t)c->o_reads + 1) * 4));
+
+    MatchArgs a{};
+    a.genome = c->o_genome.as<int32_t>();
+    a.beg = c->o_beg.as<int32_t>();
+    a.end = c->o_end.as<int32_t>();
+    a.len = c->o_len.as<uint32_t>();
+    a.n_hits = n_hits;
+    a.th = c->th;
+    a.genome_off = c->genome_off.as<int32_t>();
+    a.gstart = c->gstart.as<int32_t>();
+    a.gend = c->gend.as<int32_t>();
+    a.gpmax = c->gpmax.as<int32_t>();
+    a.gfeat = c->gfeat.as<int32_t>();
+    a.n_genomes = c->n_genomes;
+
+    unsigned long long total = 0;
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+    if (n_hits > 0) {
+        KernelTimer* kt = ktimer_begin(c, "match_count");
+        hipLaunchKernelGGL(match_count_kernel, dim3((unsigned)n_tiles), dim3(kMatchThreads), 0, c->stream, a,
+                           c->o_cnt.as<int32_t>(), c->o_tile_sum.as<unsigned long long>());
+        ktimer_end(c, kt);
+        kt = ktimer_begin(c, "scan");
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->o_tile_sum.as<unsigned long long>(),
+                           c->o_tile_off.as<unsigned long long>(), n_tiles, scalar_u64(c, 3));
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&total, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (total >= (1ull << 31)) return fail(c, WK_E_RANGE, "more than 2^31 read-gene pairs in one chunk; stage fewer hits");
+        HIP_TRY(c, c->o_pairs.reserve((size_t)(total ? total : 1) * 4));
+        kt = ktimer_begin(c, "match_write");
+        hipLaunchKernelGGL(match_write_kernel, dim3((unsigned)n_tiles), dim3(kMatchThreads), 0, c->stream, a,
+                           c->o_cnt.as<int32_t>(), c->o_tile_off.as<unsigned long long>(), c->o_poff.as<int32_t>(),
+                           c->o_pairs.as<int32_t>());
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        HIP_TRY(c, c->o_pairs.reserve(4));
+    }
+    hipLaunchKernelGGL(read_offsets_kernel, dim3((unsigned)((c->o_reads + 1 + 255) / 256)), dim3(256), 0, c->stream,
+                       c->o_hoff.as<int32_t>(), c->o_poff.as<int32_t>(), c->o_reads, n_hits, scalar_u64(c, 3),
+                       c->o_qoff.as<int32_t>());
+    HIP_TRY(c, hipGetLastError());
+    c->stat_pairs += (int64_t)total;
+    // the per-read gene lists become the current classify chunk
+    c->cur_subj = c->o_pairs.as<int32_t>();
+    c->cur_qoff = c->o_qoff.as<int32_t>();
+    c->n_reads = c->o_reads;
+    c->n_records = (int64_t)total;
+    c->subj_is_set = false;  // several hits of a read may match the same gene
+    c->chunk_valid = true;
+    return WK_OK;
+}
+
+int wk_chunk_download(wk_ctx* c, int32_t* subj, int64_t subj_cap, int32_t* qoff, int64_t qoff_cap, int64_t* n_records,
+                      int64_t* n_reads) {
+    if (!c) return WK_E_ARG;
+    if (!c->chunk_valid) return fail(c, WK_E_STATE, "no chunk staged");
+    if (n_records) *n_records = c->n_records;
+    if (n_reads) *n_reads = c->n_reads;
+    if (!subj && !qoff) return WK_OK;
+    if ((subj && subj_cap < c->n_records) || (qoff && qoff_cap < c->n_reads + 1)) return fail(c, WK_E_CAPACITY, "download buffers too small");
+    DeviceGuard guard(c->device);
+    if (subj && c->n_records) HIP_TRY(c, hipMemcpyAsync(subj, c->cur_subj, (size_t)c->n_records * 4, hipMemcpyDeviceToHost, c->stream));
+    if (qoff) HIP_TRY(c, hipMemcpyAsync(qoff, c->cur_qoff, ((size_t)c->n_reads + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WK_OK;
+}
+
+// ---- statistics & timing -------------------------------------------------------
+
+int wk_get_stats(wk_ctx* c, wk_stats* out) {
+    if (!c || !out) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    unsigned long long s[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(s, scalar_u64(c, 1), sizeof s, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long used = 0;
+    if (c->slots) {
+        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 4), 0, 8, c->stream));
+        hipLaunchKernelGGL(table_count_kernel, dim3(grid_for((int64_t)c->slots, 256, 2048)), dim3(256), 0, c->stream,
+                           c->tkeys.as<unsigned long long>(), c->slots, scalar_u64(c, 4));
+        HIP_TRY(c, hipMemcpyAsync(&used, scalar_u64(c, 4), 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->n_reads = (int64_t)s[0];
+    out->n_records = (int64_t)s[1];
+    out->n_pairs = c->stat_pairs;
+    out->table_used = (int64_t)used;
+    return WK_OK;
+}
+
+int wk_reset_stats(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 1), 0, 16, c->stream));
+    c->stat_pairs = 0;
+    return WK_OK;
+}
+
+int wk_timer_begin(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    c->timer_closed = false;
+    HIP_TRY(c, hipEventRecord(c->t0, c->stream));
+    return WK_OK;
+}
+
+int wk_timer_end(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipEventRecord(c->t1, c->stream));
+    c->timer_closed = true;
+    return WK_OK;
+}
+
+int wk_timer_ms(wk_ctx* c, double* ms) {
+    if (!c || !ms) return WK_E_ARG;
+    if (!c->timer_closed) return fail(c, WK_E_STATE, "timer region not closed");
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipEventSynchronize(c->t1));
+    float f = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&f, c->t0, c->t1));
+    *ms = (double)f;
+    return WK_OK;
+}
+
+int wk_profile_kernels(wk_ctx* c, int enable) {
+    if (!c) return WK_E_ARG;
+    c->profile = enable != 0;
+    return WK_OK;
+}
+
+int wk_last_kernel_ms(wk_ctx* c, const char* family, double* ms) {
+    if (!c || !family || !ms) return WK_E_ARG;
+    auto it = c->ktimers.find(family);
+    if (it == c->ktimers.end() || !it->second.valid) return fail(c, WK_E_STATE, "no timed launch of kernel family '%s'", family);
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipEventSynchronize(it->second.b));
+    float f = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&f, it->second.a, it->second.b));
+    *ms = (double)f;
+    return WK_OK;
+}
+
+}  // extern "C"

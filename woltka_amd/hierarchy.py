@@ -1,0 +1,186 @@
+"""Flattening of a Woltka classification hierarchy into device arrays.
+
+The reference keeps the hierarchy as Python dicts ``tree = {child: parent}``
+and ``rankdic = {node: rank}`` (woltka/workflow.py:698-815) closed by
+``fill_root`` (woltka/tree.py:302-388) so that exactly one node is its own
+parent.  The device kernels instead use integer ids assigned in DFS pre-order:
+
+  * ``parent[v] < v`` for every non-root node, ``parent[0] == 0``;
+  * the subtree of ``v`` is the contiguous id range ``[v, last[v]]``;
+
+which turns "lowest common ancestor of a set" into "lowest ancestor of the
+smallest id whose range still contains the largest id" (see
+``csrc/wk_classify.hpp``), and turns ``find_rank`` into one table gather.
+"""
+import numpy as np
+
+
+class FeatureIndex:
+    """Bijection feature name <-> int32 id.
+
+    Ids ``[0, n_nodes)`` are hierarchy nodes in pre-order; names interned later
+    (subjects that are not part of the hierarchy) get ids ``>= n_nodes``.
+    """
+
+    def __init__(self, names=()):
+        self.names = list(names)
+        self.ids = {x: i for i, x in enumerate(self.names)}
+        if len(self.ids) != len(self.names):
+            raise ValueError('Feature names are not unique.')
+
+    def __len__(self):
+        return len(self.names)
+
+    def intern(self, name):
+        """Id of ``name``, allocating a new one on first sight."""
+        try:
+            return self.ids[name]
+        except KeyError:
+            i = len(self.names)
+            self.ids[name] = i
+            self.names.append(name)
+            return i
+
+    def get(self, name, default=-1):
+        return self.ids.get(name, default)
+
+
+class Hierarchy:
+    """Pre-order flattened hierarchy.
+
+    Attributes
+    ----------
+    index : FeatureIndex
+        Node names in pre-order (``index.names[v]``).
+    parent, last, rank_code : np.ndarray of int32
+        Arrays handed to ``wk_set_tree``.
+    rank_codes : dict of str -> int
+        Code (>= 1) of every rank name present in ``rankdic``.
+    """
+
+    def __init__(self, index, parent, last, rank_code, rank_codes, depth):
+        self.index = index
+        self.parent = parent
+        self.last = last
+        self.rank_code = rank_code
+        self.rank_codes = rank_codes
+        self.depth = depth
+
+    @property
+    def n_nodes(self):
+        return self.parent.size
+
+    def code_of(self, rank):
+        """Device code of a rank name (a rank nobody carries gets a fresh,
+        never-matching code, like ``rankdic.get(x) == rank`` never being
+        true)."""
+        return self.rank_codes.get(rank, len(self.rank_codes) + 1)
+
+
+def flatten_hierarchy(tree, rankdic=None, root=None):
+    """Number the nodes of ``tree`` in DFS pre-order and build device arrays.
+
+    Parameters
+    ----------
+    tree : dict of str -> str
+        Child-to-parent map *after* ``fill_root``: every parent is a key and
+        exactly the root maps to itself.
+    rankdic : dict of str -> str, optional
+        Node-to-rank map.
+    root : str, optional
+        Root identifier (detected when omitted).
+
+    Raises
+    ------
+    ValueError
+        A parent is missing, there is no unique root, or some node cannot
+        reach the root (a cycle).  The reference would loop forever when a
+        query walks into a cycle (woltka/tree.py:418-429); here it is rejected
+        up front.
+    """
+    names = list(tree)
+    n = len(names)
+    if n == 0:
+        return Hierarchy(FeatureIndex(), np.empty(0, np.int32),
+                         np.empty(0, np.int32), np.empty(0, np.int32), {},
+                         np.empty(0, np.int32))
+    tmp = dict(zip(names, range(n)))
+    try:
+        par = np.fromiter((tmp[tree[x]] for x in names), dtype=np.int64,
+                          count=n)
+    except KeyError as e:
+        raise ValueError(f'Parent {e} is not part of the hierarchy; call '
+                         'fill_root first.')
+    ids = np.arange(n, dtype=np.int64)
+    selfp = np.flatnonzero(par == ids)
+    if root is None:
+        if selfp.size != 1:
+            raise ValueError('Hierarchy must have exactly one root.')
+        r = int(selfp[0])
+    else:
+        r = tmp[root]
+        if selfp.size != 1 or selfp[0] != r:
+            raise ValueError('Hierarchy must have exactly one root.')
+
+    # children in CSR form, grouped by parent, siblings in insertion order
+    kids = np.flatnonzero(par != ids)
+    order = kids[np.argsort(par[kids], kind='stable')]
+    nkids = np.bincount(par[kids], minlength=n)
+    koff = np.concatenate(([0], np.cumsum(nkids)))
+
+    # breadth-first levels (each level stays grouped by parent)
+    depth = np.full(n, -1, dtype=np.int64)
+    depth[r] = 0
+    levels = [np.array([r], dtype=np.int64)]
+    while True:
+        cur = levels[-1]
+        cnt = nkids[cur]
+        tot = int(cnt.sum())
+        if tot == 0:
+            break
+        rep = np.repeat(np.arange(cur.size), cnt)
+        within = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        nxt = order[koff[cur][rep] + within]
+        depth[nxt] = len(levels)
+        levels.append(nxt)
+    if (depth < 0).any():
+        bad = names[int(np.flatnonzero(depth < 0)[0])]
+        raise ValueError(f'Node "{bad}" cannot reach the root (cyclic '
+                         'hierarchy).')
+
+    # subtree sizes, bottom-up
+    size = np.ones(n, dtype=np.int64)
+    for lvl in reversed(levels[1:]):
+        np.add.at(size, par[lvl], size[lvl])
+
+    # pre-order number = parent's number + 1 + sizes of earlier siblings
+    pre = np.zeros(n, dtype=np.int64)
+    for lvl in levels[1:]:
+        s = size[lvl]
+        cs = np.cumsum(s) - s
+        p = par[lvl]
+        first = np.ones(lvl.size, dtype=bool)
+        first[1:] = p[1:] != p[:-1]
+        gstart = np.maximum.accumulate(np.where(first, np.arange(lvl.size), 0))
+        pre[lvl] = pre[p] + 1 + cs - cs[gstart]
+
+    inv = np.empty(n, dtype=np.int64)
+    inv[pre] = ids
+    index = FeatureIndex([names[i] for i in inv.tolist()])
+    parent = pre[par][inv].astype(np.int32)
+    last = (pre + size - 1)[inv].astype(np.int32)
+    dep = depth[inv].astype(np.int32)
+
+    rank_codes = {}
+    rank_code = np.zeros(n, dtype=np.int32)
+    if rankdic:
+        get = tmp.get
+        for node, rank in rankdic.items():
+            t = get(node)
+            if t is None or rank is None:
+                continue
+            code = rank_codes.get(rank)
+            if code is None:
+                code = rank_codes[rank] = len(rank_codes) + 1
+            rank_code[pre[t]] = code
+    return Hierarchy(index, parent, last, rank_code, rank_codes, dep)
