@@ -432,6 +432,22 @@ def strip_suffix(subque, sep):
     return [set(s.rsplit(sep, 1)[0] for s in subs) for subs in subque]
 
 
+def make_assigner(rank, tree=None, rankdic=None, root=None, uniq=False,
+                  major=None, above=False, subok=False, cache=1024):
+    """The per-rank memoised assigner workflow.assign_readmap builds
+    (woltka/workflow.py:1017-1032): ``lru_cache(maxsize=cache)`` over subject
+    tuples."""
+    from functools import lru_cache, partial
+    if rank is None or rank == 'none' or tree is None:
+        fn = partial(assign_none, uniq=uniq)
+    elif rank == 'free':
+        fn = partial(assign_free, tree=tree, root=root, subok=subok)
+    else:
+        fn = partial(assign_rank, rank=rank, tree=tree, rankdic=rankdic,
+                     root=root, major=major, above=above, uniq=uniq)
+    return lru_cache(maxsize=cache)(fn)
+
+
 def classify_chunk(qryque, subque, rank, tree=None, rankdic=None, root=None,
                    uniq=False, major=None, above=False, subok=False,
                    unassigned=False, strata=None):

@@ -1,0 +1,392 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (qiyunzhu/woltka
+v0.1.7 under /root/reference) in the build container.
+
+    python tests/golden/make_golden.py
+
+The reference is imported unmodified through ``_refshim`` (which stands in for
+the absent third-party ``numba``/``biom`` imports and thereby selects the
+reference's own no-JIT code path).  Outputs are small JSON files under
+``tests/golden/vectors/``: inputs + what the reference returned.  Only those
+JSON files travel to the GPU box; this script is a no-op there.
+
+All randomness is seeded, so re-running reproduces the committed files.
+"""
+import json
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+
+OUT = os.path.join(HERE, 'vectors')
+DATA = os.path.join(HERE, 'data')
+
+RANKS = ['kingdom', 'phylum', 'class', 'order', 'family', 'genus', 'species']
+
+
+def jsonable(x):
+    if isinstance(x, (set, frozenset)):
+        return sorted(jsonable(i) for i in x)
+    if isinstance(x, (list, tuple)):
+        return [jsonable(i) for i in x]
+    if isinstance(x, dict):
+        return {('|'.join(map(str, k)) if isinstance(k, tuple) else str(k)):
+                jsonable(v) for k, v in x.items()}
+    try:
+        import numpy as np
+        if isinstance(x, np.generic):
+            return x.item()
+    except ImportError:
+        pass
+    return x
+
+
+def dump(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    fp = os.path.join(OUT, name)
+    with open(fp, 'w') as f:
+        json.dump(jsonable(obj), f, separators=(',', ':'), sort_keys=True)
+    print(f'{name}: {os.path.getsize(fp)} bytes')
+
+
+# --------------------------------------------------------------------------
+
+def random_tree(rng, n):
+    """Random rooted tree as {child: parent} + rank dict, root = 'r'."""
+    tree, depth, rankdic = {'r': 'r'}, {'r': 0}, {}
+    nodes = ['r']
+    for i in range(1, n):
+        p = rng.choice(nodes[-8:] if rng.random() < 0.5 else nodes)
+        name = f't{i}'
+        tree[name] = p
+        depth[name] = depth[p] + 1
+        nodes.append(name)
+        d = depth[name]
+        # ranks roughly follow depth, with unranked intermediates
+        if d <= len(RANKS) and rng.random() < 0.75:
+            rankdic[name] = RANKS[d - 1]
+        elif rng.random() < 0.3:
+            rankdic[name] = 'no rank'
+    if rng.random() < 0.2:
+        rankdic['r'] = 'kingdom'
+    return tree, rankdic
+
+
+def gen_classify(seed=2024):
+    from woltka.classify import (assign_none, assign_free, assign_rank,
+                                 counter, counter_strat)
+    from woltka.util import round_dict
+    rng = random.Random(seed)
+    cases = []
+    for ci in range(60):
+        n = rng.choice([3, 6, 12, 25, 60, 120])
+        tree, rankdic = random_tree(rng, n)
+        nodes = list(tree)
+        leaves = [x for x in nodes if x not in set(tree.values())] or nodes
+        pool = leaves + rng.sample(nodes, min(len(nodes), 5)) + ['x1', 'x2']
+        subque, qryque = [], []
+        for qi in range(40):
+            k = rng.choice([1, 1, 1, 2, 2, 3, 4, 6, 9, 16, 20])
+            if rng.random() < 0.5:
+                anchor = rng.choice(leaves)      # related subjects
+                lin = []
+                t = anchor
+                while True:
+                    lin.append(t)
+                    if tree[t] == t:
+                        break
+                    t = tree[t]
+                top = rng.choice(lin)
+                under = [x for x in leaves if top in _lineage(x, tree)]
+                subs = set(rng.choice(under) for _ in range(k))
+            else:
+                subs = set(rng.choice(pool) for _ in range(k))
+            subque.append(tuple(sorted(subs)))
+            qryque.append(f'q{qi}')
+        strata = {q: rng.choice(['sA', 'sB', 'sC']) for q in qryque
+                  if rng.random() < 0.8}
+        runs = []
+        present = sorted(set(rankdic.values()) - {'no rank'}) or ['genus']
+        settings = [dict(rank='none'), dict(rank='none', uniq=True),
+                    dict(rank='free'), dict(rank='free', subok=True),
+                    dict(rank='none', unassigned=True, uniq=True),
+                    dict(rank='free', unassigned=True)]
+        for rank in rng.sample(present, min(3, len(present))):
+            settings += [dict(rank=rank), dict(rank=rank, uniq=True),
+                         dict(rank=rank, above=True),
+                         dict(rank=rank, major=rng.choice([51, 60, 67, 80, 99])),
+                         dict(rank=rank, major=rng.choice([55, 75]), above=True),
+                         dict(rank=rank, unassigned=True),
+                         dict(rank=rank, above=True, unassigned=True)]
+        for st in settings:
+            rank = st['rank']
+            uniq, above = st.get('uniq', False), st.get('above', False)
+            subok, major = st.get('subok', False), st.get('major')
+            if rank == 'none':
+                taxque = [assign_none(s, uniq) for s in subque]
+            elif rank == 'free':
+                taxque = [assign_free(s, tree, 'r', subok) for s in subque]
+            else:
+                taxque = [assign_rank(s, rank, tree, rankdic, 'r',
+                                      major and major / 100, above, uniq)
+                          for s in subque]
+            tq = [x or 'Unassigned' for x in taxque] \
+                if st.get('unassigned') else taxque
+            counts = dict(counter(tq))
+            scounts = dict(counter_strat(qryque, tq, strata))
+            rounded = dict(counts)
+            round_dict(rounded)
+            runs.append(dict(params=st, taxque=taxque, counts=counts,
+                             strat_counts=scounts, rounded=rounded))
+        cases.append(dict(tree=tree, rankdic=rankdic, root='r',
+                          queries=qryque, subque=subque, strata=strata,
+                          runs=runs))
+    dump('classify_random.json', cases)
+
+
+def _lineage(x, tree):
+    out = [x]
+    while tree[x] != x:
+        x = tree[x]
+        out.append(x)
+    return out
+
+
+def gen_tree_walks(seed=7):
+    """find_rank / find_lca / get_lineage / fill_root on the bundled NCBI
+    taxonomy and on random forests."""
+    from woltka.tree import (read_nodes, fill_root, find_rank, find_lca,
+                             get_lineage)
+    from woltka.file import read_map_1st
+    rng = random.Random(seed)
+    with open(os.path.join(DATA, 'taxonomy', 'nodes.dmp')) as f:
+        tree, rankdic = read_nodes(f)
+    with open(os.path.join(DATA, 'taxonomy', 'taxid.map')) as f:
+        g2t = dict(read_map_1st(f))
+    root = fill_root(tree)
+    nodes = sorted(tree)
+    q = []
+    for _ in range(300):
+        k = rng.choice([1, 2, 2, 3, 5, 8])
+        taxa = [rng.choice(nodes) for _ in range(k)]
+        if rng.random() < 0.1:
+            taxa[rng.randrange(k)] = 'missing'
+        rank = rng.choice(['phylum', 'genus', 'species', 'family', 'nope'])
+        q.append(dict(taxa=taxa, rank=rank, lca=find_lca(taxa, tree),
+                      at_rank=[find_rank(t, rank, tree, rankdic) for t in taxa],
+                      lineage=get_lineage(taxa[0], tree)))
+    forests = []
+    for _ in range(40):
+        n = rng.choice([1, 2, 5, 10, 30])
+        t = {}
+        names = [f'a{i}' for i in range(n)]
+        for i, x in enumerate(names):
+            r = rng.random()
+            if i == 0 or r < 0.15:
+                t[x] = rng.choice([None, x, f'ghost{i}'])
+            else:
+                t[x] = rng.choice(names[:i])
+        if rng.random() < 0.3:
+            t['1'] = t.get('a0')
+        before = dict(t)
+        rt = fill_root(t)
+        forests.append(dict(before=before, after=t, root=rt))
+    dump('tree_walks.json', dict(root=root, n_nodes=len(tree), g2t=g2t,
+                                 queries=q, forests=forests))
+
+
+def gen_ordinal(seed=99):
+    import numpy as np
+    from woltka.ordinal import (encode_genes, flush_chunk, match_read_gene,
+                                match_read_gene_naive, match_read_gene_quart)
+    rng = random.Random(seed)
+    cases = []
+    for ci in range(80):
+        n_genomes = rng.choice([1, 2, 4])
+        coords, idmap, raw = {}, {}, {}
+        for g in range(n_genomes):
+            ng = rng.choice([0, 1, 3, 8, 25])
+            if ng == 0 and rng.random() < 0.5:
+                continue        # genome absent from the coords table
+            pos, lst, ids, genes = rng.randrange(1, 50), [], [], []
+            for i in range(ng):
+                ln = rng.randrange(1, 120)
+                b, e = pos, pos + ln - 1
+                if rng.random() < 0.5:
+                    b, e = e, b             # reverse strand: end < start in file
+                lst += [b, e]
+                ids.append(f'g{g}_{i}')
+                genes.append((b, e))
+                step = rng.randrange(-60, 80)   # overlaps / nesting happen
+                pos = max(1, pos + step)
+            name = f'G{g}'
+            arr = encode_genes(lst)
+            arr.sort(kind='stable')
+            coords[name], idmap[name], raw[name] = arr, ids, genes
+        th = rng.choice([0.8, 0.5, 0.55, 1.0, 0.01, 0.99])
+        n_q = rng.choice([1, 3, 10, 40])
+        rids, lens, begs, ends, idxmap, hits = [], [], [], [], {}, []
+        for qi in range(n_q):
+            for _ in range(rng.choice([1, 1, 2, 3])):
+                gname = f'G{rng.randrange(n_genomes + 1)}'  # maybe unknown
+                ln = rng.choice([1, 5, 30, 100, 150, 400])
+                off = ln + rng.choice([0, 0, 3])
+                b = rng.randrange(0, 400)
+                idx = len(rids)
+                rids.append(f'q{qi}')
+                lens.append(ln)
+                begs.append(b)
+                ends.append(b + off)
+                idxmap.setdefault(gname, []).append(idx)
+                hits.append((f'q{qi}', gname, ln, b, b + off))
+        n = len(rids)
+        a_lens = np.array(lens, dtype=np.uint32)
+        a_begs = np.array(begs, dtype=np.int64)
+        a_ends = np.array(ends, dtype=np.int64)
+        qs, gs = flush_chunk(n, idxmap, rids, a_lens, a_begs.copy(),
+                             a_ends.copy(), coords, idmap, th, False)
+        expect = {q: sorted(g) for q, g in zip(qs, gs)}
+        # cross-check the three reference matchers agree (sets of pairs)
+        rels = np.ceil(a_lens * th).astype(np.uint32)
+        for gname, idxs in idxmap.items():
+            if gname not in coords:
+                continue
+            ii = np.array(idxs, dtype=np.uint32)
+            locs = np.empty(2 * ii.size, dtype=np.int64)
+            locs[0::2] = (a_begs[ii] << 24) + ii
+            locs[1::2] = (a_ends[ii] << 24) + ii + (1 << 23)
+            queue = np.concatenate((coords[gname], locs))
+            queue.sort(kind='stable')
+            s1 = set(match_read_gene(queue, rels))
+            s2 = set(match_read_gene_naive(coords[gname], locs, rels))
+            s3 = set(match_read_gene_quart(coords[gname], locs, rels))
+            assert s1 == s2 == s3, (ci, gname)
+        cases.append(dict(genes=raw, ids=idmap, th=th, hits=hits,
+                          expect=expect, order=list(qs)))
+    dump('ordinal_random.json', cases)
+
+
+def gen_parsers(seed=5):
+    from woltka.align import (parse_sam_file, parse_sam_file_ex,
+                              parse_sam_file_ft, parse_sam_file_ex_ft,
+                              cigar_to_lens, plain_mapper)
+    import lzma
+    rng = random.Random(seed)
+    with lzma.open(os.path.join(DATA, 'align', 'bowtie2', 'S01.sam.xz'),
+                   'rt') as f:
+        real = f.readlines()[:400]
+    subjects = [f'G{i}' for i in range(6)]
+    synth = ['@HD\tVN:1.0\n', '@SQ\tSN:G0\tLN:1000\n']
+    for qi in range(60):
+        flags = rng.choice([[0], [0, 256], [99, 147], [99, 147, 355, 403],
+                            [77, 141], [65, 129, 0], [16]])
+        for fl in flags:
+            rname = '*' if fl in (77, 141) or rng.random() < 0.05 \
+                else rng.choice(subjects)
+            cigar = rng.choice(['150M', '100M2D48M', '5S140M5S', '50M100N50M',
+                                '10=1X20=', '3M1I3M', '*'])
+            synth.append(f'r{qi}\t{fl}\t{rname}\t{rng.randrange(1, 900)}\t42\t'
+                         f'{cigar}\t=\t0\t0\t*\t*\n')
+    excl = {'G1', 'G4'}
+    out = {}
+    for name, lines in (('real', real), ('synth', synth)):
+        out[name] = dict(
+            lines=lines,
+            plain=[(q, s) for q, s in parse_sam_file(iter(lines))],
+            ex=[(q, s) for q, s in parse_sam_file_ex(iter(lines))],
+            excl=sorted(excl),
+            plain_ft=[(q, s) for q, s in parse_sam_file_ft(iter(lines), excl)],
+            ex_ft=[(q, s) for q, s in parse_sam_file_ex_ft(iter(lines), excl)],
+            chunks7=[(list(q), list(s)) for q, s in
+                     plain_mapper(iter(lines), fmt='sam', n=7)])
+    cig = ['150M', '100M2D48M', '5S140M5S', '50M100N50M', '10=1X20=',
+           '3M1I3M', '1M', '12H3M4P5M', '*', '']
+    out['cigars'] = {c: list(cigar_to_lens(c)) for c in cig}
+    dump('parsers.json', out)
+
+
+def gen_glue(seed=11):
+    from woltka.workflow import demultiplex, strip_suffix
+    from woltka.util import round_dict
+    rng = random.Random(seed)
+    qs = ['S1_r1', 'S1_r2', 'S2_r1', 'nosep', 'S3_', '_lead', 'S1_r3_x',
+          'S2_r9', 'S2_r10', 'S9_a', 'S1_b']
+    subs = [{f'G{i}'} for i in range(len(qs))]
+    demux = []
+    for samples in (None, ['S1', 'S2'], ['S2'], ['']):
+        res = demultiplex(qs, subs, samples)
+        demux.append(dict(samples=samples, queries=qs,
+                          subque=subs, result={('' if k is None else k) if k != ''
+                                               else '': v for k, v in res.items()}))
+    strip = dict(subque=[{'G1_1', 'G1_2', 'G2'}, {'a.b.c'}, {'_x', 'y_'}],
+                 sep='_')
+    strip['result'] = list(strip_suffix(strip['subque'], '_'))
+    vals = [0.5, 1.5, 2.5, 0.49999999, 0.50000001, 1.4999999999, 2.0,
+            1 / 3, 2 / 3, 7 / 2, 0.0000001, 1e-9, 123456.5, 33.5000000999]
+    for _ in range(200):
+        k = rng.choice([2, 3, 5, 6, 7, 9, 11, 13, 16])
+        vals.append(sum(1 / k for _ in range(rng.randrange(1, 40))) +
+                    rng.randrange(0, 50))
+    rounds = {}
+    for digits in (None, 0, 2, 3):
+        d = {str(i): v for i, v in enumerate(vals)}
+        round_dict(d, digits)
+        rounds[str(digits)] = d
+    dump('glue.json', dict(demux=demux, strip=strip, values=vals,
+                           rounds=rounds))
+
+
+def gen_readers(seed=3):
+    """Hierarchy file readers on the bundled files and on random Newick."""
+    from woltka.tree import (read_names, read_nodes, read_newick,
+                             read_columns, read_lineage)
+    rng = random.Random(seed)
+    out = {}
+    tx = os.path.join(DATA, 'taxonomy')
+    for key, fn, reader in (('names', 'names.dmp', read_names),
+                            ('nodes', 'nodes.dmp', read_nodes),
+                            ('lineages', 'lineages.txt', read_lineage),
+                            ('columns_tids', 'rank_tids.tsv', read_columns),
+                            ('nucl2lineage', os.path.join('nucl', 'nucl2lineage.txt'), read_lineage)):
+        with open(os.path.join(tx, fn)) as f:
+            out[key] = reader(f)
+    with open(os.path.join(DATA, 'tree.nwk')) as f:
+        out['newick'] = read_newick(f)
+
+    def rand_nwk(depth, counter):
+        counter[0] += 1
+        me = f'N{counter[0]}'
+        if depth == 0 or rng.random() < 0.3:
+            lab = rng.choice([me, f"'{me}'", f'"{me}"'])
+            return lab + rng.choice(['', ':0.1', ':1e-3'])
+        kids = ','.join(rand_nwk(depth - 1, counter)
+                        for _ in range(rng.choice([1, 2, 2, 3])))
+        return f'({kids}){me}' + rng.choice(['', ':0.5'])
+    nwks = []
+    for _ in range(30):
+        s = rand_nwk(rng.choice([1, 2, 4]), [0]) + ';'
+        if not s.startswith('('):
+            continue
+        lines = [s[:len(s) // 2] + '\n', ' ' + s[len(s) // 2:] + '\n']
+        nwks.append(dict(lines=lines, tree=read_newick(iter(lines))))
+    out['random_newick'] = nwks
+    dump('readers.json', out)
+
+
+def main():
+    if not _refshim.install():
+        print('reference tree not present: nothing to do')
+        return
+    gen_classify()
+    gen_tree_walks()
+    gen_ordinal()
+    gen_parsers()
+    gen_glue()
+    gen_readers()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,58 @@
+"""The C-ABI library builds, loads, and exports every symbol the header
+declares.  No device work is done here (runs on the CPU-only box)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, 'include', 'woltka_hip.h')) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(wk_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    from woltka_amd import _native
+    assert sorted(_native.SYMBOLS) == declared_symbols()
+
+
+def test_library_exports_all_symbols():
+    from woltka_amd import _native
+    assert os.path.isfile(_native.LIB_PATH), (
+        'libwoltka_hip.so not built; run __graft_entry__.build()')
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.wk_abi_version() == _native.ABI_VERSION
+
+
+def test_no_device_is_a_loud_error():
+    """Without a GPU the product path must fail, not fall back."""
+    from woltka_amd import _native
+    lib = _native.load_library()
+    h = ctypes.c_void_p()
+    rc = lib.wk_create(0, ctypes.byref(h))
+    if rc == 0:       # a GPU is present (GPU box): clean up and stop here
+        lib.wk_destroy(h)
+        pytest.skip('HIP device present')
+    assert rc == _native.E_HIP
+    assert b'no HIP device' in lib.wk_last_error(None)
+    with pytest.raises(RuntimeError):
+        _native.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    """woltka_amd must never reach into oracle/ (parity claims depend on it)."""
+    pkg = os.path.join(ROOT, 'woltka_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.hpp', '.h', '.cpp')):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert 'oracle' not in src.replace('no CPU fallback', ''), (
+                    os.path.join(dirpath, fn))

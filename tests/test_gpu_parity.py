@@ -1,0 +1,305 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors of the
+real reference and against the CPU oracle.  Integer / index work: bit-exact."""
+import numpy as np
+import pytest
+
+import c_oracle
+import woltka_oracle as orc
+from helpers import (PackedCase, assert_counts_match, decode_assign,
+                     expected_assign, fold_contrib, fold_counts, golden_counts,
+                     job_spec, load_vectors)
+from test_oracle_golden import pack_ordinal_case
+from woltka_amd import _native as nat
+from woltka_amd.hierarchy import flatten_hierarchy
+from woltka_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def device_jobs(ctx, specs):
+    """[(mode, rank_code, flags, major)] -> [nat.Job], building rank tables."""
+    jobs, slot_of = [], {}
+    for mode, code, flags, major in specs:
+        slot = 0
+        if mode == nat.MODE_RANK:
+            if code not in slot_of:
+                slot_of[code] = len(slot_of)
+                ctx.build_rank_table(slot_of[code], code)
+            slot = slot_of[code]
+        jobs.append(nat.Job(mode, slot, flags, 0, major))
+    return jobs
+
+
+def test_golden_classify(ctx):
+    """Every assigner / counter combination of classify_random.json."""
+    n = 0
+    for case in load_vectors('classify_random.json'):
+        pc = PackedCase(case)
+        h = pc.hier
+        ctx.set_tree(h.parent, h.last, h.rank_code)
+        ctx.counts_reserve(4096)
+        for run in case['runs']:
+            jobs = device_jobs(ctx, [job_spec(run['params'], h)])
+            for is_set in (True, False):
+                ctx.counts_clear()
+                assign = ctx.classify_chunk(jobs, pc.subj, pc.qoff,
+                                            subj_is_set=is_set,
+                                            want_assign=True)
+                assert decode_assign(assign[0], pc.index) == \
+                    expected_assign(run['taxque'])
+                exact = fold_counts(*ctx.counts_fetch(), pc.index)
+                assert_counts_match(exact, run['counts'])
+                assert orc.round_counts(exact) == run['rounded']
+            # stratified: reads outside the strata map are skipped
+            ctx.counts_clear()
+            ctx.classify_chunk(jobs, pc.subj, pc.qoff, group=pc.group,
+                               subj_is_set=True)
+            exact = fold_counts(*ctx.counts_fetch(), pc.index,
+                                groups=pc.group_names)
+            assert_counts_match(exact,
+                                golden_counts(run['strat_counts'], True))
+            n += 1
+    assert n > 500
+
+
+def test_golden_multi_rank_single_pass(ctx):
+    """All runs of a case as jobs of ONE kernel pass (<= 8 at a time) equal
+    the per-rank results (the reference loops over ranks, workflow.py:333)."""
+    for case in load_vectors('classify_random.json')[:25]:
+        pc = PackedCase(case)
+        h = pc.hier
+        ctx.set_tree(h.parent, h.last, h.rank_code)
+        ctx.counts_reserve(1 << 14)
+        runs = case['runs']
+        for lo in range(0, len(runs), nat.MAX_JOBS):
+            part = runs[lo:lo + nat.MAX_JOBS]
+            jobs = device_jobs(ctx, [job_spec(r['params'], h) for r in part])
+            ctx.counts_clear()
+            assign = ctx.classify_chunk(jobs, pc.subj, pc.qoff,
+                                        subj_is_set=True, want_assign=True)
+            keys, vals = ctx.counts_fetch()
+            for j, run in enumerate(part):
+                assert decode_assign(assign[j], pc.index) == \
+                    expected_assign(run['taxque'])
+                assert_counts_match(fold_counts(keys, vals, pc.index, job=j),
+                                    run['counts'])
+
+
+def test_rank_table_kernel(ctx):
+    """tree.find_rank for every node: device table == oracle walk."""
+    rng = np.random.default_rng(5)
+    tree, rankdic = synth.random_taxonomy(rng, 20000)
+    h = flatten_hierarchy(tree, rankdic)
+    ctx.set_tree(h.parent, h.last, h.rank_code)
+    for slot, (rank, code) in enumerate(list(h.rank_codes.items())[:6]):
+        ctx.build_rank_table(slot, code)
+        assert np.array_equal(ctx.get_rank_table(slot),
+                              c_oracle.rank_table(h.parent, h.rank_code, code))
+    ctx.build_rank_table(7, 9999)      # a rank nobody carries
+    assert (ctx.get_rank_table(7) == -1).all()
+
+
+def test_golden_ordinal(ctx):
+    """ordinal.flush_chunk cases: per-read gene sets from the device."""
+    for case in load_vectors('ordinal_random.json'):
+        p = pack_ordinal_case(case)
+        feat = np.arange(len(p['gene_names']), dtype=np.int32)
+        ctx.set_genes(p['genome_off'], p['gstart'], p['gend'], feat)
+        ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
+                          p['hoff'], case['th'])
+        ctx.ordinal_match()
+        subj, qoff = ctx.chunk_download()
+        got = {}
+        for r, q in enumerate(p['queries']):
+            genes = {p['gene_names'][g] for g in subj[qoff[r]:qoff[r + 1]]}
+            if genes:
+                got.setdefault(q, set()).update(genes)
+        assert {q: sorted(g) for q, g in got.items()} == case['expect']
+
+
+def _device_vs_oracle(ctx, prob, specs, lds=True):
+    h = prob['hier']
+    ctx.set_option('use_lds', int(lds))
+    if h is not None:
+        ctx.set_tree(h.parent, h.last, h.rank_code)
+    jobs = device_jobs(ctx, specs)
+    ctx.counts_reserve(max(1 << 16, 4 * prob['subj'].size))
+    ctx.reset_stats()
+    assign = ctx.classify_chunk(jobs, prob['subj'], prob['qoff'],
+                                group=prob.get('group'), subj_is_set=False,
+                                want_assign=True)
+    keys, vals = ctx.counts_fetch()
+    ojobs = [dict(mode=m, rank_code=c, flags=f, major=mj)
+             for m, c, f, mj in specs]
+    parent = h.parent if h is not None else None
+    rcode = h.rank_code if h is not None else None
+    oassign, contrib = c_oracle.classify(prob['subj'], prob['qoff'], ojobs,
+                                         parent, rcode, 0, prob.get('group'))
+    assert np.array_equal(assign, oassign)
+    okeys, ocnt = np.unique(contrib, return_counts=True)
+    order = np.argsort(keys)
+    assert np.array_equal(keys[order], okeys)
+    assert np.array_equal(vals[order], ocnt.astype(np.int64))
+    st = ctx.stats()
+    assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
+    assert st['n_records'] == prob['subj'].size
+    ctx.set_option('use_lds', 1)
+
+
+ALL_SPECS = [
+    (nat.MODE_NONE, 0, 0, 0.0),
+    (nat.MODE_NONE, 0, nat.F_UNIQ | nat.F_UNASSIGNED, 0.0),
+    (nat.MODE_FREE, 0, 0, 0.0),
+    (nat.MODE_FREE, 0, nat.F_SUBOK | nat.F_UNASSIGNED, 0.0),
+]
+
+
+def _rank_specs(h):
+    codes = h.rank_codes
+    return [
+        (nat.MODE_RANK, codes['phylum'], 0, 0.0),
+        (nat.MODE_RANK, codes['genus'], nat.F_ABOVE, 0.0),
+        (nat.MODE_RANK, codes['species'], nat.F_UNASSIGNED, 0.8),
+        (nat.MODE_RANK, codes['genus'], nat.F_UNIQ, 0.0),
+    ]
+
+
+@pytest.mark.parametrize('lds', [True, False])
+def test_random_lca_vs_oracle(ctx, lds):
+    """Config-3-shaped problem (tree, <=16 hits, duplicates, off-tree ids,
+    strata) at a size the C oracle finishes in seconds."""
+    rng = np.random.default_rng(1003)
+    prob = synth.lca_problem(rng, n_nodes=50000, n_subjects=5000,
+                             n_reads=300000, dup_frac=0.1, offtree_frac=0.02,
+                             with_group=True)
+    _device_vs_oracle(ctx, prob, ALL_SPECS + _rank_specs(prob['hier']), lds)
+
+
+def test_tiny_lds_cache_overflows_to_hbm(ctx):
+    """A 64-slot LDS cache forces the fallback path; counts must not change."""
+    rng = np.random.default_rng(7)
+    prob = synth.lca_problem(rng, n_nodes=20000, n_subjects=4000,
+                             n_reads=100000, dup_frac=0.05, offtree_frac=0.0)
+    ctx.set_option('lds_slots', 64)
+    try:
+        _device_vs_oracle(ctx, prob, ALL_SPECS + _rank_specs(prob['hier']))
+    finally:
+        ctx.set_option('lds_slots', 4096)
+
+
+def test_flat_histogram_vs_oracle(ctx):
+    """Config-2 shape (1 hit, Zipf subjects, flat map as a 2-level tree)."""
+    rng = np.random.default_rng(1002)
+    prob = synth.flat_problem(rng, n_subjects=10575, n_taxa=2000,
+                              n_reads=1000000)
+    h = prob['hier']
+    specs = [(nat.MODE_NONE, 0, 0, 0.0),
+             (nat.MODE_RANK, h.rank_codes['genus'], 0, 0.0)]
+    _device_vs_oracle(ctx, prob, specs)
+
+
+def test_ordinal_random_vs_oracle(ctx):
+    """Config-4-shaped problem vs the oracle's end-point sweep."""
+    rng = np.random.default_rng(1004)
+    p = synth.ordinal_problem(rng, n_genomes=300, genes_per_genome=100,
+                              n_pairs=150000)
+    ctx.set_genes(p['genome_off'], p['gstart'], p['gend'], p['gene_feature'])
+    for th in (0.8, 0.55, 1.0):
+        ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
+                          p['hoff'], th)
+        ctx.ordinal_match()
+        subj, qoff = ctx.chunk_download()
+        ph, pg = c_oracle.ordinal_match(p['genome_off'], p['gstart'],
+                                        p['gend'], p['genome'], p['beg'],
+                                        p['end'], p['length'], th)
+        read_of_hit = np.repeat(np.arange(p['hoff'].size - 1),
+                                np.diff(p['hoff']))
+        exp = np.unique(np.stack([read_of_hit[ph],
+                                  p['gene_feature'][pg].astype(np.int64)]),
+                        axis=1)
+        got_r = np.repeat(np.arange(qoff.size - 1), np.diff(qoff))
+        got = np.unique(np.stack([got_r, subj.astype(np.int64)]), axis=1)
+        assert np.array_equal(got, exp)
+        assert subj.size == ph.size          # one entry per (hit, gene) match
+        # ... and the gene sets classify like plain subjects (rank none)
+        ctx.counts_reserve(1 << 20)
+        ctx.classify_staged([nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)])
+        keys, vals = ctx.counts_fetch()
+        _, contrib = c_oracle.classify(subj, qoff,
+                                       [dict(mode=nat.MODE_NONE)])
+        okeys, ocnt = np.unique(contrib, return_counts=True)
+        order = np.argsort(keys)
+        assert np.array_equal(keys[order], okeys)
+        assert np.array_equal(vals[order], ocnt)
+
+
+def test_edge_cases(ctx):
+    """Empty chunk, empty reads, one giant read, k at the key limit."""
+    ctx.counts_reserve(1 << 16)
+    jobs = [nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)]
+    # empty chunk
+    ctx.classify_chunk(jobs, np.empty(0, np.int32), np.zeros(1, np.int32))
+    assert ctx.counts_fetch()[0].size == 0
+    # ragged: empty reads are skipped and reported as EMPTY
+    subj = np.array([3, 3, 5, 9], np.int32)
+    qoff = np.array([0, 0, 2, 2, 4, 4], np.int32)
+    a = ctx.classify_chunk(jobs, subj, qoff, want_assign=True)
+    assert a[0].tolist() == [nat.ASSIGN_EMPTY, 3, nat.ASSIGN_EMPTY,
+                             nat.ASSIGN_MULTI, nat.ASSIGN_EMPTY]
+    keys, vals = ctx.counts_fetch()
+    j, k, g, f = nat.decode_keys(keys)
+    assert sorted(zip(k.tolist(), f.tolist(), vals.tolist())) == \
+        [(1, 3, 1), (2, 5, 1), (2, 9, 1)]
+    # one read with the maximum number of distinct candidates
+    ctx.counts_clear()
+    big = np.arange(nat.MAX_K, dtype=np.int32)
+    ctx.classify_chunk(jobs, big, np.array([0, big.size], np.int32))
+    keys, vals = ctx.counts_fetch()
+    j, k, g, f = nat.decode_keys(keys)
+    assert keys.size == nat.MAX_K and (k == nat.MAX_K).all() and (vals == 1).all()
+    # one more distinct candidate does not fit the key layout -> loud error
+    ctx.counts_clear()
+    big = np.arange(nat.MAX_K + 1, dtype=np.int32)
+    ctx.classify_chunk(jobs, big, np.array([0, big.size], np.int32))
+    with pytest.raises(ValueError, match='more than'):
+        ctx.counts_fetch()
+    # a full count table is reported, never silently dropped
+    ctx.counts_reserve(1024)
+    many = np.arange(5000, dtype=np.int32)
+    ctx.classify_chunk(jobs, many, np.arange(5001, dtype=np.int32))
+    with pytest.raises(OverflowError, match='full'):
+        ctx.counts_fetch()
+
+
+def test_full_size_config2_properties(ctx):
+    """BASELINE config 2 at full size (10 M reads x 1 hit): size-independent
+    properties instead of the oracle — conservation of reads, agreement with a
+    numpy bincount, idempotence of a second pass (counts double)."""
+    rng = np.random.default_rng(1002)
+    prob = synth.flat_problem(rng, n_subjects=10575, n_taxa=2000,
+                              n_reads=10_000_000)
+    h = prob['hier']
+    ctx.set_tree(h.parent, h.last, h.rank_code)
+    jobs = device_jobs(ctx, [(nat.MODE_NONE, 0, 0, 0.0),
+                             (nat.MODE_RANK, h.rank_codes['genus'], 0, 0.0)])
+    ctx.counts_reserve(1 << 16)
+    ctx.chunk_stage(prob['subj'], prob['qoff'], subj_is_set=True)
+    ctx.classify_staged(jobs)
+    keys, vals = ctx.counts_fetch()
+    j, k, g, f = nat.decode_keys(keys)
+    assert (k == 1).all() and (g == 0).all()
+    for job in (0, 1):
+        assert vals[j == job].sum() == 10_000_000
+    exp = np.bincount(prob['subj'], minlength=len(h.index))
+    got = np.zeros_like(exp)
+    got[f[j == 0]] = vals[j == 0]
+    assert np.array_equal(got, exp)
+    exp_genus = np.bincount(h.parent[prob['subj']], minlength=len(h.index))
+    got = np.zeros_like(exp_genus)
+    got[f[j == 1]] = vals[j == 1]
+    assert np.array_equal(got, exp_genus)
+    ctx.classify_staged(jobs)
+    keys2, vals2 = ctx.counts_fetch()
+    o1, o2 = np.argsort(keys), np.argsort(keys2)
+    assert np.array_equal(keys[o1], keys2[o2])
+    assert np.array_equal(2 * vals[o1], vals2[o2])

@@ -77,6 +77,106 @@ class Hierarchy:
         return self.rank_codes.get(rank, len(self.rank_codes) + 1)
 
 
+class _Unreachable(Exception):
+    def __init__(self, node):
+        super().__init__(node)
+        self.node = node
+
+
+def preorder_numbering(par, root=None):
+    """DFS pre-order numbers of a rooted tree given as a parent array.
+
+    Parameters
+    ----------
+    par : np.ndarray of int64
+        ``par[v]`` is the parent of ``v``; exactly the root has ``par[r] == r``.
+    root : int, optional
+        Expected root.
+
+    Returns
+    -------
+    pre, size, depth : np.ndarray of int64
+        Pre-order number, subtree size and depth of every node.
+    r : int
+        The root.
+
+    Vectorised level by level (a hierarchy has few levels but millions of
+    nodes): siblings keep their input order.
+    """
+    n = par.size
+    ids = np.arange(n, dtype=np.int64)
+    selfp = np.flatnonzero(par == ids)
+    if selfp.size != 1 or (root is not None and selfp[0] != root):
+        raise ValueError('Hierarchy must have exactly one root.')
+    r = int(selfp[0])
+
+    # children in CSR form, grouped by parent, siblings in input order
+    kids = np.flatnonzero(par != ids)
+    order = kids[np.argsort(par[kids], kind='stable')]
+    nkids = np.bincount(par[kids], minlength=n)
+    koff = np.concatenate(([0], np.cumsum(nkids)))
+
+    # breadth-first levels (each level stays grouped by parent)
+    depth = np.full(n, -1, dtype=np.int64)
+    depth[r] = 0
+    levels = [np.array([r], dtype=np.int64)]
+    while True:
+        cur = levels[-1]
+        cnt = nkids[cur]
+        tot = int(cnt.sum())
+        if tot == 0:
+            break
+        rep = np.repeat(np.arange(cur.size), cnt)
+        within = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        nxt = order[koff[cur][rep] + within]
+        depth[nxt] = len(levels)
+        levels.append(nxt)
+    if (depth < 0).any():
+        raise _Unreachable(int(np.flatnonzero(depth < 0)[0]))
+
+    # subtree sizes, bottom-up
+    size = np.ones(n, dtype=np.int64)
+    for lvl in reversed(levels[1:]):
+        np.add.at(size, par[lvl], size[lvl])
+
+    # pre-order number = parent's number + 1 + sizes of earlier siblings
+    pre = np.zeros(n, dtype=np.int64)
+    for lvl in levels[1:]:
+        s = size[lvl]
+        cs = np.cumsum(s) - s
+        p = par[lvl]
+        first = np.ones(lvl.size, dtype=bool)
+        first[1:] = p[1:] != p[:-1]
+        gstart = np.maximum.accumulate(np.where(first, np.arange(lvl.size), 0))
+        pre[lvl] = pre[p] + 1 + cs - cs[gstart]
+    return pre, size, depth, r
+
+
+def hierarchy_from_arrays(par, rank_code, rank_codes, names=None,
+                          with_names=True):
+    """Build a ``Hierarchy`` from a parent array in arbitrary numbering
+    (synthetic benchmarks skip the string dicts).  ``names`` default to the
+    decimal input index; ``with_names=False`` leaves the index empty (large
+    synthetic trees never print feature names)."""
+    par = np.asarray(par, dtype=np.int64)
+    n = par.size
+    pre, size, depth, _ = preorder_numbering(par)
+    inv = np.empty(n, dtype=np.int64)
+    inv[pre] = np.arange(n, dtype=np.int64)
+    if not with_names:
+        names = []
+    elif names is None:
+        names = [str(i) for i in inv.tolist()]
+    else:
+        names = [names[i] for i in inv.tolist()]
+    h = Hierarchy(FeatureIndex(names), pre[par][inv].astype(np.int32),
+                  (pre + size - 1)[inv].astype(np.int32),
+                  np.asarray(rank_code, dtype=np.int32)[inv],
+                  dict(rank_codes), depth[inv].astype(np.int32))
+    h.pre_of_input = pre          # input index -> device id
+    return h
+
+
 def flatten_hierarchy(tree, rankdic=None, root=None):
     """Number the nodes of ``tree`` in DFS pre-order and build device arrays.
 
@@ -111,59 +211,13 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
     except KeyError as e:
         raise ValueError(f'Parent {e} is not part of the hierarchy; call '
                          'fill_root first.')
+    try:
+        pre, size, depth, r = preorder_numbering(
+            par, None if root is None else tmp[root])
+    except _Unreachable as e:
+        raise ValueError(f'Node "{names[e.node]}" cannot reach the root '
+                         '(cyclic hierarchy).')
     ids = np.arange(n, dtype=np.int64)
-    selfp = np.flatnonzero(par == ids)
-    if root is None:
-        if selfp.size != 1:
-            raise ValueError('Hierarchy must have exactly one root.')
-        r = int(selfp[0])
-    else:
-        r = tmp[root]
-        if selfp.size != 1 or selfp[0] != r:
-            raise ValueError('Hierarchy must have exactly one root.')
-
-    # children in CSR form, grouped by parent, siblings in insertion order
-    kids = np.flatnonzero(par != ids)
-    order = kids[np.argsort(par[kids], kind='stable')]
-    nkids = np.bincount(par[kids], minlength=n)
-    koff = np.concatenate(([0], np.cumsum(nkids)))
-
-    # breadth-first levels (each level stays grouped by parent)
-    depth = np.full(n, -1, dtype=np.int64)
-    depth[r] = 0
-    levels = [np.array([r], dtype=np.int64)]
-    while True:
-        cur = levels[-1]
-        cnt = nkids[cur]
-        tot = int(cnt.sum())
-        if tot == 0:
-            break
-        rep = np.repeat(np.arange(cur.size), cnt)
-        within = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
-        nxt = order[koff[cur][rep] + within]
-        depth[nxt] = len(levels)
-        levels.append(nxt)
-    if (depth < 0).any():
-        bad = names[int(np.flatnonzero(depth < 0)[0])]
-        raise ValueError(f'Node "{bad}" cannot reach the root (cyclic '
-                         'hierarchy).')
-
-    # subtree sizes, bottom-up
-    size = np.ones(n, dtype=np.int64)
-    for lvl in reversed(levels[1:]):
-        np.add.at(size, par[lvl], size[lvl])
-
-    # pre-order number = parent's number + 1 + sizes of earlier siblings
-    pre = np.zeros(n, dtype=np.int64)
-    for lvl in levels[1:]:
-        s = size[lvl]
-        cs = np.cumsum(s) - s
-        p = par[lvl]
-        first = np.ones(lvl.size, dtype=bool)
-        first[1:] = p[1:] != p[:-1]
-        gstart = np.maximum.accumulate(np.where(first, np.arange(lvl.size), 0))
-        pre[lvl] = pre[p] + 1 + cs - cs[gstart]
-
     inv = np.empty(n, dtype=np.int64)
     inv[pre] = ids
     index = FeatureIndex([names[i] for i in inv.tolist()])
