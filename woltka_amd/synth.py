@@ -3,7 +3,7 @@
 Everything is generated directly in packed (integer) form with numpy; the
 string-level equivalents (SAM text, nodes.dmp) are not needed to exercise the
 device path.  Used by ``bench.py`` and by the parity tests (which feed the same
-arrays to the CPU oracle).
+arrays to the CPU checker).
 """
 import numpy as np
 
