@@ -47,8 +47,9 @@ extern "C" {
 #define WK_E_HIP (-1)      /* HIP runtime error (no device, OOM, launch failure) */
 #define WK_E_ARG (-2)      /* invalid argument */
 #define WK_E_STATE (-3)    /* required table not uploaded */
-#define WK_E_CAPACITY (-4) /* count table / output buffer too small */
+#define WK_E_CAPACITY (-4) /* caller-provided output buffer too small */
 #define WK_E_RANGE (-5)    /* value does not fit the key layout (k > 4095, ...) */
+#define WK_E_TABLE_FULL (-6) /* device count table ran out of slots; counts are incomplete */
 
 /* key layout */
 #define WK_KEY_FEATURE_BITS 28
@@ -107,7 +108,9 @@ const char* wk_last_error(const wk_ctx* ctx); /* ctx may be NULL */
 int wk_device_name(const wk_ctx* ctx, char* buf, size_t cap);
 int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
 /* Tuning knobs: "lds_slots" (LDS front-cache slots per workgroup, power of two
- * in [64, 8192]), "use_lds" (0/1). Results never depend on them. */
+ * in [64, 8192]), "use_lds" (0/1), "tiled" (0/1: LDS-staged classify kernel),
+ * "threads" (workgroup size of the direct classify kernel), "blocks_per_cu"
+ * (classify grid size per CU, 1..32).  Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 
 /* ---- static state ------------------------------------------------------ */

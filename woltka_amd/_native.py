@@ -11,11 +11,14 @@ from fractions import Fraction
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libwoltka_hip.so')
+# WOLTKA_HIP_LIB lets tools/ load a measurement build (e.g. -DWK_ABLATE)
+LIB_PATH = os.environ.get('WOLTKA_HIP_LIB') or os.path.join(
+    _HERE, 'libwoltka_hip.so')
 
 # constants mirrored from include/woltka_hip.h
 ABI_VERSION = 1
-OK, E_HIP, E_ARG, E_STATE, E_CAPACITY, E_RANGE = 0, -1, -2, -3, -4, -5
+OK, E_HIP, E_ARG, E_STATE, E_CAPACITY, E_RANGE, E_TABLE_FULL = (
+    0, -1, -2, -3, -4, -5, -6)
 KEY_FEATURE_BITS, KEY_GROUP_BITS, KEY_K_BITS, KEY_JOB_BITS = 28, 21, 12, 3
 MAX_JOBS, MAX_K = 8, 4095
 FEATURE_UNASSIGNED, MAX_FEATURE = 0x0FFFFFFF, 0x0FFFFFFE
@@ -154,7 +157,7 @@ class Context:
         msg = self._lib.wk_last_error(self._h).decode()
         if rc in (E_ARG, E_RANGE):
             raise ValueError(msg)
-        if rc == E_CAPACITY:
+        if rc in (E_CAPACITY, E_TABLE_FULL):
             raise OverflowError(msg)
         raise RuntimeError(msg)
 

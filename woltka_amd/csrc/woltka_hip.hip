@@ -3,6 +3,7 @@
 // entry point that does work launches HIP kernels on the context's stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -98,8 +99,9 @@ struct wk_ctx {
     double th = 0.8;
     bool ord_valid = false;
 
-    // misc device scalars: [0]=err(int) [1]=reads [2]=records [3]=total pairs [4]=compact counter
+    // misc device scalars: [0]=err(int) [3]=total pairs [4]=compact counter
     DevBuf scalars;
+    DevBuf stat_block;  // kStatBlocks x (reads, records), see flush_stats()
     DevBuf assign_out, fetch_k, fetch_v;
     int64_t stat_pairs = 0;
 
@@ -110,7 +112,11 @@ struct wk_ctx {
     std::map<std::string, KernelTimer> ktimers;
 
     int lds_slots = 4096;  // LDS front-cache slots per workgroup (16 B each)
+    int threads = 1024;    // workgroup size of the direct classify kernel
     int use_lds = 1;
+    int blocks_per_cu = 1;
+    int ablate = 0;  // honoured only by -DWK_ABLATE measurement builds
+    int tiled = 0;  // LDS-staged classify kernel (0: direct one-thread-per-read kernel)
 };
 
 namespace {
@@ -144,6 +150,8 @@ struct DeviceGuard {
     }
 };
 
+constexpr int kStatBlocks = 16384;  // >= the largest classify grid (256 CUs x 32 + slack)
+
 unsigned long long* scalar_u64(wk_ctx* c, int idx) { return c->scalars.as<unsigned long long>() + idx; }
 int* scalar_err(wk_ctx* c) { return c->scalars.as<int>(); }
 
@@ -169,7 +177,7 @@ int check_device_errors(wk_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (e == 0) return WK_OK;
     HIP_TRY(c, hipMemsetAsync(scalar_err(c), 0, sizeof(int), c->stream));
-    if (e & kErrTableFull) return fail(c, WK_E_CAPACITY, "count table is full (%llu slots); call wk_counts_reserve with more slots", (unsigned long long)c->slots);
+    if (e & kErrTableFull) return fail(c, WK_E_TABLE_FULL, "count table is full (%llu slots); call wk_counts_reserve with more slots", (unsigned long long)c->slots);
     if (e & kErrKRange) return fail(c, WK_E_RANGE, "a read has more than %d candidate features", WK_MAX_K);
     if (e & kErrFeatureRange) return fail(c, WK_E_RANGE, "feature id outside [0, %d]", WK_MAX_FEATURE);
     if (e & kErrGroupRange) return fail(c, WK_E_RANGE, "group id outside [0, %d)", 1 << WK_KEY_GROUP_BITS);
@@ -249,14 +257,23 @@ int wk_create(int device, wk_ctx** out) {
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
         (e = c->scalars.reserve(64)) != hipSuccess ||
-        (e = hipMemsetAsync(c->scalars.p, 0, 64, c->stream)) != hipSuccess) {
+        (e = hipMemsetAsync(c->scalars.p, 0, 64, c->stream)) != hipSuccess ||
+        (e = c->stat_block.reserve((size_t)kStatBlocks * 16)) != hipSuccess ||
+        (e = hipMemsetAsync(c->stat_block.p, 0, (size_t)kStatBlocks * 16, c->stream)) != hipSuccess) {
         int rc = fail(nullptr, WK_E_HIP, "context setup failed: %s", hipGetErrorString(e));
         wk_destroy(c);
         return rc;
     }
     // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (160 KiB per CU minus the kernels' few bytes of static LDS)
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess) {
+        int rc = fail(nullptr, WK_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+        wk_destroy(c);
+        return rc;
+    }
     *out = c;
     return WK_OK;
 }
@@ -268,7 +285,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -299,6 +316,24 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "lds_slots")) {
         if (value < 64 || value > 8192 || (value & (value - 1))) return fail(c, WK_E_ARG, "lds_slots must be a power of two in [64, 8192]");
         c->lds_slots = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "blocks_per_cu")) {
+        if (value < 1 || value > 32) return fail(c, WK_E_ARG, "blocks_per_cu must be in [1, 32]");
+        c->blocks_per_cu = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "threads")) {
+        if (value < 64 || value > 1024 || (value % 64)) return fail(c, WK_E_ARG, "threads must be a multiple of 64 in [64, 1024]");
+        c->threads = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "ablate")) {
+        c->ablate = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "tiled")) {
+        c->tiled = value ? 1 : 0;
         return WK_OK;
     }
     if (!strcmp(name, "use_lds")) {
@@ -512,20 +547,26 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
         HIP_TRY(c, c->assign_out.reserve((size_t)n_jobs * (size_t)(c->n_reads ? c->n_reads : 1) * sizeof(int32_t)));
         a.out_assign = c->assign_out.as<int32_t>();
     }
-    a.stat_reads = scalar_u64(c, 1);
-    a.stat_records = scalar_u64(c, 2);
+    a.stat_block = c->stat_block.as<unsigned long long>();
+    a.ablate = (uint32_t)c->ablate;
     a.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
 
     if (c->n_reads > 0) {
-        const int threads = 256;
-        // ~8 resident workgroups per CU; each keeps its own LDS front cache
-        const int blocks = grid_for(c->n_reads, threads, c->prop.multiProcessorCount * 8);
         KernelTimer* kt = ktimer_begin(c, "classify");
-        if (c->use_lds) {
+        if (c->use_lds && c->tiled) {
+            // persistent workgroups, each with its own tile buffers + LDS front cache
+            const size_t lds = (size_t)(kTileWindow + 4 + kTileReads + 4) * sizeof(int32_t) + (size_t)c->lds_slots * 16;
+            const int64_t n_tiles = (c->n_reads + kTileReads - 1) / kTileReads;
+            const int blocks = (int)std::min<int64_t>(std::min<int64_t>(n_tiles, kStatBlocks), (int64_t)c->prop.multiProcessorCount * c->blocks_per_cu);
+            hipLaunchKernelGGL(classify_tiled_kernel, dim3(blocks), dim3(kTileThreads), lds, c->stream, a,
+                               (uint32_t)c->lds_slots, c->n_records);
+        } else if (c->use_lds) {
+            const int blocks = grid_for(c->n_reads, c->threads, std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu));
             const size_t lds = (size_t)c->lds_slots * 16;
-            hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(threads), lds, c->stream, a, (uint32_t)c->lds_slots);
+            hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)c->lds_slots);
         } else {
-            hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks), dim3(threads), 0, c->stream, a, 0u);
+            const int blocks = grid_for(c->n_reads, 256, c->prop.multiProcessorCount * 8);
+            hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, a, 0u);
         }
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
@@ -659,8 +700,8 @@ int wk_chunk_download(wk_ctx* c, int32_t* subj, int64_t subj_cap, int32_t* qoff,
 int wk_get_stats(wk_ctx* c, wk_stats* out) {
     if (!c || !out) return WK_E_ARG;
     DeviceGuard guard(c->device);
-    unsigned long long s[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(s, scalar_u64(c, 1), sizeof s, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> part((size_t)kStatBlocks * 2);
+    HIP_TRY(c, hipMemcpyAsync(part.data(), c->stat_block.p, part.size() * 8, hipMemcpyDeviceToHost, c->stream));
     unsigned long long used = 0;
     if (c->slots) {
         HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 4), 0, 8, c->stream));
@@ -669,6 +710,11 @@ int wk_get_stats(wk_ctx* c, wk_stats* out) {
         HIP_TRY(c, hipMemcpyAsync(&used, scalar_u64(c, 4), 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long s[2] = {0, 0};
+    for (int b = 0; b < kStatBlocks; ++b) {
+        s[0] += part[2 * b];
+        s[1] += part[2 * b + 1];
+    }
     out->n_reads = (int64_t)s[0];
     out->n_records = (int64_t)s[1];
     out->n_pairs = c->stat_pairs;
@@ -679,7 +725,7 @@ int wk_get_stats(wk_ctx* c, wk_stats* out) {
 int wk_reset_stats(wk_ctx* c) {
     if (!c) return WK_E_ARG;
     DeviceGuard guard(c->device);
-    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 1), 0, 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->stat_block.p, 0, (size_t)kStatBlocks * 16, c->stream));
     c->stat_pairs = 0;
     return WK_OK;
 }
