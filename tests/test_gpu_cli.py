@@ -1,0 +1,127 @@
+"""End-to-end drop-in check: `woltka classify` on the GPU path reproduces the
+reference's golden output tables byte for byte (the parameter sets of the
+reference's own woltka/tests/test_cli.py:42-177, minus the --sizes cases) and
+its console output."""
+import filecmp
+import gzip
+import os
+from os.path import join
+
+import pytest
+from click.testing import CliRunner
+
+from helpers import DATA
+
+pytestmark = pytest.mark.gpu
+
+ALN = join(DATA, 'align')
+TAX = join(DATA, 'taxonomy')
+FUN = join(DATA, 'function')
+OUT = join(DATA, 'output')
+
+
+def run(params, tmp_path, expect):
+    from woltka_amd.cli import classify_cmd
+    out = str(tmp_path / 'output.tsv')
+    res = CliRunner().invoke(classify_cmd,
+                             params + ['--output', out, '--no-exe'])
+    assert res.exit_code == 0, res.output + repr(res.exception)
+    assert filecmp.cmp(out, join(OUT, expect), shallow=False), expect
+    return res
+
+
+def test_bowtie2_ogu_and_console(tmp_path):
+    res = run(['--input', join(ALN, 'bowtie2')], tmp_path, 'bowtie2.ogu.tsv')
+    lines = res.output.splitlines()
+    assert lines[0] == f'Input directory: {join(ALN, "bowtie2")}.'
+    assert lines[1:5] == [
+        'Number of alignment files to read: 5.',
+        'Demultiplexing: off.',
+        'Classification will operate on these ranks: none.',
+        'Parsing alignment file S01.sam.xz . Done.']
+    assert lines[5] == '  Number of sequences classified: 2000.'
+    assert lines[-6:] == [
+        'Classification completed.',
+        'Format of output feature table(s): TSV.',
+        'Writing output profiles in TSV format...',
+        '  Rank: none, samples: 5, features: 49.',
+        'Profiles written.',
+        'Task completed.']
+
+
+def test_bowtie2_free(tmp_path):
+    run(['--input', join(ALN, 'bowtie2'), '--nodes', join(TAX, 'nodes.dmp'),
+         '--map', join(TAX, 'taxid.map'), '--rank', 'free'],
+        tmp_path, 'bowtie2.free.tsv')
+
+
+def test_blastn_mux_lineage_species(tmp_path):
+    run(['--input', join(ALN, 'blastn', 'mux.b6o.xz'),
+         '--lineage', join(TAX, 'lineages.txt'), '--rank', 'species'],
+        tmp_path, 'blastn.species.tsv')
+
+
+def test_burst_genus_with_readmaps(tmp_path):
+    mapdir = tmp_path / 'maps'
+    run(['--input', join(ALN, 'burst'), '--outmap', str(mapdir),
+         '--names', join(TAX, 'names.dmp'), '--nodes', join(TAX, 'nodes.dmp'),
+         '--map', join(TAX, 'taxid.map'), '--rank', 'genus', '--name-as-id'],
+        tmp_path, 'burst.genus.tsv')
+    for i in range(1, 6):
+        with gzip.open(mapdir / f'S0{i}.txt.gz', 'rt') as f:
+            obs = [x.rstrip() for x in f]
+        with gzip.open(join(OUT, 'burst.genus.map', f'S0{i}.txt.gz'),
+                       'rt') as f:
+            exp = [x.rstrip() for x in f]
+        assert obs == exp
+
+
+def test_blastn_family_percent(tmp_path):
+    run(['--input', join(ALN, 'blastn', 'mux.b6o.xz'),
+         '--names', join(TAX, 'names.dmp'), '--nodes', join(TAX, 'nodes.dmp'),
+         '--map', join(TAX, 'taxid.map'), '--rank', 'family', '--name-as-id',
+         '--frac', '--scale', '100', '--digits', '2'],
+        tmp_path, 'blastn.family.percent.tsv')
+
+
+def test_bt2sho_phylo(tmp_path):
+    run(['--input', join(ALN, 'bt2sho'), '--newick', join(DATA, 'tree.nwk'),
+         '--rank', 'free', '--subok'], tmp_path, 'bt2sho.phylo.tsv')
+
+
+def test_burst_coords_process(tmp_path):
+    run(['--input', join(ALN, 'burst'), '--rank', 'process',
+         '--coords', join(FUN, 'coords.txt.xz'),
+         '--map', join(FUN, 'uniref', 'uniref.map.xz'),
+         '--map', join(FUN, 'go', 'process.tsv.xz')],
+        tmp_path, 'burst.process.tsv')
+
+
+def test_burst_coords_stratified(tmp_path):
+    run(['--input', join(ALN, 'burst'), '--rank', 'process',
+         '--coords', join(FUN, 'coords.txt.xz'),
+         '--map', join(FUN, 'uniref', 'uniref.map.xz'),
+         '--map', join(FUN, 'go', 'process.tsv.xz'),
+         '--stratify', join(OUT, 'burst.genus.map')],
+        tmp_path, 'burst.genus.process.tsv')
+
+
+def test_split_genus_trimsub(tmp_path):
+    run(['--input', join(ALN, 'burst', 'split'), '--trim-sub', '_',
+         '--rank', 'genus', '--map', join(TAX, 'nucl', 'nucl2tid.txt'),
+         '--names', join(TAX, 'names.dmp'), '--nodes', join(TAX, 'nodes.dmp'),
+         '--name-as-id'], tmp_path, 'split.genus.tsv')
+
+
+def test_split_process(tmp_path):
+    run(['--input', join(ALN, 'burst', 'split'), '--rank', 'process',
+         '--map', join(FUN, 'nucl', 'uniref.map.xz'),
+         '--map', join(FUN, 'go', 'process.tsv.xz')],
+        tmp_path, 'split.process.tsv')
+
+
+def test_bt2sho_exclude_ogu(tmp_path):
+    """`bt2sho.filt.ogu.tsv`: command documented in the reference's
+    tests/data/README.md (`-x G000215745`)."""
+    run(['--input', join(ALN, 'bt2sho'), '--exclude', 'G000215745'],
+        tmp_path, 'bt2sho.filt.ogu.tsv')

@@ -1,0 +1,269 @@
+"""Alignment parsing and packing (host side).
+
+Host-side mirror of the reference's ``woltka/align.py``: the same four input
+formats (SAM, BLAST tabular "b6o", PAF, two-column map), the same
+query/mate/exclusion semantics, the same ``plain_mapper`` generator protocol
+(align.py:47-115) — plus ``pack_queries`` which turns the yielded
+(query, subjects) pairs into the integer CSR arrays that cross the C ABI
+(``subj`` / ``qoff`` of ``wk_chunk_stage``).
+
+Instead of the reference's sixteen hand-unrolled parser functions
+(4 formats x {plain, ex, ft, ex_ft}; align.py:258-1213) there is one row
+extractor per format and two grouping state machines (SAM with mates, and the
+mate-less formats).  Behaviours reproduced on purpose:
+
+* SAM mates: ``mate = int(FLAG) >> 6 & 3``; a QNAME yields up to three queries
+  ``q``, ``q/1``, ``q/2`` in that order (align.py:322-333); both bits set is an
+  ``IndexError`` like in the reference.
+* unmapped SAM records (RNAME ``*``) are skipped before the QNAME-change test
+  (align.py:318-319); queries are delimited by *consecutive* identical names.
+* plain flavour collects subject *sets*, the "ex" flavour keeps every hit as
+  ``(subject, score, length, start0, end)`` (align.py:309 vs :372).
+* exclusion drops the whole query name once any of its records hits an
+  excluded subject (align.py:443-469); the SAM ex+filter variant flushes its
+  last pool without looking at the keep flag (align.py:542-547).
+"""
+from functools import lru_cache
+from itertools import chain
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# format sniffing — align.infer_align_format (align.py:153-223)
+# --------------------------------------------------------------------------
+
+def infer_align_format(fh):
+    """Guess the format from the first line; returns (format, [lines read])."""
+    try:
+        line = next(fh)
+    except StopIteration:
+        raise ValueError('Alignment file is empty or unreadable.')
+    if line.split()[0] in ('@HD', '@PG'):
+        return 'sam', [line]
+    row = line.rstrip().split('\t')
+    if len(row) == 2:
+        return 'map', [line]
+    if len(row) >= 12:
+        if all(row[i].isdigit() for i in range(3, 10)):
+            return 'b6o', [line]
+        if row[4] in '+-' and all(row[i].isdigit()
+                                  for i in (1, 2, 3, 6, 7, 8, 9, 10, 11)):
+            return 'paf', [line]
+    if len(row) >= 11 and all(row[i].isdigit() for i in (1, 3, 4)):
+        return 'sam', [line]
+    raise ValueError('Cannot determine alignment file format.')
+
+
+# --------------------------------------------------------------------------
+# CIGAR — align.cigar_to_lens (align.py:550-583)
+# --------------------------------------------------------------------------
+
+@lru_cache(maxsize=128)
+def cigar_to_lens(cigar):
+    """(alignment length over M/=/X, reference span = that + D/N)."""
+    aligned = extra = 0
+    num = ''
+    for ch in cigar:
+        if ch in 'MDIHNPSX=':
+            if ch in 'M=X':
+                aligned += int(num)
+            elif ch in 'DN':
+                extra += int(num)
+            num = ''
+        else:
+            num += ch
+    return aligned, aligned + extra
+
+
+# --------------------------------------------------------------------------
+# row extractors: one alignment line -> (query, subject, record) or None
+# --------------------------------------------------------------------------
+
+def _row_map(line, extra):
+    query, found, rest = line.partition('\t')
+    if not found:
+        return None
+    return query, rest.partition('\t')[0].rstrip(), None
+
+
+def _row_b6o(line, extra):
+    if not extra:
+        parts = line.split('\t', 2)
+        if len(parts) < 3:
+            return None
+        return parts[0], parts[1], None
+    x = line.split('\t')
+    try:
+        query, subject, length, score = x[0], x[1], int(x[3]), float(x[11])
+    except IndexError:
+        return None
+    lo, hi = sorted((int(x[8]), int(x[9])))
+    return query, subject, (subject, score, length, lo - 1, hi)
+
+
+def _row_paf(line, extra):
+    if not extra:
+        parts = line.split('\t', 6)
+        if len(parts) < 7:
+            return None
+        return parts[0], parts[5], None
+    x = line.split('\t')
+    try:
+        rec = (x[5], int(x[11]), int(x[10]), int(x[7]), int(x[8]))
+    except (IndexError, ValueError):
+        return None
+    return x[0], x[5], rec
+
+
+_ROWS = {'map': _row_map, 'b6o': _row_b6o, 'paf': _row_paf}
+
+
+# --------------------------------------------------------------------------
+# grouping state machines
+# --------------------------------------------------------------------------
+
+def _parse_simple(lines, fmt, excl, extra):
+    """map / b6o / paf: one pool per run of identical query ids."""
+    row = _ROWS[fmt]
+    cur, keep = None, True
+    pool = [] if extra else set()
+    for line in lines:
+        r = row(line, extra)
+        if r is None:
+            continue
+        query, subject, rec = r
+        if query != cur:
+            if cur is not None and keep:
+                yield cur, pool
+            cur = query
+            keep = not (excl and subject in excl)
+            if keep:
+                pool = [rec] if extra else {subject}
+        elif keep:
+            if excl and subject in excl:
+                keep = False
+            elif extra:
+                pool.append(rec)
+            else:
+                pool.add(subject)
+    if cur is not None and keep:
+        yield cur, pool
+
+
+def _parse_sam(lines, excl, extra):
+    """SAM: header skipped, unmapped skipped, three mate pools per QNAME."""
+    fresh = (lambda: ([], [], [])) if extra else \
+        (lambda: (set(), set(), set()))
+    it = iter(lines)
+    body = ()
+    for line in it:                 # leading '@' lines are the header
+        if line[0] != '@':
+            body = chain((line,), it)
+            break
+    cur, keep, pools = None, True, fresh()
+
+    def flush():
+        if pools[0]:
+            yield cur, pools[0]
+        if pools[1]:
+            yield cur + '/1', pools[1]
+        if pools[2]:
+            yield cur + '/2', pools[2]
+
+    for line in body:
+        if extra:
+            qname, flag, rname, pos, _, cigar, _ = line.split('\t', 6)
+        else:
+            qname, flag, rname, _ = line.split('\t', 3)
+        if rname == '*':
+            continue
+        if qname != cur:
+            if keep:
+                yield from flush()
+            cur = qname
+            keep = not (excl and rname in excl)
+            if not keep:
+                continue
+            pools = fresh()
+        elif excl:
+            if not keep:
+                continue
+            if rname in excl:
+                keep = False
+                continue
+        mate = int(flag) >> 6 & 3
+        if extra:
+            start = int(pos) - 1
+            length, span = cigar_to_lens(cigar)
+            pools[mate].append((rname, None, length, start, start + span))
+        else:
+            pools[mate].add(rname)
+    if keep or (extra and excl):
+        yield from flush()
+
+
+def parse_align(lines, fmt, excl=None, extra=False):
+    """Iterator of (query, subjects) — ``set`` of ids, or with ``extra`` a list
+    of ``(subject, score, length, start0, end)`` records."""
+    excl = excl or None
+    if fmt == 'sam':
+        return _parse_sam(lines, excl, extra)
+    if fmt in _ROWS:
+        if fmt == 'map':
+            extra = False           # the map format has no "ex" flavour
+        return _parse_simple(lines, fmt, excl, extra)
+    raise ValueError(f'Invalid format code: "{fmt}".')
+
+
+def iter_align(fh, fmt=None, excl=None, extr=None):
+    """align.iter_align (align.py:118-150): sniff the format if not given."""
+    if not fmt:
+        fmt, head = infer_align_format(fh)
+        fh = chain(iter(head), fh)
+    return parse_align(fh, fmt, excl, bool(extr))
+
+
+def plain_mapper(fh, fmt=None, excl=None, n=1024):
+    """align.plain_mapper (align.py:47-115): chunks of ``n`` queries as
+    (list of query ids, list of subject sets)."""
+    it = iter_align(fh, fmt, excl)
+    while True:
+        qryque, subque = [], []
+        for query, subjects in it:
+            qryque.append(query)
+            subque.append(subjects)
+            if len(qryque) == n:
+                break
+        if not qryque:
+            return
+        yield qryque, subque
+        if len(qryque) < n:
+            return
+
+
+# --------------------------------------------------------------------------
+# packing: (query, subjects) pairs -> CSR arrays of feature ids
+# --------------------------------------------------------------------------
+
+def pack_queries(subque, index, trim=None):
+    """Subject collections -> (subj int32[n_records], qoff int32[n_reads+1]).
+
+    ``index`` is the job's ``FeatureIndex``; unknown subjects are interned on
+    the fly (ids >= n_nodes mean "not in the hierarchy").  ``trim`` applies
+    ``--trim-sub``: ``x.rsplit(trim, 1)[0]`` (workflow.strip_suffix,
+    workflow.py:818-841); the resulting duplicates are removed on the device.
+    """
+    intern = index.intern
+    flat = []
+    qoff = np.empty(len(subque) + 1, dtype=np.int32)
+    qoff[0] = 0
+    if trim:
+        for i, subs in enumerate(subque):
+            flat.extend(intern(s.rsplit(trim, 1)[0]) for s in subs)
+            qoff[i + 1] = len(flat)
+    else:
+        for i, subs in enumerate(subque):
+            flat.extend(map(intern, subs))
+            qoff[i + 1] = len(flat)
+    return np.array(flat, dtype=np.int32), qoff

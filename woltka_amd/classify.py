@@ -1,0 +1,290 @@
+"""Device-side classification driver (host half).
+
+Replaces the reference's ``workflow.assign_readmap`` (woltka/workflow.py:
+941-1058) and the assigners / counters of ``woltka/classify.py``: an ``Engine``
+owns one GPU context, the flattened hierarchy and one *job* per requested rank;
+``run_chunk`` packs a chunk, runs all ranks in one kernel pass and
+``collect`` folds the exact integer counts back into the reference's
+``data[rank][sample]`` dicts.
+
+Count keys carry a *group* = index of a (sample, stratum) pair, so one device
+table serves demultiplexed and stratified runs alike.
+"""
+from fractions import Fraction
+from os.path import join
+
+import numpy as np
+
+from . import _native as nat
+from .align import iter_align, pack_queries
+from .file import openzip, write_readmap
+from .hierarchy import FeatureIndex, flatten_hierarchy
+from .ordinal import pack_hits
+
+_NO_TREE_ROOT = '\x00root'      # stand-in root when no hierarchy is given
+MAX_GROUPS = 1 << nat.KEY_GROUP_BITS
+
+
+class Engine:
+    """One classification job on one GPU.
+
+    Parameters mirror the assignment options of ``workflow.classify``
+    (workflow.py:162-187).  ``major`` is the percentage given on the command
+    line; like the reference it is turned into the fraction ``major / 100``
+    (workflow.py:276) and compared in binary64 on the device.
+    """
+
+    def __init__(self, tree, rankdic, root, ranks, uniq=False, major=None,
+                 above=False, subok=False, unasgd=False, device=0,
+                 table_slots=None):
+        self.ctx = nat.Context(device)
+        self.ranks = list(ranks)
+        self.use_tree = bool(tree)
+        if tree:
+            self.hier = flatten_hierarchy(tree, rankdic, root)
+        else:
+            # `free` on an empty hierarchy still has defined results
+            # (classify.py:73-78): keep a lone root so that every subject is
+            # "not in the tree"
+            self.hier = flatten_hierarchy({_NO_TREE_ROOT: _NO_TREE_ROOT})
+        self.index = self.hier.index
+        h = self.hier
+        self.ctx.set_tree(h.parent, h.last, h.rank_code)
+        flags = 0
+        if uniq:
+            flags |= nat.F_UNIQ
+        if above:
+            flags |= nat.F_ABOVE
+        if subok:
+            flags |= nat.F_SUBOK
+        if unasgd:
+            flags |= nat.F_UNASSIGNED
+        self.jobs, self.modes, self.slots = [], [], []
+        slot_of = {}
+        for rank in self.ranks:
+            if rank is None or rank == 'none' or tree is None:
+                # workflow.py:1017: also taken when no hierarchy object exists
+                mode, slot, frac = nat.MODE_NONE, 0, 0.0
+            elif rank == 'free':
+                mode, slot, frac = nat.MODE_FREE, 0, 0.0
+            else:
+                mode = nat.MODE_RANK
+                code = h.code_of(rank)
+                if code not in slot_of:
+                    if len(slot_of) >= nat.MAX_RANK_SLOTS:
+                        raise ValueError('Too many distinct ranks.')
+                    slot_of[code] = len(slot_of)
+                    self.ctx.build_rank_table(slot_of[code], code)
+                slot = slot_of[code]
+                frac = (major / 100) if major else 0.0
+            self.jobs.append(nat.Job(mode, slot, flags, 0, frac))
+            self.modes.append(mode)
+            self.slots.append(slot)
+        self._anc = {}                      # slot -> downloaded rank table
+        self.groups = []                    # group id -> (sample, stratum)
+        self.group_ids = {}
+        self.slots_reserved = table_slots or (1 << 20)
+        self.ctx.counts_reserve(self.slots_reserved)
+        self.genes = None
+        self.gene_feature = None
+
+    def close(self):
+        self.ctx.close()
+
+    # ------------------------------------------------------------------
+    def set_genes(self, table, prefix):
+        """Upload the gene tables; gene names join the feature index (genes
+        that are nodes of the hierarchy keep their node id)."""
+        names = table.feature_names(prefix)
+        intern = self.index.intern
+        self.gene_feature = np.fromiter((intern(x) for x in names),
+                                        dtype=np.int32, count=len(names))
+        self.genes = table
+        self.ctx.set_genes(table.goff, table.start0, table.end,
+                           self.gene_feature)
+
+    def ordinal_chunks(self, fh, fmt, excl, n, th):
+        """Parse with the "ex" parsers and stage hits on the device, ``n``
+        hits at a time at query boundaries (ordinal_mapper, ordinal.py:219-
+        240).  Yields the query ids of every staged chunk; the hits are left
+        staged for ``run_chunk``."""
+        pending, nhits = [], 0
+        self._th = th
+        for query, records in iter_align(fh, fmt, excl, True):
+            if pending and nhits + len(records) > n:
+                yield self._stage_hits(pending)
+                pending, nhits = [], 0
+            pending.append((query, records))
+            nhits += len(records)
+        yield self._stage_hits(pending)
+
+    def _stage_hits(self, pairs):
+        queries, hoff, genome, beg, end, length = pack_hits(pairs, self.genes)
+        self._hits = (genome, beg, end, length, hoff)
+        return queries
+
+    # ------------------------------------------------------------------
+    def _group_array(self, n, sample_of, strata_of):
+        """Per-read group ids (int32) or None when every read is group 0."""
+        gid = self.group_ids
+        groups = self.groups
+
+        def get(sample, stratum):
+            key = (sample, stratum)
+            g = gid.get(key)
+            if g is None:
+                g = len(groups)
+                if g >= MAX_GROUPS:
+                    raise ValueError('Too many (sample, stratum) groups in '
+                                     'one pass.')
+                gid[key] = g
+                groups.append(key)
+            return g
+        per_read_sample = isinstance(sample_of, list)
+        if strata_of is None and not per_read_sample:
+            return np.full(n, get(sample_of, None), dtype=np.int32)
+        out = np.empty(n, dtype=np.int32)
+        for i in range(n):
+            s = sample_of[i] if per_read_sample else sample_of
+            if s is False:
+                out[i] = -1
+                continue
+            if strata_of is None:
+                out[i] = get(s, None)
+            else:
+                t = strata_of[i]
+                out[i] = -1 if t is None else get(s, t)
+        return out
+
+    def run_chunk(self, data, reads, subque, sample_of, strata_of, trimsub,
+                  rank2dir, outzip, namedic, ordinal):
+        """Classify one chunk at every rank; returns the number of queries the
+        reference would report for it (workflow.py:305)."""
+        n = len(reads)
+        if len(self.groups) + n + 1 >= MAX_GROUPS // 2:
+            self.collect(data)
+        group = self._group_array(n, sample_of, strata_of)
+        # every sample met in a chunk gets a (possibly empty) profile at every
+        # rank, like `data[rank].setdefault(sample, {})` in workflow.py:1058
+        seen = (set(sample_of) - {False}) if isinstance(sample_of, list) \
+            else ({sample_of} if n else set())
+        for rank in self.ranks:
+            for s in seen:
+                data[rank].setdefault(s, {})
+        want = rank2dir is not None
+        if ordinal:
+            genome, beg, end, length, hoff = self._hits
+            self.ctx.ordinal_stage(genome, beg, end, length, hoff, self._th,
+                                   group=group)
+            self.ctx.ordinal_match()
+            if trimsub:
+                raise NotImplementedError(
+                    '--trim-sub together with --coords is not available on '
+                    'the GPU path yet.')
+            before = self.ctx.stats()['n_reads']
+            assign = self.ctx.classify_staged(self.jobs, want_assign=want)
+            nq = self.ctx.stats()['n_reads'] - before
+            if want:
+                subj, qoff = self.ctx.chunk_download()
+        else:
+            subj, qoff = pack_queries(subque, self.index, trimsub)
+            assign = self.ctx.classify_chunk(
+                self.jobs, subj, qoff, group=group,
+                subj_is_set=not trimsub, want_assign=want)
+            nq = n
+        if want:
+            self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,
+                             outzip, namedic)
+        return nq
+
+    # ------------------------------------------------------------------
+    def _rank_table(self, slot):
+        if slot not in self._anc:
+            self._anc[slot] = self.ctx.get_rank_table(slot)
+        return self._anc[slot]
+
+    def _taxque(self, j, row, subj, qoff):
+        """Assignment codes of job j -> the reference's per-read values (str,
+        None, or list) for read-map output."""
+        names = self.index.names
+        out = []
+        n_nodes = self.hier.n_nodes
+        anc = self._rank_table(self.slots[j]) \
+            if self.modes[j] == nat.MODE_RANK else None
+        for r, v in enumerate(row.tolist()):
+            if v >= 0:
+                out.append(names[v])
+            elif v == nat.ASSIGN_MULTI:
+                cand = list(dict.fromkeys(subj[qoff[r]:qoff[r + 1]].tolist()))
+                if anc is None:
+                    out.append([names[c] for c in cand])
+                else:
+                    taxa = [anc[c] if c < n_nodes else -1 for c in cand]
+                    out.append([names[t] if t >= 0 else None for t in taxa])
+            elif v == nat.ASSIGN_EMPTY:
+                out.append(False)           # query vanished (no gene matched)
+            else:
+                out.append(None)
+        return out
+
+    def _write_maps(self, assign, subj, qoff, reads, sample_of, rank2dir,
+                    outzip, namedic):
+        """Append read-to-feature maps (workflow.py:1042-1046)."""
+        unas = bool(self.jobs[0].flags & nat.F_UNASSIGNED)
+        for j, rank in enumerate(self.ranks):
+            taxque = self._taxque(j, assign[j], subj, qoff)
+            per_sample = {}
+            for i, (read, taxa) in enumerate(zip(reads, taxque)):
+                s = sample_of[i] if isinstance(sample_of, list) else sample_of
+                if s is False or taxa is False:
+                    continue
+                if unas:
+                    taxa = taxa or 'Unassigned'
+                qs, ts = per_sample.setdefault(s, ([], []))
+                qs.append(read)
+                ts.append(taxa)
+            for s, (qs, ts) in per_sample.items():
+                outfp = join(rank2dir[rank], f'{s}.txt')
+                with openzip(f'{outfp}.{outzip}' if outzip else outfp,
+                             'at') as fh:
+                    write_readmap(fh, qs, ts, namedic)
+
+    # ------------------------------------------------------------------
+    def collect(self, data):
+        """Fetch the device counts, fold them into ``data`` as exact
+        ``Fraction``s (sum_k n_k / k, classify.py:167-170) and clear the
+        device table."""
+        while True:
+            try:
+                keys, vals = self.ctx.counts_fetch()
+                break
+            except OverflowError:
+                raise RuntimeError(
+                    'Device count table overflowed; re-run with a larger '
+                    'table (Engine(table_slots=...)).')
+        if keys.size:
+            job, k, grp, feat = nat.decode_keys(keys)
+            names = self.index.names
+            for j, kk, g, f, nn in zip(job.tolist(), k.tolist(), grp.tolist(),
+                                       feat.tolist(), vals.tolist()):
+                sample, stratum = self.groups[g]
+                name = 'Unassigned' if f == nat.FEATURE_UNASSIGNED \
+                    else names[f]
+                key = name if stratum is None else (stratum, name)
+                cell = data[self.ranks[j]].setdefault(sample, {})
+                cell[key] = cell.get(key, 0) + Fraction(nn, kk)
+        self.ctx.counts_clear()
+        self.groups = []
+        self.group_ids = {}
+
+    def finish(self, data):
+        """Final collection; exact rationals become the numbers the reference
+        would hold before rounding: ``int`` when integral, else one correctly
+        rounded ``float`` division."""
+        self.collect(data)
+        for profile in data.values():
+            for sample in profile.values():
+                for key, v in sample.items():
+                    if isinstance(v, Fraction):
+                        sample[key] = v.numerator if v.denominator == 1 \
+                            else v.numerator / v.denominator

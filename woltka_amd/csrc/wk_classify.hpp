@@ -107,9 +107,9 @@ __device__ __forceinline__ void count_add(const LdsCache& cache, const CountTabl
 // same candidates.  `P` is a pointer into HBM or into an LDS tile.
 template <bool kUseLds, typename P>
 __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCache& cache, P cand,
-                                             int32_t n, int64_t r, int32_t g) {
+                                             int32_t n, int64_t r, int32_t g, int32_t first) {
+    // `first` == cand[0] (loaded ahead of time by the caller)
     // one pass over the subjects: extremes (= LCA inputs) and set size 1 test
-    const int32_t first = cand[0];
     int32_t smin = first, smax = first;
     for (int32_t j = 1; j < n; ++j) {
         const int32_t c = cand[j];
@@ -287,22 +287,45 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         lds_cache_init(cache);
     }
     unsigned long long my_reads = 0, my_records = 0;
+    // Software pipeline over the thread's reads r, r+stride, ...: the offsets
+    // of read i+2 and the first subject (and stratum) of read i+1 are in
+    // flight while read i is evaluated, so the offset -> record chain is off
+    // the critical path and only the table gathers of read i are exposed.
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += stride) {
-        const int32_t s = a.qoff[r];
-        const int32_t n = a.qoff[r + 1] - s;
+    const int64_t last = a.n_reads - 1;
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto load_offsets = [&](int64_t i, int32_t& s, int32_t& e) {
+        const int64_t c = i < a.n_reads ? i : last;  // clamped: harmless re-read past the end
+        s = a.qoff[c];
+        e = a.qoff[c + 1];
+    };
+    auto load_group = [&](int64_t i) -> int32_t { return a.group ? a.group[i < a.n_reads ? i : last] : 0; };
+    int32_t s0, e0, s1, e1;
+    load_offsets(r, s0, e0);
+    load_offsets(r + stride, s1, e1);
+    int32_t f0 = (e0 > s0) ? a.subj[s0] : 0;
+    int32_t g0 = load_group(r);
+    for (; r < a.n_reads; r += stride) {
+        int32_t s2, e2;
+        load_offsets(r + 2 * stride, s2, e2);
+        const int32_t f1 = (e1 > s1) ? a.subj[s1] : 0;
+        const int32_t g1 = load_group(r + stride);
+        const int32_t n = e0 - s0;
         if (n <= 0) {
             mark_empty(a, r);
-            continue;
-        }
-        my_reads += 1;
-        my_records += (unsigned long long)n;
+        } else {
+            my_reads += 1;
+            my_records += (unsigned long long)n;
 #ifdef WK_ABLATE
-        if (a.ablate & 8) continue;  // measurement only: offsets stream alone
+            if (!(a.ablate & 8))  // measurement only: offsets stream alone
 #endif
-        const int32_t g = a.group ? a.group[r] : 0;
-        if (g >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
-        process_read<kUseLds>(a, cache, a.subj + s, n, r, g);
+            {
+                if (g0 >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
+                process_read<kUseLds>(a, cache, a.subj + s0, n, r, g0, f0);
+            }
+        }
+        s0 = s1; e0 = e1; f0 = f1; g0 = g1;
+        s1 = s2; e1 = e2;
     }
     flush_stats(a, my_reads, my_records);
     if constexpr (kUseLds) lds_cache_flush(cache, a.table);
@@ -373,9 +396,9 @@ __global__ void __launch_bounds__(kTileThreads) classify_tiled_kernel(ClassifyAr
                 const int32_t g = a.group ? a.group[r] : 0;
                 if (g >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
                 if (staged)
-                    process_read<true>(a, cache, lrec + (s - base), n, r, g);
+                    process_read<true>(a, cache, lrec + (s - base), n, r, g, lrec[s - base]);
                 else
-                    process_read<true>(a, cache, a.subj + s, n, r, g);
+                    process_read<true>(a, cache, a.subj + s, n, r, g, a.subj[s]);
             }
         }
         __syncthreads();  // the tile buffers are reused by the next tile

@@ -1,0 +1,581 @@
+"""`woltka classify` workflow on the MI355X path.
+
+Drop-in counterpart of the reference's ``woltka/workflow.py``: ``workflow()``
+(:44-159) and ``classify()`` (:162-353) keep their signatures, their console
+output and the shape of the returned ``data`` dict
+(``{rank: {sample: {feature or (stratum, feature): number}}}``).  What changes is
+*where* the per-read work happens: instead of ``assign_readmap`` looping over
+Python tuples (:941-1058), every chunk of alignments is packed into integer
+arrays (``align.pack_queries`` / ``ordinal.pack_hits``) and handed to the HIP
+kernels through ``classify.Engine``; counts come back as exact integers and are
+folded into the same dict.
+
+There is no CPU fallback: ``classify()`` needs ``libwoltka_hip.so`` and a GPU.
+"""
+from functools import partial
+from os import makedirs
+from os.path import basename, isdir, isfile, join
+
+import click
+
+from .align import plain_mapper
+from .classify import Engine
+from .file import (id2file_from_dir, id2file_from_map, openzip, path2stem,
+                   read_ids, read_map_1st, read_map_uniq, readzip, stem2rank,
+                   write_readmap)
+from .ordinal import load_gene_coords
+from .table import allkeys, prep_table, write_table
+from .tree import (fill_root, read_columns, read_lineage, read_names,
+                   read_newick, read_nodes)
+
+DEVICE_CHUNK = 2 ** 20      # queries per device chunk unless --chunk is given
+
+
+class OrdinalMapper:
+    """Coord-match mapper: gene table + overlap threshold.  ``classify()``
+    recognises it and runs match + assignment on the device without a round
+    trip; the gene table is uploaded once per job (``Engine.set_genes``)."""
+
+    def __init__(self, table, th=0.8, prefix=None):
+        self.table = table
+        self.th = th
+        self.prefix = table.isdup if prefix is None else prefix
+
+
+def _update(dic, other):
+    """util.update_dict (woltka/util.py:46-75): merge, conflicting values are
+    an error."""
+    for key, value in other.items():
+        if key in dic:
+            assert dic[key] == value, f'Conflicting values found for "{key}".'
+        else:
+            dic[key] = value
+
+
+def workflow(input_fp:     str,
+             output_fp:    str,
+             # input
+             input_fmt:    str = None,
+             input_ext:    str = None,
+             samples:      str = None,
+             demux:       bool = None,
+             exclude:      set = None,
+             trimsub:      str = None,
+             # hierarchies
+             nodes_fps:   list = [],
+             newick_fps:  list = [],
+             lineage_fps: list = [],
+             columns_fps: list = [],
+             map_fps:     list = [],
+             map_rank:    bool = False,
+             names_fps:   list = [],
+             # assignment
+             ranks:        str = None,
+             uniq:        bool = False,
+             major:       bool = None,
+             above:       bool = False,
+             subok:       bool = False,
+             # gene matching
+             coords_fp:    str = None,
+             overlap:      int = 80,
+             # stratification
+             strata_dir:   str = None,
+             # normalization
+             sizes:        str = None,
+             frac:        bool = False,
+             scale:        str = None,
+             digits:       int = None,
+             # output
+             output_fmt:   str = None,
+             unassigned:  bool = False,
+             name_as_id:  bool = False,
+             add_rank:    bool = False,
+             add_lineage: bool = False,
+             outmap_dir:   str = None,
+             outmap_zip:   str = 'gz',
+             outcov_dir:   str = None,
+             outcov_fmt:   str = None,
+             # performance
+             chunk:        int = None,
+             cache:        int = 1024,
+             no_exe:      bool = False,
+             # device
+             device:       int = 0) -> dict:
+    """Main classification workflow (command-line arguments in, profile out);
+    same steps in the same order as the reference (workflow.py:109-159)."""
+    zippers = None if no_exe else {}
+    samples, files, demux = parse_samples(input_fp, input_ext, samples, demux)
+    exclude = parse_exclude(exclude)
+    stratmap = parse_strata(strata_dir, samples)
+    tree, rankdic, namedic, root = build_hierarchy(
+        names_fps, nodes_fps, newick_fps, lineage_fps, columns_fps, map_fps,
+        map_rank, zippers)
+    mapper, chunk = build_mapper(coords_fp, outcov_dir, overlap, chunk,
+                                 zippers)
+    sizes = parse_sizes(sizes, mapper, zippers)
+    ranks, rank2dir = prepare_ranks(ranks, outmap_dir, tree, rankdic)
+    data = classify(
+        mapper, files, samples, input_fmt, demux, trimsub, tree, rankdic,
+        namedic if name_as_id else None, root, ranks, rank2dir, outmap_zip,
+        uniq, major, above, subok, sizes, unassigned, stratmap, exclude, chunk,
+        cache, zippers, outcov_dir, outcov_fmt, device=device)
+    frac_profiles(data, frac)
+    scale_profiles(data, scale)
+    round_profiles(data, digits)
+    write_profiles(data, output_fp, output_fmt, samples, tree, rankdic,
+                   namedic, name_as_id, add_rank, add_lineage)
+    click.echo('Task completed.')
+    return data
+
+
+def classify(mapper:  object,
+             files:     list or dict,
+             samples:   list = None,
+             fmt:        str = None,
+             demux:     bool = None,
+             trimsub:    str = None,
+             tree:      dict = None,
+             rankdic:   dict = None,
+             namedic:   dict = None,
+             root:       str = None,
+             ranks:      str = None,
+             rank2dir:  dict = None,
+             outzip:     str = None,
+             uniq:      bool = False,
+             major:      int = None,
+             above:     bool = False,
+             subok:     bool = False,
+             sizes:     dict = None,
+             unasgd:    bool = False,
+             stratmap:  dict = None,
+             exclude:    set = None,
+             chunk:      int = None,
+             cache:      int = 1024,
+             zippers:   dict = None,
+             outcov_dir: str = None,
+             outcov_fmt: str = None,
+             device:     int = 0) -> dict:
+    """Core of the classification workflow (workflow.py:162-353) on the GPU.
+
+    ``mapper`` is ``align.plain_mapper`` (or any generator with the reference's
+    mapper protocol, workflow.py:304) or an ``OrdinalMapper``.  ``cache`` (the
+    reference's per-rank LRU size) is accepted and ignored: nothing is
+    memoised, every read is evaluated by the kernels.  Counts are accumulated
+    as exact integers on the device, so the result does not depend on ``chunk``.
+    """
+    if sizes:
+        raise NotImplementedError(
+            'Size-normalised counting (--sizes) is not available on the GPU '
+            'path yet.')
+    if outcov_dir:
+        raise NotImplementedError(
+            'Subject coverage output (--outcov) is not available on the GPU '
+            'path yet.')
+    data = {x: {} for x in ranks}
+    outzip = outzip if outzip != 'none' else None
+    engine = Engine(tree, rankdic, root, ranks, uniq=uniq, major=major,
+                    above=above, subok=subok, unasgd=unasgd, device=device)
+    ordinal = isinstance(mapper, OrdinalMapper)
+    if ordinal:
+        engine.set_genes(mapper.table, mapper.prefix)
+    n = chunk or DEVICE_CHUNK
+    csample, strata = False, None
+    try:
+        for fp in sorted(files):
+            if fp == '-':
+                fileobj = click.open_file(fp).__iter__()
+                click.echo('Parsing alignment from stdin ', nl=False)
+            else:
+                fileobj = readzip(fp, zippers)
+                click.echo(f'Parsing alignment file {basename(fp)} ', nl=False)
+            with fileobj as fh:
+                nqry, nstep = 0, -1
+                if ordinal:
+                    chunks = engine.ordinal_chunks(fh, fmt, exclude, n,
+                                                   mapper.th)
+                else:
+                    chunks = mapper(fh, fmt=fmt, excl=exclude, n=n)
+                for chunk_ in chunks:
+                    if ordinal:
+                        qryque = chunk_
+                        subque = None
+                    else:
+                        qryque, subque = chunk_
+                    # sample of every read (demultiplexing / whitelist)
+                    if demux:
+                        sample_of, reads = demux_labels(qryque, samples)
+                    else:
+                        sample_of = files[fp] if files else None
+                        reads = qryque
+                    # stratum of every read; the strata map of a sample is read
+                    # when the sample first shows up (workflow.py:327-330)
+                    strata_of = None
+                    if stratmap:
+                        strata_of, csample, strata = strata_labels(
+                            sample_of, reads, stratmap, zippers, csample,
+                            strata)
+                    nq = engine.run_chunk(
+                        data, reads, subque, sample_of, strata_of, trimsub,
+                        rank2dir, outzip, namedic, ordinal)
+                    nqry += nq
+                    istep = nqry // 1000000 - nstep
+                    if istep:
+                        click.echo('.' * istep, nl=False)
+                        nstep += istep
+            click.echo(' Done.')
+            click.echo(f'  Number of sequences classified: {nqry}.')
+        engine.finish(data)
+    finally:
+        engine.close()
+    click.echo('Classification completed.')
+    return data
+
+
+def demux_labels(qryque, samples=None, sep='_'):
+    """workflow.demultiplex (workflow.py:844-909) as per-read labels: returns
+    (sample of each read or ``False`` when dropped, read ids).  A query splits
+    at the first separator into (sample, read); without separator (or with an
+    empty right part) the sample is ''/None-like and the read keeps the whole
+    left part; the whitelist is consulted only when the sample changes."""
+    allow = set(samples) if samples else None
+    labels, reads = [], []
+    cur = False
+    for query in qryque:
+        left, _, right = query.partition(sep)
+        sample, read = (right and left), (right or left)
+        if sample == cur:
+            labels.append(cur)
+        elif allow is None or sample in allow:
+            cur = sample
+            labels.append(sample)
+        else:
+            labels.append(False)
+        reads.append(read)
+    return labels, reads
+
+
+def strata_labels(sample_of, reads, stratmap, zippers, csample, strata):
+    """Stratum of every read (``None`` = not in the strata map, skipped by the
+    counters, classify.py:239).  Strata files are (re)read when the current
+    sample changes, in read order like the reference does chunk by chunk."""
+    out = []
+    if isinstance(sample_of, list):
+        for s, read in zip(sample_of, reads):
+            if s is False:
+                out.append(None)
+                continue
+            if s != csample:
+                strata = read_strata(stratmap[s], zippers)
+                csample = s
+            out.append(strata.get(read))
+    else:
+        if sample_of != csample:
+            strata = read_strata(stratmap[sample_of], zippers)
+            csample = sample_of
+        get = strata.get
+        out = [get(r) for r in reads]
+    return out, csample, strata
+
+
+def parse_samples(fp, ext=None, samples=None, demux=None):
+    """Sample ids, alignment files and demultiplexing switch
+    (workflow.py:356-480)."""
+    if samples:
+        if isfile(samples):
+            with openzip(samples) as fh:
+                samples = read_ids(fh)
+        else:
+            samples = samples.split(',')
+        click.echo(f'Number of samples to include: {len(samples)}.')
+    errmsg = 'Provided sample IDs and actual files are inconsistent.'
+    if fp == '-':
+        demux = demux is not False
+        if demux:
+            files = [fp]
+        else:
+            files = {fp: ''}
+            samples = ['']
+        click.echo('Input alignment is from stdin.')
+    elif isdir(fp):
+        demux = demux or False
+        map_ = id2file_from_dir(fp, ext, not demux and samples)
+        if len(map_) == 0:
+            raise ValueError('No valid file found in directory.')
+        if demux:
+            files = sorted([join(fp, x) for x in map_.values()])
+        else:
+            if not samples:
+                samples = sorted(map_.keys())
+            elif len(map_) < len(samples):
+                raise ValueError(errmsg)
+            files = {join(fp, map_[x]): x for x in samples}
+        click.echo(f'Input directory: {fp}.')
+        click.echo(f'Number of alignment files to read: {len(files)}.')
+    elif isfile(fp):
+        map_ = id2file_from_map(fp)
+        if map_:
+            demux = demux or False
+            if samples:
+                map_ = dict(map_)
+                try:
+                    files = {map_[x]: x for x in samples}
+                except KeyError:
+                    raise ValueError(errmsg)
+            else:
+                samples = [x[0] for x in map_]
+                files = {x[1]: x[0] for x in map_}
+            click.echo(f'Number of alignment files to read: {len(files)}.')
+        else:
+            demux = demux is not False
+            if demux:
+                files = [fp]
+            else:
+                sample = path2stem(fp, ext)
+                if samples and samples != [sample]:
+                    raise ValueError(errmsg)
+                files = {fp: sample}
+                samples = [sample]
+            click.echo(f'Input alignment file: {fp}.')
+    else:
+        raise ValueError(f'"{fp}" is not a valid file or directory.')
+    click.echo(f'Demultiplexing: {"on" if demux else "off"}.')
+    return samples, files, demux
+
+
+def parse_exclude(exclude=None):
+    """Subjects to exclude: comma list or id file (workflow.py:483-503)."""
+    if exclude:
+        if isfile(exclude):
+            with openzip(exclude) as fh:
+                exclude = read_ids(fh)
+        else:
+            exclude = exclude.split(',')
+        click.echo(f'Number of subjects to exclude: {len(exclude)}.')
+        return set(exclude)
+
+
+def parse_strata(fp=None, samples=None):
+    """{sample: stratification file} (workflow.py:506-533)."""
+    if not fp:
+        return
+    click.echo(f'Stratification file directory: {fp}.')
+    map_ = id2file_from_dir(fp, ids=samples)
+    if len(samples or []) > len(map_):
+        raise ValueError(
+            'Cannot locate stratification files for one or more samples.')
+    return {k: join(fp, v) for k, v in map_.items()}
+
+
+def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
+                 zippers=None):
+    """Plain mapper, or coord-match mapper when gene coordinates are given
+    (workflow.py:536-585).  Returns (mapper, chunk); ``chunk`` stays ``None``
+    unless the user set it (the device default is chosen in ``classify``)."""
+    if coords_fp:
+        click.echo('Reading gene coordinates...', nl=False)
+        with readzip(coords_fp, zippers) as fh:
+            table = load_gene_coords(fh, sort=True)
+        click.echo(' Done.')
+        click.echo(f'  Total number of host sequences: {len(table)}.')
+        return OrdinalMapper(table, th=overlap and overlap / 100), chunk
+    if outcov_dir:
+        raise NotImplementedError(
+            'Subject coverage output (--outcov) is not available on the GPU '
+            'path yet.')
+    return plain_mapper, chunk
+
+
+def parse_sizes(sizes, mapper, zippers=None):
+    """Feature sizes for ``--sizes`` (workflow.py:588-633): not on the GPU path
+    yet."""
+    if not sizes:
+        return
+    raise NotImplementedError(
+        'Size-normalised counting (--sizes) is not available on the GPU path '
+        'yet.')
+
+
+def prepare_ranks(ranks=None, outmap_dir=None, tree=None, rankdic=None):
+    """Rank list and read-map directories (workflow.py:636-695)."""
+    if ranks:
+        ranks = ranks.split(',')
+        if rankdic is not None:
+            missing = set(ranks) - {'free', 'none'} - set(rankdic.values())
+            if missing:
+                raise ValueError(f'Ranks {", ".join(sorted(missing))} are not'
+                                 ' found in classification system.')
+    else:
+        ranks = ['free' if tree else 'none']
+    click.echo('Classification will operate on these ranks: {}.'.format(
+        ', '.join(ranks)))
+    if not outmap_dir:
+        return ranks, None
+    makedirs(outmap_dir, exist_ok=True)
+    click.echo(f'Read-to-feature maps will be saved to: {outmap_dir}.')
+    if len(ranks) == 1:
+        return ranks, {ranks[0]: outmap_dir}
+    rank2dir = {}
+    for rank in ranks:
+        dir_ = join(outmap_dir, rank)
+        makedirs(dir_, exist_ok=True)
+        rank2dir[rank] = dir_
+    return ranks, rank2dir
+
+
+def build_hierarchy(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
+                    columns_fps=[], map_fps=[], map_rank=None, zippers=None):
+    """Read all hierarchy files into (tree, rankdic, namedic, root)
+    (workflow.py:698-815)."""
+    tree, rankdic, namedic = {}, {}, {}
+    is_build = any([names_fps, nodes_fps, newick_fps, lineage_fps,
+                    columns_fps, map_fps])
+    if is_build:
+        click.echo('Constructing classification system...')
+
+    def each(fps, label, reader):
+        for fp in fps:
+            click.echo(f'  Parsing {label}: {basename(fp)}...', nl=False)
+            with readzip(fp, zippers) as f:
+                yield reader(f)
+            click.echo(' Done.')
+
+    for names in each(names_fps, 'taxon names file', read_names):
+        _update(namedic, names)
+    for tree_, rankdic_ in each(nodes_fps, 'taxon nodes file', read_nodes):
+        _update(tree, tree_)
+        _update(rankdic, rankdic_)
+    for tree_ in each(newick_fps, 'Newick tree file', read_newick):
+        _update(tree, tree_)
+    for tree_, rankdic_ in each(lineage_fps, 'lineage file', read_lineage):
+        _update(tree, tree_)
+        _update(rankdic, rankdic_)
+    for tree_, rankdic_ in each(columns_fps, 'columns file', read_columns):
+        _update(tree, tree_)
+        _update(rankdic, rankdic_)
+    if map_rank is None:
+        map_rank = bool(map_fps) and not any([
+            nodes_fps, newick_fps, lineage_fps, columns_fps])
+    if map_rank:
+        click.echo('  Will extract rank name from map filename.')
+    for fp in map_fps:
+        click.echo(f'  Parsing simple map file: {basename(fp)}...', nl=False)
+        with readzip(fp, zippers) as f:
+            map_ = dict(read_map_1st(f))
+        _update(tree, map_)
+        if map_rank:
+            rank = stem2rank(path2stem(fp))
+            _update(rankdic, {k: rank for k in set(map_.values())})
+        click.echo(' Done.')
+    root = fill_root(tree)
+    if is_build:
+        click.echo('Classification system constructed.')
+        click.echo(f'  Total number of classification units: {len(tree)}.')
+    return tree, rankdic, namedic, root
+
+
+def read_strata(strata_fp, zippers=None):
+    """{query: stratum} of one sample (workflow.py:912-938)."""
+    with readzip(strata_fp, zippers) as fhs:
+        strata = dict(read_map_uniq(fhs))
+    if not strata:
+        raise ValueError('No stratification information is found in file: '
+                         f'{basename(strata_fp)}.')
+    return strata
+
+
+def scale_factor(s):
+    """"1k" / "1M" / plain numbers, case-insensitive; integral values stay
+    ``int`` (woltka/util.py:97-127)."""
+    s = s.strip().lower()
+    mult = 1
+    if s.endswith('k'):
+        mult, s = 1000, s[:-1]
+    elif s.endswith('m'):
+        mult, s = 1000000, s[:-1]
+    try:
+        return int(s) * mult
+    except ValueError:
+        try:
+            return float(s) * mult
+        except ValueError:
+            raise ValueError('Invalid scale factor.')
+
+
+def frac_profiles(data, frac=False):
+    """Divide by the per-sample total (workflow.py:1061-1084)."""
+    if not frac:
+        return
+    for profile in data.values():
+        for sample in profile.values():
+            total = sum(sample.values())
+            if not total:
+                continue
+            for feature in sample:
+                sample[feature] /= total
+
+
+def scale_profiles(data, scale=None):
+    """Multiply by a factor (workflow.py:1087-1103)."""
+    if not scale:
+        return
+    factor = scale_factor(scale)
+    for profile in data.values():
+        for sample in profile.values():
+            for feature in sample:
+                sample[feature] *= factor
+
+
+def round_half_snap(value, digits=None):
+    """One cell of util.round_dict (woltka/util.py:342-348)."""
+    error = 1e-7 / 10 ** digits if digits else 1e-7
+    near = round(value * 2, digits) / 2
+    if abs(value - near) <= error:
+        return round(near, digits)
+    return round(value, digits)
+
+
+def round_profiles(data, digits=None):
+    """Round cells, drop zeros (workflow.py:1106-1119, util.round_dict)."""
+    for profile in data.values():
+        for sample in profile.values():
+            dead = []
+            for feature, value in sample.items():
+                r = round_half_snap(value, digits)
+                if r:
+                    sample[feature] = r
+                else:
+                    dead.append(feature)
+            for feature in dead:
+                del sample[feature]
+
+
+def write_profiles(data, fp, is_biom=None, samples=None, tree=None,
+                   rankdic=None, namedic=None, name_as_id=False,
+                   add_rank=False, add_lineage=False):
+    """Write one table per rank (workflow.py:1122-1205)."""
+    if not fp:
+        return
+    if not samples:
+        samples = sorted(allkeys(data))
+    ranks = sorted(data.keys())
+    if len(ranks) == 1:
+        rank2fp = {ranks[0]: fp}
+        if is_biom is None:
+            is_biom = fp.endswith('.biom')
+    else:
+        makedirs(fp, exist_ok=True)
+        is_biom = is_biom is not False
+        ext = 'biom' if is_biom else 'tsv'
+        rank2fp = {x: join(fp, f'{x}.{ext}') for x in ranks}
+    fmt = 'BIOM' if is_biom else 'TSV'
+    click.echo(f'Format of output feature table(s): {fmt}.')
+    if namedic is None:
+        name_as_id = False
+    click.echo(f'Writing output profiles in {fmt} format...')
+    for rank, fp_ in rank2fp.items():
+        table = prep_table(data[rank], samples, tree if add_lineage else None,
+                           rankdic if add_rank else None, namedic, name_as_id)
+        write_table(table, fp_, is_biom)
+        click.echo(f'  Rank: {rank}, samples: {len(table[2])}, features: '
+                   f'{len(table[1])}.')
+    click.echo('Profiles written.')
