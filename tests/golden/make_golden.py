@@ -376,6 +376,74 @@ def gen_readers(seed=3):
     dump('readers.json', out)
 
 
+def gen_host(seed=17):
+    """Host-layer vectors: gene coordinate loading, table preparation."""
+    import io
+    import lzma
+    import numpy as np
+    from functools import partial
+    from woltka.ordinal import load_gene_coords, calc_gene_lens, ordinal_mapper
+    from woltka.table import prep_table, write_tsv
+    from woltka.file import write_readmap
+    rng = random.Random(seed)
+    text = ('>G1\ng1\t5\t29\ng2\t33\t61\ng3\t92\t64\n'
+            '## a comment-like super group\n'
+            '# G2\ng1\t10\t2\ng4\t1\t1\n>G3\n>>ignored\n')
+    out = {}
+
+    def decode(coords, idmap, isdup):
+        res = {}
+        for nucl, q in coords.items():
+            genes = {}
+            for code in q.tolist():
+                i = code & ((1 << 22) - 1)
+                if code & (1 << 23):
+                    genes[i][1] = code >> 24
+                else:
+                    genes[i] = [code >> 24, None]
+            res[nucl] = [[idmap[nucl][i]] + genes[i] for i in sorted(genes)]
+        return res
+    coords, idmap, isdup = load_gene_coords(io.StringIO(text), sort=True)
+    mapper = partial(ordinal_mapper, coords=coords, idmap=idmap, prefix=isdup)
+    out['small'] = dict(text=text, genes=decode(coords, idmap, isdup),
+                        isdup=isdup, lens=calc_gene_lens(mapper))
+    with lzma.open(os.path.join(DATA, 'function', 'coords.txt.xz'), 'rt') as f:
+        coords, idmap, isdup = load_gene_coords(f, sort=True)
+    mapper = partial(ordinal_mapper, coords=coords, idmap=idmap, prefix=isdup)
+    lens = calc_gene_lens(mapper)
+    keys = sorted(lens)
+    pick = rng.sample(keys, 200)
+    out['bundled'] = dict(n_genomes=len(coords),
+                          n_genes=sum(len(v) for v in idmap.values()),
+                          isdup=isdup, lens={k: lens[k] for k in pick},
+                          total_len=sum(lens.values()))
+    # tables
+    profile = {'S1': {'G1': 4, 'G2': 5, 'G3': 8}, 'S2': {'G1': 2, 'G4': 3.5},
+               'S3': {'G9': 0}}
+    strat = {'S1': {('A', 'G1'): 1, ('B', 'G1'): 2}, 'S2': {('A', 'G2'): 3}}
+    tree = {'G1': 'T1', 'G2': 'T1', 'G3': 'T2', 'G4': 'T2', 'T1': 'R',
+            'T2': 'R', 'R': 'R'}
+    rankdic = {'G1': 'genus', 'T1': 'family'}
+    namedic = {'G1': 'Gee one', 'G3': 'Gee three', 'T1': 'Tee'}
+    tabs = []
+    for kw in (dict(), dict(samples=['S2', 'S1', 'S7']), dict(namedic=namedic),
+               dict(namedic=namedic, name_as_id=True),
+               dict(tree=tree, rankdic=rankdic, namedic=namedic),
+               dict(tree=tree, namedic=namedic, name_as_id=True)):
+        for prof in (profile, strat):
+            tab = prep_table(prof, **kw)
+            buf = io.StringIO()
+            write_tsv(tab, buf)
+            tabs.append(dict(profile={s: jsonable(d) for s, d in prof.items()},
+                             kwargs=kw, table=tab, tsv=buf.getvalue()))
+    out['tables'] = tabs
+    buf = io.StringIO()
+    write_readmap(buf, ['q1', 'q2', 'q3', 'q4'],
+                  ['G1', ['G3', 'G1', 'G3', None], None, ['G2', 'G1']], namedic)
+    out['readmap'] = buf.getvalue()
+    dump('host.json', out)
+
+
 def main():
     if not _refshim.install():
         print('reference tree not present: nothing to do')
@@ -386,6 +454,7 @@ def main():
     gen_parsers()
     gen_glue()
     gen_readers()
+    gen_host()
 
 
 if __name__ == '__main__':

@@ -184,7 +184,22 @@ def test_tiny_lds_cache_overflows_to_hbm(ctx):
     try:
         _device_vs_oracle(ctx, prob, ALL_SPECS + _rank_specs(prob['hier']))
     finally:
-        ctx.set_option('lds_slots', 4096)
+        ctx.set_option('lds_slots', 8192)
+
+
+def test_tiled_kernel_vs_oracle(ctx):
+    """The LDS-staged (tiled) classify kernel gives the same answers."""
+    rng = np.random.default_rng(11)
+    prob = synth.lca_problem(rng, n_nodes=30000, n_subjects=3000,
+                             n_reads=200000, dup_frac=0.1, offtree_frac=0.02,
+                             with_group=True, max_hits=40)
+    ctx.set_option('tiled', 1)
+    ctx.set_option('lds_slots', 2048)
+    try:
+        _device_vs_oracle(ctx, prob, ALL_SPECS + _rank_specs(prob['hier']))
+    finally:
+        ctx.set_option('tiled', 0)
+        ctx.set_option('lds_slots', 8192)
 
 
 def test_flat_histogram_vs_oracle(ctx):

@@ -1,0 +1,247 @@
+"""Host layer (no GPU): parsers, packing, demultiplexing, gene tables, output
+tables — checked against vectors produced by the real reference."""
+import io
+import lzma
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DATA, load_vectors
+from woltka_amd import align, file as wfile, ordinal, table, workflow
+from woltka_amd.hierarchy import FeatureIndex, flatten_hierarchy
+
+
+def test_sam_parsers_match_reference():
+    v = load_vectors('parsers.json')
+    for name in ('real', 'synth'):
+        d = v[name]
+        lines = d['lines']
+        got = [[q, sorted(s)] for q, s in align.parse_align(lines, 'sam')]
+        assert got == d['plain']
+        got = [[q, [list(r) for r in s]]
+               for q, s in align.parse_align(lines, 'sam', extra=True)]
+        assert got == d['ex']
+        excl = set(d['excl'])
+        got = [[q, sorted(s)] for q, s in align.parse_align(lines, 'sam', excl)]
+        assert got == d['plain_ft']
+        got = [[q, [list(r) for r in s]]
+               for q, s in align.parse_align(lines, 'sam', excl, True)]
+        assert got == d['ex_ft']
+        chunks = [[q, [sorted(x) for x in s]] for q, s in
+                  align.plain_mapper(iter(lines), fmt='sam', n=7)]
+        assert chunks == d['chunks7']
+    for cigar, exp in v['cigars'].items():
+        assert list(align.cigar_to_lens(cigar)) == exp
+
+
+def test_mate_flag_with_both_bits_is_an_error():
+    with pytest.raises(IndexError):
+        list(align.parse_align(['q\t192\tG1\t1\t0\t5M\t*\n'], 'sam'))
+
+
+def test_format_inference():
+    def fmt(line):
+        return align.infer_align_format(iter([line]))[0]
+    assert fmt('@HD\tVN:1.0\n') == 'sam'
+    assert fmt('q\tG1\n') == 'map'
+    assert fmt('q\tG1\t99.0\t100\t0\t0\t1\t100\t5\t104\t1e-9\t180\n') == 'b6o'
+    assert fmt('q\t150\t0\t150\t+\tG1\t5000\t10\t160\t150\t150\t60\n') == 'paf'
+    assert fmt('q\t0\tG1\t5\t42\t10M\t*\t0\t0\tACGT\tIIII\n') == 'sam'
+    with pytest.raises(ValueError, match='empty'):
+        align.infer_align_format(iter([]))
+    with pytest.raises(ValueError, match='Cannot determine'):
+        align.infer_align_format(iter(['a\tb\tc\n']))
+
+
+def test_simple_formats():
+    b6 = ['q1\tG1\t99\t100\t0\t0\t1\t100\t205\t106\t1e-9\t180.5\n',
+          'q1\tG2\t99\t90\t0\t0\t1\t90\t10\t99\t1e-9\t170\n',
+          'short\tline\n',
+          'q2\tG1\t99\t80\t0\t0\t1\t80\t1\t80\t1e-9\t160\n']
+    assert [(q, sorted(s)) for q, s in align.parse_align(b6, 'b6o')] == \
+        [('q1', ['G1', 'G2']), ('q2', ['G1'])]
+    ex = list(align.parse_align(b6, 'b6o', extra=True))
+    assert ex[0] == ('q1', [('G1', 180.5, 100, 105, 205),
+                            ('G2', 170.0, 90, 9, 99)])
+    assert list(align.parse_align(b6, 'b6o', {'G2'})) == [('q2', {'G1'})]
+    paf = ['q1\t150\t0\t150\t+\tG1\t5000\t10\t160\t150\t150\t60\n',
+           'q1\t150\t0\t150\t-\tG2\t5000\t20\t170\t148\t150\t0\n']
+    assert list(align.parse_align(paf, 'paf')) == [('q1', {'G1', 'G2'})]
+    assert list(align.parse_align(paf, 'paf', extra=True)) == \
+        [('q1', [('G1', 60, 150, 10, 160), ('G2', 0, 150, 20, 170)])]
+    mp = ['q1\tG1\n', 'q1\tG2\textra\n', 'nosubject\n', 'q2\tG3 \n']
+    assert list(align.parse_align(mp, 'map')) == \
+        [('q1', {'G1', 'G2'}), ('q2', {'G3'})]
+    with pytest.raises(ValueError, match='Invalid format'):
+        align.parse_align([], 'xyz')
+
+
+def test_pack_queries_and_trim():
+    idx = FeatureIndex(['root', 'G1'])
+    subj, qoff = align.pack_queries([{'G1'}, ('G2_1', 'G2_2', 'G1')], idx,
+                                    trim='_')
+    assert qoff.tolist() == [0, 1, 4]
+    assert [idx.names[i] for i in subj.tolist()] == ['G1', 'G2', 'G2', 'G1']
+    assert idx.get('G2') == 2
+
+
+def test_demux_labels_match_reference():
+    v = load_vectors('glue.json')
+    for d in v['demux']:
+        labels, reads = workflow.demux_labels(d['queries'], d['samples'])
+        got = {}
+        for lab, read, subs in zip(labels, reads, d['subque']):
+            if lab is False:
+                continue
+            q, s = got.setdefault(lab, [[], []])
+            q.append(read)
+            s.append(sorted(subs))
+        assert got == d['result']
+
+
+def test_rounding_matches_reference():
+    v = load_vectors('glue.json')
+    for digits, exp in v['rounds'].items():
+        dg = None if digits == 'None' else int(digits)
+        data = {'r': {'s': {str(i): x for i, x in enumerate(v['values'])}}}
+        workflow.round_profiles(data, dg)
+        assert data['r']['s'] == exp
+    assert workflow.scale_factor('1k') == 1000
+    assert workflow.scale_factor(' 2.5M ') == 2500000.0
+    assert isinstance(workflow.scale_factor('100'), int)
+    with pytest.raises(ValueError, match='Invalid scale'):
+        workflow.scale_factor('abc')
+
+
+def test_gene_coords_match_reference():
+    v = load_vectors('host.json')
+    small = v['small']
+    t = ordinal.load_gene_coords(io.StringIO(small['text']))
+    assert t.isdup == small['isdup']
+    got = {}
+    for g, name in enumerate(t.genomes):
+        lo, hi = t.goff[g], t.goff[g + 1]
+        got[name] = sorted([t.names[i], int(t.start0[i]), int(t.end[i])]
+                           for i in range(lo, hi))
+    assert got == {k: sorted(x) for k, x in small['genes'].items()}
+    assert t.gene_lengths() == small['lens']
+    b = v['bundled']
+    with lzma.open(os.path.join(DATA, 'function', 'coords.txt.xz'), 'rt') as f:
+        t = ordinal.load_gene_coords(f)
+    assert len(t) == b['n_genomes'] and len(t.names) == b['n_genes']
+    assert t.isdup == b['isdup']
+    lens = t.gene_lengths()
+    assert sum(lens.values()) == b['total_len']
+    for k, x in b['lens'].items():
+        assert lens[k] == x
+    # genes are sorted by start within every genome
+    for g in range(len(t)):
+        s = t.start0[t.goff[g]:t.goff[g + 1]]
+        assert (np.diff(s) >= 0).all()
+    with pytest.raises(ValueError, match='Cannot extract'):
+        ordinal.load_gene_coords(io.StringIO('>G\ng1\t5\n'))
+    with pytest.raises(ValueError, match='No coordinate'):
+        ordinal.load_gene_coords(io.StringIO(''))
+    with pytest.raises(ValueError, match='Invalid coordinate'):
+        ordinal.load_gene_coords(io.StringIO('>G\ng1\tx\t9\n'))
+
+
+def test_tables_match_reference():
+    v = load_vectors('host.json')
+    for t in v['tables']:
+        prof = {s: {(tuple(k.split('|')) if '|' in k else k): x
+                    for k, x in d.items()} for s, d in t['profile'].items()}
+        tab = table.prep_table(prof, **t['kwargs'])
+        assert [list(map(list, tab[0])) if False else tab[0], tab[1], tab[2],
+                tab[3]] == t['table']
+        buf = io.StringIO()
+        table.write_tsv(tab, buf)
+        assert buf.getvalue() == t['tsv']
+    buf = io.StringIO()
+    wfile.write_readmap(buf, ['q1', 'q2', 'q3', 'q4'],
+                        ['G1', ['G3', 'G1', 'G3', None], None, ['G2', 'G1']],
+                        {'G1': 'Gee one', 'G3': 'Gee three', 'T1': 'Tee'})
+    assert buf.getvalue() == v['readmap']
+
+
+def test_file_helpers(tmp_path):
+    assert wfile.path2stem('/a/b/S01.sam.xz') == 'S01'
+    assert wfile.path2stem('S01.sam.xz', '.sam.xz') == 'S01'
+    with pytest.raises(ValueError):
+        wfile.path2stem('S01.sam.xz', '.bam')
+    assert wfile.stem2rank('taxid.map') == 'taxid'
+    assert wfile.stem2rank('nucl2g.txt') == 'g'
+    assert wfile.stem2rank('gene_to_uniref.map.xz') == 'uniref'
+    assert wfile.stem2rank('a-2-b.txt') == 'b'
+    assert wfile.read_ids(iter(['#x\n', 'a\tz\n', '\n', 'b\n'])) == ['a', 'b']
+    with pytest.raises(ValueError, match='Duplicate'):
+        wfile.read_ids(iter(['a\n', 'a\n']))
+    (tmp_path / 'S1.sam').write_text('x')
+    (tmp_path / 'S2.sam.gz').write_text('x')
+    (tmp_path / 'sub').mkdir()
+    assert wfile.id2file_from_dir(str(tmp_path)) == \
+        {'S1': 'S1.sam', 'S2': 'S2.sam.gz'}
+    m = tmp_path / 'map.txt'
+    m.write_text('A\tS1.sam\nB\tS2.sam.gz\n')
+    assert wfile.id2file_from_map(str(m)) == \
+        [('A', str(tmp_path / 'S1.sam')), ('B', str(tmp_path / 'S2.sam.gz'))]
+    m.write_text('A\tnope.sam\n')
+    assert wfile.id2file_from_map(str(m)) is None
+    assert list(wfile.read_map_uniq(iter(['a\tb\n', 'c\td\te\n', 'x\n']))) == \
+        [('a', 'b')]
+    assert list(wfile.read_map_1st(iter(['a\tb\n', 'c\td\te\n', 'x\n']))) == \
+        [('a', 'b'), ('c', 'd')]
+
+
+def test_hierarchy_flattening_properties():
+    tree = {'r': 'r', 'a': 'r', 'b': 'r', 'a1': 'a', 'a2': 'a', 'b1': 'b',
+            'a1x': 'a1'}
+    h = flatten_hierarchy(tree, {'a': 'phylum', 'a1': 'genus', 'zzz': 'x'})
+    n = h.n_nodes
+    assert h.index.names[0] == 'r' and h.parent[0] == 0
+    assert (h.parent[1:] < np.arange(1, n)).all()
+    for v in range(n):
+        name = h.index.names[v]
+        assert h.index.names[h.parent[v]] == tree[name]
+        # subtree = contiguous id range
+        desc = [u for u in range(n) if _is_desc(h, u, v)]
+        assert desc == list(range(v, h.last[v] + 1))
+    assert h.rank_code[h.index.ids['a']] == h.rank_codes['phylum']
+    with pytest.raises(ValueError, match='cannot reach the root'):
+        flatten_hierarchy({'r': 'r', 'x': 'y', 'y': 'x'})
+    with pytest.raises(ValueError, match='exactly one root'):
+        flatten_hierarchy({'r': 'r', 's': 's'})
+    with pytest.raises(ValueError, match='fill_root'):
+        flatten_hierarchy({'r': 'r', 'x': 'ghost'})
+
+
+def _is_desc(h, u, v):
+    while True:
+        if u == v:
+            return True
+        if h.parent[u] == u:
+            return False
+        u = h.parent[u]
+
+
+def test_workflow_argument_handling(tmp_path):
+    ranks, r2d = workflow.prepare_ranks(None, None, {'a': 'a'}, {})
+    assert ranks == ['free'] and r2d is None
+    assert workflow.prepare_ranks(None, None, {}, {})[0] == ['none']
+    with pytest.raises(ValueError, match='Ranks genus, zzz are not found'):
+        workflow.prepare_ranks('zzz,genus,free', None, {'a': 'a'},
+                               {'a': 'phylum'})
+    ranks, r2d = workflow.prepare_ranks('a,b', str(tmp_path / 'm'), {}, None)
+    assert r2d == {'a': str(tmp_path / 'm' / 'a'), 'b': str(tmp_path / 'm' / 'b')}
+    with pytest.raises(ValueError, match='not a valid file or directory'):
+        workflow.parse_samples(str(tmp_path / 'nothing'))
+    aln = os.path.join(DATA, 'align', 'bowtie2')
+    samples, files, demux = workflow.parse_samples(aln)
+    assert samples == ['S01', 'S02', 'S03', 'S04', 'S05'] and demux is False
+    assert files[os.path.join(aln, 'S03.sam.xz')] == 'S03'
+    samples, files, demux = workflow.parse_samples(aln, samples='S02,S01')
+    assert samples == ['S02', 'S01'] and len(files) == 2
+    tree, rankdic, namedic, root = workflow.build_hierarchy(
+        map_fps=[os.path.join(DATA, 'taxonomy', 'nucl', 'nucl2g.txt')])
+    assert set(rankdic.values()) == {'g'} and root == '1'

@@ -111,7 +111,7 @@ struct wk_ctx {
     bool profile = false;
     std::map<std::string, KernelTimer> ktimers;
 
-    int lds_slots = 4096;  // LDS front-cache slots per workgroup (16 B each)
+    int lds_slots = 8192;  // LDS front-cache slots per workgroup (16 B each = 128 KiB)
     int threads = 1024;    // workgroup size of the direct classify kernel
     int use_lds = 1;
     int blocks_per_cu = 1;

@@ -24,6 +24,7 @@ from .file import (id2file_from_dir, id2file_from_map, openzip, path2stem,
                    read_ids, read_map_1st, read_map_uniq, readzip, stem2rank,
                    write_readmap)
 from .ordinal import load_gene_coords
+from .shard import classify_sharded, env_rank
 from .table import allkeys, prep_table, write_table
 from .tree import (fill_root, read_columns, read_lineage, read_names,
                    read_newick, read_nodes)
@@ -114,11 +115,29 @@ def workflow(input_fp:     str,
                                  zippers)
     sizes = parse_sizes(sizes, mapper, zippers)
     ranks, rank2dir = prepare_ranks(ranks, outmap_dir, tree, rankdic)
-    data = classify(
-        mapper, files, samples, input_fmt, demux, trimsub, tree, rankdic,
-        namedic if name_as_id else None, root, ranks, rank2dir, outmap_zip,
-        uniq, major, above, subok, sizes, unassigned, stratmap, exclude, chunk,
-        cache, zippers, outcov_dir, outcov_fmt, device=device)
+
+    def run(share, dev):
+        return classify(
+            mapper, share, samples, input_fmt, demux, trimsub, tree, rankdic,
+            namedic if name_as_id else None, root, ranks, rank2dir,
+            outmap_zip, uniq, major, above, subok, sizes, unassigned, stratmap,
+            exclude, chunk, cache, zippers, outcov_dir, outcov_fmt, device=dev)
+
+    # one process per GPU under the torch.distributed launcher: alignment
+    # files (samples) shard across processes, profiles merge on the host
+    rank_, local, world = env_rank()
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group('gloo')
+        data = classify_sharded(lambda share: run(share, local), files, rank_,
+                                world)
+        for r in ranks:
+            data.setdefault(r, {})
+        if rank_ != 0:
+            return data
+    else:
+        data = run(files, device)
     frac_profiles(data, frac)
     scale_profiles(data, scale)
     round_profiles(data, digits)
