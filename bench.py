@@ -37,6 +37,24 @@ from woltka_amd import _native as nat  # noqa: E402
 from woltka_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+PROFILES = os.path.join(ROOT, 'profiles')
+
+
+def measured_traffic(workload, scale):
+    """HBM bytes per launch of the dominant kernel from the committed
+    rocprofv3 PMC pass (FETCH_SIZE / WRITE_SIZE collected in separate passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); written
+    by tools/prof_bench.sh for the same command.  None when absent or measured
+    at another scale."""
+    fp = os.path.join(PROFILES, f'traffic_{workload}.json')
+    try:
+        with open(fp) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if abs(t.get('scale', 1.0) - scale) > 1e-9:
+        return None
+    return t.get('hbm_bytes_per_launch')
 
 
 # --------------------------------------------------------------------------
@@ -309,7 +327,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'kernel': wl.dominant,
+                         'traffic': measured_traffic(a.workload, a.scale),
+                         'kernel': wl.dominant,
                          'kernel_ms': round(kern_ms, 4),
                          'algorithmic_bytes': wl.alg_bytes},
             'gpu_ms_per_step_events': round(gpu_ms / a.steps, 4),
