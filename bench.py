@@ -61,6 +61,19 @@ def measured_traffic(workload, scale):
 # workloads
 # --------------------------------------------------------------------------
 
+def stage_indexed(ctx, prob):
+    """Stage a packed problem the way the host packer does: subjects as dense
+    indices (order of first appearance) + the subject -> feature table."""
+    feats, first, sidx = np.unique(prob['subj'], return_index=True,
+                                   return_inverse=True)
+    order = np.argsort(first)               # first-appearance order
+    rank_of = np.empty_like(order)
+    rank_of[order] = np.arange(order.size)
+    ctx.set_subjects(feats[order].astype(np.int32))
+    ctx.chunk_stage(rank_of[sidx].astype(np.int32), prob['qoff'],
+                    subj_is_set=True, indexed=True)
+
+
 class FlatWorkload:
     """configs[1]: pack + histogram."""
     name = 'synthetic SAM 10M reads x 1 hit, flat subject->genus map, rank genus'
@@ -76,7 +89,7 @@ class FlatWorkload:
         ctx.build_rank_table(0, h.rank_codes['genus'])
         self.jobs = [nat.Job(nat.MODE_RANK, 0, 0, 0, 0.0)]
         ctx.counts_reserve(1 << 16)
-        ctx.chunk_stage(p['subj'], p['qoff'], subj_is_set=True)
+        stage_indexed(ctx, p)
         self.records = int(p['subj'].size)
         self.reads = int(p['qoff'].size - 1)
         # subj int32 + qoff int32 per record, + the 42 KB map
@@ -122,7 +135,7 @@ class LcaWorkload:
             ctx.build_rank_table(slot, h.rank_codes[rank])
             self.jobs.append(nat.Job(nat.MODE_RANK, slot, 0, 0, 0.0))
         ctx.counts_reserve(1 << 24)
-        ctx.chunk_stage(p['subj'], p['qoff'], subj_is_set=True)
+        stage_indexed(ctx, p)
         self.records = int(p['subj'].size)
         self.reads = int(p['qoff'].size - 1)
         # 4 B/record + 4 B/read + parent/last 8 B + 3 rank tables

@@ -72,6 +72,10 @@ extern "C" {
 #define WK_F_SUBOK 4u      /* --subok      (classify.py:75)      */
 #define WK_F_UNASSIGNED 8u /* --unassigned (workflow.py:1038-1039) */
 
+/* subj_flags of wk_chunk_stage / wk_classify_chunk */
+#define WK_SUBJ_IS_SET 1
+#define WK_SUBJ_INDEXED 2
+
 /* values written to the optional per-read assignment output */
 #define WK_ASSIGN_NONE (-1)  /* read not assigned (None)                     */
 #define WK_ASSIGN_MULTI (-2) /* read split over several features (a list)    */
@@ -138,6 +142,18 @@ int wk_set_genes(wk_ctx* ctx, const int32_t* genome_off, int32_t n_genomes,
                  const int32_t* start0, const int32_t* end,
                  const int32_t* gene_feature, int32_t n_genes);
 
+/* Optional compact subject table.  Alignment files name a limited set of
+ * subjects (genomes) over and over; the host interns them into dense *subject
+ * indices* (order of first appearance) and registers feature_of_subject[s] =
+ * the feature id of subject s (a hierarchy node id, or an id >= n_nodes).  A
+ * chunk staged with WK_SUBJ_INDEXED then carries subject indices in `subj`,
+ * and the library keeps one short row per subject (feature id + its ancestor
+ * at every requested rank), so that a record costs one gather from a table that
+ * stays cache-resident instead of one gather per rank into per-node tables.
+ * May be called again with a longer table as new subjects appear. */
+int wk_set_subjects(wk_ctx* ctx, const int32_t* feature_of_subject,
+                    int32_t n_subjects);
+
 /* ---- count table ------------------------------------------------------- */
 /* (Re)allocate the device count table with at least `min_slots` slots and
  * clear it.  Must be called before the first classify call. */
@@ -157,11 +173,12 @@ int wk_counts_fetch(wk_ctx* ctx, uint64_t* keys, int64_t* counts, int64_t cap,
  *   group[n_reads]    optional stratum/sample slot per read, -1 = read is not
  *                     in the strata map and is skipped (classify.py:239);
  *                     NULL = group 0 for every read
- * `subj_is_set` != 0 promises that no read lists the same subject twice (the
- * reference's per-read sets, align.py:309); otherwise the device removes
- * duplicates itself. */
+ * `subj_flags`: WK_SUBJ_IS_SET promises that no read lists the same subject
+ * twice (the reference's per-read sets, align.py:309); otherwise the device
+ * removes duplicates itself.  WK_SUBJ_INDEXED: `subj` holds subject indices of
+ * the table given to wk_set_subjects instead of feature ids. */
 int wk_chunk_stage(wk_ctx* ctx, const int32_t* subj, const int32_t* qoff,
-                   int64_t n_reads, const int32_t* group, int subj_is_set);
+                   int64_t n_reads, const int32_t* group, int subj_flags);
 
 /* Run `n_jobs` classification jobs over the staged chunk and add the results
  * to the count table (replaces workflow.assign_readmap, workflow.py:941-1058:
@@ -174,7 +191,7 @@ int wk_classify_staged(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
 /* Convenience: stage + classify in one call from host buffers. */
 int wk_classify_chunk(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
                       const int32_t* subj, const int32_t* qoff,
-                      int64_t n_reads, const int32_t* group, int subj_is_set,
+                      int64_t n_reads, const int32_t* group, int subj_flags,
                       int32_t* out_assign);
 
 /* Stage one chunk of ordinal-mapper input (replaces the qrys/lens/begs/ends

@@ -143,6 +143,22 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     st = ctx.stats()
     assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
     assert st['n_records'] == prob['subj'].size
+    # same chunk through the compact subject table (dense subject indices)
+    feats, sidx = np.unique(prob['subj'], return_inverse=True)
+    perm = np.random.default_rng(0).permutation(feats.size)   # any injective order
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    ctx.set_subjects(feats[perm])
+    ctx.counts_clear()
+    assign2 = ctx.classify_chunk(jobs, inv[sidx].astype(np.int32),
+                                 prob['qoff'], group=prob.get('group'),
+                                 subj_is_set=False, want_assign=True,
+                                 indexed=True)
+    keys2, vals2 = ctx.counts_fetch()
+    assert np.array_equal(assign2, oassign)
+    order = np.argsort(keys2)
+    assert np.array_equal(keys2[order], okeys)
+    assert np.array_equal(vals2[order], ocnt.astype(np.int64))
     ctx.set_option('use_lds', 1)
 
 
@@ -277,6 +293,13 @@ def test_edge_cases(ctx):
     big = np.arange(nat.MAX_K + 1, dtype=np.int32)
     ctx.classify_chunk(jobs, big, np.array([0, big.size], np.int32))
     with pytest.raises(ValueError, match='more than'):
+        ctx.counts_fetch()
+    # subject index outside the registered table -> loud error
+    ctx.counts_clear()
+    ctx.set_subjects(np.array([3, 5], np.int32))
+    ctx.classify_chunk(jobs, np.array([0, 1, 2], np.int32),
+                       np.array([0, 1, 3], np.int32), indexed=True)
+    with pytest.raises(ValueError, match='outside'):
         ctx.counts_fetch()
     # a full count table is reported, never silently dropped
     ctx.counts_reserve(1024)

@@ -25,6 +25,7 @@ FEATURE_UNASSIGNED, MAX_FEATURE = 0x0FFFFFFF, 0x0FFFFFFE
 MODE_NONE, MODE_FREE, MODE_RANK = 0, 1, 2
 F_UNIQ, F_ABOVE, F_SUBOK, F_UNASSIGNED = 1, 2, 4, 8
 ASSIGN_NONE, ASSIGN_MULTI, ASSIGN_EMPTY = -1, -2, -3
+SUBJ_IS_SET, SUBJ_INDEXED = 1, 2
 MAX_RANK_SLOTS = MAX_JOBS * 4
 
 # every symbol the header declares (checked by tests/test_abi.py)
@@ -32,6 +33,7 @@ SYMBOLS = (
     'wk_abi_version', 'wk_create', 'wk_destroy', 'wk_last_error',
     'wk_device_name', 'wk_sync', 'wk_set_option', 'wk_set_tree',
     'wk_build_rank_table', 'wk_get_rank_table', 'wk_set_genes',
+    'wk_set_subjects',
     'wk_counts_reserve', 'wk_counts_clear', 'wk_counts_fetch',
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_chunk_download',
@@ -82,6 +84,7 @@ def load_library():
         'wk_get_rank_table': (C.c_int, [p, C.c_int32, i32p]),
         'wk_set_genes': (C.c_int, [p, i32p, C.c_int32, i32p, i32p, i32p,
                                    C.c_int32]),
+        'wk_set_subjects': (C.c_int, [p, i32p, C.c_int32]),
         'wk_counts_reserve': (C.c_int, [p, C.c_int64]),
         'wk_counts_clear': (C.c_int, [p]),
         'wk_counts_fetch': (C.c_int, [p, u64p, i64p, C.c_int64, i64p]),
@@ -223,6 +226,11 @@ class Context:
             _ptr(start0, C.c_int32), _ptr(end, C.c_int32),
             _ptr(gene_feature, C.c_int32), start0.size))
 
+    def set_subjects(self, feature_of_subject):
+        f = _arr(feature_of_subject, np.int32)
+        self._check(self._lib.wk_set_subjects(self._h, _ptr(f, C.c_int32),
+                                              f.size))
+
     # -- counts -----------------------------------------------------------
     def counts_reserve(self, min_slots):
         self._check(self._lib.wk_counts_reserve(self._h, int(min_slots)))
@@ -253,7 +261,8 @@ class Context:
             arr[i] = j
         return arr
 
-    def chunk_stage(self, subj, qoff, group=None, subj_is_set=False):
+    def chunk_stage(self, subj, qoff, group=None, subj_is_set=False,
+                    indexed=False):
         subj, qoff = _arr(subj, np.int32), _arr(qoff, np.int32)
         n_reads = qoff.size - 1
         if group is not None:
@@ -262,7 +271,9 @@ class Context:
                 raise ValueError('group must have one entry per read')
         self._check(self._lib.wk_chunk_stage(
             self._h, _ptr(subj, C.c_int32), _ptr(qoff, C.c_int32), n_reads,
-            _ptr(group, C.c_int32), int(bool(subj_is_set))))
+            _ptr(group, C.c_int32),
+            (SUBJ_IS_SET if subj_is_set else 0) |
+            (SUBJ_INDEXED if indexed else 0)))
         self._n_reads = n_reads
 
     def classify_staged(self, jobs, want_assign=False):
@@ -274,8 +285,8 @@ class Context:
         return out
 
     def classify_chunk(self, jobs, subj, qoff, group=None, subj_is_set=False,
-                       want_assign=False):
-        self.chunk_stage(subj, qoff, group, subj_is_set)
+                       want_assign=False, indexed=False):
+        self.chunk_stage(subj, qoff, group, subj_is_set, indexed)
         return self.classify_staged(jobs, want_assign)
 
     # -- ordinal ----------------------------------------------------------

@@ -87,6 +87,10 @@ class Engine:
         self.ctx.counts_reserve(self.slots_reserved)
         self.genes = None
         self.gene_feature = None
+        # dense subject indices (order of first appearance in the alignments)
+        # -> feature ids, mirrored on the device by wk_set_subjects
+        self.subjects = FeatureIndex()
+        self.subj_feature = []
 
     def close(self):
         self.ctx.close()
@@ -187,10 +191,18 @@ class Engine:
             if want:
                 subj, qoff = self.ctx.chunk_download()
         else:
-            subj, qoff = pack_queries(subque, self.index, trimsub)
+            subj, qoff = pack_queries(subque, self.subjects, trimsub)
+            known = len(self.subj_feature)
+            if len(self.subjects) > known:
+                intern = self.index.intern
+                self.subj_feature.extend(
+                    intern(x) for x in self.subjects.names[known:])
+                self.ctx.set_subjects(self.subj_feature)
             assign = self.ctx.classify_chunk(
                 self.jobs, subj, qoff, group=group,
-                subj_is_set=not trimsub, want_assign=want)
+                subj_is_set=not trimsub, want_assign=want, indexed=True)
+            if want:    # read maps work on feature ids
+                subj = np.asarray(self.subj_feature, dtype=np.int32)[subj]
             nq = n
         if want:
             self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,

@@ -22,6 +22,8 @@ struct JobDev {
     uint32_t flags;
     const int32_t* anc;  // rank table (WK_MODE_RANK)
     double major;
+    int32_t col;         // column of this job's rank ancestor in the subject rows
+    int32_t _pad;
 };
 
 struct ClassifyArgs {
@@ -33,6 +35,11 @@ struct ClassifyArgs {
     int32_t n_nodes;
     int32_t n_jobs;
     int32_t subj_is_set;
+    // optional compact subject table: subj[] then holds dense subject indices and
+    // rows[s * row_w] = {feature id, rank ancestor of job column 0, 1, ...}
+    const int32_t* rows;
+    int32_t row_w;
+    int32_t n_subjects;
     JobDev jobs[WK_MAX_JOBS];
     int32_t* out_assign;  // [n_jobs * n_reads] or null
     unsigned long long* stat_block;  // [2 * gridDim.x]: per-workgroup (reads, records) totals
@@ -62,6 +69,25 @@ __global__ void __launch_bounds__(256) rank_table_kernel(const Node* __restrict_
     anc[v] = res;
 }
 
+// Compact subject rows: rows[s * w] = feature id of subject s, followed by its
+// ancestor at every rank column (one gather per rank table, done once per
+// subject instead of once per alignment record).
+struct RowCols {
+    const int32_t* anc[WK_MAX_JOBS];
+    int32_t n_cols;
+};
+__global__ void __launch_bounds__(256) subject_rows_kernel(const int32_t* __restrict__ feature_of_subject,
+                                                           int32_t n_subjects, int32_t n_nodes, RowCols cols,
+                                                           int32_t w, int32_t* __restrict__ rows) {
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_subjects) return;
+    const int32_t f = feature_of_subject[s];
+    int32_t* row = rows + (int64_t)s * w;
+    row[0] = f;
+    for (int32_t c = 0; c < w - 1; ++c)
+        row[1 + c] = (c < cols.n_cols && f >= 0 && f < n_nodes) ? cols.anc[c][f] : -1;
+}
+
 // Lowest common ancestor of a set of hierarchy nodes given only the smallest
 // and largest pre-order id in the set: the LCA of a set equals the LCA of its
 // pre-order extremes, and that is the lowest ancestor `a` of `lo` whose
@@ -78,12 +104,141 @@ __device__ __forceinline__ int32_t lca_of_range(const Node* __restrict__ nodes, 
     return u;
 }
 
-// true iff no earlier record of the same read names the same subject
+// Candidate accessors.  A read's candidates are either feature ids (the
+// rank ancestor is gathered from the per-rank table, one table per job), or
+// dense subject indices into the compact subject rows (feature id and all rank
+// ancestors of a subject sit in one row, so a record costs one short gather
+// from a table that stays L2-resident: ~100 k subjects x 16 B instead of three
+// 8 MB per-node tables at the config-3 shape).
 template <typename P>
-__device__ __forceinline__ bool first_occurrence(P cand, int32_t j) {
-    const int32_t c = cand[j];
+struct FeatureCand {
+    static constexpr bool kHasCols = false;
+    P cand;
+    int32_t n_nodes;
+    __device__ __forceinline__ int32_t id(int32_t j) const { return cand[j]; }
+    __device__ __forceinline__ int32_t feat(int32_t j) const { return cand[j]; }
+    __device__ __forceinline__ int32_t tax(int32_t j, const JobDev& job) const {
+        const int32_t c = cand[j];
+        return (c < n_nodes) ? job.anc[c] : -1;
+    }
+};
+template <typename P>
+struct RowCand {
+    static constexpr bool kHasCols = false;
+    P cand;
+    const int32_t* __restrict__ rows;
+    int32_t w;
+    __device__ __forceinline__ int32_t id(int32_t j) const { return cand[j]; }
+    __device__ __forceinline__ int32_t feat(int32_t j) const { return rows[(int64_t)cand[j] * w]; }
+    __device__ __forceinline__ int32_t tax(int32_t j, const JobDev& job) const {
+        return rows[(int64_t)cand[j] * w + 1 + job.col];
+    }
+};
+
+// Per-rank-column summary of a read's candidates (inputs of assign_rank)
+struct ColStats {
+    int32_t t0, tmin, tmax;
+    bool same, none;
+};
+__device__ __forceinline__ void col_init(ColStats& c, int32_t t) {
+    c.t0 = c.tmin = c.tmax = t;
+    c.same = true;
+    c.none = t < 0;
+}
+__device__ __forceinline__ void col_update(ColStats& c, int32_t t) {
+    c.same &= (t == c.t0);
+    c.none |= (t < 0);
+    c.tmin = t < c.tmin ? t : c.tmin;
+    c.tmax = t > c.tmax ? t : c.tmax;
+}
+
+// One pass over a read's candidates: feature extremes (LCA inputs, "set has one
+// element" test) and, for 4-wide subject rows, the statistics of all (<= 3)
+// rank columns at once — every record is touched once for all ranks, and the
+// row loads of up to four records are issued back to back.
+struct ReadScan {
+    int32_t smin, smax;
+    ColStats col[3];
+};
+
+template <typename C>
+__device__ __forceinline__ void scan_candidates(const C& cand, int32_t n, int32_t first, ReadScan& sc) {
+    sc.smin = sc.smax = first;
+    for (int32_t j = 1; j < n; ++j) {
+        const int32_t c = cand.feat(j);
+        sc.smin = c < sc.smin ? c : sc.smin;
+        sc.smax = c > sc.smax ? c : sc.smax;
+    }
+}
+
+// rows of width 4: {feature, rank col 0, 1, 2}
+template <typename P>
+struct RowCand4 {
+    static constexpr bool kHasCols = true;
+    P cand;
+    const int4* __restrict__ rows4;
+    int4 row0;  // row of candidate 0 (loaded ahead of time)
+    __device__ __forceinline__ int32_t id(int32_t j) const { return cand[j]; }
+    __device__ __forceinline__ int32_t feat(int32_t j) const { return rows4[cand[j]].x; }
+    __device__ __forceinline__ int32_t tax(int32_t j, const JobDev& job) const {
+        const int4 r = rows4[cand[j]];
+        return job.col == 0 ? r.y : (job.col == 1 ? r.z : r.w);
+    }
+};
+
+template <typename P>
+__device__ __forceinline__ void scan_candidates(const RowCand4<P>& cand, int32_t n, int32_t, ReadScan& sc) {
+    const int4 r0 = cand.row0;
+    sc.smin = sc.smax = r0.x;
+    col_init(sc.col[0], r0.y);
+    col_init(sc.col[1], r0.z);
+    col_init(sc.col[2], r0.w);
+    for (int32_t j = 1; j < n; j += 4) {
+        int32_t c[4];
+        int4 rw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = cand.cand[(j + q < n) ? (j + q) : 0];  // pad with candidate 0 (idempotent)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rw[q] = cand.rows4[c[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc.smin = rw[q].x < sc.smin ? rw[q].x : sc.smin;
+            sc.smax = rw[q].x > sc.smax ? rw[q].x : sc.smax;
+            col_update(sc.col[0], rw[q].y);
+            col_update(sc.col[1], rw[q].z);
+            col_update(sc.col[2], rw[q].w);
+        }
+    }
+}
+
+template <typename C>
+__device__ __forceinline__ ColStats rank_stats(const C& cand, const ReadScan& sc, const JobDev& job, int32_t n) {
+    if constexpr (C::kHasCols) {
+        // field-by-field value selects: selecting whole structs makes the
+        // compiler index a stack copy (scratch memory)
+        const int32_t k = job.col;
+        auto pick = [k](auto x, auto y, auto z) { return k == 0 ? x : (k == 1 ? y : z); };
+        ColStats cs;
+        cs.t0 = pick(sc.col[0].t0, sc.col[1].t0, sc.col[2].t0);
+        cs.tmin = pick(sc.col[0].tmin, sc.col[1].tmin, sc.col[2].tmin);
+        cs.tmax = pick(sc.col[0].tmax, sc.col[1].tmax, sc.col[2].tmax);
+        cs.same = pick(sc.col[0].same, sc.col[1].same, sc.col[2].same);
+        cs.none = pick(sc.col[0].none, sc.col[1].none, sc.col[2].none);
+        return cs;
+    } else {
+        ColStats cs;
+        col_init(cs, cand.tax(0, job));
+        for (int32_t j = 1; j < n; ++j) col_update(cs, cand.tax(j, job));
+        return cs;
+    }
+}
+
+// true iff no earlier record of the same read names the same subject
+template <typename C>
+__device__ __forceinline__ bool first_occurrence(const C& cand, int32_t j) {
+    const int32_t c = cand.id(j);
     for (int32_t i = 0; i < j; ++i)
-        if (cand[i] == c) return false;
+        if (cand.id(i) == c) return false;
     return true;
 }
 
@@ -103,19 +258,16 @@ __device__ __forceinline__ void count_add(const LdsCache& cache, const CountTabl
 }
 
 // Everything the reference does for ONE read (query, mate) whose n >= 1
-// candidate subjects are cand[0..n): all jobs (ranks) are evaluated from the
-// same candidates.  `P` is a pointer into HBM or into an LDS tile.
-template <bool kUseLds, typename P>
-__device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCache& cache, P cand,
+// candidate subjects are cand 0..n-1: all jobs (ranks) are evaluated from the
+// same candidates.  `C` is a FeatureCand / RowCand over HBM or an LDS tile.
+template <bool kUseLds, typename C>
+__device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCache& cache, const C& cand,
                                              int32_t n, int64_t r, int32_t g, int32_t first) {
-    // `first` == cand[0] (loaded ahead of time by the caller)
+    // `first` == cand.feat(0) (loaded ahead of time by the caller)
     // one pass over the subjects: extremes (= LCA inputs) and set size 1 test
-    int32_t smin = first, smax = first;
-    for (int32_t j = 1; j < n; ++j) {
-        const int32_t c = cand[j];
-        smin = c < smin ? c : smin;
-        smax = c > smax ? c : smax;
-    }
+    ReadScan sc;
+    scan_candidates(cand, n, first, sc);
+    const int32_t smin = sc.smin, smax = sc.smax;
     if ((uint32_t)smax > (uint32_t)WK_MAX_FEATURE || smin < 0) atomicOr(a.table.err, kErrFeatureRange);
     const bool single = (smin == smax);
 #ifdef WK_ABLATE
@@ -145,7 +297,7 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                     } else {
                         for (int32_t j = 0; j < n; ++j)
                             if (a.subj_is_set || first_occurrence(cand, j))
-                                count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)cand[j]));
+                                count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)cand.feat(j)));
                     }
                 }
             }
@@ -164,18 +316,9 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
             }
         } else {
             // assign_rank: map every subject to its ancestor at the rank
-            const int32_t* __restrict__ anc = job.anc;
-            const int32_t t0 = (first < a.n_nodes) ? anc[first] : -1;
-            int32_t tmin = t0, tmax = t0;
-            bool all_same = true, any_none = (t0 < 0);
-            for (int32_t j = 1; j < n; ++j) {
-                const int32_t c = cand[j];
-                const int32_t t = (c < a.n_nodes) ? anc[c] : -1;
-                all_same &= (t == t0);
-                any_none |= (t < 0);
-                tmin = t < tmin ? t : tmin;
-                tmax = t > tmax ? t : tmax;
-            }
+            const ColStats cs = rank_stats(cand, sc, job, n);
+            const int32_t t0 = cs.t0, tmin = cs.tmin, tmax = cs.tmax;
+            const bool all_same = cs.same, any_none = cs.none;
             if (all_same) {
                 res = t0 < 0 ? WK_ASSIGN_NONE : t0;
             } else if (job.major > 0.0) {
@@ -186,14 +329,11 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                 for (int32_t j = 0; j < n; ++j) {
                     if (!a.subj_is_set && !first_occurrence(cand, j)) continue;
                     total += 1;
-                    const int32_t cj = cand[j];
-                    const int32_t tj = (cj < a.n_nodes) ? anc[cj] : -1;
+                    const int32_t tj = cand.tax(j, job);
                     int32_t cnt = 0;
                     for (int32_t i = 0; i < n; ++i) {
                         if (!a.subj_is_set && !first_occurrence(cand, i)) continue;
-                        const int32_t ci = cand[i];
-                        const int32_t ti = (ci < a.n_nodes) ? anc[ci] : -1;
-                        cnt += (ti == tj) ? 1 : 0;
+                        cnt += (cand.tax(i, job) == tj) ? 1 : 0;
                     }
                     if (cnt > best_n) {
                         best_n = cnt;
@@ -213,17 +353,14 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                 if (g >= 0) {
                     int32_t kd = 0;
                     for (int32_t j = 0; j < n; ++j) {
-                        const int32_t c = cand[j];
-                        if (c >= a.n_nodes || anc[c] < 0) continue;
+                        if (cand.tax(j, job) < 0) continue;
                         if (a.subj_is_set || first_occurrence(cand, j)) kd += 1;
                     }
                     if (kd > WK_MAX_K) {
                         atomicOr(a.table.err, kErrKRange);
                     } else {
                         for (int32_t j = 0; j < n; ++j) {
-                            const int32_t c = cand[j];
-                            if (c >= a.n_nodes) continue;
-                            const int32_t t = anc[c];
+                            const int32_t t = cand.tax(j, job);
                             if (t < 0) continue;
                             if (a.subj_is_set || first_occurrence(cand, j))
                                 count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)t));
@@ -287,10 +424,10 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         lds_cache_init(cache);
     }
     unsigned long long my_reads = 0, my_records = 0;
-    // Software pipeline over the thread's reads r, r+stride, ...: the offsets
-    // of read i+2 and the first subject (and stratum) of read i+1 are in
-    // flight while read i is evaluated, so the offset -> record chain is off
-    // the critical path and only the table gathers of read i are exposed.
+    // Software pipeline over the thread's reads r, r+stride, ...: loads of the
+    // following reads are in flight while read i is evaluated, so the
+    // offset -> record (-> subject row) chain is off the critical path and only
+    // the gathers of read i's further candidates are exposed.
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t last = a.n_reads - 1;
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -300,32 +437,86 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         e = a.qoff[c + 1];
     };
     auto load_group = [&](int64_t i) -> int32_t { return a.group ? a.group[i < a.n_reads ? i : last] : 0; };
-    int32_t s0, e0, s1, e1;
-    load_offsets(r, s0, e0);
-    load_offsets(r + stride, s1, e1);
-    int32_t f0 = (e0 > s0) ? a.subj[s0] : 0;
-    int32_t g0 = load_group(r);
-    for (; r < a.n_reads; r += stride) {
-        int32_t s2, e2;
-        load_offsets(r + 2 * stride, s2, e2);
-        const int32_t f1 = (e1 > s1) ? a.subj[s1] : 0;
-        const int32_t g1 = load_group(r + stride);
-        const int32_t n = e0 - s0;
-        if (n <= 0) {
-            mark_empty(a, r);
-        } else {
-            my_reads += 1;
-            my_records += (unsigned long long)n;
+    auto evaluate = [&](auto cand, int32_t n, int64_t rr, int32_t g, int32_t first) {
+        my_reads += 1;
+        my_records += (unsigned long long)n;
 #ifdef WK_ABLATE
-            if (!(a.ablate & 8))  // measurement only: offsets stream alone
+        if (a.ablate & 8) return;  // measurement only: offsets stream alone
 #endif
-            {
-                if (g0 >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
-                process_read<kUseLds>(a, cache, a.subj + s0, n, r, g0, f0);
+        if (g >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
+        process_read<kUseLds>(a, cache, cand, n, rr, g, first);
+    };
+
+    if (a.rows != nullptr && a.row_w == 4) {
+        // stages: offsets (i+3) -> first subject index (i+2) -> its row (i+1) -> evaluate (i)
+        const int4* __restrict__ rows4 = reinterpret_cast<const int4*>(a.rows);
+        auto load_first = [&](int32_t s, int32_t e) -> int32_t { return (e > s) ? a.subj[s] : 0; };
+        auto load_row = [&](int32_t c) -> int4 {
+            return ((uint32_t)c < (uint32_t)a.n_subjects) ? rows4[c] : make_int4(-1, -1, -1, -1);
+        };
+        int32_t s0, e0, s1, e1, s2, e2;
+        load_offsets(r, s0, e0);
+        load_offsets(r + stride, s1, e1);
+        load_offsets(r + 2 * stride, s2, e2);
+        int32_t c0 = load_first(s0, e0), c1 = load_first(s1, e1);
+        int4 row0 = load_row(c0);
+        int32_t g0 = load_group(r);
+        for (; r < a.n_reads; r += stride) {
+            int32_t s3, e3;
+            load_offsets(r + 3 * stride, s3, e3);
+            const int32_t c2 = load_first(s2, e2);
+            const int4 row1 = load_row(c1);
+            const int32_t g1 = load_group(r + stride);
+            const int32_t n = e0 - s0;
+            if (n <= 0) {
+                mark_empty(a, r);
+            } else {
+                // every subject index of the read must lie inside the table
+                bool ok = (uint32_t)c0 < (uint32_t)a.n_subjects;
+                for (int32_t j = 1; j < n; ++j) ok &= ((uint32_t)a.subj[s0 + j] < (uint32_t)a.n_subjects);
+                if (!ok)
+                    atomicOr(a.table.err, kErrFeatureRange);
+                else
+                    evaluate(RowCand4<const int32_t*>{a.subj + s0, rows4, row0}, n, r, g0, row0.x);
             }
+            s0 = s1; e0 = e1; s1 = s2; e1 = e2; s2 = s3; e2 = e3;
+            c0 = c1; c1 = c2; row0 = row1; g0 = g1;
         }
-        s0 = s1; e0 = e1; f0 = f1; g0 = g1;
-        s1 = s2; e1 = e2;
+    } else {
+        const bool use_rows = a.rows != nullptr;
+        // first candidate of a read -> its feature id (subject rows: one more gather)
+        auto first_feature = [&](int32_t s, int32_t e) -> int32_t {
+            if (e <= s) return 0;
+            const int32_t c = a.subj[s];
+            if (!use_rows) return c;
+            return ((uint32_t)c < (uint32_t)a.n_subjects) ? a.rows[(int64_t)c * a.row_w] : -1;
+        };
+        int32_t s0, e0, s1, e1;
+        load_offsets(r, s0, e0);
+        load_offsets(r + stride, s1, e1);
+        int32_t f0 = first_feature(s0, e0);
+        int32_t g0 = load_group(r);
+        for (; r < a.n_reads; r += stride) {
+            int32_t s2, e2;
+            load_offsets(r + 2 * stride, s2, e2);
+            const int32_t f1 = first_feature(s1, e1);
+            const int32_t g1 = load_group(r + stride);
+            const int32_t n = e0 - s0;
+            if (n <= 0) {
+                mark_empty(a, r);
+            } else if (use_rows) {
+                bool ok = true;
+                for (int32_t j = 0; j < n; ++j) ok &= ((uint32_t)a.subj[s0 + j] < (uint32_t)a.n_subjects);
+                if (!ok)
+                    atomicOr(a.table.err, kErrFeatureRange);
+                else
+                    evaluate(RowCand<const int32_t*>{a.subj + s0, a.rows, a.row_w}, n, r, g0, f0);
+            } else {
+                evaluate(FeatureCand<const int32_t*>{a.subj + s0, a.n_nodes}, n, r, g0, f0);
+            }
+            s0 = s1; e0 = e1; f0 = f1; g0 = g1;
+            s1 = s2; e1 = e2;
+        }
     }
     flush_stats(a, my_reads, my_records);
     if constexpr (kUseLds) lds_cache_flush(cache, a.table);
@@ -396,9 +587,9 @@ __global__ void __launch_bounds__(kTileThreads) classify_tiled_kernel(ClassifyAr
                 const int32_t g = a.group ? a.group[r] : 0;
                 if (g >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
                 if (staged)
-                    process_read<true>(a, cache, lrec + (s - base), n, r, g, lrec[s - base]);
+                    process_read<true>(a, cache, FeatureCand<const int32_t*>{lrec + (s - base), a.n_nodes}, n, r, g, lrec[s - base]);
                 else
-                    process_read<true>(a, cache, a.subj + s, n, r, g, a.subj[s]);
+                    process_read<true>(a, cache, FeatureCand<const int32_t*>{a.subj + s, a.n_nodes}, n, r, g, a.subj[s]);
             }
         }
         __syncthreads();  // the tile buffers are reused by the next tile

@@ -122,6 +122,9 @@ __device__ __forceinline__ void cached_add(const LdsCache& c, const CountTable& 
     const uint32_t b = hash_key(key) & c.bmask;
     if (bucket_add(c.base + (size_t)b * 8, key, w)) return;
     if (bucket_add(c.base + (size_t)((b + 1) & c.bmask) * 8, key, w)) return;
+#ifdef WK_ABLATE
+    if (c.ablate & 16) return;  // measurement only: drop cache misses
+#endif
     table_add(t, key, w);  // both buckets taken by other keys: count in HBM directly
 }
 

@@ -78,6 +78,13 @@ struct wk_ctx {
     DevBuf rank_tab[WK_MAX_JOBS * 4];
     bool rank_tab_valid[WK_MAX_JOBS * 4] = {};
 
+    // compact subject table (optional)
+    DevBuf subj_feat, subj_rows;
+    int32_t n_subjects = 0;
+    int32_t rows_w = 0;
+    std::vector<int> rows_sig;  // rank slots the rows were built for (+ n_subjects)
+    bool subj_indexed = false;  // staged chunk carries subject indices
+
     // genes
     DevBuf genome_off, gstart, gend, gpmax, gfeat;
     int32_t n_genomes = 0, n_genes = 0;
@@ -285,7 +292,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->subj_feat, &c->subj_rows, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -361,6 +368,7 @@ int wk_set_tree(wk_ctx* c, const int32_t* parent, const int32_t* last, const int
     if ((rc = upload(c, c->rank_code, rank_code, (size_t)n * sizeof(int32_t)))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // `packed` is about to go out of scope
     c->n_nodes = n;
+    c->rows_sig.clear();
     for (bool& v : c->rank_tab_valid) v = false;
     return WK_OK;
 }
@@ -378,6 +386,7 @@ int wk_build_rank_table(wk_ctx* c, int32_t slot, int32_t code) {
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
     c->rank_tab_valid[slot] = true;
+    c->rows_sig.clear();
     return WK_OK;
 }
 
@@ -420,6 +429,21 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_genomes = n_genomes;
     c->n_genes = n_genes;
+    return WK_OK;
+}
+
+int wk_set_subjects(wk_ctx* c, const int32_t* feature_of_subject, int32_t n) {
+    if (!c) return WK_E_ARG;
+    if (n < 0 || (n > 0 && !feature_of_subject)) return fail(c, WK_E_ARG, "bad subject table arguments");
+    for (int32_t s = 0; s < n; ++s)
+        if (feature_of_subject[s] < 0 || feature_of_subject[s] > WK_MAX_FEATURE)
+            return fail(c, WK_E_RANGE, "subject %d: feature id outside [0, %d]", s, WK_MAX_FEATURE);
+    DeviceGuard guard(c->device);
+    int rc = upload(c, c->subj_feat, feature_of_subject, (size_t)n * sizeof(int32_t));
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_subjects = n;
+    c->rows_sig.clear();  // rows are rebuilt on the next classify call
     return WK_OK;
 }
 
@@ -486,7 +510,7 @@ int wk_counts_fetch(wk_ctx* c, uint64_t* keys, int64_t* counts, int64_t cap, int
 // ---- classify ----------------------------------------------------------------
 
 int wk_chunk_stage(wk_ctx* c, const int32_t* subj, const int32_t* qoff, int64_t n_reads, const int32_t* group,
-                   int subj_is_set) {
+                   int subj_flags) {
     if (!c) return WK_E_ARG;
     if (n_reads < 0 || !qoff) return fail(c, WK_E_ARG, "bad chunk arguments");
     const int64_t n_rec = qoff[n_reads];
@@ -502,7 +526,8 @@ int wk_chunk_stage(wk_ctx* c, const int32_t* subj, const int32_t* qoff, int64_t 
     c->n_reads = n_reads;
     c->n_records = n_rec;
     c->has_group = group != nullptr;
-    c->subj_is_set = subj_is_set != 0;
+    c->subj_is_set = (subj_flags & WK_SUBJ_IS_SET) != 0;
+    c->subj_indexed = (subj_flags & WK_SUBJ_INDEXED) != 0;
     c->chunk_valid = true;
     return WK_OK;
 }
@@ -543,6 +568,42 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
         }
         a.jobs[j] = d;
     }
+    if (c->subj_indexed) {
+        // (re)build the compact subject rows for this set of rank tables
+        if (c->n_subjects <= 0 && c->n_records > 0) return fail(c, WK_E_STATE, "chunk carries subject indices but no subject table is set (wk_set_subjects)");
+        std::vector<int> sig;
+        RowCols cols{};
+        for (int j = 0; j < n_jobs; ++j) {
+            if (jobs[j].mode != WK_MODE_RANK) continue;
+            int col = -1;
+            for (int q = 0; q < cols.n_cols; ++q)
+                if (sig[q] == jobs[j].rank_slot) col = q;
+            if (col < 0) {
+                col = cols.n_cols++;
+                sig.push_back(jobs[j].rank_slot);
+                cols.anc[col] = c->rank_tab[jobs[j].rank_slot].as<int32_t>();
+            }
+            a.jobs[j].col = col;
+        }
+        int w = 4;  // {feature, <= 3 rank columns}: the kernel's single-pass fast path
+        while (w < 1 + cols.n_cols) w <<= 1;
+        sig.push_back(-1);
+        sig.push_back(c->n_subjects);
+        if (sig != c->rows_sig || w != c->rows_w) {
+            HIP_TRY(c, c->subj_rows.reserve((size_t)std::max(c->n_subjects, 1) * w * sizeof(int32_t)));
+            if (c->n_subjects > 0) {
+                hipLaunchKernelGGL(subject_rows_kernel, dim3((c->n_subjects + 255) / 256), dim3(256), 0, c->stream,
+                                   c->subj_feat.as<int32_t>(), c->n_subjects, c->n_nodes, cols, w,
+                                   c->subj_rows.as<int32_t>());
+                HIP_TRY(c, hipGetLastError());
+            }
+            c->rows_sig = sig;
+            c->rows_w = w;
+        }
+        a.rows = c->subj_rows.as<int32_t>();
+        a.row_w = w;
+        a.n_subjects = c->n_subjects;
+    }
     if (out_assign) {
         HIP_TRY(c, c->assign_out.reserve((size_t)n_jobs * (size_t)(c->n_reads ? c->n_reads : 1) * sizeof(int32_t)));
         a.out_assign = c->assign_out.as<int32_t>();
@@ -553,7 +614,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
 
     if (c->n_reads > 0) {
         KernelTimer* kt = ktimer_begin(c, "classify");
-        if (c->use_lds && c->tiled) {
+        if (c->use_lds && c->tiled && !c->subj_indexed) {
             // persistent workgroups, each with its own tile buffers + LDS front cache
             const size_t lds = (size_t)(kTileWindow + 4 + kTileReads + 4) * sizeof(int32_t) + (size_t)c->lds_slots * 16;
             const int64_t n_tiles = (c->n_reads + kTileReads - 1) / kTileReads;
@@ -579,8 +640,8 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
 }
 
 int wk_classify_chunk(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, const int32_t* subj, const int32_t* qoff,
-                      int64_t n_reads, const int32_t* group, int subj_is_set, int32_t* out_assign) {
-    int rc = wk_chunk_stage(c, subj, qoff, n_reads, group, subj_is_set);
+                      int64_t n_reads, const int32_t* group, int subj_flags, int32_t* out_assign) {
+    int rc = wk_chunk_stage(c, subj, qoff, n_reads, group, subj_flags);
     if (rc) return rc;
     return wk_classify_staged(c, jobs, n_jobs, out_assign);
 }
@@ -676,6 +737,7 @@ int wk_ordinal_match(wk_ctx* c) {
     c->n_reads = c->o_reads;
     c->n_records = (int64_t)total;
     c->subj_is_set = false;  // several hits of a read may match the same gene
+    c->subj_indexed = false; // gene lists carry feature ids
     c->chunk_valid = true;
     return WK_OK;
 }
