@@ -226,6 +226,42 @@ int wk_chunk_download(wk_ctx* ctx, int32_t* subj, int64_t subj_cap,
 int wk_get_stats(wk_ctx* ctx, wk_stats* out);
 int wk_reset_stats(wk_ctx* ctx);
 
+/* ---- native SAM tokenizer (host, multi-threaded) ------------------------ */
+/* Replaces the per-line Python of align.parse_sam_file / parse_sam_file_ex and
+ * the packing loops of plain_mapper / ordinal_mapper (align.py:258-406,
+ * 550-583; ordinal.py:219-237) for SAM input.  Host-only: no device is needed.
+ * A tokenizer owns the subject dictionary (RNAME -> dense subject index in
+ * order of first appearance, the indices wk_set_subjects expects). */
+typedef struct wk_tok wk_tok;
+int wk_tok_create(int n_threads /* <= 0: all hardware threads */, wk_tok** out);
+void wk_tok_destroy(wk_tok* tok);
+const char* wk_tok_last_error(const wk_tok* tok);
+/* Subjects to exclude (align.py:443-469): names are blob[off[i]..off[i+1]). */
+int wk_tok_set_exclude(wk_tok* tok, const char* blob, const int32_t* off,
+                       int32_t n);
+/* Tokenize one block of SAM text.  `first_block`: the block starts the file
+ * (leading '@' header lines are skipped).  Unless `final_block`, parsing stops
+ * before the last QNAME run (it may continue in the next block); *consumed is
+ * the number of bytes used — feed the rest again, followed by more text.
+ * `extra`: also produce POS-1, reference end and aligned length per record
+ * ("ex" flavour; zero-length hits are dropped).  `want_names`: keep a
+ * descriptor of every read's QNAME.  Results are held by the tokenizer until
+ * the next call; sizes are returned in *n_reads / *n_records. */
+int wk_tok_sam(wk_tok* tok, const char* buf, int64_t len, int first_block,
+               int final_block, int extra, int want_names, int64_t* consumed,
+               int64_t* n_reads, int64_t* n_records);
+/* Copy the results out: subj[n_records] (subject indices), off[n_reads + 1]
+ * (CSR), beg/end/len[n_records] (extra only), qname[n_reads] =
+ * (byte offset in buf << 24) | (length << 2) | mate.  NULL skips an array. */
+int wk_tok_fetch(wk_tok* tok, int32_t* subj, int32_t* off, int32_t* beg,
+                 int32_t* end, uint32_t* len, uint64_t* qname);
+/* Dictionary growth: total subjects, subjects not yet reported, their bytes. */
+int wk_tok_subjects(wk_tok* tok, int32_t* n_total, int32_t* n_new,
+                    int64_t* new_bytes);
+/* Names of the not-yet-reported subjects: blob (may be NULL) and off[n_new+1];
+ * marks them reported. */
+int wk_tok_new_subjects(wk_tok* tok, char* blob, int32_t* off);
+
 /* ---- measurement ------------------------------------------------------- */
 /* HIP-event timing on the context's own stream (the stream every kernel of
  * this library is launched on).  wk_timer_begin/end bracket a region;

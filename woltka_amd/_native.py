@@ -38,7 +38,10 @@ SYMBOLS = (
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_chunk_download',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
-    'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms')
+    'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
+    'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
+    'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_fetch', 'wk_tok_subjects',
+    'wk_tok_new_subjects')
 
 
 class Job(C.Structure):
@@ -107,6 +110,15 @@ def load_library():
         'wk_profile_kernels': (C.c_int, [p, C.c_int]),
         'wk_last_kernel_ms': (C.c_int, [p, C.c_char_p,
                                         C.POINTER(C.c_double)]),
+        'wk_tok_create': (C.c_int, [C.c_int, C.POINTER(p)]),
+        'wk_tok_destroy': (None, [p]),
+        'wk_tok_last_error': (C.c_char_p, [p]),
+        'wk_tok_set_exclude': (C.c_int, [p, C.c_char_p, i32p, C.c_int32]),
+        'wk_tok_sam': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, i64p, i64p, i64p]),
+        'wk_tok_fetch': (C.c_int, [p, i32p, i32p, i32p, i32p, u32p, u64p]),
+        'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
+        'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -362,3 +374,99 @@ def counts_to_fractions(keys, vals):
         key = (j, g, f)
         res[key] = res.get(key, 0) + Fraction(n, kk)
     return res
+
+
+class Tokenizer:
+    """Native multi-threaded SAM tokenizer (host side; needs no GPU)."""
+
+    MATE_SUFFIX = ('', '/1', '/2')
+
+    def __init__(self, n_threads=0, exclude=None):
+        self._lib = load_library()
+        h = C.c_void_p()
+        if self._lib.wk_tok_create(int(n_threads), C.byref(h)) != OK:
+            raise RuntimeError('wk_tok_create failed')
+        self._h = h
+        if exclude:
+            names = [x.encode() for x in sorted(exclude)]
+            off = np.zeros(len(names) + 1, dtype=np.int32)
+            np.cumsum([len(x) for x in names], out=off[1:])
+            blob = b''.join(names)
+            self._check(self._lib.wk_tok_set_exclude(
+                self._h, blob, _ptr(off, C.c_int32), len(names)))
+
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self._lib.wk_tok_last_error(self._h).decode()
+        if rc == E_RANGE and 'mate bits' in msg:
+            raise IndexError(msg)       # align.py:339 indexes a 3-tuple with 3
+        raise ValueError(msg)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.wk_tok_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def parse(self, buf, first=False, final=False, extra=False,
+              want_names=False):
+        """Tokenize ``buf`` (bytes-like).  Returns a dict with ``consumed``,
+        ``subj``, ``off`` (+ ``beg``/``end``/``len`` with ``extra``,
+        ``qname`` descriptors with ``want_names``)."""
+        mv = memoryview(buf)
+        n = mv.nbytes
+        addr = C.c_void_p(np.frombuffer(mv, dtype=np.uint8).ctypes.data) \
+            if n else C.c_void_p(0)
+        if n == 0:
+            addr = C.cast(C.c_char_p(b''), C.c_void_p)
+        consumed, nrd, nrec = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.wk_tok_sam(
+            self._h, addr, n, int(first), int(final), int(extra),
+            int(want_names), C.byref(consumed), C.byref(nrd), C.byref(nrec)))
+        out = {'consumed': consumed.value,
+               'subj': np.empty(nrec.value, np.int32),
+               'off': np.empty(nrd.value + 1, np.int32)}
+        if extra:
+            out['beg'] = np.empty(nrec.value, np.int32)
+            out['end'] = np.empty(nrec.value, np.int32)
+            out['len'] = np.empty(nrec.value, np.uint32)
+        if want_names:
+            out['qname'] = np.empty(nrd.value, np.uint64)
+        self._check(self._lib.wk_tok_fetch(
+            self._h, _ptr(out['subj'], C.c_int32), _ptr(out['off'], C.c_int32),
+            _ptr(out.get('beg'), C.c_int32), _ptr(out.get('end'), C.c_int32),
+            _ptr(out.get('len'), C.c_uint32),
+            _ptr(out.get('qname'), C.c_uint64)))
+        return out
+
+    def new_subjects(self):
+        """Names of the subjects first seen since the last call, in index
+        order."""
+        tot, new, nbytes = C.c_int32(), C.c_int32(), C.c_int64()
+        self._check(self._lib.wk_tok_subjects(
+            self._h, C.byref(tot), C.byref(new), C.byref(nbytes)))
+        if new.value == 0:
+            return []
+        blob = C.create_string_buffer(max(1, nbytes.value))
+        off = np.empty(new.value + 1, dtype=np.int32)
+        self._check(self._lib.wk_tok_new_subjects(self._h, blob,
+                                                  _ptr(off, C.c_int32)))
+        raw = blob.raw
+        o = off.tolist()
+        return [raw[o[i]:o[i + 1]].decode() for i in range(new.value)]
+
+    @classmethod
+    def query_names(cls, buf, desc):
+        """Read ids from QNAME descriptors (QNAME + '', '/1' or '/2')."""
+        mv = buf if isinstance(buf, bytes) else bytes(buf)
+        out = []
+        for d in desc.tolist():
+            o, ln, m = d >> 24, (d >> 2) & 0x3FFFFF, d & 3
+            out.append(mv[o:o + ln].decode() + cls.MATE_SUFFIX[m])
+        return out

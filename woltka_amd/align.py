@@ -267,3 +267,113 @@ def pack_queries(subque, index, trim=None):
             flat.extend(map(intern, subs))
             qoff[i + 1] = len(flat)
     return np.array(flat, dtype=np.int32), qoff
+
+
+# --------------------------------------------------------------------------
+# native tokenizer driver (SAM): binary stream -> packed blocks
+# --------------------------------------------------------------------------
+
+def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
+                      want_names=False, head=b''):
+    """Feed a binary SAM stream through the native tokenizer
+    (``_native.Tokenizer``) block by block.
+
+    The tokenizer stops before the last QNAME run of a block (it may continue
+    in the next one); the unconsumed tail is carried over.  ``head`` is text
+    already read from the stream (format sniffing).  Yields ``(buffer, result)``
+    where ``result`` is the dict returned by ``Tokenizer.parse`` and ``buffer``
+    the bytes its QNAME descriptors point into.
+
+    A regular uncompressed file is memory-mapped and tokenised in place (no
+    copies); pipes and codec streams are read into one reusable buffer.
+    """
+    mm = _try_mmap(stream)
+    if mm is not None:
+        yield from _blocks_mmap(mm, len(head), tok, block_bytes, extra,
+                                want_names)
+        return
+    buf = bytearray(block_bytes + (1 << 16))
+    fill = len(head)
+    buf[:fill] = head
+    first = True
+    readinto = getattr(stream, 'readinto', None)
+    while True:
+        if len(buf) - fill < block_bytes // 2:
+            buf.extend(bytes(len(buf)))         # a run longer than the buffer
+        view = memoryview(buf)
+        if readinto is not None:
+            got = readinto(view[fill:]) or 0
+        else:
+            data = stream.read(len(buf) - fill)
+            got = len(data)
+            view[fill:fill + got] = data
+        final = got == 0
+        fill += got
+        if final and fill == 0:
+            return
+        res = tok.parse(view[:fill], first=first, final=final, extra=extra,
+                        want_names=want_names)
+        used = res['consumed']
+        if used == 0 and not final and res['off'].size == 1:
+            if fill == len(buf):
+                buf.extend(bytes(len(buf)))
+            continue                            # no complete run yet: read more
+        first = False
+        yield view[:fill], res
+        if final:
+            return
+        del view
+        rest = fill - used
+        buf[:rest] = buf[used:fill]
+        fill = rest
+
+
+def _try_mmap(stream):
+    """mmap of a regular file opened in binary mode, else None."""
+    import io
+    import mmap
+    import os
+    import stat
+    if not isinstance(stream, (io.BufferedReader, io.FileIO)):
+        return None
+    try:
+        fd = stream.fileno()
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_size == 0:
+            return None
+        return mmap.mmap(fd, 0, access=mmap.ACCESS_READ)
+    except (OSError, ValueError, io.UnsupportedOperation):
+        return None
+
+
+def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names):
+    """Tokenise a memory-mapped file in place.  ``start`` bytes were already
+    read from the stream for format sniffing; the map covers the whole file,
+    so they are simply parsed again from offset 0."""
+    del start
+    size = len(mm)
+    view = memoryview(mm)
+    pos, first = 0, True
+    span = block_bytes
+    try:
+        while pos < size:
+            end = min(size, pos + span)
+            final = end == size
+            res = tok.parse(view[pos:end], first=first, final=final,
+                            extra=extra, want_names=want_names)
+            used = res['consumed']
+            if used == 0 and not final and res['off'].size == 1:
+                span *= 2
+                continue
+            first = False
+            yield view[pos:end], res
+            if final:
+                break
+            pos += used
+            span = block_bytes
+    finally:
+        try:                # slices handed to the consumer may still be alive;
+            view.release()  # the map is then closed when they are collected
+            mm.close()
+        except BufferError:
+            pass

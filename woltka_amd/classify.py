@@ -21,6 +21,35 @@ from .file import openzip, write_readmap
 from .hierarchy import FeatureIndex, flatten_hierarchy
 from .ordinal import pack_hits
 
+def _prefetch(gen, depth=2):
+    """Run generator ``gen`` in a helper thread, ``depth`` items ahead: the
+    native tokenizer (which releases the GIL) parses block i+1 while block i is
+    staged and classified on the GPU."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def work():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(done)
+        except BaseException as e:      # re-raised in the consumer
+            q.put(e)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    while True:
+        item = q.get()
+        if item is done:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+    th.join()
+
+
 _NO_TREE_ROOT = '\x00root'      # stand-in root when no hierarchy is given
 MAX_GROUPS = 1 << nat.KEY_GROUP_BITS
 
@@ -91,9 +120,69 @@ class Engine:
         # -> feature ids, mirrored on the device by wk_set_subjects
         self.subjects = FeatureIndex()
         self.subj_feature = []
+        # native SAM tokenizer (created on first use) and the translation of
+        # its subject ids into `self.subjects` indices / genome indices
+        self.tok = None
+        self._tok_map = np.empty(0, dtype=np.int32)
+        self._tok_identity = True
+        self._tok_genome = np.empty(0, dtype=np.int32)
 
     def close(self):
+        if self.tok is not None:
+            self.tok.close()
         self.ctx.close()
+
+    # ------------------------------------------------------------------
+    def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
+                      want_names, trimsub=None):
+        """SAM text -> packed chunks through the native tokenizer.  Yields
+        (reads or None, packed) where packed = (subj, qoff) of subject indices,
+        or for coord-match (genome, beg, end, length, hoff)."""
+        from .align import native_sam_blocks
+        if self.tok is None:
+            self.tok = nat.Tokenizer(0, exclude)
+        tok = self.tok
+
+        def blocks():
+            for buf, res in native_sam_blocks(stream, tok, block_bytes,
+                                              extra=ordinal,
+                                              want_names=want_names,
+                                              head=head):
+                # the dictionary growth belongs to this block: fetch it before
+                # the tokenizer moves on
+                yield buf, res, tok.new_subjects()
+
+        for buf, res, fresh in _prefetch(blocks()):
+            if fresh:
+                if ordinal:
+                    gidx = self.genes.genome_index.get
+                    self._tok_genome = np.concatenate([
+                        self._tok_genome,
+                        np.fromiter((gidx(x, -1) for x in fresh), np.int32,
+                                    len(fresh))])
+                else:
+                    base = self._tok_map.size
+                    intern = self.subjects.intern
+                    if trimsub:
+                        fresh = [x.rsplit(trimsub, 1)[0] for x in fresh]
+                    ids = np.fromiter((intern(x) for x in fresh), np.int32,
+                                      len(fresh))
+                    if self._tok_identity and not np.array_equal(
+                            ids, np.arange(base, base + ids.size)):
+                        self._tok_identity = False
+                    self._tok_map = np.concatenate([self._tok_map, ids])
+            reads = nat.Tokenizer.query_names(buf, res['qname']) \
+                if want_names else None
+            del buf
+            if ordinal:
+                packed = (self._tok_genome[res['subj']], res['beg'],
+                          res['end'], res['len'], res['off'])
+            else:
+                subj = res['subj'] if self._tok_identity \
+                    else self._tok_map[res['subj']]
+                packed = (subj, res['off'])
+            if res['off'].size > 1:
+                yield reads, packed
 
     # ------------------------------------------------------------------
     def set_genes(self, table, prefix):
@@ -161,10 +250,12 @@ class Engine:
         return out
 
     def run_chunk(self, data, reads, subque, sample_of, strata_of, trimsub,
-                  rank2dir, outzip, namedic, ordinal):
+                  rank2dir, outzip, namedic, ordinal, packed=None):
         """Classify one chunk at every rank; returns the number of queries the
-        reference would report for it (workflow.py:305)."""
-        n = len(reads)
+        reference would report for it (workflow.py:305).  ``packed`` carries
+        arrays produced by the native tokenizer instead of ``subque`` / staged
+        hits."""
+        n = len(reads) if packed is None else packed[-1].size - 1
         if len(self.groups) + n + 1 >= MAX_GROUPS // 2:
             self.collect(data)
         group = self._group_array(n, sample_of, strata_of)
@@ -177,7 +268,8 @@ class Engine:
                 data[rank].setdefault(s, {})
         want = rank2dir is not None
         if ordinal:
-            genome, beg, end, length, hoff = self._hits
+            genome, beg, end, length, hoff = \
+                self._hits if packed is None else packed
             self.ctx.ordinal_stage(genome, beg, end, length, hoff, self._th,
                                    group=group)
             self.ctx.ordinal_match()
@@ -191,16 +283,22 @@ class Engine:
             if want:
                 subj, qoff = self.ctx.chunk_download()
         else:
-            subj, qoff = pack_queries(subque, self.subjects, trimsub)
+            if packed is None:
+                subj, qoff = pack_queries(subque, self.subjects, trimsub)
+            else:
+                subj, qoff = packed
             known = len(self.subj_feature)
             if len(self.subjects) > known:
                 intern = self.index.intern
                 self.subj_feature.extend(
                     intern(x) for x in self.subjects.names[known:])
                 self.ctx.set_subjects(self.subj_feature)
+            # the Python parsers hand over sets; the native tokenizer keeps
+            # every record, and trimming can merge subjects
             assign = self.ctx.classify_chunk(
                 self.jobs, subj, qoff, group=group,
-                subj_is_set=not trimsub, want_assign=want, indexed=True)
+                subj_is_set=(packed is None and not trimsub),
+                want_assign=want, indexed=True)
             if want:    # read maps work on feature ids
                 subj = np.asarray(self.subj_feature, dtype=np.int32)[subj]
             nq = n

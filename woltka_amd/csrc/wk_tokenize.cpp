@@ -1,0 +1,534 @@
+// wk_tokenize.cpp — native multi-threaded SAM tokenizer / packer (host side).
+//
+// Replaces the per-line Python of the reference's SAM parsers + plain_mapper /
+// ordinal_mapper packing (woltka/align.py:258-406, 550-583; ordinal.py:219-237)
+// for the benchmarked input format.  Same semantics:
+//   * leading '@' lines are the header; records with RNAME '*' are skipped
+//     before the QNAME-change test (align.py:295-300, 318-319);
+//   * a run of consecutive mapped records with the same QNAME yields up to
+//     three reads — unpaired, /1, /2 — chosen by (FLAG >> 6) & 3
+//     (align.py:322-333); both mate bits set is an error;
+//   * with an exclusion set, a run is dropped entirely once one of its records
+//     names an excluded subject (align.py:443-469);
+//   * "extra" flavour: POS-1, CIGAR -> (aligned length, reference span)
+//     (align.py:376-398, 572-583); zero-length hits are dropped
+//     (ordinal.py:231).
+// Subjects are interned into dense indices in order of first appearance (the
+// indices wk_set_subjects expects).  A block of text is cut into byte ranges at
+// run boundaries, one range per thread; ranges are tokenised independently and
+// concatenated, so the output does not depend on the thread count.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/woltka_hip.h"
+
+namespace {
+
+inline uint64_t hash_bytes(const char* p, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull ^ (n * 0x9E3779B97F4A7C15ull);
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        h = (h ^ v) * 0x100000001b3ull;
+        h ^= h >> 29;
+        p += 8;
+        n -= 8;
+    }
+    uint64_t v = 0;
+    memcpy(&v, p, n);
+    h = (h ^ v) * 0x100000001b3ull;
+    return h ^ (h >> 32);
+}
+
+// string -> id table; names live in an arena (stable across calls)
+struct NameTable {
+    std::vector<int32_t> slot;  // id or -1
+    std::vector<uint64_t> hash;
+    std::vector<uint32_t> off, len;  // per id
+    std::string arena;
+    size_t mask = 0;
+    NameTable() { rehash(1 << 12); }
+    void rehash(size_t n) {
+        slot.assign(n, -1);
+        mask = n - 1;
+        for (int32_t id = 0; id < (int32_t)off.size(); ++id) {
+            size_t h = hash[id] & mask;
+            while (slot[h] >= 0) h = (h + 1) & mask;
+            slot[h] = id;
+        }
+    }
+    int32_t find(const char* p, size_t n, uint64_t hv) const {
+        size_t h = hv & mask;
+        for (;;) {
+            const int32_t id = slot[h];
+            if (id < 0) return -1;
+            if (hash[id] == hv && len[id] == n && memcmp(arena.data() + off[id], p, n) == 0) return id;
+            h = (h + 1) & mask;
+        }
+    }
+    int32_t add(const char* p, size_t n, uint64_t hv) {
+        if ((off.size() + 1) * 2 > slot.size()) rehash(slot.size() * 2);
+        const int32_t id = (int32_t)off.size();
+        off.push_back((uint32_t)arena.size());
+        len.push_back((uint32_t)n);
+        hash.push_back(hv);
+        arena.append(p, n);
+        size_t h = hv & mask;
+        while (slot[h] >= 0) h = (h + 1) & mask;
+        slot[h] = id;
+        return id;
+    }
+    int32_t size() const { return (int32_t)off.size(); }
+};
+
+struct Record {
+    int32_t subj;  // global id >= 0, or -(1 + local new-name id)
+    int32_t beg, end;
+    uint32_t len;
+};
+
+struct Local {
+    std::vector<Record> rec;     // records of emitted reads, read-major
+    std::vector<int32_t> rend;   // per read: end offset into rec
+    std::vector<uint64_t> qname; // per read: (offset << 24) | (len << 2) | mate
+    NameTable fresh;             // names not yet in the global table
+    int error = 0;               // 1 = both mate bits, 2 = malformed line
+    size_t error_at = 0;
+};
+
+struct Line {
+    const char* q;
+    size_t qn;
+    const char* r;
+    size_t rn;
+    int flag;
+    const char* pos;
+    const char* cigar;
+    size_t cn;
+    bool ok;
+};
+
+// split the first 3 (or 6) tab-separated fields of [p, e)
+inline Line parse_line(const char* p, const char* e, bool extra) {
+    Line L{};
+    const char* t1 = (const char*)memchr(p, '\t', e - p);
+    if (!t1) return L;
+    const char* t2 = (const char*)memchr(t1 + 1, '\t', e - t1 - 1);
+    if (!t2) return L;
+    const char* t3 = (const char*)memchr(t2 + 1, '\t', e - t2 - 1);
+    if (!t3) return L;
+    L.q = p;
+    L.qn = t1 - p;
+    int f = 0;
+    for (const char* c = t1 + 1; c < t2; ++c) {
+        if (*c < '0' || *c > '9') return L;
+        f = f * 10 + (*c - '0');
+    }
+    L.flag = f;
+    L.r = t2 + 1;
+    L.rn = t3 - t2 - 1;
+    if (extra) {
+        const char* t4 = (const char*)memchr(t3 + 1, '\t', e - t3 - 1);
+        if (!t4) return L;
+        const char* t5 = (const char*)memchr(t4 + 1, '\t', e - t4 - 1);
+        if (!t5) return L;
+        const char* t6 = (const char*)memchr(t5 + 1, '\t', e - t5 - 1);
+        if (!t6) return L;
+        L.pos = t3 + 1;
+        L.cigar = t5 + 1;
+        L.cn = t6 - t5 - 1;
+    }
+    L.ok = true;
+    return L;
+}
+
+inline bool is_unmapped(const Line& L) { return L.rn == 1 && L.r[0] == '*'; }
+
+// align.cigar_to_lens (align.py:550-583)
+inline void cigar_lens(const char* c, size_t n, uint32_t& aligned, uint32_t& span) {
+    uint64_t a = 0, x = 0, num = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const char ch = c[i];
+        if (ch >= '0' && ch <= '9') {
+            num = num * 10 + (ch - '0');
+        } else {
+            if (ch == 'M' || ch == '=' || ch == 'X')
+                a += num;
+            else if (ch == 'D' || ch == 'N')
+                x += num;
+            num = 0;
+        }
+    }
+    aligned = (uint32_t)a;
+    span = (uint32_t)(a + x);
+}
+
+inline const char* next_line(const char* p, const char* e) {
+    const char* nl = (const char*)memchr(p, '\n', e - p);
+    return nl ? nl + 1 : e;
+}
+
+}  // namespace
+
+struct wk_tok {
+    int n_threads = 1;
+    NameTable names;     // global subject dictionary (sidx = id)
+    NameTable exclude;
+    std::string err;
+    // outputs of the last call
+    std::vector<int32_t> subj, off, beg, end;
+    std::vector<uint32_t> len;
+    std::vector<uint64_t> qname;
+    int32_t reported = 0;  // subjects already handed to the caller
+    bool in_header = false; // still inside the leading '@' lines of a file
+};
+
+namespace {
+
+void tokenize_range(const wk_tok* T, const char* base, const char* b, const char* e, bool extra, bool want_names,
+                    Local& out) {
+    const bool filt = T->exclude.size() > 0;
+    // current run state
+    const char* cur = nullptr;
+    size_t cur_n = 0;
+    bool keep = true;
+    std::vector<Record> pool[3];
+    auto flush = [&]() {
+        if (!cur || !keep) {
+            for (auto& p : pool) p.clear();
+            return;
+        }
+        for (int m = 0; m < 3; ++m) {
+            if (pool[m].empty()) continue;
+            out.rec.insert(out.rec.end(), pool[m].begin(), pool[m].end());
+            out.rend.push_back((int32_t)out.rec.size());
+            if (want_names) out.qname.push_back(((uint64_t)(cur - base) << 24) | ((uint64_t)cur_n << 2) | (uint64_t)m);
+            pool[m].clear();
+        }
+    };
+    for (const char* p = b; p < e;) {
+        const char* nl = (const char*)memchr(p, '\n', e - p);
+        const char* le = nl ? nl : e;
+        const Line L = parse_line(p, le, extra);
+        const char* line = p;
+        p = nl ? nl + 1 : e;
+        if (!L.ok) {
+            if (le == line) continue;  // empty line
+            out.error = 2;
+            out.error_at = line - base;
+            return;
+        }
+        if (is_unmapped(L)) continue;
+        if (!(cur && L.qn == cur_n && memcmp(L.q, cur, cur_n) == 0)) {
+            flush();
+            cur = L.q;
+            cur_n = L.qn;
+            keep = true;
+        } else if (!keep) {
+            continue;
+        }
+        const uint64_t hv = hash_bytes(L.r, L.rn);
+        if (filt && T->exclude.find(L.r, L.rn, hv) >= 0) {
+            keep = false;
+            continue;
+        }
+        const int mate = (L.flag >> 6) & 3;
+        if (mate == 3) {
+            out.error = 1;
+            out.error_at = line - base;
+            return;
+        }
+        Record rc{};
+        int32_t id = T->names.find(L.r, L.rn, hv);
+        if (id < 0) {
+            int32_t f = out.fresh.find(L.r, L.rn, hv);
+            if (f < 0) f = out.fresh.add(L.r, L.rn, hv);
+            id = -(1 + f);
+        }
+        rc.subj = id;
+        if (extra) {
+            long pos = 0;
+            for (const char* c = L.pos; *c >= '0' && *c <= '9'; ++c) pos = pos * 10 + (*c - '0');
+            uint32_t aligned, span;
+            cigar_lens(L.cigar, L.cn, aligned, span);
+            if (aligned == 0) continue;  // ordinal.py:231
+            rc.beg = (int32_t)(pos - 1);
+            rc.end = (int32_t)(pos - 1 + span);
+            rc.len = aligned;
+        }
+        pool[mate].push_back(rc);
+    }
+    flush();
+}
+
+// first mapped line at or after p whose QNAME differs from the previous mapped line's
+const char* run_boundary(const char* base, const char* p, const char* e) {
+    // previous mapped line before p
+    const char* prev_q = nullptr;
+    size_t prev_n = 0;
+    const char* s = p;
+    while (s > base) {
+        const char* ls = s - 1;  // points at '\n' ending the previous line
+        const char* q = ls;
+        while (q > base && q[-1] != '\n') --q;
+        Line L = parse_line(q, ls, false);
+        s = q;
+        if (L.ok && !is_unmapped(L)) {
+            prev_q = L.q;
+            prev_n = L.qn;
+            break;
+        }
+    }
+    if (!prev_q) return p;
+    while (p < e) {
+        const char* nl = (const char*)memchr(p, '\n', e - p);
+        const char* le = nl ? nl : e;
+        Line L = parse_line(p, le, false);
+        if (L.ok && !is_unmapped(L)) {
+            if (!(L.qn == prev_n && memcmp(L.q, prev_q, prev_n) == 0)) return p;
+        }
+        p = nl ? nl + 1 : e;
+    }
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wk_tok_create(int n_threads, wk_tok** out) {
+    if (!out) return WK_E_ARG;
+    wk_tok* t = new (std::nothrow) wk_tok();
+    if (!t) return WK_E_HIP;
+    if (n_threads <= 0) {
+        n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads <= 0) n_threads = 1;
+    }
+    t->n_threads = std::min(n_threads, 64);  // beyond this, thread start-up outweighs the work per block
+    *out = t;
+    return WK_OK;
+}
+
+void wk_tok_destroy(wk_tok* t) { delete t; }
+
+const char* wk_tok_last_error(const wk_tok* t) { return t ? t->err.c_str() : "null tokenizer"; }
+
+int wk_tok_set_exclude(wk_tok* t, const char* blob, const int32_t* off, int32_t n) {
+    if (!t || n < 0 || (n > 0 && (!blob || !off))) return WK_E_ARG;
+    t->exclude = NameTable();
+    for (int32_t i = 0; i < n; ++i) {
+        const char* p = blob + off[i];
+        const size_t len = (size_t)(off[i + 1] - off[i]);
+        const uint64_t hv = hash_bytes(p, len);
+        if (t->exclude.find(p, len, hv) < 0) t->exclude.add(p, len, hv);
+    }
+    return WK_OK;
+}
+
+int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int final_block, int extra, int want_names,
+               int64_t* consumed, int64_t* n_reads, int64_t* n_records) {
+    if (!t || !buf || len < 0 || !consumed || !n_reads || !n_records) return WK_E_ARG;
+    const char* b = buf;
+    const char* e = buf + len;
+    // header: leading '@' lines (align.py:295-300); it may span several blocks
+    if (first_block) t->in_header = true;
+    while (t->in_header && b < e) {
+        if (*b != '@') {
+            t->in_header = false;
+            break;
+        }
+        const char* nl = (const char*)memchr(b, '\n', e - b);
+        if (!nl && !final_block) break;  // partial header line: wait for more text
+        b = nl ? nl + 1 : e;
+    }
+    // only whole lines; unless final, stop before the last run (it may continue)
+    const char* stop = e;
+    if (!final_block) {
+        const char* last_nl = nullptr;
+        for (const char* p = e; p > b; --p)
+            if (p[-1] == '\n') {
+                last_nl = p;
+                break;
+            }
+        if (!last_nl || t->in_header) {
+            *consumed = b - buf;
+            *n_reads = *n_records = 0;
+            t->subj.clear();
+            t->off.assign(1, 0);
+            t->qname.clear();
+            t->beg.clear();
+            t->end.clear();
+            t->len.clear();
+            return WK_OK;
+        }
+        stop = last_nl;
+        // start of the last run: walk back over lines while the QNAME stays the same
+        const char* run_start = nullptr;
+        const char* q_last = nullptr;
+        size_t qn_last = 0;
+        const char* s = stop;
+        while (s > b) {
+            const char* ls = s - 1;
+            const char* q = ls;
+            while (q > b && q[-1] != '\n') --q;
+            Line L = parse_line(q, ls, false);
+            if (L.ok && !is_unmapped(L)) {
+                if (!q_last) {
+                    q_last = L.q;
+                    qn_last = L.qn;
+                    run_start = q;
+                } else if (L.qn == qn_last && memcmp(L.q, q_last, qn_last) == 0) {
+                    run_start = q;
+                } else {
+                    break;
+                }
+            }
+            s = q;
+        }
+        if (run_start) stop = run_start;
+    }
+    const int64_t span = stop - b;
+    int T = t->n_threads;
+    if (span < (int64_t)T * (1 << 16)) T = (int)std::max<int64_t>(1, span >> 16);
+    std::vector<const char*> cut(T + 1);
+    cut[0] = b;
+    cut[T] = stop;
+    for (int i = 1; i < T; ++i) {
+        const char* p = b + span * i / T;
+        if (p < cut[i - 1]) p = cut[i - 1];
+        p = (p > b) ? next_line(p - 1, stop) : b;  // to a line start
+        cut[i] = run_boundary(b, p, stop);
+    }
+    for (int i = 1; i <= T; ++i)
+        if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1];
+    std::vector<Local> loc(T);
+    if (T == 1) {
+        tokenize_range(t, buf, cut[0], cut[1], extra != 0, want_names != 0, loc[0]);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve(T);
+        for (int i = 0; i < T; ++i)
+            th.emplace_back([&, i] { tokenize_range(t, buf, cut[i], cut[i + 1], extra != 0, want_names != 0, loc[i]); });
+        for (auto& x : th) x.join();
+    }
+    for (int i = 0; i < T; ++i)
+        if (loc[i].error) {
+            char msg[160];
+            snprintf(msg, sizeof msg, loc[i].error == 1 ? "SAM flag with both mate bits set at byte %zu" : "malformed SAM line at byte %zu",
+                     loc[i].error_at);
+            t->err = msg;
+            return loc[i].error == 1 ? WK_E_RANGE : WK_E_ARG;
+        }
+    // merge fresh names in thread order (= order of first appearance in the text)
+    std::vector<std::vector<int32_t>> remap(T);
+    for (int i = 0; i < T; ++i) {
+        const NameTable& f = loc[i].fresh;
+        remap[i].resize(f.size());
+        for (int32_t k = 0; k < f.size(); ++k) {
+            const char* p = f.arena.data() + f.off[k];
+            int32_t id = t->names.find(p, f.len[k], f.hash[k]);
+            if (id < 0) id = t->names.add(p, f.len[k], f.hash[k]);
+            remap[i][k] = id;
+        }
+    }
+    // first appearance order must not depend on the thread count: names that were
+    // fresh in several ranges were added by the earliest range, which is also
+    // where they first appear in the text.  Within one range `fresh` ids follow
+    // the text order.  (A name fresh in range i is absent from all earlier ranges
+    // only if those did not see it at all.)
+    int64_t tot_reads = 0, tot_rec = 0;
+    for (int i = 0; i < T; ++i) {
+        tot_reads += (int64_t)loc[i].rend.size();
+        tot_rec += (int64_t)loc[i].rec.size();
+    }
+    if (tot_rec >= (1ll << 31)) {
+        t->err = "more than 2^31 records in one block; pass smaller blocks";
+        return WK_E_RANGE;
+    }
+    t->subj.resize(tot_rec);
+    t->off.resize(tot_reads + 1);
+    t->qname.resize(want_names ? tot_reads : 0);
+    if (extra) {
+        t->beg.resize(tot_rec);
+        t->end.resize(tot_rec);
+        t->len.resize(tot_rec);
+    } else {
+        t->beg.clear();
+        t->end.clear();
+        t->len.clear();
+    }
+    t->off[0] = 0;
+    std::vector<int64_t> rbase(T + 1, 0), qbase(T + 1, 0);
+    for (int i = 0; i < T; ++i) {
+        rbase[i + 1] = rbase[i] + (int64_t)loc[i].rec.size();
+        qbase[i + 1] = qbase[i] + (int64_t)loc[i].rend.size();
+    }
+    auto copy_out = [&](int i) {
+        const Local& L = loc[i];
+        const int64_t rb = rbase[i], qb = qbase[i];
+        for (size_t k = 0; k < L.rec.size(); ++k) {
+            const Record& rc = L.rec[k];
+            t->subj[rb + k] = rc.subj >= 0 ? rc.subj : remap[i][-(rc.subj + 1)];
+            if (extra) {
+                t->beg[rb + k] = rc.beg;
+                t->end[rb + k] = rc.end;
+                t->len[rb + k] = rc.len;
+            }
+        }
+        for (size_t k = 0; k < L.rend.size(); ++k) t->off[qb + k + 1] = (int32_t)(rb + L.rend[k]);
+        if (want_names)
+            for (size_t k = 0; k < L.qname.size(); ++k) t->qname[qb + k] = L.qname[k];
+    };
+    if (T == 1) {
+        copy_out(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < T; ++i) th.emplace_back(copy_out, i);
+        for (auto& x : th) x.join();
+    }
+    *consumed = stop - buf;
+    *n_reads = tot_reads;
+    *n_records = tot_rec;
+    return WK_OK;
+}
+
+int wk_tok_fetch(wk_tok* t, int32_t* subj, int32_t* off, int32_t* beg, int32_t* end, uint32_t* len, uint64_t* qname) {
+    if (!t) return WK_E_ARG;
+    if (subj && !t->subj.empty()) memcpy(subj, t->subj.data(), t->subj.size() * 4);
+    if (off && !t->off.empty()) memcpy(off, t->off.data(), t->off.size() * 4);
+    if (beg && !t->beg.empty()) memcpy(beg, t->beg.data(), t->beg.size() * 4);
+    if (end && !t->end.empty()) memcpy(end, t->end.data(), t->end.size() * 4);
+    if (len && !t->len.empty()) memcpy(len, t->len.data(), t->len.size() * 4);
+    if (qname && !t->qname.empty()) memcpy(qname, t->qname.data(), t->qname.size() * 8);
+    return WK_OK;
+}
+
+int wk_tok_subjects(wk_tok* t, int32_t* n_total, int32_t* n_new, int64_t* new_bytes) {
+    if (!t || !n_total || !n_new || !new_bytes) return WK_E_ARG;
+    *n_total = t->names.size();
+    *n_new = t->names.size() - t->reported;
+    int64_t bytes = 0;
+    for (int32_t i = t->reported; i < t->names.size(); ++i) bytes += t->names.len[i];
+    *new_bytes = bytes;
+    return WK_OK;
+}
+
+int wk_tok_new_subjects(wk_tok* t, char* blob, int32_t* off) {
+    if (!t || !off) return WK_E_ARG;
+    int64_t w = 0;
+    int32_t k = 0;
+    off[0] = 0;
+    for (int32_t i = t->reported; i < t->names.size(); ++i, ++k) {
+        if (blob) memcpy(blob + w, t->names.arena.data() + t->names.off[i], t->names.len[i]);
+        w += t->names.len[i];
+        off[k + 1] = (int32_t)w;
+    }
+    t->reported = t->names.size();
+    return WK_OK;
+}
+
+}  // extern "C"

@@ -45,6 +45,20 @@ def readzip(fp, zippers=None):
     return ZIP_MODULES[kind].open(fp, 'rt')
 
 
+def readzip_bytes(fp, zippers=None):
+    """Like ``readzip`` but a *binary* stream (input of the native tokenizer)."""
+    kind = ZIP_BY_EXT.get(splitext(fp)[1])
+    if kind is None:
+        return open(fp, 'rb')
+    if zippers is None:
+        return ZIP_MODULES[kind].open(fp, 'rb')
+    if kind not in zippers:
+        zippers[kind] = bool(which(kind))
+    if zippers[kind]:
+        return Popen([kind, '-cdfq', fp], stdout=PIPE).stdout
+    return ZIP_MODULES[kind].open(fp, 'rb')
+
+
 def file2stem(fname, ext=None):
     """Filename minus extension: the given ``ext`` (must match), or the last
     extension after dropping a compression suffix."""

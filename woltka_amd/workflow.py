@@ -12,17 +12,19 @@ folded into the same dict.
 
 There is no CPU fallback: ``classify()`` needs ``libwoltka_hip.so`` and a GPU.
 """
+import io
 from functools import partial
+from itertools import chain
 from os import makedirs
 from os.path import basename, isdir, isfile, join
 
 import click
 
-from .align import plain_mapper
+from .align import infer_align_format, plain_mapper
 from .classify import Engine
 from .file import (id2file_from_dir, id2file_from_map, openzip, path2stem,
-                   read_ids, read_map_1st, read_map_uniq, readzip, stem2rank,
-                   write_readmap)
+                   read_ids, read_map_1st, read_map_uniq, readzip, readzip_bytes,
+                   stem2rank, write_readmap)
 from .ordinal import load_gene_coords
 from .shard import classify_sharded, env_rank
 from .table import allkeys, prep_table, write_table
@@ -30,6 +32,7 @@ from .tree import (fill_root, read_columns, read_lineage, read_names,
                    read_newick, read_nodes)
 
 DEVICE_CHUNK = 2 ** 20      # queries per device chunk unless --chunk is given
+NATIVE_BLOCK = 1 << 27      # bytes of SAM text per native tokenizer call
 
 
 class OrdinalMapper:
@@ -200,22 +203,47 @@ def classify(mapper:  object,
     n = chunk or DEVICE_CHUNK
     csample, strata = False, None
     try:
+        # SAM input goes through the native multi-threaded tokenizer; other
+        # formats (and the SAM "extra + exclude" flavour, whose reference
+        # parser has a quirk reproduced only by the Python one) use the Python
+        # parsers.  Query names are materialised only when something needs them.
+        native_ok = (mapper is plain_mapper or ordinal) and \
+            not (ordinal and exclude) and not (ordinal and trimsub)
+        want_names = bool(demux or stratmap or rank2dir is not None)
         for fp in sorted(files):
             if fp == '-':
-                fileobj = click.open_file(fp).__iter__()
+                stream = click.get_binary_stream('stdin')
                 click.echo('Parsing alignment from stdin ', nl=False)
             else:
-                fileobj = readzip(fp, zippers)
+                stream = readzip_bytes(fp, zippers)
                 click.echo(f'Parsing alignment file {basename(fp)} ', nl=False)
-            with fileobj as fh:
+            with stream:
                 nqry, nstep = 0, -1
-                if ordinal:
-                    chunks = engine.ordinal_chunks(fh, fmt, exclude, n,
-                                                   mapper.th)
+                fmt_, head = fmt, b''
+                if not fmt_:
+                    head = stream.readline()
+                    fmt_ = infer_align_format(iter(
+                        [head.decode()] if head else []))[0]
+                native = native_ok and fmt_ == 'sam'
+                if native:
+                    chunks = engine.native_chunks(
+                        stream, head, exclude, NATIVE_BLOCK, ordinal,
+                        want_names, trimsub)
                 else:
-                    chunks = mapper(fh, fmt=fmt, excl=exclude, n=n)
-                for chunk_ in chunks:
+                    text = io.TextIOWrapper(stream, encoding='utf-8')
+                    fh = chain([head.decode()], text) if head else text
                     if ordinal:
+                        chunks = engine.ordinal_chunks(fh, fmt_, exclude, n,
+                                                       mapper.th)
+                    else:
+                        chunks = mapper(fh, fmt=fmt_, excl=exclude, n=n)
+                for chunk_ in chunks:
+                    packed = None
+                    if native:
+                        qryque, packed = chunk_
+                        subque = None
+                        engine._th = mapper.th if ordinal else None
+                    elif ordinal:
                         qryque = chunk_
                         subque = None
                     else:
@@ -234,8 +262,9 @@ def classify(mapper:  object,
                             sample_of, reads, stratmap, zippers, csample,
                             strata)
                     nq = engine.run_chunk(
-                        data, reads, subque, sample_of, strata_of, trimsub,
-                        rank2dir, outzip, namedic, ordinal)
+                        data, reads, subque, sample_of, strata_of,
+                        None if native else trimsub,
+                        rank2dir, outzip, namedic, ordinal, packed=packed)
                     nqry += nq
                     istep = nqry // 1000000 - nstep
                     if istep:
