@@ -71,6 +71,8 @@ extern "C" {
 #define WK_F_ABOVE 2u      /* --above      (classify.py:119-123) */
 #define WK_F_SUBOK 4u      /* --subok      (classify.py:75)      */
 #define WK_F_UNASSIGNED 8u /* --unassigned (workflow.py:1038-1039) */
+#define WK_F_SIZED 16u     /* --sizes: contributions go to the (feature, subject)
+                              log instead of the count table (classify.py:174-213) */
 
 /* subj_flags of wk_chunk_stage / wk_classify_chunk */
 #define WK_SUBJ_IS_SET 1
@@ -163,6 +165,16 @@ int wk_counts_clear(wk_ctx* ctx);
  * to the required size if cap is too small. Order is unspecified. */
 int wk_counts_fetch(wk_ctx* ctx, uint64_t* keys, int64_t* counts, int64_t cap,
                     int64_t* n);
+
+/* ---- contribution log of size-normalised jobs --------------------------- */
+/* A WK_F_SIZED job does not count: every contribution is appended to a log as
+ * 4 x int32 {feature, subject feature id, job << 16 | divisor, group}; its
+ * value is sizes[subject] / divisor (classify.counter_size, classify.py:
+ * 174-213), which the host evaluates.  wk_log_fetch copies the entries logged
+ * so far and empties the log; WK_E_CAPACITY (with *n = entries needed) means
+ * the log overflowed — reserve more and re-run the chunk. */
+int wk_log_reserve(wk_ctx* ctx, int64_t n_entries);
+int wk_log_fetch(wk_ctx* ctx, int32_t* out, int64_t cap, int64_t* n);
 
 /* ---- per-chunk work ---------------------------------------------------- */
 /* Stage one packed chunk of plain-mapper output in HBM (replaces the

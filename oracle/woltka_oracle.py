@@ -188,6 +188,32 @@ def count_float(taxque):
     return res
 
 
+def count_sized(subque, taxque, sizes, qryque=None, strata=None):
+    """classify.counter_size / counter_size_strat (woltka/classify.py:174-213,
+    252-297) in binary64: a unique assignment adds the mean of its subjects'
+    sizes; a list adds ``sizes[sub] * (1 / #non-None)`` per (taxon, subject)
+    pair.  ``sizes`` holds reciprocals (workflow.py:633).  KeyError when a
+    counted read has a subject without size."""
+    res = defaultdict(int)
+    for i, (subs, taxa) in enumerate(zip(subque, taxque)):
+        if not taxa:
+            continue
+        if strata is not None:
+            if qryque[i] not in strata:
+                continue
+            wrap = (lambda t, s=strata[qryque[i]]: (s, t))
+        else:
+            wrap = (lambda t: t)
+        if isinstance(taxa, str):
+            res[wrap(taxa)] += sum(sizes[x] for x in subs) / len(subs)
+        else:
+            k = 1 / len([t for t in taxa if t])
+            for taxon, sub in zip(taxa, subs):
+                if taxon:
+                    res[wrap(taxon)] += sizes[sub] * k
+    return dict(res)
+
+
 def round_half_snap(value, digits=None):
     """One cell of util.round_dict (woltka/util.py:323-354): values within
     1e-7 of a half are snapped onto it before Python's banker's ``round``."""

@@ -77,7 +77,8 @@ def random_tree(rng, n):
 
 def gen_classify(seed=2024):
     from woltka.classify import (assign_none, assign_free, assign_rank,
-                                 counter, counter_strat)
+                                 counter, counter_strat, counter_size,
+                                 counter_size_strat)
     from woltka.util import round_dict
     rng = random.Random(seed)
     cases = []
@@ -108,6 +109,8 @@ def gen_classify(seed=2024):
             qryque.append(f'q{qi}')
         strata = {q: rng.choice(['sA', 'sB', 'sC']) for q in qryque
                   if rng.random() < 0.8}
+        allsubs = sorted(set().union(*map(set, subque)))
+        sizes = {x: 1 / rng.randrange(500, 9000) for x in allsubs}
         runs = []
         present = sorted(set(rankdic.values()) - {'no rank'}) or ['genus']
         settings = [dict(rank='none'), dict(rank='none', uniq=True),
@@ -139,11 +142,15 @@ def gen_classify(seed=2024):
             scounts = dict(counter_strat(qryque, tq, strata))
             rounded = dict(counts)
             round_dict(rounded)
+            sized = dict(counter_size(subque, tq, sizes))
+            sized_strat = dict(counter_size_strat(qryque, subque, tq, sizes,
+                                                  strata))
             runs.append(dict(params=st, taxque=taxque, counts=counts,
-                             strat_counts=scounts, rounded=rounded))
+                             strat_counts=scounts, rounded=rounded,
+                             sized=sized, sized_strat=sized_strat))
         cases.append(dict(tree=tree, rankdic=rankdic, root='r',
                           queries=qryque, subque=subque, strata=strata,
-                          runs=runs))
+                          sizes=sizes, runs=runs))
     dump('classify_random.json', cases)
 
 

@@ -125,3 +125,21 @@ def test_bt2sho_exclude_ogu(tmp_path):
     tests/data/README.md (`-x G000215745`)."""
     run(['--input', join(ALN, 'bt2sho'), '--exclude', 'G000215745'],
         tmp_path, 'bt2sho.filt.ogu.tsv')
+
+
+def test_bt2sho_order_cpm_sizes(tmp_path):
+    """--sizes with a length map (counter_size, classify.py:174-213)."""
+    run(['--input', join(ALN, 'bt2sho'), '--names', join(TAX, 'names.dmp'),
+         '--nodes', join(TAX, 'nodes.dmp'), '--map', join(TAX, 'taxid.map'),
+         '--rank', 'order', '--sizes', join(TAX, 'length.map'),
+         '--scale', '1M', '--digits', '3'], tmp_path, 'bt2sho.order.cpm.tsv')
+
+
+def test_bt2sho_component_rpk_gene_lengths(tmp_path):
+    """--sizes . (gene lengths from the coordinates, ordinal.calc_gene_lens)."""
+    run(['--input', join(ALN, 'bt2sho'), '--rank', 'component',
+         '--coords', join(FUN, 'coords.txt.xz'),
+         '--map', join(FUN, 'uniref', 'uniref.map.xz'),
+         '--map', join(FUN, 'go', 'component.tsv.xz'),
+         '--sizes', '.', '--scale', '1k', '--digits', '3'],
+        tmp_path, 'bt2sho.component.rpk.tsv')

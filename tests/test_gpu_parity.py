@@ -62,6 +62,46 @@ def test_golden_classify(ctx):
     assert n > 500
 
 
+def test_golden_size_normalised(ctx):
+    """WK_F_SIZED jobs: the (feature, subject, divisor) log folded with the
+    size map equals classify.counter_size / counter_size_strat."""
+    from math import fsum
+    for case in load_vectors('classify_random.json')[:30]:
+        pc = PackedCase(case)
+        h = pc.hier
+        ctx.set_tree(h.parent, h.last, h.rank_code)
+        ctx.counts_reserve(4096)
+        ctx.log_reserve(64)             # tiny: forces the overflow + re-run path
+        names = pc.index.names
+        sizes = case['sizes']
+        for run in case['runs']:
+            mode, code, flags, major = job_spec(run['params'], h)
+            jobs = device_jobs(ctx, [(mode, code, flags | nat.F_SIZED, major)])
+            for group, gold, gnames in (
+                    (None, run['sized'], None),
+                    (pc.group, golden_counts(run['sized_strat'], True),
+                     pc.group_names)):
+                ctx.classify_chunk(jobs, pc.subj, pc.qoff, group=group,
+                                   subj_is_set=True)
+                while True:
+                    try:
+                        rows = ctx.log_fetch()
+                        break
+                    except OverflowError:
+                        ctx.log_reserve(ctx._log_cap * 4)
+                        ctx.classify_staged(jobs)
+                assert ctx.counts_fetch()[0].size == 0   # nothing counted
+                terms = {}
+                for f, s, meta, g in rows.tolist():
+                    name = 'Unassigned' if f == nat.FEATURE_UNASSIGNED \
+                        else names[f]
+                    key = name if gnames is None else (gnames[g], name)
+                    terms.setdefault(key, []).append(
+                        sizes[names[s]] / (meta & 0xFFFF))
+                got = {k: fsum(v) for k, v in terms.items()}
+                assert_counts_match(got, gold, 1e-12)
+
+
 def test_golden_multi_rank_single_pass(ctx):
     """All runs of a case as jobs of ONE kernel pass (<= 8 at a time) equal
     the per-rank results (the reference loops over ranks, workflow.py:333)."""

@@ -46,6 +46,18 @@ def test_python_oracle_assign_and_count(classify_cases):
                 unassigned=p.get('unassigned', False), strata=case['strata'])
             assert_counts_match(scounts,
                                 golden_counts(run['strat_counts'], True))
+            tq = [t or 'Unassigned' for t in taxque] \
+                if p.get('unassigned') else taxque
+            # list results pair taxa with subjects positionally: use the
+            # reference's own taxque order for the sized check
+            rtq = [t or 'Unassigned' for t in run['taxque']] \
+                if p.get('unassigned') else run['taxque']
+            sized = orc.count_sized(case['subque'], rtq, case['sizes'])
+            assert_counts_match(sized, run['sized'], 1e-12)
+            sized = orc.count_sized(case['subque'], rtq, case['sizes'],
+                                    case['queries'], case['strata'])
+            assert_counts_match(sized,
+                                golden_counts(run['sized_strat'], True), 1e-12)
             n_runs += 1
     assert n_runs > 500
 

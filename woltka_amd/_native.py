@@ -23,7 +23,7 @@ KEY_FEATURE_BITS, KEY_GROUP_BITS, KEY_K_BITS, KEY_JOB_BITS = 28, 21, 12, 3
 MAX_JOBS, MAX_K = 8, 4095
 FEATURE_UNASSIGNED, MAX_FEATURE = 0x0FFFFFFF, 0x0FFFFFFE
 MODE_NONE, MODE_FREE, MODE_RANK = 0, 1, 2
-F_UNIQ, F_ABOVE, F_SUBOK, F_UNASSIGNED = 1, 2, 4, 8
+F_UNIQ, F_ABOVE, F_SUBOK, F_UNASSIGNED, F_SIZED = 1, 2, 4, 8, 16
 ASSIGN_NONE, ASSIGN_MULTI, ASSIGN_EMPTY = -1, -2, -3
 SUBJ_IS_SET, SUBJ_INDEXED = 1, 2
 MAX_RANK_SLOTS = MAX_JOBS * 4
@@ -35,6 +35,7 @@ SYMBOLS = (
     'wk_build_rank_table', 'wk_get_rank_table', 'wk_set_genes',
     'wk_set_subjects',
     'wk_counts_reserve', 'wk_counts_clear', 'wk_counts_fetch',
+    'wk_log_reserve', 'wk_log_fetch',
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_chunk_download',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
@@ -91,6 +92,8 @@ def load_library():
         'wk_counts_reserve': (C.c_int, [p, C.c_int64]),
         'wk_counts_clear': (C.c_int, [p]),
         'wk_counts_fetch': (C.c_int, [p, u64p, i64p, C.c_int64, i64p]),
+        'wk_log_reserve': (C.c_int, [p, C.c_int64]),
+        'wk_log_fetch': (C.c_int, [p, i32p, C.c_int64, i64p]),
         'wk_chunk_stage': (C.c_int, [p, i32p, i32p, C.c_int64, i32p,
                                      C.c_int]),
         'wk_classify_staged': (C.c_int, [p, C.POINTER(Job), C.c_int32, i32p]),
@@ -264,6 +267,19 @@ class Context:
             self._h, _ptr(keys, C.c_uint64), _ptr(vals, C.c_int64), n.value,
             C.byref(n)))
         return keys[:n.value], vals[:n.value]
+
+    def log_reserve(self, n_entries):
+        self._check(self._lib.wk_log_reserve(self._h, int(n_entries)))
+        self._log_cap = int(n_entries)
+
+    def log_fetch(self):
+        """Entries of the contribution log as int32[n, 4] = (feature, subject,
+        job << 16 | divisor, group); empties the log."""
+        out = np.empty((self._log_cap, 4), dtype=np.int32)
+        n = C.c_int64(0)
+        self._check(self._lib.wk_log_fetch(self._h, _ptr(out, C.c_int32),
+                                           self._log_cap, C.byref(n)))
+        return out[:n.value]
 
     # -- classify ---------------------------------------------------------
     @staticmethod

@@ -65,7 +65,7 @@ class Engine:
 
     def __init__(self, tree, rankdic, root, ranks, uniq=False, major=None,
                  above=False, subok=False, unasgd=False, device=0,
-                 table_slots=None):
+                 table_slots=None, sizes=None):
         self.ctx = nat.Context(device)
         self.ranks = list(ranks)
         self.use_tree = bool(tree)
@@ -88,6 +88,13 @@ class Engine:
             flags |= nat.F_SUBOK
         if unasgd:
             flags |= nat.F_UNASSIGNED
+        # --sizes: every contribution is logged as (feature, subject, divisor)
+        # and weighted by sizes[subject] on the host (classify.py:174-297)
+        self.sizes = sizes
+        self.sized = {}                 # (job, group key, feature, subj, div) -> n
+        if sizes:
+            flags |= nat.F_SIZED
+            self.ctx.log_reserve(1 << 22)
         self.jobs, self.modes, self.slots = [], [], []
         slot_of = {}
         for rank in self.ranks:
@@ -302,6 +309,8 @@ class Engine:
             if want:    # read maps work on feature ids
                 subj = np.asarray(self.subj_feature, dtype=np.int32)[subj]
             nq = n
+        if self.sizes:
+            self._collect_log()
         if want:
             self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,
                              outzip, namedic)
@@ -360,6 +369,46 @@ class Engine:
                     write_readmap(fh, qs, ts, namedic)
 
     # ------------------------------------------------------------------
+    def _collect_log(self):
+        """Fold the contribution log of the chunk just classified.  If the log
+        overflowed, enlarge it and run the staged chunk again (size-normalised
+        jobs write nothing but the log, so a re-run is harmless)."""
+        while True:
+            try:
+                rows = self.ctx.log_fetch()
+                break
+            except OverflowError:
+                self.ctx.log_reserve(self.ctx._log_cap * 4)
+                self.ctx.classify_staged(self.jobs)
+        if not rows.size:
+            return
+        uniq, cnt = np.unique(rows, axis=0, return_counts=True)
+        acc = self.sized
+        groups = self.groups
+        for (f, s, meta, g), c in zip(uniq.tolist(), cnt.tolist()):
+            key = (meta >> 16, groups[g], f, s, meta & 0xFFFF)
+            acc[key] = acc.get(key, 0) + c
+
+    def _finish_sized(self, data):
+        """value = sum over contributions of sizes[subject] / divisor."""
+        from math import fsum
+        names = self.index.names
+        sizes = self.sizes
+        terms = {}
+        try:
+            for (j, (sample, stratum), f, s, div), c in self.sized.items():
+                name = 'Unassigned' if f == nat.FEATURE_UNASSIGNED \
+                    else names[f]
+                key = name if stratum is None else (stratum, name)
+                terms.setdefault((self.ranks[j], sample, key), []).append(
+                    c * sizes[names[s]] / div)
+        except KeyError:
+            raise ValueError(
+                'One or more subjects are not found in the size map.')
+        for (rank, sample, key), vals in terms.items():
+            data[rank].setdefault(sample, {})[key] = fsum(vals)
+        self.sized = {}
+
     def collect(self, data):
         """Fetch the device counts, fold them into ``data`` as exact
         ``Fraction``s (sum_k n_k / k, classify.py:167-170) and clear the
@@ -392,6 +441,8 @@ class Engine:
         would hold before rounding: ``int`` when integral, else one correctly
         rounded ``float`` division."""
         self.collect(data)
+        if self.sizes:
+            self._finish_sized(data)
         for profile in data.values():
             for sample in profile.values():
                 for key, v in sample.items():

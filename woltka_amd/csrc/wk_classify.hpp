@@ -44,6 +44,10 @@ struct ClassifyArgs {
     int32_t* out_assign;  // [n_jobs * n_reads] or null
     unsigned long long* stat_block;  // [2 * gridDim.x]: per-workgroup (reads, records) totals
     CountTable table;
+    // contribution log of size-normalised jobs (WK_F_SIZED): 4 x int32 per entry
+    int32_t* log;
+    unsigned long long* log_cursor;
+    int64_t log_cap;
     uint32_t ablate;  // measurement builds only (-DWK_ABLATE): 1 = drop counts, 2 = skip flush
 };
 
@@ -257,6 +261,26 @@ __device__ __forceinline__ void count_add(const LdsCache& cache, const CountTabl
         table_add(table, key, 1ull);
 }
 
+// Size-normalised counting (classify.counter_size, classify.py:174-213) needs
+// the (feature, subject) pair of every contribution: its value is
+// sizes[subject] / divisor.  Such jobs append {feature, subject, job<<16 |
+// divisor, group} to a log that the host folds exactly; one returning atomic
+// per wave-level append (the active lanes share a ballot).
+__device__ __forceinline__ void log_append(const ClassifyArgs& a, int32_t feature, int32_t subject, int jb,
+                                           int32_t divisor, int32_t g) {
+    const unsigned long long mask = __ballot(1);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(a.log_cursor, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, kWave);
+    const unsigned long long pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if ((int64_t)pos < a.log_cap) {
+        int4 e = make_int4(feature, subject, (jb << 16) | divisor, g);
+        reinterpret_cast<int4*>(a.log)[pos] = e;
+    }  // overflow is detected by the host from the cursor
+}
+
 // Everything the reference does for ONE read (query, mate) whose n >= 1
 // candidate subjects are cand 0..n-1: all jobs (ranks) are evaluated from the
 // same candidates.  `C` is a FeatureCand / RowCand over HBM or an LDS tile.
@@ -296,8 +320,13 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                         atomicOr(a.table.err, kErrKRange);
                     } else {
                         for (int32_t j = 0; j < n; ++j)
-                            if (a.subj_is_set || first_occurrence(cand, j))
-                                count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)cand.feat(j)));
+                            if (a.subj_is_set || first_occurrence(cand, j)) {
+                                const int32_t f = cand.feat(j);
+                                if (job.flags & WK_F_SIZED)
+                                    log_append(a, f, f, jb, kd, g);
+                                else
+                                    count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)f));
+                            }
                     }
                 }
             }
@@ -362,8 +391,12 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                         for (int32_t j = 0; j < n; ++j) {
                             const int32_t t = cand.tax(j, job);
                             if (t < 0) continue;
-                            if (a.subj_is_set || first_occurrence(cand, j))
-                                count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)t));
+                            if (a.subj_is_set || first_occurrence(cand, j)) {
+                                if (job.flags & WK_F_SIZED)
+                                    log_append(a, t, cand.feat(j), jb, kd, g);
+                                else
+                                    count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)t));
+                            }
                         }
                     }
                 }
@@ -372,10 +405,29 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
 
         if (a.out_assign) a.out_assign[(int64_t)jb * a.n_reads + r] = res;
         if (g >= 0) {
+            int32_t f = -1;
             if (res >= 0)
-                count_add<kUseLds>(cache, a.table, make_key(jb, 1, g, (uint32_t)res));
+                f = res;
             else if (res == WK_ASSIGN_NONE && (job.flags & WK_F_UNASSIGNED))
-                count_add<kUseLds>(cache, a.table, make_key(jb, 1, g, WK_FEATURE_UNASSIGNED));
+                f = WK_FEATURE_UNASSIGNED;
+            if (f >= 0) {
+                if (job.flags & WK_F_SIZED) {
+                    // mean of the subjects' sizes: sum(sizes[x] for x in subs) / len(subs)
+                    int32_t kd = n;
+                    if (!a.subj_is_set) {
+                        kd = 0;
+                        for (int32_t j = 0; j < n; ++j) kd += first_occurrence(cand, j) ? 1 : 0;
+                    }
+                    if (kd > WK_MAX_K) {
+                        atomicOr(a.table.err, kErrKRange);
+                    } else {
+                        for (int32_t j = 0; j < n; ++j)
+                            if (a.subj_is_set || first_occurrence(cand, j)) log_append(a, f, cand.feat(j), jb, kd, g);
+                    }
+                } else {
+                    count_add<kUseLds>(cache, a.table, make_key(jb, 1, g, (uint32_t)f));
+                }
+            }
         }
     }
 }

@@ -106,9 +106,11 @@ struct wk_ctx {
     double th = 0.8;
     bool ord_valid = false;
 
-    // misc device scalars: [0]=err(int) [3]=total pairs [4]=compact counter
+    // misc device scalars: [0]=err(int) [3]=total pairs [4]=compact counter [5]=log cursor
     DevBuf scalars;
     DevBuf stat_block;  // kStatBlocks x (reads, records), see flush_stats()
+    DevBuf log;         // contribution log of WK_F_SIZED jobs, cursor = scalars[5]
+    int64_t log_cap = 0;
     DevBuf assign_out, fetch_k, fetch_v;
     int64_t stat_pairs = 0;
 
@@ -292,7 +294,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->subj_feat, &c->subj_rows, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -507,6 +509,37 @@ int wk_counts_fetch(wk_ctx* c, uint64_t* keys, int64_t* counts, int64_t cap, int
     return WK_OK;
 }
 
+int wk_log_reserve(wk_ctx* c, int64_t n_entries) {
+    if (!c) return WK_E_ARG;
+    if (n_entries < 1) return fail(c, WK_E_ARG, "log capacity must be positive");
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->log.reserve((size_t)n_entries * 16));
+    c->log_cap = n_entries;
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 5), 0, 8, c->stream));
+    return WK_OK;
+}
+
+int wk_log_fetch(wk_ctx* c, int32_t* out, int64_t cap, int64_t* n) {
+    if (!c || !n) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    int rc = check_device_errors(c);
+    if (rc) return rc;
+    unsigned long long used = 0;
+    HIP_TRY(c, hipMemcpyAsync(&used, scalar_u64(c, 5), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n = (int64_t)used;
+    if ((int64_t)used > c->log_cap) {
+        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 5), 0, 8, c->stream));
+        return fail(c, WK_E_CAPACITY, "contribution log overflowed: %llu entries needed, %lld reserved", used, (long long)c->log_cap);
+    }
+    if ((int64_t)used > cap || (used && !out)) return fail(c, WK_E_CAPACITY, "output capacity %lld < %llu entries", (long long)cap, used);
+    if (used) HIP_TRY(c, hipMemcpyAsync(out, c->log.p, (size_t)used * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 5), 0, 8, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WK_OK;
+}
+
 // ---- classify ----------------------------------------------------------------
 
 int wk_chunk_stage(wk_ctx* c, const int32_t* subj, const int32_t* qoff, int64_t n_reads, const int32_t* group,
@@ -610,6 +643,12 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
     }
     a.stat_block = c->stat_block.as<unsigned long long>();
     a.ablate = (uint32_t)c->ablate;
+    a.log = c->log.as<int32_t>();
+    a.log_cursor = scalar_u64(c, 5);
+    a.log_cap = c->log_cap;
+    for (int j = 0; j < n_jobs; ++j)
+        if ((jobs[j].flags & WK_F_SIZED) && c->log_cap <= 0)
+            return fail(c, WK_E_STATE, "job %d is size-normalised but no log is reserved (wk_log_reserve)", j);
     a.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
 
     if (c->n_reads > 0) {

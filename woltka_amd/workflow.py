@@ -185,10 +185,6 @@ def classify(mapper:  object,
     memoised, every read is evaluated by the kernels.  Counts are accumulated
     as exact integers on the device, so the result does not depend on ``chunk``.
     """
-    if sizes:
-        raise NotImplementedError(
-            'Size-normalised counting (--sizes) is not available on the GPU '
-            'path yet.')
     if outcov_dir:
         raise NotImplementedError(
             'Subject coverage output (--outcov) is not available on the GPU '
@@ -196,7 +192,8 @@ def classify(mapper:  object,
     data = {x: {} for x in ranks}
     outzip = outzip if outzip != 'none' else None
     engine = Engine(tree, rankdic, root, ranks, uniq=uniq, major=major,
-                    above=above, subok=subok, unasgd=unasgd, device=device)
+                    above=above, subok=subok, unasgd=unasgd, device=device,
+                    sizes=sizes)
     ordinal = isinstance(mapper, OrdinalMapper)
     if ordinal:
         engine.set_genes(mapper.table, mapper.prefix)
@@ -434,13 +431,23 @@ def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
 
 
 def parse_sizes(sizes, mapper, zippers=None):
-    """Feature sizes for ``--sizes`` (workflow.py:588-633): not on the GPU path
-    yet."""
+    """Feature sizes for ``--sizes`` as reciprocals (workflow.py:588-633):
+    a two-column map file, or "." = gene lengths from the coordinates."""
     if not sizes:
         return
-    raise NotImplementedError(
-        'Size-normalised counting (--sizes) is not available on the GPU path '
-        'yet.')
+    if sizes == '.':
+        click.echo('Calculating gene lengths from coordinates...', nl=False)
+        if not isinstance(mapper, OrdinalMapper):
+            raise ValueError('Gene coordinates file is not provided.')
+        sizemap = mapper.table.gene_lengths(mapper.prefix)
+        click.echo(' Done.')
+    else:
+        click.echo(f'Reading subject sizes file: {basename(sizes)}...',
+                   nl=False)
+        with readzip(sizes, zippers) as f:
+            sizemap = {k: float(v) for k, v in read_map_1st(f)}
+        click.echo(' Done.')
+    return {k: 1 / v for k, v in sizemap.items()}
 
 
 def prepare_ranks(ranks=None, outmap_dir=None, tree=None, rankdic=None):
