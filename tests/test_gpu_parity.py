@@ -199,6 +199,15 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     order = np.argsort(keys2)
     assert np.array_equal(keys2[order], okeys)
     assert np.array_equal(vals2[order], ocnt.astype(np.int64))
+    # ... and with the dense-bin path switched off
+    ctx.set_option('dense', 0)
+    ctx.counts_clear()
+    ctx.classify_staged(jobs)
+    keys3, vals3 = ctx.counts_fetch()
+    order = np.argsort(keys3)
+    assert np.array_equal(keys3[order], okeys)
+    assert np.array_equal(vals3[order], ocnt.astype(np.int64))
+    ctx.set_option('dense', 1)
     ctx.set_option('use_lds', 1)
 
 

@@ -20,16 +20,18 @@ def main():
     ap.add_argument('--ablate', type=int, default=0)
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--tiled', type=int, default=-1)
+    ap.add_argument('--dense', type=int, default=1)
     a = ap.parse_args()
     ctx = nat.Context(0)
     wl = bench.WORKLOADS[a.workload](ctx, 1002, a.scale)
     ctx.profile_kernels(True)
     ctx.set_option('ablate', a.ablate)
+    ctx.set_option('dense', a.dense)
     print(f'workload {wl.name}: {wl.records} records, {wl.alg_bytes / 1e6:.1f} MB algorithmic')
     cfgs = []
     for tiled in ((1, 0) if a.tiled < 0 else (a.tiled,)):
         for slots in ((4096,) if a.quick else (1024, 2048, 4096, 8192)):
-            for threads, bpc in (((512, 2),) if tiled else ((1024, 1), (1024, 2), (512, 2), (512, 4), (256, 4), (256, 8))):
+            for threads, bpc in (((512, 2),) if tiled else ((1024, 1), (1024, 2), (512, 2), (512, 4), (512, 3), (256, 8))):
                 if tiled and slots > 4096:
                     continue
                 cfgs.append((tiled, slots, threads, bpc))

@@ -44,6 +44,10 @@ struct ClassifyArgs {
     int32_t* out_assign;  // [n_jobs * n_reads] or null
     unsigned long long* stat_block;  // [2 * gridDim.x]: per-workgroup (reads, records) totals
     CountTable table;
+    // dense bins (see LdsCache): per-workgroup slab rows in HBM, merged by
+    // dense_merge_kernel
+    uint32_t dense_bins;
+    uint32_t* dense_slab;  // [gridDim.x][n_jobs * dense_bins]
     // contribution log of size-normalised jobs (WK_F_SIZED): 4 x int32 per entry
     int32_t* log;
     unsigned long long* log_cursor;
@@ -247,18 +251,24 @@ __device__ __forceinline__ bool first_occurrence(const C& cand, int32_t j) {
 }
 
 template <bool kUseLds>
-__device__ __forceinline__ void count_add(const LdsCache& cache, const CountTable& table,
-                                          uint64_t key) {
+__device__ __forceinline__ void count_add(const LdsCache& cache, const CountTable& table, int jb, uint32_t k,
+                                          int32_t g, uint32_t feature) {
+    const uint64_t key = make_key(jb, k, g, feature);
 #ifdef WK_ABLATE
     if (cache.ablate & 1) {  // measurement only: drop the count, keep the key live
         asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)));
         return;
     }
 #endif
-    if constexpr (kUseLds)
+    if constexpr (kUseLds) {
+        if (cache.dense && k == 1 && g == 0 && feature < cache.dense_bins) {
+            atomicAdd(&cache.dense[(uint32_t)jb * cache.dense_bins + feature], 1u);
+            return;
+        }
         cached_add(cache, table, key, 1ull);
-    else
+    } else {
         table_add(table, key, 1ull);
+    }
 }
 
 // Size-normalised counting (classify.counter_size, classify.py:174-213) needs
@@ -325,7 +335,7 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                                 if (job.flags & WK_F_SIZED)
                                     log_append(a, f, f, jb, kd, g);
                                 else
-                                    count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)f));
+                                    count_add<kUseLds>(cache, a.table, jb, kd, g, (uint32_t)f);
                             }
                     }
                 }
@@ -395,7 +405,7 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                                 if (job.flags & WK_F_SIZED)
                                     log_append(a, t, cand.feat(j), jb, kd, g);
                                 else
-                                    count_add<kUseLds>(cache, a.table, make_key(jb, kd, g, (uint32_t)t));
+                                    count_add<kUseLds>(cache, a.table, jb, kd, g, (uint32_t)t);
                             }
                         }
                     }
@@ -425,7 +435,7 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                             if (a.subj_is_set || first_occurrence(cand, j)) log_append(a, f, cand.feat(j), jb, kd, g);
                     }
                 } else {
-                    count_add<kUseLds>(cache, a.table, make_key(jb, 1, g, (uint32_t)f));
+                    count_add<kUseLds>(cache, a.table, jb, 1, g, (uint32_t)f);
                 }
             }
         }
@@ -473,6 +483,12 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
     if constexpr (kUseLds) {
         cache.base = reinterpret_cast<unsigned long long*>(smem);
         cache.bmask = lds_slots / 4 - 1;
+        if (a.dense_bins) {
+            cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
+            cache.dense_bins = a.dense_bins;
+            const uint32_t nb = a.dense_bins * (uint32_t)a.n_jobs;
+            for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cache.dense[i] = 0u;
+        }
         lds_cache_init(cache);
     }
     unsigned long long my_reads = 0, my_records = 0;
@@ -571,7 +587,26 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         }
     }
     flush_stats(a, my_reads, my_records);
-    if constexpr (kUseLds) lds_cache_flush(cache, a.table);
+    if constexpr (kUseLds) {
+        lds_cache_flush(cache, a.table);  // starts with a workgroup barrier
+        if (cache.dense) {
+            const uint32_t nb = a.dense_bins * (uint32_t)a.n_jobs;
+            uint32_t* row = a.dense_slab + (size_t)blockIdx.x * nb;
+            for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) row[i] = cache.dense[i];
+        }
+    }
+}
+
+// Column sums of the workgroups' dense-bin slab rows -> count table.  One key
+// per non-empty bin, so no two adds ever meet on a slot.
+__global__ void __launch_bounds__(256) dense_merge_kernel(const uint32_t* __restrict__ slab, uint32_t n_rows,
+                                                          uint32_t n_jobs, uint32_t bins, CountTable table) {
+    const uint32_t nb = n_jobs * bins;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    unsigned long long sum = 0;
+    for (uint32_t r = 0; r < n_rows; ++r) sum += slab[(size_t)r * nb + i];
+    if (sum) table_add(table, make_key(i / bins, 1, 0, i % bins), sum);
 }
 
 // Tiled variant.  A workgroup walks over tiles of kTileReads consecutive reads.

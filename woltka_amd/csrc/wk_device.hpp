@@ -79,6 +79,11 @@ __device__ __forceinline__ void table_add(const CountTable& t, uint64_t key, uns
 struct LdsCache {
     unsigned long long* base;  // [buckets * 8]
     uint32_t bmask;            // buckets - 1
+    // dense bins for the bulk of the traffic when the id space is small: the
+    // count of (job, k = 1, group 0, feature < dense_bins) is one ds_add_u32,
+    // no key compare, and the bins of all workgroups are merged without atomics
+    uint32_t* dense;           // [n_jobs * dense_bins] or null
+    uint32_t dense_bins;
 #ifdef WK_ABLATE
     uint32_t ablate;
 #endif

@@ -79,8 +79,10 @@ struct wk_ctx {
     bool rank_tab_valid[WK_MAX_JOBS * 4] = {};
 
     // compact subject table (optional)
-    DevBuf subj_feat, subj_rows;
+    DevBuf subj_feat, subj_rows, dense_slab;
     int32_t n_subjects = 0;
+    int32_t max_subject_feature = -1;
+    int use_dense = 1;
     int32_t rows_w = 0;
     std::vector<int> rows_sig;  // rank slots the rows were built for (+ n_subjects)
     bool subj_indexed = false;  // staged chunk carries subject indices
@@ -294,7 +296,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -339,6 +341,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     }
     if (!strcmp(name, "ablate")) {
         c->ablate = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "dense")) {
+        c->use_dense = value ? 1 : 0;
         return WK_OK;
     }
     if (!strcmp(name, "tiled")) {
@@ -437,9 +443,13 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
 int wk_set_subjects(wk_ctx* c, const int32_t* feature_of_subject, int32_t n) {
     if (!c) return WK_E_ARG;
     if (n < 0 || (n > 0 && !feature_of_subject)) return fail(c, WK_E_ARG, "bad subject table arguments");
-    for (int32_t s = 0; s < n; ++s)
+    int32_t mx = -1;
+    for (int32_t s = 0; s < n; ++s) {
         if (feature_of_subject[s] < 0 || feature_of_subject[s] > WK_MAX_FEATURE)
             return fail(c, WK_E_RANGE, "subject %d: feature id outside [0, %d]", s, WK_MAX_FEATURE);
+        mx = std::max(mx, feature_of_subject[s]);
+    }
+    c->max_subject_feature = mx;
     DeviceGuard guard(c->device);
     int rc = upload(c, c->subj_feat, feature_of_subject, (size_t)n * sizeof(int32_t));
     if (rc) return rc;
@@ -662,8 +672,35 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                                (uint32_t)c->lds_slots, c->n_records);
         } else if (c->use_lds) {
             const int blocks = grid_for(c->n_reads, c->threads, std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu));
-            const size_t lds = (size_t)c->lds_slots * 16;
-            hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)c->lds_slots);
+            // dense bins: small id space, subject-indexed chunk, no size-normalised job
+            int64_t bins = 0;
+            int lds_slots = c->lds_slots;
+            if (c->use_dense && c->subj_indexed) {
+                const int64_t b = std::max<int64_t>(c->n_nodes, (int64_t)c->max_subject_feature + 1);
+                bool sized = false;
+                for (int j = 0; j < n_jobs; ++j) sized |= (jobs[j].flags & WK_F_SIZED) != 0;
+                if (!sized && b * n_jobs <= 28672) {  // <= 112 KiB of bins + 32 KiB hash cache = 144 KiB LDS
+                    bins = b;
+                    lds_slots = std::min(lds_slots, 2048);
+                    // two workgroups per CU fit if each stays below 80 KiB
+                    if (c->blocks_per_cu >= 2 && b * n_jobs * 4 + 1024 * 16 <= 80 * 1024) lds_slots = 1024;
+                }
+            }
+            size_t lds = (size_t)lds_slots * 16;
+            if (bins) {
+                lds += (size_t)bins * n_jobs * 4;
+                HIP_TRY(c, c->dense_slab.reserve((size_t)blocks * bins * n_jobs * 4));
+                a.dense_bins = (uint32_t)bins;
+                a.dense_slab = c->dense_slab.as<uint32_t>();
+            }
+            hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)lds_slots);
+            if (bins) {
+                ktimer_end(c, kt);
+                kt = ktimer_begin(c, "dense_merge");
+                const uint32_t nb = (uint32_t)(bins * n_jobs);
+                hipLaunchKernelGGL(dense_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
+                                   c->dense_slab.as<uint32_t>(), (uint32_t)blocks, (uint32_t)n_jobs, (uint32_t)bins, a.table);
+            }
         } else {
             const int blocks = grid_for(c->n_reads, 256, c->prop.multiProcessorCount * 8);
             hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, a, 0u);
