@@ -45,52 +45,87 @@ __device__ __forceinline__ int64_t effective_len(uint32_t len, double th) {
     return (int64_t)ceil((double)len * th);
 }
 
-// Visit every gene matching the hit, calling f(gene_index).
-template <typename F>
-__device__ __forceinline__ void for_each_match(const MatchArgs& a, int64_t h, F&& f) {
+struct HitQuery {
+    int64_t rs, re, rel;
+    int32_t lo, hi;  // gene range of the hit's genome (empty: hit cannot match)
+};
+
+__device__ __forceinline__ HitQuery load_hit(const MatchArgs& a, int64_t h) {
+    HitQuery q{0, 0, 1, 0, 0};
+    if (h >= a.n_hits) return q;
     const int32_t g = a.genome[h];
     const uint32_t len = a.len[h];
-    if (g < 0 || g >= a.n_genomes || len == 0) return;  // ordinal.py:231, 294-297
-    const int64_t rs = a.beg[h];
-    const int64_t re = a.end[h];
-    const int64_t rel = effective_len(len, a.th);
-    const int32_t lo = a.genome_off[g];
-    const int32_t hi = a.genome_off[g + 1];
-    // a matching gene starts at or before re - rel ...
-    const int64_t max_start = re - rel;
-    int32_t l = lo, r = hi;
-    while (l < r) {  // upper bound: first gene with start0 > max_start
-        const int32_t m = l + ((r - l) >> 1);
-        if ((int64_t)a.gstart[m] <= max_start)
-            l = m + 1;
-        else
-            r = m;
-    }
-    // ... and ends at or after rs + rel
-    const int64_t min_end = rs + rel;
-    for (int32_t j = l - 1; j >= lo; --j) {
+    if (g < 0 || g >= a.n_genomes || len == 0) return q;  // ordinal.py:231, 294-297
+    q.rs = a.beg[h];
+    q.re = a.end[h];
+    q.rel = effective_len(len, a.th);
+    q.lo = a.genome_off[g];
+    q.hi = a.genome_off[g + 1];
+    return q;
+}
+
+// Backward scan from the upper bound `ub` (first gene with start0 > re - rel):
+// a matching gene starts at or before re - rel and ends at or after rs + rel;
+// the running maximum of the ends stops the scan.
+template <typename F>
+__device__ __forceinline__ void scan_matches(const MatchArgs& a, const HitQuery& q, int32_t ub, F&& f) {
+    const int64_t min_end = q.rs + q.rel;
+    for (int32_t j = ub - 1; j >= q.lo; --j) {
         if ((int64_t)a.gpmax[j] < min_end) break;  // nothing at or before j reaches the hit
         const int64_t gs = a.gstart[j];
         const int64_t ge = a.gend[j];
-        const int64_t ov = (ge < re ? ge : re) - (gs > rs ? gs : rs);
-        if (ov >= rel) f(j);
+        const int64_t ov = (ge < q.re ? ge : q.re) - (gs > q.rs ? gs : q.rs);
+        if (ov >= q.rel) f(j);
     }
 }
 
-// Pass 1: number of matching genes per hit + per-tile totals.
+// Pass 1: number of matching genes per hit + per-tile totals.  The binary
+// searches of a thread's kMatchItems hits advance in lock step, so their
+// gathers (cache-resident gene starts) are issued back to back; the upper
+// bound is kept for pass 2.
 __global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
                                                                     int32_t* __restrict__ cnt,
+                                                                    int32_t* __restrict__ ubound,
                                                                     unsigned long long* __restrict__ tile_sum) {
     __shared__ unsigned long long wsum[kMatchThreads / kWave];
     const int64_t base = (int64_t)blockIdx.x * kMatchTile;
+    HitQuery q[kMatchItems];
+    int32_t l[kMatchItems], r[kMatchItems];
+#pragma unroll
+    for (int it = 0; it < kMatchItems; ++it) {
+        q[it] = load_hit(a, base + it * kMatchThreads + threadIdx.x);
+        l[it] = q[it].lo;
+        r[it] = q[it].hi;
+    }
+    bool more = true;
+    while (more) {  // upper bound: first gene with start0 > re - rel
+        int32_t m[kMatchItems], v[kMatchItems];
+#pragma unroll
+        for (int it = 0; it < kMatchItems; ++it) {
+            m[it] = l[it] + ((r[it] - l[it]) >> 1);
+            v[it] = (l[it] < r[it]) ? a.gstart[m[it]] : 0;
+        }
+        more = false;
+#pragma unroll
+        for (int it = 0; it < kMatchItems; ++it) {
+            if (l[it] < r[it]) {
+                if ((int64_t)v[it] <= q[it].re - q[it].rel)
+                    l[it] = m[it] + 1;
+                else
+                    r[it] = m[it];
+            }
+            more |= l[it] < r[it];
+        }
+    }
     unsigned long long mine = 0;
 #pragma unroll
     for (int it = 0; it < kMatchItems; ++it) {
         const int64_t h = base + it * kMatchThreads + threadIdx.x;
         if (h < a.n_hits) {
             int32_t c = 0;
-            for_each_match(a, h, [&](int32_t) { c += 1; });
+            scan_matches(a, q[it], l[it], [&](int32_t) { c += 1; });
             cnt[h] = c;
+            ubound[h] = l[it];
             mine += (unsigned long long)c;
         }
     }
@@ -139,6 +174,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const unsigned long lon
 // matched gene feature ids.
 __global__ void __launch_bounds__(kMatchThreads) match_write_kernel(MatchArgs a,
                                                                     const int32_t* __restrict__ cnt,
+                                                                    const int32_t* __restrict__ ubound,
                                                                     const unsigned long long* __restrict__ tile_off,
                                                                     int32_t* __restrict__ poff,
                                                                     int32_t* __restrict__ pairs) {
@@ -188,9 +224,9 @@ __global__ void __launch_bounds__(kMatchThreads) match_write_kernel(MatchArgs a,
         if (h < a.n_hits) {
             const int64_t o = toff + scan[idx];
             poff[h] = (int32_t)o;
-            if (cnt[h] > 0) {
+            if (cnt[h] > 0) {  // only matching hits re-scan (no second search)
                 int64_t w = o;
-                for_each_match(a, h, [&](int32_t j) { pairs[w++] = a.gfeat[j]; });
+                scan_matches(a, load_hit(a, h), ubound[h], [&](int32_t j) { pairs[w++] = a.gfeat[j]; });
             }
         }
     }
