@@ -598,15 +598,28 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
 }
 
 // Column sums of the workgroups' dense-bin slab rows -> count table.  One key
-// per non-empty bin, so no two adds ever meet on a slot.
-__global__ void __launch_bounds__(256) dense_merge_kernel(const uint32_t* __restrict__ slab, uint32_t n_rows,
-                                                          uint32_t n_jobs, uint32_t bins, CountTable table) {
+// per non-empty bin, so no two adds ever meet on a slot.  A workgroup owns 64
+// adjacent bins (one 256-byte segment per slab row) and splits the rows over
+// 16 waves; partial sums meet in LDS.
+__global__ void __launch_bounds__(1024) dense_merge_kernel(const uint32_t* __restrict__ slab, uint32_t n_rows,
+                                                           uint32_t n_jobs, uint32_t bins, CountTable table) {
+    __shared__ unsigned long long part[16][64];
     const uint32_t nb = n_jobs * bins;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb) return;
+    const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64 + lane;
     unsigned long long sum = 0;
-    for (uint32_t r = 0; r < n_rows; ++r) sum += slab[(size_t)r * nb + i];
-    if (sum) table_add(table, make_key(i / bins, 1, 0, i % bins), sum);
+    if (i < nb) {
+#pragma unroll 4
+        for (uint32_t r = grp; r < n_rows; r += 16) sum += slab[(size_t)r * nb + i];
+    }
+    part[grp][lane] = sum;
+    __syncthreads();
+    if (grp == 0 && i < nb) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tot += part[g][lane];
+        if (tot) table_add(table, make_key(i / bins, 1, 0, i % bins), tot);
+    }
 }
 
 // Tiled variant.  A workgroup walks over tiles of kTileReads consecutive reads.

@@ -698,7 +698,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "dense_merge");
                 const uint32_t nb = (uint32_t)(bins * n_jobs);
-                hipLaunchKernelGGL(dense_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(dense_merge_kernel, dim3((nb + 63) / 64), dim3(1024), 0, c->stream,
                                    c->dense_slab.as<uint32_t>(), (uint32_t)blocks, (uint32_t)n_jobs, (uint32_t)bins, a.table);
             }
         } else {
