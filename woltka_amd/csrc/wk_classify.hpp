@@ -442,6 +442,39 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
     }
 }
 
+// A read with a single candidate (the bulk of real inputs) needs none of the
+// set logic: every assigner reduces to one table value.  `row` is the
+// candidate's subject row {feature, rank col 0, 1, 2}.
+template <bool kUseLds>
+__device__ __forceinline__ void process_single(const ClassifyArgs& a, const LdsCache& cache, const int4 row,
+                                               int64_t r, int32_t g) {
+    const int32_t f = row.x;
+    if ((uint32_t)f > (uint32_t)WK_MAX_FEATURE) atomicOr(a.table.err, kErrFeatureRange);
+    for (int jb = 0; jb < a.n_jobs; ++jb) {
+        const JobDev job = a.jobs[jb];
+        int32_t res;
+        if (job.mode == WK_MODE_NONE) {
+            res = f;
+        } else if (job.mode == WK_MODE_FREE) {
+            res = (job.flags & WK_F_SUBOK) ? f : ((f < a.n_nodes) ? a.nodes[f].parent : WK_ASSIGN_NONE);
+        } else {
+            const int32_t t = job.col == 0 ? row.y : (job.col == 1 ? row.z : row.w);
+            res = t < 0 ? WK_ASSIGN_NONE : t;
+        }
+        if (a.out_assign) a.out_assign[(int64_t)jb * a.n_reads + r] = res;
+        if (g < 0) continue;
+        int32_t out = res;
+        if (res < 0) {
+            if (!(job.flags & WK_F_UNASSIGNED)) continue;
+            out = WK_FEATURE_UNASSIGNED;
+        }
+        if (job.flags & WK_F_SIZED)
+            log_append(a, out, f, jb, 1, g);
+        else
+            count_add<kUseLds>(cache, a.table, jb, 1, g, (uint32_t)out);
+    }
+}
+
 __device__ __forceinline__ void mark_empty(const ClassifyArgs& a, int64_t r) {
     if (a.out_assign)
         for (int j = 0; j < a.n_jobs; ++j) a.out_assign[(int64_t)j * a.n_reads + r] = WK_ASSIGN_EMPTY;
@@ -538,6 +571,14 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
             const int32_t n = e0 - s0;
             if (n <= 0) {
                 mark_empty(a, r);
+            } else if (n == 1 && (uint32_t)c0 < (uint32_t)a.n_subjects) {
+                my_reads += 1;
+                my_records += 1;
+                if (g0 >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
+#ifdef WK_ABLATE
+                if (!(a.ablate & 8))
+#endif
+                    process_single<kUseLds>(a, cache, row0, r, g0);
             } else {
                 // every subject index of the read must lie inside the table
                 bool ok = (uint32_t)c0 < (uint32_t)a.n_subjects;
