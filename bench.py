@@ -119,6 +119,7 @@ class FlatWorkload:
 class LcaWorkload:
     """configs[2]: multi-hit reads, taxonomy tree, 3 ranks + free in one pass."""
     dominant = 'classify'
+    families = ('classify', 'partition_merge')
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -190,7 +191,8 @@ class OrdinalWorkload:
         # + ~0.8 pairs/record x 8 B out (pair + offset)
         self.alg_bytes = 20 * self.records + 16 * p['gstart'].size + \
             int(6.4 * self.records)
-        self.families = ('match_count', 'match_write', 'classify')
+        self.families = ('match_count', 'match_write', 'classify',
+                         'partition_merge')
 
     def family_bytes(self, family):
         """Algorithmic bytes of one launch of each kernel of the step."""
@@ -201,6 +203,8 @@ class OrdinalWorkload:
             return 16 * self.records + tables + 8 * self.records
         if family == 'match_write':     # hits + counts in, offsets + pairs out
             return 24 * self.records + tables + 4 * self.records + 4 * pairs
+        if family == 'partition_merge':
+            return 0
         return 4 * pairs + 4 * (self.reads + 1)     # classify over gene lists
 
     def step(self):

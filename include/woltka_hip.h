@@ -115,7 +115,8 @@ int wk_device_name(const wk_ctx* ctx, char* buf, size_t cap);
 int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
 /* Tuning knobs: "lds_slots" (LDS front-cache slots per workgroup, power of two
  * in [64, 8192]), "use_lds" (0/1), "tiled" (0/1: LDS-staged classify kernel),
- * "dense" (0/1: dense LDS bins for small id spaces), "threads" (workgroup size of
+ * "dense" (0/1: dense LDS bins for small id spaces), "plog" (0 off / 1 auto / 2
+ * always: partitioned miss log), "plog_max_bytes", "threads" (workgroup size of
  * the direct classify kernel), "blocks_per_cu"
  * (classify grid size per CU, 1..32).  Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);

@@ -199,15 +199,21 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     order = np.argsort(keys2)
     assert np.array_equal(keys2[order], okeys)
     assert np.array_equal(vals2[order], ocnt.astype(np.int64))
-    # ... and with the dense-bin path switched off
-    ctx.set_option('dense', 0)
-    ctx.counts_clear()
-    ctx.classify_staged(jobs)
-    keys3, vals3 = ctx.counts_fetch()
-    order = np.argsort(keys3)
-    assert np.array_equal(keys3[order], okeys)
-    assert np.array_equal(vals3[order], ocnt.astype(np.int64))
+    # ... with the dense-bin path switched off, and with the partitioned miss
+    # log forced on (tiny streams -> also exercises the overflow fallback)
+    for opts in (dict(dense=0, plog=0), dict(dense=0, plog=2),
+                 dict(dense=0, plog=2, plog_max_bytes=1 << 22)):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.counts_clear()
+        ctx.classify_staged(jobs)
+        keys3, vals3 = ctx.counts_fetch()
+        order = np.argsort(keys3)
+        assert np.array_equal(keys3[order], okeys), opts
+        assert np.array_equal(vals3[order], ocnt.astype(np.int64)), opts
     ctx.set_option('dense', 1)
+    ctx.set_option('plog', 1)
+    ctx.set_option('plog_max_bytes', 4 << 30)
     ctx.set_option('use_lds', 1)
 
 

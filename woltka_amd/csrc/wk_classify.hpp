@@ -48,6 +48,11 @@ struct ClassifyArgs {
     // dense_merge_kernel
     uint32_t dense_bins;
     uint32_t* dense_slab;  // [gridDim.x][n_jobs * dense_bins]
+    // partitioned miss log (see LdsCache): [gridDim.x][kLogParts][plog_cap] keys
+    // and [gridDim.x][kLogParts] stream lengths
+    unsigned long long* plog;
+    uint32_t* plog_cnt;
+    uint32_t plog_cap;
     // contribution log of size-normalised jobs (WK_F_SIZED): 4 x int32 per entry
     int32_t* log;
     unsigned long long* log_cursor;
@@ -516,7 +521,12 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
     if constexpr (kUseLds) {
         cache.base = reinterpret_cast<unsigned long long*>(smem);
         cache.bmask = lds_slots / 4 - 1;
-        if (a.dense_bins) {
+        if (a.plog) {
+            cache.plog_cur = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
+            cache.plog = a.plog + (size_t)blockIdx.x * kLogParts * a.plog_cap;
+            cache.plog_cap = a.plog_cap;
+            for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) cache.plog_cur[i] = 0u;
+        } else if (a.dense_bins) {
             cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
             cache.dense_bins = a.dense_bins;
             const uint32_t nb = a.dense_bins * (uint32_t)a.n_jobs;
@@ -630,6 +640,13 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
     flush_stats(a, my_reads, my_records);
     if constexpr (kUseLds) {
         lds_cache_flush(cache, a.table);  // starts with a workgroup barrier
+        if (cache.plog_cur) {
+            uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * kLogParts;
+            for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) {
+                const uint32_t n = cache.plog_cur[i];
+                cnt[i] = n < a.plog_cap ? n : a.plog_cap;
+            }
+        }
         if (cache.dense) {
             const uint32_t nb = a.dense_bins * (uint32_t)a.n_jobs;
             uint32_t* row = a.dense_slab + (size_t)blockIdx.x * nb;
@@ -661,6 +678,30 @@ __global__ void __launch_bounds__(1024) dense_merge_kernel(const uint32_t* __res
         for (int g = 0; g < 16; ++g) tot += part[g][lane];
         if (tot) table_add(table, make_key(i / bins, 1, 0, i % bins), tot);
     }
+}
+
+// Aggregation of the partitioned miss log: workgroup p gathers partition p's
+// streams of all classify workgroups (short contiguous runs of keys), counts
+// them in an LDS hash table — a partition holds ~1/1024 of the distinct keys —
+// and adds every distinct key to the count table once.  Partitions are disjoint
+// in key space, so those adds never contend.
+__global__ void __launch_bounds__(1024) partition_merge_kernel(const unsigned long long* __restrict__ plog,
+                                                               const uint32_t* __restrict__ plog_cnt,
+                                                               uint32_t n_rows, uint32_t plog_cap,
+                                                               uint32_t lds_slots, CountTable table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsCache cache{};
+    cache.base = reinterpret_cast<unsigned long long*>(smem);
+    cache.bmask = lds_slots / 4 - 1;
+    lds_cache_init(cache);
+    const uint32_t part = blockIdx.x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    for (uint32_t row = wave; row < n_rows; row += n_waves) {  // one stream per wave at a time
+        const uint32_t n = plog_cnt[(size_t)row * kLogParts + part];
+        const unsigned long long* src = plog + ((size_t)row * kLogParts + part) * plog_cap;
+        for (uint32_t i = lane; i < n; i += 64) cached_add(cache, table, src[i], 1ull);
+    }
+    lds_cache_flush(cache, table);
 }
 
 // Tiled variant.  A workgroup walks over tiles of kTileReads consecutive reads.

@@ -18,6 +18,8 @@ constexpr int kErrFeatureRange = 4;
 constexpr int kErrGroupRange = 8;
 constexpr int kErrPairOverflow = 16;
 
+constexpr uint32_t kLogParts = 1024;  // hash partitions of the miss log
+
 __host__ __device__ __forceinline__ uint64_t make_key(uint32_t job, uint32_t k, uint32_t group,
                                                       uint32_t feature) {
     return ((uint64_t)job << 61) | ((uint64_t)k << 49) | ((uint64_t)group << 28) | (uint64_t)feature;
@@ -84,6 +86,13 @@ struct LdsCache {
     // no key compare, and the bins of all workgroups are merged without atomics
     uint32_t* dense;           // [n_jobs * dense_bins] or null
     uint32_t dense_bins;
+    // partitioned miss log: a key that finds no LDS slot is appended to the
+    // stream of (this workgroup, hash partition) in HBM instead of paying a
+    // device-scope atomic; partition_merge_kernel aggregates each partition in
+    // LDS afterwards.  plog_cur[p] counts the appends of partition p.
+    uint32_t* plog_cur;            // LDS [kLogParts] or null
+    unsigned long long* plog;      // HBM, this workgroup's [kLogParts][plog_cap] keys
+    uint32_t plog_cap;
 #ifdef WK_ABLATE
     uint32_t ablate;
 #endif
@@ -126,11 +135,21 @@ __device__ __forceinline__ void cached_add(const LdsCache& c, const CountTable& 
                                            unsigned long long w) {
     const uint32_t b = hash_key(key) & c.bmask;
     if (bucket_add(c.base + (size_t)b * 8, key, w)) return;
-    if (bucket_add(c.base + (size_t)((b + 1) & c.bmask) * 8, key, w)) return;
+    // with a miss log behind the cache a second probe costs more than a miss
+    if (!c.plog_cur && bucket_add(c.base + (size_t)((b + 1) & c.bmask) * 8, key, w)) return;
 #ifdef WK_ABLATE
     if (c.ablate & 16) return;  // measurement only: drop cache misses
 #endif
-    table_add(t, key, w);  // both buckets taken by other keys: count in HBM directly
+    if (c.plog_cur && w == 1ull) {
+        // partition by the high hash bits (the low bits pick the LDS bucket)
+        const uint32_t part = (hash_key(key) * 0x9E3779B1u) >> 22;  // kLogParts = 2^10
+        const uint32_t pos = atomicAdd(&c.plog_cur[part], 1u);
+        if (pos < c.plog_cap) {
+            c.plog[(size_t)part * c.plog_cap + pos] = key;
+            return;
+        }
+    }
+    table_add(t, key, w);  // no log, or its stream is full: count in HBM directly
 }
 
 __device__ __forceinline__ void lds_cache_flush(const LdsCache& c, const CountTable& t) {

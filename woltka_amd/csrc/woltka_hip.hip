@@ -79,7 +79,9 @@ struct wk_ctx {
     bool rank_tab_valid[WK_MAX_JOBS * 4] = {};
 
     // compact subject table (optional)
-    DevBuf subj_feat, subj_rows, dense_slab;
+    DevBuf subj_feat, subj_rows, dense_slab, plog, plog_cnt;
+    int use_plog = 1;                     // partitioned miss log (auto: large chunks without dense bins)
+    int64_t plog_max_bytes = 4ll << 30;   // upper bound of the miss-log buffer
     int32_t n_subjects = 0;
     int32_t max_subject_feature = -1;
     int use_dense = 1;
@@ -280,6 +282,8 @@ int wk_create(int device, wk_ctx** out) {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&partition_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess) {
         int rc = fail(nullptr, WK_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
         wk_destroy(c);
@@ -296,7 +300,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -341,6 +345,15 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     }
     if (!strcmp(name, "ablate")) {
         c->ablate = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "plog")) {  // 0 = off, 1 = auto (large chunks), 2 = always
+        c->use_plog = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "plog_max_bytes")) {
+        if (value < (1 << 20)) return fail(c, WK_E_ARG, "plog_max_bytes must be at least 1 MiB");
+        c->plog_max_bytes = value;
         return WK_OK;
     }
     if (!strcmp(name, "dense")) {
@@ -687,6 +700,26 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 }
             }
             size_t lds = (size_t)lds_slots * 16;
+            // partitioned miss log: worth its fixed cost (1024-workgroup merge
+            // launch) only when many keys can miss the LDS cache
+            uint32_t plog_cap = 0;
+            if (!bins && (c->use_plog == 2 || (c->use_plog == 1 && c->n_records + c->n_reads >= (1 << 22)))) {
+                bool sized = false;
+                for (int j = 0; j < n_jobs; ++j) sized |= (jobs[j].flags & WK_F_SIZED) != 0;
+                const int64_t streams = (int64_t)blocks * kLogParts;
+                // room for 3x the expected entries per stream if every contribution missed
+                int64_t cap = 3 * ((c->n_records + c->n_reads) * (int64_t)n_jobs / streams + 1) + 16;
+                cap = std::min<int64_t>(cap, c->plog_max_bytes / 8 / streams);
+                if (!sized && cap >= 16) {
+                    plog_cap = (uint32_t)cap;
+                    lds = (size_t)lds_slots * 16 + kLogParts * 4;  // + 4 KiB of stream cursors
+                    HIP_TRY(c, c->plog.reserve((size_t)streams * plog_cap * 8));
+                    HIP_TRY(c, c->plog_cnt.reserve((size_t)streams * 4));
+                    a.plog = c->plog.as<unsigned long long>();
+                    a.plog_cnt = c->plog_cnt.as<uint32_t>();
+                    a.plog_cap = plog_cap;
+                }
+            }
             if (bins) {
                 lds += (size_t)bins * n_jobs * 4;
                 HIP_TRY(c, c->dense_slab.reserve((size_t)blocks * bins * n_jobs * 4));
@@ -694,6 +727,13 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 a.dense_slab = c->dense_slab.as<uint32_t>();
             }
             hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)lds_slots);
+            if (plog_cap) {
+                ktimer_end(c, kt);
+                kt = ktimer_begin(c, "partition_merge");
+                hipLaunchKernelGGL(partition_merge_kernel, dim3(kLogParts), dim3(1024), (size_t)8192 * 16, c->stream,
+                                   c->plog.as<unsigned long long>(), c->plog_cnt.as<uint32_t>(), (uint32_t)blocks,
+                                   plog_cap, 8192u, a.table);
+            }
             if (bins) {
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "dense_merge");
