@@ -151,16 +151,19 @@ struct RowCand {
 // Per-rank-column summary of a read's candidates (inputs of assign_rank)
 struct ColStats {
     int32_t t0, tmin, tmax;
+    int32_t valid;  // records whose ancestor at the rank exists (= k of a list result when the read is a set)
     bool same, none;
 };
 __device__ __forceinline__ void col_init(ColStats& c, int32_t t) {
     c.t0 = c.tmin = c.tmax = t;
+    c.valid = t >= 0 ? 1 : 0;
     c.same = true;
     c.none = t < 0;
 }
 __device__ __forceinline__ void col_update(ColStats& c, int32_t t) {
     c.same &= (t == c.t0);
     c.none |= (t < 0);
+    c.valid += t >= 0 ? 1 : 0;
     c.tmin = t < c.tmin ? t : c.tmin;
     c.tmax = t > c.tmax ? t : c.tmax;
 }
@@ -220,6 +223,11 @@ __device__ __forceinline__ void scan_candidates(const RowCand4<P>& cand, int32_t
             col_update(sc.col[0], rw[q].y);
             col_update(sc.col[1], rw[q].z);
             col_update(sc.col[2], rw[q].w);
+            if (j + q >= n) {  // padding repeats candidate 0: undo its `valid` contribution
+                sc.col[0].valid -= rw[q].y >= 0 ? 1 : 0;
+                sc.col[1].valid -= rw[q].z >= 0 ? 1 : 0;
+                sc.col[2].valid -= rw[q].w >= 0 ? 1 : 0;
+            }
         }
     }
 }
@@ -235,6 +243,7 @@ __device__ __forceinline__ ColStats rank_stats(const C& cand, const ReadScan& sc
         cs.t0 = pick(sc.col[0].t0, sc.col[1].t0, sc.col[2].t0);
         cs.tmin = pick(sc.col[0].tmin, sc.col[1].tmin, sc.col[2].tmin);
         cs.tmax = pick(sc.col[0].tmax, sc.col[1].tmax, sc.col[2].tmax);
+        cs.valid = pick(sc.col[0].valid, sc.col[1].valid, sc.col[2].valid);
         cs.same = pick(sc.col[0].same, sc.col[1].same, sc.col[2].same);
         cs.none = pick(sc.col[0].none, sc.col[1].none, sc.col[2].none);
         return cs;
@@ -242,7 +251,7 @@ __device__ __forceinline__ ColStats rank_stats(const C& cand, const ReadScan& sc
         ColStats cs;
         col_init(cs, cand.tax(0, job));
         for (int32_t j = 1; j < n; ++j) col_update(cs, cand.tax(j, job));
-        return cs;
+        return cs;  // cs.valid counts records; equals the list's k when the read is a set
     }
 }
 
@@ -395,22 +404,34 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                 // entries dropped before k is taken (classify.py:167-168)
                 res = WK_ASSIGN_MULTI;
                 if (g >= 0) {
-                    int32_t kd = 0;
-                    for (int32_t j = 0; j < n; ++j) {
-                        if (cand.tax(j, job) < 0) continue;
-                        if (a.subj_is_set || first_occurrence(cand, j)) kd += 1;
+                    int32_t kd = cs.valid;  // exact when the read is a set
+                    if (!a.subj_is_set) {
+                        kd = 0;
+                        for (int32_t j = 0; j < n; ++j) {
+                            if (cand.tax(j, job) < 0) continue;
+                            if (first_occurrence(cand, j)) kd += 1;
+                        }
                     }
                     if (kd > WK_MAX_K) {
                         atomicOr(a.table.err, kErrKRange);
                     } else {
-                        for (int32_t j = 0; j < n; ++j) {
-                            const int32_t t = cand.tax(j, job);
-                            if (t < 0) continue;
-                            if (a.subj_is_set || first_occurrence(cand, j)) {
-                                if (job.flags & WK_F_SIZED)
-                                    log_append(a, t, cand.feat(j), jb, kd, g);
-                                else
-                                    count_add<kUseLds>(cache, a.table, jb, kd, g, (uint32_t)t);
+                        // candidates in groups of four: their table values are
+                        // gathered back to back before any is counted
+                        for (int32_t j0 = 0; j0 < n; j0 += 4) {
+                            int32_t t4[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) t4[q] = (j0 + q < n) ? cand.tax(j0 + q, job) : -1;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int32_t t = t4[q];
+                                if (t < 0) continue;
+                                const int32_t j = j0 + q;
+                                if (a.subj_is_set || first_occurrence(cand, j)) {
+                                    if (job.flags & WK_F_SIZED)
+                                        log_append(a, t, cand.feat(j), jb, kd, g);
+                                    else
+                                        count_add<kUseLds>(cache, a.table, jb, kd, g, (uint32_t)t);
+                                }
                             }
                         }
                     }
