@@ -36,6 +36,7 @@ struct MatchArgs {
     const int32_t* gend;        // [n_genes]
     const int32_t* gpmax;       // [n_genes] running max of gend inside the genome
     const int32_t* gfeat;       // [n_genes] feature id
+    const int4* gene4;          // [n_genes] {start0, end, running max end, feature}: one gather per scanned gene
     int32_t n_genomes;
 };
 
@@ -71,11 +72,12 @@ template <typename F>
 __device__ __forceinline__ void scan_matches(const MatchArgs& a, const HitQuery& q, int32_t ub, F&& f) {
     const int64_t min_end = q.rs + q.rel;
     for (int32_t j = ub - 1; j >= q.lo; --j) {
-        if ((int64_t)a.gpmax[j] < min_end) break;  // nothing at or before j reaches the hit
-        const int64_t gs = a.gstart[j];
-        const int64_t ge = a.gend[j];
+        const int4 g = a.gene4[j];
+        if ((int64_t)g.z < min_end) break;  // nothing at or before j reaches the hit
+        const int64_t gs = g.x;
+        const int64_t ge = g.y;
         const int64_t ov = (ge < q.re ? ge : q.re) - (gs > q.rs ? gs : q.rs);
-        if (ov >= q.rel) f(j);
+        if (ov >= q.rel) f(g.w);
     }
 }
 
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(kMatchThreads) match_write_kernel(MatchArgs a,
             poff[h] = (int32_t)o;
             if (cnt[h] > 0) {  // only matching hits re-scan (no second search)
                 int64_t w = o;
-                scan_matches(a, load_hit(a, h), ubound[h], [&](int32_t j) { pairs[w++] = a.gfeat[j]; });
+                scan_matches(a, load_hit(a, h), ubound[h], [&](int32_t feat) { pairs[w++] = feat; });
             }
         }
     }

@@ -90,7 +90,7 @@ struct wk_ctx {
     bool subj_indexed = false;  // staged chunk carries subject indices
 
     // genes
-    DevBuf genome_off, gstart, gend, gpmax, gfeat;
+    DevBuf genome_off, gstart, gend, gpmax, gfeat, gene4;
     int32_t n_genomes = 0, n_genes = 0;
 
     // count table
@@ -297,7 +297,7 @@ void wk_destroy(wk_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat,
+    DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_poff, &c->o_pairs, &c->o_qoff,
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->assign_out, &c->fetch_k, &c->fetch_v};
@@ -447,6 +447,14 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
     if ((rc = upload(c, c->gend, end, (size_t)n_genes * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->gpmax, pmax.data(), (size_t)n_genes * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->gfeat, gene_feature, (size_t)n_genes * sizeof(int32_t)))) return rc;
+    std::vector<int32_t> packed((size_t)n_genes * 4);
+    for (int32_t i = 0; i < n_genes; ++i) {
+        packed[4 * (size_t)i] = start0[i];
+        packed[4 * (size_t)i + 1] = end[i];
+        packed[4 * (size_t)i + 2] = pmax[i];
+        packed[4 * (size_t)i + 3] = gene_feature[i];
+    }
+    if ((rc = upload(c, c->gene4, packed.data(), packed.size() * sizeof(int32_t)))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_genomes = n_genomes;
     c->n_genes = n_genes;
@@ -816,6 +824,7 @@ int wk_ordinal_match(wk_ctx* c) {
     a.gend = c->gend.as<int32_t>();
     a.gpmax = c->gpmax.as<int32_t>();
     a.gfeat = c->gfeat.as<int32_t>();
+    a.gene4 = c->gene4.as<int4>();
     a.n_genomes = c->n_genomes;
 
     unsigned long long total = 0;
