@@ -269,6 +269,21 @@ int wk_tok_sam(wk_tok* tok, const char* buf, int64_t len, int first_block,
  * (byte offset in buf << 24) | (length << 2) | mate.  NULL skips an array. */
 int wk_tok_fetch(wk_tok* tok, int32_t* subj, int32_t* off, int32_t* beg,
                  int32_t* end, uint32_t* len, uint64_t* qname);
+/* `want_names` of wk_tok_sam is a bit set: 1 = QNAME descriptors, 2 = stratum of
+ * every read (read id = QNAME + "" | "/1" | "/2" looked up in the table loaded
+ * with wk_tok_strata_load; -1 = not found: the read is skipped by the
+ * stratified counters, classify.py:239).  wk_tok_fetch_groups copies them. */
+int wk_tok_fetch_groups(wk_tok* tok, int32_t* group);
+/* Stratification map of the current sample (file.read_map_uniq +
+ * workflow.read_strata; file.py:368-385, workflow.py:912-938): lines
+ * "read id <tab> label" with exactly two columns, appended block by block
+ * (blocks must end at line ends).  Labels get stratum ids in order of first
+ * appearance; a repeated read id keeps its last label. */
+int wk_tok_strata_clear(wk_tok* tok);
+int wk_tok_strata_load(wk_tok* tok, const char* buf, int64_t len,
+                       int64_t* n_entries, int32_t* n_labels);
+int wk_tok_strata_labels(wk_tok* tok, char* blob /* NULL: sizes only */,
+                         int64_t* off /* [n_labels + 1] */);
 /* Dictionary growth: total subjects, subjects not yet reported, their bytes. */
 int wk_tok_subjects(wk_tok* tok, int32_t* n_total, int32_t* n_new,
                     int64_t* new_bytes);

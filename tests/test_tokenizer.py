@@ -146,3 +146,31 @@ def test_mmap_path_equals_stream_path(tmp_path):
                 del buf
         tok.close()
         assert reads == exp
+
+
+def test_native_strata_join_matches_python():
+    v = load_vectors('parsers.json')
+    lines = v['synth']['lines']
+    text = ''.join(lines).encode()
+    pairs = list(align.parse_align(lines, 'sam'))
+    queries = [q for q, _ in pairs]
+    rng = np.random.default_rng(3)
+    keep = [q for q in queries if rng.random() < 0.7]
+    rows = [f'{q}\tL{int(rng.integers(0, 5))} \n' for q in keep]
+    rows += ['bad\tline\textra\n', 'nolabel\n', f'{keep[0]}\tLAST\n']
+    # Python semantics: exactly two columns, label rstripped, last one wins
+    from woltka_amd.file import read_map_uniq
+    exp_map = dict(read_map_uniq(iter(rows)))
+    for threads, block in ((1, 1 << 20), (4, 600)):
+        tok = Tokenizer(threads)
+        labels = tok.load_strata(io.BytesIO(''.join(rows).encode()), 256)
+        got = []
+        for buf, res in align.native_sam_blocks(io.BytesIO(text), tok, block,
+                                                want_groups=True):
+            got.extend(res['group'].tolist())
+        tok.close()
+        assert len(got) == len(queries)
+        assert [labels[g] if g >= 0 else None for g in got] == \
+            [exp_map.get(q) for q in queries]
+    tok = Tokenizer(1)
+    assert tok.load_strata(io.BytesIO(b'no tab here\n')) == []

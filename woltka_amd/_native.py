@@ -42,7 +42,8 @@ SYMBOLS = (
     'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
     'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_fetch', 'wk_tok_subjects',
-    'wk_tok_new_subjects')
+    'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
+    'wk_tok_strata_load', 'wk_tok_strata_labels')
 
 
 class Job(C.Structure):
@@ -122,6 +123,10 @@ def load_library():
         'wk_tok_fetch': (C.c_int, [p, i32p, i32p, i32p, i32p, u32p, u64p]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
+        'wk_tok_fetch_groups': (C.c_int, [p, i32p]),
+        'wk_tok_strata_clear': (C.c_int, [p]),
+        'wk_tok_strata_load': (C.c_int, [p, C.c_void_p, C.c_int64, i64p, i32p]),
+        'wk_tok_strata_labels': (C.c_int, [p, C.c_char_p, i64p]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -430,11 +435,44 @@ class Tokenizer:
         except Exception:
             pass
 
+    def load_strata(self, stream, block_bytes=1 << 27):
+        """Load a read-to-stratum map (binary stream) for the sample that is
+        about to be parsed; returns the label names (index = stratum id)."""
+        self._check(self._lib.wk_tok_strata_clear(self._h))
+        n_ent, n_lab = C.c_int64(0), C.c_int32(0)
+        carry = b''
+        while True:
+            data = stream.read(block_bytes)
+            buf = carry + data
+            if not data:
+                cut = len(buf)
+            else:
+                cut = buf.rfind(b'\n') + 1
+            if cut:
+                raw = np.frombuffer(buf, dtype=np.uint8, count=cut)
+                self._check(self._lib.wk_tok_strata_load(
+                    self._h, C.c_void_p(raw.ctypes.data), cut,
+                    C.byref(n_ent), C.byref(n_lab)))
+            carry = buf[cut:]
+            if not data:
+                break
+        if n_ent.value == 0:
+            return []
+        off = np.empty(n_lab.value + 1, dtype=np.int64)
+        self._check(self._lib.wk_tok_strata_labels(self._h, None,
+                                                   _ptr(off, C.c_int64)))
+        blob = C.create_string_buffer(max(1, int(off[-1])))
+        self._check(self._lib.wk_tok_strata_labels(self._h, blob,
+                                                   _ptr(off, C.c_int64)))
+        raw, o = blob.raw, off.tolist()
+        return [raw[o[i]:o[i + 1]].decode() for i in range(n_lab.value)]
+
     def parse(self, buf, first=False, final=False, extra=False,
-              want_names=False):
+              want_names=False, want_groups=False):
         """Tokenize ``buf`` (bytes-like).  Returns a dict with ``consumed``,
         ``subj``, ``off`` (+ ``beg``/``end``/``len`` with ``extra``,
-        ``qname`` descriptors with ``want_names``)."""
+        ``qname`` descriptors with ``want_names``, ``group`` = stratum ids with
+        ``want_groups``)."""
         mv = memoryview(buf)
         n = mv.nbytes
         addr = C.c_void_p(np.frombuffer(mv, dtype=np.uint8).ctypes.data) \
@@ -444,7 +482,8 @@ class Tokenizer:
         consumed, nrd, nrec = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._lib.wk_tok_sam(
             self._h, addr, n, int(first), int(final), int(extra),
-            int(want_names), C.byref(consumed), C.byref(nrd), C.byref(nrec)))
+            int(bool(want_names)) | (2 if want_groups else 0),
+            C.byref(consumed), C.byref(nrd), C.byref(nrec)))
         out = {'consumed': consumed.value,
                'subj': np.empty(nrec.value, np.int32),
                'off': np.empty(nrd.value + 1, np.int32)}
@@ -459,6 +498,10 @@ class Tokenizer:
             _ptr(out.get('beg'), C.c_int32), _ptr(out.get('end'), C.c_int32),
             _ptr(out.get('len'), C.c_uint32),
             _ptr(out.get('qname'), C.c_uint64)))
+        if want_groups:
+            out['group'] = np.empty(nrd.value, np.int32)
+            self._check(self._lib.wk_tok_fetch_groups(
+                self._h, _ptr(out['group'], C.c_int32)))
         return out
 
     def new_subjects(self):

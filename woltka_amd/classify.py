@@ -130,6 +130,9 @@ class Engine:
         # native SAM tokenizer (created on first use) and the translation of
         # its subject ids into `self.subjects` indices / genome indices
         self.tok = None
+        self._exclude = None
+        self._gmap_key, self._gmap = None, None
+        self._epoch = 0
         self._tok_map = np.empty(0, dtype=np.int32)
         self._tok_identity = True
         self._tok_genome = np.empty(0, dtype=np.int32)
@@ -140,8 +143,22 @@ class Engine:
         self.ctx.close()
 
     # ------------------------------------------------------------------
+    def load_strata(self, fp, zippers):
+        """Read-to-stratum map of one sample into the native tokenizer;
+        returns the stratum labels (workflow.read_strata, workflow.py:912-938)."""
+        from os.path import basename
+        from .file import readzip_bytes
+        if self.tok is None:
+            self.tok = nat.Tokenizer(0, self._exclude)
+        with readzip_bytes(fp, zippers) as fh:
+            labels = self.tok.load_strata(fh)
+        if not labels:
+            raise ValueError('No stratification information is found in file: '
+                             f'{basename(fp)}.')
+        return labels
+
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
-                      want_names, trimsub=None):
+                      want_names, trimsub=None, want_groups=False):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed) where packed = (subj, qoff) of subject indices,
         or for coord-match (genome, beg, end, length, hoff)."""
@@ -154,7 +171,8 @@ class Engine:
             for buf, res in native_sam_blocks(stream, tok, block_bytes,
                                               extra=ordinal,
                                               want_names=want_names,
-                                              head=head):
+                                              head=head,
+                                              want_groups=want_groups):
                 # the dictionary growth belongs to this block: fetch it before
                 # the tokenizer moves on
                 yield buf, res, tok.new_subjects()
@@ -189,7 +207,7 @@ class Engine:
                     else self._tok_map[res['subj']]
                 packed = (subj, res['off'])
             if res['off'].size > 1:
-                yield reads, packed
+                yield reads, packed, res.get('group')
 
     # ------------------------------------------------------------------
     def set_genes(self, table, prefix):
@@ -256,8 +274,31 @@ class Engine:
                 out[i] = -1 if t is None else get(s, t)
         return out
 
+    def _strata_groups(self, sample, labels, ids):
+        """Stratum ids of the native tokenizer -> group ids of (sample, label)
+        pairs; -1 (read not in the strata map) stays -1."""
+        key = (sample, self._epoch, len(labels))
+        if self._gmap_key != key:
+            gid, groups = self.group_ids, self.groups
+            gmap = np.empty(len(labels), dtype=np.int32)
+            for i, lab in enumerate(labels):
+                k = (sample, lab)
+                g = gid.get(k)
+                if g is None:
+                    g = len(groups)
+                    if g >= MAX_GROUPS:
+                        raise ValueError('Too many (sample, stratum) groups '
+                                         'in one pass.')
+                    gid[k] = g
+                    groups.append(k)
+                gmap[i] = g
+            self._gmap_key, self._gmap = key, gmap
+        return np.where(ids >= 0, self._gmap[np.maximum(ids, 0)],
+                        -1).astype(np.int32)
+
     def run_chunk(self, data, reads, subque, sample_of, strata_of, trimsub,
-                  rank2dir, outzip, namedic, ordinal, packed=None):
+                  rank2dir, outzip, namedic, ordinal, packed=None,
+                  strata_ids=None, strata_labels=None):
         """Classify one chunk at every rank; returns the number of queries the
         reference would report for it (workflow.py:305).  ``packed`` carries
         arrays produced by the native tokenizer instead of ``subque`` / staged
@@ -265,7 +306,10 @@ class Engine:
         n = len(reads) if packed is None else packed[-1].size - 1
         if len(self.groups) + n + 1 >= MAX_GROUPS // 2:
             self.collect(data)
-        group = self._group_array(n, sample_of, strata_of)
+        if strata_ids is not None:
+            group = self._strata_groups(sample_of, strata_labels, strata_ids)
+        else:
+            group = self._group_array(n, sample_of, strata_of)
         # every sample met in a chunk gets a (possibly empty) profile at every
         # rank, like `data[rank].setdefault(sample, {})` in workflow.py:1058
         seen = (set(sample_of) - {False}) if isinstance(sample_of, list) \
@@ -435,6 +479,7 @@ class Engine:
         self.ctx.counts_clear()
         self.groups = []
         self.group_ids = {}
+        self._epoch += 1
 
     def finish(self, data):
         """Final collection; exact rationals become the numbers the reference

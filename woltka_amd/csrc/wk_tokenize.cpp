@@ -95,6 +95,7 @@ struct Local {
     std::vector<Record> rec;     // records of emitted reads, read-major
     std::vector<int32_t> rend;   // per read: end offset into rec
     std::vector<uint64_t> qname; // per read: (offset << 24) | (len << 2) | mate
+    std::vector<int32_t> group;  // per read: stratum id or -1 (want_groups)
     NameTable fresh;             // names not yet in the global table
     int error = 0;               // 1 = both mate bits, 2 = malformed line
     size_t error_at = 0;
@@ -185,13 +186,21 @@ struct wk_tok {
     std::vector<uint64_t> qname;
     int32_t reported = 0;  // subjects already handed to the caller
     bool in_header = false; // still inside the leading '@' lines of a file
+    // stratification of the current sample: read id -> stratum (file.read_map_uniq
+    // + workflow.read_strata, file.py:368-385, workflow.py:912-938)
+    NameTable strata_keys;
+    std::vector<int32_t> strata_of;  // per key id
+    NameTable strata_labels;
+    std::vector<int32_t> group;      // per read of the last call: stratum id or -1
 };
 
 namespace {
 
 void tokenize_range(const wk_tok* T, const char* base, const char* b, const char* e, bool extra, bool want_names,
-                    Local& out) {
+                    bool want_groups, Local& out) {
     const bool filt = T->exclude.size() > 0;
+    static const char* const kSuffix[3] = {"", "/1", "/2"};
+    std::string keybuf;
     // current run state
     const char* cur = nullptr;
     size_t cur_n = 0;
@@ -207,6 +216,12 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
             out.rec.insert(out.rec.end(), pool[m].begin(), pool[m].end());
             out.rend.push_back((int32_t)out.rec.size());
             if (want_names) out.qname.push_back(((uint64_t)(cur - base) << 24) | ((uint64_t)cur_n << 2) | (uint64_t)m);
+            if (want_groups) {  // stratum of read id = QNAME + mate suffix
+                keybuf.assign(cur, cur_n);
+                keybuf.append(kSuffix[m]);
+                const int32_t id = T->strata_keys.find(keybuf.data(), keybuf.size(), hash_bytes(keybuf.data(), keybuf.size()));
+                out.group.push_back(id < 0 ? -1 : T->strata_of[id]);
+            }
             pool[m].clear();
         }
     };
@@ -360,6 +375,7 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
             t->subj.clear();
             t->off.assign(1, 0);
             t->qname.clear();
+            t->group.clear();
             t->beg.clear();
             t->end.clear();
             t->len.clear();
@@ -407,12 +423,14 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
         if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1];
     std::vector<Local> loc(T);
     if (T == 1) {
-        tokenize_range(t, buf, cut[0], cut[1], extra != 0, want_names != 0, loc[0]);
+        tokenize_range(t, buf, cut[0], cut[1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0, loc[0]);
     } else {
         std::vector<std::thread> th;
         th.reserve(T);
         for (int i = 0; i < T; ++i)
-            th.emplace_back([&, i] { tokenize_range(t, buf, cut[i], cut[i + 1], extra != 0, want_names != 0, loc[i]); });
+            th.emplace_back([&, i] {
+                tokenize_range(t, buf, cut[i], cut[i + 1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0, loc[i]);
+            });
         for (auto& x : th) x.join();
     }
     for (int i = 0; i < T; ++i)
@@ -451,7 +469,8 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
     }
     t->subj.resize(tot_rec);
     t->off.resize(tot_reads + 1);
-    t->qname.resize(want_names ? tot_reads : 0);
+    t->qname.resize((want_names & 1) ? tot_reads : 0);
+    t->group.resize((want_names & 2) ? tot_reads : 0);
     if (extra) {
         t->beg.resize(tot_rec);
         t->end.resize(tot_rec);
@@ -480,8 +499,10 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
             }
         }
         for (size_t k = 0; k < L.rend.size(); ++k) t->off[qb + k + 1] = (int32_t)(rb + L.rend[k]);
-        if (want_names)
+        if (want_names & 1)
             for (size_t k = 0; k < L.qname.size(); ++k) t->qname[qb + k] = L.qname[k];
+        if (want_names & 2)
+            for (size_t k = 0; k < L.group.size(); ++k) t->group[qb + k] = L.group[k];
     };
     if (T == 1) {
         copy_out(0);
@@ -504,6 +525,67 @@ int wk_tok_fetch(wk_tok* t, int32_t* subj, int32_t* off, int32_t* beg, int32_t* 
     if (end && !t->end.empty()) memcpy(end, t->end.data(), t->end.size() * 4);
     if (len && !t->len.empty()) memcpy(len, t->len.data(), t->len.size() * 4);
     if (qname && !t->qname.empty()) memcpy(qname, t->qname.data(), t->qname.size() * 8);
+    return WK_OK;
+}
+
+int wk_tok_fetch_groups(wk_tok* t, int32_t* group) {
+    if (!t) return WK_E_ARG;
+    if (group && !t->group.empty()) memcpy(group, t->group.data(), t->group.size() * 4);
+    return WK_OK;
+}
+
+int wk_tok_strata_clear(wk_tok* t) {
+    if (!t) return WK_E_ARG;
+    t->strata_keys = NameTable();
+    t->strata_of.clear();
+    t->strata_labels = NameTable();
+    return WK_OK;
+}
+
+// Lines "read id <tab> label" with exactly two columns; the label loses its
+// trailing white space; a repeated read id keeps its last label (dict()).
+int wk_tok_strata_load(wk_tok* t, const char* buf, int64_t len, int64_t* n_entries, int32_t* n_labels) {
+    if (!t || (len > 0 && !buf) || len < 0) return WK_E_ARG;
+    const char* p = buf;
+    const char* e = buf + len;
+    while (p < e) {
+        const char* nl = (const char*)memchr(p, '\n', e - p);
+        const char* le = nl ? nl + 1 : e;  // line including its newline
+        const char* tab = (const char*)memchr(p, '\t', le - p);
+        if (tab && !memchr(tab + 1, '\t', le - tab - 1)) {
+            const char* vb = tab + 1;
+            const char* ve = le;
+            while (ve > vb && (ve[-1] == '\n' || ve[-1] == '\r' || ve[-1] == ' ' || ve[-1] == '\v' || ve[-1] == '\f')) --ve;
+            const size_t kn = (size_t)(tab - p);
+            const uint64_t kh = hash_bytes(p, kn);
+            const uint64_t lh = hash_bytes(vb, (size_t)(ve - vb));
+            int32_t lab = t->strata_labels.find(vb, (size_t)(ve - vb), lh);
+            if (lab < 0) lab = t->strata_labels.add(vb, (size_t)(ve - vb), lh);
+            int32_t id = t->strata_keys.find(p, kn, kh);
+            if (id < 0) {
+                id = t->strata_keys.add(p, kn, kh);
+                t->strata_of.push_back(lab);
+            } else {
+                t->strata_of[id] = lab;
+            }
+        }
+        p = le;
+    }
+    if (n_entries) *n_entries = t->strata_keys.size();
+    if (n_labels) *n_labels = t->strata_labels.size();
+    return WK_OK;
+}
+
+// Label names: blob (NULL = size query) and off[n_labels + 1]
+int wk_tok_strata_labels(wk_tok* t, char* blob, int64_t* off) {
+    if (!t || !off) return WK_E_ARG;
+    int64_t w = 0;
+    off[0] = 0;
+    for (int32_t i = 0; i < t->strata_labels.size(); ++i) {
+        if (blob) memcpy(blob + w, t->strata_labels.arena.data() + t->strata_labels.off[i], t->strata_labels.len[i]);
+        w += t->strata_labels.len[i];
+        off[i + 1] = w;
+    }
     return WK_OK;
 }
 

@@ -206,7 +206,11 @@ def classify(mapper:  object,
         # parsers.  Query names are materialised only when something needs them.
         native_ok = (mapper is plain_mapper or ordinal) and \
             not (ordinal and exclude) and not (ordinal and trimsub)
-        want_names = bool(demux or stratmap or rank2dir is not None)
+        # stratification without demultiplexing is joined natively (read id ->
+        # stratum inside the tokenizer)
+        native_strata = bool(stratmap) and not demux
+        engine._exclude = exclude
+        labels = None
         for fp in sorted(files):
             if fp == '-':
                 stream = click.get_binary_stream('stdin')
@@ -222,10 +226,18 @@ def classify(mapper:  object,
                     fmt_ = infer_align_format(iter(
                         [head.decode()] if head else []))[0]
                 native = native_ok and fmt_ == 'sam'
+                want_names = bool(demux or rank2dir is not None or
+                                  (stratmap and not (native and native_strata)))
                 if native:
+                    if native_strata:
+                        sample = files[fp] if files else None
+                        if sample != csample or labels is None:
+                            labels = engine.load_strata(stratmap[sample],
+                                                        zippers)
+                            csample = sample
                     chunks = engine.native_chunks(
                         stream, head, exclude, NATIVE_BLOCK, ordinal,
-                        want_names, trimsub)
+                        want_names, trimsub, want_groups=native_strata)
                 else:
                     text = io.TextIOWrapper(stream, encoding='utf-8')
                     fh = chain([head.decode()], text) if head else text
@@ -235,9 +247,9 @@ def classify(mapper:  object,
                     else:
                         chunks = mapper(fh, fmt=fmt_, excl=exclude, n=n)
                 for chunk_ in chunks:
-                    packed = None
+                    packed = strata_ids = None
                     if native:
-                        qryque, packed = chunk_
+                        qryque, packed, strata_ids = chunk_
                         subque = None
                         engine._th = mapper.th if ordinal else None
                     elif ordinal:
@@ -254,14 +266,15 @@ def classify(mapper:  object,
                     # stratum of every read; the strata map of a sample is read
                     # when the sample first shows up (workflow.py:327-330)
                     strata_of = None
-                    if stratmap:
+                    if stratmap and strata_ids is None:
                         strata_of, csample, strata = strata_labels(
                             sample_of, reads, stratmap, zippers, csample,
                             strata)
                     nq = engine.run_chunk(
                         data, reads, subque, sample_of, strata_of,
                         None if native else trimsub,
-                        rank2dir, outzip, namedic, ordinal, packed=packed)
+                        rank2dir, outzip, namedic, ordinal, packed=packed,
+                        strata_ids=strata_ids, strata_labels=labels)
                     nqry += nq
                     istep = nqry // 1000000 - nstep
                     if istep:
