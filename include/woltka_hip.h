@@ -284,6 +284,20 @@ int wk_tok_strata_load(wk_tok* tok, const char* buf, int64_t len,
                        int64_t* n_entries, int32_t* n_labels);
 int wk_tok_strata_labels(wk_tok* tok, char* blob /* NULL: sizes only */,
                          int64_t* off /* [n_labels + 1] */);
+/* Read-map text (file.write_readmap, file.py:469-500), multi-threaded.  One line
+ * per assigned read: "read id <tab> name", or "read id <tab> name:n <tab> ..."
+ * for a read split over several features; such reads (assign[r] ==
+ * WK_ASSIGN_MULTI) take their (feature, count) lists, already sorted by
+ * descending count then feature id string, from m_feat/m_count[m_off[i] ..
+ * m_off[i+1]) in read order.  Unassigned reads are written as "Unassigned" when
+ * `unassigned`, else skipped.  names_blob/names_off give the text printed for
+ * feature id f.  With out == NULL only *written (the size) is computed. */
+int wk_format_readmap(const char* text, const uint64_t* qname,
+                      const int32_t* assign, int64_t n_reads,
+                      const int64_t* m_off, const int32_t* m_feat,
+                      const int32_t* m_count, const char* names_blob,
+                      const int64_t* names_off, int32_t n_names, int unassigned,
+                      int n_threads, char* out, int64_t cap, int64_t* written);
 /* Dictionary growth: total subjects, subjects not yet reported, their bytes. */
 int wk_tok_subjects(wk_tok* tok, int32_t* n_total, int32_t* n_new,
                     int64_t* new_bytes);

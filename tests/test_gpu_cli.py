@@ -170,3 +170,50 @@ def test_native_strata_equals_python_path(tmp_path):
         d_python = workflow.classify(python_only, files, **kw)
     assert d_native == d_python
     assert any(isinstance(k, tuple) for k in d_native['none']['S01'])
+
+
+@pytest.mark.parametrize('extra', [['--rank', 'genus', '--name-as-id',
+                                    '--names', join(TAX, 'names.dmp'),
+                                    '--unassigned'],
+                                   ['--rank', 'none'],
+                                   ['--rank', 'species,free', '--zipmap', 'xz']])
+def test_native_readmaps_equal_python_path(tmp_path, extra):
+    """SAM + --outmap: read maps formatted by the native writer equal the
+    ones written by the Python path (forced through a wrapped mapper)."""
+    import contextlib
+    import io
+    import lzma
+    from click.testing import CliRunner
+    from woltka_amd import align, cli, workflow
+    base = ['--input', join(ALN, 'bt2sho'), '--nodes', join(TAX, 'nodes.dmp'),
+            '--map', join(TAX, 'taxid.map'), '--no-exe'] + extra
+
+    def invoke(tag):
+        out = tmp_path / tag
+        res = CliRunner().invoke(cli.classify_cmd, base + [
+            '--output', str(out / 'o'), '--outmap', str(out / 'maps'),
+            '--to-tsv'])
+        assert res.exit_code == 0, res.output + repr(res.exception)
+        texts = {}
+        for dirpath, _, files in os.walk(out / 'maps'):
+            for fn in files:
+                fp = os.path.join(dirpath, fn)
+                opener = lzma.open if fn.endswith('.xz') else gzip.open
+                with opener(fp, 'rt') as f:
+                    texts[os.path.relpath(fp, out / 'maps')] = f.read()
+        return texts
+    native = invoke('native')
+    real = workflow.build_mapper
+
+    def python_only(*a, **k):
+        return align.plain_mapper(*a, **k)
+    workflow.build_mapper = lambda *a, **k: (python_only, real(*a, **k)[1])
+    try:
+        python = invoke('python')
+    finally:
+        workflow.build_mapper = real
+    assert native.keys() == python.keys() and len(native) >= 5
+    assert native == python
+    assert any('\t' in line and ':' in line
+               for t in native.values() for line in t.splitlines()) or \
+        extra[1] == 'genus'

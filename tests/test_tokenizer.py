@@ -174,3 +174,81 @@ def test_native_strata_join_matches_python():
             [exp_map.get(q) for q in queries]
     tok = Tokenizer(1)
     assert tok.load_strata(io.BytesIO(b'no tab here\n')) == []
+
+
+def test_native_readmap_format_matches_python():
+    from woltka_amd import _native as nat
+    from woltka_amd.file import write_readmap
+    v = load_vectors('parsers.json')
+    lines = v['synth']['lines']
+    text = ''.join(lines).encode()
+    tok = Tokenizer(2)
+    res = tok.parse(text, first=True, final=True, want_names=True)
+    queries = Tokenizer.query_names(text, res['qname'])
+    rng = np.random.default_rng(9)
+    feats = [f'T{i}' for i in range(12)] + ['a longer name with spaces']
+    namedic = {'T3': 'Three', 'T7': 'Seven seven'}
+    n = len(queries)
+    assign = np.empty(n, np.int32)
+    taxque, m_off, m_feat, m_count = [], [0], [], []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.5:
+            f = int(rng.integers(0, len(feats)))
+            assign[i] = f
+            taxque.append(feats[f])
+        elif r < 0.65:
+            assign[i] = nat.ASSIGN_NONE
+            taxque.append(None)
+        elif r < 0.7:
+            assign[i] = nat.ASSIGN_EMPTY
+            taxque.append(False)
+        else:
+            assign[i] = nat.ASSIGN_MULTI
+            k = int(rng.integers(2, 6))
+            lst = [feats[int(x)] for x in rng.integers(0, len(feats), k)]
+            taxque.append(lst)
+            tally = {}
+            for t in lst:
+                tally[t] = tally.get(t, 0) + 1
+            for t, c in sorted(tally.items(), key=lambda x: (-x[1], x[0])):
+                m_feat.append(feats.index(t))
+                m_count.append(c * int(rng.choice([1, 1, 13, 1234])))
+            m_off.append(len(m_feat))
+    # python expectation (counts rewritten to the scaled ones)
+    it = iter(range(len(m_off) - 1))
+    for unassigned in (False, True):
+        shown = [namedic.get(x, x) for x in feats]
+        got = nat.format_readmap(text, res['qname'], assign, m_off, m_feat,
+                                 m_count, shown, unassigned=unassigned,
+                                 n_threads=3).decode()
+        exp = []
+        mi = 0
+        for q, a, tx in zip(queries, assign.tolist(), taxque):
+            if a >= 0:
+                exp.append(f'{q}\t{shown[a]}')
+            elif a == nat.ASSIGN_MULTI:
+                cols = [f'{shown[m_feat[k]]}:{m_count[k]}'
+                        for k in range(m_off[mi], m_off[mi + 1])]
+                exp.append('\t'.join([q] + cols))
+                mi += 1
+            elif a == nat.ASSIGN_NONE and unassigned:
+                exp.append(f'{q}\tUnassigned')
+        assert got == ''.join(x + '\n' for x in exp)
+    # and the unscaled lists agree with file.write_readmap itself
+    buf = io.StringIO()
+    tq = [t if t is not False else None for t in taxque]
+    write_readmap(buf, queries, tq, namedic)
+    m_count1 = []
+    for t in taxque:
+        if isinstance(t, list):
+            tally = {}
+            for x in t:
+                tally[x] = tally.get(x, 0) + 1
+            m_count1 += [c for _, c in sorted(tally.items(),
+                                              key=lambda x: (-x[1], x[0]))]
+    got = nat.format_readmap(text, res['qname'], assign, m_off, m_feat,
+                             m_count1, [namedic.get(x, x) for x in feats]
+                             ).decode()
+    assert got == buf.getvalue()
+    tok.close()

@@ -43,7 +43,7 @@ SYMBOLS = (
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
     'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_fetch', 'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
-    'wk_tok_strata_load', 'wk_tok_strata_labels')
+    'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap')
 
 
 class Job(C.Structure):
@@ -127,6 +127,10 @@ def load_library():
         'wk_tok_strata_clear': (C.c_int, [p]),
         'wk_tok_strata_load': (C.c_int, [p, C.c_void_p, C.c_int64, i64p, i32p]),
         'wk_tok_strata_labels': (C.c_int, [p, C.c_char_p, i64p]),
+        'wk_format_readmap': (C.c_int, [C.c_void_p, u64p, i32p, C.c_int64, i64p,
+                                        i32p, i32p, C.c_char_p, i64p, C.c_int32,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                        i64p]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -529,3 +533,35 @@ class Tokenizer:
             o, ln, m = d >> 24, (d >> 2) & 0x3FFFFF, d & 3
             out.append(mv[o:o + ln].decode() + cls.MATE_SUFFIX[m])
         return out
+
+
+def format_readmap(buf, qname, assign, m_off, m_feat, m_count, names,
+                   unassigned=False, n_threads=0):
+    """Read-map text (bytes) of one chunk through ``wk_format_readmap``.
+    ``names[f]`` is the text printed for feature id ``f`` (list of str)."""
+    lib = load_library()
+    enc = [x.encode() for x in names]
+    noff = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in enc], out=noff[1:])
+    blob = b''.join(enc)
+    qname = _arr(qname, np.uint64)
+    assign = _arr(assign, np.int32)
+    m_off = _arr(m_off, np.int64)
+    m_feat = _arr(m_feat, np.int32)
+    m_count = _arr(m_count, np.int32)
+    raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+    text = C.c_void_p(raw.ctypes.data if raw.size else 0)
+    if raw.size == 0:
+        text = C.cast(C.c_char_p(b''), C.c_void_p)
+    n = C.c_int64(0)
+    args = (text, _ptr(qname, C.c_uint64), _ptr(assign, C.c_int32),
+            assign.size, _ptr(m_off, C.c_int64), _ptr(m_feat, C.c_int32),
+            _ptr(m_count, C.c_int32), blob, _ptr(noff, C.c_int64), len(enc),
+            int(bool(unassigned)), int(n_threads))
+    if lib.wk_format_readmap(*args, None, 0, C.byref(n)) != OK:
+        raise ValueError('wk_format_readmap: bad arguments')
+    out = np.empty(n.value, dtype=np.uint8)
+    if n.value and lib.wk_format_readmap(
+            *args, C.c_void_p(out.ctypes.data), n.value, C.byref(n)) != OK:
+        raise RuntimeError('wk_format_readmap failed')
+    return out.tobytes()

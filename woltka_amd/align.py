@@ -322,9 +322,13 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
         yield view[:fill], res
         if final:
             return
-        del view
+        # the consumer (possibly a block behind, in another thread) still
+        # reads read ids out of this buffer: continue in a fresh one
         rest = fill - used
-        buf[:rest] = buf[used:fill]
+        nxt = bytearray(max(len(buf), rest + block_bytes))
+        nxt[:rest] = view[used:fill]
+        del view
+        buf = nxt
         fill = rest
 
 

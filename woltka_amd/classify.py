@@ -50,6 +50,40 @@ def _prefetch(gen, depth=2):
     th.join()
 
 
+def _append_compressed(path, data, kind, block=8 << 20):
+    """Append ``data`` (bytes of whole lines) to ``path``; gz / bz2 / xz output
+    is written as independent members compressed in parallel (all three
+    formats allow concatenated streams)."""
+    if not data:
+        open(path, 'ab').close()
+        return
+    if not kind:
+        with open(path, 'ab') as f:
+            f.write(data)
+        return
+    import bz2
+    import lzma
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def gz(b):
+        c = zlib.compressobj(4, zlib.DEFLATED, 31)
+        return c.compress(b) + c.flush()
+    pack = {'gz': gz, 'bz2': bz2.compress, 'xz': lzma.compress}[kind]
+    cuts, pos = [0], 0
+    while len(data) - pos > block:
+        nl = data.rfind(b'\n', pos, pos + block) + 1
+        pos = nl if nl > pos else pos + block
+        cuts.append(pos)
+    cuts.append(len(data))
+    parts = [data[a:b] for a, b in zip(cuts, cuts[1:])]
+    with ThreadPoolExecutor(max_workers=min(32, len(parts))) as ex:
+        packed = list(ex.map(pack, parts))
+    with open(path, 'ab') as f:
+        for p in packed:
+            f.write(p)
+
+
 _NO_TREE_ROOT = '\x00root'      # stand-in root when no hierarchy is given
 MAX_GROUPS = 1 << nat.KEY_GROUP_BITS
 
@@ -158,7 +192,8 @@ class Engine:
         return labels
 
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
-                      want_names, trimsub=None, want_groups=False):
+                      want_names, trimsub=None, want_groups=False,
+                      want_strings=True):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed) where packed = (subj, qoff) of subject indices,
         or for coord-match (genome, beg, end, length, hoff)."""
@@ -197,7 +232,9 @@ class Engine:
                         self._tok_identity = False
                     self._tok_map = np.concatenate([self._tok_map, ids])
             reads = nat.Tokenizer.query_names(buf, res['qname']) \
-                if want_names else None
+                if (want_names and want_strings) else None
+            names = (buf, res['qname']) if (want_names and not want_strings) \
+                else None
             del buf
             if ordinal:
                 packed = (self._tok_genome[res['subj']], res['beg'],
@@ -207,7 +244,7 @@ class Engine:
                     else self._tok_map[res['subj']]
                 packed = (subj, res['off'])
             if res['off'].size > 1:
-                yield reads, packed, res.get('group')
+                yield reads, packed, res.get('group'), names
 
     # ------------------------------------------------------------------
     def set_genes(self, table, prefix):
@@ -298,7 +335,7 @@ class Engine:
 
     def run_chunk(self, data, reads, subque, sample_of, strata_of, trimsub,
                   rank2dir, outzip, namedic, ordinal, packed=None,
-                  strata_ids=None, strata_labels=None):
+                  strata_ids=None, strata_labels=None, names=None):
         """Classify one chunk at every rank; returns the number of queries the
         reference would report for it (workflow.py:305).  ``packed`` carries
         arrays produced by the native tokenizer instead of ``subque`` / staged
@@ -355,7 +392,10 @@ class Engine:
             nq = n
         if self.sizes:
             self._collect_log()
-        if want:
+        if want and names is not None:
+            self._write_maps_native(assign, subj, qoff, names, sample_of,
+                                    rank2dir, outzip, namedic)
+        elif want:
             self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,
                              outzip, namedic)
         return nq
@@ -413,6 +453,67 @@ class Engine:
                     write_readmap(fh, qs, ts, namedic)
 
     # ------------------------------------------------------------------
+    def _multi_lists(self, j, row, subj, qoff):
+        """(m_off, m_feat, m_count) of the reads split over several features at
+        job j, vectorised: distinct subjects per read -> their taxon -> counts
+        -> order by (-count, feature id string) like file.write_readmap."""
+        multi = np.flatnonzero(row == nat.ASSIGN_MULTI)
+        if multi.size == 0:
+            return (np.zeros(1, np.int64), np.empty(0, np.int32),
+                    np.empty(0, np.int32))
+        lo, hi = qoff[multi].astype(np.int64), qoff[multi + 1].astype(np.int64)
+        cnt = hi - lo
+        read_i = np.repeat(np.arange(multi.size, dtype=np.int64), cnt)
+        rec = np.repeat(lo - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) \
+            + np.arange(int(cnt.sum()), dtype=np.int64)
+        feat = subj[rec].astype(np.int64)
+        pairs = np.unique(read_i * (1 << 32) + feat)        # distinct subjects
+        read_i, feat = pairs >> 32, pairs & 0xFFFFFFFF
+        if self.modes[j] == nat.MODE_RANK:
+            anc = self._rank_table(self.slots[j]).astype(np.int64)
+            inside = feat < self.hier.n_nodes
+            tax = np.where(inside, anc[np.where(inside, feat, 0)], -1)
+            ok = tax >= 0
+            read_i, tax = read_i[ok], tax[ok]
+        else:
+            tax = feat
+        keys, count = np.unique(read_i * (1 << 32) + tax, return_counts=True)
+        read_i, tax = keys >> 32, keys & 0xFFFFFFFF
+        ut, inv = np.unique(tax, return_inverse=True)
+        names = self.index.names
+        order = sorted(range(ut.size), key=lambda i: names[ut[i]])
+        rank = np.empty(ut.size, dtype=np.int64)
+        rank[order] = np.arange(ut.size)
+        o = np.lexsort((rank[inv], -count, read_i))
+        m_off = np.zeros(multi.size + 1, dtype=np.int64)
+        np.cumsum(np.bincount(read_i, minlength=multi.size), out=m_off[1:])
+        return m_off, tax[o].astype(np.int32), count[o].astype(np.int32)
+
+    def _write_maps_native(self, assign, subj, qoff, names, sample,
+                           rank2dir, outzip, namedic):
+        """Read maps of one (non-demultiplexed) chunk through the native
+        formatter; compression runs on a thread pool, one member per block."""
+        buf, qname = names
+        unas = bool(self.jobs[0].flags & nat.F_UNASSIGNED)
+        for j, rank in enumerate(self.ranks):
+            row = assign[j]
+            m_off, m_feat, m_count = self._multi_lists(j, row, subj, qoff)
+            used = np.unique(np.concatenate([row[row >= 0], m_feat]))
+            remap = np.zeros(int(used.max()) + 1 if used.size else 1,
+                             dtype=np.int32)
+            remap[used] = np.arange(used.size, dtype=np.int32)
+            inames = self.index.names
+            shown = [inames[f] for f in used.tolist()]
+            if namedic:
+                shown = [namedic.get(x, x) for x in shown]
+            row2 = np.where(row >= 0, remap[np.maximum(row, 0)], row)
+            text = nat.format_readmap(buf, qname, row2, m_off,
+                                      remap[m_feat] if m_feat.size else m_feat,
+                                      m_count, shown, unassigned=unas)
+            outfp = join(rank2dir[rank], f'{sample}.txt')
+            _append_compressed(f'{outfp}.{outzip}' if outzip else outfp, text,
+                               outzip)
+
     def _collect_log(self):
         """Fold the contribution log of the chunk just classified.  If the log
         overflowed, enlarge it and run the staged chunk again (size-normalised

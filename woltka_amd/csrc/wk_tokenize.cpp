@@ -589,6 +589,120 @@ int wk_tok_strata_labels(wk_tok* t, char* blob, int64_t* off) {
     return WK_OK;
 }
 
+// Read-map text (file.write_readmap, file.py:469-500): one line per assigned read,
+// "read id <tab> name" or "read id <tab> name:count <tab> ..." for reads split over
+// several features (their (feature, count) lists arrive pre-sorted).  Two passes per
+// thread range: sizes, then bytes; `out` NULL returns the size only.
+int wk_format_readmap(const char* text, const uint64_t* qname, const int32_t* assign, int64_t n_reads,
+                      const int64_t* m_off, const int32_t* m_feat, const int32_t* m_count, const char* names_blob,
+                      const int64_t* names_off, int32_t n_names, int unassigned, int n_threads, char* out, int64_t cap,
+                      int64_t* written) {
+    if (!text || !qname || !assign || n_reads < 0 || !names_off || !written) return WK_E_ARG;
+    static const char* const kSuffix[3] = {"", "/1", "/2"};
+    static const size_t kSuffixLen[3] = {0, 2, 2};
+    static const char kUnassigned[] = "Unassigned";
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(64, std::max(1u, std::thread::hardware_concurrency()));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n_reads / 4096 + 1));
+    // index of each MULTI read into m_off: running count over the reads
+    std::vector<int64_t> mbase(T + 1, 0), size(T, 0), start(T + 1, 0);
+    auto range = [&](int i, int64_t& lo, int64_t& hi) {
+        lo = n_reads * i / T;
+        hi = n_reads * (i + 1) / T;
+    };
+    auto digits = [](int32_t v) {
+        int d = 1;
+        while (v >= 10) {
+            v /= 10;
+            ++d;
+        }
+        return d;
+    };
+    auto name_len = [&](int32_t f) -> int64_t {
+        return (f >= 0 && f < n_names) ? names_off[f + 1] - names_off[f] : 0;
+    };
+    // pass 0: MULTI reads per range
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < T; ++i)
+            th.emplace_back([&, i] {
+                int64_t lo, hi, c = 0;
+                range(i, lo, hi);
+                for (int64_t r = lo; r < hi; ++r) c += assign[r] == WK_ASSIGN_MULTI;
+                mbase[i + 1] = c;
+            });
+        for (auto& x : th) x.join();
+        for (int i = 0; i < T; ++i) mbase[i + 1] += mbase[i];
+    }
+    auto walk = [&](int i, char* dst) -> int64_t {
+        int64_t lo, hi, w = 0, m = mbase[i];
+        range(i, lo, hi);
+        char num[16];
+        for (int64_t r = lo; r < hi; ++r) {
+            const int32_t a = assign[r];
+            const bool multi = a == WK_ASSIGN_MULTI;
+            if (!(a >= 0 || multi || (a == WK_ASSIGN_NONE && unassigned))) continue;
+            const uint64_t d = qname[r];
+            const size_t qo = (size_t)(d >> 24), qn = (size_t)((d >> 2) & 0x3FFFFF), mate = (size_t)(d & 3);
+            if (dst) {
+                memcpy(dst + w, text + qo, qn);
+                memcpy(dst + w + qn, kSuffix[mate], kSuffixLen[mate]);
+            }
+            w += (int64_t)(qn + kSuffixLen[mate]);
+            if (multi) {
+                for (int64_t k = m_off[m]; k < m_off[m + 1]; ++k) {
+                    const int32_t f = m_feat[k];
+                    const int64_t nl = name_len(f);
+                    const int dg = digits(m_count[k]);
+                    if (dst) {
+                        dst[w] = '\t';
+                        memcpy(dst + w + 1, names_blob + names_off[f], (size_t)nl);
+                        dst[w + 1 + nl] = ':';
+                        int32_t v = m_count[k];
+                        for (int q = dg - 1; q >= 0; --q) {
+                            num[q] = (char)('0' + v % 10);
+                            v /= 10;
+                        }
+                        memcpy(dst + w + 2 + nl, num, (size_t)dg);
+                    }
+                    w += 2 + nl + dg;
+                }
+                ++m;
+            } else if (a >= 0) {
+                const int64_t nl = name_len(a);
+                if (dst) {
+                    dst[w] = '\t';
+                    memcpy(dst + w + 1, names_blob + names_off[a], (size_t)nl);
+                }
+                w += 1 + nl;
+            } else {
+                if (dst) {
+                    dst[w] = '\t';
+                    memcpy(dst + w + 1, kUnassigned, sizeof kUnassigned - 1);
+                }
+                w += 1 + (int64_t)(sizeof kUnassigned - 1);
+            }
+            if (dst) dst[w] = '\n';
+            w += 1;
+        }
+        return w;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < T; ++i) th.emplace_back([&, i] { size[i] = walk(i, nullptr); });
+        for (auto& x : th) x.join();
+    }
+    for (int i = 0; i < T; ++i) start[i + 1] = start[i] + size[i];
+    *written = start[T];
+    if (!out) return WK_OK;
+    if (cap < start[T]) return WK_E_CAPACITY;
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < T; ++i) th.emplace_back([&, i] { walk(i, out + start[i]); });
+        for (auto& x : th) x.join();
+    }
+    return WK_OK;
+}
+
 int wk_tok_subjects(wk_tok* t, int32_t* n_total, int32_t* n_new, int64_t* new_bytes) {
     if (!t || !n_total || !n_new || !new_bytes) return WK_E_ARG;
     *n_total = t->names.size();

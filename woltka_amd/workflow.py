@@ -235,9 +235,15 @@ def classify(mapper:  object,
                             labels = engine.load_strata(stratmap[sample],
                                                         zippers)
                             csample = sample
+                    # read ids as Python strings only when the host logic
+                    # needs them (demultiplexing, Python-side strata join);
+                    # read maps alone are formatted natively from descriptors
+                    want_strings = bool(demux or (
+                        stratmap and not native_strata))
                     chunks = engine.native_chunks(
                         stream, head, exclude, NATIVE_BLOCK, ordinal,
-                        want_names, trimsub, want_groups=native_strata)
+                        want_names, trimsub, want_groups=native_strata,
+                        want_strings=want_strings)
                 else:
                     text = io.TextIOWrapper(stream, encoding='utf-8')
                     fh = chain([head.decode()], text) if head else text
@@ -247,9 +253,9 @@ def classify(mapper:  object,
                     else:
                         chunks = mapper(fh, fmt=fmt_, excl=exclude, n=n)
                 for chunk_ in chunks:
-                    packed = strata_ids = None
+                    packed = strata_ids = names = None
                     if native:
-                        qryque, packed, strata_ids = chunk_
+                        qryque, packed, strata_ids, names = chunk_
                         subque = None
                         engine._th = mapper.th if ordinal else None
                     elif ordinal:
@@ -274,7 +280,8 @@ def classify(mapper:  object,
                         data, reads, subque, sample_of, strata_of,
                         None if native else trimsub,
                         rank2dir, outzip, namedic, ordinal, packed=packed,
-                        strata_ids=strata_ids, strata_labels=labels)
+                        strata_ids=strata_ids, strata_labels=labels,
+                        names=names)
                     nqry += nq
                     istep = nqry // 1000000 - nstep
                     if istep:
