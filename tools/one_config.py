@@ -21,4 +21,11 @@ for o in a.opt:
 for _ in range(a.steps):
     wl.step()
 ctx.sync()
+ctx.profile_kernels(True)
+wl.step()
+for f in getattr(wl, 'families', ('classify',)):
+    try:
+        print(f, round(ctx.last_kernel_ms(f) * 1e3, 1), 'us')
+    except RuntimeError:
+        pass
 print('done', wl.check())

@@ -37,7 +37,9 @@ struct MatchArgs {
     const int32_t* gpmax;       // [n_genes] running max of gend inside the genome
     const int32_t* gfeat;       // [n_genes] feature id
     const int4* gene4;          // [n_genes] {start0, end, running max end, feature}: one gather per scanned gene
+    const int4* ginfo;          // [n_genomes] {first gene, gene count, smallest start0, float bits of (count-1)/(largest-smallest start0)}
     int32_t n_genomes;
+    int32_t ablate;  // measurement builds only (-DWK_ABLATE): 1 = no scan, 2 = no search, 4 = no table lookups at all
 };
 
 // rel = ceil(len * th) evaluated in fp64 exactly like numpy does in
@@ -49,10 +51,12 @@ __device__ __forceinline__ int64_t effective_len(uint32_t len, double th) {
 struct HitQuery {
     int64_t rs, re, rel;
     int32_t lo, hi;  // gene range of the hit's genome (empty: hit cannot match)
+    int32_t first;        // smallest gene start0 of the genome
+    float scale;          // genes per base between the first and the last start
 };
 
 __device__ __forceinline__ HitQuery load_hit(const MatchArgs& a, int64_t h) {
-    HitQuery q{0, 0, 1, 0, 0};
+    HitQuery q{0, 0, 1, 0, 0, 0, 0.f};
     if (h >= a.n_hits) return q;
     const int32_t g = a.genome[h];
     const uint32_t len = a.len[h];
@@ -60,8 +64,14 @@ __device__ __forceinline__ HitQuery load_hit(const MatchArgs& a, int64_t h) {
     q.rs = a.beg[h];
     q.re = a.end[h];
     q.rel = effective_len(len, a.th);
-    q.lo = a.genome_off[g];
-    q.hi = a.genome_off[g + 1];
+#ifdef WK_ABLATE
+    if (a.ablate & 4) return q;
+#endif
+    const int4 gi = a.ginfo[g];
+    q.lo = gi.x;
+    q.hi = gi.x + gi.y;
+    q.first = gi.z;
+    q.scale = __int_as_float(gi.w);
     return q;
 }
 
@@ -99,8 +109,61 @@ __global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
         l[it] = q[it].lo;
         r[it] = q[it].hi;
     }
+#ifdef WK_ABLATE
+    if (a.ablate & 2) {
+#pragma unroll
+        for (int it = 0; it < kMatchItems; ++it) q[it].hi = q[it].lo + (q[it].hi > q[it].lo ? 1 : 0);
+    }
+#endif
+    // Upper bound = first gene with start0 > re - rel.  Genes are spread fairly
+    // evenly along a genome, so an interpolated guess lands within a few genes
+    // of it; a window of 8 genes around the guess is verified with two gathers
+    // and only when that fails does the search widen (binary search in the
+    // remaining half).  All kMatchItems searches advance in lock step.
+#pragma unroll
+    for (int it = 0; it < kMatchItems; ++it) {
+        const int64_t t = q[it].re - q[it].rel;
+        const int32_t n = q[it].hi - q[it].lo;
+        if (n > 16 && t >= q[it].first) {
+            // the guess only picks the window that is then verified, so float
+            // precision is irrelevant for correctness
+            int32_t guess = q[it].lo + (int32_t)((float)(t - q[it].first) * q[it].scale);
+            guess = guess > q[it].hi - 1 ? q[it].hi - 1 : guess;
+            int32_t wl = guess - 4, wr = guess + 4;
+            wl = wl < q[it].lo ? q[it].lo : wl;
+            wr = wr > q[it].hi - 1 ? q[it].hi - 1 : wr;
+            l[it] = wl;  // provisional window [wl, wr]
+            r[it] = wr;
+        } else {
+            l[it] = r[it] = -1;  // no window: plain binary search over the genome
+        }
+    }
+    {
+        int32_t vl[kMatchItems], vr[kMatchItems];
+#pragma unroll
+        for (int it = 0; it < kMatchItems; ++it) {
+            vl[it] = (l[it] >= 0) ? a.gstart[l[it]] : 0;
+            vr[it] = (l[it] >= 0) ? a.gstart[r[it]] : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < kMatchItems; ++it) {
+            const int64_t t = q[it].re - q[it].rel;
+            if (l[it] < 0) {
+                l[it] = q[it].lo;
+                r[it] = q[it].hi;
+            } else if ((int64_t)vl[it] > t) {  // answer at or left of the window
+                r[it] = l[it];
+                l[it] = q[it].lo;
+            } else if ((int64_t)vr[it] <= t) {  // answer right of the window
+                l[it] = r[it] + 1;
+                r[it] = q[it].hi;
+            } else {  // gstart[wl] <= t < gstart[wr]: answer inside (wl, wr]
+                l[it] = l[it] + 1;
+            }
+        }
+    }
     bool more = true;
-    while (more) {  // upper bound: first gene with start0 > re - rel
+    while (more) {  // binary search of the (narrowed) range
         int32_t m[kMatchItems], v[kMatchItems];
 #pragma unroll
         for (int it = 0; it < kMatchItems; ++it) {
@@ -125,7 +188,10 @@ __global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
         const int64_t h = base + it * kMatchThreads + threadIdx.x;
         if (h < a.n_hits) {
             int32_t c = 0;
-            scan_matches(a, q[it], l[it], [&](int32_t) { c += 1; });
+#ifdef WK_ABLATE
+            if (!(a.ablate & 1))
+#endif
+                scan_matches(a, q[it], l[it], [&](int32_t) { c += 1; });
             cnt[h] = c;
             ubound[h] = l[it];
             mine += (unsigned long long)c;

@@ -90,7 +90,7 @@ struct wk_ctx {
     bool subj_indexed = false;  // staged chunk carries subject indices
 
     // genes
-    DevBuf genome_off, gstart, gend, gpmax, gfeat, gene4;
+    DevBuf genome_off, gstart, gend, gpmax, gfeat, gene4, ginfo;
     int32_t n_genomes = 0, n_genes = 0;
 
     // count table
@@ -297,7 +297,7 @@ void wk_destroy(wk_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4,
+    DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4, &c->ginfo,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_poff, &c->o_pairs, &c->o_qoff,
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->assign_out, &c->fetch_k, &c->fetch_v};
@@ -455,6 +455,17 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
         packed[4 * (size_t)i + 3] = gene_feature[i];
     }
     if ((rc = upload(c, c->gene4, packed.data(), packed.size() * sizeof(int32_t)))) return rc;
+    std::vector<int32_t> info((size_t)n_genomes * 4);
+    for (int32_t g = 0; g < n_genomes; ++g) {
+        const int32_t lo = genome_off[g], n = genome_off[g + 1] - lo;
+        info[4 * (size_t)g] = lo;
+        info[4 * (size_t)g + 1] = n;
+        info[4 * (size_t)g + 2] = n ? start0[lo] : 0;
+        const int64_t span = n ? (int64_t)start0[lo + n - 1] - start0[lo] : 0;
+        const float scale = span > 0 ? (float)(n - 1) / (float)span : 0.f;
+        memcpy(&info[4 * (size_t)g + 3], &scale, 4);
+    }
+    if ((rc = upload(c, c->ginfo, info.data(), info.size() * sizeof(int32_t)))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_genomes = n_genomes;
     c->n_genes = n_genes;
@@ -825,7 +836,9 @@ int wk_ordinal_match(wk_ctx* c) {
     a.gpmax = c->gpmax.as<int32_t>();
     a.gfeat = c->gfeat.as<int32_t>();
     a.gene4 = c->gene4.as<int4>();
+    a.ginfo = c->ginfo.as<int4>();
     a.n_genomes = c->n_genomes;
+    a.ablate = c->ablate;
 
     unsigned long long total = 0;
     HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
