@@ -472,33 +472,36 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
 // set logic: every assigner reduces to one table value.  `row` is the
 // candidate's subject row {feature, rank col 0, 1, 2}.
 template <bool kUseLds>
-__device__ __forceinline__ void process_single(const ClassifyArgs& a, const LdsCache& cache, const int4 row,
-                                               int64_t r, int32_t g) {
+__device__ __forceinline__ void single_job(const ClassifyArgs& a, const LdsCache& cache, const JobDev& job, int jb,
+                                           const int4 row, uint32_t r, int32_t g) {
     const int32_t f = row.x;
-    if ((uint32_t)f > (uint32_t)WK_MAX_FEATURE) atomicOr(a.table.err, kErrFeatureRange);
-    for (int jb = 0; jb < a.n_jobs; ++jb) {
-        const JobDev job = a.jobs[jb];
-        int32_t res;
-        if (job.mode == WK_MODE_NONE) {
-            res = f;
-        } else if (job.mode == WK_MODE_FREE) {
-            res = (job.flags & WK_F_SUBOK) ? f : ((f < a.n_nodes) ? a.nodes[f].parent : WK_ASSIGN_NONE);
-        } else {
-            const int32_t t = job.col == 0 ? row.y : (job.col == 1 ? row.z : row.w);
-            res = t < 0 ? WK_ASSIGN_NONE : t;
-        }
-        if (a.out_assign) a.out_assign[(int64_t)jb * a.n_reads + r] = res;
-        if (g < 0) continue;
-        int32_t out = res;
-        if (res < 0) {
-            if (!(job.flags & WK_F_UNASSIGNED)) continue;
-            out = WK_FEATURE_UNASSIGNED;
-        }
-        if (job.flags & WK_F_SIZED)
-            log_append(a, out, f, jb, 1, g);
-        else
-            count_add<kUseLds>(cache, a.table, jb, 1, g, (uint32_t)out);
+    int32_t res;
+    if (job.mode == WK_MODE_NONE) {
+        res = f;
+    } else if (job.mode == WK_MODE_FREE) {
+        res = (job.flags & WK_F_SUBOK) ? f : ((f < a.n_nodes) ? a.nodes[f].parent : WK_ASSIGN_NONE);
+    } else {
+        const int32_t t = job.col == 0 ? row.y : (job.col == 1 ? row.z : row.w);
+        res = t < 0 ? WK_ASSIGN_NONE : t;
     }
+    if (a.out_assign) a.out_assign[(int64_t)jb * a.n_reads + r] = res;
+    if (g < 0) return;
+    int32_t out = res;
+    if (res < 0) {
+        if (!(job.flags & WK_F_UNASSIGNED)) return;
+        out = WK_FEATURE_UNASSIGNED;
+    }
+    if (job.flags & WK_F_SIZED)
+        log_append(a, out, f, jb, 1, g);
+    else
+        count_add<kUseLds>(cache, a.table, jb, 1, g, (uint32_t)out);
+}
+
+template <bool kUseLds>
+__device__ __forceinline__ void process_single(const ClassifyArgs& a, const LdsCache& cache, const int4 row,
+                                               uint32_t r, int32_t g) {
+    if ((uint32_t)row.x > (uint32_t)WK_MAX_FEATURE) atomicOr(a.table.err, kErrFeatureRange);
+    for (int jb = 0; jb < a.n_jobs; ++jb) single_job<kUseLds>(a, cache, a.jobs[jb], jb, row, r, g);
 }
 
 __device__ __forceinline__ void mark_empty(const ClassifyArgs& a, int64_t r) {
@@ -593,6 +596,8 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         int32_t c0 = load_first(s0, e0), c1 = load_first(s1, e1);
         int4 row0 = load_row(c0);
         int32_t g0 = load_group(r);
+        const bool one_job = a.n_jobs == 1;
+        const JobDev job0 = a.jobs[0];  // kept in registers for the common single-rank run
         for (; r < a.n_reads; r += stride) {
             int32_t s3, e3;
             load_offsets(r + 3 * stride, s3, e3);
@@ -609,7 +614,14 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
 #ifdef WK_ABLATE
                 if (!(a.ablate & 8))
 #endif
-                    process_single<kUseLds>(a, cache, row0, r, g0);
+                {
+                    if (one_job) {
+                        if ((uint32_t)row0.x > (uint32_t)WK_MAX_FEATURE) atomicOr(a.table.err, kErrFeatureRange);
+                        single_job<kUseLds>(a, cache, job0, 0, row0, r, g0);
+                    } else {
+                        process_single<kUseLds>(a, cache, row0, r, g0);
+                    }
+                }
             } else {
                 // every subject index of the read must lie inside the table
                 bool ok = (uint32_t)c0 < (uint32_t)a.n_subjects;
