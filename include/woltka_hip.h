@@ -274,6 +274,15 @@ int wk_tok_fetch(wk_tok* tok, int32_t* subj, int32_t* off, int32_t* beg,
  * with wk_tok_strata_load; -1 = not found: the read is skipped by the
  * stratified counters, classify.py:239).  wk_tok_fetch_groups copies them. */
 int wk_tok_fetch_groups(wk_tok* tok, int32_t* group);
+/* Bit 4 of `want_names`: demultiplexing (workflow.demultiplex, workflow.py:
+ * 844-909) — the sample of a read is the text before the first '_' of its read
+ * id if anything follows it, else the empty name; samples are interned in
+ * order of first appearance.  wk_tok_fetch_samples copies the per-read sample
+ * ids; wk_tok_new_samples returns the names first seen since the last call
+ * (call with blob == NULL and off == NULL for the count, then with off[n+1]
+ * for the sizes, then with blob). */
+int wk_tok_fetch_samples(wk_tok* tok, int32_t* sample);
+int wk_tok_new_samples(wk_tok* tok, char* blob, int64_t* off, int32_t* n_new);
 /* Stratification map of the current sample (file.read_map_uniq +
  * workflow.read_strata; file.py:368-385, workflow.py:912-938): lines
  * "read id <tab> label" with exactly two columns, appended block by block

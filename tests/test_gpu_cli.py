@@ -217,3 +217,31 @@ def test_native_readmaps_equal_python_path(tmp_path, extra):
     assert any('\t' in line and ':' in line
                for t in native.values() for line in t.splitlines()) or \
         extra[1] == 'genus'
+
+
+def test_native_demux_equals_python_path(tmp_path):
+    """A multiplexed SAM file (sample_read ids) through the native
+    demultiplexer equals the Python demultiplexer, with and without a sample
+    whitelist."""
+    import contextlib
+    import io
+    import lzma
+    from woltka_amd import align, workflow
+    mux = tmp_path / 'mux.sam'
+    with open(mux, 'w') as out:
+        for i in range(1, 6):
+            with lzma.open(join(ALN, 'bt2sho', f'S0{i}.sam.xz'), 'rt') as f:
+                for line in f:
+                    if line[0] != '@':
+                        out.write(f'S0{i}_{line}')
+
+    def python_only(*a, **k):
+        return align.plain_mapper(*a, **k)
+    for samples in (None, ['S02', 'S04']):
+        with contextlib.redirect_stdout(io.StringIO()):
+            kw = dict(samples=samples, demux=True, ranks=['none'], fmt='sam')
+            d_native = workflow.classify(align.plain_mapper, [str(mux)], **kw)
+            d_python = workflow.classify(python_only, [str(mux)], **kw)
+        assert d_native == d_python
+        assert sorted(d_native['none']) == (samples or
+                                            ['S01', 'S02', 'S03', 'S04', 'S05'])

@@ -252,3 +252,24 @@ def test_native_readmap_format_matches_python():
                              ).decode()
     assert got == buf.getvalue()
     tok.close()
+
+
+def test_native_demux_matches_python():
+    from woltka_amd.workflow import demux_labels
+    qn = ['S1_r1', 'S1_r2', 'S2_r1', 'nosep', 'S3_', '_lead', 'S1_r3_x',
+          'S2_r9', 'S9_a', 'S1_b', 'S3_']
+    flags = [0, 99, 147, 0, 0, 0, 0, 0, 0, 0, 64]
+    lines = [f'{q}\t{f}\tG{i}\t1\t0\t5M\t*\n'
+             for i, (q, f) in enumerate(zip(qn, flags))]
+    queries = [q for q, _ in align.parse_align(lines, 'sam')]
+    exp, _ = demux_labels(queries)
+    for threads, block in ((1, 1 << 20), (3, 40)):
+        tok = Tokenizer(threads)
+        names, ids = [], []
+        for buf, res in align.native_sam_blocks(
+                io.BytesIO(''.join(lines).encode()), tok, block,
+                want_samples=True):
+            names.extend(tok.new_samples())
+            ids.extend(res['sample'].tolist())
+        tok.close()
+        assert [names[i] for i in ids] == exp

@@ -43,7 +43,8 @@ SYMBOLS = (
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
     'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_fetch', 'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
-    'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap')
+    'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
+    'wk_tok_fetch_samples', 'wk_tok_new_samples')
 
 
 class Job(C.Structure):
@@ -125,6 +126,8 @@ def load_library():
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
         'wk_tok_fetch_groups': (C.c_int, [p, i32p]),
         'wk_tok_strata_clear': (C.c_int, [p]),
+        'wk_tok_fetch_samples': (C.c_int, [p, i32p]),
+        'wk_tok_new_samples': (C.c_int, [p, C.c_char_p, i64p, i32p]),
         'wk_tok_strata_load': (C.c_int, [p, C.c_void_p, C.c_int64, i64p, i32p]),
         'wk_tok_strata_labels': (C.c_int, [p, C.c_char_p, i64p]),
         'wk_format_readmap': (C.c_int, [C.c_void_p, u64p, i32p, C.c_int64, i64p,
@@ -471,8 +474,24 @@ class Tokenizer:
         raw, o = blob.raw, off.tolist()
         return [raw[o[i]:o[i + 1]].decode() for i in range(n_lab.value)]
 
+    def new_samples(self):
+        """Sample names first seen since the last call (index order)."""
+        n = C.c_int32(0)
+        self._check(self._lib.wk_tok_new_samples(self._h, None, None,
+                                                 C.byref(n)))
+        if n.value == 0:
+            return []
+        off = np.empty(n.value + 1, dtype=np.int64)
+        self._check(self._lib.wk_tok_new_samples(
+            self._h, None, _ptr(off, C.c_int64), C.byref(n)))
+        blob = C.create_string_buffer(max(1, int(off[-1])))
+        self._check(self._lib.wk_tok_new_samples(
+            self._h, blob, _ptr(off, C.c_int64), C.byref(n)))
+        raw, o = blob.raw, off.tolist()
+        return [raw[o[i]:o[i + 1]].decode() for i in range(n.value)]
+
     def parse(self, buf, first=False, final=False, extra=False,
-              want_names=False, want_groups=False):
+              want_names=False, want_groups=False, want_samples=False):
         """Tokenize ``buf`` (bytes-like).  Returns a dict with ``consumed``,
         ``subj``, ``off`` (+ ``beg``/``end``/``len`` with ``extra``,
         ``qname`` descriptors with ``want_names``, ``group`` = stratum ids with
@@ -486,7 +505,8 @@ class Tokenizer:
         consumed, nrd, nrec = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._lib.wk_tok_sam(
             self._h, addr, n, int(first), int(final), int(extra),
-            int(bool(want_names)) | (2 if want_groups else 0),
+            int(bool(want_names)) | (2 if want_groups else 0) |
+            (4 if want_samples else 0),
             C.byref(consumed), C.byref(nrd), C.byref(nrec)))
         out = {'consumed': consumed.value,
                'subj': np.empty(nrec.value, np.int32),
@@ -502,6 +522,10 @@ class Tokenizer:
             _ptr(out.get('beg'), C.c_int32), _ptr(out.get('end'), C.c_int32),
             _ptr(out.get('len'), C.c_uint32),
             _ptr(out.get('qname'), C.c_uint64)))
+        if want_samples:
+            out['sample'] = np.empty(nrd.value, np.int32)
+            self._check(self._lib.wk_tok_fetch_samples(
+                self._h, _ptr(out['sample'], C.c_int32)))
         if want_groups:
             out['group'] = np.empty(nrd.value, np.int32)
             self._check(self._lib.wk_tok_fetch_groups(

@@ -274,7 +274,8 @@ def pack_queries(subque, index, trim=None):
 # --------------------------------------------------------------------------
 
 def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
-                      want_names=False, head=b'', want_groups=False):
+                      want_names=False, head=b'', want_groups=False,
+                      want_samples=False):
     """Feed a binary SAM stream through the native tokenizer
     (``_native.Tokenizer``) block by block.
 
@@ -290,7 +291,7 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
     mm = _try_mmap(stream)
     if mm is not None:
         yield from _blocks_mmap(mm, len(head), tok, block_bytes, extra,
-                                want_names, want_groups)
+                                want_names, want_groups, want_samples)
         return
     buf = bytearray(block_bytes + (1 << 16))
     fill = len(head)
@@ -312,7 +313,8 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
         if final and fill == 0:
             return
         res = tok.parse(view[:fill], first=first, final=final, extra=extra,
-                        want_names=want_names, want_groups=want_groups)
+                        want_names=want_names, want_groups=want_groups,
+                        want_samples=want_samples)
         used = res['consumed']
         if used == 0 and not final and res['off'].size == 1:
             if fill == len(buf):
@@ -351,7 +353,7 @@ def _try_mmap(stream):
 
 
 def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
-                 want_groups=False):
+                 want_groups=False, want_samples=False):
     """Tokenise a memory-mapped file in place.  ``start`` bytes were already
     read from the stream for format sniffing; the map covers the whole file,
     so they are simply parsed again from offset 0."""
@@ -366,7 +368,8 @@ def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
             final = end == size
             res = tok.parse(view[pos:end], first=first, final=final,
                             extra=extra, want_names=want_names,
-                            want_groups=want_groups)
+                            want_groups=want_groups,
+                            want_samples=want_samples)
             used = res['consumed']
             if used == 0 and not final and res['off'].size == 1:
                 span *= 2

@@ -164,6 +164,8 @@ class Engine:
         # native SAM tokenizer (created on first use) and the translation of
         # its subject ids into `self.subjects` indices / genome indices
         self.tok = None
+        self._tok_samples = []          # sample names of the native demultiplexer
+        self._smap_key, self._smap = None, None
         self._exclude = None
         self._gmap_key, self._gmap = None, None
         self._epoch = 0
@@ -193,7 +195,7 @@ class Engine:
 
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,
-                      want_strings=True):
+                      want_strings=True, want_samples=False):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed) where packed = (subj, qoff) of subject indices,
         or for coord-match (genome, beg, end, length, hoff)."""
@@ -207,12 +209,15 @@ class Engine:
                                               extra=ordinal,
                                               want_names=want_names,
                                               head=head,
-                                              want_groups=want_groups):
+                                              want_groups=want_groups,
+                                              want_samples=want_samples):
                 # the dictionary growth belongs to this block: fetch it before
                 # the tokenizer moves on
-                yield buf, res, tok.new_subjects()
+                yield buf, res, tok.new_subjects(), \
+                    (tok.new_samples() if want_samples else [])
 
-        for buf, res, fresh in _prefetch(blocks()):
+        for buf, res, fresh, fresh_samples in _prefetch(blocks()):
+            self._tok_samples.extend(fresh_samples)
             if fresh:
                 if ordinal:
                     gidx = self.genes.genome_index.get
@@ -244,7 +249,7 @@ class Engine:
                     else self._tok_map[res['subj']]
                 packed = (subj, res['off'])
             if res['off'].size > 1:
-                yield reads, packed, res.get('group'), names
+                yield reads, packed, res.get('group'), names, res.get('sample')
 
     # ------------------------------------------------------------------
     def set_genes(self, table, prefix):
@@ -333,9 +338,36 @@ class Engine:
         return np.where(ids >= 0, self._gmap[np.maximum(ids, 0)],
                         -1).astype(np.int32)
 
+    def _sample_groups(self, ids, allow):
+        """Sample ids of the native demultiplexer -> group ids of (sample,
+        None); samples outside the whitelist -> -1.  Returns (groups, samples
+        met)."""
+        names = self._tok_samples
+        key = (self._epoch, len(names))
+        if self._smap_key != key:
+            gid, groups = self.group_ids, self.groups
+            smap = np.empty(len(names), dtype=np.int32)
+            for i, name in enumerate(names):
+                if allow is not None and name not in allow:
+                    smap[i] = -1
+                    continue
+                k = (name, None)
+                g = gid.get(k)
+                if g is None:
+                    g = len(groups)
+                    gid[k] = g
+                    groups.append(k)
+                smap[i] = g
+            self._smap_key, self._smap = key, smap
+        group = self._smap[ids]
+        met = {names[i] for i in np.unique(ids).tolist()
+               if self._smap[i] >= 0}
+        return group, met
+
     def run_chunk(self, data, reads, subque, sample_of, strata_of, trimsub,
                   rank2dir, outzip, namedic, ordinal, packed=None,
-                  strata_ids=None, strata_labels=None, names=None):
+                  strata_ids=None, strata_labels=None, names=None,
+                  sample_ids=None, allow=None):
         """Classify one chunk at every rank; returns the number of queries the
         reference would report for it (workflow.py:305).  ``packed`` carries
         arrays produced by the native tokenizer instead of ``subque`` / staged
@@ -343,14 +375,19 @@ class Engine:
         n = len(reads) if packed is None else packed[-1].size - 1
         if len(self.groups) + n + 1 >= MAX_GROUPS // 2:
             self.collect(data)
-        if strata_ids is not None:
+        seen = None
+        if sample_ids is not None:
+            group, seen = self._sample_groups(sample_ids, allow)
+        elif strata_ids is not None:
             group = self._strata_groups(sample_of, strata_labels, strata_ids)
         else:
             group = self._group_array(n, sample_of, strata_of)
         # every sample met in a chunk gets a (possibly empty) profile at every
         # rank, like `data[rank].setdefault(sample, {})` in workflow.py:1058
-        seen = (set(sample_of) - {False}) if isinstance(sample_of, list) \
-            else ({sample_of} if n else set())
+        if seen is None:
+            seen = (set(sample_of) - {False}) \
+                if isinstance(sample_of, list) \
+                else ({sample_of} if n else set())
         for rank in self.ranks:
             for s in seen:
                 data[rank].setdefault(s, {})

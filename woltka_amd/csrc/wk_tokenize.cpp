@@ -96,6 +96,8 @@ struct Local {
     std::vector<int32_t> rend;   // per read: end offset into rec
     std::vector<uint64_t> qname; // per read: (offset << 24) | (len << 2) | mate
     std::vector<int32_t> group;  // per read: stratum id or -1 (want_groups)
+    std::vector<int32_t> sample; // per read: sample id >= 0, or -(1 + local new-name id) (want_samples)
+    NameTable fresh_samples;
     NameTable fresh;             // names not yet in the global table
     int error = 0;               // 1 = both mate bits, 2 = malformed line
     size_t error_at = 0;
@@ -192,12 +194,17 @@ struct wk_tok {
     std::vector<int32_t> strata_of;  // per key id
     NameTable strata_labels;
     std::vector<int32_t> group;      // per read of the last call: stratum id or -1
+    // demultiplexing (workflow.demultiplex, workflow.py:844-909): sample = text
+    // before the first '_' of the read id, if anything follows it
+    NameTable samples;
+    std::vector<int32_t> sample;     // per read of the last call
+    int32_t samples_reported = 0;
 };
 
 namespace {
 
 void tokenize_range(const wk_tok* T, const char* base, const char* b, const char* e, bool extra, bool want_names,
-                    bool want_groups, Local& out) {
+                    bool want_groups, bool want_samples, Local& out) {
     const bool filt = T->exclude.size() > 0;
     static const char* const kSuffix[3] = {"", "/1", "/2"};
     std::string keybuf;
@@ -216,6 +223,21 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
             out.rec.insert(out.rec.end(), pool[m].begin(), pool[m].end());
             out.rend.push_back((int32_t)out.rec.size());
             if (want_names) out.qname.push_back(((uint64_t)(cur - base) << 24) | ((uint64_t)cur_n << 2) | (uint64_t)m);
+            if (want_samples) {
+                // query.partition('_'): sample = left part if the right part
+                // (which includes a mate suffix) is not empty, else ''
+                const char* us = (const char*)memchr(cur, '_', cur_n);
+                size_t sn = 0;
+                if (us && ((size_t)(us - cur) + 1 < cur_n || m != 0)) sn = (size_t)(us - cur);
+                const uint64_t hv = hash_bytes(cur, sn);
+                int32_t id = T->samples.find(cur, sn, hv);
+                if (id < 0) {
+                    int32_t f = out.fresh_samples.find(cur, sn, hv);
+                    if (f < 0) f = out.fresh_samples.add(cur, sn, hv);
+                    id = -(1 + f);
+                }
+                out.sample.push_back(id);
+            }
             if (want_groups) {  // stratum of read id = QNAME + mate suffix
                 keybuf.assign(cur, cur_n);
                 keybuf.append(kSuffix[m]);
@@ -376,6 +398,7 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
             t->off.assign(1, 0);
             t->qname.clear();
             t->group.clear();
+            t->sample.clear();
             t->beg.clear();
             t->end.clear();
             t->len.clear();
@@ -423,13 +446,15 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
         if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1];
     std::vector<Local> loc(T);
     if (T == 1) {
-        tokenize_range(t, buf, cut[0], cut[1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0, loc[0]);
+        tokenize_range(t, buf, cut[0], cut[1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0,
+                       (want_names & 4) != 0, loc[0]);
     } else {
         std::vector<std::thread> th;
         th.reserve(T);
         for (int i = 0; i < T; ++i)
             th.emplace_back([&, i] {
-                tokenize_range(t, buf, cut[i], cut[i + 1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0, loc[i]);
+                tokenize_range(t, buf, cut[i], cut[i + 1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0,
+                               (want_names & 4) != 0, loc[i]);
             });
         for (auto& x : th) x.join();
     }
@@ -453,6 +478,17 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
             remap[i][k] = id;
         }
     }
+    std::vector<std::vector<int32_t>> sremap(T);
+    for (int i = 0; i < T; ++i) {
+        const NameTable& f = loc[i].fresh_samples;
+        sremap[i].resize(f.size());
+        for (int32_t k = 0; k < f.size(); ++k) {
+            const char* p = f.arena.data() + f.off[k];
+            int32_t id = t->samples.find(p, f.len[k], f.hash[k]);
+            if (id < 0) id = t->samples.add(p, f.len[k], f.hash[k]);
+            sremap[i][k] = id;
+        }
+    }
     // first appearance order must not depend on the thread count: names that were
     // fresh in several ranges were added by the earliest range, which is also
     // where they first appear in the text.  Within one range `fresh` ids follow
@@ -471,6 +507,7 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
     t->off.resize(tot_reads + 1);
     t->qname.resize((want_names & 1) ? tot_reads : 0);
     t->group.resize((want_names & 2) ? tot_reads : 0);
+    t->sample.resize((want_names & 4) ? tot_reads : 0);
     if (extra) {
         t->beg.resize(tot_rec);
         t->end.resize(tot_rec);
@@ -503,6 +540,9 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
             for (size_t k = 0; k < L.qname.size(); ++k) t->qname[qb + k] = L.qname[k];
         if (want_names & 2)
             for (size_t k = 0; k < L.group.size(); ++k) t->group[qb + k] = L.group[k];
+        if (want_names & 4)
+            for (size_t k = 0; k < L.sample.size(); ++k)
+                t->sample[qb + k] = L.sample[k] >= 0 ? L.sample[k] : sremap[i][-(L.sample[k] + 1)];
     };
     if (T == 1) {
         copy_out(0);
@@ -531,6 +571,29 @@ int wk_tok_fetch(wk_tok* t, int32_t* subj, int32_t* off, int32_t* beg, int32_t* 
 int wk_tok_fetch_groups(wk_tok* t, int32_t* group) {
     if (!t) return WK_E_ARG;
     if (group && !t->group.empty()) memcpy(group, t->group.data(), t->group.size() * 4);
+    return WK_OK;
+}
+
+int wk_tok_fetch_samples(wk_tok* t, int32_t* sample) {
+    if (!t) return WK_E_ARG;
+    if (sample && !t->sample.empty()) memcpy(sample, t->sample.data(), t->sample.size() * 4);
+    return WK_OK;
+}
+
+// Names of the samples first seen since the last call: sizes with blob == NULL
+int wk_tok_new_samples(wk_tok* t, char* blob, int64_t* off, int32_t* n_new) {
+    if (!t || !n_new) return WK_E_ARG;
+    *n_new = t->samples.size() - t->samples_reported;
+    if (!off) return WK_OK;
+    int64_t w = 0;
+    int32_t k = 0;
+    off[0] = 0;
+    for (int32_t i = t->samples_reported; i < t->samples.size(); ++i, ++k) {
+        if (blob) memcpy(blob + w, t->samples.arena.data() + t->samples.off[i], t->samples.len[i]);
+        w += t->samples.len[i];
+        off[k + 1] = w;
+    }
+    if (blob || *n_new == 0) t->samples_reported = t->samples.size();
     return WK_OK;
 }
 

@@ -209,6 +209,9 @@ def classify(mapper:  object,
         # stratification without demultiplexing is joined natively (read id ->
         # stratum inside the tokenizer)
         native_strata = bool(stratmap) and not demux
+        # demultiplexing alone (no strata, no read maps) is done natively too
+        native_demux = bool(demux) and not stratmap and rank2dir is None
+        allow = set(samples) if (demux and samples) else None
         engine._exclude = exclude
         labels = None
         for fp in sorted(files):
@@ -226,7 +229,8 @@ def classify(mapper:  object,
                     fmt_ = infer_align_format(iter(
                         [head.decode()] if head else []))[0]
                 native = native_ok and fmt_ == 'sam'
-                want_names = bool(demux or rank2dir is not None or
+                want_names = bool((demux and not native_demux) or
+                                  rank2dir is not None or
                                   (stratmap and not (native and native_strata)))
                 if native:
                     if native_strata:
@@ -238,12 +242,12 @@ def classify(mapper:  object,
                     # read ids as Python strings only when the host logic
                     # needs them (demultiplexing, Python-side strata join);
                     # read maps alone are formatted natively from descriptors
-                    want_strings = bool(demux or (
+                    want_strings = bool((demux and not native_demux) or (
                         stratmap and not native_strata))
                     chunks = engine.native_chunks(
                         stream, head, exclude, NATIVE_BLOCK, ordinal,
                         want_names, trimsub, want_groups=native_strata,
-                        want_strings=want_strings)
+                        want_strings=want_strings, want_samples=native_demux)
                 else:
                     text = io.TextIOWrapper(stream, encoding='utf-8')
                     fh = chain([head.decode()], text) if head else text
@@ -253,9 +257,9 @@ def classify(mapper:  object,
                     else:
                         chunks = mapper(fh, fmt=fmt_, excl=exclude, n=n)
                 for chunk_ in chunks:
-                    packed = strata_ids = names = None
+                    packed = strata_ids = names = sample_ids = None
                     if native:
-                        qryque, packed, strata_ids, names = chunk_
+                        qryque, packed, strata_ids, names, sample_ids = chunk_
                         subque = None
                         engine._th = mapper.th if ordinal else None
                     elif ordinal:
@@ -264,7 +268,9 @@ def classify(mapper:  object,
                     else:
                         qryque, subque = chunk_
                     # sample of every read (demultiplexing / whitelist)
-                    if demux:
+                    if demux and sample_ids is not None:
+                        sample_of, reads = None, None
+                    elif demux:
                         sample_of, reads = demux_labels(qryque, samples)
                     else:
                         sample_of = files[fp] if files else None
@@ -281,7 +287,7 @@ def classify(mapper:  object,
                         None if native else trimsub,
                         rank2dir, outzip, namedic, ordinal, packed=packed,
                         strata_ids=strata_ids, strata_labels=labels,
-                        names=names)
+                        names=names, sample_ids=sample_ids, allow=allow)
                     nqry += nq
                     istep = nqry // 1000000 - nstep
                     if istep:
