@@ -245,3 +245,36 @@ def test_native_demux_equals_python_path(tmp_path):
         assert d_native == d_python
         assert sorted(d_native['none']) == (samples or
                                             ['S01', 'S02', 'S03', 'S04', 'S05'])
+
+
+def test_q2_style_classify(tmp_path):
+    """q2 method surface: multiplexed blastn alignment + lineage taxonomy;
+    unrounded counts agree with the CLI golden after rounding."""
+    import contextlib
+    import io
+    from woltka_amd.q2 import classify
+    from woltka_amd.workflow import round_half_snap
+    with open(join(TAX, 'lineages.txt')) as f:
+        taxonomy = dict(line.rstrip('\n').split('\t') for line in f
+                        if not line.startswith('#'))
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = classify(join(ALN, 'blastn', 'mux.b6o.xz'), 'species',
+                       reference_taxonomy=taxonomy)
+    data, features, samples, metadata = res if isinstance(res, tuple) else (
+        res.matrix_data.toarray().tolist(), list(res.ids('observation')),
+        list(res.ids('sample')), None)
+    with open(join(OUT, 'blastn.species.tsv')) as f:
+        header = f.readline().rstrip('\n').split('\t')
+        gold = {row[0]: row[1:] for row in
+                (line.rstrip('\n').split('\t') for line in f)}
+    assert header[1:] == samples
+    got = {}
+    for feat, row in zip(features, data):
+        vals = [round_half_snap(v) for v in row]
+        if any(vals):
+            got[feat] = [str(v) for v in vals]
+    assert got == gold
+    with pytest.raises(ValueError, match='Only one reference'):
+        classify('x', 'genus', reference_taxonomy={}, reference_nodes='y')
+    with pytest.raises(ValueError, match='must be specified'):
+        classify('x', 'genus')
