@@ -78,7 +78,7 @@ class FlatWorkload:
     """configs[1]: pack + histogram."""
     name = 'synthetic SAM 10M reads x 1 hit, flat subject->genus map, rank genus'
     dominant = 'classify'
-    families = ('classify', 'dense_merge')
+    families = ('classify', 'leftover', 'dense_merge')
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -119,7 +119,7 @@ class FlatWorkload:
 class LcaWorkload:
     """configs[2]: multi-hit reads, taxonomy tree, 3 ranks + free in one pass."""
     dominant = 'classify'
-    families = ('classify', 'partition_merge')
+    families = ('classify', 'leftover', 'partition_merge')
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx

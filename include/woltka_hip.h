@@ -118,7 +118,12 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * "dense" (0/1: dense LDS bins for small id spaces), "plog" (0 off / 1 auto / 2
  * always: partitioned miss log), "plog_max_bytes", "threads" (workgroup size of
  * the direct classify kernel), "blocks_per_cu"
- * (classify grid size per CU, 1..32).  Results never depend on them. */
+ * (classify grid size per CU, 1..32), "split" (0 off / 1 on: single-candidate
+ * reads in a first small kernel, the rest compacted into per-workgroup lists
+ * for the generic kernel), "subject_bins" (0/1: with a small subject table the
+ * first pass histograms subject indices and the assigners run once per
+ * subject), "single_blocks_per_cu" (grid of the first pass).
+ * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 
 /* ---- static state ------------------------------------------------------ */
@@ -257,8 +262,9 @@ int wk_tok_set_exclude(wk_tok* tok, const char* blob, const int32_t* off,
  * (leading '@' header lines are skipped).  Unless `final_block`, parsing stops
  * before the last QNAME run (it may continue in the next block); *consumed is
  * the number of bytes used — feed the rest again, followed by more text.
- * `extra`: also produce POS-1, reference end and aligned length per record
- * ("ex" flavour; zero-length hits are dropped).  `want_names`: keep a
+ * `extra` bit 0: also produce POS-1, reference end and aligned length per
+ * record ("ex" flavour; zero-length hits are dropped unless bit 1 is set — the
+ * coverage mapper, range.py:21, keeps them).  `want_names`: keep a
  * descriptor of every read's QNAME.  Results are held by the tokenizer until
  * the next call; sizes are returned in *n_reads / *n_records. */
 int wk_tok_sam(wk_tok* tok, const char* buf, int64_t len, int first_block,
@@ -319,8 +325,8 @@ int wk_tok_new_subjects(wk_tok* tok, char* blob, int32_t* off);
  * this library is launched on).  wk_timer_begin/end bracket a region;
  * wk_timer_ms returns the elapsed GPU time of the last closed region.
  * wk_last_kernel_ms returns the duration of the most recent launch of the
- * named kernel family ("classify", "match_count", "match_write", "scan",
- * "rank_table", "compact"), measured with events around that launch; event
+ * named kernel family ("classify", "leftover", "dense_merge", "partition_merge",
+ * "match_count", "match_write", "scan", "rank_table", "compact"), measured with events around that launch; event
  * recording around individual kernels is enabled by wk_profile_kernels(1). */
 int wk_timer_begin(wk_ctx* ctx);
 int wk_timer_end(wk_ctx* ctx);

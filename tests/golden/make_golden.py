@@ -451,6 +451,56 @@ def gen_host(seed=17):
     dump('host.json', out)
 
 
+def gen_coverage(seed=23):
+    """--outcov: merge_ranges on random interval lists, write_coverage's
+    coordinate styles, and the reference workflow's .cov files for the bowtie2
+    (one file per sample), burst (b6o) and multiplexed inputs."""
+    import tempfile
+    from woltka.range import merge_ranges, write_coverage
+    from woltka.workflow import workflow
+    rng = random.Random(seed)
+    merges = []
+    for _ in range(60):
+        k = rng.randint(0, 12)
+        flat = []
+        for _ in range(k):
+            a = rng.randint(0, 60)
+            flat.extend((a, a + rng.randint(-1, 15)))
+        merges.append({'ranges': flat, 'merged': merge_ranges(flat)})
+    styles = {}
+    covers = {'S1': {'G2': [5, 10, 20, 35], 'G1': [0, 7]}, 'S0': {'G9': [3, 4]}}
+    for fmt in (None, 'bed', 'BED', 'gff', '0i', '1i', '1e', '-2e', 'xe', 'foo'):
+        with tempfile.TemporaryDirectory() as tmp:
+            try:
+                write_coverage(covers, tmp, fmt)
+            except ValueError as e:
+                styles[str(fmt)] = {'error': str(e)}
+                continue
+            styles[str(fmt)] = {x[:-4]: open(os.path.join(tmp, x)).read()
+                                for x in sorted(os.listdir(tmp))}
+    runs = {}
+    ref = os.path.join(_refshim.REFERENCE_ROOT, 'woltka', 'tests', 'data')
+    jobs = {
+        'bowtie2': dict(input_fp=os.path.join(ref, 'align', 'bowtie2')),
+        'bowtie2_gff': dict(input_fp=os.path.join(ref, 'align', 'bowtie2'),
+                            outcov_fmt='gff'),
+        'burst': dict(input_fp=os.path.join(ref, 'align', 'burst')),
+        'bt2sho_exclude': dict(
+            input_fp=os.path.join(ref, 'align', 'bt2sho'),
+            exclude='G000215745'),
+    }
+    for name, kw in jobs.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            cov = os.path.join(tmp, 'cov')
+            res = workflow(output_fp=os.path.join(tmp, 'out.tsv'),
+                           outcov_dir=cov, **kw)
+            runs[name] = {
+                'profile': res['none'],
+                'cov': {x[:-4]: open(os.path.join(cov, x)).read()
+                        for x in sorted(os.listdir(cov))}}
+    dump('coverage.json', {'merges': merges, 'styles': styles, 'runs': runs})
+
+
 def main():
     if not _refshim.install():
         print('reference tree not present: nothing to do')
@@ -462,6 +512,7 @@ def main():
     gen_glue()
     gen_readers()
     gen_host()
+    gen_coverage()
 
 
 if __name__ == '__main__':

@@ -278,3 +278,83 @@ def test_q2_style_classify(tmp_path):
         classify('x', 'genus', reference_taxonomy={}, reference_nodes='y')
     with pytest.raises(ValueError, match='must be specified'):
         classify('x', 'genus')
+
+
+# --------------------------------------------------------------------------
+# --outcov: subject coverage maps next to the profile (woltka/range.py;
+# reference test: woltka/tests/test_workflow.py:50-63)
+# --------------------------------------------------------------------------
+
+def _coverage_gold():
+    import json
+    with open(join(DATA, '..', 'vectors', 'coverage.json')) as fh:
+        return json.load(fh)['runs']
+
+
+def _read_cov(dir_):
+    return {x[:-4]: open(join(dir_, x)).read() for x in sorted(os.listdir(dir_))}
+
+
+@pytest.mark.parametrize('name,params', [
+    ('bowtie2', ['--input', join(ALN, 'bowtie2')]),             # native SAM
+    ('bowtie2_gff', ['--input', join(ALN, 'bowtie2'), '--cov-fmt', 'gff']),
+    ('burst', ['--input', join(ALN, 'burst')]),                 # Python b6o
+    ('bt2sho_exclude', ['--input', join(ALN, 'bt2sho'),         # Python SAM
+                        '--exclude', 'G000215745'])])
+def test_outcov_matches_reference(tmp_path, name, params):
+    gold = _coverage_gold()[name]
+    cov = str(tmp_path / 'cov')
+    run(params + ['--outcov', cov], tmp_path,
+        'bowtie2.ogu.tsv' if name.startswith('bowtie2') else None)
+    assert _read_cov(cov) == gold['cov']
+    # the profile next to it is the reference's too
+    with open(tmp_path / 'output.tsv') as fh:
+        head = fh.readline().rstrip('\n').split('\t')[1:]
+        got = {s: {} for s in head}
+        for line in fh:
+            row = line.rstrip('\n').split('\t')
+            for s, v in zip(head, row[1:]):
+                if v != '0':
+                    got[s][row[0]] = int(v)
+    assert got == gold['profile']
+
+
+def test_outcov_line_checks_of_reference_test(tmp_path):
+    """The assertions of woltka/tests/test_workflow.py:50-63."""
+    cov = str(tmp_path / 'cov')
+    run(['--input', join(ALN, 'bowtie2'), '--outcov', cov], tmp_path, None)
+    with open(join(cov, 'S04.cov')) as f:
+        obs = f.read().splitlines()
+    assert len(obs) == 1078
+    assert obs[10] == 'G000007265\t2092665\t2092815'
+    assert obs[200] == 'G000215745\t768757\t769038'
+
+
+def test_outcov_demultiplexed_equals_per_file(tmp_path):
+    """Coverage of a multiplexed SAM file (demultiplexed on the fly, with a
+    whitelist) equals the per-file coverage of the same records."""
+    import lzma
+    mux = tmp_path / 'mux.sam'
+    with open(mux, 'w') as out:
+        for i in range(1, 6):
+            with lzma.open(join(ALN, 'bowtie2', f'S0{i}.sam.xz'), 'rt') as f:
+                for line in f:
+                    if line[0] != '@':
+                        out.write(f'S0{i}_{line}')
+    ids = tmp_path / 'ids.txt'
+    ids.write_text('S02\nS04\n')
+    cov = str(tmp_path / 'cov')
+    run(['--input', str(mux), '--demux', '--samples', str(ids),
+         '--outcov', cov], tmp_path, None)
+    gold = _coverage_gold()['bowtie2']['cov']
+    assert _read_cov(cov) == {s: gold[s] for s in ('S02', 'S04')}
+
+
+def test_outcov_with_coords_is_rejected(tmp_path):
+    from woltka_amd.cli import classify_cmd
+    res = CliRunner().invoke(classify_cmd, [
+        '--input', join(ALN, 'burst'), '--coords',
+        join(FUN, 'coords.txt.xz'), '--outcov', str(tmp_path / 'cov'),
+        '--output', str(tmp_path / 'o.tsv'), '--no-exe'])
+    assert res.exit_code != 0
+    assert '--outcov' in str(res.exception)

@@ -201,8 +201,17 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     assert np.array_equal(vals2[order], ocnt.astype(np.int64))
     # ... with the dense-bin path switched off, and with the partitioned miss
     # log forced on (tiny streams -> also exercises the overflow fallback)
+    # ... and with the two-class split (single-candidate pass + compacted
+    # second pass) forced on / off on top of each counting level
     for opts in (dict(dense=0, plog=0), dict(dense=0, plog=2),
-                 dict(dense=0, plog=2, plog_max_bytes=1 << 22)):
+                 dict(dense=0, plog=2, plog_max_bytes=1 << 22),
+                 dict(dense=1, plog=1, plog_max_bytes=4 << 30, split=2),
+                 dict(dense=0, plog=0, split=2), dict(dense=0, plog=2, split=2),
+                 dict(dense=0, plog=2, plog_max_bytes=1 << 22, split=2),
+                 # the per-read first pass instead of the subject histogram
+                 dict(dense=1, plog=1, plog_max_bytes=4 << 30, subject_bins=0),
+                 dict(dense=0, plog=0), dict(dense=0, plog=2),
+                 dict(dense=1, plog=1, split=0, subject_bins=1)):
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.counts_clear()
@@ -214,6 +223,20 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     ctx.set_option('dense', 1)
     ctx.set_option('plog', 1)
     ctx.set_option('plog_max_bytes', 4 << 30)
+    # per-read assignments and statistics through the forced split
+    ctx.set_option('split', 2)
+    ctx.counts_clear()
+    ctx.reset_stats()
+    assign4 = ctx.classify_staged(jobs, want_assign=True)
+    keys4, vals4 = ctx.counts_fetch()
+    assert np.array_equal(assign4, oassign)
+    order = np.argsort(keys4)
+    assert np.array_equal(keys4[order], okeys)
+    assert np.array_equal(vals4[order], ocnt.astype(np.int64))
+    st = ctx.stats()
+    assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
+    assert st['n_records'] == prob['subj'].size
+    ctx.set_option('split', 1)
     ctx.set_option('use_lds', 1)
 
 

@@ -172,6 +172,7 @@ class Engine:
         self._tok_map = np.empty(0, dtype=np.int32)
         self._tok_identity = True
         self._tok_genome = np.empty(0, dtype=np.int32)
+        self._tok_cover = np.empty(0, dtype=np.int64)
 
     def close(self):
         if self.tok is not None:
@@ -195,10 +196,14 @@ class Engine:
 
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,
-                      want_strings=True, want_samples=False):
+                      want_strings=True, want_samples=False, cover=None):
         """SAM text -> packed chunks through the native tokenizer.  Yields
-        (reads or None, packed) where packed = (subj, qoff) of subject indices,
-        or for coord-match (genome, beg, end, length, hoff)."""
+        (reads or None, packed, strata ids, name descriptors, sample ids,
+        ranges) where packed = (subj, qoff) of subject indices, or for
+        coord-match (genome, beg, end, length, hoff).  With ``cover`` (a
+        ``ranges.Coverage``) the "ex" columns are produced for plain
+        classification too and ``ranges`` = (coverage subject id, beg, end) per
+        record."""
         from .align import native_sam_blocks
         if self.tok is None:
             self.tok = nat.Tokenizer(0, exclude)
@@ -206,7 +211,8 @@ class Engine:
 
         def blocks():
             for buf, res in native_sam_blocks(stream, tok, block_bytes,
-                                              extra=ordinal,
+                                              extra=3 if cover is not None
+                                              else int(ordinal),
                                               want_names=want_names,
                                               head=head,
                                               want_groups=want_groups,
@@ -218,6 +224,11 @@ class Engine:
 
         for buf, res, fresh, fresh_samples in _prefetch(blocks()):
             self._tok_samples.extend(fresh_samples)
+            if fresh and cover is not None:
+                self._tok_cover = np.concatenate([
+                    self._tok_cover,
+                    np.fromiter(map(cover.subject, fresh), np.int64,
+                                len(fresh))])
             if fresh:
                 if ordinal:
                     gidx = self.genes.genome_index.get
@@ -248,8 +259,11 @@ class Engine:
                 subj = res['subj'] if self._tok_identity \
                     else self._tok_map[res['subj']]
                 packed = (subj, res['off'])
+            ranges = None if cover is None else (
+                self._tok_cover[res['subj']], res['beg'], res['end'])
             if res['off'].size > 1:
-                yield reads, packed, res.get('group'), names, res.get('sample')
+                yield reads, packed, res.get('group'), names, \
+                    res.get('sample'), ranges
 
     # ------------------------------------------------------------------
     def set_genes(self, table, prefix):

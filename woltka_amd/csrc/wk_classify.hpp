@@ -47,7 +47,8 @@ struct ClassifyArgs {
     // dense bins (see LdsCache): per-workgroup slab rows in HBM, merged by
     // dense_merge_kernel
     uint32_t dense_bins;
-    uint32_t* dense_slab;  // [gridDim.x][n_jobs * dense_bins]
+    uint32_t dense_total;  // bins per slab row: n_jobs * dense_bins, or the subject count (count-first pass)
+    uint32_t* dense_slab;  // [gridDim.x][dense_total]
     // partitioned miss log (see LdsCache): [gridDim.x][kLogParts][plog_cap] keys
     // and [gridDim.x][kLogParts] stream lengths
     unsigned long long* plog;
@@ -58,6 +59,17 @@ struct ClassifyArgs {
     unsigned long long* log_cursor;
     int64_t log_cap;
     uint32_t ablate;  // measurement builds only (-DWK_ABLATE): 1 = drop counts, 2 = skip flush
+    // second pass (classify_kernel after classify_single_kernel): merges the
+    // first pass's slab (first_*), compacts its workgroup's share of left_mask
+    // into read_list[blockIdx.x * list_seg ...] and walks that list
+    const unsigned long long* left_mask;
+    uint32_t n_mask_words;
+    uint32_t list_seg;
+    uint32_t* read_list;
+    const uint32_t* first_slab;  // [first_rows][first_total] or null
+    uint32_t first_rows, first_total;
+    int32_t first_by_subject;  // slab columns are subject indices (else job * bins + feature)
+    int32_t resume;            // continue the first pass's miss-log streams
 };
 
 // tree.find_rank for all nodes (tree.py:467-510): the taxon itself is tested
@@ -471,19 +483,22 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
 // A read with a single candidate (the bulk of real inputs) needs none of the
 // set logic: every assigner reduces to one table value.  `row` is the
 // candidate's subject row {feature, rank col 0, 1, 2}.
+// Assignment of a read with one candidate under one job (classify.py:216-331
+// with a one-element subject set): the feature itself, its parent, or its
+// ancestor at the job's rank.
+__device__ __forceinline__ int32_t single_result(const ClassifyArgs& a, const JobDev& job, const int4 row) {
+    const int32_t f = row.x;
+    if (job.mode == WK_MODE_NONE) return f;
+    if (job.mode == WK_MODE_FREE)
+        return (job.flags & WK_F_SUBOK) ? f : ((f < a.n_nodes) ? a.nodes[f].parent : WK_ASSIGN_NONE);
+    const int32_t t = job.col == 0 ? row.y : (job.col == 1 ? row.z : row.w);
+    return t < 0 ? WK_ASSIGN_NONE : t;
+}
+
 template <bool kUseLds>
 __device__ __forceinline__ void single_job(const ClassifyArgs& a, const LdsCache& cache, const JobDev& job, int jb,
                                            const int4 row, uint32_t r, int32_t g) {
-    const int32_t f = row.x;
-    int32_t res;
-    if (job.mode == WK_MODE_NONE) {
-        res = f;
-    } else if (job.mode == WK_MODE_FREE) {
-        res = (job.flags & WK_F_SUBOK) ? f : ((f < a.n_nodes) ? a.nodes[f].parent : WK_ASSIGN_NONE);
-    } else {
-        const int32_t t = job.col == 0 ? row.y : (job.col == 1 ? row.z : row.w);
-        res = t < 0 ? WK_ASSIGN_NONE : t;
-    }
+    const int32_t res = single_result(a, job, row);
     if (a.out_assign) a.out_assign[(int64_t)jb * a.n_reads + r] = res;
     if (g < 0) return;
     int32_t out = res;
@@ -492,7 +507,7 @@ __device__ __forceinline__ void single_job(const ClassifyArgs& a, const LdsCache
         out = WK_FEATURE_UNASSIGNED;
     }
     if (job.flags & WK_F_SIZED)
-        log_append(a, out, f, jb, 1, g);
+        log_append(a, out, row.x, jb, 1, g);
     else
         count_add<kUseLds>(cache, a.table, jb, 1, g, (uint32_t)out);
 }
@@ -532,40 +547,168 @@ __device__ __forceinline__ void flush_stats(const ClassifyArgs& a, unsigned long
     }
 }
 
+// LDS front cache of a classify workgroup: hash buckets, then either the
+// miss-log cursors or the dense bins.  With `a.resume` (second pass of the
+// two-class split) the cursors start from the stream lengths the first pass
+// left.
+__device__ __forceinline__ void cache_setup(LdsCache& cache, const ClassifyArgs& a, unsigned char* smem,
+                                            uint32_t lds_slots) {
+    cache.base = reinterpret_cast<unsigned long long*>(smem);
+    cache.bmask = lds_slots / 4 - 1;
+    if (a.plog) {
+        cache.plog_cur = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
+        cache.plog = a.plog + (size_t)blockIdx.x * kLogParts * a.plog_cap;
+        cache.plog_cap = a.plog_cap;
+        const uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * kLogParts;
+        for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) cache.plog_cur[i] = a.resume ? cnt[i] : 0u;
+    } else if (a.dense_bins) {
+        cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
+        cache.dense_bins = a.dense_bins;
+        const uint32_t nb = a.dense_total;
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cache.dense[i] = 0u;
+    }
+    lds_cache_init(cache);
+}
+
+__device__ __forceinline__ void cache_finish(const LdsCache& cache, const ClassifyArgs& a) {
+    lds_cache_flush(cache, a.table);  // starts with a workgroup barrier
+    if (cache.plog_cur) {
+        uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * kLogParts;
+        for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) {
+            const uint32_t n = cache.plog_cur[i];
+            cnt[i] = n < a.plog_cap ? n : a.plog_cap;
+        }
+    }
+    if (cache.dense) {
+        const uint32_t nb = a.dense_total;
+        uint32_t* row = a.dense_slab + (size_t)blockIdx.x * nb;
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) row[i] = cache.dense[i];
+    }
+}
+
+// Second-pass prologue 1: the first pass's slab -> count table.  Column sums
+// over the first pass's workgroups (a unit = 64 adjacent columns, its rows
+// split over the waves); per-subject columns then go through every job's
+// assigner once — the per-read loop of classify.assign_* collapsed to a
+// per-subject one — and (job, feature) columns are keys already.  A chunk of
+// the split holds < 2^30 reads, so 32-bit sums are exact.
+__device__ __forceinline__ void merge_first_pass(const ClassifyArgs& a, uint32_t (*part)[kWave]) {
+    if (!a.first_slab) return;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t units = (a.first_total + kWave - 1) / kWave;
+    for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const uint32_t i = u * kWave + lane;
+        uint32_t sum = 0;
+        if (i < a.first_total) {
+#pragma unroll 4
+            for (uint32_t row = wave; row < a.first_rows; row += n_waves) sum += a.first_slab[(size_t)row * a.first_total + i];
+        }
+        part[wave][lane] = sum;
+        __syncthreads();
+        if (wave == 0 && i < a.first_total) {
+            for (uint32_t q = 1; q < n_waves; ++q) sum += part[q][lane];
+            if (sum != 0u) {
+                if (a.first_by_subject) {
+                    const int4 row = reinterpret_cast<const int4*>(a.rows)[i];
+                    if ((uint32_t)row.x > (uint32_t)WK_MAX_FEATURE) atomicOr(a.table.err, kErrFeatureRange);
+                    for (int jb = 0; jb < a.n_jobs; ++jb) {
+                        const JobDev& job = a.jobs[jb];
+                        const int32_t res = single_result(a, job, row);
+                        int32_t out = res;
+                        if (res < 0) {
+                            if (!(job.flags & WK_F_UNASSIGNED)) continue;
+                            out = WK_FEATURE_UNASSIGNED;
+                        }
+                        table_add(a.table, make_key((uint32_t)jb, 1u, 0u, (uint32_t)out), sum);
+                    }
+                } else {
+                    const uint32_t bins = a.first_total / (uint32_t)a.n_jobs;
+                    table_add(a.table, make_key(i / bins, 1u, 0u, i % bins), sum);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Second-pass prologue 2: the workgroup's share of left_mask (128-byte chunks
+// of 16 words = 1024 reads, dealt round-robin so that clustered multi-hit
+// reads spread over all workgroups) -> its segment of read_list.  Returns the
+// number of reads listed.  No global atomics, no grid-wide step.
+__device__ __forceinline__ uint32_t compact_left(const ClassifyArgs& a, uint32_t* scan_tot) {
+    uint32_t* __restrict__ list = a.read_list + (size_t)blockIdx.x * a.list_seg;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t per_round = blockDim.x >> 4;  // chunks per round
+    uint32_t running = 0;
+    for (uint32_t c0 = 0; ((size_t)c0 * gridDim.x + blockIdx.x) * 16u < a.n_mask_words; c0 += per_round) {
+        const uint32_t c = c0 + (threadIdx.x >> 4);
+        const size_t w = (((size_t)c * gridDim.x + blockIdx.x) << 4) + (threadIdx.x & 15u);
+        unsigned long long m = w < a.n_mask_words ? a.left_mask[w] : 0ull;
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        uint32_t inc = cnt;  // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off, kWave);
+            if ((int)lane >= off) inc += v;
+        }
+        if (lane == kWave - 1) scan_tot[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t q = 0; q < n_waves; ++q) {
+            const uint32_t tq = scan_tot[q];
+            before += q < wave ? tq : 0u;
+            total += tq;
+        }
+        uint32_t pos = running + before + inc - cnt;
+        while (m) {
+            const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
+            list[pos++] = ((uint32_t)w << 6) + b;
+            m &= m - 1ull;
+        }
+        running += total;
+        __syncthreads();
+    }
+    return running;
+}
+
 // Direct variant: one thread per read, candidates read straight from HBM.
 // Kept as the simple baseline of the tiled kernel (A/B via the "tiled" option)
 // and used when the LDS front cache is switched off.
-template <bool kUseLds>
+template <bool kUseLds, bool kListed = false>
 __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool listed = kUseLds && kListed;
+    int64_t n_items = a.n_reads;
+    const uint32_t* __restrict__ my_list = nullptr;
+    if constexpr (listed) {
+        __shared__ uint32_t part[16][kWave];
+        __shared__ uint32_t scan_tot[16];
+        merge_first_pass(a, part);
+        n_items = (int64_t)compact_left(a, scan_tot);  // ends with a workgroup barrier
+        my_list = a.read_list + (size_t)blockIdx.x * a.list_seg;
+        if (n_items == 0) {
+            // nothing left over here; a pass that owns its log streams leaves
+            // this workgroup's empty for the merge
+            if (a.plog && !a.resume)
+                for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x)
+                    a.plog_cnt[(size_t)blockIdx.x * kLogParts + i] = 0u;
+            return;
+        }
+    }
     LdsCache cache{};
 #ifdef WK_ABLATE
     cache.ablate = a.ablate;
 #endif
-    if constexpr (kUseLds) {
-        cache.base = reinterpret_cast<unsigned long long*>(smem);
-        cache.bmask = lds_slots / 4 - 1;
-        if (a.plog) {
-            cache.plog_cur = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
-            cache.plog = a.plog + (size_t)blockIdx.x * kLogParts * a.plog_cap;
-            cache.plog_cap = a.plog_cap;
-            for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) cache.plog_cur[i] = 0u;
-        } else if (a.dense_bins) {
-            cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
-            cache.dense_bins = a.dense_bins;
-            const uint32_t nb = a.dense_bins * (uint32_t)a.n_jobs;
-            for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cache.dense[i] = 0u;
-        }
-        lds_cache_init(cache);
-    }
+    if constexpr (kUseLds) cache_setup(cache, a, smem, lds_slots);
     unsigned long long my_reads = 0, my_records = 0;
     // Software pipeline over the thread's reads r, r+stride, ...: loads of the
     // following reads are in flight while read i is evaluated, so the
     // offset -> record (-> subject row) chain is off the critical path and only
     // the gathers of read i's further candidates are exposed.
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // (a listed pass walks its workgroup's own list: workgroup-local stride)
+    const int64_t stride = listed ? (int64_t)blockDim.x : (int64_t)gridDim.x * blockDim.x;
     const int64_t last = a.n_reads - 1;
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t r = listed ? (int64_t)threadIdx.x : (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     auto load_offsets = [&](int64_t i, int32_t& s, int32_t& e) {
         const int64_t c = i < a.n_reads ? i : last;  // clamped: harmless re-read past the end
         s = a.qoff[c];
@@ -589,24 +732,33 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         auto load_row = [&](int32_t c) -> int4 {
             return ((uint32_t)c < (uint32_t)a.n_subjects) ? rows4[c] : make_int4(-1, -1, -1, -1);
         };
+        // with a read list (second pass of the two-class split) one more
+        // stage in front: list entry (i+4) -> offsets (i+3) -> ...
+        auto item = [&](int64_t i) -> int64_t {
+            if constexpr (!listed) return i;
+            else return (int64_t)my_list[i < n_items ? i : n_items - 1];
+        };
+        int64_t i = r;
+        int64_t r0 = item(i), r1 = item(i + stride), r2 = item(i + 2 * stride), r3 = item(i + 3 * stride);
         int32_t s0, e0, s1, e1, s2, e2;
-        load_offsets(r, s0, e0);
-        load_offsets(r + stride, s1, e1);
-        load_offsets(r + 2 * stride, s2, e2);
+        load_offsets(r0, s0, e0);
+        load_offsets(r1, s1, e1);
+        load_offsets(r2, s2, e2);
         int32_t c0 = load_first(s0, e0), c1 = load_first(s1, e1);
         int4 row0 = load_row(c0);
-        int32_t g0 = load_group(r);
+        int32_t g0 = load_group(r0);
         const bool one_job = a.n_jobs == 1;
         const JobDev job0 = a.jobs[0];  // kept in registers for the common single-rank run
-        for (; r < a.n_reads; r += stride) {
+        for (; i < n_items; i += stride) {
+            const int64_t r4 = item(i + 4 * stride);
             int32_t s3, e3;
-            load_offsets(r + 3 * stride, s3, e3);
+            load_offsets(r3, s3, e3);
             const int32_t c2 = load_first(s2, e2);
             const int4 row1 = load_row(c1);
-            const int32_t g1 = load_group(r + stride);
+            const int32_t g1 = load_group(r1);
             const int32_t n = e0 - s0;
             if (n <= 0) {
-                mark_empty(a, r);
+                mark_empty(a, r0);
             } else if (n == 1 && (uint32_t)c0 < (uint32_t)a.n_subjects) {
                 my_reads += 1;
                 my_records += 1;
@@ -617,9 +769,9 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
                 {
                     if (one_job) {
                         if ((uint32_t)row0.x > (uint32_t)WK_MAX_FEATURE) atomicOr(a.table.err, kErrFeatureRange);
-                        single_job<kUseLds>(a, cache, job0, 0, row0, r, g0);
+                        single_job<kUseLds>(a, cache, job0, 0, row0, r0, g0);
                     } else {
-                        process_single<kUseLds>(a, cache, row0, r, g0);
+                        process_single<kUseLds>(a, cache, row0, r0, g0);
                     }
                 }
             } else {
@@ -629,10 +781,11 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
                 if (!ok)
                     atomicOr(a.table.err, kErrFeatureRange);
                 else
-                    evaluate(RowCand4<const int32_t*>{a.subj + s0, rows4, row0}, n, r, g0, row0.x);
+                    evaluate(RowCand4<const int32_t*>{a.subj + s0, rows4, row0}, n, r0, g0, row0.x);
             }
             s0 = s1; e0 = e1; s1 = s2; e1 = e2; s2 = s3; e2 = e3;
             c0 = c1; c1 = c2; row0 = row1; g0 = g1;
+            r0 = r1; r1 = r2; r2 = r3; r3 = r4;
         }
     } else {
         const bool use_rows = a.rows != nullptr;
@@ -671,21 +824,157 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         }
     }
     flush_stats(a, my_reads, my_records);
-    if constexpr (kUseLds) {
-        lds_cache_flush(cache, a.table);  // starts with a workgroup barrier
-        if (cache.plog_cur) {
-            uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * kLogParts;
-            for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) {
-                const uint32_t n = cache.plog_cur[i];
-                cnt[i] = n < a.plog_cap ? n : a.plog_cap;
+    if constexpr (kUseLds) cache_finish(cache, a);
+}
+
+// ---- two-class split ---------------------------------------------------------
+// Real inputs are mostly reads with one candidate plus a tail of multi-hit
+// reads.  Evaluating both classes in one loop leaves the lanes of the cheap
+// class idle while one lane walks a candidate list, and the generic
+// evaluator's register / scalar pressure slows the cheap class down as well.
+// So the chunk is split by class:
+//   1. classify_single_kernel: a small kernel that evaluates every read with
+//      exactly one candidate (and marks empty reads), and emits one bit per
+//      read — the ballot of "not handled here" — into left_mask;
+//   2. classify_kernel as the second pass: every workgroup merges its share of
+//      the first pass's bins into the count table, compacts its share of the
+//      bits into a list of read indices and walks that list (every lane busy
+//      with a multi-hit read).  Two launches per chunk, no grid-wide step.
+// All index arithmetic of pass 1 is 32-bit; the host selects the split only
+// when n_reads, n_records < 2^30 and n_subjects < 2^28.
+//
+// Count first, classify later (kBySubject): when the subject table is small
+// (the usual genome-level databases: ~10-30 k subjects) the first pass does not
+// even look at the subject rows — it histograms the *subject indices* of the
+// single-candidate reads in LDS bins (one coalesced 4-byte load + one ds_add
+// per read), and the second pass's prologue applies the assigners once per
+// subject instead of once per read.  A random 16-byte row gather per read costs a full
+// 128-byte L2->L1 line each, which bounds the per-read variant.
+//
+// kReads reads per thread and round, 64 apart inside the wave's window, so that
+// every load is coalesced and kReads x more bytes are in flight per wave.
+template <bool kBySubject, bool kOneJob, int kReads>
+__global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, uint32_t lds_slots,
+                                                               unsigned long long* __restrict__ left_mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsCache cache{};
+#ifdef WK_ABLATE
+    cache.ablate = a.ablate;
+#endif
+    cache_setup(cache, a, smem, lds_slots);
+
+    const uint32_t n_reads = (uint32_t)a.n_reads, last = n_reads - 1u;
+    const uint32_t n_subjects = (uint32_t)a.n_subjects;
+    const uint32_t tile = blockDim.x * (uint32_t)kReads;  // reads per workgroup round
+    const uint32_t stride = gridDim.x * tile;
+    const char* __restrict__ qoff_b = reinterpret_cast<const char*>(a.qoff);
+    const char* __restrict__ subj_b = reinterpret_cast<const char*>(a.subj);
+    const char* __restrict__ rows_b = reinterpret_cast<const char*>(a.rows);
+    const char* __restrict__ group_b = reinterpret_cast<const char*>(a.group);
+    const bool grouped = !kBySubject && a.group != nullptr;
+    // read k of this thread in the round that starts at `base`: the wave's
+    // window is kReads * 64 consecutive reads, lane-contiguous per k
+    const uint32_t lane_off = (threadIdx.x >> 6) * (kWave * (uint32_t)kReads) + (threadIdx.x & (kWave - 1));
+
+    struct Offs { int32_t s[kReads], e[kReads]; };
+    struct Firsts { uint32_t c[kReads]; };
+    struct Rows { int4 v[kBySubject ? 1 : kReads]; };
+    // byte offsets stay below 2^32: every access is base (SGPR pair) + 32-bit lane offset
+    auto load_offsets = [&](uint32_t base, Offs& o) {
+#pragma unroll
+        for (int k = 0; k < kReads; ++k) {
+            const uint32_t i = base + lane_off + (uint32_t)k * kWave;
+            const uint32_t off = (i < last ? i : last) << 2;  // clamped: harmless re-read past the end
+            o.s[k] = *reinterpret_cast<const int32_t*>(qoff_b + off);
+            o.e[k] = *reinterpret_cast<const int32_t*>(qoff_b + off + 4u);
+        }
+    };
+    auto load_firsts = [&](const Offs& o, Firsts& f) {
+#pragma unroll
+        for (int k = 0; k < kReads; ++k)
+            f.c[k] = (o.e[k] > o.s[k]) ? *reinterpret_cast<const uint32_t*>(subj_b + ((uint32_t)o.s[k] << 2))
+                                       : 0xFFFFFFFFu;
+    };
+    auto load_rows = [&](const Firsts& f, Rows& w) {
+        if constexpr (!kBySubject) {
+#pragma unroll
+            for (int k = 0; k < kReads; ++k)
+                w.v[k] = (f.c[k] < n_subjects) ? *reinterpret_cast<const int4*>(rows_b + (f.c[k] << 4))
+                                               : make_int4(-1, -1, -1, -1);
+        }
+    };
+
+    uint32_t base = blockIdx.x * tile;
+    uint32_t handled = 0, bad = 0;
+    // stages: offsets (t+3) -> first subject indices (t+2) -> their rows (t+1) -> evaluate (t)
+    Offs o0{}, o1{}, o2{}, o3{};
+    Firsts f0{}, f1{}, f2{};
+    Rows w0{}, w1{};
+    load_offsets(base, o0);
+    load_offsets(base + stride, o1);
+    load_offsets(base + 2u * stride, o2);
+    load_firsts(o0, f0);
+    load_firsts(o1, f1);
+    load_rows(f0, w0);
+    const JobDev job0 = a.jobs[0];
+    const int n_jobs = kOneJob ? 1 : a.n_jobs;
+    for (; base < n_reads; base += stride) {
+        load_offsets(base + 3u * stride, o3);
+        load_firsts(o2, f2);
+        load_rows(f1, w1);
+        int32_t g[kReads];
+#pragma unroll
+        for (int k = 0; k < kReads; ++k) g[k] = 0;
+        if (grouped) {
+#pragma unroll
+            for (int k = 0; k < kReads; ++k) {
+                const uint32_t i = base + lane_off + (uint32_t)k * kWave;
+                g[k] = *reinterpret_cast<const int32_t*>(group_b + ((i < last ? i : last) << 2));
             }
         }
-        if (cache.dense) {
-            const uint32_t nb = a.dense_bins * (uint32_t)a.n_jobs;
-            uint32_t* row = a.dense_slab + (size_t)blockIdx.x * nb;
-            for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) row[i] = cache.dense[i];
+        bool mine[kReads];
+#pragma unroll
+        for (int k = 0; k < kReads; ++k) {
+            const uint32_t r = base + lane_off + (uint32_t)k * kWave;
+            const int32_t n = o0.e[k] - o0.s[k];
+            const bool in = r < n_reads;
+            mine[k] = in & (n == 1) & (f0.c[k] < n_subjects);
+            if (in & (n <= 0)) mark_empty(a, r);
+            handled += mine[k] ? 1u : 0u;
+            // one bit per read: left for the second pass (several candidates, or
+            // a subject index outside the table, which that pass reports)
+            const unsigned long long left = __ballot(in & (n > 0) & !mine[k]);
+            if ((threadIdx.x & (kWave - 1)) == 0 && r < n_reads) left_mask[r >> 6] = left;
+            if constexpr (kBySubject) {
+#ifdef WK_ABLATE
+                if (a.ablate & 9) continue;
+#endif
+                if (mine[k]) atomicAdd(&cache.dense[f0.c[k]], 1u);
+            } else {
+                bad |= (mine[k] && (uint32_t)w0.v[k].x > (uint32_t)WK_MAX_FEATURE) ? 1u : 0u;
+                bad |= (mine[k] && g[k] >= (1 << WK_KEY_GROUP_BITS)) ? 2u : 0u;
+            }
         }
+        if constexpr (!kBySubject) {
+#ifdef WK_ABLATE
+            if (!(a.ablate & 8))
+#endif
+            for (int jb = 0; jb < n_jobs; ++jb) {
+                const JobDev& job = kOneJob ? job0 : a.jobs[jb];
+#pragma unroll
+                for (int k = 0; k < kReads; ++k)
+                    if (mine[k])
+                        single_job<true>(a, cache, job, jb, w0.v[k], base + lane_off + (uint32_t)k * kWave, g[k]);
+            }
+        }
+        o0 = o1; o1 = o2; o2 = o3;
+        f0 = f1; f1 = f2;
+        w0 = w1;
     }
+    if (bad & 1u) atomicOr(a.table.err, kErrFeatureRange);
+    if (bad & 2u) atomicOr(a.table.err, kErrGroupRange);
+    flush_stats(a, handled, handled);
+    cache_finish(cache, a);
 }
 
 // Column sums of the workgroups' dense-bin slab rows -> count table.  One key
@@ -723,11 +1012,16 @@ __global__ void __launch_bounds__(1024) partition_merge_kernel(const unsigned lo
                                                                uint32_t n_rows, uint32_t plog_cap,
                                                                uint32_t lds_slots, CountTable table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t part = blockIdx.x;
+    // an empty partition (a second pass with little left over) costs one look
+    // at its stream lengths, not an LDS table
+    uint32_t any = 0;
+    for (uint32_t row = threadIdx.x; row < n_rows; row += blockDim.x) any |= plog_cnt[(size_t)row * kLogParts + part];
+    if (!__syncthreads_or((int)(any != 0u))) return;
     LdsCache cache{};
     cache.base = reinterpret_cast<unsigned long long*>(smem);
     cache.bmask = lds_slots / 4 - 1;
     lds_cache_init(cache);
-    const uint32_t part = blockIdx.x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
     for (uint32_t row = wave; row < n_rows; row += n_waves) {  // one stream per wave at a time
         const uint32_t n = plog_cnt[(size_t)row * kLogParts + part];

@@ -203,8 +203,9 @@ struct wk_tok {
 
 namespace {
 
-void tokenize_range(const wk_tok* T, const char* base, const char* b, const char* e, bool extra, bool want_names,
+void tokenize_range(const wk_tok* T, const char* base, const char* b, const char* e, int extra_bits, bool want_names,
                     bool want_groups, bool want_samples, Local& out) {
+    const bool extra = (extra_bits & 1) != 0, keep_empty = (extra_bits & 2) != 0;
     const bool filt = T->exclude.size() > 0;
     static const char* const kSuffix[3] = {"", "/1", "/2"};
     std::string keybuf;
@@ -292,7 +293,7 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
             for (const char* c = L.pos; *c >= '0' && *c <= '9'; ++c) pos = pos * 10 + (*c - '0');
             uint32_t aligned, span;
             cigar_lens(L.cigar, L.cn, aligned, span);
-            if (aligned == 0) continue;  // ordinal.py:231
+            if (aligned == 0 && !keep_empty) continue;  // ordinal.py:231 (range.py keeps them)
             rc.beg = (int32_t)(pos - 1);
             rc.end = (int32_t)(pos - 1 + span);
             rc.len = aligned;
@@ -446,14 +447,14 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
         if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1];
     std::vector<Local> loc(T);
     if (T == 1) {
-        tokenize_range(t, buf, cut[0], cut[1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0,
+        tokenize_range(t, buf, cut[0], cut[1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
                        (want_names & 4) != 0, loc[0]);
     } else {
         std::vector<std::thread> th;
         th.reserve(T);
         for (int i = 0; i < T; ++i)
             th.emplace_back([&, i] {
-                tokenize_range(t, buf, cut[i], cut[i + 1], extra != 0, (want_names & 1) != 0, (want_names & 2) != 0,
+                tokenize_range(t, buf, cut[i], cut[i + 1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
                                (want_names & 4) != 0, loc[i]);
             });
         for (auto& x : th) x.join();

@@ -130,6 +130,12 @@ struct wk_ctx {
     int blocks_per_cu = 1;
     int ablate = 0;  // honoured only by -DWK_ABLATE measurement builds
     int tiled = 0;  // LDS-staged classify kernel (0: direct one-thread-per-read kernel)
+    // two-class split (single-candidate pass, then the generic pass over the
+    // rest): 0 = off, 1/2 = on whenever the chunk qualifies
+    int use_split = 1;
+    int single_blocks_per_cu = 1;
+    DevBuf left_mask, left_list, first_slab;
+    int use_subject_bins = 1;  // count-first mode of the split for small subject tables
 };
 
 namespace {
@@ -279,7 +285,15 @@ int wk_create(int device, wk_ctx** out) {
     }
     // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
     // (160 KiB per CU minus the kernels' few bytes of static LDS)
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true>),
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<true, true, 4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
@@ -300,7 +314,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4, &c->ginfo,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -358,6 +372,20 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     }
     if (!strcmp(name, "dense")) {
         c->use_dense = value ? 1 : 0;
+        return WK_OK;
+    }
+    if (!strcmp(name, "split")) {  // 0 = off, 1 = auto, 2 = always (when the chunk qualifies)
+        if (value < 0 || value > 2) return fail(c, WK_E_ARG, "split must be 0, 1 or 2");
+        c->use_split = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "subject_bins")) {
+        c->use_subject_bins = value ? 1 : 0;
+        return WK_OK;
+    }
+    if (!strcmp(name, "single_blocks_per_cu")) {
+        if (value < 1 || value > 8) return fail(c, WK_E_ARG, "single_blocks_per_cu must be in [1, 8]");
+        c->single_blocks_per_cu = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "tiled")) {
@@ -703,14 +731,25 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             hipLaunchKernelGGL(classify_tiled_kernel, dim3(blocks), dim3(kTileThreads), lds, c->stream, a,
                                (uint32_t)c->lds_slots, c->n_records);
         } else if (c->use_lds) {
-            const int blocks = grid_for(c->n_reads, c->threads, std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu));
+            bool sized = false;
+            for (int j = 0; j < n_jobs; ++j) sized |= (jobs[j].flags & WK_F_SIZED) != 0;
+            // two-class split (32-bit byte offsets in the first pass bound the
+            // sizes).  It pays even when only half of the reads have a single
+            // candidate (config 3: 10.6 -> 7.7 ms); a chunk without any pays one
+            // streaming pass over the offsets.
+            const bool split = c->use_split && c->subj_indexed && a.row_w == 4 && c->n_reads < (1ll << 30) &&
+                               c->n_records < (1ll << 30) && c->n_subjects < (1 << 28);
+            // ... and with a small subject table the first pass only histograms
+            // subject indices; the assigners run once per subject afterwards
+            const bool by_subject = split && c->use_subject_bins && !out_assign && !c->has_group && !sized &&
+                                    c->n_subjects <= 28672;
+            const int max_blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu);
+            const int blocks = grid_for(c->n_reads, c->threads, max_blocks);
             // dense bins: small id space, subject-indexed chunk, no size-normalised job
             int64_t bins = 0;
             int lds_slots = c->lds_slots;
-            if (c->use_dense && c->subj_indexed) {
+            if (c->use_dense && c->subj_indexed && !by_subject) {
                 const int64_t b = std::max<int64_t>(c->n_nodes, (int64_t)c->max_subject_feature + 1);
-                bool sized = false;
-                for (int j = 0; j < n_jobs; ++j) sized |= (jobs[j].flags & WK_F_SIZED) != 0;
                 if (!sized && b * n_jobs <= 28672) {  // <= 112 KiB of bins + 32 KiB hash cache = 144 KiB LDS
                     bins = b;
                     lds_slots = std::min(lds_slots, 2048);
@@ -722,12 +761,17 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // partitioned miss log: worth its fixed cost (1024-workgroup merge
             // launch) only when many keys can miss the LDS cache
             uint32_t plog_cap = 0;
-            if (!bins && (c->use_plog == 2 || (c->use_plog == 1 && c->n_records + c->n_reads >= (1 << 22)))) {
-                bool sized = false;
-                for (int j = 0; j < n_jobs; ++j) sized |= (jobs[j].flags & WK_F_SIZED) != 0;
+            // contributions that can reach the log: all of them, or — when the
+            // single-candidate reads are counted per subject — those of the
+            // multi-hit reads (each has >= 2 records, so at most twice the
+            // excess of records over reads when no read is empty; an estimate,
+            // the streams overflow into the count table)
+            const int64_t contrib = by_subject ? 3 * std::max<int64_t>(c->n_records - c->n_reads, 0) + 1024
+                                               : c->n_records + c->n_reads;
+            if (!bins && (c->use_plog == 2 || (c->use_plog == 1 && contrib >= (1 << 22)))) {
                 const int64_t streams = (int64_t)blocks * kLogParts;
                 // room for 3x the expected entries per stream if every contribution missed
-                int64_t cap = 3 * ((c->n_records + c->n_reads) * (int64_t)n_jobs / streams + 1) + 16;
+                int64_t cap = 3 * (contrib * (int64_t)n_jobs / streams + 1) + 16;
                 cap = std::min<int64_t>(cap, c->plog_max_bytes / 8 / streams);
                 if (!sized && cap >= 16) {
                     plog_cap = (uint32_t)cap;
@@ -743,9 +787,76 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 lds += (size_t)bins * n_jobs * 4;
                 HIP_TRY(c, c->dense_slab.reserve((size_t)blocks * bins * n_jobs * 4));
                 a.dense_bins = (uint32_t)bins;
+                a.dense_total = (uint32_t)(bins * n_jobs);
                 a.dense_slab = c->dense_slab.as<uint32_t>();
             }
-            hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)lds_slots);
+            if (split) {
+                // ---- first pass: single-candidate reads -----------------------------
+                const uint32_t n_words = (uint32_t)((c->n_reads + 63) / 64);
+                const uint32_t list_seg = (((n_words + 15u) / 16u + (uint32_t)blocks - 1u) / (uint32_t)blocks) * 1024u;
+                HIP_TRY(c, c->left_mask.reserve((size_t)n_words * 8));
+                HIP_TRY(c, c->left_list.reserve((size_t)blocks * list_seg * 4));
+                unsigned long long* mask = c->left_mask.as<unsigned long long>();
+                ClassifyArgs first = a;
+                first.plog = nullptr;  // (kept when the first pass counts per read, below)
+                first.plog_cnt = nullptr;
+                first.plog_cap = 0;
+                int blocks1 = blocks;
+                if (by_subject) {
+                    // its own grid and LDS layout: no hash cache to speak of, bins = subjects
+                    blocks1 = grid_for((c->n_reads + 3) / 4, 1024,
+                                       std::min(kStatBlocks, c->prop.multiProcessorCount * c->single_blocks_per_cu));
+                    HIP_TRY(c, c->first_slab.reserve((size_t)blocks1 * c->n_subjects * 4));
+                    first.dense_bins = (uint32_t)c->n_subjects;
+                    first.dense_total = (uint32_t)c->n_subjects;
+                    first.dense_slab = c->first_slab.as<uint32_t>();
+                    hipLaunchKernelGGL((classify_single_kernel<true, true, 4>), dim3(blocks1), dim3(1024),
+                                       64 * 16 + (size_t)c->n_subjects * 4, c->stream, first, 64u, mask);
+                } else {
+                    // per-read evaluation with the same counting levels as the second
+                    // pass; dense bins go to a slab of their own, log streams are shared
+                    size_t lds1 = lds;
+                    if (bins) {
+                        HIP_TRY(c, c->first_slab.reserve((size_t)blocks * bins * n_jobs * 4));
+                        first.dense_slab = c->first_slab.as<uint32_t>();
+                    } else {
+                        first.plog = a.plog;
+                        first.plog_cnt = a.plog_cnt;
+                        first.plog_cap = a.plog_cap;
+                    }
+                    if (n_jobs == 1)
+                        hipLaunchKernelGGL((classify_single_kernel<false, true, 1>), dim3(blocks), dim3(c->threads), lds1,
+                                           c->stream, first, (uint32_t)lds_slots, mask);
+                    else
+                        hipLaunchKernelGGL((classify_single_kernel<false, false, 1>), dim3(blocks), dim3(c->threads), lds1,
+                                           c->stream, first, (uint32_t)lds_slots, mask);
+                }
+                ktimer_end(c, kt);
+                kt = ktimer_begin(c, "leftover");
+                // ---- second pass: merges the first pass's bins, lists and walks the rest
+                a.left_mask = mask;
+                a.n_mask_words = n_words;
+                a.list_seg = list_seg;
+                a.read_list = c->left_list.as<uint32_t>();
+                if (by_subject || bins) {
+                    a.first_slab = c->first_slab.as<uint32_t>();
+                    a.first_rows = (uint32_t)blocks1;
+                    a.first_total = first.dense_total;
+                    a.first_by_subject = by_subject ? 1 : 0;
+                }
+                a.resume = (!by_subject && !bins && plog_cap) ? 1 : 0;
+                if (bins) {  // the second pass counts in the hash cache only
+                    a.dense_bins = 0;
+                    a.dense_total = 0;
+                    a.dense_slab = nullptr;
+                    lds = (size_t)lds_slots * 16;
+                    bins = 0;
+                }
+            }
+            if (split)
+                hipLaunchKernelGGL((classify_kernel<true, true>), dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)lds_slots);
+            else
+                hipLaunchKernelGGL((classify_kernel<true, false>), dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)lds_slots);
             if (plog_cap) {
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "partition_merge");

@@ -19,6 +19,7 @@ from os import makedirs
 from os.path import basename, isdir, isfile, join
 
 import click
+import numpy as np
 
 from .align import infer_align_format, plain_mapper
 from .classify import Engine
@@ -26,6 +27,7 @@ from .file import (id2file_from_dir, id2file_from_map, openzip, path2stem,
                    read_ids, read_map_1st, read_map_uniq, readzip, readzip_bytes,
                    stem2rank, write_readmap)
 from .ordinal import load_gene_coords
+from .ranges import Coverage, range_mapper, write_coverage
 from .shard import classify_sharded, env_rank
 from .table import allkeys, prep_table, write_table
 from .tree import (fill_root, read_columns, read_lineage, read_names,
@@ -185,11 +187,8 @@ def classify(mapper:  object,
     memoised, every read is evaluated by the kernels.  Counts are accumulated
     as exact integers on the device, so the result does not depend on ``chunk``.
     """
-    if outcov_dir:
-        raise NotImplementedError(
-            'Subject coverage output (--outcov) is not available on the GPU '
-            'path yet.')
     data = {x: {} for x in ranks}
+    cover = Coverage() if outcov_dir else None
     outzip = outzip if outzip != 'none' else None
     engine = Engine(tree, rankdic, root, ranks, uniq=uniq, major=major,
                     above=above, subok=subok, unasgd=unasgd, device=device,
@@ -204,13 +203,18 @@ def classify(mapper:  object,
         # formats (and the SAM "extra + exclude" flavour, whose reference
         # parser has a quirk reproduced only by the Python one) use the Python
         # parsers.  Query names are materialised only when something needs them.
-        native_ok = (mapper is plain_mapper or ordinal) and \
-            not (ordinal and exclude) and not (ordinal and trimsub)
+        if cover is not None and ordinal:
+            raise ValueError('Subject coverage (--outcov) needs subject-level '
+                             'alignments; it cannot be combined with --coords.')
+        native_ok = (mapper is plain_mapper or mapper is range_mapper or
+                     ordinal) and not ((ordinal or cover is not None) and
+                                       exclude) and not (ordinal and trimsub)
         # stratification without demultiplexing is joined natively (read id ->
         # stratum inside the tokenizer)
         native_strata = bool(stratmap) and not demux
         # demultiplexing alone (no strata, no read maps) is done natively too
-        native_demux = bool(demux) and not stratmap and rank2dir is None
+        native_demux = bool(demux) and not stratmap and rank2dir is None \
+            and cover is None
         allow = set(samples) if (demux and samples) else None
         engine._exclude = exclude
         labels = None
@@ -247,7 +251,8 @@ def classify(mapper:  object,
                     chunks = engine.native_chunks(
                         stream, head, exclude, NATIVE_BLOCK, ordinal,
                         want_names, trimsub, want_groups=native_strata,
-                        want_strings=want_strings, want_samples=native_demux)
+                        want_strings=want_strings, want_samples=native_demux,
+                        cover=cover)
                 else:
                     text = io.TextIOWrapper(stream, encoding='utf-8')
                     fh = chain([head.decode()], text) if head else text
@@ -259,7 +264,8 @@ def classify(mapper:  object,
                 for chunk_ in chunks:
                     packed = strata_ids = names = sample_ids = None
                     if native:
-                        qryque, packed, strata_ids, names, sample_ids = chunk_
+                        qryque, packed, strata_ids, names, sample_ids, \
+                            ranges = chunk_
                         subque = None
                         engine._th = mapper.th if ordinal else None
                     elif ordinal:
@@ -275,6 +281,19 @@ def classify(mapper:  object,
                     else:
                         sample_of = files[fp] if files else None
                         reads = qryque
+                    # (optional) aligned ranges per (sample, subject)
+                    # (parse_ranges, workflow.py:312)
+                    if cover is not None and native:
+                        if demux:
+                            per_read = np.fromiter(
+                                (-1 if x is False else cover.sample(x)
+                                 for x in sample_of), np.int64, len(sample_of))
+                            who = np.repeat(per_read, np.diff(packed[-1]))
+                        else:
+                            who = cover.sample(sample_of)
+                        cover.add(who, *ranges)
+                    elif cover is not None:
+                        cover.add_queries(sample_of, subque)
                     # stratum of every read; the strata map of a sample is read
                     # when the sample first shows up (workflow.py:327-330)
                     strata_of = None
@@ -298,6 +317,10 @@ def classify(mapper:  object,
         engine.finish(data)
     finally:
         engine.close()
+    if cover is not None:
+        click.echo('Calculating per sample coverage...', nl=False)
+        write_coverage(cover.merged(), outcov_dir, outcov_fmt)
+        click.echo(' Done.')
     click.echo('Classification completed.')
     return data
 
@@ -449,11 +472,7 @@ def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
         click.echo(' Done.')
         click.echo(f'  Total number of host sequences: {len(table)}.')
         return OrdinalMapper(table, th=overlap and overlap / 100), chunk
-    if outcov_dir:
-        raise NotImplementedError(
-            'Subject coverage output (--outcov) is not available on the GPU '
-            'path yet.')
-    return plain_mapper, chunk
+    return (range_mapper if outcov_dir else plain_mapper), chunk
 
 
 def parse_sizes(sizes, mapper, zippers=None):
