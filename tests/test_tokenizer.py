@@ -273,3 +273,27 @@ def test_native_demux_matches_python():
             ids.extend(res['sample'].tolist())
         tok.close()
         assert [names[i] for i in ids] == exp
+
+
+def test_plain_flavour_hands_over_sets():
+    """Duplicate subjects of a read are dropped by the plain flavour (the
+    reference's plain parsers build sets) and kept by the "ex" flavour."""
+    rows = [('r1', 'G1'), ('r1', 'G2'), ('r1', 'G1'), ('r1', 'G1'),
+            ('r2', 'G3'), ('r3', 'G2'), ('r3', 'G2')]
+    # a read with more than 64 records exercises the sort-based branch
+    rows += [('r4', f'H{i % 70}') for i in range(200)]
+    text = ''.join(f'{q}\t0\t{s}\t{10 + i}\t255\t50M\t*\t0\t0\t*\t*\n'
+                   for i, (q, s) in enumerate(rows)).encode()
+    for threads in (1, 3):
+        tok = Tokenizer(threads)
+        res = tok.parse(text, first=True, final=True)
+        names = tok.new_subjects()
+        n = np.diff(res['off']).tolist()
+        assert n == [2, 1, 1, 70]
+        got = [sorted(names[s] for s in res['subj'][a:b])
+               for a, b in zip(res['off'][:-1], res['off'][1:])]
+        assert got[0] == ['G1', 'G2'] and got[2] == ['G2']
+        assert got[3] == sorted(f'H{i}' for i in range(70))
+        res = tok.parse(text, first=True, final=True, extra=True)
+        assert np.diff(res['off']).tolist() == [4, 1, 2, 200]
+        tok.close()

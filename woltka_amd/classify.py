@@ -381,7 +381,7 @@ class Engine:
     def run_chunk(self, data, reads, subque, sample_of, strata_of, trimsub,
                   rank2dir, outzip, namedic, ordinal, packed=None,
                   strata_ids=None, strata_labels=None, names=None,
-                  sample_ids=None, allow=None):
+                  sample_ids=None, allow=None, packed_is_set=False):
         """Classify one chunk at every rank; returns the number of queries the
         reference would report for it (workflow.py:305).  ``packed`` carries
         arrays produced by the native tokenizer instead of ``subque`` / staged
@@ -432,11 +432,12 @@ class Engine:
                 self.subj_feature.extend(
                     intern(x) for x in self.subjects.names[known:])
                 self.ctx.set_subjects(self.subj_feature)
-            # the Python parsers hand over sets; the native tokenizer keeps
-            # every record, and trimming can merge subjects
+            # the Python parsers and the native tokenizer hand over sets;
+            # trimming can merge subjects
             assign = self.ctx.classify_chunk(
                 self.jobs, subj, qoff, group=group,
-                subj_is_set=(packed is None and not trimsub),
+                subj_is_set=(packed_is_set if packed is not None
+                             else not trimsub),
                 want_assign=want, indexed=True)
             if want:    # read maps work on feature ids
                 subj = np.asarray(self.subj_feature, dtype=np.int32)[subj]

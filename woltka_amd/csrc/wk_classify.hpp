@@ -49,6 +49,7 @@ struct ClassifyArgs {
     uint32_t dense_bins;
     uint32_t dense_total;  // bins per slab row: n_jobs * dense_bins, or the subject count (count-first pass)
     uint32_t* dense_slab;  // [gridDim.x][dense_total]
+    int32_t slab16;        // slab rows hold 16-bit counts (a workgroup sees < 65536 reads): half the traffic
     // partitioned miss log (see LdsCache): [gridDim.x][kLogParts][plog_cap] keys
     // and [gridDim.x][kLogParts] stream lengths
     unsigned long long* plog;
@@ -69,6 +70,7 @@ struct ClassifyArgs {
     const uint32_t* first_slab;  // [first_rows][first_total] or null
     uint32_t first_rows, first_total;
     int32_t first_by_subject;  // slab columns are subject indices (else job * bins + feature)
+    int32_t first_slab16;
     int32_t resume;            // continue the first pass's miss-log streams
 };
 
@@ -581,8 +583,17 @@ __device__ __forceinline__ void cache_finish(const LdsCache& cache, const Classi
     }
     if (cache.dense) {
         const uint32_t nb = a.dense_total;
-        uint32_t* row = a.dense_slab + (size_t)blockIdx.x * nb;
-        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) row[i] = cache.dense[i];
+        if (a.slab16) {  // two bins per word; rows are padded to an even length
+            const uint32_t half = (nb + 1u) >> 1;
+            uint32_t* row = a.dense_slab + (size_t)blockIdx.x * half;
+            for (uint32_t i = threadIdx.x; i < half; i += blockDim.x) {
+                const uint32_t hi = 2u * i + 1u < nb ? cache.dense[2u * i + 1u] : 0u;
+                row[i] = cache.dense[2u * i] | (hi << 16);
+            }
+        } else {
+            uint32_t* row = a.dense_slab + (size_t)blockIdx.x * nb;
+            for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) row[i] = cache.dense[i];
+        }
     }
 }
 
@@ -600,8 +611,15 @@ __device__ __forceinline__ void merge_first_pass(const ClassifyArgs& a, uint32_t
         const uint32_t i = u * kWave + lane;
         uint32_t sum = 0;
         if (i < a.first_total) {
+            if (a.first_slab16) {
+                const uint16_t* slab = reinterpret_cast<const uint16_t*>(a.first_slab);
+                const size_t pitch = (size_t)((a.first_total + 1u) & ~1u);
 #pragma unroll 4
-            for (uint32_t row = wave; row < a.first_rows; row += n_waves) sum += a.first_slab[(size_t)row * a.first_total + i];
+                for (uint32_t row = wave; row < a.first_rows; row += n_waves) sum += slab[(size_t)row * pitch + i];
+            } else {
+#pragma unroll 4
+                for (uint32_t row = wave; row < a.first_rows; row += n_waves) sum += a.first_slab[(size_t)row * a.first_total + i];
+            }
         }
         part[wave][lane] = sum;
         __syncthreads();
@@ -734,28 +752,33 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         };
         // with a read list (second pass of the two-class split) one more
         // stage in front: list entry (i+4) -> offsets (i+3) -> ...
-        auto item = [&](int64_t i) -> int64_t {
-            if constexpr (!listed) return i;
-            else return (int64_t)my_list[i < n_items ? i : n_items - 1];
+        // (list entries are 32-bit and live in registers only in the listed
+        // variant; the direct variant derives the read index from i)
+        auto entry = [&](int64_t i) -> uint32_t {
+            if constexpr (listed) return my_list[i < n_items ? i : n_items - 1];
+            else return 0u;
         };
         int64_t i = r;
-        int64_t r0 = item(i), r1 = item(i + stride), r2 = item(i + 2 * stride), r3 = item(i + 3 * stride);
+        [[maybe_unused]] uint32_t q0 = entry(i), q1 = entry(i + stride), q2 = entry(i + 2 * stride),
+                                  q3 = entry(i + 3 * stride);
+#define WK_RID(k, q) (listed ? (int64_t)(q) : i + (k) * stride)
         int32_t s0, e0, s1, e1, s2, e2;
-        load_offsets(r0, s0, e0);
-        load_offsets(r1, s1, e1);
-        load_offsets(r2, s2, e2);
+        load_offsets(WK_RID(0, q0), s0, e0);
+        load_offsets(WK_RID(1, q1), s1, e1);
+        load_offsets(WK_RID(2, q2), s2, e2);
         int32_t c0 = load_first(s0, e0), c1 = load_first(s1, e1);
         int4 row0 = load_row(c0);
-        int32_t g0 = load_group(r0);
+        int32_t g0 = load_group(WK_RID(0, q0));
         const bool one_job = a.n_jobs == 1;
         const JobDev job0 = a.jobs[0];  // kept in registers for the common single-rank run
         for (; i < n_items; i += stride) {
-            const int64_t r4 = item(i + 4 * stride);
+            [[maybe_unused]] const uint32_t q4 = entry(i + 4 * stride);
+            const int64_t r0 = WK_RID(0, q0);
             int32_t s3, e3;
-            load_offsets(r3, s3, e3);
+            load_offsets(WK_RID(3, q3), s3, e3);
             const int32_t c2 = load_first(s2, e2);
             const int4 row1 = load_row(c1);
-            const int32_t g1 = load_group(r1);
+            const int32_t g1 = load_group(WK_RID(1, q1));
             const int32_t n = e0 - s0;
             if (n <= 0) {
                 mark_empty(a, r0);
@@ -785,8 +808,9 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
             }
             s0 = s1; e0 = e1; s1 = s2; e1 = e2; s2 = s3; e2 = e3;
             c0 = c1; c1 = c2; row0 = row1; g0 = g1;
-            r0 = r1; r1 = r2; r2 = r3; r3 = r4;
+            if constexpr (listed) { q0 = q1; q1 = q2; q2 = q3; q3 = q4; }
         }
+#undef WK_RID
     } else {
         const bool use_rows = a.rows != nullptr;
         // first candidate of a read -> its feature id (subject rows: one more gather)

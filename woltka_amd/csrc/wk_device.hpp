@@ -136,6 +136,8 @@ __device__ __forceinline__ void cached_add(const LdsCache& c, const CountTable& 
     const uint32_t b = hash_key(key) & c.bmask;
     if (bucket_add(c.base + (size_t)b * 8, key, w)) return;
     // with a miss log behind the cache a second probe costs more than a miss
+    // (sending list results straight to the log was tried: the extra live
+    // value spills registers in the evaluator and costs more than it saves)
     if (!c.plog_cur && bucket_add(c.base + (size_t)((b + 1) & c.bmask) * 8, key, w)) return;
 #ifdef WK_ABLATE
     if (c.ablate & 16) return;  // measurement only: drop cache misses

@@ -221,6 +221,23 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
         }
         for (int m = 0; m < 3; ++m) {
             if (pool[m].empty()) continue;
+            if (!extra && pool[m].size() > 1) {
+                // the plain parsers collect subject *sets* (align.py:258-330):
+                // duplicates go here, so the device never has to look for them
+                auto& v = pool[m];
+                if (v.size() <= 64) {
+                    size_t w = 1;
+                    for (size_t i = 1; i < v.size(); ++i) {
+                        bool dup = false;
+                        for (size_t j = 0; j < w && !dup; ++j) dup = v[j].subj == v[i].subj;
+                        if (!dup) v[w++] = v[i];
+                    }
+                    v.resize(w);
+                } else {
+                    std::sort(v.begin(), v.end(), [](const Record& x, const Record& y) { return x.subj < y.subj; });
+                    v.erase(std::unique(v.begin(), v.end(), [](const Record& x, const Record& y) { return x.subj == y.subj; }), v.end());
+                }
+            }
             out.rec.insert(out.rec.end(), pool[m].begin(), pool[m].end());
             out.rend.push_back((int32_t)out.rec.size());
             if (want_names) out.qname.push_back(((uint64_t)(cur - base) << 24) | ((uint64_t)cur_n << 2) | (uint64_t)m);

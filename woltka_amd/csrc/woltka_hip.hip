@@ -810,6 +810,9 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     first.dense_bins = (uint32_t)c->n_subjects;
                     first.dense_total = (uint32_t)c->n_subjects;
                     first.dense_slab = c->first_slab.as<uint32_t>();
+                    // reads per workgroup: its rounds x 4096
+                    const int64_t rounds = ((c->n_reads + 4095) / 4096 + blocks1 - 1) / blocks1;
+                    first.slab16 = rounds * 4096 <= 65535 ? 1 : 0;
                     hipLaunchKernelGGL((classify_single_kernel<true, true, 4>), dim3(blocks1), dim3(1024),
                                        64 * 16 + (size_t)c->n_subjects * 4, c->stream, first, 64u, mask);
                 } else {
@@ -819,6 +822,8 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     if (bins) {
                         HIP_TRY(c, c->first_slab.reserve((size_t)blocks * bins * n_jobs * 4));
                         first.dense_slab = c->first_slab.as<uint32_t>();
+                        const int64_t per_wg = ((c->n_reads + (int64_t)blocks * c->threads - 1) / ((int64_t)blocks * c->threads)) * c->threads;
+                        first.slab16 = per_wg <= 65535 ? 1 : 0;
                     } else {
                         first.plog = a.plog;
                         first.plog_cnt = a.plog_cnt;
@@ -843,8 +848,10 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     a.first_rows = (uint32_t)blocks1;
                     a.first_total = first.dense_total;
                     a.first_by_subject = by_subject ? 1 : 0;
+                    a.first_slab16 = first.slab16;
                 }
                 a.resume = (!by_subject && !bins && plog_cap) ? 1 : 0;
+                a.slab16 = 0;
                 if (bins) {  // the second pass counts in the hash cache only
                     a.dense_bins = 0;
                     a.dense_total = 0;

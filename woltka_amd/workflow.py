@@ -306,7 +306,8 @@ def classify(mapper:  object,
                         None if native else trimsub,
                         rank2dir, outzip, namedic, ordinal, packed=packed,
                         strata_ids=strata_ids, strata_labels=labels,
-                        names=names, sample_ids=sample_ids, allow=allow)
+                        names=names, sample_ids=sample_ids, allow=allow,
+                        packed_is_set=not trimsub and cover is None)
                     nqry += nq
                     istep = nqry // 1000000 - nstep
                     if istep:
