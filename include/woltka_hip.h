@@ -58,6 +58,13 @@ extern "C" {
 #define WK_KEY_JOB_BITS 3
 #define WK_MAX_JOBS 8
 #define WK_MAX_K 4095
+/* Contributions 1/k with k <= WK_WEIGHT_MAX_K are accumulated under k = 0 as
+ * multiples of 1 / WK_WEIGHT_L (L = lcm(1..16), exact in 64 bits for > 2^43
+ * reads): one key per (job, group, feature) instead of one per k, so the
+ * on-chip caches aggregate far more.  Keys with k >= 1 hold plain counts of
+ * 1/k contributions (k = 1 from the dense / per-subject paths, k > 16 always). */
+#define WK_WEIGHT_L 720720
+#define WK_WEIGHT_MAX_K 16
 #define WK_FEATURE_UNASSIGNED 0x0FFFFFFF /* 'Unassigned', workflow.py:1038-1039 */
 #define WK_MAX_FEATURE 0x0FFFFFFE
 

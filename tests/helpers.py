@@ -86,8 +86,17 @@ def fold_counts(keys, vals, index, job=0, groups=None):
         name = 'Unassigned' if ff == nat.FEATURE_UNASSIGNED \
             else index.names[ff]
         key = name if groups is None else (groups[gg], name)
-        res[key] = res.get(key, 0) + Fraction(n, kk)
+        res[key] = res.get(key, 0) + Fraction(n, kk or nat.WEIGHT_L)
     return res
+
+
+def assert_same_counts(keys, vals, okeys, ocnt, msg=None):
+    """Bit-exact equality of two count tables in canonical form (1/k
+    contributions with k <= 16 as multiples of 1/L under k = 0)."""
+    k1, v1 = nat.canonical_counts(keys, vals)
+    k2, v2 = nat.canonical_counts(okeys, ocnt)
+    assert np.array_equal(k1, k2), msg
+    assert np.array_equal(v1, v2), msg
 
 
 def fold_contrib(contrib, index, job=0, groups=None):

@@ -1,11 +1,14 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors of the
 real reference and against the CPU oracle.  Integer / index work: bit-exact."""
+from fractions import Fraction
+
 import numpy as np
 import pytest
 
 import c_oracle
 import woltka_oracle as orc
-from helpers import (PackedCase, assert_counts_match, decode_assign,
+from helpers import (PackedCase, assert_counts_match, assert_same_counts,
+                     decode_assign,
                      expected_assign, fold_contrib, fold_counts, golden_counts,
                      job_spec, load_vectors)
 from test_oracle_golden import pack_ordinal_case
@@ -177,9 +180,7 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
                                          parent, rcode, 0, prob.get('group'))
     assert np.array_equal(assign, oassign)
     okeys, ocnt = np.unique(contrib, return_counts=True)
-    order = np.argsort(keys)
-    assert np.array_equal(keys[order], okeys)
-    assert np.array_equal(vals[order], ocnt.astype(np.int64))
+    assert_same_counts(keys, vals, okeys, ocnt)
     st = ctx.stats()
     assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
     assert st['n_records'] == prob['subj'].size
@@ -196,9 +197,7 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
                                  indexed=True)
     keys2, vals2 = ctx.counts_fetch()
     assert np.array_equal(assign2, oassign)
-    order = np.argsort(keys2)
-    assert np.array_equal(keys2[order], okeys)
-    assert np.array_equal(vals2[order], ocnt.astype(np.int64))
+    assert_same_counts(keys2, vals2, okeys, ocnt)
     # ... with the dense-bin path switched off, and with the partitioned miss
     # log forced on (tiny streams -> also exercises the overflow fallback)
     # ... and with the two-class split (single-candidate pass + compacted
@@ -217,9 +216,7 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
         ctx.counts_clear()
         ctx.classify_staged(jobs)
         keys3, vals3 = ctx.counts_fetch()
-        order = np.argsort(keys3)
-        assert np.array_equal(keys3[order], okeys), opts
-        assert np.array_equal(vals3[order], ocnt.astype(np.int64)), opts
+        assert_same_counts(keys3, vals3, okeys, ocnt, opts)
     ctx.set_option('dense', 1)
     ctx.set_option('plog', 1)
     ctx.set_option('plog_max_bytes', 4 << 30)
@@ -230,9 +227,7 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     assign4 = ctx.classify_staged(jobs, want_assign=True)
     keys4, vals4 = ctx.counts_fetch()
     assert np.array_equal(assign4, oassign)
-    order = np.argsort(keys4)
-    assert np.array_equal(keys4[order], okeys)
-    assert np.array_equal(vals4[order], ocnt.astype(np.int64))
+    assert_same_counts(keys4, vals4, okeys, ocnt)
     st = ctx.stats()
     assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
     assert st['n_records'] == prob['subj'].size
@@ -337,9 +332,7 @@ def test_ordinal_random_vs_oracle(ctx):
         _, contrib = c_oracle.classify(subj, qoff,
                                        [dict(mode=nat.MODE_NONE)])
         okeys, ocnt = np.unique(contrib, return_counts=True)
-        order = np.argsort(keys)
-        assert np.array_equal(keys[order], okeys)
-        assert np.array_equal(vals[order], ocnt)
+        assert_same_counts(keys, vals, okeys, ocnt)
 
 
 def test_edge_cases(ctx):
@@ -356,9 +349,8 @@ def test_edge_cases(ctx):
     assert a[0].tolist() == [nat.ASSIGN_EMPTY, 3, nat.ASSIGN_EMPTY,
                              nat.ASSIGN_MULTI, nat.ASSIGN_EMPTY]
     keys, vals = ctx.counts_fetch()
-    j, k, g, f = nat.decode_keys(keys)
-    assert sorted(zip(k.tolist(), f.tolist(), vals.tolist())) == \
-        [(1, 3, 1), (2, 5, 1), (2, 9, 1)]
+    assert nat.counts_to_fractions(keys, vals) == {
+        (0, 0, 3): 1, (0, 0, 5): Fraction(1, 2), (0, 0, 9): Fraction(1, 2)}
     # one read with the maximum number of distinct candidates
     ctx.counts_clear()
     big = np.arange(nat.MAX_K, dtype=np.int32)
@@ -401,9 +393,11 @@ def test_full_size_config2_properties(ctx):
     ctx.counts_reserve(1 << 16)
     ctx.chunk_stage(prob['subj'], prob['qoff'], subj_is_set=True)
     ctx.classify_staged(jobs)
-    keys, vals = ctx.counts_fetch()
+    keys, vals = nat.canonical_counts(*ctx.counts_fetch())
     j, k, g, f = nat.decode_keys(keys)
-    assert (k == 1).all() and (g == 0).all()
+    assert (k == 0).all() and (g == 0).all()
+    assert (vals % nat.WEIGHT_L == 0).all()
+    vals = (vals // nat.WEIGHT_L).astype(np.int64)
     for job in (0, 1):
         assert vals[j == job].sum() == 10_000_000
     exp = np.bincount(prob['subj'], minlength=len(h.index))
@@ -415,7 +409,6 @@ def test_full_size_config2_properties(ctx):
     got[f[j == 1]] = vals[j == 1]
     assert np.array_equal(got, exp_genus)
     ctx.classify_staged(jobs)
-    keys2, vals2 = ctx.counts_fetch()
-    o1, o2 = np.argsort(keys), np.argsort(keys2)
-    assert np.array_equal(keys[o1], keys2[o2])
-    assert np.array_equal(2 * vals[o1], vals2[o2])
+    keys2, vals2 = nat.canonical_counts(*ctx.counts_fetch())
+    assert np.array_equal(keys, keys2)
+    assert np.array_equal(2 * vals * nat.WEIGHT_L, vals2.astype(np.int64))

@@ -392,15 +392,38 @@ class Context:
         return ms.value
 
 
+WEIGHT_L = 720720       # WK_WEIGHT_L: k = 0 keys hold multiples of 1 / L
+WEIGHT_MAX_K = 16
+
+
+def canonical_counts(keys, vals):
+    """One canonical form of a count table: every 1/k contribution with
+    k <= WEIGHT_MAX_K moved under k = 0 in units of 1 / WEIGHT_L (what the
+    hash-cache paths of the device produce directly), equal keys merged.
+    Returns (sorted keys, values) as uint64 arrays."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    vals = np.asarray(vals).astype(np.uint64)
+    k = (keys >> np.uint64(49)) & np.uint64(MAX_K)
+    small = (k >= 1) & (k <= WEIGHT_MAX_K)
+    factor = np.where(small, np.uint64(WEIGHT_L) // np.maximum(k, np.uint64(1)),
+                      np.uint64(1))
+    merged = np.where(small, keys & ~(np.uint64(MAX_K) << np.uint64(49)), keys)
+    uniq, inv = np.unique(merged, return_inverse=True)
+    out = np.zeros(uniq.size, dtype=np.uint64)
+    np.add.at(out, inv, vals * factor)
+    return uniq, out
+
+
 def counts_to_fractions(keys, vals):
     """Fold (job, k, group, feature) -> n into {(job, group, feature):
-    Fraction} = sum_k n_k / k  (exact; woltka/classify.py:167-170)."""
+    Fraction} = sum_k n_k / k  (exact; woltka/classify.py:167-170); k = 0
+    marks values in units of 1 / WEIGHT_L."""
     job, k, grp, feat = decode_keys(keys)
     res = {}
     for j, kk, g, f, n in zip(job.tolist(), k.tolist(), grp.tolist(),
                               feat.tolist(), np.asarray(vals).tolist()):
         key = (j, g, f)
-        res[key] = res.get(key, 0) + Fraction(n, kk)
+        res[key] = res.get(key, 0) + Fraction(n, kk or WEIGHT_L)
     return res
 
 

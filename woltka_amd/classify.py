@@ -628,7 +628,7 @@ class Engine:
                     else names[f]
                 key = name if stratum is None else (stratum, name)
                 cell = data[self.ranks[j]].setdefault(sample, {})
-                cell[key] = cell.get(key, 0) + Fraction(nn, kk)
+                cell[key] = cell.get(key, 0) + Fraction(nn, kk or nat.WEIGHT_L)
         self.ctx.counts_clear()
         self.groups = []
         self.group_ids = {}

@@ -281,7 +281,10 @@ __device__ __forceinline__ bool first_occurrence(const C& cand, int32_t j) {
 template <bool kUseLds>
 __device__ __forceinline__ void count_add(const LdsCache& cache, const CountTable& table, int jb, uint32_t k,
                                           int32_t g, uint32_t feature) {
-    const uint64_t key = make_key(jb, k, g, feature);
+    // 1/k with k <= 16 is counted as L/k under k = 0 (see WK_WEIGHT_L)
+    const bool weighted = k <= (uint32_t)WK_WEIGHT_MAX_K;
+    const uint64_t key = make_key(jb, weighted ? 0u : k, g, feature);
+    const unsigned long long w = weighted ? (unsigned long long)weight_of(k) : 1ull;
 #ifdef WK_ABLATE
     if (cache.ablate & 1) {  // measurement only: drop the count, keep the key live
         asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)));
@@ -293,9 +296,9 @@ __device__ __forceinline__ void count_add(const LdsCache& cache, const CountTabl
             atomicAdd(&cache.dense[(uint32_t)jb * cache.dense_bins + feature], 1u);
             return;
         }
-        cached_add(cache, table, key, 1ull);
+        cached_add(cache, table, key, w);
     } else {
-        table_add(table, key, 1ull);
+        table_add(table, key, w);
     }
 }
 
@@ -1050,7 +1053,14 @@ __global__ void __launch_bounds__(1024) partition_merge_kernel(const unsigned lo
     for (uint32_t row = wave; row < n_rows; row += n_waves) {  // one stream per wave at a time
         const uint32_t n = plog_cnt[(size_t)row * kLogParts + part];
         const unsigned long long* src = plog + ((size_t)row * kLogParts + part) * plog_cap;
-        for (uint32_t i = lane; i < n; i += 64) cached_add(cache, table, src[i], 1ull);
+        for (uint32_t i = lane; i < n; i += 64) {
+            // an entry with k in [1, 16] is one contribution to the weighted key
+            const unsigned long long e = src[i];
+            const uint32_t k = (uint32_t)(e >> 49) & (uint32_t)WK_MAX_K;
+            const bool weighted = k >= 1u && k <= (uint32_t)WK_WEIGHT_MAX_K;
+            cached_add(cache, table, weighted ? (e & ~kKeyKMask) : e,
+                       weighted ? (unsigned long long)weight_of(k) : 1ull);
+        }
     }
     lds_cache_flush(cache, table);
 }

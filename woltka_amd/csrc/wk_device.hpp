@@ -25,6 +25,14 @@ __host__ __device__ __forceinline__ uint64_t make_key(uint32_t job, uint32_t k, 
     return ((uint64_t)job << 61) | ((uint64_t)k << 49) | ((uint64_t)group << 28) | (uint64_t)feature;
 }
 
+// WK_WEIGHT_L / k for k in [1, 16] (exact: the quotient is an integer below
+// 2^20, the reciprocal's error stays far below the 0.5 rounding margin), and
+// the inverse.
+__device__ __forceinline__ uint32_t weight_of(uint32_t k) {
+    return (uint32_t)((float)WK_WEIGHT_L * __builtin_amdgcn_rcpf((float)k) + 0.5f);
+}
+constexpr uint64_t kKeyKMask = (uint64_t)WK_MAX_K << 49;
+
 // 64-bit finaliser (splitmix64) — spreads the low feature bits over the table.
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 30;
@@ -142,12 +150,15 @@ __device__ __forceinline__ void cached_add(const LdsCache& c, const CountTable& 
 #ifdef WK_ABLATE
     if (c.ablate & 16) return;  // measurement only: drop cache misses
 #endif
-    if (c.plog_cur && w == 1ull) {
+    if (c.plog_cur) {
         // partition by the high hash bits (the low bits pick the LDS bucket)
         const uint32_t part = (hash_key(key) * 0x9E3779B1u) >> 22;  // kLogParts = 2^10
         const uint32_t pos = atomicAdd(&c.plog_cur[part], 1u);
         if (pos < c.plog_cap) {
-            c.plog[(size_t)part * c.plog_cap + pos] = key;
+            // a log entry is one contribution: a weighted key (k field 0)
+            // travels with its k = L / w in the k field
+            const uint64_t entry = (key & kKeyKMask) ? key : key | ((uint64_t)weight_of((uint32_t)w) << 49);
+            c.plog[(size_t)part * c.plog_cap + pos] = entry;
             return;
         }
     }
