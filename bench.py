@@ -315,8 +315,11 @@ def main():
         wl.step()
     ctx.timer_end()
     ctx.sync()
-    barrier()
+    # this rank's K steps, device work drained; the closing barrier follows and
+    # the slowest rank's time is what counts (MAX below) — the barrier's own
+    # latency (gloo, host side) is not part of anybody's steps
     elapsed = time.perf_counter() - t0
+    barrier()
     gpu_ms = ctx.timer_ms()
     if dist is not None:
         import torch
