@@ -277,6 +277,18 @@ int wk_tok_set_exclude(wk_tok* tok, const char* blob, const int32_t* off,
 int wk_tok_sam(wk_tok* tok, const char* buf, int64_t len, int first_block,
                int final_block, int extra, int want_names, int64_t* consumed,
                int64_t* n_reads, int64_t* n_records);
+/* The same for any of the reference's alignment formats (align.py:153-223):
+ * simple maps (parse_map_file, align.py:621), BLAST tabular (parse_b6o_file
+ * :753 / _ex :807) and PAF (parse_paf_file :984 / _ex :1046) group runs of
+ * equal first columns; lines that are not rows of the format are skipped like
+ * the reference's `except IndexError: continue`. */
+#define WK_FMT_SAM 0
+#define WK_FMT_MAP 1
+#define WK_FMT_B6O 2
+#define WK_FMT_PAF 3
+int wk_tok_text(wk_tok* tok, int fmt, const char* buf, int64_t len,
+                int first_block, int final_block, int extra, int want_names,
+                int64_t* consumed, int64_t* n_reads, int64_t* n_records);
 /* Copy the results out: subj[n_records] (subject indices), off[n_reads + 1]
  * (CSR), beg/end/len[n_records] (extra only), qname[n_reads] =
  * (byte offset in buf << 24) | (length << 2) | mate.  NULL skips an array. */

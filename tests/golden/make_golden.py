@@ -315,6 +315,66 @@ def gen_parsers(seed=5):
     dump('parsers.json', out)
 
 
+def gen_simple_parsers(seed=31):
+    """map / b6o / paf: the reference's four parser flavours on lines of its
+    own test data plus synthetic edge cases (short lines, comment lines,
+    reversed coordinates, interleaved runs, CRLF, empty fields)."""
+    import bz2
+    from woltka.align import iter_align
+    rng = random.Random(seed)
+    ref = os.path.join(_refshim.REFERENCE_ROOT, 'woltka', 'tests', 'data',
+                       'align')
+    with bz2.open(os.path.join(ref, 'burst', 'S01.b6.bz2'), 'rt') as f:
+        b6o_real = f.readlines()[:250]
+    with open(os.path.join(ref, 'centrifuge', 'S01.map')) as f:
+        map_real = f.readlines()[:250]
+    subj = [f'G{i}' for i in range(7)]
+    b6o, paf, mapl = [], [], []
+    for qi in range(70):
+        q = f'q{qi // 2 if qi % 7 == 0 else qi}'      # some adjacent repeats
+        for _ in range(rng.choice([1, 1, 2, 3, 5])):
+            s = rng.choice(subj)
+            a, b = rng.randrange(1, 5000), rng.randrange(1, 5000)
+            ln = rng.choice([0, 50, 100, 150])
+            b6o.append(f'{q}\t{s}\t{rng.random() * 100:.2f}\t{ln}\t1\t0\t1\t'
+                       f'{ln}\t{a}\t{b}\t1e-{rng.randrange(3, 50)}\t'
+                       f'{rng.random() * 300:.1f}\n')
+            lo = min(a, b)
+            paf.append(f'{q}\t150\t0\t{ln}\t{rng.choice("+-")}\t{s}\t9000\t'
+                       f'{lo}\t{lo + ln}\t{ln}\t{ln}\t{rng.randrange(61)}\t'
+                       f'tp:A:P\n')
+            mapl.append(f'{q}\t{s}\n')
+        r = rng.random()
+        if r < 0.1:
+            b6o.append('# a comment line\n')
+            paf.append('short\tline\n')
+            mapl.append('no tab here\n')
+        elif r < 0.2:
+            b6o.append(f'{q}\tG0\tonly three columns\n')
+            paf.append(f'{q}\t150\t0\t10\t+\tG1\t9000\tx\t20\t10\t10\t60\n')
+            mapl.append(f'{q}\tG3 \textra\tcolumns\n')
+        elif r < 0.25:
+            b6o.append('\n')
+            paf.append('\n')
+            mapl.append('\tG2\n')
+    b6o.append('last\tG6\t99\t150\t1\t0\t1\t150\t300\t151\t0.0\t200\r\n')
+    paf.append('last\t150\t0\t150\t+\tG6\t9000\t5\t155\t150\t150\t60\r\n')
+    mapl.append('last\tG6\r\n')
+    excl = {'G1', 'G4', 'G000006745'}
+    out = {}
+    for name, fmt, lines in (('b6o_real', 'b6o', b6o_real),
+                             ('map_real', 'map', map_real),
+                             ('b6o', 'b6o', b6o), ('paf', 'paf', paf),
+                             ('map', 'map', mapl)):
+        out[name] = dict(
+            fmt=fmt, lines=lines, excl=sorted(excl),
+            plain=list(iter_align(iter(lines), fmt)),
+            ex=list(iter_align(iter(lines), fmt, None, True)),
+            plain_ft=list(iter_align(iter(lines), fmt, excl)),
+            ex_ft=list(iter_align(iter(lines), fmt, excl, True)))
+    dump('simple_parsers.json', out)
+
+
 def gen_glue(seed=11):
     from woltka.workflow import demultiplex, strip_suffix
     from woltka.util import round_dict
@@ -509,6 +569,7 @@ def main():
     gen_tree_walks()
     gen_ordinal()
     gen_parsers()
+    gen_simple_parsers()
     gen_glue()
     gen_readers()
     gen_host()

@@ -35,6 +35,25 @@ def test_sam_parsers_match_reference():
         assert list(align.cigar_to_lens(cigar)) == exp
 
 
+def test_simple_format_parsers_match_reference():
+    """map / b6o / paf: all four flavours of the reference (plain, ex, and
+    both with exclusion) on its own test data and on edge-case lines."""
+    for name, d in load_vectors('simple_parsers.json').items():
+        lines, fmt, excl = d['lines'], d['fmt'], set(d['excl'])
+        plain = fmt == 'map'
+
+        def norm(pairs, ex):
+            if ex and not plain:
+                return [[q, [list(r) for r in s]] for q, s in pairs]
+            return [[q, sorted(s)] for q, s in pairs]
+        for key, ex, ft in (('plain', False, None), ('ex', True, None),
+                            ('plain_ft', False, excl), ('ex_ft', True, excl)):
+            got = norm(align.parse_align(lines, fmt, ft, ex), ex)
+            want = d[key] if ex and not plain else \
+                [[q, sorted(s)] for q, s in d[key]]
+            assert got == want, (name, key)
+
+
 def test_mate_flag_with_both_bits_is_an_error():
     with pytest.raises(IndexError):
         list(align.parse_align(['q\t192\tG1\t1\t0\t5M\t*\n'], 'sam'))

@@ -10,12 +10,13 @@ from woltka_amd import align
 from woltka_amd._native import Tokenizer
 
 
-def run_native(text, threads, block, excl=None, extra=False):
+def run_native(text, threads, block, excl=None, extra=False, fmt='sam'):
     tok = Tokenizer(threads, exclude=excl)
     names = []
     reads = []
     for buf, res in align.native_sam_blocks(io.BytesIO(text), tok, block,
-                                            extra=extra, want_names=True):
+                                            extra=extra, want_names=True,
+                                            fmt=fmt):
         names.extend(tok.new_subjects())
         q = Tokenizer.query_names(buf, res['qname'])
         off = res['off'].tolist()
@@ -297,3 +298,30 @@ def test_plain_flavour_hands_over_sets():
         res = tok.parse(text, first=True, final=True, extra=True)
         assert np.diff(res['off']).tolist() == [4, 1, 2, 200]
         tok.close()
+
+
+@pytest.mark.parametrize('threads,block', [(1, 1 << 20), (2, 4096), (5, 300),
+                                           (3, 97)])
+def test_simple_formats_match_reference(threads, block):
+    """map / b6o / paf through the native tokenizer == the reference's
+    parsers (vectors made by make_golden.gen_simple_parsers), every flavour;
+    the "ex" records carry (subject, length, start, end) — the score column is
+    not kept by the device path."""
+    for name, d in load_vectors('simple_parsers.json').items():
+        fmt, excl = d['fmt'], set(d['excl'])
+        text = ''.join(d['lines']).encode()
+        for key, ex, ft in (('plain', False, None), ('plain_ft', False, excl),
+                            ('ex', True, None), ('ex_ft', True, excl)):
+            if ex and fmt == 'map':
+                continue
+            got, _ = run_native(text, threads, block, excl=ft, extra=ex,
+                                fmt=fmt)
+            if ex:
+                want = [(q, [(r[0], None, r[2], r[3], r[4]) for r in s
+                             if r[2]])           # zero-length hits are dropped
+                        for q, s in d[key]]
+                want = [(q, s) for q, s in want if s]
+                got = [(q, s) for q, s in got if s]
+            else:
+                want = [(q, set(s)) for q, s in d[key]]
+            assert got == want, (name, key, threads, block)

@@ -41,7 +41,8 @@ SYMBOLS = (
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
     'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
-    'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_fetch', 'wk_tok_subjects',
+    'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_text', 'wk_tok_fetch',
+    'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
     'wk_tok_fetch_samples', 'wk_tok_new_samples')
@@ -121,6 +122,9 @@ def load_library():
         'wk_tok_set_exclude': (C.c_int, [p, C.c_char_p, i32p, C.c_int32]),
         'wk_tok_sam': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.c_int, C.c_int, i64p, i64p, i64p]),
+        'wk_tok_text': (C.c_int, [p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, i64p, i64p,
+                                  i64p]),
         'wk_tok_fetch': (C.c_int, [p, i32p, i32p, i32p, i32p, u32p, u64p]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
@@ -513,9 +517,13 @@ class Tokenizer:
         raw, o = blob.raw, off.tolist()
         return [raw[o[i]:o[i + 1]].decode() for i in range(n.value)]
 
+    FORMATS = {'sam': 0, 'map': 1, 'b6o': 2, 'paf': 3}
+
     def parse(self, buf, first=False, final=False, extra=False,
-              want_names=False, want_groups=False, want_samples=False):
-        """Tokenize ``buf`` (bytes-like).  Returns a dict with ``consumed``,
+              want_names=False, want_groups=False, want_samples=False,
+              fmt='sam'):
+        """Tokenize ``buf`` (bytes-like) of alignment format ``fmt``
+        (sam / map / b6o / paf).  Returns a dict with ``consumed``,
         ``subj``, ``off`` (+ ``beg``/``end``/``len`` with ``extra``,
         ``qname`` descriptors with ``want_names``, ``group`` = stratum ids with
         ``want_groups``)."""
@@ -526,8 +534,11 @@ class Tokenizer:
         if n == 0:
             addr = C.cast(C.c_char_p(b''), C.c_void_p)
         consumed, nrd, nrec = C.c_int64(), C.c_int64(), C.c_int64()
-        self._check(self._lib.wk_tok_sam(
-            self._h, addr, n, int(first), int(final), int(extra),
+        if fmt == 'map':
+            extra = False           # no "ex" flavour (align.py:236)
+        self._check(self._lib.wk_tok_text(
+            self._h, self.FORMATS[fmt], addr, n, int(first), int(final),
+            int(extra),
             int(bool(want_names)) | (2 if want_groups else 0) |
             (4 if want_samples else 0),
             C.byref(consumed), C.byref(nrd), C.byref(nrec)))

@@ -273,11 +273,15 @@ def pack_queries(subque, index, trim=None):
 # native tokenizer driver (SAM): binary stream -> packed blocks
 # --------------------------------------------------------------------------
 
+NATIVE_FORMATS = ('sam', 'map', 'b6o', 'paf')
+
+
 def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
                       want_names=False, head=b'', want_groups=False,
-                      want_samples=False):
-    """Feed a binary SAM stream through the native tokenizer
-    (``_native.Tokenizer``) block by block.
+                      want_samples=False, fmt='sam'):
+    """Feed a binary alignment stream (SAM by default; map / b6o / paf via
+    ``fmt``) through the native tokenizer (``_native.Tokenizer``) block by
+    block.
 
     The tokenizer stops before the last QNAME run of a block (it may continue
     in the next one); the unconsumed tail is carried over.  ``head`` is text
@@ -291,7 +295,7 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
     mm = _try_mmap(stream)
     if mm is not None:
         yield from _blocks_mmap(mm, len(head), tok, block_bytes, extra,
-                                want_names, want_groups, want_samples)
+                                want_names, want_groups, want_samples, fmt)
         return
     buf = bytearray(block_bytes + (1 << 16))
     fill = len(head)
@@ -314,7 +318,7 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
             return
         res = tok.parse(view[:fill], first=first, final=final, extra=extra,
                         want_names=want_names, want_groups=want_groups,
-                        want_samples=want_samples)
+                        want_samples=want_samples, fmt=fmt)
         used = res['consumed']
         if used == 0 and not final and res['off'].size == 1:
             if fill == len(buf):
@@ -353,7 +357,7 @@ def _try_mmap(stream):
 
 
 def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
-                 want_groups=False, want_samples=False):
+                 want_groups=False, want_samples=False, fmt='sam'):
     """Tokenise a memory-mapped file in place.  ``start`` bytes were already
     read from the stream for format sniffing; the map covers the whole file,
     so they are simply parsed again from offset 0."""
@@ -369,7 +373,7 @@ def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
             res = tok.parse(view[pos:end], first=first, final=final,
                             extra=extra, want_names=want_names,
                             want_groups=want_groups,
-                            want_samples=want_samples)
+                            want_samples=want_samples, fmt=fmt)
             used = res['consumed']
             if used == 0 and not final and res['off'].size == 1:
                 span *= 2

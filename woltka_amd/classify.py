@@ -196,7 +196,8 @@ class Engine:
 
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,
-                      want_strings=True, want_samples=False, cover=None):
+                      want_strings=True, want_samples=False, cover=None,
+                      fmt='sam'):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed, strata ids, name descriptors, sample ids,
         ranges) where packed = (subj, qoff) of subject indices, or for
@@ -216,7 +217,8 @@ class Engine:
                                               want_names=want_names,
                                               head=head,
                                               want_groups=want_groups,
-                                              want_samples=want_samples):
+                                              want_samples=want_samples,
+                                              fmt=fmt):
                 # the dictionary growth belongs to this block: fetch it before
                 # the tokenizer moves on
                 yield buf, res, tok.new_subjects(), \

@@ -113,6 +113,10 @@ struct Line {
     const char* cigar;
     size_t cn;
     bool ok;
+    // map / b6o / paf rows of the "ex" flavour carry their numbers directly
+    int32_t beg, end;
+    uint32_t len;
+    bool bad_number;  // a field Python's int() would refuse (the reference raises)
 };
 
 // split the first 3 (or 6) tab-separated fields of [p, e)
@@ -150,6 +154,98 @@ inline Line parse_line(const char* p, const char* e, bool extra) {
 }
 
 inline bool is_unmapped(const Line& L) { return L.rn == 1 && L.r[0] == '*'; }
+
+// decimal integer like Python's int() on a clean field: optional sign, digits
+inline bool parse_int(const char* p, const char* e, long& v) {
+    auto blank = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
+    while (p < e && blank(*p)) ++p;  // int() ignores surrounding whitespace
+    while (e > p && blank(e[-1])) --e;
+    bool neg = false;
+    if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
+    if (p >= e) return false;
+    long x = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        x = x * 10 + (*p - '0');
+    }
+    v = neg ? -x : x;
+    return true;
+}
+
+// Row extractors of the simple formats (align.py: parse_map_file :621,
+// parse_b6o_file :753 / _ex :807, parse_paf_file :984 / _ex :1046): a line
+// that does not qualify is skipped (ok = false), like the reference's
+// `except IndexError: continue`.
+inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
+    if (fmt == WK_FMT_SAM) return parse_line(p, e, extra);
+    Line L{};
+    const char* f[13];  // field starts; f[i + 1] - 1 is the tab that ends field i
+    int nf = 0;
+    f[0] = p;
+    const int want = fmt == WK_FMT_MAP ? 2 : (extra ? 12 : (fmt == WK_FMT_B6O ? 3 : 7));
+    for (const char* c = p; nf < want;) {
+        const char* t = (const char*)memchr(c, '\t', e - c);
+        if (!t) {
+            f[++nf] = e + 1;  // last field runs to the end of the line
+            break;
+        }
+        f[++nf] = t + 1;
+        c = t + 1;
+    }
+    // nf = number of fields seen (up to `want`); field i = [f[i], f[i + 1] - 1)
+    auto fb = [&](int i) { return f[i]; };
+    auto fe = [&](int i) { return f[i + 1] - 1; };
+    if (fmt == WK_FMT_MAP) {
+        if (nf < 2) return L;  // no tab
+        L.q = fb(0);
+        L.qn = fe(0) - fb(0);
+        const char* rb = fb(1);
+        const char* re = fe(1);
+        while (re > rb && (re[-1] == ' ' || re[-1] == '\r' || re[-1] == '\n' || re[-1] == '\t' || re[-1] == '\v' ||
+                           re[-1] == '\f'))
+            --re;  // str.rstrip()
+        L.r = rb;
+        L.rn = re - rb;
+        L.ok = true;
+        return L;
+    }
+    if (nf < want) return L;
+    const int sub = fmt == WK_FMT_B6O ? 1 : 5;
+    L.q = fb(0);
+    L.qn = fe(0) - fb(0);
+    L.r = fb(sub);
+    L.rn = fe(sub) - fb(sub);
+    if (!extra) {
+        // (b6o: "a\tb" without a third column is not a row; the third split
+        // part exists only behind a second tab)
+        L.ok = true;
+        return L;
+    }
+    long a, b, n;
+    if (fmt == WK_FMT_B6O) {
+        // length = int(x[3]); start, end = sorted(int(x[8]), int(x[9])); x[11] must exist
+        if (!parse_int(fb(3), fe(3), n) || !parse_int(fb(8), fe(8), a) || !parse_int(fb(9), fe(9), b)) {
+            L.bad_number = true;
+            return L;
+        }
+        L.len = (uint32_t)n;
+        L.beg = (int32_t)((a < b ? a : b) - 1);
+        L.end = (int32_t)(a < b ? b : a);
+    } else {
+        // length = int(x[10]), start = int(x[7]), end = int(x[8]), score = int(x[11])
+        long sc;
+        if (!parse_int(fb(10), fe(10), n) || !parse_int(fb(7), fe(7), a) || !parse_int(fb(8), fe(8), b) ||
+            !parse_int(fb(11), fe(11), sc))
+            return L;  // ValueError is caught there: the row is skipped
+        L.len = (uint32_t)n;
+        L.beg = (int32_t)a;
+        L.end = (int32_t)b;
+    }
+    L.ok = true;
+    return L;
+}
+
+inline bool is_row(int fmt, const Line& L) { return L.ok && !(fmt == WK_FMT_SAM && is_unmapped(L)); }
 
 // align.cigar_to_lens (align.py:550-583)
 inline void cigar_lens(const char* c, size_t n, uint32_t& aligned, uint32_t& span) {
@@ -203,7 +299,7 @@ struct wk_tok {
 
 namespace {
 
-void tokenize_range(const wk_tok* T, const char* base, const char* b, const char* e, int extra_bits, bool want_names,
+void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, const char* e, int extra_bits, bool want_names,
                     bool want_groups, bool want_samples, Local& out) {
     const bool extra = (extra_bits & 1) != 0, keep_empty = (extra_bits & 2) != 0;
     const bool filt = T->exclude.size() > 0;
@@ -268,16 +364,17 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
     for (const char* p = b; p < e;) {
         const char* nl = (const char*)memchr(p, '\n', e - p);
         const char* le = nl ? nl : e;
-        const Line L = parse_line(p, le, extra);
+        const Line L = parse_row(fmt, p, le, extra);
         const char* line = p;
         p = nl ? nl + 1 : e;
         if (!L.ok) {
             if (le == line) continue;  // empty line
+            if (fmt != WK_FMT_SAM && !L.bad_number) continue;  // not a row of this format
             out.error = 2;
             out.error_at = line - base;
             return;
         }
-        if (is_unmapped(L)) continue;
+        if (fmt == WK_FMT_SAM && is_unmapped(L)) continue;
         if (!(cur && L.qn == cur_n && memcmp(L.q, cur, cur_n) == 0)) {
             flush();
             cur = L.q;
@@ -291,7 +388,7 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
             keep = false;
             continue;
         }
-        const int mate = (L.flag >> 6) & 3;
+        const int mate = fmt == WK_FMT_SAM ? (L.flag >> 6) & 3 : 0;
         if (mate == 3) {
             out.error = 1;
             out.error_at = line - base;
@@ -305,7 +402,7 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
             id = -(1 + f);
         }
         rc.subj = id;
-        if (extra) {
+        if (extra && fmt == WK_FMT_SAM) {
             long pos = 0;
             for (const char* c = L.pos; *c >= '0' && *c <= '9'; ++c) pos = pos * 10 + (*c - '0');
             uint32_t aligned, span;
@@ -314,6 +411,11 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
             rc.beg = (int32_t)(pos - 1);
             rc.end = (int32_t)(pos - 1 + span);
             rc.len = aligned;
+        } else if (extra) {
+            if (L.len == 0 && !keep_empty) continue;
+            rc.beg = L.beg;
+            rc.end = L.end;
+            rc.len = L.len;
         }
         pool[mate].push_back(rc);
     }
@@ -321,7 +423,7 @@ void tokenize_range(const wk_tok* T, const char* base, const char* b, const char
 }
 
 // first mapped line at or after p whose QNAME differs from the previous mapped line's
-const char* run_boundary(const char* base, const char* p, const char* e) {
+const char* run_boundary(int fmt, bool extra, const char* base, const char* p, const char* e) {
     // previous mapped line before p
     const char* prev_q = nullptr;
     size_t prev_n = 0;
@@ -330,9 +432,9 @@ const char* run_boundary(const char* base, const char* p, const char* e) {
         const char* ls = s - 1;  // points at '\n' ending the previous line
         const char* q = ls;
         while (q > base && q[-1] != '\n') --q;
-        Line L = parse_line(q, ls, false);
+        Line L = parse_row(fmt, q, ls, extra);
         s = q;
-        if (L.ok && !is_unmapped(L)) {
+        if (is_row(fmt, L)) {
             prev_q = L.q;
             prev_n = L.qn;
             break;
@@ -342,8 +444,8 @@ const char* run_boundary(const char* base, const char* p, const char* e) {
     while (p < e) {
         const char* nl = (const char*)memchr(p, '\n', e - p);
         const char* le = nl ? nl : e;
-        Line L = parse_line(p, le, false);
-        if (L.ok && !is_unmapped(L)) {
+        Line L = parse_row(fmt, p, le, extra);
+        if (is_row(fmt, L)) {
             if (!(L.qn == prev_n && memcmp(L.q, prev_q, prev_n) == 0)) return p;
         }
         p = nl ? nl + 1 : e;
@@ -386,11 +488,22 @@ int wk_tok_set_exclude(wk_tok* t, const char* blob, const int32_t* off, int32_t 
 
 int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int final_block, int extra, int want_names,
                int64_t* consumed, int64_t* n_reads, int64_t* n_records) {
+    return wk_tok_text(t, WK_FMT_SAM, buf, len, first_block, final_block, extra, want_names, consumed, n_reads, n_records);
+}
+
+int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_block, int final_block, int extra,
+                int want_names, int64_t* consumed, int64_t* n_reads, int64_t* n_records) {
     if (!t || !buf || len < 0 || !consumed || !n_reads || !n_records) return WK_E_ARG;
+    if (fmt < WK_FMT_SAM || fmt > WK_FMT_PAF) {
+        t->err = "unknown alignment format code";
+        return WK_E_ARG;
+    }
+    if (fmt == WK_FMT_MAP) extra = 0;  // no "ex" flavour (align.py:236)
+    const bool ex = (extra & 1) != 0;
     const char* b = buf;
     const char* e = buf + len;
     // header: leading '@' lines (align.py:295-300); it may span several blocks
-    if (first_block) t->in_header = true;
+    if (first_block) t->in_header = fmt == WK_FMT_SAM;
     while (t->in_header && b < e) {
         if (*b != '@') {
             t->in_header = false;
@@ -432,8 +545,8 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
             const char* ls = s - 1;
             const char* q = ls;
             while (q > b && q[-1] != '\n') --q;
-            Line L = parse_line(q, ls, false);
-            if (L.ok && !is_unmapped(L)) {
+            Line L = parse_row(fmt, q, ls, ex);
+            if (is_row(fmt, L)) {
                 if (!q_last) {
                     q_last = L.q;
                     qn_last = L.qn;
@@ -458,20 +571,20 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
         const char* p = b + span * i / T;
         if (p < cut[i - 1]) p = cut[i - 1];
         p = (p > b) ? next_line(p - 1, stop) : b;  // to a line start
-        cut[i] = run_boundary(b, p, stop);
+        cut[i] = run_boundary(fmt, ex, b, p, stop);
     }
     for (int i = 1; i <= T; ++i)
         if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1];
     std::vector<Local> loc(T);
     if (T == 1) {
-        tokenize_range(t, buf, cut[0], cut[1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
+        tokenize_range(t, fmt, buf, cut[0], cut[1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
                        (want_names & 4) != 0, loc[0]);
     } else {
         std::vector<std::thread> th;
         th.reserve(T);
         for (int i = 0; i < T; ++i)
             th.emplace_back([&, i] {
-                tokenize_range(t, buf, cut[i], cut[i + 1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
+                tokenize_range(t, fmt, buf, cut[i], cut[i + 1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
                                (want_names & 4) != 0, loc[i]);
             });
         for (auto& x : th) x.join();
@@ -479,7 +592,7 @@ int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int fin
     for (int i = 0; i < T; ++i)
         if (loc[i].error) {
             char msg[160];
-            snprintf(msg, sizeof msg, loc[i].error == 1 ? "SAM flag with both mate bits set at byte %zu" : "malformed SAM line at byte %zu",
+            snprintf(msg, sizeof msg, loc[i].error == 1 ? "SAM flag with both mate bits set at byte %zu" : "malformed alignment line at byte %zu",
                      loc[i].error_at);
             t->err = msg;
             return loc[i].error == 1 ? WK_E_RANGE : WK_E_ARG;

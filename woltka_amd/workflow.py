@@ -21,7 +21,7 @@ from os.path import basename, isdir, isfile, join
 import click
 import numpy as np
 
-from .align import infer_align_format, plain_mapper
+from .align import NATIVE_FORMATS, infer_align_format, plain_mapper
 from .classify import Engine
 from .file import (id2file_from_dir, id2file_from_map, openzip, path2stem,
                    read_ids, read_map_1st, read_map_uniq, readzip, readzip_bytes,
@@ -199,10 +199,11 @@ def classify(mapper:  object,
     n = chunk or DEVICE_CHUNK
     csample, strata = False, None
     try:
-        # SAM input goes through the native multi-threaded tokenizer; other
-        # formats (and the SAM "extra + exclude" flavour, whose reference
-        # parser has a quirk reproduced only by the Python one) use the Python
-        # parsers.  Query names are materialised only when something needs them.
+        # SAM, BLAST tabular, PAF and simple map input go through the native
+        # multi-threaded tokenizer; the "extra + exclude" flavour (the
+        # reference's SAM parser for it has a quirk reproduced only by the
+        # Python one) and anything else use the Python parsers.  Query names
+        # are materialised only when something needs them.
         if cover is not None and ordinal:
             raise ValueError('Subject coverage (--outcov) needs subject-level '
                              'alignments; it cannot be combined with --coords.')
@@ -232,7 +233,8 @@ def classify(mapper:  object,
                     head = stream.readline()
                     fmt_ = infer_align_format(iter(
                         [head.decode()] if head else []))[0]
-                native = native_ok and fmt_ == 'sam'
+                native = native_ok and fmt_ in NATIVE_FORMATS and not (
+                    fmt_ == 'map' and (ordinal or cover is not None))
                 want_names = bool((demux and not native_demux) or
                                   rank2dir is not None or
                                   (stratmap and not (native and native_strata)))
@@ -252,7 +254,7 @@ def classify(mapper:  object,
                         stream, head, exclude, NATIVE_BLOCK, ordinal,
                         want_names, trimsub, want_groups=native_strata,
                         want_strings=want_strings, want_samples=native_demux,
-                        cover=cover)
+                        cover=cover, fmt=fmt_)
                 else:
                     text = io.TextIOWrapper(stream, encoding='utf-8')
                     fh = chain([head.decode()], text) if head else text
