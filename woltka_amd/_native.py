@@ -398,6 +398,7 @@ class Context:
 
 WEIGHT_L = 720720       # WK_WEIGHT_L: k = 0 keys hold multiples of 1 / L
 WEIGHT_MAX_K = 16
+KEY_K_MASK = np.uint64(0xFFF << 49)
 
 
 def canonical_counts(keys, vals):

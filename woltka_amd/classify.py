@@ -389,7 +389,16 @@ class Engine:
         arrays produced by the native tokenizer instead of ``subque`` / staged
         hits."""
         n = len(reads) if packed is None else packed[-1].size - 1
-        if len(self.groups) + n + 1 >= MAX_GROUPS // 2:
+        # room for the (sample, stratum) groups this chunk can add
+        if sample_ids is not None:
+            fresh = len(self._tok_samples) + 1
+        elif strata_ids is not None:
+            fresh = len(strata_labels) + 1
+        elif isinstance(sample_of, list) or strata_of is not None:
+            fresh = n + 1
+        else:
+            fresh = 1
+        if len(self.groups) + fresh >= MAX_GROUPS // 2:
             self.collect(data)
         seen = None
         if sample_ids is not None:
@@ -621,16 +630,34 @@ class Engine:
                     'Device count table overflowed; re-run with a larger '
                     'table (Engine(table_slots=...)).')
         if keys.size:
+            # everything with k <= 16 folds to integer multiples of 1/L per
+            # (job, group, feature) in numpy; the rare k > 16 stay Fractions
             job, k, grp, feat = nat.decode_keys(keys)
+            big = k > nat.WEIGHT_MAX_K
+            units = vals.astype(np.int64) * np.where(
+                big | (k == 0), 1, nat.WEIGHT_L // np.maximum(k, 1))
+            cells, inv = np.unique(keys[~big] & ~nat.KEY_K_MASK,
+                                   return_inverse=True)
+            tot = np.zeros(cells.size, dtype=np.int64)
+            np.add.at(tot, inv, units[~big])
+            cj, _, cg, cf = nat.decode_keys(cells)
             names = self.index.names
-            for j, kk, g, f, nn in zip(job.tolist(), k.tolist(), grp.tolist(),
-                                       feat.tolist(), vals.tolist()):
+            L = nat.WEIGHT_L
+
+            def add(j, g, f, value):
                 sample, stratum = self.groups[g]
                 name = 'Unassigned' if f == nat.FEATURE_UNASSIGNED \
                     else names[f]
                 key = name if stratum is None else (stratum, name)
                 cell = data[self.ranks[j]].setdefault(sample, {})
-                cell[key] = cell.get(key, 0) + Fraction(nn, kk or nat.WEIGHT_L)
+                cell[key] = cell.get(key, 0) + value
+            for j, g, f, u in zip(cj.tolist(), cg.tolist(), cf.tolist(),
+                                  tot.tolist()):
+                add(j, g, f, u // L if u % L == 0 else Fraction(u, L))
+            for j, kk, g, f, nn in zip(job[big].tolist(), k[big].tolist(),
+                                       grp[big].tolist(), feat[big].tolist(),
+                                       vals[big].tolist()):
+                add(j, g, f, Fraction(nn, kk))
         self.ctx.counts_clear()
         self.groups = []
         self.group_ids = {}
