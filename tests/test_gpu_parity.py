@@ -412,3 +412,53 @@ def test_full_size_config2_properties(ctx):
     keys2, vals2 = nat.canonical_counts(*ctx.counts_fetch())
     assert np.array_equal(keys, keys2)
     assert np.array_equal(2 * vals * nat.WEIGHT_L, vals2.astype(np.int64))
+
+
+def test_full_size_mixed_chunk_through_the_split(ctx):
+    """Config-2 size (10 M reads) the way the product stages it — dense subject
+    indices, two-class split, per-subject counting in the first pass — with
+    1 % multi-hit and 0.5 % empty reads mixed in, against the C oracle
+    (bit-exact counts) and the read/record statistics."""
+    rng = np.random.default_rng(77)
+    n_reads = 10_000_000
+    prob = synth.flat_problem(rng, n_subjects=10575, n_taxa=2000,
+                              n_reads=n_reads)
+    h = prob['hier']
+    k = np.ones(n_reads, dtype=np.int64)
+    multi = rng.random(n_reads) < 0.01
+    k[multi] = rng.integers(2, 6, int(multi.sum()))
+    k[rng.random(n_reads) < 0.005] = 0
+    qoff = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(k, out=qoff[1:])
+    subj = prob['subj'][rng.integers(0, n_reads, int(qoff[-1]))]
+    specs = [(nat.MODE_NONE, 0, 0, 0.0),
+             (nat.MODE_RANK, h.rank_codes['genus'], 0, 0.0),
+             (nat.MODE_FREE, 0, nat.F_UNASSIGNED, 0.0)]
+    ctx.set_tree(h.parent, h.last, h.rank_code)
+    jobs = device_jobs(ctx, specs)
+    feats, sidx = np.unique(subj, return_inverse=True)
+    ctx.set_subjects(feats.astype(np.int32))
+    ctx.counts_reserve(1 << 20)
+    ctx.reset_stats()
+    ctx.chunk_stage(sidx.astype(np.int32), qoff.astype(np.int32),
+                    subj_is_set=False, indexed=True)
+    ctx.classify_staged(jobs)
+    keys, vals = ctx.counts_fetch()
+    st = ctx.stats()
+    assert st['n_reads'] == int((k > 0).sum())
+    assert st['n_records'] == int(qoff[-1])
+    ojobs = [dict(mode=m, rank_code=c, flags=f, major=mj)
+             for m, c, f, mj in specs]
+    _, contrib = c_oracle.classify(subj.astype(np.int32),
+                                   qoff.astype(np.int32), ojobs, h.parent,
+                                   h.rank_code, 0, None)
+    okeys, ocnt = np.unique(contrib, return_counts=True)
+    assert_same_counts(keys, vals, okeys, ocnt)
+    # the single-pass kernel gives the same table
+    ctx.set_option('split', 0)
+    try:
+        ctx.classify_staged(jobs)
+        keys2, vals2 = ctx.counts_fetch()
+    finally:
+        ctx.set_option('split', 1)
+    assert_same_counts(keys2, vals2, okeys, 2 * ocnt)
