@@ -300,7 +300,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    ctx = nat.Context(local)
+    # one process per GPU; a launcher that narrows the visible devices to one
+    # per process leaves a single device 0
+    ctx = nat.Context(local % max(nat.device_count(), 1))
     # one sample set per GPU: different seed per rank, same shape (weak scaling)
     wl = WORKLOADS[a.workload](ctx, seed=1002 + rank, scale=a.scale)
     ctx.sync()

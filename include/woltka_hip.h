@@ -114,6 +114,8 @@ typedef struct wk_stats {
 
 /* ---- life cycle -------------------------------------------------------- */
 int wk_abi_version(void);
+/* Number of HIP devices visible to this process (0 when there is none). */
+int wk_device_count(void);
 /* Create a context on HIP device `device`.  Fails (WK_E_HIP) without a GPU. */
 int wk_create(int device, wk_ctx** out);
 void wk_destroy(wk_ctx* ctx);

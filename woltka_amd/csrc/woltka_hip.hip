@@ -257,6 +257,11 @@ extern "C" {
 
 int wk_abi_version(void) { return WK_ABI_VERSION; }
 
+int wk_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 const char* wk_last_error(const wk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
 int wk_create(int device, wk_ctx** out) {
