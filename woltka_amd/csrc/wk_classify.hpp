@@ -342,6 +342,12 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
     }
 #endif
 
+    // Jobs whose result is a list over a *set* of subject rows are only marked
+    // here and emitted together below: one more pass over the rows for all of
+    // them instead of one pass per job.
+    constexpr bool kFuseLists = kUseLds && C::kHasCols;
+    uint32_t list_jobs = 0;
+
     for (int jb = 0; jb < a.n_jobs; ++jb) {
         const JobDev job = a.jobs[jb];
         int32_t res = WK_ASSIGN_NONE;  // feature id, NONE, or MULTI
@@ -351,7 +357,9 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                 res = first;
             } else if (!(job.flags & WK_F_UNIQ)) {
                 res = WK_ASSIGN_MULTI;
-                if (g >= 0) {
+                if (kFuseLists && g >= 0 && a.subj_is_set && !(job.flags & WK_F_SIZED) && n <= WK_MAX_K) {
+                    list_jobs |= 1u << jb;
+                } else if (g >= 0) {
                     int32_t kd = n;
                     if (!a.subj_is_set) {
                         kd = 0;
@@ -420,7 +428,9 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                 // the list `taxa`: one entry per distinct subject, None
                 // entries dropped before k is taken (classify.py:167-168)
                 res = WK_ASSIGN_MULTI;
-                if (g >= 0) {
+                if (kFuseLists && g >= 0 && a.subj_is_set && !(job.flags & WK_F_SIZED) && n <= WK_MAX_K) {
+                    list_jobs |= 1u << jb;
+                } else if (g >= 0) {
                     int32_t kd = cs.valid;  // exact when the read is a set
                     if (!a.subj_is_set) {
                         kd = 0;
@@ -479,6 +489,34 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                     }
                 } else {
                     count_add<kUseLds>(cache, a.table, jb, 1, g, (uint32_t)f);
+                }
+            }
+        }
+    }
+
+    if constexpr (kFuseLists) {
+        if (list_jobs) {
+            // the rows once more, four at a time, for all marked jobs: each
+            // distinct subject adds 1/k to its feature (rank none) or to its
+            // ancestor at the job's rank, None entries dropped before k is taken
+            for (int32_t j0 = 0; j0 < n; j0 += 4) {
+                int4 rw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rw[q] = cand.rows4[cand.cand[(j0 + q < n) ? (j0 + q) : 0]];
+                for (int jb = 0; jb < a.n_jobs; ++jb) {
+                    if (!((list_jobs >> jb) & 1u)) continue;
+                    const JobDev& job = a.jobs[jb];
+                    const bool by_rank = job.mode == WK_MODE_RANK;
+                    const int32_t col = job.col;
+                    const int32_t kd =
+                        !by_rank ? n : (col == 0 ? sc.col[0].valid : (col == 1 ? sc.col[1].valid : sc.col[2].valid));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (j0 + q >= n) continue;
+                        const int32_t t = !by_rank ? rw[q].x : (col == 0 ? rw[q].y : (col == 1 ? rw[q].z : rw[q].w));
+                        if (t < 0) continue;
+                        count_add<kUseLds>(cache, a.table, jb, (uint32_t)kd, g, (uint32_t)t);
+                    }
                 }
             }
         }
