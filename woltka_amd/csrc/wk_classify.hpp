@@ -72,6 +72,11 @@ struct ClassifyArgs {
     int32_t first_by_subject;  // slab columns are subject indices (else job * bins + feature)
     int32_t first_slab16;
     int32_t resume;            // continue the first pass's miss-log streams
+    // chunks of feature ids (no subject rows, e.g. the gene lists of the
+    // coord-match): the first pass builds a read's row from these per-rank
+    // tables, column c of job.col == c
+    const int32_t* col_anc[3];
+    int32_t n_cols;
 };
 
 // tree.find_rank for all nodes (tree.py:467-510): the taxon itself is tested
@@ -861,31 +866,40 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
             if (!use_rows) return c;
             return ((uint32_t)c < (uint32_t)a.n_subjects) ? a.rows[(int64_t)c * a.row_w] : -1;
         };
+        // (second pass of the split: the workgroup's own list of reads)
+        auto item = [&](int64_t i) -> int64_t {
+            if constexpr (listed) return (int64_t)my_list[i < n_items ? i : n_items - 1];
+            else return i;
+        };
+        int64_t i = r;
+        int64_t ra = item(i), rb = item(i + stride);
         int32_t s0, e0, s1, e1;
-        load_offsets(r, s0, e0);
-        load_offsets(r + stride, s1, e1);
+        load_offsets(ra, s0, e0);
+        load_offsets(rb, s1, e1);
         int32_t f0 = first_feature(s0, e0);
-        int32_t g0 = load_group(r);
-        for (; r < a.n_reads; r += stride) {
+        int32_t g0 = load_group(ra);
+        for (; i < n_items; i += stride) {
+            const int64_t rc = item(i + 2 * stride);
             int32_t s2, e2;
-            load_offsets(r + 2 * stride, s2, e2);
+            load_offsets(rc, s2, e2);
             const int32_t f1 = first_feature(s1, e1);
-            const int32_t g1 = load_group(r + stride);
+            const int32_t g1 = load_group(rb);
             const int32_t n = e0 - s0;
             if (n <= 0) {
-                mark_empty(a, r);
+                mark_empty(a, ra);
             } else if (use_rows) {
                 bool ok = true;
                 for (int32_t j = 0; j < n; ++j) ok &= ((uint32_t)a.subj[s0 + j] < (uint32_t)a.n_subjects);
                 if (!ok)
                     atomicOr(a.table.err, kErrFeatureRange);
                 else
-                    evaluate(RowCand<const int32_t*>{a.subj + s0, a.rows, a.row_w}, n, r, g0, f0);
+                    evaluate(RowCand<const int32_t*>{a.subj + s0, a.rows, a.row_w}, n, ra, g0, f0);
             } else {
-                evaluate(FeatureCand<const int32_t*>{a.subj + s0, a.n_nodes}, n, r, g0, f0);
+                evaluate(FeatureCand<const int32_t*>{a.subj + s0, a.n_nodes}, n, ra, g0, f0);
             }
             s0 = s1; e0 = e1; f0 = f1; g0 = g1;
             s1 = s2; e1 = e2;
+            ra = rb; rb = rc;
         }
     }
     flush_stats(a, my_reads, my_records);
@@ -918,7 +932,7 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
 //
 // kReads reads per thread and round, 64 apart inside the wave's window, so that
 // every load is coalesced and kReads x more bytes are in flight per wave.
-template <bool kBySubject, bool kOneJob, int kReads>
+template <bool kBySubject, bool kOneJob, int kReads, bool kFeature = false>
 __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, uint32_t lds_slots,
                                                                unsigned long long* __restrict__ left_mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -929,7 +943,9 @@ __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, u
     cache_setup(cache, a, smem, lds_slots);
 
     const uint32_t n_reads = (uint32_t)a.n_reads, last = n_reads - 1u;
-    const uint32_t n_subjects = (uint32_t)a.n_subjects;
+    // (feature-id chunks: the candidate is the feature itself, any id is "in the table")
+    const uint32_t n_subjects = kFeature ? 0xFFFFFFFFu : (uint32_t)a.n_subjects;
+    const uint32_t n_nodes = (uint32_t)a.n_nodes;
     const uint32_t tile = blockDim.x * (uint32_t)kReads;  // reads per workgroup round
     const uint32_t stride = gridDim.x * tile;
     const char* __restrict__ qoff_b = reinterpret_cast<const char*>(a.qoff);
@@ -961,7 +977,20 @@ __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, u
                                        : 0xFFFFFFFFu;
     };
     auto load_rows = [&](const Firsts& f, Rows& w) {
-        if constexpr (!kBySubject) {
+        if constexpr (kFeature) {
+            // {feature, its ancestor at the rank of column 0, 1, 2}: one 4-byte
+            // gather per rank column in use
+#pragma unroll
+            for (int k = 0; k < kReads; ++k) {
+                const uint32_t c = f.c[k];
+                const bool in = c < n_nodes;
+                int4 v = make_int4((int32_t)c, -1, -1, -1);
+                if (a.n_cols > 0 && in) v.y = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.col_anc[0]) + (c << 2));
+                if (a.n_cols > 1 && in) v.z = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.col_anc[1]) + (c << 2));
+                if (a.n_cols > 2 && in) v.w = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.col_anc[2]) + (c << 2));
+                w.v[k] = v;
+            }
+        } else if constexpr (!kBySubject) {
 #pragma unroll
             for (int k = 0; k < kReads; ++k)
                 w.v[k] = (f.c[k] < n_subjects) ? *reinterpret_cast<const int4*>(rows_b + (f.c[k] << 4))

@@ -300,6 +300,10 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, 1, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&partition_merge_kernel),
@@ -711,6 +715,28 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
         a.rows = c->subj_rows.as<int32_t>();
         a.row_w = w;
         a.n_subjects = c->n_subjects;
+    } else {
+        // chunk of feature ids: rank columns for the first pass of the split
+        // (at most three distinct ranks, like a subject row)
+        int slots[3];
+        int n_cols = 0;
+        for (int j = 0; j < n_jobs && n_cols >= 0; ++j) {
+            if (jobs[j].mode != WK_MODE_RANK) continue;
+            int col = -1;
+            for (int q = 0; q < n_cols; ++q)
+                if (slots[q] == jobs[j].rank_slot) col = q;
+            if (col < 0) {
+                if (n_cols == 3) {
+                    n_cols = -1;  // too many ranks: no split for this launch
+                    break;
+                }
+                col = n_cols++;
+                slots[col] = jobs[j].rank_slot;
+                a.col_anc[col] = c->rank_tab[jobs[j].rank_slot].as<int32_t>();
+            }
+            a.jobs[j].col = col;
+        }
+        a.n_cols = n_cols;
     }
     if (out_assign) {
         HIP_TRY(c, c->assign_out.reserve((size_t)n_jobs * (size_t)(c->n_reads ? c->n_reads : 1) * sizeof(int32_t)));
@@ -742,11 +768,12 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // sizes).  It pays even when only half of the reads have a single
             // candidate (config 3: 10.6 -> 7.7 ms); a chunk without any pays one
             // streaming pass over the offsets.
-            const bool split = c->use_split && c->subj_indexed && a.row_w == 4 && c->n_reads < (1ll << 30) &&
-                               c->n_records < (1ll << 30) && c->n_subjects < (1 << 28);
+            const bool feature_chunk = !c->subj_indexed;
+            const bool split = c->use_split && c->n_reads < (1ll << 30) && c->n_records < (1ll << 30) &&
+                               (feature_chunk ? a.n_cols >= 0 : (a.row_w == 4 && c->n_subjects < (1 << 28)));
             // ... and with a small subject table the first pass only histograms
             // subject indices; the assigners run once per subject afterwards
-            const bool by_subject = split && c->use_subject_bins && !out_assign && !c->has_group && !sized &&
+            const bool by_subject = split && !feature_chunk && c->use_subject_bins && !out_assign && !c->has_group && !sized &&
                                     c->n_subjects <= 28672;
             const int max_blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu);
             const int blocks = grid_for(c->n_reads, c->threads, max_blocks);
@@ -834,7 +861,13 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                         first.plog_cnt = a.plog_cnt;
                         first.plog_cap = a.plog_cap;
                     }
-                    if (n_jobs == 1)
+                    if (feature_chunk && n_jobs == 1)
+                        hipLaunchKernelGGL((classify_single_kernel<false, true, 1, true>), dim3(blocks), dim3(c->threads), lds1,
+                                           c->stream, first, (uint32_t)lds_slots, mask);
+                    else if (feature_chunk)
+                        hipLaunchKernelGGL((classify_single_kernel<false, false, 1, true>), dim3(blocks), dim3(c->threads), lds1,
+                                           c->stream, first, (uint32_t)lds_slots, mask);
+                    else if (n_jobs == 1)
                         hipLaunchKernelGGL((classify_single_kernel<false, true, 1>), dim3(blocks), dim3(c->threads), lds1,
                                            c->stream, first, (uint32_t)lds_slots, mask);
                     else
