@@ -98,6 +98,7 @@ __device__ __forceinline__ void scan_matches(const MatchArgs& a, const HitQuery&
 __global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
                                                                     int32_t* __restrict__ cnt,
                                                                     int32_t* __restrict__ ubound,
+                                                                    int2* __restrict__ first2,
                                                                     unsigned long long* __restrict__ tile_sum) {
     __shared__ unsigned long long wsum[kMatchThreads / kWave];
     const int64_t base = (int64_t)blockIdx.x * kMatchTile;
@@ -188,11 +189,17 @@ __global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
         const int64_t h = base + it * kMatchThreads + threadIdx.x;
         if (h < a.n_hits) {
             int32_t c = 0;
+            int2 f2 = make_int2(-1, -1);  // the first two matches ride along: pass 2 rescans only hits with more
 #ifdef WK_ABLATE
             if (!(a.ablate & 1))
 #endif
-                scan_matches(a, q[it], l[it], [&](int32_t) { c += 1; });
+                scan_matches(a, q[it], l[it], [&](int32_t feat) {
+                    if (c == 0) f2.x = feat;
+                    if (c == 1) f2.y = feat;
+                    c += 1;
+                });
             cnt[h] = c;
+            first2[h] = f2;
             ubound[h] = l[it];
             mine += (unsigned long long)c;
         }
@@ -243,6 +250,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const unsigned long lon
 __global__ void __launch_bounds__(kMatchThreads) match_write_kernel(MatchArgs a,
                                                                     const int32_t* __restrict__ cnt,
                                                                     const int32_t* __restrict__ ubound,
+                                                                    const int2* __restrict__ first2,
                                                                     const unsigned long long* __restrict__ tile_off,
                                                                     int32_t* __restrict__ poff,
                                                                     int32_t* __restrict__ pairs) {
@@ -292,9 +300,14 @@ __global__ void __launch_bounds__(kMatchThreads) match_write_kernel(MatchArgs a,
         if (h < a.n_hits) {
             const int64_t o = toff + scan[idx];
             poff[h] = (int32_t)o;
-            if (cnt[h] > 0) {  // only matching hits re-scan (no second search)
+            const int32_t c = cnt[h];
+            if (c > 2) {  // rare (nested / overlapping genes): scan again from the stored upper bound
                 int64_t w = o;
                 scan_matches(a, load_hit(a, h), ubound[h], [&](int32_t feat) { pairs[w++] = feat; });
+            } else if (c > 0) {
+                const int2 f2 = first2[h];
+                pairs[o] = f2.x;
+                if (c == 2) pairs[o + 1] = f2.y;
             }
         }
     }

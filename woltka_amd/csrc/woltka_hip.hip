@@ -105,7 +105,7 @@ struct wk_ctx {
     bool has_group = false, subj_is_set = false, chunk_valid = false;
 
     // staged ordinal chunk
-    DevBuf o_genome, o_beg, o_end, o_len, o_hoff, o_cnt, o_ub, o_poff, o_pairs, o_qoff, o_tile_sum, o_tile_off;
+    DevBuf o_genome, o_beg, o_end, o_len, o_hoff, o_cnt, o_ub, o_first2, o_poff, o_pairs, o_qoff, o_tile_sum, o_tile_off;
     int64_t n_hits = 0, o_reads = 0;
     double th = 0.8;
     bool ord_valid = false;
@@ -322,7 +322,7 @@ void wk_destroy(wk_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4, &c->ginfo,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
-                      &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_poff, &c->o_pairs, &c->o_qoff,
+                      &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
@@ -975,6 +975,7 @@ int wk_ordinal_match(wk_ctx* c) {
     HIP_TRY(c, c->o_cnt.reserve((size_t)(n_hits ? n_hits : 1) * 4));
     HIP_TRY(c, c->o_poff.reserve((size_t)(n_hits ? n_hits : 1) * 4));
     HIP_TRY(c, c->o_ub.reserve((size_t)(n_hits ? n_hits : 1) * 4));
+    HIP_TRY(c, c->o_first2.reserve((size_t)(n_hits ? n_hits : 1) * 8));
     HIP_TRY(c, c->o_tile_sum.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
     HIP_TRY(c, c->o_tile_off.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
     HIP_TRY(c, c->o_qoff.reserve(((size_t)c->o_reads + 1) * 4));
@@ -1001,7 +1002,7 @@ int wk_ordinal_match(wk_ctx* c) {
     if (n_hits > 0) {
         KernelTimer* kt = ktimer_begin(c, "match_count");
         hipLaunchKernelGGL(match_count_kernel, dim3((unsigned)n_tiles), dim3(kMatchThreads), 0, c->stream, a,
-                           c->o_cnt.as<int32_t>(), c->o_ub.as<int32_t>(), c->o_tile_sum.as<unsigned long long>());
+                           c->o_cnt.as<int32_t>(), c->o_ub.as<int32_t>(), c->o_first2.as<int2>(), c->o_tile_sum.as<unsigned long long>());
         ktimer_end(c, kt);
         kt = ktimer_begin(c, "scan");
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->o_tile_sum.as<unsigned long long>(),
@@ -1014,7 +1015,7 @@ int wk_ordinal_match(wk_ctx* c) {
         HIP_TRY(c, c->o_pairs.reserve((size_t)(total ? total : 1) * 4));
         kt = ktimer_begin(c, "match_write");
         hipLaunchKernelGGL(match_write_kernel, dim3((unsigned)n_tiles), dim3(kMatchThreads), 0, c->stream, a,
-                           c->o_cnt.as<int32_t>(), c->o_ub.as<int32_t>(), c->o_tile_off.as<unsigned long long>(), c->o_poff.as<int32_t>(),
+                           c->o_cnt.as<int32_t>(), c->o_ub.as<int32_t>(), c->o_first2.as<int2>(), c->o_tile_off.as<unsigned long long>(), c->o_poff.as<int32_t>(),
                            c->o_pairs.as<int32_t>());
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
