@@ -12,6 +12,8 @@ which turns "lowest common ancestor of a set" into "lowest ancestor of the
 smallest id whose range still contains the largest id" (see
 ``csrc/wk_classify.hpp``), and turns ``find_rank`` into one table gather.
 """
+from itertools import repeat
+
 import numpy as np
 
 
@@ -24,7 +26,7 @@ class FeatureIndex:
 
     def __init__(self, names=()):
         self.names = list(names)
-        self.ids = {x: i for i, x in enumerate(self.names)}
+        self.ids = dict(zip(self.names, range(len(self.names))))
         if len(self.ids) != len(self.names):
             raise ValueError('Feature names are not unique.')
 
@@ -206,8 +208,9 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
                          np.empty(0, np.int32))
     tmp = dict(zip(names, range(n)))
     try:
-        par = np.fromiter((tmp[tree[x]] for x in names), dtype=np.int64,
-                          count=n)
+        # (C-level map: NCBI-sized hierarchies have millions of nodes)
+        par = np.fromiter(map(tmp.__getitem__, tree.values()),
+                          dtype=np.int64, count=n)
     except KeyError as e:
         raise ValueError(f'Parent {e} is not part of the hierarchy; call '
                          'fill_root first.')
@@ -228,13 +231,18 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
     rank_codes = {}
     rank_code = np.zeros(n, dtype=np.int32)
     if rankdic:
-        get = tmp.get
-        for node, rank in rankdic.items():
-            t = get(node)
-            if t is None or rank is None:
-                continue
-            code = rank_codes.get(rank)
-            if code is None:
-                code = rank_codes[rank] = len(rank_codes) + 1
-            rank_code[pre[t]] = code
+        # codes in order of first appearance among the ranked nodes of the tree
+        at = np.fromiter(map(tmp.get, rankdic, repeat(-1)), dtype=np.int64,
+                         count=len(rankdic))
+        ranks = list(rankdic.values())
+        keep = at >= 0
+        if None in set(ranks):
+            keep &= np.fromiter((r is not None for r in ranks), dtype=bool,
+                                count=len(ranks))
+        if not keep.all():
+            ranks = [r for r, k in zip(ranks, keep.tolist()) if k]
+            at = at[keep]
+        rank_codes = {r: i + 1 for i, r in enumerate(dict.fromkeys(ranks))}
+        rank_code[pre[at]] = np.fromiter(map(rank_codes.__getitem__, ranks),
+                                         dtype=np.int32, count=len(ranks))
     return Hierarchy(index, parent, last, rank_code, rank_codes, dep)
