@@ -177,6 +177,38 @@ def test_native_strata_join_matches_python():
     assert tok.load_strata(io.BytesIO(b'no tab here\n')) == []
 
 
+def test_large_strata_map_is_built_by_all_threads():
+    """A map big enough for the parallel loader (ranges parsed by several
+    threads, 64 shards): same join as the Python dict, a repeated read id keeps
+    its last label, across block boundaries too."""
+    rng = np.random.default_rng(9)
+    n = 120000
+    ids = rng.permutation(n)
+    rows = [f'read{int(i):07d}\tL{int(i) % 37}\n' for i in ids]
+    # duplicates: later lines win, also when they sit in another thread's range
+    for i in rng.integers(0, n, 5000).tolist():
+        rows.append(f'read{i:07d}\tDUP{i % 11}\n')
+    rows.insert(1000, 'one\ttoo\tmany\n')
+    from woltka_amd.file import read_map_uniq
+    exp = dict(read_map_uniq(iter(rows)))
+    blob = ''.join(rows).encode()
+    probe = rng.integers(0, n + 50, 3000).tolist()
+    sam = ''.join(f'read{i:07d}\t0\tG1\t1\t255\t10M\t*\t0\t0\t*\t*\n'
+                  for i in probe).encode()
+    want = [exp.get(f'read{i:07d}') for i in probe]
+    for threads, block in ((1, 1 << 27), (8, 1 << 27), (8, 700001)):
+        tok = Tokenizer(threads)
+        labels = tok.load_strata(io.BytesIO(blob), block)
+        res = tok.parse(sam, first=True, final=True, want_groups=True)
+        got = [labels[g] if g >= 0 else None for g in res['group'].tolist()]
+        tok.close()
+        # consecutive equal read ids are one read: compare per distinct run
+        runs = [probe[0]] + [b for a, b in zip(probe, probe[1:]) if a != b]
+        assert got == [exp.get(f'read{i:07d}') for i in runs]
+        assert sorted(set(labels)) == sorted(set(exp.values()))
+    assert want
+
+
 def test_native_readmap_format_matches_python():
     from woltka_amd import _native as nat
     from woltka_amd.file import write_readmap

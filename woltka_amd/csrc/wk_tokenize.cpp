@@ -18,6 +18,7 @@
 // run boundaries, one range per thread; ranges are tokenised independently and
 // concatenated, so the output does not depend on the thread count.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -286,9 +287,18 @@ struct wk_tok {
     bool in_header = false; // still inside the leading '@' lines of a file
     // stratification of the current sample: read id -> stratum (file.read_map_uniq
     // + workflow.read_strata, file.py:368-385, workflow.py:912-938)
-    NameTable strata_keys;
-    std::vector<int32_t> strata_of;  // per key id
+    // (sharded by the top hash bits so that a map of tens of millions of reads is
+    // built by all threads: each shard is owned by one thread while loading)
+    static constexpr int kStrataShards = 64;
+    NameTable strata_keys[kStrataShards];
+    std::vector<int32_t> strata_of[kStrataShards];  // per key id of the shard
     NameTable strata_labels;
+    int32_t strata_find(const char* p, size_t n) const {
+        const uint64_t hv = hash_bytes(p, n);
+        const int sh = (int)(hv >> 58);
+        const int32_t id = strata_keys[sh].find(p, n, hv);
+        return id < 0 ? -1 : strata_of[sh][id];
+    }
     std::vector<int32_t> group;      // per read of the last call: stratum id or -1
     // demultiplexing (workflow.demultiplex, workflow.py:844-909): sample = text
     // before the first '_' of the read id, if anything follows it
@@ -355,8 +365,7 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
             if (want_groups) {  // stratum of read id = QNAME + mate suffix
                 keybuf.assign(cur, cur_n);
                 keybuf.append(kSuffix[m]);
-                const int32_t id = T->strata_keys.find(keybuf.data(), keybuf.size(), hash_bytes(keybuf.data(), keybuf.size()));
-                out.group.push_back(id < 0 ? -1 : T->strata_of[id]);
+                out.group.push_back(T->strata_find(keybuf.data(), keybuf.size()));
             }
             pool[m].clear();
         }
@@ -730,8 +739,10 @@ int wk_tok_new_samples(wk_tok* t, char* blob, int64_t* off, int32_t* n_new) {
 
 int wk_tok_strata_clear(wk_tok* t) {
     if (!t) return WK_E_ARG;
-    t->strata_keys = NameTable();
-    t->strata_of.clear();
+    for (int i = 0; i < wk_tok::kStrataShards; ++i) {
+        t->strata_keys[i] = NameTable();
+        t->strata_of[i].clear();
+    }
     t->strata_labels = NameTable();
     return WK_OK;
 }
@@ -740,32 +751,97 @@ int wk_tok_strata_clear(wk_tok* t) {
 // trailing white space; a repeated read id keeps its last label (dict()).
 int wk_tok_strata_load(wk_tok* t, const char* buf, int64_t len, int64_t* n_entries, int32_t* n_labels) {
     if (!t || (len > 0 && !buf) || len < 0) return WK_E_ARG;
-    const char* p = buf;
+    constexpr int S = wk_tok::kStrataShards;
+    struct Entry {
+        const char* key;
+        uint32_t kn;
+        int32_t label;  // id in the parsing thread's local label table
+        uint64_t kh;
+    };
+    // phase 1: line-aligned ranges parsed in parallel into per-shard buckets
+    int T = (int)std::max<int64_t>(1, std::min<int64_t>(t->n_threads, len >> 16));
+    std::vector<const char*> cut(T + 1);
     const char* e = buf + len;
-    while (p < e) {
-        const char* nl = (const char*)memchr(p, '\n', e - p);
-        const char* le = nl ? nl + 1 : e;  // line including its newline
-        const char* tab = (const char*)memchr(p, '\t', le - p);
-        if (tab && !memchr(tab + 1, '\t', le - tab - 1)) {
-            const char* vb = tab + 1;
-            const char* ve = le;
-            while (ve > vb && (ve[-1] == '\n' || ve[-1] == '\r' || ve[-1] == ' ' || ve[-1] == '\v' || ve[-1] == '\f')) --ve;
-            const size_t kn = (size_t)(tab - p);
-            const uint64_t kh = hash_bytes(p, kn);
-            const uint64_t lh = hash_bytes(vb, (size_t)(ve - vb));
-            int32_t lab = t->strata_labels.find(vb, (size_t)(ve - vb), lh);
-            if (lab < 0) lab = t->strata_labels.add(vb, (size_t)(ve - vb), lh);
-            int32_t id = t->strata_keys.find(p, kn, kh);
-            if (id < 0) {
-                id = t->strata_keys.add(p, kn, kh);
-                t->strata_of.push_back(lab);
-            } else {
-                t->strata_of[id] = lab;
-            }
-        }
-        p = le;
+    cut[0] = buf;
+    cut[T] = e;
+    for (int i = 1; i < T; ++i) {
+        const char* p = buf + len * i / T;
+        if (p < cut[i - 1]) p = cut[i - 1];
+        cut[i] = (p > buf) ? next_line(p - 1, e) : buf;
     }
-    if (n_entries) *n_entries = t->strata_keys.size();
+    std::vector<std::vector<Entry>> bucket((size_t)T * S);
+    std::vector<NameTable> labels(T);
+    auto parse = [&](int ti) {
+        const char* p = cut[ti];
+        const char* stop = cut[ti + 1];
+        NameTable& lt = labels[ti];
+        std::vector<Entry>* mine = &bucket[(size_t)ti * S];
+        while (p < stop) {
+            const char* nl = (const char*)memchr(p, '\n', stop - p);
+            const char* le = nl ? nl + 1 : stop;  // line including its newline
+            const char* tab = (const char*)memchr(p, '\t', le - p);
+            if (tab && !memchr(tab + 1, '\t', le - tab - 1)) {
+                const char* vb = tab + 1;
+                const char* ve = le;
+                while (ve > vb && (ve[-1] == '\n' || ve[-1] == '\r' || ve[-1] == ' ' || ve[-1] == '\v' || ve[-1] == '\f')) --ve;
+                const size_t kn = (size_t)(tab - p);
+                const uint64_t kh = hash_bytes(p, kn);
+                const uint64_t lh = hash_bytes(vb, (size_t)(ve - vb));
+                int32_t lab = lt.find(vb, (size_t)(ve - vb), lh);
+                if (lab < 0) lab = lt.add(vb, (size_t)(ve - vb), lh);
+                mine[kh >> 58].push_back(Entry{p, (uint32_t)kn, lab, kh});
+            }
+            p = le;
+        }
+    };
+    auto run = [&](int n, auto&& fn) {
+        if (T == 1) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::vector<std::thread> th;
+        std::atomic<int> next{0};
+        for (int w = 0; w < std::min(T, n); ++w)
+            th.emplace_back([&] {
+                for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+            });
+        for (auto& x : th) x.join();
+    };
+    run(T, parse);
+    // labels: local ids -> global ids, merged in text order
+    std::vector<std::vector<int32_t>> remap(T);
+    for (int ti = 0; ti < T; ++ti) {
+        const NameTable& f = labels[ti];
+        remap[ti].resize(f.size());
+        for (int32_t k = 0; k < f.size(); ++k) {
+            const char* p = f.arena.data() + f.off[k];
+            int32_t id = t->strata_labels.find(p, f.len[k], f.hash[k]);
+            if (id < 0) id = t->strata_labels.add(p, f.len[k], f.hash[k]);
+            remap[ti][k] = id;
+        }
+    }
+    // phase 2: every shard takes its buckets in text order (a repeated read id
+    // keeps its last label, like dict())
+    run(S, [&](int sh) {
+        NameTable& keys = t->strata_keys[sh];
+        std::vector<int32_t>& of = t->strata_of[sh];
+        for (int ti = 0; ti < T; ++ti)
+            for (const Entry& en : bucket[(size_t)ti * S + sh]) {
+                const int32_t lab = remap[ti][en.label];
+                int32_t id = keys.find(en.key, en.kn, en.kh);
+                if (id < 0) {
+                    id = keys.add(en.key, en.kn, en.kh);
+                    of.push_back(lab);
+                } else {
+                    of[id] = lab;
+                }
+            }
+    });
+    if (n_entries) {
+        int64_t n = 0;
+        for (int sh = 0; sh < S; ++sh) n += t->strata_keys[sh].size();
+        *n_entries = n;
+    }
     if (n_labels) *n_labels = t->strata_labels.size();
     return WK_OK;
 }
