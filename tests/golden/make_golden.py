@@ -561,6 +561,194 @@ def gen_coverage(seed=23):
     dump('coverage.json', {'merges': merges, 'styles': styles, 'runs': runs})
 
 
+def _random_alignment(rng, fmt, subjects, n_queries, prefix='', suffix=''):
+    """Text of a small alignment file: runs of 1-6 hits per query (repeats
+    and duplicates included), subjects drawn with a skew."""
+    lines = []
+    if fmt == 'sam':
+        lines.append('@HD\tVN:1.0\tSO:unsorted\n')
+    weights = [1.0 / (i + 1) for i in range(len(subjects))]
+    for qi in range(n_queries):
+        q = f'{prefix}r{qi:04d}'
+        paired = fmt == 'sam' and rng.random() < 0.4
+        for h in range(rng.choice([1, 1, 1, 2, 3, 4, 6])):
+            s = rng.choices(subjects, weights)[0] + suffix
+            pos = rng.randrange(1, 1_500_000)
+            ln = rng.choice([50, 100, 150, 150, 151])
+            if fmt == 'sam':
+                flag = rng.choice([99, 147, 355, 403]) if paired \
+                    else rng.choice([0, 16, 256])
+                lines.append(f'{q}\t{flag}\t{s}\t{pos}\t255\t{ln}M\t=\t0\t0'
+                             f'\t*\t*\n')
+            elif fmt == 'b6o':
+                a, b = pos, pos + ln - 1
+                if rng.random() < 0.5:
+                    a, b = b, a
+                lines.append(f'{q}\t{s}\t{rng.uniform(90, 100):.2f}\t{ln}\t0\t0'
+                             f'\t1\t{ln}\t{a}\t{b}\t1e-50\t'
+                             f'{rng.uniform(100, 300):.1f}\n')
+            elif fmt == 'paf':
+                lines.append(f'{q}\t{ln}\t0\t{ln}\t{rng.choice("+-")}\t{s}\t'
+                             f'5000000\t{pos - 1}\t{pos - 1 + ln}\t{ln}\t{ln}'
+                             f'\t{rng.randrange(61)}\ttp:A:P\n')
+            else:
+                lines.append(f'{q}\t{s}\n')
+    return ''.join(lines)
+
+
+def gen_cli_random(seed=47, n_cases=48):
+    """`woltka classify` on random small inputs with random option sets:
+    every case stores its input files, the keyword arguments and what the
+    reference wrote (table text, read maps) or raised."""
+    import gzip
+    import tempfile
+    from woltka.workflow import workflow
+    rng = random.Random(seed)
+    tax = os.path.join(DATA, 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        genomes = [x.split('\t')[0] for x in f]
+    ext = {'sam': 'sam', 'b6o': 'b6', 'paf': 'paf', 'map': 'map'}
+    cases = []
+    while len(cases) < n_cases:
+        fmt = rng.choice(['sam', 'sam', 'b6o', 'paf', 'map'])
+        layout = rng.choice(['file', 'dir', 'dir', 'mux'])
+        subjects = rng.sample(genomes, rng.randint(6, 40))
+        kw, files = {'output_fmt': False}, {}     # False = --to-tsv
+        trim = rng.random() < 0.15
+        suffix = '_1' if trim else ''
+        if trim:
+            kw['trimsub'] = '_'
+        if layout == 'file':
+            files[f'aln/S1.{ext[fmt]}'] = _random_alignment(
+                rng, fmt, subjects, rng.randint(20, 80), suffix=suffix)
+            kw['input_fp'] = f'aln/S1.{ext[fmt]}'
+        elif layout == 'dir':
+            for i in range(rng.randint(2, 4)):
+                files[f'aln/S{i + 1}.{ext[fmt]}'] = _random_alignment(
+                    rng, fmt, subjects, rng.randint(10, 60), suffix=suffix)
+            kw['input_fp'] = 'aln'
+        else:
+            parts = []
+            for smp in rng.sample(['A', 'B', 'C', 'D'], rng.randint(2, 4)):
+                body = _random_alignment(rng, fmt, subjects,
+                                         rng.randint(10, 40), f'{smp}_', suffix)
+                parts.append(body if not parts or fmt != 'sam'
+                             else body.split('\n', 1)[1])
+            files[f'mux.{ext[fmt]}'] = ''.join(parts)
+            kw['input_fp'] = f'mux.{ext[fmt]}'
+            kw['demux'] = True
+            if rng.random() < 0.4:
+                files['ids.txt'] = 'A\nC\n'
+                kw['samples'] = 'ids.txt'
+        if rng.random() < 0.5:
+            kw['input_fmt'] = fmt
+        # classification system
+        system = rng.choice(['ogu', 'nodes', 'nodes', 'lineage', 'columns',
+                             'map'])
+        if system == 'nodes':
+            kw['nodes_fps'] = ['$TAX/nodes.dmp']
+            kw['map_fps'] = ['$TAX/taxid.map']
+            if rng.random() < 0.7:
+                kw['names_fps'] = ['$TAX/names.dmp']
+            kw['ranks'] = rng.choice(['free', 'phylum', 'genus', 'species',
+                                      'phylum,genus,species', 'free,family',
+                                      'none,genus'])
+        elif system == 'lineage':
+            kw['lineage_fps'] = ['$TAX/lineages.txt']
+            kw['ranks'] = rng.choice(['phylum', 'genus', 'free',
+                                      'class,species'])
+        elif system == 'columns':
+            kw['columns_fps'] = [rng.choice(['$TAX/rank_tids.tsv',
+                                             '$TAX/rank_names.tsv'])]
+            kw['ranks'] = rng.choice(['phylum', 'genus,species', 'order'])
+        elif system == 'map':
+            kw['map_fps'] = ['$TAX/taxid.map']
+            kw['map_rank'] = True
+        if system != 'ogu':
+            r = rng.random()
+            if r < 0.2:
+                kw['uniq'] = True
+            elif r < 0.4:
+                kw['major'] = rng.choice([51, 60, 75, 90])
+            elif r < 0.55:
+                kw['above'] = True
+            if 'free' in kw.get('ranks', '') and rng.random() < 0.5:
+                kw['subok'] = True
+            for flag in ('name_as_id', 'add_rank', 'add_lineage'):
+                if rng.random() < 0.25:
+                    kw[flag] = True
+        if rng.random() < 0.3:
+            kw['unassigned'] = True
+        if rng.random() < 0.2:
+            kw['exclude'] = ','.join(x + suffix
+                                     for x in rng.sample(subjects, 2))
+        r = rng.random()
+        if r < 0.15:
+            kw['frac'] = True
+        elif r < 0.3:
+            kw['scale'] = rng.choice(['1k', '1M', '100'])
+        if rng.random() < 0.25:
+            kw['digits'] = rng.choice([1, 3])
+        if rng.random() < 0.15 and not trim:
+            kw['sizes'] = '$TAX/length.map'
+            kw['scale'] = '1M'
+        want_maps = system != 'ogu' and rng.random() < 0.3
+        if rng.random() < 0.2:
+            kw['chunk'] = rng.choice([7, 50])
+        with tempfile.TemporaryDirectory() as tmp:
+            for rel, text in files.items():
+                os.makedirs(os.path.dirname(os.path.join(tmp, rel)) or tmp,
+                            exist_ok=True)
+                with open(os.path.join(tmp, rel), 'w') as f:
+                    f.write(text)
+
+            def real(v):
+                if isinstance(v, list):
+                    return [real(x) for x in v]
+                if isinstance(v, str) and v.startswith('$TAX/'):
+                    return os.path.join(tax, v[5:])
+                if isinstance(v, str) and (v in files or v == 'aln'):
+                    return os.path.join(tmp, v)
+                return v
+            args = {k: real(v) for k, v in kw.items()}
+            args['output_fp'] = os.path.join(tmp, 'out')
+            if want_maps:
+                args['outmap_dir'] = os.path.join(tmp, 'maps')
+            multi = ',' in kw.get('ranks', '')
+            expect = {}
+            try:
+                import contextlib
+                import io
+                with contextlib.redirect_stdout(io.StringIO()):
+                    workflow(**args)
+            except Exception as e:     # noqa: an invalid combination
+                expect['error'] = [type(e).__name__, str(e)]
+            else:
+                outs = {}
+                if multi:
+                    for fn in sorted(os.listdir(args['output_fp'])):
+                        with open(os.path.join(args['output_fp'], fn)) as f:
+                            outs[fn] = f.read()
+                else:
+                    with open(args['output_fp']) as f:
+                        outs['out'] = f.read()
+                expect['tables'] = outs
+                if want_maps:
+                    maps = {}
+                    for root, _, fns in os.walk(args['outmap_dir']):
+                        for fn in fns:
+                            rel = os.path.relpath(os.path.join(root, fn),
+                                                  args['outmap_dir'])
+                            with gzip.open(os.path.join(root, fn), 'rt') as f:
+                                maps[rel] = f.read()
+                    expect['maps'] = maps
+        if 'error' in expect and sum('error' in c['expect'] for c in cases) >= 4:
+            continue            # enough failing combinations already
+        cases.append(dict(files=files, kwargs=kw, want_maps=want_maps,
+                          expect=expect))
+    dump('cli_random.json', cases)
+
+
 def main():
     if not _refshim.install():
         print('reference tree not present: nothing to do')
@@ -574,6 +762,7 @@ def main():
     gen_readers()
     gen_host()
     gen_coverage()
+    gen_cli_random()
 
 
 if __name__ == '__main__':

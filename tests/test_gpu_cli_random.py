@@ -1,0 +1,77 @@
+"""`woltka classify` on random small inputs with random option sets: 48 cases
+made by tests/golden/make_golden.gen_cli_random — input files, keyword
+arguments of workflow.workflow (= the CLI options) and what the reference
+wrote (table text per rank, decompressed read maps) or raised.  The GPU path
+must write the same bytes / raise the same error."""
+import contextlib
+import gzip
+import io
+import os
+from os.path import join
+
+import pytest
+
+from helpers import DATA, load_vectors
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_vectors('cli_random.json')
+TAX = join(DATA, 'taxonomy')
+
+
+def _label(i):
+    kw = CASES[i]['kwargs']
+    bits = [os.path.splitext(kw['input_fp'])[1].lstrip('.') or 'dir',
+            kw.get('ranks', 'map' if kw.get('map_rank') else 'ogu')]
+    bits += [k for k in ('demux', 'uniq', 'major', 'above', 'subok',
+                         'unassigned', 'exclude', 'trimsub', 'sizes', 'frac',
+                         'scale', 'digits', 'chunk') if k in kw]
+    return f'{i}-' + '-'.join(map(str, bits))
+
+
+@pytest.mark.parametrize('i', range(len(CASES)), ids=_label)
+def test_random_cli_case(tmp_path, i):
+    from woltka_amd.workflow import workflow
+    case = CASES[i]
+    for rel, text in case['files'].items():
+        fp = tmp_path / rel
+        fp.parent.mkdir(parents=True, exist_ok=True)
+        fp.write_text(text)
+
+    def real(v):
+        if isinstance(v, list):
+            return [real(x) for x in v]
+        if isinstance(v, str) and v.startswith('$TAX/'):
+            return join(TAX, v[5:])
+        if isinstance(v, str) and (v in case['files'] or v == 'aln'):
+            return str(tmp_path / v)
+        return v
+    args = {k: real(v) for k, v in case['kwargs'].items()}
+    args['output_fp'] = str(tmp_path / 'out')
+    if case['want_maps']:
+        args['outmap_dir'] = str(tmp_path / 'maps')
+    args['no_exe'] = True
+    expect = case['expect']
+    if 'error' in expect:
+        with pytest.raises(Exception) as err, \
+                contextlib.redirect_stdout(io.StringIO()):
+            workflow(**args)
+        assert type(err.value).__name__ == expect['error'][0]
+        assert str(err.value) == expect['error'][1]
+        return
+    with contextlib.redirect_stdout(io.StringIO()):
+        workflow(**args)
+    if len(expect['tables']) == 1 and 'out' in expect['tables']:
+        got = {'out': (tmp_path / 'out').read_text()}
+    else:
+        got = {fn: (tmp_path / 'out' / fn).read_text()
+               for fn in sorted(os.listdir(tmp_path / 'out'))}
+    assert got == expect['tables']
+    if case['want_maps']:
+        maps = {}
+        for root, _, fns in os.walk(args['outmap_dir']):
+            for fn in fns:
+                rel = os.path.relpath(join(root, fn), args['outmap_dir'])
+                with gzip.open(join(root, fn), 'rt') as f:
+                    maps[rel] = f.read()
+        assert maps == expect['maps']
