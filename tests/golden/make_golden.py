@@ -749,6 +749,109 @@ def gen_cli_random(seed=47, n_cases=48):
     dump('cli_random.json', cases)
 
 
+def gen_cli_coords(seed=53, n_cases=14):
+    """Coord-match (`--coords`) on random small inputs: reads placed over /
+    next to genes of the bundled coordinates file, three formats with
+    coordinates, random overlap thresholds, optional gene-length normalisation
+    and gene -> function maps."""
+    import lzma
+    import tempfile
+    from woltka.workflow import workflow
+    rng = random.Random(seed)
+    fun = os.path.join(DATA, 'function')
+    genes = {}
+    with lzma.open(os.path.join(fun, 'coords.txt.xz'), 'rt') as f:
+        for line in f:
+            if line.startswith('>'):
+                cur = genes.setdefault(line[1:].strip(), [])
+            else:
+                x = line.split('\t')
+                a, b = int(x[1]), int(x[2])
+                cur.append((min(a, b), max(a, b)))
+    genomes = [g for g in genes if len(genes[g]) > 50]
+    ext = {'sam': 'sam', 'b6o': 'b6', 'paf': 'paf'}
+    cases = []
+    for _ in range(n_cases):
+        fmt = rng.choice(['sam', 'b6o', 'paf'])
+        subjects = rng.sample(genomes, rng.randint(3, 10))
+        files, kw = {}, {'output_fmt': False, 'coords_fp': '$FUN/coords.txt.xz'}
+        for si in range(rng.randint(1, 3)):
+            lines = ['@HD\tVN:1.0\n'] if fmt == 'sam' else []
+            for qi in range(rng.randint(15, 60)):
+                q = f'r{qi:04d}'
+                paired = fmt == 'sam' and rng.random() < 0.5
+                for h in range(rng.choice([1, 1, 2, 3])):
+                    s = rng.choice(subjects)
+                    gs, ge = rng.choice(genes[s])
+                    ln = rng.choice([75, 100, 150])
+                    pos = max(1, gs + rng.randint(-ln, ge - gs))
+                    if fmt == 'sam':
+                        flag = rng.choice([99, 147]) if paired else \
+                            rng.choice([0, 16, 256])
+                        cig = rng.choice([f'{ln}M', f'{ln - 10}M2D10M',
+                                          f'5S{ln - 5}M'])
+                        lines.append(f'{q}\t{flag}\t{s}\t{pos}\t255\t{cig}\t='
+                                     f'\t0\t0\t*\t*\n')
+                    elif fmt == 'b6o':
+                        a, b = pos, pos + ln - 1
+                        if rng.random() < 0.5:
+                            a, b = b, a
+                        lines.append(f'{q}\t{s}\t99.0\t{ln}\t0\t0\t1\t{ln}\t'
+                                     f'{a}\t{b}\t1e-9\t200\n')
+                    else:
+                        lines.append(f'{q}\t{ln}\t0\t{ln}\t+\t{s}\t9999999\t'
+                                     f'{pos - 1}\t{pos - 1 + ln}\t{ln}\t{ln}\t'
+                                     f'60\n')
+            files[f'aln/S{si + 1}.{ext[fmt]}'] = ''.join(lines)
+        kw['input_fp'] = 'aln'
+        kw['overlap'] = rng.choice([50, 80, 80, 100])
+        r = rng.random()
+        if r < 0.3:
+            kw['map_fps'] = ['$FUN/uniref/uniref.map.xz', '$FUN/go/process.tsv.xz']
+            kw['map_rank'] = None       # what the CLI passes: filenames name the ranks
+            kw['ranks'] = rng.choice(['process', 'uniref', 'none,process'])
+        elif r < 0.5:
+            kw['sizes'] = '.'
+            kw['scale'] = '1k'
+            kw['digits'] = 3
+        if rng.random() < 0.3:
+            kw['unassigned'] = True
+        if rng.random() < 0.3:
+            kw['chunk'] = rng.choice([5, 40])
+        with tempfile.TemporaryDirectory() as tmp:
+            for rel, text in files.items():
+                os.makedirs(os.path.dirname(os.path.join(tmp, rel)),
+                            exist_ok=True)
+                with open(os.path.join(tmp, rel), 'w') as f:
+                    f.write(text)
+
+            def real(v):
+                if isinstance(v, list):
+                    return [real(x) for x in v]
+                if isinstance(v, str) and v.startswith('$FUN/'):
+                    return os.path.join(fun, v[5:])
+                if v == 'aln':
+                    return os.path.join(tmp, v)
+                return v
+            args = {k: real(v) for k, v in kw.items()}
+            args['output_fp'] = os.path.join(tmp, 'out')
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                workflow(**args)
+            if ',' in kw.get('ranks', ''):
+                outs = {}
+                for fn in sorted(os.listdir(args['output_fp'])):
+                    with open(os.path.join(args['output_fp'], fn)) as f:
+                        outs[fn] = f.read()
+            else:
+                with open(args['output_fp']) as f:
+                    outs = {'out': f.read()}
+        cases.append(dict(files=files, kwargs=kw, want_maps=False,
+                          expect={'tables': outs}))
+    dump('cli_coords.json', cases)
+
+
 def main():
     if not _refshim.install():
         print('reference tree not present: nothing to do')
@@ -763,6 +866,7 @@ def main():
     gen_host()
     gen_coverage()
     gen_cli_random()
+    gen_cli_coords()
 
 
 if __name__ == '__main__':

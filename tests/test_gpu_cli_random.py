@@ -2,7 +2,10 @@
 made by tests/golden/make_golden.gen_cli_random — input files, keyword
 arguments of workflow.workflow (= the CLI options) and what the reference
 wrote (table text per rank, decompressed read maps) or raised.  The GPU path
-must write the same bytes / raise the same error."""
+must write the same bytes / raise the same error.  14 more cases
+(gen_cli_coords) go through `--coords`: reads placed over / next to genes of
+the bundled coordinates, three formats, overlap 50 / 80 / 100, gene-length
+normalisation (`--sizes .`) and gene -> function maps."""
 import contextlib
 import gzip
 import io
@@ -15,15 +18,16 @@ from helpers import DATA, load_vectors
 
 pytestmark = pytest.mark.gpu
 
-CASES = load_vectors('cli_random.json')
+CASES = load_vectors('cli_random.json') + load_vectors('cli_coords.json')
 TAX = join(DATA, 'taxonomy')
+FUN = join(DATA, 'function')
 
 
 def _label(i):
     kw = CASES[i]['kwargs']
     bits = [os.path.splitext(kw['input_fp'])[1].lstrip('.') or 'dir',
             kw.get('ranks', 'map' if kw.get('map_rank') else 'ogu')]
-    bits += [k for k in ('demux', 'uniq', 'major', 'above', 'subok',
+    bits += [k for k in ('coords_fp', 'overlap', 'demux', 'uniq', 'major', 'above', 'subok',
                          'unassigned', 'exclude', 'trimsub', 'sizes', 'frac',
                          'scale', 'digits', 'chunk') if k in kw]
     return f'{i}-' + '-'.join(map(str, bits))
@@ -43,6 +47,8 @@ def test_random_cli_case(tmp_path, i):
             return [real(x) for x in v]
         if isinstance(v, str) and v.startswith('$TAX/'):
             return join(TAX, v[5:])
+        if isinstance(v, str) and v.startswith('$FUN/'):
+            return join(FUN, v[5:])
         if isinstance(v, str) and (v in case['files'] or v == 'aln'):
             return str(tmp_path / v)
         return v
