@@ -852,6 +852,83 @@ def gen_cli_coords(seed=53, n_cases=14):
     dump('cli_coords.json', cases)
 
 
+def gen_cli_strata(seed=59, n_cases=8):
+    """Two-pass stratified runs (README "combined taxonomic & functional"):
+    pass 1 writes read maps at a rank, pass 2 classifies stratified by them."""
+    import contextlib
+    import io
+    import tempfile
+    from woltka.workflow import workflow
+    rng = random.Random(seed)
+    tax = os.path.join(DATA, 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        genomes = [x.split('\t')[0] for x in f]
+    cases = []
+    for _ in range(n_cases):
+        fmt = rng.choice(['sam', 'b6o', 'map'])
+        ext = {'sam': 'sam', 'b6o': 'b6', 'map': 'map'}[fmt]
+        subjects = rng.sample(genomes, rng.randint(8, 30))
+        files = {}
+        demux = rng.random() < 0.3
+        if demux:
+            parts = []
+            for smp in ('A', 'B', 'C'):
+                body = _random_alignment(rng, fmt, subjects,
+                                         rng.randint(15, 40), f'{smp}_')
+                parts.append(body if not parts or fmt != 'sam'
+                             else body.split('\n', 1)[1])
+            files[f'mux.{ext}'] = ''.join(parts)
+            inp = f'mux.{ext}'
+        else:
+            for i in range(rng.randint(1, 3)):
+                files[f'aln/S{i + 1}.{ext}'] = _random_alignment(
+                    rng, fmt, subjects, rng.randint(15, 50))
+            inp = 'aln'
+        rank1 = rng.choice(['phylum', 'genus', 'family'])
+        kw1 = dict(input_fp=inp, output_fmt=False, ranks=rank1,
+                   nodes_fps=['$TAX/nodes.dmp'], map_fps=['$TAX/taxid.map'],
+                   names_fps=['$TAX/names.dmp'],
+                   name_as_id=rng.random() < 0.5,
+                   outmap_zip=rng.choice(['gz', 'none', 'bz2']))
+        kw2 = dict(input_fp=inp, output_fmt=False,
+                   ranks=rng.choice(['none', 'species', 'free']),
+                   nodes_fps=['$TAX/nodes.dmp'], map_fps=['$TAX/taxid.map'],
+                   uniq=rng.random() < 0.3, unassigned=rng.random() < 0.3)
+        if demux:
+            kw1['demux'] = kw2['demux'] = True
+        with tempfile.TemporaryDirectory() as tmp:
+            for rel, text in files.items():
+                os.makedirs(os.path.dirname(os.path.join(tmp, rel)) or tmp,
+                            exist_ok=True)
+                with open(os.path.join(tmp, rel), 'w') as f:
+                    f.write(text)
+
+            def real(v):
+                if isinstance(v, list):
+                    return [real(x) for x in v]
+                if isinstance(v, str) and v.startswith('$TAX/'):
+                    return os.path.join(tax, v[5:])
+                if isinstance(v, str) and (v in files or v == 'aln'):
+                    return os.path.join(tmp, v)
+                return v
+            a1 = {k: real(v) for k, v in kw1.items()}
+            a1.update(output_fp=os.path.join(tmp, 'out1'),
+                      outmap_dir=os.path.join(tmp, 'maps'))
+            a2 = {k: real(v) for k, v in kw2.items()}
+            a2.update(output_fp=os.path.join(tmp, 'out2'),
+                      strata_dir=os.path.join(tmp, 'maps'))
+            with contextlib.redirect_stdout(io.StringIO()):
+                workflow(**a1)
+                workflow(**a2)
+            with open(a1['output_fp']) as f:
+                t1 = f.read()
+            with open(a2['output_fp']) as f:
+                t2 = f.read()
+        cases.append(dict(files=files, pass1=kw1, pass2=kw2,
+                          expect=dict(table1=t1, table2=t2)))
+    dump('cli_strata.json', cases)
+
+
 def main():
     if not _refshim.install():
         print('reference tree not present: nothing to do')
@@ -867,6 +944,7 @@ def main():
     gen_coverage()
     gen_cli_random()
     gen_cli_coords()
+    gen_cli_strata()
 
 
 if __name__ == '__main__':

@@ -81,3 +81,38 @@ def test_random_cli_case(tmp_path, i):
                 with gzip.open(join(root, fn), 'rt') as f:
                     maps[rel] = f.read()
         assert maps == expect['maps']
+
+
+STRATA = load_vectors('cli_strata.json')
+
+
+@pytest.mark.parametrize('i', range(len(STRATA)))
+def test_random_two_pass_stratified(tmp_path, i):
+    """Pass 1 writes read maps at a rank (gz / bz2 / plain), pass 2 is
+    stratified by them: both tables as the reference wrote them."""
+    from woltka_amd.workflow import workflow
+    case = STRATA[i]
+    for rel, text in case['files'].items():
+        fp = tmp_path / rel
+        fp.parent.mkdir(parents=True, exist_ok=True)
+        fp.write_text(text)
+
+    def real(v):
+        if isinstance(v, list):
+            return [real(x) for x in v]
+        if isinstance(v, str) and v.startswith('$TAX/'):
+            return join(TAX, v[5:])
+        if isinstance(v, str) and (v in case['files'] or v == 'aln'):
+            return str(tmp_path / v)
+        return v
+    a1 = {k: real(v) for k, v in case['pass1'].items()}
+    a1.update(output_fp=str(tmp_path / 'out1'),
+              outmap_dir=str(tmp_path / 'maps'), no_exe=True)
+    a2 = {k: real(v) for k, v in case['pass2'].items()}
+    a2.update(output_fp=str(tmp_path / 'out2'),
+              strata_dir=str(tmp_path / 'maps'), no_exe=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        workflow(**a1)
+        workflow(**a2)
+    assert (tmp_path / 'out1').read_text() == case['expect']['table1']
+    assert (tmp_path / 'out2').read_text() == case['expect']['table2']
