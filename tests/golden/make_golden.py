@@ -749,7 +749,7 @@ def gen_cli_random(seed=47, n_cases=48):
     dump('cli_random.json', cases)
 
 
-def gen_cli_coords(seed=53, n_cases=14):
+def gen_cli_coords(seed=53, n_cases=18):
     """Coord-match (`--coords`) on random small inputs: reads placed over /
     next to genes of the bundled coordinates file, three formats with
     coordinates, random overlap thresholds, optional gene-length normalisation
@@ -814,6 +814,8 @@ def gen_cli_coords(seed=53, n_cases=14):
             kw['sizes'] = '.'
             kw['scale'] = '1k'
             kw['digits'] = 3
+        elif r < 0.7:
+            kw['trimsub'] = '_'         # gene ids "genome_i" -> genome
         if rng.random() < 0.3:
             kw['unassigned'] = True
         if rng.random() < 0.3:

@@ -2,7 +2,7 @@
 made by tests/golden/make_golden.gen_cli_random — input files, keyword
 arguments of workflow.workflow (= the CLI options) and what the reference
 wrote (table text per rank, decompressed read maps) or raised.  The GPU path
-must write the same bytes / raise the same error.  14 more cases
+must write the same bytes / raise the same error.  18 more cases
 (gen_cli_coords) go through `--coords`: reads placed over / next to genes of
 the bundled coordinates, three formats, overlap 50 / 80 / 100, gene-length
 normalisation (`--sizes .`) and gene -> function maps."""

@@ -268,10 +268,16 @@ class Engine:
                     res.get('sample'), ranges
 
     # ------------------------------------------------------------------
-    def set_genes(self, table, prefix):
+    def set_genes(self, table, prefix, trimsub=None):
         """Upload the gene tables; gene names join the feature index (genes
-        that are nodes of the hierarchy keep their node id)."""
+        that are nodes of the hierarchy keep their node id).  ``trimsub``
+        (``--trim-sub`` next to ``--coords``: workflow.strip_suffix runs on the
+        gene ids the mapper returns, workflow.py:318-319) is applied to the
+        names once here; genes that collapse share a feature and the device
+        takes the union."""
         names = table.feature_names(prefix)
+        if trimsub:
+            names = [x.rsplit(trimsub, 1)[0] for x in names]
         intern = self.index.intern
         self.gene_feature = np.fromiter((intern(x) for x in names),
                                         dtype=np.int32, count=len(names))
@@ -423,10 +429,6 @@ class Engine:
             self.ctx.ordinal_stage(genome, beg, end, length, hoff, self._th,
                                    group=group)
             self.ctx.ordinal_match()
-            if trimsub:
-                raise NotImplementedError(
-                    '--trim-sub together with --coords is not available on '
-                    'the GPU path yet.')
             before = self.ctx.stats()['n_reads']
             assign = self.ctx.classify_staged(self.jobs, want_assign=want)
             nq = self.ctx.stats()['n_reads'] - before

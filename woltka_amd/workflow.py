@@ -197,7 +197,7 @@ def classify(mapper:  object,
                     sizes=sizes)
     ordinal = isinstance(mapper, OrdinalMapper)
     if ordinal:
-        engine.set_genes(mapper.table, mapper.prefix)
+        engine.set_genes(mapper.table, mapper.prefix, trimsub)
     n = chunk or DEVICE_CHUNK
     csample, strata = False, None
     try:
@@ -211,7 +211,7 @@ def classify(mapper:  object,
                              'alignments; it cannot be combined with --coords.')
         native_ok = (mapper is plain_mapper or mapper is range_mapper or
                      ordinal) and not ((ordinal or cover is not None) and
-                                       exclude) and not (ordinal and trimsub)
+                                       exclude)
         # stratification without demultiplexing is joined natively (read id ->
         # stratum inside the tokenizer)
         native_strata = bool(stratmap) and not demux
