@@ -168,6 +168,25 @@ class LcaWorkload:
                     records=int(qoff[nreads]))
 
 
+class LcaFreeWorkload(LcaWorkload):
+    """configs[2], the `--rank free` variant: lowest common ancestor of every
+    multi-hit read (one pass, one job)."""
+
+    def __init__(self, ctx, seed, scale=1.0):
+        super().__init__(ctx, seed, scale)
+        self.name = self.name.replace('ranks phylum,genus,species',
+                                      'rank free')
+        self.jobs = [nat.Job(nat.MODE_FREE, 0, 0, 0, 0.0)]
+        h = self.prob['hier']
+        self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
+                          8 * h.n_nodes)
+
+    def cpu_sample(self, n):
+        d = super().cpu_sample(n)
+        d['ranks'] = ['free']
+        return d
+
+
 class OrdinalWorkload:
     """configs[3]: coord-match + gene histogram."""
     dominant = 'match_count'
@@ -220,7 +239,7 @@ class OrdinalWorkload:
 
 
 WORKLOADS = {'flat': FlatWorkload, 'lca': LcaWorkload,
-             'ordinal': OrdinalWorkload}
+             'lca_free': LcaFreeWorkload, 'ordinal': OrdinalWorkload}
 
 
 # --------------------------------------------------------------------------
