@@ -214,32 +214,47 @@ __global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
     }
 }
 
-// Exclusive scan of the tile totals (single workgroup, serial over chunks of
-// blockDim; n_tiles is n_hits / 1024 so this is tiny).
+// Exclusive scan of the tile totals (single workgroup; n_tiles is n_hits / 1024).
+// A round covers 8 tiles per thread: serial prefix inside the thread, shuffle
+// scan of the thread totals inside the wave, wave totals combined through LDS —
+// two barriers per 8192 tiles.
 __global__ void __launch_bounds__(1024) tile_scan_kernel(const unsigned long long* __restrict__ tile_sum,
                                                          unsigned long long* __restrict__ tile_off,
                                                          int64_t n_tiles,
                                                          unsigned long long* __restrict__ total) {
-    __shared__ unsigned long long buf[1024];
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n_tiles; base += blockDim.x) {
-        const int64_t i = base + threadIdx.x;
-        const unsigned long long v = (i < n_tiles) ? tile_sum[i] : 0ull;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        // Hillis-Steele inclusive scan in LDS
-        for (int off = 1; off < (int)blockDim.x; off <<= 1) {
-            unsigned long long add = (threadIdx.x >= (unsigned)off) ? buf[threadIdx.x - off] : 0ull;
-            __syncthreads();
-            buf[threadIdx.x] += add;
-            __syncthreads();
+    constexpr int kPer = 8;
+    __shared__ unsigned long long wave_tot[16];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    unsigned long long carry = 0;  // identical in every thread
+    for (int64_t base = 0; base < n_tiles; base += (int64_t)blockDim.x * kPer) {
+        const int64_t first = base + (int64_t)threadIdx.x * kPer;
+        unsigned long long v[kPer], mine = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            v[k] = (first + k < n_tiles) ? tile_sum[first + k] : 0ull;
+            mine += v[k];
         }
-        const unsigned long long incl = buf[threadIdx.x];
-        if (i < n_tiles) tile_off[i] = carry + incl - v;
+        unsigned long long inc = mine;  // inclusive scan of the thread totals inside the wave
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned long long up = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += up;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
         __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry += incl;
+        unsigned long long before = 0, round_total = 0;
+        for (int q = 0; q < n_waves; ++q) {
+            const unsigned long long t = wave_tot[q];
+            before += q < wave ? t : 0ull;
+            round_total += t;
+        }
+        unsigned long long run = carry + before + inc - mine;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (first + k < n_tiles) tile_off[first + k] = run;
+            run += v[k];
+        }
+        carry += round_total;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry;
