@@ -358,3 +358,19 @@ def test_outcov_with_coords_is_rejected(tmp_path):
         '--output', str(tmp_path / 'o.tsv'), '--no-exe'])
     assert res.exit_code != 0
     assert '--outcov' in str(res.exception)
+
+
+def test_stdin_input(tmp_path):
+    """`-i -`: the alignment arrives on stdin (sample id '' like the
+    reference: the header cell is empty); golden made by feeding the same
+    text to the reference's CLI."""
+    import lzma
+    from woltka_amd.cli import classify_cmd
+    with lzma.open(join(ALN, 'bowtie2', 'S01.sam.xz'), 'rt') as f:
+        text = f.read()
+    out = str(tmp_path / 'o.tsv')
+    res = CliRunner().invoke(classify_cmd, ['-i', '-', '-o', out, '--no-exe'],
+                             input=text)
+    assert res.exit_code == 0, res.output + repr(res.exception)
+    assert 'Parsing alignment from stdin . Done.' in res.output
+    assert filecmp.cmp(out, join(OUT, 'bowtie2.S01.stdin.tsv'), shallow=False)
