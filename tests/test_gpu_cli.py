@@ -374,3 +374,26 @@ def test_stdin_input(tmp_path):
     assert res.exit_code == 0, res.output + repr(res.exception)
     assert 'Parsing alignment from stdin . Done.' in res.output
     assert filecmp.cmp(out, join(OUT, 'bowtie2.S01.stdin.tsv'), shallow=False)
+
+
+def test_external_decompressor_pipe(tmp_path):
+    """Without --no-exe the compressed inputs are inflated by `xz` / `bzip2`
+    child processes (file.readzip) and the tokenizer reads the pipe."""
+    from shutil import which
+    from woltka_amd.cli import classify_cmd
+    if not (which('xz') and which('bzip2')):
+        pytest.skip('no external decompressors on this box')
+    for sub, gold in (('bowtie2', 'bowtie2.ogu.tsv'),):
+        out = str(tmp_path / f'{sub}.tsv')
+        res = CliRunner().invoke(classify_cmd, ['--input', join(ALN, sub),
+                                                '--output', out])
+        assert res.exit_code == 0, res.output + repr(res.exception)
+        assert filecmp.cmp(out, join(OUT, gold), shallow=False)
+    out = str(tmp_path / 'burst.tsv')
+    res = CliRunner().invoke(classify_cmd, [
+        '--input', join(ALN, 'burst'), '--output', out, '--rank', 'process',
+        '--coords', join(FUN, 'coords.txt.xz'),
+        '--map', join(FUN, 'uniref', 'uniref.map.xz'),
+        '--map', join(FUN, 'go', 'process.tsv.xz')])
+    assert res.exit_code == 0, res.output + repr(res.exception)
+    assert filecmp.cmp(out, join(OUT, 'burst.process.tsv'), shallow=False)
