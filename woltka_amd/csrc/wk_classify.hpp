@@ -644,12 +644,16 @@ __device__ __forceinline__ void cache_finish(const LdsCache& cache, const Classi
     }
     if (cache.dense) {
         const uint32_t nb = a.dense_total;
-        if (a.slab16) {  // two bins per word; rows are padded to an even length
-            const uint32_t half = (nb + 1u) >> 1;
-            uint32_t* row = a.dense_slab + (size_t)blockIdx.x * half;
+        if (a.slab16) {
+            // 16-bit counts, unit-major: the 64 columns of unit u from all
+            // workgroups are adjacent ([u][workgroup][64]), so the merge reads
+            // one contiguous 128 B x n_workgroups block per unit
+            const uint32_t half = ((nb + kWave - 1u) / kWave) * (kWave / 2u);  // words, units padded to 64 columns
             for (uint32_t i = threadIdx.x; i < half; i += blockDim.x) {
+                const uint32_t u = i >> 5, w = i & 31u;
+                const uint32_t lo = 2u * i < nb ? cache.dense[2u * i] : 0u;
                 const uint32_t hi = 2u * i + 1u < nb ? cache.dense[2u * i + 1u] : 0u;
-                row[i] = cache.dense[2u * i] | (hi << 16);
+                a.dense_slab[((size_t)u * gridDim.x + blockIdx.x) * 32u + w] = lo | (hi << 16);
             }
         } else {
             uint32_t* row = a.dense_slab + (size_t)blockIdx.x * nb;
@@ -671,21 +675,48 @@ __device__ __forceinline__ void merge_first_pass(const ClassifyArgs& a, uint32_t
     for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {
         const uint32_t i = u * kWave + lane;
         uint32_t sum = 0;
-        if (i < a.first_total) {
-            if (a.first_slab16) {
-                const uint16_t* slab = reinterpret_cast<const uint16_t*>(a.first_slab);
-                const size_t pitch = (size_t)((a.first_total + 1u) & ~1u);
-#pragma unroll 4
-                for (uint32_t row = wave; row < a.first_rows; row += n_waves) sum += slab[(size_t)row * pitch + i];
-            } else {
-#pragma unroll 4
-                for (uint32_t row = wave; row < a.first_rows; row += n_waves) sum += a.first_slab[(size_t)row * a.first_total + i];
+        if (a.first_slab16) {
+            // the unit's block [first_rows][64] of 16-bit counts is contiguous:
+            // 16-byte loads (8 columns of one row per lane, 8 rows per wave
+            // load), then the lanes that hold the same columns are folded
+            const uint4* blk = reinterpret_cast<const uint4*>(a.first_slab) + (size_t)u * a.first_rows * 8u;
+            const uint32_t n16 = a.first_rows * 8u;  // 16-byte pieces in the block
+            uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t t = threadIdx.x; t < n16; t += blockDim.x) {
+                const uint4 v = blk[t];
+                acc[0] += v.x & 0xFFFFu; acc[1] += v.x >> 16;
+                acc[2] += v.y & 0xFFFFu; acc[3] += v.y >> 16;
+                acc[4] += v.z & 0xFFFFu; acc[5] += v.z >> 16;
+                acc[6] += v.w & 0xFFFFu; acc[7] += v.w >> 16;
             }
+            // piece t covers columns 8 * (t % 8) .. +7: lanes l, l ^ 8, l ^ 16, l ^ 32 agree
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[k] += __shfl_xor(acc[k], 8, kWave);
+                acc[k] += __shfl_xor(acc[k], 16, kWave);
+                acc[k] += __shfl_xor(acc[k], 32, kWave);
+            }
+            // lane l < 8 now holds the wave's sums of columns 8l .. 8l + 7;
+            // hand column `lane` to lane `lane`
+            const uint32_t src = lane >> 3;
+            uint32_t mine = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t got = __shfl(acc[k], (int)src, kWave);
+                if ((lane & 7u) == (uint32_t)k) mine = got;
+            }
+            sum = mine;
+        } else if (i < a.first_total) {
+#pragma unroll 4
+            for (uint32_t row = wave; row < a.first_rows; row += n_waves) sum += a.first_slab[(size_t)row * a.first_total + i];
         }
         part[wave][lane] = sum;
         __syncthreads();
         if (wave == 0 && i < a.first_total) {
             for (uint32_t q = 1; q < n_waves; ++q) sum += part[q][lane];
+#ifdef WK_ABLATE
+            if (a.ablate & 128) sum = 0u;  // measurement only: column sums without the table adds
+#endif
             if (sum != 0u) {
                 if (a.first_by_subject) {
                     const int4 row = reinterpret_cast<const int4*>(a.rows)[i];
@@ -762,7 +793,13 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
     if constexpr (listed) {
         __shared__ uint32_t part[16][kWave];
         __shared__ uint32_t scan_tot[16];
+#ifdef WK_ABLATE
+        if (!(a.ablate & 32))
+#endif
         merge_first_pass(a, part);
+#ifdef WK_ABLATE
+        if (a.ablate & 64) return;
+#endif
         n_items = (int64_t)compact_left(a, scan_tot);  // ends with a workgroup barrier
         my_list = a.read_list + (size_t)blockIdx.x * a.list_seg;
         if (n_items == 0) {

@@ -838,7 +838,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     // its own grid and LDS layout: no hash cache to speak of, bins = subjects
                     blocks1 = grid_for((c->n_reads + 3) / 4, 1024,
                                        std::min(kStatBlocks, c->prop.multiProcessorCount * c->single_blocks_per_cu));
-                    HIP_TRY(c, c->first_slab.reserve((size_t)blocks1 * c->n_subjects * 4));
+                    HIP_TRY(c, c->first_slab.reserve((size_t)blocks1 * ((size_t)c->n_subjects + 64) * 4));  // (16-bit layout pads units to 64 columns)
                     first.dense_bins = (uint32_t)c->n_subjects;
                     first.dense_total = (uint32_t)c->n_subjects;
                     first.dense_slab = c->first_slab.as<uint32_t>();
@@ -852,7 +852,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     // pass; dense bins go to a slab of their own, log streams are shared
                     size_t lds1 = lds;
                     if (bins) {
-                        HIP_TRY(c, c->first_slab.reserve((size_t)blocks * bins * n_jobs * 4));
+                        HIP_TRY(c, c->first_slab.reserve((size_t)blocks * ((size_t)bins * n_jobs + 64) * 4));
                         first.dense_slab = c->first_slab.as<uint32_t>();
                         const int64_t per_wg = ((c->n_reads + (int64_t)blocks * c->threads - 1) / ((int64_t)blocks * c->threads)) * c->threads;
                         first.slab16 = per_wg <= 65535 ? 1 : 0;
