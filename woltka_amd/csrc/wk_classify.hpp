@@ -209,10 +209,12 @@ __device__ __forceinline__ void col_update(ColStats& c, int32_t t) {
 struct ReadScan {
     int32_t smin, smax;
     ColStats col[3];
+    bool bad;  // a subject index outside the subject table (checked while scanning)
 };
 
 template <typename C>
 __device__ __forceinline__ void scan_candidates(const C& cand, int32_t n, int32_t first, ReadScan& sc) {
+    sc.bad = false;
     sc.smin = sc.smax = first;
     for (int32_t j = 1; j < n; ++j) {
         const int32_t c = cand.feat(j);
@@ -228,6 +230,7 @@ struct RowCand4 {
     P cand;
     const int4* __restrict__ rows4;
     int4 row0;  // row of candidate 0 (loaded ahead of time)
+    uint32_t n_subjects;
     __device__ __forceinline__ int32_t id(int32_t j) const { return cand[j]; }
     __device__ __forceinline__ int32_t feat(int32_t j) const { return rows4[cand[j]].x; }
     __device__ __forceinline__ int32_t tax(int32_t j, const JobDev& job) const {
@@ -239,6 +242,7 @@ struct RowCand4 {
 template <typename P>
 __device__ __forceinline__ void scan_candidates(const RowCand4<P>& cand, int32_t n, int32_t, ReadScan& sc) {
     const int4 r0 = cand.row0;
+    sc.bad = false;
     sc.smin = sc.smax = r0.x;
     col_init(sc.col[0], r0.y);
     col_init(sc.col[1], r0.z);
@@ -249,7 +253,12 @@ __device__ __forceinline__ void scan_candidates(const RowCand4<P>& cand, int32_t
 #pragma unroll
         for (int q = 0; q < 4; ++q) c[q] = cand.cand[(j + q < n) ? (j + q) : 0];  // pad with candidate 0 (idempotent)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rw[q] = cand.rows4[c[q]];
+        for (int q = 0; q < 4; ++q) {
+            // an index outside the table is reported, its row never fetched
+            const bool in = (uint32_t)c[q] < cand.n_subjects;
+            sc.bad |= !in;
+            rw[q] = cand.rows4[in ? c[q] : 0];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             sc.smin = rw[q].x < sc.smin ? rw[q].x : sc.smin;
@@ -352,6 +361,10 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
     // one pass over the subjects: extremes (= LCA inputs) and set size 1 test
     ReadScan sc;
     scan_candidates(cand, n, first, sc);
+    if (sc.bad) {
+        atomicOr(a.table.err, kErrFeatureRange);
+        return;
+    }
     const int32_t smin = sc.smin, smax = sc.smax;
     if ((uint32_t)smax > (uint32_t)WK_MAX_FEATURE || smin < 0) atomicOr(a.table.err, kErrFeatureRange);
     const bool single = (smin == smax);
@@ -896,13 +909,12 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
                     }
                 }
             } else {
-                // every subject index of the read must lie inside the table
-                bool ok = (uint32_t)c0 < (uint32_t)a.n_subjects;
-                for (int32_t j = 1; j < n; ++j) ok &= ((uint32_t)a.subj[s0 + j] < (uint32_t)a.n_subjects);
-                if (!ok)
+                // (subject indices outside the table are caught while the rows are
+                // scanned; the first one here, its row was fetched ahead)
+                if ((uint32_t)c0 >= (uint32_t)a.n_subjects)
                     atomicOr(a.table.err, kErrFeatureRange);
                 else
-                    evaluate(RowCand4<const int32_t*>{a.subj + s0, rows4, row0}, n, r0, g0, row0.x);
+                    evaluate(RowCand4<const int32_t*>{a.subj + s0, rows4, row0, (uint32_t)a.n_subjects}, n, r0, g0, row0.x);
             }
             s0 = s1; e0 = e1; s1 = s2; e1 = e2; s2 = s3; e2 = e3;
             c0 = c1; c1 = c2; row0 = row1; g0 = g1;
