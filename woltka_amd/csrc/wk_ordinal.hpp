@@ -199,8 +199,8 @@ __global__ void __launch_bounds__(kMatchThreads) match_count_kernel(MatchArgs a,
                     c += 1;
                 });
             cnt[h] = c;
-            first2[h] = f2;
-            ubound[h] = l[it];
+            if (c > 0) first2[h] = f2;      // (pass 2 reads these only for such hits)
+            if (c > 2) ubound[h] = l[it];
             mine += (unsigned long long)c;
         }
     }
