@@ -291,6 +291,11 @@ int wk_tok_sam(wk_tok* tok, const char* buf, int64_t len, int first_block,
 int wk_tok_text(wk_tok* tok, int fmt, const char* buf, int64_t len,
                 int first_block, int final_block, int extra, int want_names,
                 int64_t* consumed, int64_t* n_reads, int64_t* n_records);
+/* *out = offset of the first line at or after `pos` that starts a new run of
+ * equal query ids — where one large file may be cut into byte ranges for
+ * several processes without splitting a read. */
+int wk_tok_boundary(int fmt, int extra, const char* buf, int64_t len,
+                    int64_t pos, int64_t* out);
 /* Copy the results out: subj[n_records] (subject indices), off[n_reads + 1]
  * (CSR), beg/end/len[n_records] (extra only), qname[n_reads] =
  * (byte offset in buf << 24) | (length << 2) | mate.  NULL skips an array. */

@@ -397,3 +397,29 @@ def test_external_decompressor_pipe(tmp_path):
         '--map', join(FUN, 'go', 'process.tsv.xz')])
     assert res.exit_code == 0, res.output + repr(res.exception)
     assert filecmp.cmp(out, join(OUT, 'burst.process.tsv'), shallow=False)
+
+
+def test_byte_range_parts_equal_whole_file(tmp_path):
+    """One multiplexed file classified as 3 byte ranges (what three processes
+    would each take) and merged as exact rationals == the whole file, with
+    multi-hit reads (fractions) and paired mates at the cuts."""
+    import contextlib
+    import io
+    import lzma
+    from woltka_amd import align, shard, workflow
+    from woltka_amd.hierarchy import flatten_hierarchy  # noqa: F401
+    mux = tmp_path / 'mux.sam'
+    with open(mux, 'w') as out:
+        for i in range(1, 6):
+            with lzma.open(join(ALN, 'bt2sho', f'S0{i}.sam.xz'), 'rt') as f:
+                for line in f:
+                    if line[0] != '@':
+                        out.write(f'S0{i}_{line}')
+    kw = dict(demux=True, ranks=['none'], fmt='sam', exact=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        whole = workflow.classify(align.plain_mapper, [str(mux)], **kw)
+        parts = [workflow.classify(align.plain_mapper,
+                                   [shard.FilePart(str(mux), i, 3)], **kw)
+                 for i in range(3)]
+    assert shard.merge_profiles(parts) == whole
+    assert sorted(whole['none']) == ['S01', 'S02', 'S03', 'S04', 'S05']

@@ -91,3 +91,68 @@ def test_two_process_gloo_equals_single_process():
     table.write_tsv(table.prep_table(data['none']), buf)
     with open(os.path.join(DATA, 'output', 'bowtie2.ogu.tsv')) as f:
         assert buf.getvalue() == f.read()
+
+
+def test_large_plain_file_is_cut_into_byte_ranges(tmp_path):
+    """A plain file much larger than a share's due becomes FilePart pieces;
+    compressed files and --outmap / --outcov runs (split=False) never do."""
+    big = tmp_path / 'big.sam'
+    big.write_bytes(b'x' * (3 << 20))
+    small = tmp_path / 'small.sam'
+    small.write_bytes(b'y' * 1000)
+    gz = tmp_path / 'big.sam.gz'
+    gz.write_bytes(b'z' * (3 << 20))
+    files = {str(big): 'B', str(small): 'S', str(gz): 'Z'}
+    shares = shard.partition_files(files, 4)
+    pieces = [fp for share in shares for fp in share]
+    parts = [fp for fp in pieces if isinstance(fp, shard.FilePart)]
+    assert sorted((p.part, p.parts) for p in parts) == [(0, 2), (1, 2)]
+    assert all(p.path == str(big) for p in parts)
+    assert str(gz) in pieces and str(small) in pieces
+    assert all(share[fp] in 'BSZ' for share in shares for fp in share)
+    flat = shard.partition_files(files, 4, split=False)
+    assert not any(isinstance(fp, shard.FilePart)
+                   for share in flat for fp in share)
+
+
+@pytest.mark.parametrize('fmt', ['sam', 'b6o', 'map'])
+def test_byte_ranges_never_split_a_read(tmp_path, fmt):
+    """Tokenising the n byte ranges of a file gives, concatenated, exactly the
+    reads of the whole file (native tokenizer, CPU)."""
+    import numpy as np
+    from woltka_amd import align
+    from woltka_amd._native import Tokenizer
+    rng = np.random.default_rng(4)
+    lines = ['@HD\tVN:1.0\n'] if fmt == 'sam' else []
+    for q in range(3000):
+        for _ in range(int(rng.integers(1, 7))):
+            s = f'G{int(rng.integers(0, 40)):03d}'
+            if fmt == 'sam':
+                lines.append(f'read{q}\t{int(rng.choice([0, 99, 147]))}\t{s}\t5'
+                             f'\t255\t50M\t*\t0\t0\t*\t*\n')
+            elif fmt == 'b6o':
+                lines.append(f'read{q}\t{s}\t99\t50\t0\t0\t1\t50\t5\t54\t0\t90\n')
+            else:
+                lines.append(f'read{q}\t{s}\n')
+    fp = tmp_path / f'x.{fmt}'
+    fp.write_text(''.join(lines))
+
+    def reads(part):
+        tok = Tokenizer(3)
+        out, names = [], []
+        with open(fp, 'rb') as f:
+            for buf, res in align.native_sam_blocks(f, tok, 1 << 14, fmt=fmt,
+                                                    want_names=True,
+                                                    part=part):
+                names.extend(tok.new_subjects())
+                q = Tokenizer.query_names(buf, res['qname'])
+                off = res['off'].tolist()
+                out.extend((q[i], sorted(names[s] for s in
+                                         res['subj'][off[i]:off[i + 1]]))
+                           for i in range(len(q)))
+        tok.close()
+        return out
+    whole = reads(None)
+    for n in (2, 5):
+        cat = [r for i in range(n) for r in reads((i, n))]
+        assert cat == whole

@@ -42,7 +42,8 @@ SYMBOLS = (
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
     'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
-    'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_text', 'wk_tok_fetch',
+    'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_text', 'wk_tok_boundary',
+    'wk_tok_fetch',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
@@ -124,6 +125,8 @@ def load_library():
         'wk_tok_set_exclude': (C.c_int, [p, C.c_char_p, i32p, C.c_int32]),
         'wk_tok_sam': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.c_int, C.c_int, i64p, i64p, i64p]),
+        'wk_tok_boundary': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                      C.c_int64, i64p]),
         'wk_tok_text': (C.c_int, [p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                   C.c_int, C.c_int, C.c_int, i64p, i64p,
                                   i64p]),
@@ -526,6 +529,24 @@ class Tokenizer:
         return [raw[o[i]:o[i + 1]].decode() for i in range(n.value)]
 
     FORMATS = {'sam': 0, 'map': 1, 'b6o': 2, 'paf': 3}
+
+    @staticmethod
+    def boundary(buf, pos, fmt='sam', extra=False):
+        """Offset of the first line at or after ``pos`` of ``buf`` (bytes-like,
+        e.g. a memory-mapped file) that starts a new run of equal query ids."""
+        mv = memoryview(buf)
+        n = mv.nbytes
+        if pos <= 0 or n == 0:
+            return 0
+        if pos >= n:
+            return n
+        out = C.c_int64(0)
+        addr = C.c_void_p(np.frombuffer(mv, dtype=np.uint8).ctypes.data)
+        rc = load_library().wk_tok_boundary(Tokenizer.FORMATS[fmt], int(extra),
+                                            addr, n, int(pos), C.byref(out))
+        if rc != OK:
+            raise ValueError('wk_tok_boundary failed')
+        return out.value
 
     def parse(self, buf, first=False, final=False, extra=False,
               want_names=False, want_groups=False, want_samples=False,

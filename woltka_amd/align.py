@@ -278,7 +278,7 @@ NATIVE_FORMATS = ('sam', 'map', 'b6o', 'paf')
 
 def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
                       want_names=False, head=b'', want_groups=False,
-                      want_samples=False, fmt='sam'):
+                      want_samples=False, fmt='sam', part=None):
     """Feed a binary alignment stream (SAM by default; map / b6o / paf via
     ``fmt``) through the native tokenizer (``_native.Tokenizer``) block by
     block.
@@ -295,8 +295,11 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
     mm = _try_mmap(stream)
     if mm is not None:
         yield from _blocks_mmap(mm, len(head), tok, block_bytes, extra,
-                                want_names, want_groups, want_samples, fmt)
+                                want_names, want_groups, want_samples, fmt,
+                                part)
         return
+    if part is not None:
+        raise ValueError('A byte range needs a regular uncompressed file.')
     buf = bytearray(block_bytes + (1 << 16))
     fill = len(head)
     buf[:fill] = head
@@ -357,14 +360,22 @@ def _try_mmap(stream):
 
 
 def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
-                 want_groups=False, want_samples=False, fmt='sam'):
+                 want_groups=False, want_samples=False, fmt='sam', part=None):
     """Tokenise a memory-mapped file in place.  ``start`` bytes were already
     read from the stream for format sniffing; the map covers the whole file,
-    so they are simply parsed again from offset 0."""
+    so they are simply parsed again from offset 0.  ``part`` = (i, n) restricts
+    the work to the i-th of n byte ranges of the file, cut where a new run of
+    equal query ids starts (every process finds the same cuts)."""
     del start
-    size = len(mm)
     view = memoryview(mm)
     pos, first = 0, True
+    size = len(mm)
+    if part is not None:
+        from ._native import Tokenizer
+        i, n = part
+        pos = Tokenizer.boundary(view, size * i // n, fmt, extra)
+        size = Tokenizer.boundary(view, size * (i + 1) // n, fmt, extra)
+        first = pos == 0
     span = block_bytes
     try:
         while pos < size:

@@ -197,7 +197,7 @@ class Engine:
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,
                       want_strings=True, want_samples=False, cover=None,
-                      fmt='sam'):
+                      fmt='sam', part=None):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed, strata ids, name descriptors, sample ids,
         ranges) where packed = (subj, qoff) of subject indices, or for
@@ -218,7 +218,7 @@ class Engine:
                                               head=head,
                                               want_groups=want_groups,
                                               want_samples=want_samples,
-                                              fmt=fmt):
+                                              fmt=fmt, part=part):
                 # the dictionary growth belongs to this block: fetch it before
                 # the tokenizer moves on
                 yield buf, res, tok.new_subjects(), \
@@ -665,16 +665,26 @@ class Engine:
         self.group_ids = {}
         self._epoch += 1
 
-    def finish(self, data):
+    def finish(self, data, exact=False):
         """Final collection; exact rationals become the numbers the reference
         would hold before rounding: ``int`` when integral, else one correctly
-        rounded ``float`` division."""
+        rounded ``float`` division.  ``exact`` leaves the rationals in place
+        (profiles of several processes are then added exactly and converted
+        once, ``exact_to_numbers``)."""
         self.collect(data)
         if self.sizes:
             self._finish_sized(data)
-        for profile in data.values():
-            for sample in profile.values():
-                for key, v in sample.items():
-                    if isinstance(v, Fraction):
-                        sample[key] = v.numerator if v.denominator == 1 \
-                            else v.numerator / v.denominator
+        if exact:
+            return
+        exact_to_numbers(data)
+
+
+def exact_to_numbers(data):
+    """``Fraction`` cells -> ``int`` when integral, else one correctly rounded
+    ``float`` division."""
+    for profile in data.values():
+        for sample in profile.values():
+            for key, v in sample.items():
+                if isinstance(v, Fraction):
+                    sample[key] = v.numerator if v.denominator == 1 \
+                        else v.numerator / v.denominator

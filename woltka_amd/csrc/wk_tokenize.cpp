@@ -495,6 +495,26 @@ int wk_tok_set_exclude(wk_tok* t, const char* blob, const int32_t* off, int32_t 
     return WK_OK;
 }
 
+// Offset of the first line at or after `pos` that starts a new run of equal
+// query ids (a cut there never splits a read): the unit of byte-range sharding
+// of one large file over several processes.  0 stays 0, len stays len.
+int wk_tok_boundary(int fmt, int extra, const char* buf, int64_t len, int64_t pos, int64_t* out) {
+    if (!buf || len < 0 || !out || fmt < WK_FMT_SAM || fmt > WK_FMT_PAF) return WK_E_ARG;
+    if (pos <= 0) {
+        *out = 0;
+        return WK_OK;
+    }
+    if (pos >= len) {
+        *out = len;
+        return WK_OK;
+    }
+    if (fmt == WK_FMT_MAP) extra = 0;
+    const char* e = buf + len;
+    const char* p = next_line(buf + pos - 1, e);  // first line start at or after pos
+    *out = run_boundary(fmt, (extra & 1) != 0, buf, p, e) - buf;
+    return WK_OK;
+}
+
 int wk_tok_sam(wk_tok* t, const char* buf, int64_t len, int first_block, int final_block, int extra, int want_names,
                int64_t* consumed, int64_t* n_reads, int64_t* n_records) {
     return wk_tok_text(t, WK_FMT_SAM, buf, len, first_block, final_block, extra, want_names, consumed, n_reads, n_records);

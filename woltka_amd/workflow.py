@@ -22,13 +22,14 @@ import click
 import numpy as np
 
 from .align import NATIVE_FORMATS, infer_align_format, plain_mapper
-from .classify import Engine
+from .classify import Engine, exact_to_numbers
 from .file import (id2file_from_dir, id2file_from_map, openzip, path2stem,
                    read_ids, read_map_1st, read_map_uniq, readzip, readzip_bytes,
                    stem2rank, write_readmap)
 from .ordinal import load_gene_coords
 from .ranges import Coverage, range_mapper, write_coverage
-from .shard import classify_sharded, env_rank
+from .shard import (FilePart, classify_sharded, env_rank, file_key,
+                    file_path)
 from .table import allkeys, prep_table, write_table
 from .tree import (fill_root, read_columns, read_lineage, read_names,
                    read_newick, read_nodes)
@@ -121,12 +122,13 @@ def workflow(input_fp:     str,
     sizes = parse_sizes(sizes, mapper, zippers)
     ranks, rank2dir = prepare_ranks(ranks, outmap_dir, tree, rankdic)
 
-    def run(share, dev):
+    def run(share, dev, exact=False):
         return classify(
             mapper, share, samples, input_fmt, demux, trimsub, tree, rankdic,
             namedic if name_as_id else None, root, ranks, rank2dir,
             outmap_zip, uniq, major, above, subok, sizes, unassigned, stratmap,
-            exclude, chunk, cache, zippers, outcov_dir, outcov_fmt, device=dev)
+            exclude, chunk, cache, zippers, outcov_dir, outcov_fmt, device=dev,
+            exact=exact)
 
     # one process per GPU under the torch.distributed launcher: alignment
     # files (samples) shard across processes, profiles merge on the host
@@ -137,8 +139,13 @@ def workflow(input_fp:     str,
             dist.init_process_group('gloo')
         from . import _native as nat
         dev = local % max(nat.device_count(), 1)    # narrowed visibility: 0
-        data = classify_sharded(lambda share: run(share, dev), files, rank_,
-                                world)
+        # one large plain file may be cut into byte ranges, unless per-sample
+        # side files (read maps, coverage) are written; cells of a sample
+        # that several processes saw are added as exact rationals
+        data = classify_sharded(lambda share: run(share, dev, exact=True),
+                                files, rank_, world,
+                                split=not (outmap_dir or outcov_dir))
+        exact_to_numbers(data)
         for r in ranks:
             data.setdefault(r, {})
         if rank_ != 0:
@@ -180,7 +187,8 @@ def classify(mapper:  object,
              zippers:   dict = None,
              outcov_dir: str = None,
              outcov_fmt: str = None,
-             device:     int = 0) -> dict:
+             device:     int = 0,
+             exact:     bool = False) -> dict:
     """Core of the classification workflow (workflow.py:162-353) on the GPU.
 
     ``mapper`` is ``align.plain_mapper`` (or any generator with the reference's
@@ -221,13 +229,18 @@ def classify(mapper:  object,
         allow = set(samples) if (demux and samples) else None
         engine._exclude = exclude
         labels = None
-        for fp in sorted(files):
-            if fp == '-':
+        for fp in sorted(files, key=file_key):
+            # (a FilePart is one of several byte ranges of a large file that
+            # other processes share, shard.partition_files)
+            path = file_path(fp)
+            part = (fp.part, fp.parts) if isinstance(fp, FilePart) else None
+            if path == '-':
                 stream = click.get_binary_stream('stdin')
                 click.echo('Parsing alignment from stdin ', nl=False)
             else:
-                stream = readzip_bytes(fp, zippers)
-                click.echo(f'Parsing alignment file {basename(fp)} ', nl=False)
+                stream = readzip_bytes(path, zippers)
+                click.echo(f'Parsing alignment file {basename(path)} ',
+                           nl=False)
             with stream:
                 nqry, nstep = 0, -1
                 fmt_, head = fmt, b''
@@ -237,6 +250,13 @@ def classify(mapper:  object,
                         [head.decode()] if head else []))[0]
                 native = native_ok and fmt_ in NATIVE_FORMATS and not (
                     fmt_ == 'map' and (ordinal or cover is not None))
+                if part is not None and not native:
+                    # byte ranges are a feature of the native tokenizer: the
+                    # first part takes the whole file, the others nothing
+                    if part[0]:
+                        click.echo(' Done.')
+                        continue
+                    part = None
                 want_names = bool((demux and not native_demux) or
                                   rank2dir is not None or
                                   (stratmap and not (native and native_strata)))
@@ -256,7 +276,7 @@ def classify(mapper:  object,
                         stream, head, exclude, NATIVE_BLOCK, ordinal,
                         want_names, trimsub, want_groups=native_strata,
                         want_strings=want_strings, want_samples=native_demux,
-                        cover=cover, fmt=fmt_)
+                        cover=cover, fmt=fmt_, part=part)
                 else:
                     text = io.TextIOWrapper(stream, encoding='utf-8')
                     fh = chain([head.decode()], text) if head else text
@@ -319,7 +339,7 @@ def classify(mapper:  object,
                         nstep += istep
             click.echo(' Done.')
             click.echo(f'  Number of sequences classified: {nqry}.')
-        engine.finish(data)
+        engine.finish(data, exact)
     finally:
         engine.close()
     if cover is not None:
