@@ -596,7 +596,7 @@ def _random_alignment(rng, fmt, subjects, n_queries, prefix='', suffix=''):
     return ''.join(lines)
 
 
-def gen_cli_random(seed=47, n_cases=48):
+def gen_cli_random(seed=47, n_cases=56):
     """`woltka classify` on random small inputs with random option sets:
     every case stores its input files, the keyword arguments and what the
     reference wrote (table text, read maps) or raised."""
@@ -650,9 +650,11 @@ def gen_cli_random(seed=47, n_cases=48):
             kw['map_fps'] = ['$TAX/taxid.map']
             if rng.random() < 0.7:
                 kw['names_fps'] = ['$TAX/names.dmp']
-            kw['ranks'] = rng.choice(['free', 'phylum', 'genus', 'species',
-                                      'phylum,genus,species', 'free,family',
-                                      'none,genus'])
+            kw['ranks'] = rng.choice([
+                'free', 'phylum', 'genus', 'species', 'phylum,genus,species',
+                'free,family', 'none,genus',
+                'phylum,class,order,family,genus,species',     # > 3 rank columns
+                'none,free,kingdom,phylum,class,order,family,genus'])
         elif system == 'lineage':
             kw['lineage_fps'] = ['$TAX/lineages.txt']
             kw['ranks'] = rng.choice(['phylum', 'genus', 'free',

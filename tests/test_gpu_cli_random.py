@@ -1,4 +1,4 @@
-"""`woltka classify` on random small inputs with random option sets: 48 cases
+"""`woltka classify` on random small inputs with random option sets: 56 cases
 made by tests/golden/make_golden.gen_cli_random — input files, keyword
 arguments of workflow.workflow (= the CLI options) and what the reference
 wrote (table text per rank, decompressed read maps) or raised.  The GPU path
@@ -18,7 +18,9 @@ from helpers import DATA, load_vectors
 
 pytestmark = pytest.mark.gpu
 
-CASES = load_vectors('cli_random.json') + load_vectors('cli_coords.json')
+_BIG = 'big_' if os.environ.get('WOLTKA_BIG_SWEEP') else ''    # one-off sweeps
+CASES = load_vectors(_BIG + 'cli_random.json') + \
+    load_vectors(_BIG + 'cli_coords.json')
 TAX = join(DATA, 'taxonomy')
 FUN = join(DATA, 'function')
 
@@ -83,7 +85,7 @@ def test_random_cli_case(tmp_path, i):
         assert maps == expect['maps']
 
 
-STRATA = load_vectors('cli_strata.json')
+STRATA = load_vectors(_BIG + 'cli_strata.json')
 
 
 @pytest.mark.parametrize('i', range(len(STRATA)))

@@ -59,12 +59,16 @@ def write_tsv(table, fh):
     """Tab-delimited table: ``#FeatureID``, samples, optional metadata."""
     data, features, samples, metadata = table
     metacols = list(metadata[0]) if metadata else []
-    header = ['#FeatureID'] + list(samples) + metacols
+    # (the sample block is one joined field, table.py:274-283: a table without
+    # samples still carries its tab)
+    header = ['#FeatureID', '\t'.join(samples)]
+    if metacols:
+        header.append('\t'.join(metacols))
     print(*header, sep='\t', file=fh)
     for i, feature in enumerate(features):
-        row = [feature] + [str(v) for v in data[i]]
+        row = [feature, '\t'.join(map(str, data[i]))]
         if metacols:
-            row += list(metadata[i].values())
+            row.append('\t'.join(metadata[i].values()))
         print(*row, sep='\t', file=fh)
 
 
