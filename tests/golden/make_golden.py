@@ -576,8 +576,10 @@ def _random_alignment(rng, fmt, subjects, n_queries, prefix='', suffix=''):
             pos = rng.randrange(1, 1_500_000)
             ln = rng.choice([50, 100, 150, 150, 151])
             if fmt == 'sam':
-                flag = rng.choice([99, 147, 355, 403]) if paired \
+                flag = rng.choice([99, 147, 355, 403, 65, 129]) if paired \
                     else rng.choice([0, 16, 256])
+                if rng.random() < 0.04:     # an unmapped record inside the run
+                    lines.append(f'{q}\t{flag | 4}\t*\t0\t0\t*\t*\t0\t0\t*\t*\n')
                 lines.append(f'{q}\t{flag}\t{s}\t{pos}\t255\t{ln}M\t=\t0\t0'
                              f'\t*\t*\n')
             elif fmt == 'b6o':
@@ -592,8 +594,23 @@ def _random_alignment(rng, fmt, subjects, n_queries, prefix='', suffix=''):
                              f'5000000\t{pos - 1}\t{pos - 1 + ln}\t{ln}\t{ln}'
                              f'\t{rng.randrange(61)}\ttp:A:P\n')
             else:
-                lines.append(f'{q}\t{s}\n')
+                lines.append(f'{q}\t{s}\n' if rng.random() < 0.9
+                             else f'{q}\t{s}\textra column\n')
+        if fmt == 'b6o' and rng.random() < 0.03:
+            lines.append('# BLAST-style comment line\n')
     return ''.join(lines)
+
+
+def _write_case_file(path, text):
+    """Write a fixture's input file; the extension picks the compression."""
+    import bz2
+    import gzip
+    import lzma
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    opener = {'.gz': gzip.open, '.bz2': bz2.open, '.xz': lzma.open}.get(
+        os.path.splitext(path)[1], open)
+    with opener(path, 'wt') as f:
+        f.write(text)
 
 
 def gen_cli_random(seed=47, n_cases=56):
@@ -614,19 +631,22 @@ def gen_cli_random(seed=47, n_cases=56):
         layout = rng.choice(['file', 'dir', 'dir', 'mux'])
         subjects = rng.sample(genomes, rng.randint(6, 40))
         kw, files = {'output_fmt': False}, {}     # False = --to-tsv
+        zext = rng.choice(['', '', '', '.gz', '.bz2', '.xz'])
         trim = rng.random() < 0.15
         suffix = '_1' if trim else ''
         if trim:
             kw['trimsub'] = '_'
         if layout == 'file':
-            files[f'aln/S1.{ext[fmt]}'] = _random_alignment(
+            files[f'aln/S1.{ext[fmt]}{zext}'] = _random_alignment(
                 rng, fmt, subjects, rng.randint(20, 80), suffix=suffix)
-            kw['input_fp'] = f'aln/S1.{ext[fmt]}'
+            kw['input_fp'] = f'aln/S1.{ext[fmt]}{zext}'
         elif layout == 'dir':
             for i in range(rng.randint(2, 4)):
-                files[f'aln/S{i + 1}.{ext[fmt]}'] = _random_alignment(
+                files[f'aln/S{i + 1}.{ext[fmt]}{zext}'] = _random_alignment(
                     rng, fmt, subjects, rng.randint(10, 60), suffix=suffix)
             kw['input_fp'] = 'aln'
+            if rng.random() < 0.3:      # explicit sample order / subset
+                kw['samples'] = rng.choice(['S2,S1', 'S1', 'S2,S1,S9'])
         else:
             parts = []
             for smp in rng.sample(['A', 'B', 'C', 'D'], rng.randint(2, 4)):
@@ -644,7 +664,7 @@ def gen_cli_random(seed=47, n_cases=56):
             kw['input_fmt'] = fmt
         # classification system
         system = rng.choice(['ogu', 'nodes', 'nodes', 'lineage', 'columns',
-                             'map'])
+                             'map', 'newick'])
         if system == 'nodes':
             kw['nodes_fps'] = ['$TAX/nodes.dmp']
             kw['map_fps'] = ['$TAX/taxid.map']
@@ -654,7 +674,7 @@ def gen_cli_random(seed=47, n_cases=56):
                 'free', 'phylum', 'genus', 'species', 'phylum,genus,species',
                 'free,family', 'none,genus',
                 'phylum,class,order,family,genus,species',     # > 3 rank columns
-                'none,free,kingdom,phylum,class,order,family,genus'])
+                'none,free,superkingdom,phylum,class,order,family,genus'])
         elif system == 'lineage':
             kw['lineage_fps'] = ['$TAX/lineages.txt']
             kw['ranks'] = rng.choice(['phylum', 'genus', 'free',
@@ -666,6 +686,9 @@ def gen_cli_random(seed=47, n_cases=56):
         elif system == 'map':
             kw['map_fps'] = ['$TAX/taxid.map']
             kw['map_rank'] = True
+        elif system == 'newick':
+            kw['newick_fps'] = ['$TAX/../tree.nwk']
+            kw['ranks'] = 'free'
         if system != 'ogu':
             r = rng.random()
             if r < 0.2:
@@ -695,14 +718,14 @@ def gen_cli_random(seed=47, n_cases=56):
             kw['sizes'] = '$TAX/length.map'
             kw['scale'] = '1M'
         want_maps = system != 'ogu' and rng.random() < 0.3
+        want_cov = fmt != 'map' and rng.random() < 0.15
+        if want_cov:
+            kw['outcov_fmt'] = rng.choice([None, 'bed', 'gff', '1e'])
         if rng.random() < 0.2:
             kw['chunk'] = rng.choice([7, 50])
         with tempfile.TemporaryDirectory() as tmp:
             for rel, text in files.items():
-                os.makedirs(os.path.dirname(os.path.join(tmp, rel)) or tmp,
-                            exist_ok=True)
-                with open(os.path.join(tmp, rel), 'w') as f:
-                    f.write(text)
+                _write_case_file(os.path.join(tmp, rel), text)
 
             def real(v):
                 if isinstance(v, list):
@@ -716,6 +739,8 @@ def gen_cli_random(seed=47, n_cases=56):
             args['output_fp'] = os.path.join(tmp, 'out')
             if want_maps:
                 args['outmap_dir'] = os.path.join(tmp, 'maps')
+            if want_cov:
+                args['outcov_dir'] = os.path.join(tmp, 'cov')
             multi = ',' in kw.get('ranks', '')
             expect = {}
             try:
@@ -744,10 +769,14 @@ def gen_cli_random(seed=47, n_cases=56):
                             with gzip.open(os.path.join(root, fn), 'rt') as f:
                                 maps[rel] = f.read()
                     expect['maps'] = maps
-        if 'error' in expect and sum('error' in c['expect'] for c in cases) >= 4:
+                if want_cov:
+                    expect['cov'] = {
+                        fn: open(os.path.join(args['outcov_dir'], fn)).read()
+                        for fn in sorted(os.listdir(args['outcov_dir']))}
+        if 'error' in expect and sum('error' in c['expect'] for c in cases) >= 6:
             continue            # enough failing combinations already
         cases.append(dict(files=files, kwargs=kw, want_maps=want_maps,
-                          expect=expect))
+                          want_cov=want_cov, expect=expect))
     dump('cli_random.json', cases)
 
 

@@ -25,6 +25,17 @@ TAX = join(DATA, 'taxonomy')
 FUN = join(DATA, 'function')
 
 
+def write_case_file(path, text):
+    """A fixture's input file; the extension picks the compression."""
+    import bz2
+    import lzma
+    path.parent.mkdir(parents=True, exist_ok=True)
+    opener = {'.gz': gzip.open, '.bz2': bz2.open, '.xz': lzma.open}.get(
+        path.suffix, open)
+    with opener(path, 'wt') as f:
+        f.write(text)
+
+
 def _label(i):
     kw = CASES[i]['kwargs']
     bits = [os.path.splitext(kw['input_fp'])[1].lstrip('.') or 'dir',
@@ -40,9 +51,7 @@ def test_random_cli_case(tmp_path, i):
     from woltka_amd.workflow import workflow
     case = CASES[i]
     for rel, text in case['files'].items():
-        fp = tmp_path / rel
-        fp.parent.mkdir(parents=True, exist_ok=True)
-        fp.write_text(text)
+        write_case_file(tmp_path / rel, text)
 
     def real(v):
         if isinstance(v, list):
@@ -58,7 +67,9 @@ def test_random_cli_case(tmp_path, i):
     args['output_fp'] = str(tmp_path / 'out')
     if case['want_maps']:
         args['outmap_dir'] = str(tmp_path / 'maps')
-    args['no_exe'] = True
+    if case.get('want_cov'):
+        args['outcov_dir'] = str(tmp_path / 'cov')
+    args['no_exe'] = i % 2 == 0     # built-in codecs / external decompressors
     expect = case['expect']
     if 'error' in expect:
         with pytest.raises(Exception) as err, \
@@ -83,6 +94,10 @@ def test_random_cli_case(tmp_path, i):
                 with gzip.open(join(root, fn), 'rt') as f:
                     maps[rel] = f.read()
         assert maps == expect['maps']
+    if case.get('want_cov'):
+        got_cov = {fn: open(join(args['outcov_dir'], fn)).read()
+                   for fn in sorted(os.listdir(args['outcov_dir']))}
+        assert got_cov == expect['cov']
 
 
 STRATA = load_vectors(_BIG + 'cli_strata.json')
@@ -95,9 +110,7 @@ def test_random_two_pass_stratified(tmp_path, i):
     from woltka_amd.workflow import workflow
     case = STRATA[i]
     for rel, text in case['files'].items():
-        fp = tmp_path / rel
-        fp.parent.mkdir(parents=True, exist_ok=True)
-        fp.write_text(text)
+        write_case_file(tmp_path / rel, text)
 
     def real(v):
         if isinstance(v, list):
