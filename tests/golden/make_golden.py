@@ -885,6 +885,61 @@ def gen_cli_coords(seed=53, n_cases=18):
     dump('cli_coords.json', cases)
 
 
+MEDIUM = [
+    # (name, seed, format, queries, keyword arguments)
+    ('sam_3ranks', 71, 'sam', 450_000,
+     dict(nodes_fps=['$TAX/nodes.dmp'], map_fps=['$TAX/taxid.map'],
+          names_fps=['$TAX/names.dmp'], ranks='phylum,genus,species')),
+    ('sam_free_major', 73, 'sam', 360_000,
+     dict(nodes_fps=['$TAX/nodes.dmp'], map_fps=['$TAX/taxid.map'],
+          ranks='free,family', major=70, unassigned=True)),
+    ('b6o_ogu_frac', 79, 'b6o', 450_000, dict(frac=True, digits=6)),
+    ('map_lineage', 83, 'map', 600_000,
+     dict(lineage_fps=['$TAX/lineages.txt'], ranks='class,genus', above=True)),
+]
+
+
+def medium_input(seed, fmt, n_queries, genomes):
+    """The alignment text of a MEDIUM case (regenerated by the test from the
+    same seed: only the expected tables are committed)."""
+    rng = random.Random(seed)
+    return _random_alignment(rng, fmt, rng.sample(genomes, 60), n_queries)
+
+
+def gen_cli_medium():
+    """A few runs three orders of magnitude larger than the random cases
+    (multi-block tokenising, many device chunks, cache overflow paths) against
+    the reference's tables."""
+    import contextlib
+    import io
+    import tempfile
+    from woltka.workflow import workflow
+    tax = os.path.join(DATA, 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        genomes = [x.split('\t')[0] for x in f]
+    out = {}
+    for name, seed, fmt, nq, kw in MEDIUM:
+        text = medium_input(seed, fmt, nq, genomes)
+        with tempfile.TemporaryDirectory() as tmp:
+            fp = os.path.join(tmp, f'S1.{fmt}')
+            with open(fp, 'w') as f:
+                f.write(text)
+            args = {k: ([os.path.join(tax, x[5:]) for x in v]
+                        if isinstance(v, list) else v) for k, v in kw.items()}
+            args.update(input_fp=fp, input_fmt=fmt, output_fmt=False,
+                        output_fp=os.path.join(tmp, 'out'))
+            with contextlib.redirect_stdout(io.StringIO()):
+                workflow(**args)
+            if ',' in kw.get('ranks', ''):
+                tables = {fn: open(os.path.join(args['output_fp'], fn)).read()
+                          for fn in sorted(os.listdir(args['output_fp']))}
+            else:
+                tables = {'out': open(args['output_fp']).read()}
+        out[name] = dict(records=text.count('\n'), tables=tables)
+        print(name, out[name]['records'], 'records')
+    dump('cli_medium.json', out)
+
+
 def gen_cli_strata(seed=59, n_cases=8):
     """Two-pass stratified runs (README "combined taxonomic & functional"):
     pass 1 writes read maps at a rank, pass 2 classifies stratified by them."""
@@ -978,6 +1033,7 @@ def main():
     gen_cli_random()
     gen_cli_coords()
     gen_cli_strata()
+    gen_cli_medium()
 
 
 if __name__ == '__main__':

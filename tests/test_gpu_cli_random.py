@@ -131,3 +131,40 @@ def test_random_two_pass_stratified(tmp_path, i):
         workflow(**a2)
     assert (tmp_path / 'out1').read_text() == case['expect']['table1']
     assert (tmp_path / 'out2').read_text() == case['expect']['table2']
+
+
+def _medium():
+    import sys
+    sys.path.insert(0, join(os.path.dirname(__file__), 'golden'))
+    import make_golden
+    return make_golden
+
+
+@pytest.mark.parametrize('case', range(4))
+def test_medium_size_runs(tmp_path, case):
+    """Runs of 1-1.5 M records (multi-block tokenising on all threads, cache
+    overflow and miss-log paths on the device) against the reference's tables;
+    the input text is regenerated from the case's seed by the same generator
+    that fed the reference (tests/golden/make_golden.medium_input)."""
+    from woltka_amd.workflow import workflow
+    mg = _medium()
+    name, seed, fmt, nq, kw = mg.MEDIUM[case]
+    gold = load_vectors('cli_medium.json')[name]
+    with open(join(TAX, 'taxid.map')) as f:
+        genomes = [x.split('\t')[0] for x in f]
+    text = mg.medium_input(seed, fmt, nq, genomes)
+    assert text.count('\n') == gold['records']
+    fp = tmp_path / f'S1.{fmt}'
+    fp.write_text(text)
+    args = {k: ([join(TAX, x[5:]) for x in v] if isinstance(v, list) else v)
+            for k, v in kw.items()}
+    args.update(input_fp=str(fp), input_fmt=fmt, output_fmt=False,
+                output_fp=str(tmp_path / 'out'))
+    with contextlib.redirect_stdout(io.StringIO()):
+        workflow(**args)
+    if len(gold['tables']) == 1 and 'out' in gold['tables']:
+        got = {'out': (tmp_path / 'out').read_text()}
+    else:
+        got = {fn: (tmp_path / 'out' / fn).read_text()
+               for fn in sorted(os.listdir(tmp_path / 'out'))}
+    assert got == gold['tables']
