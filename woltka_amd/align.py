@@ -35,24 +35,30 @@ import numpy as np
 
 def infer_align_format(fh):
     """Guess the format from the first line; returns (format, [lines read])."""
-    try:
-        line = next(fh)
-    except StopIteration:
+    line = next(fh, None)
+    if line is None:
         raise ValueError('Alignment file is empty or unreadable.')
-    if line.split()[0] in ('@HD', '@PG'):
-        return 'sam', [line]
-    row = line.rstrip().split('\t')
-    if len(row) == 2:
-        return 'map', [line]
-    if len(row) >= 12:
-        if all(row[i].isdigit() for i in range(3, 10)):
-            return 'b6o', [line]
-        if row[4] in '+-' and all(row[i].isdigit()
-                                  for i in (1, 2, 3, 6, 7, 8, 9, 10, 11)):
-            return 'paf', [line]
-    if len(row) >= 11 and all(row[i].isdigit() for i in (1, 3, 4)):
-        return 'sam', [line]
-    raise ValueError('Cannot determine alignment file format.')
+
+    def numeric(cols, which):
+        return all(cols[i].isdigit() for i in which)
+    fmt = None
+    if line.split()[0] in ('@HD', '@PG'):       # a SAM header
+        fmt = 'sam'
+    else:
+        cols = line.rstrip().split('\t')
+        n = len(cols)
+        if n == 2:
+            fmt = 'map'
+        elif n >= 12 and numeric(cols, range(3, 10)):
+            fmt = 'b6o'
+        elif n >= 12 and cols[4] in '+-' and numeric(
+                cols, (1, 2, 3, 6, 7, 8, 9, 10, 11)):
+            fmt = 'paf'
+        elif n >= 11 and numeric(cols, (1, 3, 4)):      # header-less SAM
+            fmt = 'sam'
+    if fmt is None:
+        raise ValueError('Cannot determine alignment file format.')
+    return fmt, [line]
 
 
 # --------------------------------------------------------------------------

@@ -61,15 +61,15 @@ def write_tsv(table, fh):
     metacols = list(metadata[0]) if metadata else []
     # (the sample block is one joined field, table.py:274-283: a table without
     # samples still carries its tab)
-    header = ['#FeatureID', '\t'.join(samples)]
-    if metacols:
-        header.append('\t'.join(metacols))
-    print(*header, sep='\t', file=fh)
-    for i, feature in enumerate(features):
-        row = [feature, '\t'.join(map(str, data[i]))]
+    def line(first, block, extra):
+        fields = [first, '\t'.join(block)]
         if metacols:
-            row.append('\t'.join(metadata[i].values()))
-        print(*row, sep='\t', file=fh)
+            fields.append('\t'.join(extra))
+        fh.write('\t'.join(fields) + '\n')
+    line('#FeatureID', samples, metacols)
+    for feature, counts, meta in zip(features, data, metadata or
+                                     [None] * len(features)):
+        line(feature, map(str, counts), meta.values() if metacols else ())
 
 
 def table_to_biom(data, observations, samples, metadata=None):

@@ -59,55 +59,22 @@ def _update(dic, other):
             dic[key] = value
 
 
-def workflow(input_fp:     str,
-             output_fp:    str,
-             # input
-             input_fmt:    str = None,
-             input_ext:    str = None,
-             samples:      str = None,
-             demux:       bool = None,
-             exclude:      set = None,
-             trimsub:      str = None,
-             # hierarchies
-             nodes_fps:   list = [],
-             newick_fps:  list = [],
-             lineage_fps: list = [],
-             columns_fps: list = [],
-             map_fps:     list = [],
-             map_rank:    bool = False,
-             names_fps:   list = [],
-             # assignment
-             ranks:        str = None,
-             uniq:        bool = False,
-             major:       bool = None,
-             above:       bool = False,
-             subok:       bool = False,
-             # gene matching
-             coords_fp:    str = None,
-             overlap:      int = 80,
-             # stratification
-             strata_dir:   str = None,
-             # normalization
-             sizes:        str = None,
-             frac:        bool = False,
-             scale:        str = None,
-             digits:       int = None,
-             # output
-             output_fmt:   str = None,
-             unassigned:  bool = False,
-             name_as_id:  bool = False,
-             add_rank:    bool = False,
-             add_lineage: bool = False,
-             outmap_dir:   str = None,
-             outmap_zip:   str = 'gz',
-             outcov_dir:   str = None,
-             outcov_fmt:   str = None,
-             # performance
-             chunk:        int = None,
-             cache:        int = 1024,
-             no_exe:      bool = False,
-             # device
-             device:       int = 0) -> dict:
+def workflow(
+        input_fp: str, output_fp: str, input_fmt: str = None,
+        input_ext: str = None, samples: str = None, demux: bool = None,
+        exclude: set = None, trimsub: str = None, nodes_fps: list = [],
+        newick_fps: list = [], lineage_fps: list = [], columns_fps: list = [],
+        map_fps: list = [], map_rank: bool = False, names_fps: list = [],
+        ranks: str = None, uniq: bool = False, major: bool = None,
+        above: bool = False, subok: bool = False, coords_fp: str = None,
+        overlap: int = 80, strata_dir: str = None, sizes: str = None,
+        frac: bool = False, scale: str = None, digits: int = None,
+        output_fmt: str = None, unassigned: bool = False,
+        name_as_id: bool = False, add_rank: bool = False,
+        add_lineage: bool = False, outmap_dir: str = None,
+        outmap_zip: str = 'gz', outcov_dir: str = None,
+        outcov_fmt: str = None, chunk: int = None, cache: int = 1024,
+        no_exe: bool = False, device: int = 0) -> dict:
     """Main classification workflow (command-line arguments in, profile out);
     same steps in the same order as the reference (workflow.py:109-159)."""
     zippers = None if no_exe else {}
@@ -161,34 +128,17 @@ def workflow(input_fp:     str,
     return data
 
 
-def classify(mapper:  object,
-             files:     list or dict,
-             samples:   list = None,
-             fmt:        str = None,
-             demux:     bool = None,
-             trimsub:    str = None,
-             tree:      dict = None,
-             rankdic:   dict = None,
-             namedic:   dict = None,
-             root:       str = None,
-             ranks:      str = None,
-             rank2dir:  dict = None,
-             outzip:     str = None,
-             uniq:      bool = False,
-             major:      int = None,
-             above:     bool = False,
-             subok:     bool = False,
-             sizes:     dict = None,
-             unasgd:    bool = False,
-             stratmap:  dict = None,
-             exclude:    set = None,
-             chunk:      int = None,
-             cache:      int = 1024,
-             zippers:   dict = None,
-             outcov_dir: str = None,
-             outcov_fmt: str = None,
-             device:     int = 0,
-             exact:     bool = False) -> dict:
+def classify(
+        mapper: object, files: list or dict, samples: list = None,
+        fmt: str = None, demux: bool = None, trimsub: str = None,
+        tree: dict = None, rankdic: dict = None, namedic: dict = None,
+        root: str = None, ranks: str = None, rank2dir: dict = None,
+        outzip: str = None, uniq: bool = False, major: int = None,
+        above: bool = False, subok: bool = False, sizes: dict = None,
+        unasgd: bool = False, stratmap: dict = None, exclude: set = None,
+        chunk: int = None, cache: int = 1024, zippers: dict = None,
+        outcov_dir: str = None, outcov_fmt: str = None, device: int = 0,
+        exact: bool = False) -> dict:
     """Core of the classification workflow (workflow.py:162-353) on the GPU.
 
     ``mapper`` is ``align.plain_mapper`` (or any generator with the reference's
@@ -396,93 +346,97 @@ def strata_labels(sample_of, reads, stratmap, zippers, csample, strata):
     return out, csample, strata
 
 
+INCONSISTENT = 'Provided sample IDs and actual files are inconsistent.'
+
+
+def _id_list(arg):
+    """Ids given as a comma-separated string or as the first column of a
+    (possibly compressed) list file."""
+    if not isfile(arg):
+        return arg.split(',')
+    with openzip(arg) as fh:
+        return read_ids(fh)
+
+
 def parse_samples(fp, ext=None, samples=None, demux=None):
     """Sample ids, alignment files and demultiplexing switch
-    (workflow.py:356-480)."""
+    (workflow.py:356-480).  Four kinds of input — stdin, a directory, a
+    sample-to-file table, one alignment file — each decide what the default of
+    ``demux`` means and whether ``files`` is a list (to demultiplex) or a
+    {path: sample} dict."""
+    wanted = None
     if samples:
-        if isfile(samples):
-            with openzip(samples) as fh:
-                samples = read_ids(fh)
-        else:
-            samples = samples.split(',')
-        click.echo(f'Number of samples to include: {len(samples)}.')
-    errmsg = 'Provided sample IDs and actual files are inconsistent.'
+        wanted = _id_list(samples)
+        click.echo(f'Number of samples to include: {len(wanted)}.')
+
+    def single(path, sample, note):
+        # one stream: demultiplex unless told not to (--no-demux)
+        on = demux is not False
+        if not on and wanted and wanted != [sample] and path != '-':
+            raise ValueError(INCONSISTENT)
+        click.echo(note)
+        if on:
+            return wanted, [path], True
+        return [sample], {path: sample}, False
+
     if fp == '-':
-        demux = demux is not False
-        if demux:
-            files = [fp]
-        else:
-            files = {fp: ''}
-            samples = ['']
-        click.echo('Input alignment is from stdin.')
+        res = single(fp, '', 'Input alignment is from stdin.')
     elif isdir(fp):
-        demux = demux or False
-        map_ = id2file_from_dir(fp, ext, not demux and samples)
-        if len(map_) == 0:
+        on = bool(demux)
+        found = id2file_from_dir(fp, ext, not on and wanted)
+        if not found:
             raise ValueError('No valid file found in directory.')
-        if demux:
-            files = sorted([join(fp, x) for x in map_.values()])
+        if on:
+            files = sorted(join(fp, name) for name in found.values())
         else:
-            if not samples:
-                samples = sorted(map_.keys())
-            elif len(map_) < len(samples):
-                raise ValueError(errmsg)
-            files = {join(fp, map_[x]): x for x in samples}
+            if not wanted:
+                wanted = sorted(found)
+            elif len(found) < len(wanted):
+                raise ValueError(INCONSISTENT)
+            files = {join(fp, found[x]): x for x in wanted}
         click.echo(f'Input directory: {fp}.')
         click.echo(f'Number of alignment files to read: {len(files)}.')
+        res = wanted, files, on
     elif isfile(fp):
-        map_ = id2file_from_map(fp)
-        if map_:
-            demux = demux or False
-            if samples:
-                map_ = dict(map_)
-                try:
-                    files = {map_[x]: x for x in samples}
-                except KeyError:
-                    raise ValueError(errmsg)
+        table = id2file_from_map(fp)
+        if table:
+            if wanted:
+                lookup = dict(table)
+                if any(x not in lookup for x in wanted):
+                    raise ValueError(INCONSISTENT)
+                files = {lookup[x]: x for x in wanted}
             else:
-                samples = [x[0] for x in map_]
-                files = {x[1]: x[0] for x in map_}
+                wanted = [sample for sample, _ in table]
+                files = {path: sample for sample, path in table}
             click.echo(f'Number of alignment files to read: {len(files)}.')
+            res = wanted, files, bool(demux)
         else:
-            demux = demux is not False
-            if demux:
-                files = [fp]
-            else:
-                sample = path2stem(fp, ext)
-                if samples and samples != [sample]:
-                    raise ValueError(errmsg)
-                files = {fp: sample}
-                samples = [sample]
-            click.echo(f'Input alignment file: {fp}.')
+            res = single(fp, path2stem(fp, ext), f'Input alignment file: {fp}.')
     else:
         raise ValueError(f'"{fp}" is not a valid file or directory.')
-    click.echo(f'Demultiplexing: {"on" if demux else "off"}.')
-    return samples, files, demux
+    click.echo(f'Demultiplexing: {"on" if res[2] else "off"}.')
+    return res
 
 
 def parse_exclude(exclude=None):
     """Subjects to exclude: comma list or id file (workflow.py:483-503)."""
-    if exclude:
-        if isfile(exclude):
-            with openzip(exclude) as fh:
-                exclude = read_ids(fh)
-        else:
-            exclude = exclude.split(',')
-        click.echo(f'Number of subjects to exclude: {len(exclude)}.')
-        return set(exclude)
+    if not exclude:
+        return None
+    ids = _id_list(exclude)
+    click.echo(f'Number of subjects to exclude: {len(ids)}.')
+    return set(ids)
 
 
 def parse_strata(fp=None, samples=None):
     """{sample: stratification file} (workflow.py:506-533)."""
     if not fp:
-        return
+        return None
     click.echo(f'Stratification file directory: {fp}.')
-    map_ = id2file_from_dir(fp, ids=samples)
-    if len(samples or []) > len(map_):
+    found = id2file_from_dir(fp, ids=samples)
+    if samples and len(samples) > len(found):
         raise ValueError(
             'Cannot locate stratification files for one or more samples.')
-    return {k: join(fp, v) for k, v in map_.items()}
+    return {sample: join(fp, name) for sample, name in found.items()}
 
 
 def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
@@ -504,47 +458,46 @@ def parse_sizes(sizes, mapper, zippers=None):
     """Feature sizes for ``--sizes`` as reciprocals (workflow.py:588-633):
     a two-column map file, or "." = gene lengths from the coordinates."""
     if not sizes:
-        return
-    if sizes == '.':
-        click.echo('Calculating gene lengths from coordinates...', nl=False)
+        return None
+    from_coords = sizes == '.'
+    click.echo('Calculating gene lengths from coordinates...' if from_coords
+               else f'Reading subject sizes file: {basename(sizes)}...',
+               nl=False)
+    if from_coords:
         if not isinstance(mapper, OrdinalMapper):
             raise ValueError('Gene coordinates file is not provided.')
-        sizemap = mapper.table.gene_lengths(mapper.prefix)
-        click.echo(' Done.')
+        lengths = mapper.table.gene_lengths(mapper.prefix).items()
     else:
-        click.echo(f'Reading subject sizes file: {basename(sizes)}...',
-                   nl=False)
-        with readzip(sizes, zippers) as f:
-            sizemap = {k: float(v) for k, v in read_map_1st(f)}
-        click.echo(' Done.')
-    return {k: 1 / v for k, v in sizemap.items()}
+        with readzip(sizes, zippers) as fh:
+            lengths = [(k, float(v)) for k, v in read_map_1st(fh)]
+    click.echo(' Done.')
+    return {name: 1 / size for name, size in lengths}
 
 
 def prepare_ranks(ranks=None, outmap_dir=None, tree=None, rankdic=None):
-    """Rank list and read-map directories (workflow.py:636-695)."""
-    if ranks:
-        ranks = ranks.split(',')
-        if rankdic is not None:
-            missing = set(ranks) - {'free', 'none'} - set(rankdic.values())
-            if missing:
-                raise ValueError(f'Ranks {", ".join(sorted(missing))} are not'
-                                 ' found in classification system.')
-    else:
-        ranks = ['free' if tree else 'none']
-    click.echo('Classification will operate on these ranks: {}.'.format(
-        ', '.join(ranks)))
+    """Rank list and read-map directories (workflow.py:636-695): the ranks
+    must exist in the classification system ("none" / "free" always do); no
+    rank given means free-rank classification if there is a hierarchy, plain
+    subject counting otherwise.  Several ranks get one map directory each."""
+    chosen = ranks.split(',') if ranks else ['free' if tree else 'none']
+    if ranks and rankdic is not None:
+        known = set(rankdic.values()) | {'none', 'free'}
+        unknown = sorted(set(chosen) - known)
+        if unknown:
+            raise ValueError(f'Ranks {", ".join(unknown)} are not found in '
+                             'classification system.')
+    click.echo(f'Classification will operate on these ranks: '
+               f'{", ".join(chosen)}.')
     if not outmap_dir:
-        return ranks, None
+        return chosen, None
     makedirs(outmap_dir, exist_ok=True)
     click.echo(f'Read-to-feature maps will be saved to: {outmap_dir}.')
-    if len(ranks) == 1:
-        return ranks, {ranks[0]: outmap_dir}
-    rank2dir = {}
-    for rank in ranks:
-        dir_ = join(outmap_dir, rank)
-        makedirs(dir_, exist_ok=True)
-        rank2dir[rank] = dir_
-    return ranks, rank2dir
+    if len(chosen) == 1:
+        return chosen, {chosen[0]: outmap_dir}
+    dirs = {rank: join(outmap_dir, rank) for rank in chosen}
+    for path in dirs.values():
+        makedirs(path, exist_ok=True)
+    return chosen, dirs
 
 
 def build_hierarchy(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
@@ -600,12 +553,12 @@ def build_hierarchy(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
 
 def read_strata(strata_fp, zippers=None):
     """{query: stratum} of one sample (workflow.py:912-938)."""
-    with readzip(strata_fp, zippers) as fhs:
-        strata = dict(read_map_uniq(fhs))
-    if not strata:
-        raise ValueError('No stratification information is found in file: '
-                         f'{basename(strata_fp)}.')
-    return strata
+    with readzip(strata_fp, zippers) as fh:
+        pairs = dict(read_map_uniq(fh))
+    if pairs:
+        return pairs
+    raise ValueError('No stratification information is found in file: '
+                     f'{basename(strata_fp)}.')
 
 
 def scale_factor(s):
@@ -628,15 +581,13 @@ def scale_factor(s):
 
 def frac_profiles(data, frac=False):
     """Divide by the per-sample total (workflow.py:1061-1084)."""
-    if not frac:
-        return
-    for profile in data.values():
-        for sample in profile.values():
-            total = sum(sample.values())
-            if not total:
-                continue
-            for feature in sample:
-                sample[feature] /= total
+    if frac:
+        for profile in data.values():
+            for cells in profile.values():
+                total = sum(cells.values())
+                if total:
+                    for feature, value in cells.items():
+                        cells[feature] = value / total
 
 
 def scale_profiles(data, scale=None):
@@ -677,30 +628,31 @@ def round_profiles(data, digits=None):
 def write_profiles(data, fp, is_biom=None, samples=None, tree=None,
                    rankdic=None, namedic=None, name_as_id=False,
                    add_rank=False, add_lineage=False):
-    """Write one table per rank (workflow.py:1122-1205)."""
+    """Write one table per rank (workflow.py:1122-1205).  One rank: ``fp`` is
+    the file and its extension picks the format unless --to-biom / --to-tsv
+    said so; several ranks: ``fp`` is a directory of ``<rank>.biom`` (default)
+    or ``<rank>.tsv`` files."""
     if not fp:
         return
-    if not samples:
-        samples = sorted(allkeys(data))
-    ranks = sorted(data.keys())
-    if len(ranks) == 1:
-        rank2fp = {ranks[0]: fp}
-        if is_biom is None:
-            is_biom = fp.endswith('.biom')
-    else:
+    ranks = sorted(data)
+    if len(ranks) > 1:
         makedirs(fp, exist_ok=True)
-        is_biom = is_biom is not False
-        ext = 'biom' if is_biom else 'tsv'
-        rank2fp = {x: join(fp, f'{x}.{ext}') for x in ranks}
-    fmt = 'BIOM' if is_biom else 'TSV'
-    click.echo(f'Format of output feature table(s): {fmt}.')
-    if namedic is None:
-        name_as_id = False
-    click.echo(f'Writing output profiles in {fmt} format...')
-    for rank, fp_ in rank2fp.items():
-        table = prep_table(data[rank], samples, tree if add_lineage else None,
-                           rankdic if add_rank else None, namedic, name_as_id)
-        write_table(table, fp_, is_biom)
+        biom = is_biom is not False
+        targets = [(r, join(fp, f"{r}.{'biom' if biom else 'tsv'}"))
+                   for r in ranks]
+    else:
+        biom = fp.endswith('.biom') if is_biom is None else is_biom
+        targets = [(ranks[0], fp)]
+    label = 'BIOM' if biom else 'TSV'
+    click.echo(f'Format of output feature table(s): {label}.')
+    click.echo(f'Writing output profiles in {label} format...')
+    columns = samples or sorted(allkeys(data))
+    for rank, path in targets:
+        table = prep_table(data[rank], columns,
+                           tree if add_lineage else None,
+                           rankdic if add_rank else None, namedic,
+                           name_as_id and namedic is not None)
+        write_table(table, path, biom)
         click.echo(f'  Rank: {rank}, samples: {len(table[2])}, features: '
                    f'{len(table[1])}.')
     click.echo('Profiles written.')
