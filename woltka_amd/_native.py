@@ -404,6 +404,7 @@ class Context:
 WEIGHT_L = 720720       # WK_WEIGHT_L: k = 0 keys hold multiples of 1 / L
 WEIGHT_MAX_K = 16
 KEY_K_MASK = np.uint64(0xFFF << 49)
+KEY_GROUP_SHIFT = 28        # key >> 28 = (job, k, group)
 
 
 def device_count():

@@ -169,6 +169,7 @@ class Engine:
         self._exclude = None
         self._gmap_key, self._gmap = None, None
         self._epoch = 0
+        self._units, self._big = {}, {}     # folded counts until `finish`
         self._tok_map = np.empty(0, dtype=np.int32)
         self._tok_identity = True
         self._tok_genome = np.empty(0, dtype=np.int32)
@@ -633,7 +634,10 @@ class Engine:
                     'table (Engine(table_slots=...)).')
         if keys.size:
             # everything with k <= 16 folds to integer multiples of 1/L per
-            # (job, group, feature) in numpy; the rare k > 16 stay Fractions
+            # (job, group, feature) in numpy; the cells of one (job, group) —
+            # contiguous after the sort — are then named and stored in bulk.
+            # The units stay integers until `finish`; the rare k > 16
+            # contributions are kept as Fractions next to them.
             job, k, grp, feat = nat.decode_keys(keys)
             big = k > nat.WEIGHT_MAX_K
             units = vals.astype(np.int64) * np.where(
@@ -642,24 +646,39 @@ class Engine:
                                    return_inverse=True)
             tot = np.zeros(cells.size, dtype=np.int64)
             np.add.at(tot, inv, units[~big])
-            cj, _, cg, cf = nat.decode_keys(cells)
             names = self.index.names
-            L = nat.WEIGHT_L
-
-            def add(j, g, f, value):
+            if cells.size:
+                run_of = cells >> np.uint64(nat.KEY_GROUP_SHIFT)    # (job, k=0, group)
+                cuts = np.flatnonzero(run_of[1:] != run_of[:-1]) + 1
+                lo = [0] + cuts.tolist()
+                hi = cuts.tolist() + [cells.size]
+                cj, _, cg, cf = nat.decode_keys(cells)
+                for a, b in zip(lo, hi):
+                    sample, stratum = self.groups[int(cg[a])]
+                    feats = cf[a:b].tolist()
+                    if feats[-1] == nat.FEATURE_UNASSIGNED:     # the largest id
+                        labels = [names[f] for f in feats[:-1]] + ['Unassigned']
+                    else:
+                        labels = [names[f] for f in feats]
+                    if stratum is not None:
+                        labels = [(stratum, x) for x in labels]
+                    dst = self._units.setdefault(
+                        (self.ranks[int(cj[a])], sample), {})
+                    if dst:
+                        get = dst.get
+                        for key, u in zip(labels, tot[a:b].tolist()):
+                            dst[key] = get(key, 0) + u
+                    else:
+                        dst.update(zip(labels, tot[a:b].tolist()))
+            for j, kk, g, f, nn in zip(job[big].tolist(), k[big].tolist(),
+                                       grp[big].tolist(), feat[big].tolist(),
+                                       vals[big].tolist()):
                 sample, stratum = self.groups[g]
                 name = 'Unassigned' if f == nat.FEATURE_UNASSIGNED \
                     else names[f]
                 key = name if stratum is None else (stratum, name)
-                cell = data[self.ranks[j]].setdefault(sample, {})
-                cell[key] = cell.get(key, 0) + value
-            for j, g, f, u in zip(cj.tolist(), cg.tolist(), cf.tolist(),
-                                  tot.tolist()):
-                add(j, g, f, u // L if u % L == 0 else Fraction(u, L))
-            for j, kk, g, f, nn in zip(job[big].tolist(), k[big].tolist(),
-                                       grp[big].tolist(), feat[big].tolist(),
-                                       vals[big].tolist()):
-                add(j, g, f, Fraction(nn, kk))
+                dst = self._big.setdefault((self.ranks[j], sample), {})
+                dst[key] = dst.get(key, 0) + Fraction(nn, kk)
         self.ctx.counts_clear()
         self.groups = []
         self.group_ids = {}
@@ -672,6 +691,27 @@ class Engine:
         (profiles of several processes are then added exactly and converted
         once, ``exact_to_numbers``)."""
         self.collect(data)
+        # units of 1/L (+ the k > 16 rationals) -> the caller's profile
+        L = nat.WEIGHT_L
+        for (rank, sample), cells in self._units.items():
+            dst = data[rank].setdefault(sample, {})
+            extra = self._big.pop((rank, sample), {})
+            for key, u in cells.items():
+                if exact or key in extra:
+                    v = Fraction(u, L) + extra.pop(key, 0)
+                    if not exact:
+                        v = v.numerator if v.denominator == 1 \
+                            else v.numerator / v.denominator
+                else:   # int when integral, else one correctly rounded division
+                    v = u // L if u % L == 0 else u / L
+                dst[key] = dst[key] + v if key in dst else v
+            for key, v in extra.items():
+                dst[key] = dst.get(key, 0) + v
+        for (rank, sample), extra in self._big.items():
+            dst = data[rank].setdefault(sample, {})
+            for key, v in extra.items():
+                dst[key] = dst.get(key, 0) + v
+        self._units, self._big = {}, {}
         if self.sizes:
             self._finish_sized(data)
         if exact:
