@@ -131,7 +131,8 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * reads in a first small kernel, the rest compacted into per-workgroup lists
  * for the generic kernel), "subject_bins" (0/1: with a small subject table the
  * first pass histograms subject indices and the assigners run once per
- * subject), "single_blocks_per_cu" (grid of the first pass).
+ * subject), "hot_bins" (0/1: for larger tables the first 24,576 subject indices
+ * are histogrammed, the others evaluated per read), "single_blocks_per_cu" (grid of the first pass).
  * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 

@@ -462,3 +462,19 @@ def test_full_size_mixed_chunk_through_the_split(ctx):
     finally:
         ctx.set_option('split', 1)
     assert_same_counts(keys2, vals2, okeys, 2 * ocnt)
+
+
+def test_hot_subject_bins_vs_oracle(ctx):
+    """A subject table beyond the LDS bins (40 k subjects): the first pass
+    counts the first 24,576 subject indices in bins and takes the per-read
+    path for the others; with the bins switched off as well."""
+    rng = np.random.default_rng(2024)
+    prob = synth.lca_problem(rng, n_nodes=120000, n_subjects=40000,
+                             n_reads=400000, dup_frac=0.0, offtree_frac=0.0)
+    specs = ALL_SPECS[:2] + _rank_specs(prob['hier'])[:3]
+    _device_vs_oracle(ctx, prob, specs)
+    ctx.set_option('hot_bins', 0)
+    try:
+        _device_vs_oracle(ctx, prob, specs)
+    finally:
+        ctx.set_option('hot_bins', 1)

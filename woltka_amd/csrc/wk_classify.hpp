@@ -63,6 +63,7 @@ struct ClassifyArgs {
     // dense_merge_kernel
     uint32_t dense_bins;
     uint32_t dense_total;  // bins per slab row: n_jobs * dense_bins, or the subject count (count-first pass)
+    int32_t dense_by_subject;  // the bins are indexed by subject (first pass only)
     uint32_t* dense_slab;  // [gridDim.x][dense_total]
     int32_t slab16;        // slab rows hold 16-bit counts (a workgroup sees < 65536 reads): half the traffic
     // partitioned miss log (see LdsCache): [gridDim.x][kLogParts][plog_cap] keys
@@ -637,9 +638,10 @@ __device__ __forceinline__ void cache_setup(LdsCache& cache, const ClassifyArgs&
         cache.plog_cap = a.plog_cap;
         const uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * kLogParts;
         for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) cache.plog_cur[i] = a.resume ? cnt[i] : 0u;
-    } else if (a.dense_bins) {
-        cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
-        cache.dense_bins = a.dense_bins;
+    }
+    if (a.dense_bins) {  // (behind the log cursors when both are in use: the hot-subject first pass)
+        cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16 + (a.plog ? kLogParts * 4 : 0));
+        cache.dense_bins = a.dense_by_subject ? 0u : a.dense_bins;  // count_add only knows (job, feature) bins
         const uint32_t nb = a.dense_total;
         for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cache.dense[i] = 0u;
     }
@@ -996,7 +998,11 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
 //
 // kReads reads per thread and round, 64 apart inside the wave's window, so that
 // every load is coalesced and kReads x more bytes are in flight per wave.
-template <bool kBySubject, bool kOneJob, int kReads, bool kFeature = false>
+// kHot: the subject table is larger than the LDS bins; only the first
+// `dense_bins` subject indices — indices follow first appearance, so with
+// skewed abundances these are the bulk of the reads — are histogrammed, the
+// others take the per-read path (row gather + count).
+template <bool kBySubject, bool kOneJob, int kReads, bool kFeature = false, bool kHot = false>
 __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, uint32_t lds_slots,
                                                                unsigned long long* __restrict__ left_mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1023,7 +1029,8 @@ __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, u
 
     struct Offs { int32_t s[kReads], e[kReads]; };
     struct Firsts { uint32_t c[kReads]; };
-    struct Rows { int4 v[kBySubject ? 1 : kReads]; };
+    struct Rows { int4 v[(kBySubject && !kHot) ? 1 : kReads]; };
+    const uint32_t hot = kHot ? a.dense_total : 0xFFFFFFFFu;  // subject indices counted in the bins
     // byte offsets stay below 2^32: every access is base (SGPR pair) + 32-bit lane offset
     auto load_offsets = [&](uint32_t base, Offs& o) {
 #pragma unroll
@@ -1054,6 +1061,11 @@ __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, u
                 if (a.n_cols > 2 && in) v.w = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.col_anc[2]) + (c << 2));
                 w.v[k] = v;
             }
+        } else if constexpr (kHot) {
+#pragma unroll
+            for (int k = 0; k < kReads; ++k)  // only the cold subjects' rows are fetched
+                w.v[k] = (f.c[k] >= hot && f.c[k] < n_subjects) ? *reinterpret_cast<const int4*>(rows_b + (f.c[k] << 4))
+                                                                : make_int4(-1, -1, -1, -1);
         } else if constexpr (!kBySubject) {
 #pragma unroll
             for (int k = 0; k < kReads; ++k)
@@ -1107,13 +1119,17 @@ __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, u
 #ifdef WK_ABLATE
                 if (a.ablate & 9) continue;
 #endif
-                if (mine[k]) atomicAdd(&cache.dense[f0.c[k]], 1u);
+                if (mine[k] && f0.c[k] < hot) atomicAdd(&cache.dense[f0.c[k]], 1u);
+                if constexpr (kHot) {
+                    mine[k] = mine[k] && f0.c[k] >= hot;  // what is left for the per-read path below
+                    bad |= (mine[k] && (uint32_t)w0.v[k].x > (uint32_t)WK_MAX_FEATURE) ? 1u : 0u;
+                }
             } else {
                 bad |= (mine[k] && (uint32_t)w0.v[k].x > (uint32_t)WK_MAX_FEATURE) ? 1u : 0u;
                 bad |= (mine[k] && g[k] >= (1 << WK_KEY_GROUP_BITS)) ? 2u : 0u;
             }
         }
-        if constexpr (!kBySubject) {
+        if constexpr (!kBySubject || kHot) {
 #ifdef WK_ABLATE
             if (!(a.ablate & 8))
 #endif

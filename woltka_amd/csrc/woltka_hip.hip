@@ -135,7 +135,8 @@ struct wk_ctx {
     int use_split = 1;
     int single_blocks_per_cu = 1;
     DevBuf left_mask, left_list, first_slab;
-    int use_subject_bins = 1;  // count-first mode of the split for small subject tables
+    int use_subject_bins = 1;
+    int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
 };
 
 namespace {
@@ -300,6 +301,10 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<true, true, 2, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<true, false, 2, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, 1, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1, true>),
@@ -386,6 +391,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "split")) {  // 0 = off, 1 = auto, 2 = always (when the chunk qualifies)
         if (value < 0 || value > 2) return fail(c, WK_E_ARG, "split must be 0, 1 or 2");
         c->use_split = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "hot_bins")) {
+        c->use_hot_bins = value ? 1 : 0;
         return WK_OK;
     }
     if (!strcmp(name, "subject_bins")) {
@@ -773,14 +782,18 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                                (feature_chunk ? a.n_cols >= 0 : (a.row_w == 4 && c->n_subjects < (1 << 28)));
             // ... and with a small subject table the first pass only histograms
             // subject indices; the assigners run once per subject afterwards
-            const bool by_subject = split && !feature_chunk && c->use_subject_bins && !out_assign && !c->has_group && !sized &&
-                                    c->n_subjects <= 28672;
+            const bool subject_ok = split && !feature_chunk && c->use_subject_bins && !out_assign && !c->has_group && !sized;
+            const bool by_subject = subject_ok && c->n_subjects <= 28672;
+            // a larger table: the first 24,576 subject indices (first appearance
+            // order: the abundant ones) in bins, the others per read
+            const bool hot_subjects = subject_ok && !by_subject && c->use_subject_bins >= 1 && c->use_hot_bins;
+            constexpr int kHotBins = 24576;
             const int max_blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu);
             const int blocks = grid_for(c->n_reads, c->threads, max_blocks);
             // dense bins: small id space, subject-indexed chunk, no size-normalised job
             int64_t bins = 0;
             int lds_slots = c->lds_slots;
-            if (c->use_dense && c->subj_indexed && !by_subject) {
+            if (c->use_dense && c->subj_indexed && !by_subject && !hot_subjects) {
                 const int64_t b = std::max<int64_t>(c->n_nodes, (int64_t)c->max_subject_feature + 1);
                 if (!sized && b * n_jobs <= 28672) {  // <= 112 KiB of bins + 32 KiB hash cache = 144 KiB LDS
                     bins = b;
@@ -841,12 +854,34 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     HIP_TRY(c, c->first_slab.reserve((size_t)blocks1 * ((size_t)c->n_subjects + 64) * 4));  // (16-bit layout pads units to 64 columns)
                     first.dense_bins = (uint32_t)c->n_subjects;
                     first.dense_total = (uint32_t)c->n_subjects;
+                    first.dense_by_subject = 1;
                     first.dense_slab = c->first_slab.as<uint32_t>();
                     // reads per workgroup: its rounds x 4096
                     const int64_t rounds = ((c->n_reads + 4095) / 4096 + blocks1 - 1) / blocks1;
                     first.slab16 = rounds * 4096 <= 65535 ? 1 : 0;
                     hipLaunchKernelGGL((classify_single_kernel<true, true, 4>), dim3(blocks1), dim3(1024),
                                        64 * 16 + (size_t)c->n_subjects * 4, c->stream, first, 64u, mask);
+                } else if (hot_subjects) {
+                    // hash cache + log cursors like the second pass (shared streams),
+                    // plus the hot subjects' bins behind them
+                    HIP_TRY(c, c->first_slab.reserve((size_t)blocks * ((size_t)kHotBins + 64) * 4));
+                    first.plog = a.plog;
+                    first.plog_cnt = a.plog_cnt;
+                    first.plog_cap = a.plog_cap;
+                    first.dense_bins = kHotBins;
+                    first.dense_total = kHotBins;
+                    first.dense_by_subject = 1;
+                    first.dense_slab = c->first_slab.as<uint32_t>();
+                    const int64_t per_wg = ((c->n_reads + (int64_t)blocks * c->threads * 2 - 1) / ((int64_t)blocks * c->threads * 2)) * c->threads * 2;
+                    first.slab16 = per_wg <= 65535 ? 1 : 0;
+                    const int hot_slots = std::min(lds_slots, 2048);
+                    const size_t lds1 = (size_t)hot_slots * 16 + (a.plog ? kLogParts * 4 : 0) + (size_t)kHotBins * 4;
+                    if (n_jobs == 1)
+                        hipLaunchKernelGGL((classify_single_kernel<true, true, 2, false, true>), dim3(blocks), dim3(c->threads), lds1,
+                                           c->stream, first, (uint32_t)hot_slots, mask);
+                    else
+                        hipLaunchKernelGGL((classify_single_kernel<true, false, 2, false, true>), dim3(blocks), dim3(c->threads), lds1,
+                                           c->stream, first, (uint32_t)hot_slots, mask);
                 } else {
                     // per-read evaluation with the same counting levels as the second
                     // pass; dense bins go to a slab of their own, log streams are shared
@@ -881,11 +916,11 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 a.n_mask_words = n_words;
                 a.list_seg = list_seg;
                 a.read_list = c->left_list.as<uint32_t>();
-                if (by_subject || bins) {
+                if (by_subject || hot_subjects || bins) {
                     a.first_slab = c->first_slab.as<uint32_t>();
                     a.first_rows = (uint32_t)blocks1;
                     a.first_total = first.dense_total;
-                    a.first_by_subject = by_subject ? 1 : 0;
+                    a.first_by_subject = (by_subject || hot_subjects) ? 1 : 0;
                     a.first_slab16 = first.slab16;
                 }
                 a.resume = (!by_subject && !bins && plog_cap) ? 1 : 0;
