@@ -478,3 +478,77 @@ def test_hot_subject_bins_vs_oracle(ctx):
         _device_vs_oracle(ctx, prob, specs)
     finally:
         ctx.set_option('hot_bins', 1)
+
+
+def _as_sets(prob, rng, big_reads=0):
+    """Drop duplicate subjects inside reads (the tokenizer's promise) and,
+    optionally, append a few reads with several hundred distinct subjects."""
+    qoff = prob['qoff'].astype(np.int64)
+    n_reads = qoff.size - 1
+    read_of = np.repeat(np.arange(n_reads, dtype=np.int64), np.diff(qoff))
+    subj = prob['subj'].astype(np.int64)
+    if big_reads:
+        pool = np.unique(subj)
+        extra_r, extra_s = [], []
+        for b in range(big_reads):
+            k = int(rng.integers(65, min(700, pool.size)))
+            extra_s.append(rng.choice(pool, k, replace=False))
+            extra_r.append(np.full(k, n_reads + b, dtype=np.int64))
+        read_of = np.concatenate([read_of] + extra_r)
+        subj = np.concatenate([subj] + extra_s)
+        n_reads += big_reads
+    pairs = np.unique((read_of << 32) | subj)
+    out = dict(prob)
+    out['subj'] = (pairs & 0xFFFFFFFF).astype(np.int32)
+    cnt = np.bincount((pairs >> 32).astype(np.int64), minlength=n_reads)
+    out['qoff'] = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    if 'group' in prob:
+        g = prob['group']
+        out['group'] = np.concatenate(
+            [g, rng.integers(0, 40, n_reads - g.size).astype(np.int32)])
+    return out
+
+
+@pytest.mark.parametrize('with_group', [False, True])
+def test_subject_sets_with_long_reads_vs_oracle(ctx, with_group):
+    """Chunks of subject *sets* (what the native tokenizer hands over), with
+    a few reads of several hundred distinct subjects, under rank-none and
+    given-rank jobs: counts, per-read assignments and statistics against the
+    C oracle."""
+    rng = np.random.default_rng(31)
+    prob = synth.lca_problem(rng, n_nodes=60000, n_subjects=6000,
+                             n_reads=300000, dup_frac=0.0, offtree_frac=0.0,
+                             with_group=with_group, max_hits=24)
+    prob = _as_sets(prob, rng, big_reads=40)
+    h = prob['hier']
+    codes = h.rank_codes
+    specs = [(nat.MODE_NONE, 0, 0, 0.0),
+             (nat.MODE_NONE, 0, nat.F_UNIQ | nat.F_UNASSIGNED, 0.0),
+             (nat.MODE_RANK, codes['phylum'], 0, 0.0),
+             (nat.MODE_RANK, codes['species'], nat.F_UNASSIGNED, 0.0),
+             (nat.MODE_RANK, codes['genus'], nat.F_UNIQ, 0.0)]
+    ctx.set_tree(h.parent, h.last, h.rank_code)
+    jobs = device_jobs(ctx, specs)
+    feats, sidx = np.unique(prob['subj'], return_inverse=True)
+    ctx.set_subjects(feats.astype(np.int32))
+    ctx.counts_reserve(1 << 22)
+    ojobs = [dict(mode=m, rank_code=c, flags=f, major=mj)
+             for m, c, f, mj in specs]
+    oassign, contrib = c_oracle.classify(prob['subj'], prob['qoff'], ojobs,
+                                         h.parent, h.rank_code, 0,
+                                         prob.get('group'))
+    okeys, ocnt = np.unique(contrib, return_counts=True)
+    for want in (False, True):
+        ctx.counts_clear()
+        ctx.reset_stats()
+        assign = ctx.classify_chunk(jobs, sidx.astype(np.int32),
+                                    prob['qoff'], group=prob.get('group'),
+                                    subj_is_set=True, want_assign=want,
+                                    indexed=True)
+        keys, vals = ctx.counts_fetch()
+        assert_same_counts(keys, vals, okeys, ocnt, want)
+        if want:
+            assert np.array_equal(assign, oassign)
+        st = ctx.stats()
+        assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
+        assert st['n_records'] == prob['subj'].size
