@@ -1017,6 +1017,266 @@ def gen_cli_strata(seed=59, n_cases=8):
     dump('cli_strata.json', cases)
 
 
+def _random_profile(rng, kind, meta=None):
+    """TSV text of a random profile.  kind: 'int', 'float', 'strat' (ids
+    "A|b"), 'nested' (ids "A_1_x"), with optional metadata columns."""
+    n_samples = rng.randint(1, 5)
+    samples = [f'S{i + 1}' for i in range(n_samples)]
+    n = rng.randint(0 if rng.random() < 0.05 else 1, 25)
+    if kind == 'strat':
+        ids = [f'{rng.choice("ABCD")}{rng.choice(["", "", "|"])}'
+               f'{"|".join(rng.choice("abcde") for _ in range(rng.randint(0, 2)))}'
+               for _ in range(n)]
+    elif kind == 'nested':
+        ids = ['_'.join([rng.choice(['G1', 'G2', 'G3'])] +
+                        [str(rng.randint(1, 4))
+                         for _ in range(rng.randint(0, 2))])
+               for _ in range(n)]
+    else:
+        ids = [f'F{rng.randint(1, 30)}' for _ in range(n)]
+    ids = list(dict.fromkeys(x for x in ids if x))
+    if meta is None:
+        meta = rng.choice(
+            [[], [], [], ['Name'], ['Name', 'Rank'], ['Rank', 'Lineage'],
+             ['Name', 'Rank', 'Lineage']] +
+            ([['Lineage', 'Name']] if rng.random() < 0.1 else []))
+    lines = ['\t'.join(['#FeatureID'] + samples + meta)]
+    digits = rng.choice([1, 2, 3, 6])
+    for x in ids:
+        if kind == 'float' or (kind != 'int' and rng.random() < 0.3):
+            cells = [str(round(rng.random() * rng.choice([1, 10, 1000]),
+                               digits)) if rng.random() < 0.7 else '0'
+                     for _ in samples]
+        else:
+            cells = [str(rng.choice([0, 0, 1, 2, 5, 17, 250, 10 ** 6]))
+                     for _ in samples]
+        lines.append('\t'.join([x] + cells + [f'{m[0]}{x}' for m in meta]))
+    return '\n'.join(lines) + '\n', ids
+
+
+def gen_tools(seed=71, n_cases=170):
+    """The table commands (normalize / filter / merge / collapse / coverage)
+    through the reference's command line: on the bundled tables with the
+    option sets its own tests and README use, and on random small tables with
+    random options.  Every case stores its input files (random ones) or names
+    them (bundled ones, relative to tests/golden/data), the arguments, and
+    what the reference printed, wrote and exited with."""
+    import tempfile
+    from click.testing import CliRunner
+    from woltka.cli import cli
+    rng = random.Random(seed)
+    runner = CliRunner()
+    cases = []
+
+    def run(cmd, args, files=None):
+        """args: list of (flag, value) where value '@name' is a generated
+        file, '$path' a bundled one, '>' the output path."""
+        with tempfile.TemporaryDirectory() as tmp:
+            for name, text in (files or {}).items():
+                _write_case_file(os.path.join(tmp, name), text)
+            out = os.path.join(tmp, 'output.tsv')
+            argv = [cmd]
+            for flag, value in args:
+                argv.append(flag)
+                if value is None:
+                    continue
+                v = str(value)
+                if v.startswith('@'):
+                    v = os.path.join(tmp, v[1:])
+                elif v.startswith('$'):
+                    v = os.path.join(DATA, v[1:])
+                elif v == '>':
+                    v = out
+                argv.append(v)
+            res = runner.invoke(cli, argv)
+            written = None
+            if os.path.isfile(out):
+                with open(out) as f:
+                    written = f.read()
+            stdout = res.output.replace(tmp, '<tmp>').replace(DATA, '<data>')
+            error = None
+            if res.exception and not isinstance(res.exception, SystemExit):
+                error = type(res.exception).__name__
+                if error not in ('ValueError',):
+                    return      # a crash of the reference: nothing to pin
+            cases.append(dict(cmd=cmd, args=args, files=files or {},
+                              exit_code=res.exit_code, stdout=stdout,
+                              output=written, error=error))
+
+    io = lambda fp: [('--input', fp), ('--output', '>')]     # noqa: E731
+    # ---- bundled tables (test_tools.py, test_cli.py:179-259, README)
+    run('normalize', io('$output/bowtie2.ogu.tsv') + [('--digits', 3)])
+    run('normalize', io('$output/bowtie2.ogu.tsv') +
+        [('--sizes', '$taxonomy/length.map'), ('--scale', '1M')])
+    run('normalize', io('$output/bowtie2.ogu.tsv') + [('--scale', 'Hi!')])
+    run('normalize', io('$output/bowtie2.orf.tsv') +
+        [('--sizes', '$function/coords.txt.xz'), ('--scale', '1k'),
+         ('--digits', 3)])
+    run('normalize', io('$output/bowtie2.ogu.tsv') +
+        [('--sizes', '$tree.nwk')])
+    run('normalize', io('$output/bowtie2.free.tsv') + [('--scale', '100'),
+                                                       ('--digits', 2)])
+    run('filter', io('$output/blastn.species.tsv') + [('--min-count', 5)])
+    run('filter', io('$output/blastn.species.tsv') + [('--min-percent', 1)])
+    run('filter', io('$output/bowtie2.free.tsv') + [('--min-percent', 1)])
+    run('filter', io('$output/blastn.species.tsv'))
+    run('filter', io('$output/blastn.species.tsv') +
+        [('--min-count', 10), ('--min-percent', 10)])
+    run('filter', io('$output/blastn.species.tsv') + [('--min-percent', 120)])
+    run('merge', [('--input', '$output/burst.process.tsv'),
+                  ('--input', '$output/split.process.tsv'), ('--output', '>')])
+    run('merge', [('--input', '$output/burst.process.tsv'),
+                  ('--output', '>')])
+    run('merge', [('--input', '$output/burst.genus.tsv'),
+                  ('--input', '$output/split.genus.tsv'),
+                  ('--input', '$output/bowtie2.free.tsv'), ('--output', '>')])
+    run('merge', [('--input', '$output/burst.process.tsv'),
+                  ('--input', '$tree.nwk'), ('--output', '>')])
+    run('collapse', io('$output/truth.gene.tsv') +
+        [('--map', '$function/nucl/uniref.map.xz')])
+    run('collapse', io('$output/truth.uniref.tsv') +
+        [('--map', '$function/go/goslim.tsv.xz'),
+         ('--names', '$function/go/name.txt.xz')])
+    run('collapse', io('$output/truth.uniref.tsv') +
+        [('--map', '$function/go/goslim.tsv.xz'),
+         ('--names', '$function/go/name.txt.xz'), ('--divide', None)])
+    run('collapse', io('$output/truth.uniref.tsv') +
+        [('--map', '$tree.nwk'), ('--divide', None)])
+    run('collapse', io('$output/burst.genus.process.tsv') +
+        [('--map', '$function/go/go2slim.map.xz'), ('--field', 2)])
+    run('collapse', io('$output/burst.genus.process.tsv') +
+        [('--map', '$function/go/go2slim.map.xz'), ('--field', 2),
+         ('--divide', None)])
+    run('collapse', io('$output/burst.genus.process.tsv') + [('--field', 1)])
+    run('collapse', io('$output/bowtie2.orf.tsv') +
+        [('--field', 1), ('--sep', '_'), ('--nested', None)])
+    run('coverage', [('--input', '$output/truth.metacyc.tsv'),
+                     ('--map', '$function/metacyc/pathway_mbrs.txt'),
+                     ('--output', '>')])
+    run('coverage', [('--input', '$output/truth.metacyc.tsv'),
+                     ('--map', '$function/metacyc/pathway_mbrs.txt'),
+                     ('--output', '>'), ('--threshold', 80),
+                     ('--names', '$function/metacyc/pathway_name.txt')])
+    run('coverage', [('--input', '$output/truth.metacyc.tsv'),
+                     ('--map', '$function/metacyc/pathway_mbrs.txt'),
+                     ('--output', '>'), ('--count', None)])
+    run('coverage', [('--input', '$output/truth.metacyc.tsv'),
+                     ('--map', '$tree.nwk'), ('--output', '>'),
+                     ('--count', None)])
+    n_bundled = len(cases)
+
+    # ---- random tables
+    while len(cases) < n_cases:
+        cmd = rng.choice(['normalize', 'filter', 'merge', 'collapse',
+                          'collapse', 'coverage'])
+        files, args = {}, []
+        if cmd == 'normalize':
+            text, ids = _random_profile(rng, rng.choice(['int', 'float']))
+            files['in.tsv'] = text
+            args = io('@in.tsv')
+            how = rng.random()
+            if how < 0.4:
+                drop = set(rng.sample(ids, 1)) if ids and \
+                    rng.random() < 0.15 else set()
+                files['sizes.map'] = ''.join(
+                    f'{x}\t{rng.choice([1, 2, 3, 7, 1000, 2.5])}\n'
+                    for x in ids if x not in drop)
+                args.append(('--sizes', '@sizes.map'))
+            elif how < 0.5:
+                files['sizes.map'] = '>G1\n' + ''.join(
+                    f'{x}\t{a}\t{a + rng.randint(-50, 50)}\n'
+                    for x in ids for a in [rng.randint(1, 900)])
+                args.append(('--sizes', '@sizes.map'))
+            if rng.random() < 0.5:
+                args.append(('--scale', rng.choice(
+                    ['100', '1k', '1M', '2.5', '0.5k', 'x'])))
+            if rng.random() < 0.6:
+                args.append(('--digits', rng.randint(0, 6)))
+        elif cmd == 'filter':
+            files['in.tsv'] = _random_profile(
+                rng, rng.choice(['int', 'float', 'strat']))[0]
+            args = io('@in.tsv')
+            how = rng.random()
+            if how < 0.45 or how > 0.95:
+                args.append(('--min-count', rng.choice([1, 2, 5, 100])))
+            if 0.4 < how < 0.9 or how > 0.95:
+                args.append(('--min-percent',
+                             rng.choice([0.01, 1, 10, 33.3, 50, 99.9, 100])))
+        elif cmd == 'merge':
+            k = rng.choice([1, 2, 2, 2, 3, 3, 4])
+            kind = rng.choice(['int', 'float', 'strat'])
+            use_dir = rng.random() < 0.2
+            meta = rng.choice([[], [], ['Name'], ['Rank', 'Lineage']])
+            for i in range(k):
+                files[f'{"dir/" if use_dir else ""}t{i}.tsv'] = \
+                    _random_profile(rng, kind, None if rng.random() < 0.1
+                                    else meta)[0]
+            if use_dir:
+                args = [('--input', '@dir')]
+            else:
+                args = [('--input', f'@t{i}.tsv') for i in range(k)]
+            args.append(('--output', '>'))
+        elif cmd == 'collapse':
+            kind = rng.choice(['int', 'float', 'strat', 'strat', 'nested'])
+            text, ids = _random_profile(rng, kind)
+            files['in.tsv'] = text
+            args = io('@in.tsv')
+            nested = kind == 'nested' and rng.random() < 0.8
+            field = None
+            if kind in ('strat', 'nested') and rng.random() < 0.85:
+                field = rng.randint(1, 3)
+                args.append(('--field', field))
+            if nested:
+                args.append(('--nested', None))
+            if kind == 'nested' and not nested:
+                args.append(('--sep', '_'))
+            sep = '_' if kind == 'nested' else '|'
+            if rng.random() < 0.75 or field is None:
+                pool = set()
+                for x in ids:
+                    parts = x.split(sep)
+                    pool.update(parts)
+                    pool.update(sep.join(parts[:i + 1])
+                                for i in range(len(parts)))
+                    pool.add(x)
+                pool = sorted(pool - {''})
+                lines = []
+                for src in rng.sample(pool, rng.randint(0, len(pool))):
+                    tg = [f'T{rng.randint(1, 6)}'
+                          for _ in range(rng.randint(1, 3))]
+                    lines.append('\t'.join([src] + tg))
+                    if rng.random() < 0.2:
+                        lines.append(f'{src}\tT{rng.randint(1, 9)}')
+                files['map.txt'] = '\n'.join(lines) + ('\n' if lines else '')
+                args.append(('--map', '@map.txt'))
+                if rng.random() < 0.5:
+                    args.append(('--divide', None))
+            if rng.random() < 0.3:
+                files['names.txt'] = ''.join(
+                    f'T{i}\tname of T{i}\n' for i in range(1, 6))
+                args.append(('--names', '@names.txt'))
+        else:
+            text, ids = _random_profile(rng, rng.choice(['int', 'float']))
+            files['in.tsv'] = text
+            pool = [f'F{i}' for i in range(1, 31)]
+            files['map.txt'] = ''.join(
+                '\t'.join([f'P{g}'] + rng.sample(pool, rng.randint(1, 8))) +
+                '\n' for g in range(rng.randint(0, 8)))
+            args = [('--input', '@in.tsv'), ('--map', '@map.txt'),
+                    ('--output', '>')]
+            if rng.random() < 0.4:
+                args.append(('--threshold', rng.choice([1, 25, 50, 80, 100])))
+            if rng.random() < 0.3:
+                args.append(('--count', None))
+            if rng.random() < 0.3:
+                files['names.txt'] = ''.join(
+                    f'P{i}\tpathway {i}\n' for i in range(0, 5))
+                args.append(('--names', '@names.txt'))
+        run(cmd, args, files)
+    dump('tools.json', dict(n_bundled=n_bundled, cases=cases))
+
+
+
 def main():
     if not _refshim.install():
         print('reference tree not present: nothing to do')
@@ -1034,6 +1294,7 @@ def main():
     gen_cli_coords()
     gen_cli_strata()
     gen_cli_medium()
+    gen_tools()
 
 
 if __name__ == '__main__':

@@ -2,13 +2,15 @@
 
 Option-for-option counterpart of the reference's ``classify`` command
 (woltka/cli.py:41-199): same flags, destinations, types, defaults and help
-texts, so that ``--help`` and every existing invocation look the same.  Only
-``classify`` exists here — the table utilities (collapse, normalize, filter,
-merge, coverage) operate on finished small tables and are out of scope (SURVEY
-§2 rows 13-14).  One extra option, ``--device``, selects the GPU.
+texts, so that ``--help`` and every existing invocation look the same.  One
+extra option, ``--device``, selects the GPU.
 
 The options are kept as one table (flags, keyword arguments of
 ``click.option``) and attached in a loop.
+
+The table commands — ``collapse``, ``normalize``, ``filter``, ``merge``,
+``coverage`` — are declared the same way in ``cli_tables.py`` and registered
+on the same group.
 """
 import click
 
@@ -80,7 +82,14 @@ OPTIONS = [
 ]
 
 
-@click.group(**CMD_KA)
+class RegistrationOrder(click.Group):
+    """Commands listed as registered, not alphabetically (woltka/cli.py:19)."""
+
+    def list_commands(self, ctx):
+        return list(self.commands)
+
+
+@click.group(cls=RegistrationOrder, **CMD_KA)
 @click.version_option('0.1.7')
 def cli():
     """Woltka: a versatile meta'omic data classifier (MI355X hot path).
@@ -100,6 +109,11 @@ def _classify(**kwargs):
 for _flags, _kw in reversed(OPTIONS):
     _classify = click.option(*_flags, **_kw)(_classify)
 classify_cmd = cli.command('classify', **CMD_KA)(_classify)
+
+
+from .cli_tables import register as _register_table_commands  # noqa: E402
+collapse_cmd, normalize_cmd, filter_cmd, merge_cmd, coverage_cmd = \
+    _register_table_commands(cli, CMD_KA)
 
 
 if __name__ == '__main__':
