@@ -125,7 +125,8 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
 /* Tuning knobs: "lds_slots" (LDS front-cache slots per workgroup, power of two
  * in [64, 8192]), "use_lds" (0/1), "tiled" (0/1: LDS-staged classify kernel),
  * "dense" (0/1: dense LDS bins for small id spaces), "plog" (0 off / 1 auto / 2
- * always: partitioned miss log), "plog_max_bytes", "threads" (workgroup size of
+ * always: partitioned miss log), "plog_max_bytes", "log_parts" (0 auto / 256 /
+ * 1024 hash partitions of that log), "threads" (workgroup size of
  * the direct classify kernel), "blocks_per_cu"
  * (classify grid size per CU, 1..32), "split" (0 off / 1 on: single-candidate
  * reads in a first small kernel, the rest compacted into per-workgroup lists

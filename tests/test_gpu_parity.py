@@ -210,7 +210,13 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
                  # the per-read first pass instead of the subject histogram
                  dict(dense=1, plog=1, plog_max_bytes=4 << 30, subject_bins=0),
                  dict(dense=0, plog=0), dict(dense=0, plog=2),
-                 dict(dense=1, plog=1, split=0, subject_bins=1)):
+                 # 256 / 1024 partitions of the miss log
+                 dict(dense=0, plog=2, log_parts=256),
+                 dict(dense=0, plog=2, log_parts=1024, split=2),
+                 dict(dense=0, plog=2, plog_max_bytes=1 << 22, log_parts=256,
+                      split=2),
+                 dict(dense=1, plog=1, split=0, subject_bins=1, log_parts=0,
+                      plog_max_bytes=4 << 30)):
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.counts_clear()
@@ -220,6 +226,7 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     ctx.set_option('dense', 1)
     ctx.set_option('plog', 1)
     ctx.set_option('plog_max_bytes', 4 << 30)
+    ctx.set_option('log_parts', 0)
     # per-read assignments and statistics through the forced split
     ctx.set_option('split', 2)
     ctx.counts_clear()

@@ -66,11 +66,15 @@ struct ClassifyArgs {
     int32_t dense_by_subject;  // the bins are indexed by subject (first pass only)
     uint32_t* dense_slab;  // [gridDim.x][dense_total]
     int32_t slab16;        // slab rows hold 16-bit counts (a workgroup sees < 65536 reads): half the traffic
-    // partitioned miss log (see LdsCache): [gridDim.x][kLogParts][plog_cap] keys
-    // and [gridDim.x][kLogParts] stream lengths
+    // partitioned miss log (see LdsCache): [gridDim.x][log_parts][plog_cap] keys
+    // and [gridDim.x][log_parts] stream lengths.  log_parts (a power of two) is
+    // 256 when the distinct keys of a launch fit 256 LDS tables of the merge —
+    // a workgroup's open 128-byte log lines (32 workgroups x 256 streams per
+    // XCD = 1 MiB) then stay in L2 until they are full — else 1024
     unsigned long long* plog;
     uint32_t* plog_cnt;
     uint32_t plog_cap;
+    uint32_t log_parts;
     // contribution log of size-normalised jobs (WK_F_SIZED): 4 x int32 per entry
     int32_t* log;
     unsigned long long* log_cursor;
@@ -634,13 +638,14 @@ __device__ __forceinline__ void cache_setup(LdsCache& cache, const ClassifyArgs&
     cache.bmask = lds_slots / 4 - 1;
     if (a.plog) {
         cache.plog_cur = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
-        cache.plog = a.plog + (size_t)blockIdx.x * kLogParts * a.plog_cap;
+        cache.plog = a.plog + (size_t)blockIdx.x * a.log_parts * a.plog_cap;
         cache.plog_cap = a.plog_cap;
-        const uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * kLogParts;
-        for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) cache.plog_cur[i] = a.resume ? cnt[i] : 0u;
+        cache.plog_shift = (uint32_t)__clz((int)a.log_parts) + 1u;
+        const uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * a.log_parts;
+        for (uint32_t i = threadIdx.x; i < a.log_parts; i += blockDim.x) cache.plog_cur[i] = a.resume ? cnt[i] : 0u;
     }
     if (a.dense_bins) {  // (behind the log cursors when both are in use: the hot-subject first pass)
-        cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16 + (a.plog ? kLogParts * 4 : 0));
+        cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16 + (a.plog ? a.log_parts * 4 : 0));
         cache.dense_bins = a.dense_by_subject ? 0u : a.dense_bins;  // count_add only knows (job, feature) bins
         const uint32_t nb = a.dense_total;
         for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cache.dense[i] = 0u;
@@ -651,8 +656,8 @@ __device__ __forceinline__ void cache_setup(LdsCache& cache, const ClassifyArgs&
 __device__ __forceinline__ void cache_finish(const LdsCache& cache, const ClassifyArgs& a) {
     lds_cache_flush(cache, a.table);  // starts with a workgroup barrier
     if (cache.plog_cur) {
-        uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * kLogParts;
-        for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x) {
+        uint32_t* cnt = a.plog_cnt + (size_t)blockIdx.x * a.log_parts;
+        for (uint32_t i = threadIdx.x; i < a.log_parts; i += blockDim.x) {
             const uint32_t n = cache.plog_cur[i];
             cnt[i] = n < a.plog_cap ? n : a.plog_cap;
         }
@@ -821,8 +826,8 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
             // nothing left over here; a pass that owns its log streams leaves
             // this workgroup's empty for the merge
             if (a.plog && !a.resume)
-                for (uint32_t i = threadIdx.x; i < kLogParts; i += blockDim.x)
-                    a.plog_cnt[(size_t)blockIdx.x * kLogParts + i] = 0u;
+                for (uint32_t i = threadIdx.x; i < a.log_parts; i += blockDim.x)
+                    a.plog_cnt[(size_t)blockIdx.x * a.log_parts + i] = 0u;
             return;
         }
     }
@@ -1178,7 +1183,7 @@ __global__ void __launch_bounds__(1024) dense_merge_kernel(const uint32_t* __res
 
 // Aggregation of the partitioned miss log: workgroup p gathers partition p's
 // streams of all classify workgroups (short contiguous runs of keys), counts
-// them in an LDS hash table — a partition holds ~1/1024 of the distinct keys —
+// them in an LDS hash table — a partition holds 1/gridDim.x of the distinct keys —
 // and adds every distinct key to the count table once.  Partitions are disjoint
 // in key space, so those adds never contend.
 __global__ void __launch_bounds__(1024) partition_merge_kernel(const unsigned long long* __restrict__ plog,
@@ -1186,11 +1191,11 @@ __global__ void __launch_bounds__(1024) partition_merge_kernel(const unsigned lo
                                                                uint32_t n_rows, uint32_t plog_cap,
                                                                uint32_t lds_slots, CountTable table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t part = blockIdx.x;
+    const uint32_t part = blockIdx.x, n_parts = gridDim.x;
     // an empty partition (a second pass with little left over) costs one look
     // at its stream lengths, not an LDS table
     uint32_t any = 0;
-    for (uint32_t row = threadIdx.x; row < n_rows; row += blockDim.x) any |= plog_cnt[(size_t)row * kLogParts + part];
+    for (uint32_t row = threadIdx.x; row < n_rows; row += blockDim.x) any |= plog_cnt[(size_t)row * n_parts + part];
     if (!__syncthreads_or((int)(any != 0u))) return;
     LdsCache cache{};
     cache.base = reinterpret_cast<unsigned long long*>(smem);
@@ -1198,8 +1203,8 @@ __global__ void __launch_bounds__(1024) partition_merge_kernel(const unsigned lo
     lds_cache_init(cache);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
     for (uint32_t row = wave; row < n_rows; row += n_waves) {  // one stream per wave at a time
-        const uint32_t n = plog_cnt[(size_t)row * kLogParts + part];
-        const unsigned long long* src = plog + ((size_t)row * kLogParts + part) * plog_cap;
+        const uint32_t n = plog_cnt[(size_t)row * n_parts + part];
+        const unsigned long long* src = plog + ((size_t)row * n_parts + part) * plog_cap;
         for (uint32_t i = lane; i < n; i += 64) {
             // an entry with k in [1, 16] is one contribution to the weighted key
             const unsigned long long e = src[i];

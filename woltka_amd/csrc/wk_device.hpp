@@ -18,7 +18,7 @@ constexpr int kErrFeatureRange = 4;
 constexpr int kErrGroupRange = 8;
 constexpr int kErrPairOverflow = 16;
 
-constexpr uint32_t kLogParts = 1024;  // hash partitions of the miss log
+constexpr uint32_t kLogPartsMax = 1024;  // hash partitions of the miss log: 256 or 1024, chosen per launch
 
 __host__ __device__ __forceinline__ uint64_t make_key(uint32_t job, uint32_t k, uint32_t group,
                                                       uint32_t feature) {
@@ -98,9 +98,10 @@ struct LdsCache {
     // stream of (this workgroup, hash partition) in HBM instead of paying a
     // device-scope atomic; partition_merge_kernel aggregates each partition in
     // LDS afterwards.  plog_cur[p] counts the appends of partition p.
-    uint32_t* plog_cur;            // LDS [kLogParts] or null
-    unsigned long long* plog;      // HBM, this workgroup's [kLogParts][plog_cap] keys
+    uint32_t* plog_cur;            // LDS [log_parts] or null
+    unsigned long long* plog;      // HBM, this workgroup's [log_parts][plog_cap] keys
     uint32_t plog_cap;
+    uint32_t plog_shift;           // 32 - log2(log_parts)
 #ifdef WK_ABLATE
     uint32_t ablate;
 #endif
@@ -152,7 +153,7 @@ __device__ __forceinline__ void cached_add(const LdsCache& c, const CountTable& 
 #endif
     if (c.plog_cur) {
         // partition by the high hash bits (the low bits pick the LDS bucket)
-        const uint32_t part = (hash_key(key) * 0x9E3779B1u) >> 22;  // kLogParts = 2^10
+        const uint32_t part = (hash_key(key) * 0x9E3779B1u) >> c.plog_shift;
         const uint32_t pos = atomicAdd(&c.plog_cur[part], 1u);
         if (pos < c.plog_cap) {
             // a log entry is one contribution: a weighted key (k field 0)

@@ -77,6 +77,9 @@ struct wk_ctx {
     int32_t n_nodes = 0;
     DevBuf rank_tab[WK_MAX_JOBS * 4];
     bool rank_tab_valid[WK_MAX_JOBS * 4] = {};
+    int64_t rank_tab_nodes[WK_MAX_JOBS * 4] = {};  // nodes that carry the slot's rank (distinct results a job can have)
+    std::vector<int32_t> rank_code_host;           // host copy of the rank codes (for those counts)
+    int log_parts_opt = 0;                         // 0 = auto, else 256 / 1024
 
     // compact subject table (optional)
     DevBuf subj_feat, subj_rows, dense_slab, plog, plog_cnt;
@@ -379,6 +382,11 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         c->use_plog = (int)value;
         return WK_OK;
     }
+    if (!strcmp(name, "log_parts")) {  // 0 = auto, 256 or 1024
+        if (value != 0 && value != 256 && value != 1024) return fail(c, WK_E_ARG, "log_parts must be 0, 256 or 1024");
+        c->log_parts_opt = (int)value;
+        return WK_OK;
+    }
     if (!strcmp(name, "plog_max_bytes")) {
         if (value < (1 << 20)) return fail(c, WK_E_ARG, "plog_max_bytes must be at least 1 MiB");
         c->plog_max_bytes = value;
@@ -434,6 +442,7 @@ int wk_set_tree(wk_ctx* c, const int32_t* parent, const int32_t* last, const int
     if ((rc = upload(c, c->nodes, packed.data(), (size_t)n * sizeof(Node)))) return rc;
     if ((rc = upload(c, c->rank_code, rank_code, (size_t)n * sizeof(int32_t)))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // `packed` is about to go out of scope
+    c->rank_code_host.assign(rank_code, rank_code + n);
     c->n_nodes = n;
     c->rows_sig.clear();
     for (bool& v : c->rank_tab_valid) v = false;
@@ -453,6 +462,7 @@ int wk_build_rank_table(wk_ctx* c, int32_t slot, int32_t code) {
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
     c->rank_tab_valid[slot] = true;
+    c->rank_tab_nodes[slot] = std::count(c->rank_code_host.begin(), c->rank_code_host.end(), code);
     c->rows_sig.clear();
     return WK_OK;
 }
@@ -814,13 +824,30 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             const int64_t contrib = by_subject ? 3 * std::max<int64_t>(c->n_records - c->n_reads, 0) + 1024
                                                : c->n_records + c->n_reads;
             if (!bins && (c->use_plog == 2 || (c->use_plog == 1 && contrib >= (1 << 22)))) {
-                const int64_t streams = (int64_t)blocks * kLogParts;
+                // partitions: the merge counts a partition in one LDS table of
+                // 8192 slots, so 256 partitions hold ~1.3 M distinct keys at a
+                // comfortable load; fewer partitions keep a workgroup's open
+                // log lines in L2 until they are full.  Distinct keys of a
+                // launch <= sum over jobs of the ids the job can emit.
+                int64_t distinct = 0;
+                for (int j = 0; j < n_jobs; ++j) {
+                    const int64_t ids = jobs[j].mode == WK_MODE_RANK   ? c->rank_tab_nodes[jobs[j].rank_slot]
+                                        : jobs[j].mode == WK_MODE_FREE ? (int64_t)c->n_nodes
+                                        : c->subj_indexed              ? (int64_t)c->n_subjects
+                                        : c->n_genes > 0               ? (int64_t)c->n_genes
+                                                                       : (int64_t)WK_MAX_FEATURE;
+                    distinct += ids + 1;
+                }
+                const uint32_t log_parts = c->log_parts_opt ? (uint32_t)c->log_parts_opt
+                                           : (!c->has_group && distinct <= 256 * 5120) ? 256u : kLogPartsMax;
+                a.log_parts = log_parts;
+                const int64_t streams = (int64_t)blocks * log_parts;
                 // room for 3x the expected entries per stream if every contribution missed
                 int64_t cap = 3 * (contrib * (int64_t)n_jobs / streams + 1) + 16;
                 cap = std::min<int64_t>(cap, c->plog_max_bytes / 8 / streams);
                 if (!sized && cap >= 16) {
                     plog_cap = (uint32_t)cap;
-                    lds = (size_t)lds_slots * 16 + kLogParts * 4;  // + 4 KiB of stream cursors
+                    lds = (size_t)lds_slots * 16 + log_parts * 4;  // + the stream cursors
                     HIP_TRY(c, c->plog.reserve((size_t)streams * plog_cap * 8));
                     HIP_TRY(c, c->plog_cnt.reserve((size_t)streams * 4));
                     a.plog = c->plog.as<unsigned long long>();
@@ -875,7 +902,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     const int64_t per_wg = ((c->n_reads + (int64_t)blocks * c->threads * 2 - 1) / ((int64_t)blocks * c->threads * 2)) * c->threads * 2;
                     first.slab16 = per_wg <= 65535 ? 1 : 0;
                     const int hot_slots = std::min(lds_slots, 2048);
-                    const size_t lds1 = (size_t)hot_slots * 16 + (a.plog ? kLogParts * 4 : 0) + (size_t)kHotBins * 4;
+                    const size_t lds1 = (size_t)hot_slots * 16 + (a.plog ? a.log_parts * 4 : 0) + (size_t)kHotBins * 4;
                     if (n_jobs == 1)
                         hipLaunchKernelGGL((classify_single_kernel<true, true, 2, false, true>), dim3(blocks), dim3(c->threads), lds1,
                                            c->stream, first, (uint32_t)hot_slots, mask);
@@ -940,7 +967,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             if (plog_cap) {
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "partition_merge");
-                hipLaunchKernelGGL(partition_merge_kernel, dim3(kLogParts), dim3(1024), (size_t)8192 * 16, c->stream,
+                hipLaunchKernelGGL(partition_merge_kernel, dim3(a.log_parts), dim3(1024), (size_t)8192 * 16, c->stream,
                                    c->plog.as<unsigned long long>(), c->plog_cnt.as<uint32_t>(), (uint32_t)blocks,
                                    plog_cap, 8192u, a.table);
             }
