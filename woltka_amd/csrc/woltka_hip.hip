@@ -383,7 +383,7 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         return WK_OK;
     }
     if (!strcmp(name, "log_parts")) {  // 0 = auto, 256 or 1024
-        if (value != 0 && value != 256 && value != 1024) return fail(c, WK_E_ARG, "log_parts must be 0, 256 or 1024");
+        if (value != 0 && (value < 64 || value > 1024 || (value & (value - 1)))) return fail(c, WK_E_ARG, "log_parts must be 0 or a power of two in [64, 1024]");
         c->log_parts_opt = (int)value;
         return WK_OK;
     }
