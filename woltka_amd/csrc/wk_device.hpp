@@ -122,8 +122,13 @@ __device__ __forceinline__ void lds_cache_init(const LdsCache& c) {
 // try to count `key` in bucket b; true on success
 __device__ __forceinline__ bool bucket_add(unsigned long long* bk, uint64_t key, unsigned long long w) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2 k01 = *reinterpret_cast<const volatile u64x2*>(bk);  // ds_read_b128
-    const u64x2 k23 = *reinterpret_cast<const volatile u64x2*>(bk + 2);
+    // (the LDS address space spelled out: a volatile load through a generic
+    // pointer compiles to flat_load ... sc0 sc1 with a wait after each, not to
+    // two ds_read_b128 in flight together)
+    typedef const volatile __attribute__((address_space(3))) u64x2* lds_keys_t;
+    const lds_keys_t keys = (lds_keys_t)bk;
+    const u64x2 k01 = keys[0];
+    const u64x2 k23 = keys[1];
     unsigned long long snap[4] = {k01.x, k01.y, k23.x, k23.y};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
