@@ -237,6 +237,51 @@ class OrdinalWorkload:
     def cpu_sample(self, n):
         return None
 
+    cpu_what = ('per-genome sweep of ordinal.match_read_gene over chunks of '
+                '2^20 hits, gene sets per query, rank-none counter: '
+                'oracle/woltka_oracle.py')
+
+    def cpu_time(self, n):
+        """(records, seconds) of the reference's coord-match procedure on the
+        first ~n hits, restated in Python (oracle/woltka_oracle.py:
+        ordinal.flush_chunk's per-genome sweep = match_sweep, gene sets per
+        query, rank-none counter), chunks of 2^20 hits (ordinal.py:167)."""
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import woltka_oracle as orc
+        p = self.prob
+        hoff = p['hoff']
+        n_reads = int(np.searchsorted(hoff, n, side='left'))
+        n = int(hoff[n_reads])
+        read_of = np.repeat(np.arange(n_reads), np.diff(hoff[:n_reads + 1]))
+        goff = p['genome_off'].tolist()
+        gs, ge = p['gstart'].tolist(), p['gend'].tolist()
+        gf = [f'g{x}' for x in p['gene_feature'].tolist()]     # ids are strings upstream
+        genome = p['genome'][:n].tolist()
+        beg, end = p['beg'][:n].tolist(), p['end'][:n].tolist()
+        length = p['length'][:n].tolist()
+        read_of = read_of.tolist()
+        t0 = time.perf_counter()
+        data = {}
+        for lo in range(0, n, 1 << 20):
+            hi = min(n, lo + (1 << 20))
+            per_genome = {}
+            for h in range(lo, hi):
+                if length[h]:
+                    per_genome.setdefault(genome[h], []).append(h)
+            res = {}
+            for g, hits in per_genome.items():
+                a, b = goff[g], goff[g + 1]
+                pairs = orc.match_sweep(
+                    list(zip(gs[a:b], ge[a:b])),
+                    [(beg[h], end[h], length[h]) for h in hits], 0.8)
+                for r, j in pairs:
+                    res.setdefault(read_of[hits[r]], set()).add(gf[a + j])
+            counts = orc.count_float(
+                orc.assign_none(tuple(v)) for v in res.values())
+            for k, v in counts.items():
+                data[k] = data.get(k, 0) + v
+        return n, time.perf_counter() - t0
+
 
 WORKLOADS = {'flat': FlatWorkload, 'lca': LcaWorkload,
              'lca_free': LcaFreeWorkload, 'ordinal': OrdinalWorkload}
@@ -250,10 +295,20 @@ def cpu_baseline(wl, budget_s=15.0):
     """Time the pure-Python restatement of the reference
     (oracle/woltka_oracle.py: per-read assigners + counter, chunks of 1024
     queries as workflow.py:584) on a bounded sample of the same workload, one
-    core; also time the plain-C oracle on the same sample."""
+    core."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import woltka_oracle as orc
     probe = 100_000
+    if hasattr(wl, 'cpu_time'):
+        n, t = wl.cpu_time(probe)
+        more = int(min(n / t * budget_s, wl.records))
+        if more > probe * 1.5:
+            n, t = wl.cpu_time(more)
+        return {'value': round(n / t, 1), 'unit': 'records/s', 'cores': 1,
+                'kind': 'port',
+                'sample': (f'{n} records of the same workload, pure-Python '
+                           f'restatement of the reference ({wl.cpu_what}), '
+                           f'1 core, {t:.1f} s; text parsing excluded')}
     s = wl.cpu_sample(probe)
     if s is None:
         return None
