@@ -125,15 +125,17 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
 /* Tuning knobs: "lds_slots" (LDS front-cache slots per workgroup, power of two
  * in [64, 8192]), "use_lds" (0/1), "tiled" (0/1: LDS-staged classify kernel),
  * "dense" (0/1: dense LDS bins for small id spaces), "plog" (0 off / 1 auto / 2
- * always: partitioned miss log), "plog_max_bytes", "log_parts" (0 auto / 256 /
- * 1024 hash partitions of that log), "threads" (workgroup size of
+ * always: partitioned miss log), "plog_max_bytes", "log_parts" (0 auto, or a
+ * power of two in [64, 1024]: hash partitions of that log), "threads" (workgroup size of
  * the direct classify kernel), "blocks_per_cu"
  * (classify grid size per CU, 1..32), "split" (0 off / 1 on: single-candidate
  * reads in a first small kernel, the rest compacted into per-workgroup lists
  * for the generic kernel), "subject_bins" (0/1: with a small subject table the
  * first pass histograms subject indices and the assigners run once per
  * subject), "hot_bins" (0/1: for larger tables the first 24,576 subject indices
- * are histogrammed, the others evaluated per read), "single_blocks_per_cu" (grid of the first pass).
+ * are histogrammed, the others evaluated per read), "count_kernel" (0/1: the
+ * subject histogram as its own statically pipelined kernel),
+ * "single_blocks_per_cu" (grid of the first pass).
  * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 

@@ -207,6 +207,8 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
                  dict(dense=1, plog=1, plog_max_bytes=4 << 30, split=2),
                  dict(dense=0, plog=0, split=2), dict(dense=0, plog=2, split=2),
                  dict(dense=0, plog=2, plog_max_bytes=1 << 22, split=2),
+                 # the subject histogram by the templated first-pass kernel
+                 dict(dense=1, plog=1, plog_max_bytes=4 << 30, count_kernel=0),
                  # the per-read first pass instead of the subject histogram
                  dict(dense=1, plog=1, plog_max_bytes=4 << 30, subject_bins=0),
                  dict(dense=0, plog=0), dict(dense=0, plog=2),
@@ -216,7 +218,7 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
                  dict(dense=0, plog=2, plog_max_bytes=1 << 22, log_parts=256,
                       split=2),
                  dict(dense=1, plog=1, split=0, subject_bins=1, log_parts=0,
-                      plog_max_bytes=4 << 30)):
+                      plog_max_bytes=4 << 30, count_kernel=1)):
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.counts_clear()
@@ -227,6 +229,7 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     ctx.set_option('plog', 1)
     ctx.set_option('plog_max_bytes', 4 << 30)
     ctx.set_option('log_parts', 0)
+    ctx.set_option('count_kernel', 1)
     # per-read assignments and statistics through the forced split
     ctx.set_option('split', 2)
     ctx.counts_clear()

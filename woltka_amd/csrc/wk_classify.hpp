@@ -1156,6 +1156,95 @@ __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, u
     cache_finish(cache, a);
 }
 
+// Count first, classify later, as its own kernel (what classify_single_kernel<
+// true, ., 4> computes when the bins cover the whole subject table): the three
+// load stages are kept in a ring of kRing register sets that is addressed by
+// *code position* — the loop body is unrolled kRing times — instead of being
+// rotated with register copies.  A copy of a register that a load has not
+// filled yet makes the compiler wait for every load in flight at the loop's
+// back edge (s_waitcnt vmcnt(0)), which leaves one round of loads per wave in
+// flight; here the offsets of three rounds and the subject indices of two are
+// outstanding while a round is counted.
+__global__ void __launch_bounds__(1024) count_subjects_kernel(ClassifyArgs a, uint32_t lds_slots,
+                                                              unsigned long long* __restrict__ left_mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsCache cache{};
+#ifdef WK_ABLATE
+    cache.ablate = a.ablate;
+#endif
+    cache_setup(cache, a, smem, lds_slots);
+    constexpr int kReads = 4;  // reads per thread and round, 64 apart in the wave's window
+    constexpr int kRing = 5;   // rounds in flight: offsets t+4 .. t+2, subject indices t+2 .. t+1, count t
+    constexpr int kAhead = 2;  // rounds between a round's subject-index loads and its counting
+    const uint32_t n_reads = (uint32_t)a.n_reads, last = n_reads - 1u;
+    const uint32_t n_subjects = (uint32_t)a.n_subjects;
+    const uint32_t tile = blockDim.x * (uint32_t)kReads;
+    const uint32_t stride = gridDim.x * tile;
+    const char* __restrict__ qoff_b = reinterpret_cast<const char*>(a.qoff);
+    const char* __restrict__ subj_b = reinterpret_cast<const char*>(a.subj);
+    const uint32_t lane_off = (threadIdx.x >> 6) * (kWave * (uint32_t)kReads) + (threadIdx.x & (kWave - 1));
+    struct Round {
+        int32_t s[kReads], e[kReads];
+        uint32_t c[kReads];
+    };
+    Round ring[kRing];
+    auto load_offsets = [&](uint32_t base, Round& x) {
+#pragma unroll
+        for (int k = 0; k < kReads; ++k) {
+            const uint32_t i = base + lane_off + (uint32_t)k * kWave;
+            const uint32_t off = (i < last ? i : last) << 2;  // clamped: harmless re-read past the end
+            x.s[k] = *reinterpret_cast<const int32_t*>(qoff_b + off);
+            x.e[k] = *reinterpret_cast<const int32_t*>(qoff_b + off + 4u);
+        }
+    };
+    auto load_firsts = [&](Round& x) {
+#pragma unroll
+        for (int k = 0; k < kReads; ++k)
+            x.c[k] = (x.e[k] > x.s[k]) ? *reinterpret_cast<const uint32_t*>(subj_b + ((uint32_t)x.s[k] << 2))
+                                       : 0xFFFFFFFFu;
+    };
+    uint32_t handled = 0;
+    auto count_round = [&](uint32_t base, const Round& x) {
+#pragma unroll
+        for (int k = 0; k < kReads; ++k) {
+            const uint32_t r = base + lane_off + (uint32_t)k * kWave;
+            const int32_t n = x.e[k] - x.s[k];
+            const bool in = r < n_reads;
+            const bool mine = in & (n == 1) & (x.c[k] < n_subjects);
+            handled += mine ? 1u : 0u;
+            // one bit per read: left for the second pass (several candidates, or
+            // a subject index outside the table, which that pass reports)
+            const unsigned long long left = __ballot(in & (n > 0) & !mine);
+            if ((threadIdx.x & (kWave - 1)) == 0 && r < n_reads) left_mask[r >> 6] = left;
+#ifdef WK_ABLATE
+            if (a.ablate & 9) continue;
+#endif
+            if (mine) atomicAdd(&cache.dense[x.c[k]], 1u);
+        }
+    };
+    uint32_t base = blockIdx.x * tile;
+    // prologue: offsets of rounds 0 .. kRing-2, subject indices of rounds 0 .. kAhead-1
+#pragma unroll
+    for (int u = 0; u < kRing - 1; ++u) load_offsets(base + (uint32_t)u * stride, ring[u]);
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) load_firsts(ring[u]);
+    bool more = base < n_reads;
+    while (more) {
+#pragma unroll
+        for (int u = 0; u < kRing; ++u) {  // round t lives in ring[t % kRing]
+            if (more) {
+                load_offsets(base + (uint32_t)(kRing - 1) * stride, ring[(u + kRing - 1) % kRing]);
+                load_firsts(ring[(u + kAhead) % kRing]);
+                count_round(base, ring[u]);
+                base += stride;
+                more = base < n_reads;
+            }
+        }
+    }
+    flush_stats(a, handled, handled);
+    cache_finish(cache, a);
+}
+
 // Column sums of the workgroups' dense-bin slab rows -> count table.  One key
 // per non-empty bin, so no two adds ever meet on a slot.  A workgroup owns 64
 // adjacent bins (one 256-byte segment per slab row) and splits the rows over

@@ -137,6 +137,7 @@ struct wk_ctx {
     // rest): 0 = off, 1/2 = on whenever the chunk qualifies
     int use_split = 1;
     int single_blocks_per_cu = 1;
+    int use_count_kernel = 1;  // count-first pass as count_subjects_kernel (statically pipelined)
     DevBuf left_mask, left_list, first_slab;
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
@@ -300,6 +301,8 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<true, true, 4>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count_subjects_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, 1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1>),
@@ -407,6 +410,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     }
     if (!strcmp(name, "subject_bins")) {
         c->use_subject_bins = value ? 1 : 0;
+        return WK_OK;
+    }
+    if (!strcmp(name, "count_kernel")) {
+        c->use_count_kernel = value ? 1 : 0;
         return WK_OK;
     }
     if (!strcmp(name, "single_blocks_per_cu")) {
@@ -886,8 +893,12 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     // reads per workgroup: its rounds x 4096
                     const int64_t rounds = ((c->n_reads + 4095) / 4096 + blocks1 - 1) / blocks1;
                     first.slab16 = rounds * 4096 <= 65535 ? 1 : 0;
-                    hipLaunchKernelGGL((classify_single_kernel<true, true, 4>), dim3(blocks1), dim3(1024),
-                                       64 * 16 + (size_t)c->n_subjects * 4, c->stream, first, 64u, mask);
+                    if (c->use_count_kernel)
+                        hipLaunchKernelGGL(count_subjects_kernel, dim3(blocks1), dim3(1024),
+                                           64 * 16 + (size_t)c->n_subjects * 4, c->stream, first, 64u, mask);
+                    else
+                        hipLaunchKernelGGL((classify_single_kernel<true, true, 4>), dim3(blocks1), dim3(1024),
+                                           64 * 16 + (size_t)c->n_subjects * 4, c->stream, first, 64u, mask);
                 } else if (hot_subjects) {
                     // hash cache + log cursors like the second pass (shared streams),
                     // plus the hot subjects' bins behind them
