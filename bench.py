@@ -79,6 +79,9 @@ class FlatWorkload:
     name = 'synthetic SAM 10M reads x 1 hit, flat subject->genus map, rank genus'
     dominant = 'classify'
     families = ('classify', 'leftover', 'dense_merge')
+    # timer family -> kernel symbol in the rocprofv3 summaries (profiles/)
+    symbols = {'classify': 'wk::count_subjects_kernel',
+               'leftover': 'wk::classify_kernel<true, true>'}
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -120,6 +123,9 @@ class LcaWorkload:
     """configs[2]: multi-hit reads, taxonomy tree, 3 ranks + free in one pass."""
     dominant = 'classify'
     families = ('classify', 'leftover', 'partition_merge')
+    symbols = {'classify': 'wk::classify_single_kernel<true, false, 2, false, true>',
+               'leftover': 'wk::classify_kernel<true, true>',
+               'partition_merge': 'wk::partition_merge_kernel'}
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -448,6 +454,8 @@ def main():
                          'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': measured_traffic(a.workload, a.scale),
                          'kernel': dominant,
+                         'kernel_symbol': getattr(wl, 'symbols', {}).get(
+                             dominant, f'wk::{dominant}_kernel'),
                          'kernel_ms': round(kern_ms, 4),
                          'algorithmic_bytes': alg_bytes,
                          'kernels_ms': {f: round(v, 4)
