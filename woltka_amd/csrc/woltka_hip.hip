@@ -820,7 +820,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 }
             }
             size_t lds = (size_t)lds_slots * 16;
-            // partitioned miss log: worth its fixed cost (1024-workgroup merge
+            // partitioned miss log: worth its fixed cost (one more merge
             // launch) only when many keys can miss the LDS cache
             uint32_t plog_cap = 0;
             // contributions that can reach the log: all of them, or — when the
