@@ -215,6 +215,9 @@ int upload(wk_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     return WK_OK;
 }
 
+// reads per thread and round in the per-read first pass (classify_single_kernel)
+constexpr int kPerReadItems = 2;
+
 int grid_for(int64_t n, int threads, int max_blocks) {
     int64_t b = (n + threads - 1) / threads;
     if (b < 1) b = 1;
@@ -303,17 +306,17 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count_subjects_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, 1>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, kPerReadItems>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, kPerReadItems>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<true, true, 2, false, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<true, false, 2, false, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, 1, true>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, true, kPerReadItems, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, 1, true>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, kPerReadItems, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
@@ -935,16 +938,16 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                         first.plog_cap = a.plog_cap;
                     }
                     if (feature_chunk && n_jobs == 1)
-                        hipLaunchKernelGGL((classify_single_kernel<false, true, 1, true>), dim3(blocks), dim3(c->threads), lds1,
+                        hipLaunchKernelGGL((classify_single_kernel<false, true, kPerReadItems, true>), dim3(blocks), dim3(c->threads), lds1,
                                            c->stream, first, (uint32_t)lds_slots, mask);
                     else if (feature_chunk)
-                        hipLaunchKernelGGL((classify_single_kernel<false, false, 1, true>), dim3(blocks), dim3(c->threads), lds1,
+                        hipLaunchKernelGGL((classify_single_kernel<false, false, kPerReadItems, true>), dim3(blocks), dim3(c->threads), lds1,
                                            c->stream, first, (uint32_t)lds_slots, mask);
                     else if (n_jobs == 1)
-                        hipLaunchKernelGGL((classify_single_kernel<false, true, 1>), dim3(blocks), dim3(c->threads), lds1,
+                        hipLaunchKernelGGL((classify_single_kernel<false, true, kPerReadItems>), dim3(blocks), dim3(c->threads), lds1,
                                            c->stream, first, (uint32_t)lds_slots, mask);
                     else
-                        hipLaunchKernelGGL((classify_single_kernel<false, false, 1>), dim3(blocks), dim3(c->threads), lds1,
+                        hipLaunchKernelGGL((classify_single_kernel<false, false, kPerReadItems>), dim3(blocks), dim3(c->threads), lds1,
                                            c->stream, first, (uint32_t)lds_slots, mask);
                 }
                 ktimer_end(c, kt);
