@@ -804,7 +804,12 @@ __device__ __forceinline__ uint32_t compact_left(const ClassifyArgs& a, uint32_t
 // Direct variant: one thread per read, candidates read straight from HBM.
 // Kept as the simple baseline of the tiled kernel (A/B via the "tiled" option)
 // and used when the LDS front cache is switched off.
-template <bool kUseLds, bool kListed = false>
+//
+// kPath fixes the kind of candidates at compile time — 0: subject indices with
+// 4-column rows, 1: subject indices with rows of another width, 2: feature ids —
+// so that a launch carries one copy of the evaluator instead of three (80 KB of
+// code against a 64 KB instruction cache); -1 decides at run time.
+template <bool kUseLds, bool kListed = false, int kPath = -1>
 __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool listed = kUseLds && kListed;
@@ -861,7 +866,8 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         process_read<kUseLds>(a, cache, cand, n, rr, g, first);
     };
 
-    if (a.rows != nullptr && a.row_w == 4) {
+    const bool rows4_path = kPath < 0 ? (a.rows != nullptr && a.row_w == 4) : kPath == 0;
+    if (rows4_path) {
         // stages: offsets (i+3) -> first subject index (i+2) -> its row (i+1) -> evaluate (i)
         const int4* __restrict__ rows4 = reinterpret_cast<const int4*>(a.rows);
         auto load_first = [&](int32_t s, int32_t e) -> int32_t { return (e > s) ? a.subj[s] : 0; };
@@ -929,7 +935,7 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         }
 #undef WK_RID
     } else {
-        const bool use_rows = a.rows != nullptr;
+        const bool use_rows = kPath < 0 ? a.rows != nullptr : kPath == 1;
         // first candidate of a read -> its feature id (subject rows: one more gather)
         auto first_feature = [&](int32_t s, int32_t e) -> int32_t {
             if (e <= s) return 0;

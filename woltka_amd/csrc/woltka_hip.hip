@@ -298,9 +298,17 @@ int wk_create(int device, wk_ctx** out) {
     }
     // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
     // (160 KiB per CU minus the kernels' few bytes of static LDS)
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false>),
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, true>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, true, 0>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, true, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, true, 2>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<true, true, 4>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
@@ -974,10 +982,21 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     bins = 0;
                 }
             }
-            if (split)
-                hipLaunchKernelGGL((classify_kernel<true, true>), dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)lds_slots);
+            // one evaluator per kind of candidates (see classify_kernel's kPath)
+            const int path = (a.rows != nullptr && a.row_w == 4) ? 0 : a.rows != nullptr ? 1 : 2;
+            const dim3 grid(blocks), block(c->threads);
+            if (split && path == 0)
+                hipLaunchKernelGGL((classify_kernel<true, true, 0>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
+            else if (split && path == 1)
+                hipLaunchKernelGGL((classify_kernel<true, true, 1>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
+            else if (split)
+                hipLaunchKernelGGL((classify_kernel<true, true, 2>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
+            else if (path == 0)
+                hipLaunchKernelGGL((classify_kernel<true, false, 0>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
+            else if (path == 1)
+                hipLaunchKernelGGL((classify_kernel<true, false, 1>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
             else
-                hipLaunchKernelGGL((classify_kernel<true, false>), dim3(blocks), dim3(c->threads), lds, c->stream, a, (uint32_t)lds_slots);
+                hipLaunchKernelGGL((classify_kernel<true, false, 2>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
             if (plog_cap) {
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "partition_merge");
