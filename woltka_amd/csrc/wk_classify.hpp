@@ -9,14 +9,17 @@
 //   workflow.assign_readmap's Unassigned substitution (woltka/workflow.py:1038-1039)
 //
 // Kernels, in the order a chunk meets them:
-//   classify_single_kernel   pass 1 of the two-class split: reads with exactly one
-//                            candidate (per-subject histogram in LDS bins when the
-//                            subject table is small, per-read evaluation else) + one
-//                            "left for pass 2" bit per read
-//   classify_kernel<., true> pass 2: merges pass 1's bins into the count table,
+//   count_subjects_kernel    pass 1 of the two-class split when the subject table
+//                            fits the LDS bins: histogram of the subject indices of
+//                            the reads with exactly one candidate + one "left for
+//                            pass 2" bit per read
+//   classify_single_kernel   pass 1 otherwise: hot subjects in bins + per-read
+//                            evaluation of the others, or per-read evaluation alone
+//   classify_kernel<., true, path> pass 2: merges pass 1's bins into the count table,
 //                            compacts its share of the bits into a read list, walks
-//                            it with the generic evaluator (process_read)
-//   classify_kernel<., false> the generic evaluator over all reads (split off /
+//                            it with the generic evaluator (process_read); one
+//                            instantiation per kind of candidates (path)
+//   classify_kernel<., false, path> the generic evaluator over all reads (split off /
 //                            not applicable); classify_tiled_kernel: LDS-staged variant
 //   partition_merge_kernel   aggregation of the partitioned miss log
 //   dense_merge_kernel       column sums of dense-bin slab rows (unsplit dense mode)
