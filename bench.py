@@ -81,7 +81,7 @@ class FlatWorkload:
     families = ('classify', 'leftover', 'dense_merge')
     # timer family -> kernel symbol in the rocprofv3 summaries (profiles/)
     symbols = {'classify': 'wk::count_subjects_kernel',
-               'leftover': 'wk::classify_kernel<true, true>'}
+               'leftover': 'wk::classify_kernel<true, true, 0>'}
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -124,7 +124,7 @@ class LcaWorkload:
     dominant = 'classify'
     families = ('classify', 'leftover', 'partition_merge')
     symbols = {'classify': 'wk::classify_single_kernel<true, false, 2, false, true>',
-               'leftover': 'wk::classify_kernel<true, true>',
+               'leftover': 'wk::classify_kernel<true, true, 0>',
                'partition_merge': 'wk::partition_merge_kernel'}
 
     def __init__(self, ctx, seed, scale=1.0):
