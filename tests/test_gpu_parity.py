@@ -562,3 +562,78 @@ def test_subject_sets_with_long_reads_vs_oracle(ctx, with_group):
         st = ctx.stats()
         assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
         assert st['n_records'] == prob['subj'].size
+
+
+def _nested_gene_problem(rng, n_reads=4000):
+    """A few genomes whose genes pile up on top of each other (a read matches
+    up to ~40 of them) next to ordinary ones: queries with more distinct genes
+    than wk_ordinal_classify keeps in LDS."""
+    goff, gs, ge = [0], [], []
+    for g in range(6):
+        if g < 2:       # 60 genes over the same 4 kb
+            s = np.sort(rng.integers(0, 600, 60))
+            e = s + rng.integers(2500, 4000, 60)
+        else:
+            s = np.sort(rng.integers(0, 50000, 80))
+            e = s + rng.integers(300, 1500, 80)
+        gs.append(s)
+        ge.append(e)
+        goff.append(goff[-1] + s.size)
+    gs, ge = np.concatenate(gs), np.concatenate(ge)
+    order = np.concatenate([a + np.argsort(gs[a:b], kind='stable')
+                            for a, b in zip(goff[:-1], goff[1:])])
+    gs, ge = gs[order].astype(np.int32), ge[order].astype(np.int32)
+    feat = rng.permutation(gs.size).astype(np.int32) + 5   # arbitrary ids
+    nh = rng.integers(1, 4, n_reads)
+    hoff = np.concatenate([[0], np.cumsum(nh)]).astype(np.int32)
+    n_hits = int(hoff[-1])
+    genome = rng.integers(0, 6, n_hits).astype(np.int32)
+    length = rng.integers(50, 250, n_hits).astype(np.uint32)
+    beg = np.where(genome < 2, rng.integers(0, 3500, n_hits),
+                   rng.integers(0, 51000, n_hits)).astype(np.int32)
+    length[rng.random(n_hits) < 0.02] = 0            # dropped hits
+    genome[rng.random(n_hits) < 0.02] = 7            # unknown genome
+    return dict(genome_off=np.asarray(goff, np.int32), gstart=gs, gend=ge,
+                gene_feature=feat, genome=genome, beg=beg,
+                end=(beg + length.astype(np.int32)).astype(np.int32),
+                length=length, hoff=hoff)
+
+
+@pytest.mark.parametrize('flags', [0, nat.F_UNIQ,
+                                   nat.F_UNIQ | nat.F_UNASSIGNED])
+def test_nested_genes_vs_oracle(ctx, flags):
+    """Queries that match dozens of stacked genes (the rescanning branch of
+    match_write, long gene lists with repeats across a query's hits), dropped
+    and unknown-genome hits, groups with excluded reads: pair list and counts
+    against the oracle."""
+    rng = np.random.default_rng(77)
+    p = _nested_gene_problem(rng)
+    n_reads = p['hoff'].size - 1
+    ctx.set_genes(p['genome_off'], p['gstart'], p['gend'], p['gene_feature'])
+    ctx.counts_reserve(1 << 20)
+    jobs = [nat.Job(nat.MODE_NONE, 0, flags, 0, 0.0)]
+    ojobs = [dict(mode=nat.MODE_NONE, flags=flags)]
+    for th in (0.8, 0.5):
+        for group in (None, rng.integers(-1, 5, n_reads).astype(np.int32)):
+            ctx.counts_clear()
+            ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
+                              p['hoff'], th, group=group)
+            ctx.ordinal_match()
+            subj, qoff = ctx.chunk_download()
+            ph, pg = c_oracle.ordinal_match(p['genome_off'], p['gstart'],
+                                            p['gend'], p['genome'], p['beg'],
+                                            p['end'], p['length'], th)
+            assert subj.size == ph.size
+            assert (np.diff(qoff) > 8).any()
+            read_of_hit = np.repeat(np.arange(n_reads), np.diff(p['hoff']))
+            exp = np.unique(np.stack([read_of_hit[ph], p['gene_feature'][pg]
+                                      .astype(np.int64)]), axis=1)
+            got_r = np.repeat(np.arange(n_reads), np.diff(qoff))
+            got = np.unique(np.stack([got_r, subj.astype(np.int64)]), axis=1)
+            assert np.array_equal(got, exp)
+            ctx.classify_staged(jobs)
+            keys, vals = ctx.counts_fetch()
+            _, contrib = c_oracle.classify(subj, qoff, ojobs, None, None, 0,
+                                           group)
+            okeys, ocnt = np.unique(contrib, return_counts=True)
+            assert_same_counts(keys, vals, okeys, ocnt, (flags, th))
