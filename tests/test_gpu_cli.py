@@ -423,3 +423,57 @@ def test_byte_range_parts_equal_whole_file(tmp_path):
                  for i in range(3)]
     assert shard.merge_profiles(parts) == whole
     assert sorted(whole['none']) == ['S01', 'S02', 'S03', 'S04', 'S05']
+
+
+def test_assign_readmap_entry_point(tmp_path):
+    """workflow.assign_readmap — the reference's per-chunk entry point
+    (workflow.py:941-1058) — driven chunk by chunk like the reference drives
+    it: counts (plain, stratified, size-normalised), the Unassigned
+    substitution and the read map against what the reference's assigners and
+    counters gave on the same queries (classify_random.json)."""
+    from helpers import assert_counts_match, golden_counts, load_vectors
+    from woltka_amd.workflow import assign_readmap
+    checked = 0
+    for case in load_vectors('classify_random.json')[:12]:
+        tree, rankdic = case['tree'], case['rankdic']
+        qry = case['queries']
+        sub = [tuple(x) for x in case['subque']]
+        for run in case['runs']:
+            st = run['params']
+            rank = st['rank']
+            kw = dict(tree=tree, rankdic=rankdic, root=case['root'],
+                      uniq=st.get('uniq', False),
+                      major=st.get('major') and st['major'] / 100,
+                      above=st.get('above', False),
+                      subok=st.get('subok', False),
+                      unasgd=st.get('unassigned', False))
+            for name, extra, gold in (
+                    ('plain', {}, run['counts']),
+                    ('strat', dict(strata=case['strata']),
+                     golden_counts(run['strat_counts'], True)),
+                    ('sized', dict(sizes=case['sizes']), run['sized'])):
+                data, assigners = {rank: {}}, {}
+                half = len(qry) // 2
+                for lo, hi in ((0, half), (half, len(qry))):    # two chunks
+                    assign_readmap(qry[lo:hi], sub[lo:hi], data, rank, 'S1',
+                                   assigners, **kw, **extra)
+                for engine in assigners.values():
+                    engine.close()
+                assert_counts_match(data[rank].get('S1', {}), gold, 1e-9)
+                checked += 1
+    assert checked > 300
+    # the read map of a chunk, appended like the reference does
+    case = load_vectors('classify_random.json')[0]
+    run = next(r for r in case['runs'] if r['params'] == dict(rank='free'))
+    outdir = tmp_path / 'maps'
+    outdir.mkdir()
+    data, assigners = {'free': {}}, {}
+    assign_readmap(case['queries'], [tuple(x) for x in case['subque']], data,
+                   'free', 'S1', assigners, rank2dir={'free': str(outdir)},
+                   outzip=None, tree=case['tree'], rankdic=case['rankdic'],
+                   root=case['root'])
+    for engine in assigners.values():
+        engine.close()
+    lines = (outdir / 'S1.txt').read_text().splitlines()
+    exp = [f'{q}\t{t}' for q, t in zip(case['queries'], run['taxque']) if t]
+    assert lines == exp

@@ -99,7 +99,7 @@ class Engine:
 
     def __init__(self, tree, rankdic, root, ranks, uniq=False, major=None,
                  above=False, subok=False, unasgd=False, device=0,
-                 table_slots=None, sizes=None):
+                 table_slots=None, sizes=None, major_frac=None):
         self.ctx = nat.Context(device)
         self.ranks = list(ranks)
         self.use_tree = bool(tree)
@@ -146,7 +146,9 @@ class Engine:
                     slot_of[code] = len(slot_of)
                     self.ctx.build_rank_table(slot_of[code], code)
                 slot = slot_of[code]
-                frac = (major / 100) if major else 0.0
+                # (assign_readmap's callers hand over the fraction itself)
+                frac = major_frac if major_frac else \
+                    (major / 100) if major else 0.0
             self.jobs.append(nat.Job(mode, slot, flags, 0, frac))
             self.modes.append(mode)
             self.slots.append(slot)

@@ -300,6 +300,43 @@ def classify(
     return data
 
 
+def assign_readmap(qryque, subque, data, rank, sample, assigners, cache=1024,
+                   rank2dir=None, outzip=None, tree=None, rankdic=None,
+                   namedic=None, root=None, uniq=False, major=None,
+                   above=False, subok=False, sizes=None, unasgd=False,
+                   strata=None):
+    """One chunk of queries at one rank: classify, write the read map if asked
+    for, and add the counts into ``data[rank][sample]`` — the reference's
+    per-chunk entry point (workflow.py:941-1058) on the GPU.
+
+    ``classify()`` above does not go through it (it keeps all ranks of a chunk
+    in one launch and the counts on the device until the end); it is here for
+    callers that drive the reference chunk by chunk.  ``assigners`` caches one
+    device engine per rank, like the reference caches one assigner per rank;
+    ``cache`` (an LRU size) has no counterpart.  ``major`` is the fraction, as
+    in the reference.  Counts are exact: a cell that the reference holds as a
+    float sum of 1/k terms is an ``int`` when integral, else the correctly
+    rounded quotient."""
+    plain = rank is None or rank == 'none' or tree is None
+    key = 'none' if plain else rank
+    engine = assigners.get(key)
+    if engine is None:
+        engine = assigners[key] = Engine(
+            None if plain else tree, rankdic, root, [key], uniq=uniq,
+            above=above, subok=subok, unasgd=unasgd, sizes=sizes,
+            major_frac=major)
+    qryque, subque = list(qryque), list(subque)
+    strata_of = [strata.get(q) for q in qryque] if strata else None
+    part = {key: {}}
+    engine.run_chunk(part, qryque, subque, sample, strata_of, None,
+                     None if rank2dir is None else {key: rank2dir[rank]},
+                     outzip, namedic, False)
+    engine.finish(part)
+    cells = data[rank].setdefault(sample, {})
+    for feature, value in part[key].get(sample, {}).items():
+        cells[feature] = cells[feature] + value if feature in cells else value
+
+
 def demux_labels(qryque, samples=None, sep='_'):
     """workflow.demultiplex (workflow.py:844-909) as per-read labels: returns
     (sample of each read or ``False`` when dropped, read ids).  A query splits
