@@ -168,6 +168,24 @@ def read_map_1st(fh, sep='\t'):
             yield key, rest.partition(sep)[0].rstrip()
 
 
+def read_map_all(fh, sep='\t'):
+    """(first column, [other columns]) of lines with at least two columns
+    (woltka/file.py:409-426)."""
+    for line in fh:
+        key, found, rest = line.partition(sep)
+        if found:
+            yield key, rest.rstrip().split(sep)
+
+
+def read_map_many(fh, sep='\t'):
+    """{key: [values]} over all lines of a mapping file, one-to-many lines
+    and repeated keys alike (woltka/file.py:429-466)."""
+    res = {}
+    for key, values in read_map_all(fh, sep):
+        res.setdefault(key, []).extend(values)
+    return res
+
+
 def write_readmap(fh, qryque, taxque, namedic=None):
     """Write "query <tab> taxon" or "query <tab> taxon:n <tab> ..." lines;
     multiple assignments are listed by descending count, then name."""

@@ -13,7 +13,7 @@ from sys import exit
 import click
 
 from . import table as T
-from .file import readzip, read_map_1st
+from .file import readzip, read_map_1st, read_map_all, read_map_many
 from .tree import read_names
 from .workflow import scale_factor
 
@@ -24,24 +24,6 @@ def _step(message):
 
 def _done():
     click.echo(' Done.')
-
-
-def read_map_all(fh, sep='\t'):
-    """(first column, [other columns]) of lines with at least two columns
-    (woltka/file.py:409-426)."""
-    for line in fh:
-        key, found, rest = line.partition(sep)
-        if found:
-            yield key, rest.rstrip().split(sep)
-
-
-def read_map_many(fh, sep='\t'):
-    """{key: [values]} over all lines of a mapping file, one-to-many lines
-    and repeated keys alike (woltka/file.py:429-466)."""
-    res = {}
-    for key, values in read_map_all(fh, sep):
-        res.setdefault(key, []).extend(values)
-    return res
 
 
 def load_gene_lens(fh):

@@ -360,6 +360,27 @@ def demux_labels(qryque, samples=None, sep='_'):
     return labels, reads
 
 
+def demultiplex(qryque, subque, samples=None, sep='_'):
+    """{sample: (read ids, subject(s) queue)} of a multiplexed chunk, samples
+    in order of first appearance (workflow.py:844-909); the per-read form the
+    device path uses is ``demux_labels``."""
+    labels, reads = demux_labels(qryque, samples, sep)
+    res = {}
+    for label, read, subjects in zip(labels, reads, subque):
+        if label is not False:
+            ids, subs = res.setdefault(label, ([], []))
+            ids.append(read)
+            subs.append(subjects)
+    return res
+
+
+def strip_suffix(subque, sep):
+    """Subject ids cut at their last ``sep``, every query's subjects as a set
+    again (workflow.py:818-841); the packers do this while interning
+    (``pack_queries(trim=)``, the tokenizer's ``trimsub``)."""
+    return ({x.rsplit(sep, 1)[0] for x in subjects} for subjects in subque)
+
+
 def strata_labels(sample_of, reads, stratmap, zippers, csample, strata):
     """Stratum of every read (``None`` = not in the strata map, skipped by the
     counters, classify.py:239).  Strata files are (re)read when the current
