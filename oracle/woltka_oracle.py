@@ -102,7 +102,7 @@ def assign_free(subs, tree, root=None, subok=False):
     return None if lca == root else lca
 
 
-def majority(taxa, th):
+def majority(taxa, th=0.8):
     """classify.majority (woltka/classify.py:300-317) with util.count_list
     (woltka/util.py:387-403): None is a countable value; the comparison
     ``n >= len(taxa) * th`` is done in binary64."""

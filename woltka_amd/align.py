@@ -222,6 +222,54 @@ def parse_align(lines, fmt, excl=None, extra=False):
     raise ValueError(f'Invalid format code: "{fmt}".')
 
 
+def _named_parser(fmt, extra, filtered):
+    if filtered:
+        def parser(fh, excl):
+            return parse_align(fh, fmt, excl, extra)
+    else:
+        def parser(fh):
+            return parse_align(fh, fmt, None, extra)
+    parser.__name__ = (f'parse_{fmt}_file' + ('_ex' if extra else '') +
+                       ('_ft' if filtered else ''))
+    parser.__doc__ = (f'{fmt} lines -> (query, subjects) pairs'
+                      f'{" with alignment records" if extra else ""}'
+                      f'{"; queries hitting an excluded subject are dropped" if filtered else ""}'
+                      ' (the reference keeps one function per combination, '
+                      'align.py:258-1213; here all are parse_align).')
+    return parser
+
+
+# the reference's per-format entry points, by name
+parse_sam_file = _named_parser('sam', False, False)
+parse_sam_file_ex = _named_parser('sam', True, False)
+parse_sam_file_ft = _named_parser('sam', False, True)
+parse_sam_file_ex_ft = _named_parser('sam', True, True)
+parse_map_file = _named_parser('map', False, False)
+parse_map_file_ft = _named_parser('map', False, True)
+parse_b6o_file = _named_parser('b6o', False, False)
+parse_b6o_file_ex = _named_parser('b6o', True, False)
+parse_b6o_file_ft = _named_parser('b6o', False, True)
+parse_b6o_file_ex_ft = _named_parser('b6o', True, True)
+parse_paf_file = _named_parser('paf', False, False)
+parse_paf_file_ex = _named_parser('paf', True, False)
+parse_paf_file_ft = _named_parser('paf', False, True)
+parse_paf_file_ex_ft = _named_parser('paf', True, True)
+
+
+def assign_parser(fmt, extr=False, filt=False):
+    """The parser function of a format / flavour (align.py:226-255)."""
+    if fmt not in ('map', 'b6o', 'sam', 'paf'):
+        raise ValueError(f'Invalid format code: "{fmt}".')
+    name = f'parse_{fmt}_file' + ('_ex' if extr and fmt != 'map' else '') + \
+        ('_ft' if filt else '')
+    return globals()[name]
+
+
+def cigar_to_lens_ord(cigar):
+    """``cigar_to_lens`` on character codes (align.py:586-620); same result."""
+    return cigar_to_lens(cigar)
+
+
 def iter_align(fh, fmt=None, excl=None, extr=None):
     """align.iter_align (align.py:118-150): sniff the format if not given."""
     if not fmt:
