@@ -11,7 +11,9 @@ here against vectors produced by running the real reference (qiyunzhu/woltka
 v0.1.7, imported from /root/reference in the build container by
 ``tests/golden/make_golden.py``) and against the known-answer cases of the
 reference's own unit tests (woltka/tests/test_classify.py, test_tree.py,
-test_ordinal.py, test_align.py).
+test_ordinal.py, test_align.py).  In the build container the reference's
+``test_tree.py`` and ``test_classify.py`` also run against these functions
+themselves (``tools/ref_unit_tests.sh``: 18 / 18 pass).
 
 Each function cites the reference code it restates (paths relative to the
 reference repository root).
