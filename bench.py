@@ -122,8 +122,9 @@ class FlatWorkload:
 class LcaWorkload:
     """configs[2]: multi-hit reads, taxonomy tree, 3 ranks + free in one pass."""
     dominant = 'classify'
-    families = ('classify', 'leftover', 'partition_merge')
-    symbols = {'classify': 'wk::classify_single_kernel<true, false, 2, false, true>',
+    families = ('classify', 'weigh_merge', 'leftover', 'partition_merge')
+    symbols = {'classify': 'wk::weigh_subjects_kernel<true>',
+               'weigh_merge': 'wk::weigh_merge_kernel',
                'leftover': 'wk::classify_kernel<true, true, 0>',
                'partition_merge': 'wk::partition_merge_kernel'}
 
@@ -133,9 +134,10 @@ class LcaWorkload:
         n_reads = int(50_000_000 * scale)
         self.name = (f'synthetic SAM {n_reads / 1e6:g}M reads x <=16 hits, '
                      '2M-node taxonomy, ranks phylum,genus,species')
-        self.prob = p = synth.lca_problem(rng, n_nodes=2_000_000,
-                                          n_subjects=100_000, n_reads=n_reads,
-                                          with_names=False)
+        # (reads are sets of subjects, as the plain parsers produce them)
+        self.prob = p = synth.as_sets(synth.lca_problem(
+            rng, n_nodes=2_000_000, n_subjects=100_000, n_reads=n_reads,
+            with_names=False))
         h = p['hier']
         ctx.set_tree(h.parent, h.last, h.rank_code)
         self.jobs = []

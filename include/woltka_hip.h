@@ -84,6 +84,7 @@ extern "C" {
 /* subj_flags of wk_chunk_stage / wk_classify_chunk */
 #define WK_SUBJ_IS_SET 1
 #define WK_SUBJ_INDEXED 2
+#define WK_GROUP_UNIFORM 4 /* `group` points to ONE id that holds for every read */
 
 /* values written to the optional per-read assignment output */
 #define WK_ASSIGN_NONE (-1)  /* read not assigned (None)                     */
@@ -135,7 +136,9 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * subject), "hot_bins" (0/1: for larger tables the first 24,576 subject indices
  * are histogrammed, the others evaluated per read), "count_kernel" (0/1: the
  * subject histogram as its own statically pipelined kernel),
- * "single_blocks_per_cu" (grid of the first pass).
+ * "single_blocks_per_cu" (grid of the first pass), "weigh" (0 off / 1 auto / 2
+ * whenever the jobs allow it: plain rank jobs as one weighted histogram over
+ * subject indices, csrc/wk_weigh.hpp).
  * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 
@@ -204,7 +207,10 @@ int wk_log_fetch(wk_ctx* ctx, int32_t* out, int64_t cap, int64_t* n);
  *                     chunk holds < 2^31 records; larger inputs are chunked)
  *   group[n_reads]    optional stratum/sample slot per read, -1 = read is not
  *                     in the strata map and is skipped (classify.py:239);
- *                     NULL = group 0 for every read
+ *                     NULL = group 0 for every read; with WK_GROUP_UNIFORM
+ *                     group[0] is the group of every read (one sample per
+ *                     input file, workflow.py:304-335: the usual case, and
+ *                     the one the per-subject counting paths need)
  * `subj_flags`: WK_SUBJ_IS_SET promises that no read lists the same subject
  * twice (the reference's per-read sets, align.py:309); otherwise the device
  * removes duplicates itself.  WK_SUBJ_INDEXED: `subj` holds subject indices of
@@ -355,7 +361,7 @@ int wk_tok_new_subjects(wk_tok* tok, char* blob, int32_t* off);
  * this library is launched on).  wk_timer_begin/end bracket a region;
  * wk_timer_ms returns the elapsed GPU time of the last closed region.
  * wk_last_kernel_ms returns the duration of the most recent launch of the
- * named kernel family ("classify", "leftover", "dense_merge", "partition_merge",
+ * named kernel family ("classify", "leftover", "weigh_merge", "dense_merge", "partition_merge",
  * "match_count", "match_write", "scan", "rank_table", "compact"), measured with events around that launch; event
  * recording around individual kernels is enabled by wk_profile_kernels(1). */
 int wk_timer_begin(wk_ctx* ctx);

@@ -25,7 +25,7 @@ FEATURE_UNASSIGNED, MAX_FEATURE = 0x0FFFFFFF, 0x0FFFFFFE
 MODE_NONE, MODE_FREE, MODE_RANK = 0, 1, 2
 F_UNIQ, F_ABOVE, F_SUBOK, F_UNASSIGNED, F_SIZED = 1, 2, 4, 8, 16
 ASSIGN_NONE, ASSIGN_MULTI, ASSIGN_EMPTY = -1, -2, -3
-SUBJ_IS_SET, SUBJ_INDEXED = 1, 2
+SUBJ_IS_SET, SUBJ_INDEXED, GROUP_UNIFORM = 1, 2, 4
 MAX_RANK_SLOTS = MAX_JOBS * 4
 
 # every symbol the header declares (checked by tests/test_abi.py)
@@ -312,17 +312,22 @@ class Context:
 
     def chunk_stage(self, subj, qoff, group=None, subj_is_set=False,
                     indexed=False):
+        """``group``: None (group 0), one int (every read belongs to that
+        group: WK_GROUP_UNIFORM) or an int32 array with one entry per read."""
         subj, qoff = _arr(subj, np.int32), _arr(qoff, np.int32)
         n_reads = qoff.size - 1
-        if group is not None:
+        flags = (SUBJ_IS_SET if subj_is_set else 0) | \
+            (SUBJ_INDEXED if indexed else 0)
+        if group is not None and np.ndim(group) == 0:
+            group = np.array([int(group)], dtype=np.int32)
+            flags |= GROUP_UNIFORM
+        elif group is not None:
             group = _arr(group, np.int32)
             if group.size != n_reads:
                 raise ValueError('group must have one entry per read')
         self._check(self._lib.wk_chunk_stage(
             self._h, _ptr(subj, C.c_int32), _ptr(qoff, C.c_int32), n_reads,
-            _ptr(group, C.c_int32),
-            (SUBJ_IS_SET if subj_is_set else 0) |
-            (SUBJ_INDEXED if indexed else 0)))
+            _ptr(group, C.c_int32), flags))
         self._n_reads = n_reads
 
     def classify_staged(self, jobs, want_assign=False):

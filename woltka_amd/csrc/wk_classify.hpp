@@ -47,7 +47,8 @@ struct JobDev {
 struct ClassifyArgs {
     const int32_t* subj;   // [n_records]
     const int32_t* qoff;   // [n_reads + 1]
-    const int32_t* group;  // [n_reads] or null
+    const int32_t* group;  // [n_reads] or null: every read belongs to group_base
+    int32_t group_base;
     int64_t n_reads;
     const Node* nodes;  // [n_nodes] or null
     int32_t n_nodes;
@@ -329,7 +330,7 @@ __device__ __forceinline__ void count_add(const LdsCache& cache, const CountTabl
     }
 #endif
     if constexpr (kUseLds) {
-        if (cache.dense && k == 1 && g == 0 && feature < cache.dense_bins) {
+        if (cache.dense && k == 1 && g == cache.dense_group && feature < cache.dense_bins) {
             atomicAdd(&cache.dense[(uint32_t)jb * cache.dense_bins + feature], 1u);
             return;
         }
@@ -650,6 +651,7 @@ __device__ __forceinline__ void cache_setup(LdsCache& cache, const ClassifyArgs&
     if (a.dense_bins) {  // (behind the log cursors when both are in use: the hot-subject first pass)
         cache.dense = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16 + (a.plog ? a.log_parts * 4 : 0));
         cache.dense_bins = a.dense_by_subject ? 0u : a.dense_bins;  // count_add only knows (job, feature) bins
+        cache.dense_group = a.group_base;
         const uint32_t nb = a.dense_total;
         for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) cache.dense[i] = 0u;
     }
@@ -752,11 +754,11 @@ __device__ __forceinline__ void merge_first_pass(const ClassifyArgs& a, uint32_t
                             if (!(job.flags & WK_F_UNASSIGNED)) continue;
                             out = WK_FEATURE_UNASSIGNED;
                         }
-                        table_add(a.table, make_key((uint32_t)jb, 1u, 0u, (uint32_t)out), sum);
+                        table_add(a.table, make_key((uint32_t)jb, 1u, (uint32_t)a.group_base, (uint32_t)out), sum);
                     }
                 } else {
                     const uint32_t bins = a.first_total / (uint32_t)a.n_jobs;
-                    table_add(a.table, make_key(i / bins, 1u, 0u, i % bins), sum);
+                    table_add(a.table, make_key(i / bins, 1u, (uint32_t)a.group_base, i % bins), sum);
                 }
             }
         }
@@ -858,7 +860,7 @@ __global__ void __launch_bounds__(1024) classify_kernel(ClassifyArgs a, uint32_t
         s = a.qoff[c];
         e = a.qoff[c + 1];
     };
-    auto load_group = [&](int64_t i) -> int32_t { return a.group ? a.group[i < a.n_reads ? i : last] : 0; };
+    auto load_group = [&](int64_t i) -> int32_t { return a.group ? a.group[i < a.n_reads ? i : last] : a.group_base; };
     auto evaluate = [&](auto cand, int32_t n, int64_t rr, int32_t g, int32_t first) {
         my_reads += 1;
         my_records += (unsigned long long)n;
@@ -1108,7 +1110,7 @@ __global__ void __launch_bounds__(1024) classify_single_kernel(ClassifyArgs a, u
         load_rows(f1, w1);
         int32_t g[kReads];
 #pragma unroll
-        for (int k = 0; k < kReads; ++k) g[k] = 0;
+        for (int k = 0; k < kReads; ++k) g[k] = a.group_base;
         if (grouped) {
 #pragma unroll
             for (int k = 0; k < kReads; ++k) {
@@ -1259,7 +1261,8 @@ __global__ void __launch_bounds__(1024) count_subjects_kernel(ClassifyArgs a, ui
 // adjacent bins (one 256-byte segment per slab row) and splits the rows over
 // 16 waves; partial sums meet in LDS.
 __global__ void __launch_bounds__(1024) dense_merge_kernel(const uint32_t* __restrict__ slab, uint32_t n_rows,
-                                                           uint32_t n_jobs, uint32_t bins, CountTable table) {
+                                                           uint32_t n_jobs, uint32_t bins, uint32_t group,
+                                                           CountTable table) {
     __shared__ unsigned long long part[16][64];
     const uint32_t nb = n_jobs * bins;
     const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1275,7 +1278,7 @@ __global__ void __launch_bounds__(1024) dense_merge_kernel(const uint32_t* __res
         unsigned long long tot = 0;
 #pragma unroll
         for (int g = 0; g < 16; ++g) tot += part[g][lane];
-        if (tot) table_add(table, make_key(i / bins, 1, 0, i % bins), tot);
+        if (tot) table_add(table, make_key(i / bins, 1, group, i % bins), tot);
     }
 }
 
@@ -1377,7 +1380,7 @@ __global__ void __launch_bounds__(kTileThreads) classify_tiled_kernel(ClassifyAr
             } else {
                 my_reads += 1;
                 my_records += (unsigned long long)n;
-                const int32_t g = a.group ? a.group[r] : 0;
+                const int32_t g = a.group ? a.group[r] : a.group_base;
                 if (g >= (1 << WK_KEY_GROUP_BITS)) atomicOr(a.table.err, kErrGroupRange);
                 if (staged)
                     process_read<true>(a, cache, FeatureCand<const int32_t*>{lrec + (s - base), a.n_nodes}, n, r, g, lrec[s - base]);

@@ -90,10 +90,11 @@ struct LdsCache {
     unsigned long long* base;  // [buckets * 8]
     uint32_t bmask;            // buckets - 1
     // dense bins for the bulk of the traffic when the id space is small: the
-    // count of (job, k = 1, group 0, feature < dense_bins) is one ds_add_u32,
+    // count of (job, k = 1, dense_group, feature < dense_bins) is one ds_add_u32,
     // no key compare, and the bins of all workgroups are merged without atomics
     uint32_t* dense;           // [n_jobs * dense_bins] or null
     uint32_t dense_bins;
+    int32_t dense_group;       // the group the bins count (reads of other groups take the hash cache)
     // partitioned miss log: a key that finds no LDS slot is appended to the
     // stream of (this workgroup, hash partition) in HBM instead of paying a
     // device-scope atomic; partition_merge_kernel aggregates each partition in

@@ -16,6 +16,7 @@
 #include "wk_classify.hpp"
 #include "wk_device.hpp"
 #include "wk_ordinal.hpp"
+#include "wk_weigh.hpp"
 
 using namespace wk;
 
@@ -106,6 +107,7 @@ struct wk_ctx {
     const int32_t* cur_qoff = nullptr;
     int64_t n_reads = 0, n_records = 0;
     bool has_group = false, subj_is_set = false, chunk_valid = false;
+    int32_t group_base = 0;  // group of every read of a chunk staged without a group array
 
     // staged ordinal chunk
     DevBuf o_genome, o_beg, o_end, o_len, o_hoff, o_cnt, o_ub, o_first2, o_poff, o_pairs, o_qoff, o_tile_sum, o_tile_off;
@@ -139,6 +141,11 @@ struct wk_ctx {
     int single_blocks_per_cu = 1;
     int use_count_kernel = 1;  // count-first pass as count_subjects_kernel (statically pipelined)
     DevBuf left_mask, left_list, first_slab;
+    // weighted subject histogram (wk_weigh.hpp): 0 = off, 1 = auto, 2 = whenever applicable
+    int use_weigh = 1;
+    DevBuf w_slab, w_hi, w_invalid;
+    size_t w_hi_clean = 0;        // leading entries of w_hi known to be zero
+    bool rows_any_invalid = false;  // some subject lacks an ancestor at a rank column of the current rows
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
 };
@@ -326,6 +333,12 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, kPerReadItems, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_subjects_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_subjects_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_merge_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&partition_merge_kernel),
@@ -345,7 +358,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4, &c->ginfo,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -430,6 +443,11 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_blocks_per_cu")) {
         if (value < 1 || value > 8) return fail(c, WK_E_ARG, "single_blocks_per_cu must be in [1, 8]");
         c->single_blocks_per_cu = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "weigh")) {  // 0 = off, 1 = auto (large multi-hit chunks), 2 = whenever the jobs allow it
+        if (value < 0 || value > 2) return fail(c, WK_E_ARG, "weigh must be 0, 1 or 2");
+        c->use_weigh = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "tiled")) {
@@ -664,17 +682,23 @@ int wk_chunk_stage(wk_ctx* c, const int32_t* subj, const int32_t* qoff, int64_t 
     if (n_reads < 0 || !qoff) return fail(c, WK_E_ARG, "bad chunk arguments");
     const int64_t n_rec = qoff[n_reads];
     if (qoff[0] != 0 || n_rec < 0 || (n_rec > 0 && !subj)) return fail(c, WK_E_ARG, "qoff must start at 0 and end at n_records");
+    const bool uniform = (subj_flags & WK_GROUP_UNIFORM) != 0;
+    if (uniform && (!group || group[0] < 0 || group[0] >= (1 << WK_KEY_GROUP_BITS)))
+        return fail(c, WK_E_ARG, "WK_GROUP_UNIFORM needs one group id in [0, %d)", 1 << WK_KEY_GROUP_BITS);
     DeviceGuard guard(c->device);
     int rc;
+    // (64 bytes of slack behind the records: the weighted histogram reads them 16 bytes at a time)
+    HIP_TRY(c, c->c_subj.reserve((size_t)n_rec * sizeof(int32_t) + 64));
     if ((rc = upload(c, c->c_subj, subj, (size_t)n_rec * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->c_qoff, qoff, ((size_t)n_reads + 1) * sizeof(int32_t)))) return rc;
-    if (group && (rc = upload(c, c->c_group, group, (size_t)n_reads * sizeof(int32_t)))) return rc;
+    if (group && !uniform && (rc = upload(c, c->c_group, group, (size_t)n_reads * sizeof(int32_t)))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffers are only valid during the call
     c->cur_subj = c->c_subj.as<int32_t>();
     c->cur_qoff = c->c_qoff.as<int32_t>();
     c->n_reads = n_reads;
     c->n_records = n_rec;
-    c->has_group = group != nullptr;
+    c->has_group = group != nullptr && !uniform;
+    c->group_base = uniform ? group[0] : 0;
     c->subj_is_set = (subj_flags & WK_SUBJ_IS_SET) != 0;
     c->subj_indexed = (subj_flags & WK_SUBJ_INDEXED) != 0;
     c->chunk_valid = true;
@@ -692,6 +716,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
     a.subj = c->cur_subj;
     a.qoff = c->cur_qoff;
     a.group = c->has_group ? c->c_group.as<int32_t>() : nullptr;
+    a.group_base = c->has_group ? 0 : c->group_base;
     a.n_reads = c->n_reads;
     a.nodes = c->n_nodes ? c->nodes.as<Node>() : nullptr;
     a.n_nodes = c->n_nodes;
@@ -748,6 +773,20 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             }
             c->rows_sig = sig;
             c->rows_w = w;
+            // which subjects the weighted histogram cannot take (wk_weigh.hpp)
+            c->rows_any_invalid = false;
+            if (c->n_subjects > 0) {
+                HIP_TRY(c, c->w_invalid.reserve(((size_t)c->n_subjects / 32 + 2) * 4));
+                HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 6), 0, 8, c->stream));
+                hipLaunchKernelGGL(subject_invalid_kernel, dim3((c->n_subjects + 255) / 256), dim3(256), 0, c->stream,
+                                   c->subj_rows.as<int32_t>(), w, cols.n_cols, c->n_subjects,
+                                   c->w_invalid.as<uint32_t>(), reinterpret_cast<uint32_t*>(scalar_u64(c, 6)));
+                HIP_TRY(c, hipGetLastError());
+                uint32_t any = 0;
+                HIP_TRY(c, hipMemcpyAsync(&any, scalar_u64(c, 6), 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->rows_any_invalid = any != 0;
+            }
         }
         a.rows = c->subj_rows.as<int32_t>();
         a.row_w = w;
@@ -816,12 +855,43 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // order: the abundant ones) in bins, the others per read
             const bool hot_subjects = subject_ok && !by_subject && c->use_subject_bins >= 1 && c->use_hot_bins;
             constexpr int kHotBins = 24576;
+            // weighted subject histogram (wk_weigh.hpp): plain assigners only, every
+            // read a set of subject indices, one group, no per-read output
+            bool weigh = c->use_weigh && c->subj_indexed && c->subj_is_set && !c->has_group && !out_assign && !sized &&
+                         c->n_reads < (1ll << 30) && c->n_records < (1ll << 30) && c->n_subjects > 0;
+            for (int j = 0; j < n_jobs && weigh; ++j) {
+                if (jobs[j].mode == WK_MODE_NONE)
+                    weigh = !(jobs[j].flags & WK_F_UNIQ);
+                else if (jobs[j].mode == WK_MODE_RANK)
+                    weigh = !(jobs[j].flags & (WK_F_UNIQ | WK_F_ABOVE)) && !(jobs[j].major > 0.0);
+                else
+                    weigh = false;
+            }
+            // auto: chunks that are worth the fixed cost (slab rows of every
+            // workgroup) and are not all single-candidate reads (the count-first
+            // pass above is the faster special case of those)
+            if (weigh && c->use_weigh == 1)
+                weigh = c->n_reads >= (1 << 16) && c->n_records > c->n_reads + c->n_reads / 64;
+            uint32_t w_bins = 0, w_slices = 0, w_teams = 0, w_xcd = 8, w_inv_words = 0;
+            if (weigh) {
+                const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
+                if (cus % w_xcd) w_xcd = 1;
+                w_inv_words = c->rows_any_invalid ? ((uint32_t)c->n_subjects + 31u) / 32u : 0u;
+                const int64_t cap = ((int64_t)kWeighMaxLds - 4 * (int64_t)w_inv_words) / 4;
+                if (cap >= 1024) {
+                    w_slices = (uint32_t)((c->n_subjects + cap - 1) / cap);
+                    w_bins = (((uint32_t)c->n_subjects + w_slices - 1) / w_slices + 63u) & ~63u;
+                    if (w_bins > cap) w_bins = (uint32_t)cap;
+                    w_teams = (cus / w_xcd) / w_slices;
+                }
+                if (!w_teams || (int64_t)w_bins * w_slices < c->n_subjects) weigh = false;
+            }
             const int max_blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu);
             const int blocks = grid_for(c->n_reads, c->threads, max_blocks);
             // dense bins: small id space, subject-indexed chunk, no size-normalised job
             int64_t bins = 0;
             int lds_slots = c->lds_slots;
-            if (c->use_dense && c->subj_indexed && !by_subject && !hot_subjects) {
+            if (c->use_dense && c->subj_indexed && !by_subject && !hot_subjects && !weigh) {
                 const int64_t b = std::max<int64_t>(c->n_nodes, (int64_t)c->max_subject_feature + 1);
                 if (!sized && b * n_jobs <= 28672) {  // <= 112 KiB of bins + 32 KiB hash cache = 144 KiB LDS
                     bins = b;
@@ -841,7 +911,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // the streams overflow into the count table)
             const int64_t contrib = by_subject ? 3 * std::max<int64_t>(c->n_records - c->n_reads, 0) + 1024
                                                : c->n_records + c->n_reads;
-            if (!bins && (c->use_plog == 2 || (c->use_plog == 1 && contrib >= (1 << 22)))) {
+            if (!bins && !weigh && (c->use_plog == 2 || (c->use_plog == 1 && contrib >= (1 << 22)))) {
                 // partitions: the merge counts a partition in one LDS table of
                 // 8192 slots, so 256 partitions hold ~1.3 M distinct keys at a
                 // comfortable load; fewer partitions keep a workgroup's open
@@ -880,7 +950,69 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 a.dense_total = (uint32_t)(bins * n_jobs);
                 a.dense_slab = c->dense_slab.as<uint32_t>();
             }
-            if (split) {
+            if (weigh) {
+                // ---- weighted subject histogram + per-subject merge; the reads it
+                // does not cover go to the second pass below through left_mask
+                const uint32_t n_words = (uint32_t)((c->n_reads + 63) / 64);
+                const uint32_t list_seg = (((n_words + 15u) / 16u + (uint32_t)blocks - 1u) / (uint32_t)blocks) * 1024u;
+                const uint32_t n_teams = w_xcd * w_teams;
+                HIP_TRY(c, c->left_mask.reserve((size_t)n_words * 8));
+                HIP_TRY(c, c->left_list.reserve((size_t)blocks * list_seg * 4));
+                HIP_TRY(c, c->w_slab.reserve((size_t)w_slices * n_teams * w_bins * 4));
+                if ((size_t)c->n_subjects > c->w_hi_clean) {
+                    HIP_TRY(c, c->w_hi.reserve((size_t)c->n_subjects * 4 + ((size_t)c->n_subjects * 4) / 2));
+                    HIP_TRY(c, hipMemsetAsync(c->w_hi.p, 0, c->w_hi.cap, c->stream));
+                    c->w_hi_clean = c->w_hi.cap / 4;
+                }
+                WeighArgs wa{};
+                wa.subj = a.subj;
+                wa.qoff = a.qoff;
+                wa.n_reads = (uint32_t)c->n_reads;
+                wa.n_subjects = (uint32_t)c->n_subjects;
+                wa.bins = w_bins;
+                wa.n_slices = w_slices;
+                wa.teams_per_xcd = w_teams;
+                wa.n_xcd = w_xcd;
+                wa.invalid = w_inv_words ? c->w_invalid.as<uint32_t>() : nullptr;
+                wa.invalid_words = w_inv_words;
+                wa.slab = c->w_slab.as<uint32_t>();
+                wa.hi = c->w_hi.as<uint32_t>();
+                wa.left_mask = c->left_mask.as<unsigned long long>();
+                wa.stat_block = a.stat_block;
+                const size_t wlds = (size_t)w_bins * 4 + (size_t)w_inv_words * 4;
+                const dim3 wgrid((unsigned)c->prop.multiProcessorCount);
+                if (w_inv_words)
+                    hipLaunchKernelGGL(weigh_subjects_kernel<false>, wgrid, dim3(kWeighThreads), wlds, c->stream, wa);
+                else
+                    hipLaunchKernelGGL(weigh_subjects_kernel<true>, wgrid, dim3(kWeighThreads), wlds, c->stream, wa);
+                ktimer_end(c, kt);
+                kt = ktimer_begin(c, "weigh_merge");
+                WeighMergeArgs wm{};
+                wm.slab = wa.slab;
+                wm.hi = wa.hi;
+                wm.n_subjects = wa.n_subjects;
+                wm.bins = w_bins;
+                wm.n_teams = n_teams;
+                wm.rows = a.rows;
+                wm.row_w = a.row_w;
+                wm.n_jobs = n_jobs;
+                for (int j = 0; j < n_jobs; ++j) {
+                    wm.mode[j] = a.jobs[j].mode;
+                    wm.col[j] = a.jobs[j].col;
+                }
+                wm.group = (uint32_t)a.group_base;
+                wm.table = a.table;
+                hipLaunchKernelGGL(weigh_merge_kernel, dim3((wa.n_subjects + 1023u) / 1024u), dim3(1024), (size_t)4096 * 16,
+                                   c->stream, wm, 4096u);
+                ktimer_end(c, kt);
+                kt = ktimer_begin(c, "leftover");
+                a.left_mask = wa.left_mask;
+                a.n_mask_words = n_words;
+                a.list_seg = list_seg;
+                a.read_list = c->left_list.as<uint32_t>();
+                a.resume = 0;
+                a.slab16 = 0;
+            } else if (split) {
                 // ---- first pass: single-candidate reads -----------------------------
                 const uint32_t n_words = (uint32_t)((c->n_reads + 63) / 64);
                 const uint32_t list_seg = (((n_words + 15u) / 16u + (uint32_t)blocks - 1u) / (uint32_t)blocks) * 1024u;
@@ -985,11 +1117,12 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // one evaluator per kind of candidates (see classify_kernel's kPath)
             const int path = (a.rows != nullptr && a.row_w == 4) ? 0 : a.rows != nullptr ? 1 : 2;
             const dim3 grid(blocks), block(c->threads);
-            if (split && path == 0)
+            const bool listed = split || weigh;
+            if (listed && path == 0)
                 hipLaunchKernelGGL((classify_kernel<true, true, 0>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
-            else if (split && path == 1)
+            else if (listed && path == 1)
                 hipLaunchKernelGGL((classify_kernel<true, true, 1>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
-            else if (split)
+            else if (listed)
                 hipLaunchKernelGGL((classify_kernel<true, true, 2>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
             else if (path == 0)
                 hipLaunchKernelGGL((classify_kernel<true, false, 0>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
@@ -1009,7 +1142,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 kt = ktimer_begin(c, "dense_merge");
                 const uint32_t nb = (uint32_t)(bins * n_jobs);
                 hipLaunchKernelGGL(dense_merge_kernel, dim3((nb + 63) / 64), dim3(1024), 0, c->stream,
-                                   c->dense_slab.as<uint32_t>(), (uint32_t)blocks, (uint32_t)n_jobs, (uint32_t)bins, a.table);
+                                   c->dense_slab.as<uint32_t>(), (uint32_t)blocks, (uint32_t)n_jobs, (uint32_t)bins, (uint32_t)a.group_base, a.table);
             }
         } else {
             const int blocks = grid_for(c->n_reads, 256, c->prop.multiProcessorCount * 8);
@@ -1055,6 +1188,7 @@ int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const
     c->o_reads = n_reads;
     c->th = th;
     c->has_group = group != nullptr;
+    c->group_base = 0;
     c->ord_valid = true;
     c->chunk_valid = false;
     return WK_OK;

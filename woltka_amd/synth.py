@@ -119,11 +119,24 @@ def lca_problem(rng, n_nodes, n_subjects, n_reads, dup_frac=0.0,
         anc[m] = hp[anc[m]]
     lo = np.searchsorted(subjects, anc, side='left')
     hi = np.searchsorted(subjects, hl[anc], side='right')
+    # an alignment file names a subject once per read and mate (the plain
+    # parsers build sets, align.py:309): climb until the ancestor has at least
+    # k subjects below it, then take k *distinct* ones, evenly spaced from a
+    # random start
+    short = np.flatnonzero((hi - lo < k) & (anc != 0))
+    while short.size:
+        anc[short] = hp[anc[short]]
+        lo[short] = np.searchsorted(subjects, anc[short], side='left')
+        hi[short] = np.searchsorted(subjects, hl[anc[short]], side='right')
+        short = short[(hi[short] - lo[short] < k[short]) & (anc[short] != 0)]
+    k = np.minimum(k, np.maximum(hi - lo, 1))
     qoff = np.zeros(n_reads + 1, dtype=np.int64)
     np.cumsum(k, out=qoff[1:])
     read_of = np.repeat(np.arange(n_reads), k)
-    span = (hi - lo)[read_of]
-    pick = lo[read_of] + (rng.random(read_of.size) * span).astype(np.int64)
+    j = np.arange(read_of.size, dtype=np.int64) - qoff[read_of]
+    span = np.maximum(hi - lo, 1)[read_of]
+    start = (rng.random(n_reads) * (hi - lo)).astype(np.int64)[read_of]
+    pick = lo[read_of] + (start + (j * span) // k[read_of]) % span
     subj = subjects[np.minimum(pick, subjects.size - 1)]
     # single-hit reads hit their anchor
     single = (k == 1)[read_of]
@@ -145,6 +158,24 @@ def lca_problem(rng, n_nodes, n_subjects, n_reads, dup_frac=0.0,
         g[rng.random(n_reads) < 0.1] = -1            # query not in strata
         prob['group'] = g
     return prob
+
+
+def as_sets(prob):
+    """Drop repeated subjects inside reads: what the plain parsers hand over
+    (`subque` holds sets, woltka/align.py:309) and what the native tokenizer
+    promises with WK_SUBJ_IS_SET.  Reads keep their order; subjects inside a
+    read come out ascending."""
+    qoff = prob['qoff'].astype(np.int64)
+    n_reads = qoff.size - 1
+    read_of = np.repeat(np.arange(n_reads, dtype=np.int64), np.diff(qoff))
+    pairs = np.unique((read_of << 32) | prob['subj'].astype(np.int64))
+    out = dict(prob)
+    out['subj'] = (pairs & 0xFFFFFFFF).astype(np.int32)
+    cnt = np.bincount(pairs >> 32, minlength=n_reads)
+    q = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(cnt, out=q[1:])
+    out['qoff'] = q.astype(np.int32)
+    return out
 
 
 def flat_problem(rng, n_subjects=10575, n_taxa=2000, n_reads=10_000_000,
