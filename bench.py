@@ -1,31 +1,42 @@
 #!/usr/bin/env python3
 """Benchmark of the classify hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload flat|lca|ordinal]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lca|...]
 
-A *step* is one pass of the hot path over one batch of synthetic input that is
-already resident in HBM (packed arrays staged before the timed region):
+The headline workload is BASELINE.json configs[2], the largest configuration
+that fits one GPU: synthetic SAM of 50 M reads x <=16 hits (~250 M alignment
+records), a 2 M-node NCBI-shaped taxonomy, `--rank phylum,genus,species`.  A
+*step* is `passes` passes of the hot path over that batch, already resident
+in HBM (1.2 GB of packed arrays staged before the timed region, far beyond the
+256 MiB Infinity Cache); `passes` is sized so that the K timed steps last about
+a second.  The metric is alignment records classified per second, whole job.
 
-  flat     BASELINE.json configs[1]: 10 M reads x 1 hit, flat subject->genus
-           map, `--rank genus`: gather + per-sample histogram      (default)
-  lca      configs[2]: reads x <=16 hits, ~2 M-node taxonomy,
-           `--rank phylum,genus,species` in one pass + free-rank LCA
-  ordinal  configs[3]: paired reads over 5 k genomes x 500 k genes,
-           coord-match + gene histogram
+Next to the headline the same JSON line carries
+  roofline      dominant kernel of the headline workload: algorithmic bytes /
+                HIP-event duration on the library's stream vs 8 TB/s
+  configs       the same figures for the other single-GPU configurations
+                (`lca_free`, `ordinal` = configs[3], `flat` = configs[1] over
+                eight distinct staged chunks, 640 MB, so the bytes come from
+                HBM) — N = 1 only
+  e2e           SAM text in the page cache -> profile dict through
+                `workflow.classify` (tokenizer + H2D + kernels + folding inside
+                the timed region) — N = 1 only
+  cpu_baseline  the pure-Python restatement of the reference
+                (oracle/woltka_oracle.py) on this host's cores, parsing included
 
-The metric is alignment records classified per second (whole job, all ranks).
-For N > 1 the driver launches one process per GPU with torch.distributed.run;
-samples shard across GPUs with no data-path collective, so the
-only communication is the timing barrier / max-reduce (gloo, host side).
-
-The printed JSON line carries `roofline` (dominant kernel, algorithmic bytes /
-HIP-event duration vs 8 TB/s) and `cpu_baseline` (the pure-Python restatement
-of the reference timed on this host, rank 0, N = 1 only).
+N > 1: one process per GPU.  Under `torch.distributed.run` the ranks come from
+the environment (gloo for the barrier / max); a plain `python bench.py --gpus N`
+spawns the N processes itself (multiprocessing).  Samples shard across GPUs
+with no data-path collective: every rank classifies its own sample
+set of the same shape (weak scaling).
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -63,44 +74,67 @@ def measured_traffic(workload, scale):
 
 def stage_indexed(ctx, prob):
     """Stage a packed problem the way the host packer does: subjects as dense
-    indices (order of first appearance) + the subject -> feature table."""
+    indices (order of first appearance) + the subject -> feature table, one
+    sample (= one uniform group id) per chunk."""
     feats, first, sidx = np.unique(prob['subj'], return_index=True,
                                    return_inverse=True)
     order = np.argsort(first)               # first-appearance order
     rank_of = np.empty_like(order)
     rank_of[order] = np.arange(order.size)
     ctx.set_subjects(feats[order].astype(np.int32))
-    ctx.chunk_stage(rank_of[sidx].astype(np.int32), prob['qoff'],
+    ctx.chunk_stage(rank_of[sidx].astype(np.int32), prob['qoff'], group=0,
                     subj_is_set=True, indexed=True)
 
 
 class FlatWorkload:
-    """configs[1]: pack + histogram."""
-    name = 'synthetic SAM 10M reads x 1 hit, flat subject->genus map, rank genus'
+    """configs[1]: pack + histogram; `n_chunks` distinct staged chunks (one
+    context each), 80 MB apiece, visited in turn."""
+    key = 'flat'
     dominant = 'classify'
     families = ('classify', 'leftover', 'dense_merge')
-    # timer family -> kernel symbol in the rocprofv3 summaries (profiles/)
     symbols = {'classify': 'wk::count_subjects_kernel',
                'leftover': 'wk::classify_kernel<true, true, 0>'}
 
-    def __init__(self, ctx, seed, scale=1.0):
+    def __init__(self, ctx, seed, scale=1.0, n_chunks=8):
         self.ctx = ctx
-        rng = np.random.default_rng(seed)
-        self.prob = p = synth.flat_problem(rng, n_reads=int(10_000_000 * scale),
-                                           with_names=False)
-        h = p['hier']
-        ctx.set_tree(h.parent, h.last, h.rank_code)
-        ctx.build_rank_table(0, h.rank_codes['genus'])
+        self.ctxs = [ctx] + [nat.Context(ctx.device)
+                             for _ in range(n_chunks - 1)]
+        n_reads = int(10_000_000 * scale)
+        self.name = (f'synthetic SAM {n_reads / 1e6:g}M reads x 1 hit, flat '
+                     f'subject->genus map, rank genus; {n_chunks} distinct '
+                     'staged chunks visited in turn')
+        self.records = self.reads = 0
+        self.alg_bytes = 0
+        for i, c in enumerate(self.ctxs):
+            rng = np.random.default_rng(seed + 1000 * i)
+            p = synth.flat_problem(rng, n_reads=n_reads, with_names=False)
+            h = p['hier']
+            c.set_tree(h.parent, h.last, h.rank_code)
+            c.build_rank_table(0, h.rank_codes['genus'])
+            c.counts_reserve(1 << 16)
+            stage_indexed(c, p)
+            if i == 0:
+                self.prob = p
+            self.records += int(p['subj'].size)
+            self.reads += int(p['qoff'].size - 1)
+            # SURVEY §8d: subj int32 + qoff int32 per record, + the 42 KB map
+            self.alg_bytes += 4 * int(p['subj'].size) + \
+                4 * int(p['qoff'].size) + 4 * h.n_nodes
         self.jobs = [nat.Job(nat.MODE_RANK, 0, 0, 0, 0.0)]
-        ctx.counts_reserve(1 << 16)
-        stage_indexed(ctx, p)
-        self.records = int(p['subj'].size)
-        self.reads = int(p['qoff'].size - 1)
-        # SURVEY §8d: subj int32 + qoff int32 per record, + the 42 KB map
-        self.alg_bytes = 4 * self.records + 4 * (self.reads + 1) + 4 * h.n_nodes
+        self.n_chunks = n_chunks
+        self.launch_bytes = self.alg_bytes // n_chunks  # per kernel launch
 
     def step(self):
-        self.ctx.classify_staged(self.jobs)
+        for c in self.ctxs:
+            c.classify_staged(self.jobs)
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def close(self):
+        for c in self.ctxs[1:]:
+            c.close()
 
     def check(self):
         keys, vals = self.ctx.counts_fetch()
@@ -120,13 +154,15 @@ class FlatWorkload:
 
 
 class LcaWorkload:
-    """configs[2]: multi-hit reads, taxonomy tree, 3 ranks + free in one pass."""
+    """configs[2]: multi-hit reads, taxonomy tree, 3 ranks in one pass."""
+    key = 'lca'
     dominant = 'classify'
     families = ('classify', 'weigh_merge', 'leftover', 'partition_merge')
-    symbols = {'classify': 'wk::weigh_subjects_kernel<true>',
+    symbols = {'classify': 'wk::weigh_stream_kernel<5, 2>',
                'weigh_merge': 'wk::weigh_merge_kernel',
                'leftover': 'wk::classify_kernel<true, true, 0>',
                'partition_merge': 'wk::partition_merge_kernel'}
+    ranks = ('phylum', 'genus', 'species')
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -141,7 +177,7 @@ class LcaWorkload:
         h = p['hier']
         ctx.set_tree(h.parent, h.last, h.rank_code)
         self.jobs = []
-        for slot, rank in enumerate(('phylum', 'genus', 'species')):
+        for slot, rank in enumerate(self.ranks):
             ctx.build_rank_table(slot, h.rank_codes[rank])
             self.jobs.append(nat.Job(nat.MODE_RANK, slot, 0, 0, 0.0))
         ctx.counts_reserve(1 << 24)
@@ -151,18 +187,28 @@ class LcaWorkload:
         # 4 B/record + 4 B/read + parent/last 8 B + 3 rank tables
         self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
                           8 * h.n_nodes + 3 * 4 * h.n_nodes)
+        self.launch_bytes = self.alg_bytes
 
     def step(self):
         self.ctx.classify_staged(self.jobs)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def close(self):
+        pass
 
     def check(self):
         keys, vals = self.ctx.counts_fetch()
         return int(keys.size)
 
+    def names(self):
+        return [f'T{i:07d}' for i in range(self.prob['hier'].n_nodes)]
+
     def cpu_sample(self, n):
         p, h = self.prob, self.prob['hier']
         nn = h.n_nodes
-        names = [f'T{i:07d}' for i in range(nn)]
+        names = self.names()
         tree = {names[v]: names[int(h.parent[v])] for v in range(nn)}
         inv = {c: r for r, c in h.rank_codes.items()}
         rankdic = {names[v]: inv[int(c)] for v, c in enumerate(h.rank_code) if c}
@@ -172,32 +218,40 @@ class LcaWorkload:
         subque = [tuple(set(names[s] for s in sub[qoff[i]:qoff[i + 1]]))
                   for i in range(nreads)]
         return dict(tree=tree, rankdic=rankdic, root=names[0], subque=subque,
-                    ranks=['phylum', 'genus', 'species'],
-                    records=int(qoff[nreads]))
+                    ranks=list(self.ranks), records=int(qoff[nreads]))
 
 
 class LcaFreeWorkload(LcaWorkload):
     """configs[2], the `--rank free` variant: lowest common ancestor of every
     multi-hit read (one pass, one job)."""
+    key = 'lca_free'
+    families = ('classify', 'leftover', 'partition_merge')
+    symbols = {'classify': 'wk::classify_single_kernel<true, true, 2, false, true>',
+               'leftover': 'wk::classify_kernel<true, true, 0>',
+               'partition_merge': 'wk::partition_merge_kernel'}
+    ranks = ('free',)
 
-    def __init__(self, ctx, seed, scale=1.0):
-        super().__init__(ctx, seed, scale)
+    def __init__(self, ctx, seed, scale=1.0, share=None):
+        if share is None:
+            super().__init__(ctx, seed, scale)
+        else:                       # same staged chunk, other jobs
+            self.ctx, self.prob = ctx, share.prob
+            self.records, self.reads = share.records, share.reads
+            self.name = share.name
         self.name = self.name.replace('ranks phylum,genus,species',
                                       'rank free')
         self.jobs = [nat.Job(nat.MODE_FREE, 0, 0, 0, 0.0)]
         h = self.prob['hier']
         self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
                           8 * h.n_nodes)
-
-    def cpu_sample(self, n):
-        d = super().cpu_sample(n)
-        d['ranks'] = ['free']
-        return d
+        self.launch_bytes = self.alg_bytes
 
 
 class OrdinalWorkload:
     """configs[3]: coord-match + gene histogram."""
+    key = 'ordinal'
     dominant = 'match_count'
+    symbols = {}
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -218,8 +272,10 @@ class OrdinalWorkload:
         # + ~0.8 pairs/record x 8 B out (pair + offset)
         self.alg_bytes = 20 * self.records + 16 * p['gstart'].size + \
             int(6.4 * self.records)
-        self.families = ('match_count', 'match_write', 'classify',
+        self.launch_bytes = self.alg_bytes
+        self.families = ('match_count', 'match_write', 'classify', 'leftover',
                          'partition_merge')
+        self._steps = 0
 
     def family_bytes(self, family):
         """Algorithmic bytes of one launch of each kernel of the step."""
@@ -235,9 +291,15 @@ class OrdinalWorkload:
         return 4 * pairs + 4 * (self.reads + 1)     # classify over gene lists
 
     def step(self):
-        self._steps = getattr(self, '_steps', 0) + 1
+        self._steps += 1
         self.ctx.ordinal_match()
         self.ctx.classify_staged(self.jobs)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def close(self):
+        pass
 
     def check(self):
         return int(self.ctx.stats()['n_pairs'])
@@ -296,16 +358,171 @@ WORKLOADS = {'flat': FlatWorkload, 'lca': LcaWorkload,
 
 
 # --------------------------------------------------------------------------
+# synthetic text (end-to-end leg, parse-inclusive CPU baseline)
+# --------------------------------------------------------------------------
+
+def write_sam_lca(path, prob, n_reads, block=4_000_000):
+    """SAM text of the first `n_reads` reads of a packed config-3 problem, one
+    line per alignment record (trimmed as doc/perform.md:122-128 recommends:
+    SEQ / QUAL '*'), formatted with numpy (fixed-width decimal fields).
+    Returns (records, bytes)."""
+    qoff = prob['qoff']
+    n_rec = int(qoff[n_reads])
+    read_of = np.repeat(np.arange(n_reads, dtype=np.int64),
+                        np.diff(qoff[:n_reads + 1]))
+    subj = prob['subj'][:n_rec].astype(np.int64)
+    tmpl = np.frombuffer(b'R000000000\t0\tT0000000\t1\t42\t150M\t*\t0\t0\t*\t*\n',
+                         dtype=np.uint8)
+    size = 0
+    with open(path, 'wb') as f:
+        f.write(b'@HD\tVN:1.0\tSO:unsorted\n')
+        for lo in range(0, n_rec, block):
+            hi = min(n_rec, lo + block)
+            lines = np.tile(tmpl, (hi - lo, 1))
+            r, s = read_of[lo:hi], subj[lo:hi]
+            for k in range(9):
+                lines[:, 1 + k] = 48 + (r // 10 ** (8 - k)) % 10
+            for k in range(7):
+                lines[:, 14 + k] = 48 + (s // 10 ** (6 - k)) % 10
+            f.write(lines.tobytes())
+            size += lines.size
+    return n_rec, size + 23
+
+
+def write_nodes_dmp(path, hier):
+    inv = {c: r for r, c in hier.rank_codes.items()}
+    par, rc = hier.parent.tolist(), hier.rank_code.tolist()
+    with open(path, 'w') as f:
+        f.writelines(f'T{v:07d}\t|\tT{par[v]:07d}\t|\t'
+                     f'{inv.get(rc[v], "no rank")}\t|\n'
+                     for v in range(hier.n_nodes))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def e2e_leg(wl, device, frac=0.4, workdir=None):
+    """`workflow.classify` from SAM text + nodes.dmp on local disk (page
+    cache) to the profile dict: tokenizer, H2D staging, kernels and the
+    folding of the counts are all inside the timed region; so is the one-off
+    flattening of the 2 M-node hierarchy (reported separately as setup_s).
+    The text holds the first `frac` of the headline workload's reads."""
+    from woltka_amd import classify as C
+    from woltka_amd import workflow
+    n_reads = max(1000, int(wl.reads * frac))
+    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
+        sam = os.path.join(tmp, 'S1.sam')
+        nodes = os.path.join(tmp, 'nodes.dmp')
+        t0 = time.perf_counter()
+        n_rec, n_bytes = write_sam_lca(sam, wl.prob, n_reads)
+        write_nodes_dmp(nodes, wl.prob['hier'])
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        tree, rankdic, namedic, root = quiet(workflow.build_hierarchy,
+                                             nodes_fps=[nodes])
+        t_read = time.perf_counter() - t0
+        mapper, chunk = quiet(workflow.build_mapper)
+        setup = {'t': 0.0}
+        orig_init = C.Engine.__init__
+
+        def timed_init(this, *a, **k):
+            t = time.perf_counter()
+            try:
+                return orig_init(this, *a, **k)
+            finally:
+                setup['t'] += time.perf_counter() - t
+        C.Engine.__init__ = timed_init
+        try:
+            best = None
+            for rep in range(2):            # second run: page cache warm
+                setup['t'] = 0.0
+                t0 = time.perf_counter()
+                data = quiet(workflow.classify, mapper, {sam: 'S1'}, ['S1'],
+                             fmt='sam', tree=tree, rankdic=rankdic, root=root,
+                             ranks=list(wl.ranks), chunk=chunk, device=device)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, setup['t'])
+        finally:
+            C.Engine.__init__ = orig_init
+        dt, t_setup = best
+        cells = sum(len(v.get('S1', ())) for v in data.values())
+    return {'value': round(n_rec / dt, 1), 'unit': 'records/s',
+            'records': n_rec, 'reads': n_reads, 'text_bytes': n_bytes,
+            'seconds': round(dt, 3), 'setup_s': round(t_setup, 3),
+            'value_streaming': round(n_rec / max(dt - t_setup, 1e-9), 1),
+            'hierarchy_files_read_s': round(t_read, 2),
+            'text_generated_s': round(t_gen, 1), 'cells': cells,
+            'what': ('workflow.classify on SAM text in the page cache (first '
+                     f'{frac:g} of the headline reads, 2M-node nodes.dmp): '
+                     'tokenizer + H2D + kernels + count folding timed; '
+                     'setup_s = hierarchy dicts -> device tables, inside '
+                     '`seconds`')}
+
+
+# --------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1)
 # --------------------------------------------------------------------------
 
-def cpu_baseline(wl, budget_s=15.0):
-    """Time the pure-Python restatement of the reference
-    (oracle/woltka_oracle.py: per-read assigners + counter, chunks of 1024
-    queries as workflow.py:584) on a bounded sample of the same workload, one
-    core."""
+def _cpu_assign(sample):
+    """Per-read assigners + counter of the reference, restated
+    (oracle/woltka_oracle.py), chunks of 1024 queries as workflow.py:584;
+    returns seconds."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import woltka_oracle as orc
+    data = {r: {} for r in sample['ranks']}
+    sub = sample['subque']
+    assigners = {r: orc.make_assigner(r, sample['tree'], sample['rankdic'],
+                                      sample['root'])
+                 for r in sample['ranks']}
+    t0 = time.perf_counter()
+    for lo in range(0, len(sub), 1024):
+        part = sub[lo:lo + 1024]
+        for rank in sample['ranks']:
+            counts = orc.count_float(map(assigners[rank], part))
+            d = data[rank]
+            for k, v in counts.items():
+                d[k] = d.get(k, 0) + v
+    return time.perf_counter() - t0
+
+
+_CPU_SAMPLE = None      # inherited by the forked workers of the all-core run
+
+
+def _cpu_parse_assign(sam):
+    """One worker of the parse-inclusive baseline: SAM text -> plain mapper
+    chunks -> assigners -> counter, all in the oracle's Python; returns
+    (records, seconds)."""
+    sample = _CPU_SAMPLE
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import woltka_oracle as orc
+    assigners = {r: orc.make_assigner(r, sample['tree'], sample['rankdic'],
+                                      sample['root'])
+                 for r in sample['ranks']}
+    data = {r: {} for r in sample['ranks']}
+    n_rec = 0
+    t0 = time.perf_counter()
+    with open(sam) as f:
+        for qryque, subque in orc.chunk_plain(orc.parse_sam_lines(f), 1024):
+            part = [tuple(s) for s in subque]
+            n_rec += sum(map(len, part))
+            for rank in sample['ranks']:
+                counts = orc.count_float(map(assigners[rank], part))
+                d = data[rank]
+                for k, v in counts.items():
+                    d[k] = d.get(k, 0) + v
+    return n_rec, time.perf_counter() - t0
+
+
+def cpu_baseline(wl, budget_s=12.0, workdir=None):
+    """The pure-Python restatement of the reference (oracle/woltka_oracle.py)
+    on a bounded sample of the same workload: one core without parsing (the
+    packed hot path alone), and — for the SAM workloads — parsing included on
+    one core and on all cores of this host, one process per slice of the
+    sample (the split-and-merge practice of doc/perform.md:70-92)."""
+    global _CPU_SAMPLE
     probe = 100_000
     if hasattr(wl, 'cpu_time'):
         n, t = wl.cpu_time(probe)
@@ -320,31 +537,12 @@ def cpu_baseline(wl, budget_s=15.0):
     s = wl.cpu_sample(probe)
     if s is None:
         return None
-
-    def run(sample):
-        # same structure as workflow.classify / assign_readmap: per-rank
-        # LRU-cached assigner, float counter per chunk, sum_dict into data
-        data = {r: {} for r in sample['ranks']}
-        sub = sample['subque']
-        assigners = {r: orc.make_assigner(r, sample['tree'], sample['rankdic'],
-                                          sample['root'])
-                     for r in sample['ranks']}
-        t0 = time.perf_counter()
-        for lo in range(0, len(sub), 1024):
-            part = sub[lo:lo + 1024]
-            for rank in sample['ranks']:
-                counts = orc.count_float(map(assigners[rank], part))
-                d = data[rank]
-                for k, v in counts.items():
-                    d[k] = d.get(k, 0) + v
-        return time.perf_counter() - t0
-
-    t = run(s)
+    t = _cpu_assign(s)
     rate = s['records'] / t
     n = int(min(max(probe, rate * budget_s), wl.records))
     if n > probe * 1.5:
         s = wl.cpu_sample(n)
-        t = run(s)
+        t = _cpu_assign(s)
         rate = s['records'] / t
     out = {'value': round(rate, 1), 'unit': 'records/s', 'cores': 1,
            'kind': 'port',
@@ -352,72 +550,120 @@ def cpu_baseline(wl, budget_s=15.0):
                       'pure-Python restatement of the reference assigners (LRU '
                       'cache 1024) + counter (oracle/woltka_oracle.py), chunks of 1024 '
                       f'queries, 1 core, {t:.1f} s; text parsing excluded')}
+    if not hasattr(wl, 'names'):
+        return out
+    # parse-inclusive: SAM text of a slice per process
+    import multiprocessing as mp
+    # (a process per core on a 256-thread host only measures the page faults of
+    # 256 forked copies of the hierarchy dicts: bounded at 32)
+    cores = min(os.cpu_count() or 1, 32)
+    per = max(20_000, int(rate * 0.25 * budget_s))    # records per process
+    qoff = wl.prob['qoff']
+    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
+        reads = int(np.searchsorted(qoff, per))
+        sam = os.path.join(tmp, 'slice.sam')
+        write_sam_lca(sam, wl.prob, reads)
+        _CPU_SAMPLE = dict(s, subque=None)
+        n1, t1 = _cpu_parse_assign(sam)
+        out['parse_inclusive'] = {
+            'value': round(n1 / t1, 1), 'cores': 1,
+            'sample': f'{n1} records of SAM text, parse + assign + count, {t1:.1f} s'}
+        t0 = time.perf_counter()
+        with mp.get_context('fork').Pool(cores) as pool:
+            res = pool.map(_cpu_parse_assign, [sam] * cores)
+        wall = time.perf_counter() - t0
+        tot = sum(r[0] for r in res)
+        out['parse_inclusive_all_cores'] = {
+            'value': round(tot / wall, 1), 'cores': cores,
+            'sample': (f'{cores} processes x {n1} records of SAM text each '
+                       f'(split by sample, doc/perform.md:70-92), {wall:.1f} s wall')}
+        _CPU_SAMPLE = None
     return out
 
 
 # --------------------------------------------------------------------------
+# measurement
+# --------------------------------------------------------------------------
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='flat')
-    ap.add_argument('--scale', type=float, default=1.0,
-                    help='fraction of the named workload size (default: full)')
-    ap.add_argument('--no-cpu', action='store_true',
-                    help='skip the CPU baseline leg')
-    a = ap.parse_args()
+class NoSync:
+    def barrier(self):
+        pass
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    if world > 1:
+    def allmax(self, x):
+        return x
+
+    def close(self):
+        pass
+
+
+class TorchSync(NoSync):
+    """Ranks launched by torch.distributed.run: gloo, host side."""
+
+    def __init__(self, rank, world):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
+        self.dist = dist
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def barrier(self):
+        self.dist.barrier()
 
-    # one process per GPU; a launcher that narrows the visible devices to one
-    # per process leaves a single device 0
-    ctx = nat.Context(local % max(nat.device_count(), 1))
-    # one sample set per GPU: different seed per rank, same shape (weak scaling)
-    wl = WORKLOADS[a.workload](ctx, seed=1002 + rank, scale=a.scale)
-    ctx.sync()
-
-    for _ in range(a.warmup):
-        wl.step()
-    ctx.sync()
-    barrier()
-    ctx.timer_begin()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.step()
-    ctx.timer_end()
-    ctx.sync()
-    # this rank's K steps, device work drained; the closing barrier follows and
-    # the slowest rank's time is what counts (MAX below) — the barrier's own
-    # latency (gloo, host side) is not part of anybody's steps
-    elapsed = time.perf_counter() - t0
-    barrier()
-    gpu_ms = ctx.timer_ms()
-    if dist is not None:
+    def allmax(self, x):
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    checksum = wl.check()
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
 
-    # dominant-kernel duration: HIP events around each launch on the library's
-    # own stream, averaged over a separate loop of launches
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class MpSync(NoSync):
+    """Ranks spawned by this script: a multiprocessing barrier and a shared
+    array."""
+
+    def __init__(self, rank, bar, shared):
+        self.rank, self.bar, self.shared = rank, bar, shared
+
+    def barrier(self):
+        self.bar.wait()
+
+    def allmax(self, x):
+        self.shared[self.rank] = x
+        self.bar.wait()
+        m = max(self.shared[:])
+        self.bar.wait()
+        return m
+
+
+def timed_steps(wl, steps, warmup, passes, sync):
+    """W warmup steps, barrier, K timed steps, device drained; MAX over ranks.
+    Returns seconds."""
+    for _ in range(warmup):
+        for _ in range(passes):
+            wl.step()
+    wl.sync()
+    sync.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for _ in range(passes):
+            wl.step()
+    wl.sync()
+    # this rank's K steps, device work drained; the slowest rank's time is what
+    # counts (MAX below) — the barrier's own latency is not part of the steps
+    elapsed = time.perf_counter() - t0
+    sync.barrier()
+    return sync.allmax(elapsed)
+
+
+def kernel_times(wl, n=10):
+    """HIP events around each launch on the library's stream (first context),
+    averaged over a separate loop of launches."""
+    ctx = wl.ctx
     ctx.profile_kernels(True)
     families = getattr(wl, 'families', (wl.dominant,))
     durs = {f: [] for f in families}
-    for _ in range(min(a.steps, 20)):
+    for _ in range(n):
         wl.step()
         for f in families:
             try:
@@ -425,53 +671,230 @@ def main():
             except RuntimeError:        # kernel family not launched in this step
                 pass
     ctx.profile_kernels(False)
-    means = {f: float(np.mean(v)) for f, v in durs.items() if v}
+    wl.sync()
+    return {f: float(np.mean(v)) for f, v in durs.items() if v}
+
+
+def config_block(wl, seconds, passes, steps, scale, key):
+    means = kernel_times(wl)
     dominant = max(means, key=means.get)
     kern_ms = means[dominant]
-    alg_bytes = wl.family_bytes(dominant) if hasattr(wl, 'family_bytes') \
-        else wl.alg_bytes
-
-    if rank == 0:
-        ms_per_step = elapsed * 1e3 / a.steps
-        value = wl.records * world / (elapsed / a.steps)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        line = {
-            'metric': 'alignment records/sec classified',
-            'value': round(value, 1),
-            'unit': 'records/s',
-            'n_gpus': world,
-            'steps': a.steps,
-            'warmup': a.warmup,
-            'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'int32',
-            'data': 'synthetic',
-            'config': {'workload': wl.name, 'records_per_gpu': wl.records,
-                       'reads_per_gpu': wl.reads, 'scale': a.scale,
-                       'sharding': f'samples x {world} GPUs, no collective'},
+    if hasattr(wl, 'family_bytes'):
+        alg = wl.family_bytes(dominant)
+    else:
+        alg = wl.launch_bytes
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+    ms_pass = seconds * 1e3 / (steps * passes)
+    return {'workload': wl.name, 'records': wl.records, 'reads': wl.reads,
+            'ms_per_pass': round(ms_pass, 4),
+            'value': round(wl.records / (ms_pass * 1e-3), 1),
+            'timed_region_s': round(seconds, 3),
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': measured_traffic(a.workload, a.scale),
+                         'traffic': measured_traffic(key, scale),
                          'kernel': dominant,
                          'kernel_symbol': getattr(wl, 'symbols', {}).get(
                              dominant, f'wk::{dominant}_kernel'),
                          'kernel_ms': round(kern_ms, 4),
-                         'algorithmic_bytes': alg_bytes,
+                         'algorithmic_bytes': alg,
                          'kernels_ms': {f: round(v, 4)
-                                        for f, v in means.items()}},
-            'gpu_ms_per_step_events': round(gpu_ms / a.steps, 4),
-            'device': ctx.device_name,
-            'checksum': checksum,
-        }
-        if world == 1 and not a.no_cpu:
-            line['cpu_baseline'] = cpu_baseline(wl)
-        print(json.dumps(line))
+                                        for f, v in means.items()}}}
+
+
+def passes_for(wl, steps, target_s=1.0):
+    """Passes per step so that `steps` timed steps last about `target_s`."""
+    for _ in range(2):
+        wl.step()
+    wl.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        wl.step()
+    wl.sync()
+    one = (time.perf_counter() - t0) / 3
+    return max(1, int(round(target_s / max(steps, 1) / max(one, 1e-6))))
+
+
+def run_rank(a, rank, world, local, sync):
+    # one process per GPU; a launcher that narrows the visible devices to one
+    # per process leaves a single device 0
+    dev = local % max(nat.device_count(), 1)
+    ctx = nat.Context(dev)
+    for kv in a.opt:
+        name, _, value = kv.partition('=')
+        ctx.set_option(name, int(value))
+    # one sample set per GPU: different seed per rank, same shape (weak scaling)
+    wl = WORKLOADS[a.workload](ctx, seed=1002 + rank, scale=a.scale)
+    wl.sync()
+    passes = a.passes or passes_for(wl, a.steps)
+    if world > 1:                   # every rank the same number of passes
+        passes = int(sync.allmax(float(passes)))
+    elapsed = timed_steps(wl, a.steps, a.warmup, passes, sync)
+    checksum = wl.check()
+    if rank != 0:
+        wl.close()
+        ctx.close()
+        return None
+    block = config_block(wl, elapsed, passes, a.steps, a.scale, a.workload)
+    ms_per_step = elapsed * 1e3 / a.steps
+    value = wl.records * passes * world / (elapsed / a.steps)
+    line = {
+        'metric': 'alignment records/sec classified',
+        'value': round(value, 1),
+        'unit': 'records/s',
+        'n_gpus': world,
+        'steps': a.steps,
+        'warmup': a.warmup,
+        'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'int32',
+        'data': 'synthetic',
+        'config': {'workload': wl.name, 'records_per_gpu': wl.records,
+                   'reads_per_gpu': wl.reads, 'scale': a.scale,
+                   'passes_per_step': passes,
+                   'ms_per_pass': block['ms_per_pass'],
+                   'timed_region_s': round(elapsed, 3),
+                   'sharding': f'samples x {world} GPUs, no collective'},
+        'roofline': block['roofline'],
+        'device': ctx.device_name,
+        'checksum': checksum,
+    }
+    if world > 1 or a.headline_only:
+        wl.close()
+        ctx.close()
+        return line
+    configs = {}
+    if a.workload == 'lca':
+        try:
+            free = LcaFreeWorkload(ctx, 0, a.scale, share=wl)
+            p2 = passes_for(free, a.steps, 0.5)
+            t = timed_steps(free, a.steps, 1, p2, NoSync())
+            configs['lca_free'] = config_block(free, t, p2, a.steps, a.scale,
+                                               'lca_free')
+            ctx.counts_clear()
+        except Exception as e:      # a side block must not cost the headline
+            configs['lca_free'] = {'error': repr(e)}
+        try:
+            line['e2e'] = e2e_leg(wl, dev, workdir=a.tmp)
+        except Exception as e:
+            line['e2e'] = {'error': repr(e)}
+    if not a.no_cpu:
+        try:
+            line['cpu_baseline'] = cpu_baseline(wl, workdir=a.tmp)
+        except Exception as e:
+            line['cpu_baseline'] = {'error': repr(e)}
+    wl.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    del wl
+    for key in ('ordinal', 'flat'):
+        if key == a.workload:
+            continue
+        try:
+            c2 = nat.Context(dev)
+            w2 = WORKLOADS[key](c2, seed=1002, scale=a.scale)
+            w2.sync()
+            p2 = passes_for(w2, a.steps, 0.5)
+            t = timed_steps(w2, a.steps, 1, p2, NoSync())
+            configs[key] = config_block(w2, t, p2, a.steps, a.scale, key)
+            if key == 'ordinal' and not a.no_cpu:
+                configs[key]['cpu_baseline'] = cpu_baseline(w2, 8.0)
+            w2.close()
+            c2.close()
+            del w2
+        except Exception as e:
+            configs[key] = {'error': repr(e)}
+    line['configs'] = configs
+    return line
+
+
+def _child(a, rank, world, bar, shared, conn):
+    try:
+        line = run_rank(a, rank, world, rank, MpSync(rank, bar, shared))
+        conn.send(('ok', line))
+    except BaseException as e:      # noqa: BLE001 - reported by the parent
+        try:
+            bar.abort()
+        except Exception:
+            pass
+        conn.send(('error', repr(e)))
+    finally:
+        conn.close()
+
+
+def spawn_local(a):
+    """`python bench.py --gpus N` without a launcher: N processes, one per
+    device, a multiprocessing barrier between them; rank 0's line is printed
+    by the parent."""
+    import multiprocessing as mp
+    mpc = mp.get_context('spawn')
+    world = a.gpus
+    bar = mpc.Barrier(world)
+    shared = mpc.Array('d', world)
+    procs, conns = [], []
+    for rank in range(world):
+        parent, child = mpc.Pipe(duplex=False)
+        p = mpc.Process(target=_child, args=(a, rank, world, bar, shared, child))
+        p.start()
+        child.close()
+        procs.append(p)
+        conns.append(parent)
+    line, errors = None, []
+    for rank, (p, c) in enumerate(zip(procs, conns)):
+        try:
+            status, payload = c.recv()
+        except EOFError:
+            status, payload = 'error', 'process died'
+        if status != 'ok':
+            errors.append(f'rank {rank}: {payload}')
+        elif rank == 0:
+            line = payload
+        p.join()
+    if errors:
+        raise SystemExit('bench failed: ' + '; '.join(errors))
+    return line
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='lca')
+    ap.add_argument('--scale', type=float, default=1.0,
+                    help='fraction of the named workload size (default: full)')
+    ap.add_argument('--passes', type=int, default=0,
+                    help='passes over the staged batch per step (default: '
+                         'sized for a timed region of about one second)')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE',
+                    help='wk_set_option knob (measurement; results never '
+                         'depend on them)')
+    ap.add_argument('--no-cpu', action='store_true',
+                    help='skip the CPU baseline leg')
+    ap.add_argument('--headline-only', action='store_true',
+                    help='skip the per-config blocks, the end-to-end leg and '
+                         'the CPU baseline')
+    ap.add_argument('--tmp', default=None,
+                    help='directory for the synthetic text files')
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse_args()
+    if 'WORLD_SIZE' in os.environ:      # launched by torch.distributed.run
+        rank = int(os.environ.get('RANK', '0'))
+        world = int(os.environ['WORLD_SIZE'])
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        sync = TorchSync(rank, world) if world > 1 else NoSync()
+        line = run_rank(a, rank, world, local, sync)
+        sync.close()
+    elif a.gpus > 1:
+        line = spawn_local(a)
+    else:
+        line = run_rank(a, 0, 1, 0, NoSync())
+    if line is not None:
+        print(json.dumps(line))
 
 
 if __name__ == '__main__':

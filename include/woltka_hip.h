@@ -115,6 +115,10 @@ typedef struct wk_stats {
 
 /* ---- life cycle -------------------------------------------------------- */
 int wk_abi_version(void);
+/* Digest of the sources this library was compiled from (csrc/ + this header;
+ * computed by the build recipe, __graft_entry__.build_native, which rebuilds
+ * on a mismatch): proof that the .so in use is not a stale one. */
+const char* wk_build_id(void);
 /* Number of HIP devices visible to this process (0 when there is none). */
 int wk_device_count(void);
 /* Create a context on HIP device `device`.  Fails (WK_E_HIP) without a GPU. */
@@ -138,7 +142,8 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * subject histogram as its own statically pipelined kernel),
  * "single_blocks_per_cu" (grid of the first pass), "weigh" (0 off / 1 auto / 2
  * whenever the jobs allow it: plain rank jobs as one weighted histogram over
- * subject indices, csrc/wk_weigh.hpp).
+ * subject indices, csrc/wk_weigh.hpp; "weigh_stream" 0/1 picks its
+ * one-lane-per-record kernel, "weigh_rpw" its reads per wave).
  * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 

@@ -1020,6 +1020,121 @@ def gen_cli_strata(seed=59, n_cases=8):
     dump('cli_strata.json', cases)
 
 
+def gen_cli_config5(seed=61, n_samples=8, n_pairs=200):
+    """BASELINE config 5 at fixture size: `n_samples` samples of paired,
+    multi-hit SAM with coordinates, classified in the two passes of the
+    reference's "combined taxonomic & functional" recipe (README.md:125-150):
+    pass 1 = taxonomy tree, `--rank genus --outmap`; pass 2 = `--coords` +
+    gene -> function maps, `--stratify` by the read maps of pass 1.  One case
+    with a file per sample, one with all samples multiplexed in one file
+    (`--demux`)."""
+    import contextlib
+    import gzip
+    import io
+    import lzma
+    import tempfile
+    from woltka.workflow import workflow
+    rng = random.Random(seed)
+    tax = os.path.join(DATA, 'taxonomy')
+    fun = os.path.join(DATA, 'function')
+    genes = {}
+    with lzma.open(os.path.join(fun, 'coords.txt.xz'), 'rt') as f:
+        for line in f:
+            if line.startswith('>'):
+                cur = genes.setdefault(line[1:].strip(), [])
+            else:
+                x = line.split('\t')
+                a, b = int(x[1]), int(x[2])
+                cur.append((min(a, b), max(a, b)))
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        known = {x.split('\t')[0] for x in f}
+    genomes = sorted(g for g in genes if len(genes[g]) > 50 and g in known)
+    weights = [1.0 / (i + 1) for i in range(len(genomes))]
+
+    def sample_text(prefix):
+        lines = []
+        for qi in range(n_pairs):
+            q = f'{prefix}p{qi:05d}'
+            # config-3 hit model: one hit, or several on related genomes
+            k = 1 if rng.random() < 0.5 else rng.randint(2, 6)
+            first = rng.choices(range(len(genomes)), weights)[0]
+            picks = [first] + [min(len(genomes) - 1,
+                                   max(0, first + rng.randint(-3, 3)))
+                               for _ in range(k - 1)]
+            for h, gi in enumerate(picks):
+                s = genomes[gi]
+                gs, ge = rng.choice(genes[s])
+                pos = max(1, gs + rng.randint(-100, max(1, ge - gs - 50)))
+                sec = 256 if h else 0
+                lines.append(f'{q}\t{99 + sec}\t{s}\t{pos}\t42\t150M\t=\t'
+                             f'{pos + 100}\t250\t*\t*\n')
+                lines.append(f'{q}\t{147 + sec}\t{s}\t{pos + 100}\t42\t'
+                             f'{rng.choice(["150M", "140M5D10M", "148M2S"])}'
+                             f'\t=\t{pos}\t-250\t*\t*\n')
+        return ''.join(lines)
+
+    cases = []
+    for demux in (False, True):
+        files = {}
+        if demux:
+            files['mux.sam'] = '@HD\tVN:1.0\n' + ''.join(
+                sample_text(f'S{i + 1:02d}_') for i in range(n_samples))
+            inp = 'mux.sam'
+        else:
+            for i in range(n_samples):
+                files[f'aln/S{i + 1:02d}.sam'] = '@HD\tVN:1.0\n' + \
+                    sample_text('')
+            inp = 'aln'
+        kw1 = dict(input_fp=inp, output_fmt=False, ranks='genus',
+                   nodes_fps=['$TAX/nodes.dmp'], map_fps=['$TAX/taxid.map'],
+                   names_fps=['$TAX/names.dmp'], name_as_id=True,
+                   outmap_zip='gz')
+        kw2 = dict(input_fp=inp, output_fmt=False, ranks='process',
+                   coords_fp='$FUN/coords.txt.xz', overlap=80,
+                   map_fps=['$FUN/uniref/uniref.map.xz',
+                            '$FUN/go/process.tsv.xz'], map_rank=None)
+        if demux:
+            kw1['demux'] = kw2['demux'] = True
+        with tempfile.TemporaryDirectory() as tmp:
+            for rel, text in files.items():
+                os.makedirs(os.path.dirname(os.path.join(tmp, rel)) or tmp,
+                            exist_ok=True)
+                with open(os.path.join(tmp, rel), 'w') as f:
+                    f.write(text)
+
+            def real(v):
+                if isinstance(v, list):
+                    return [real(x) for x in v]
+                if isinstance(v, str) and v.startswith('$TAX/'):
+                    return os.path.join(tax, v[5:])
+                if isinstance(v, str) and v.startswith('$FUN/'):
+                    return os.path.join(fun, v[5:])
+                if isinstance(v, str) and (v in files or v == 'aln'):
+                    return os.path.join(tmp, v)
+                return v
+            a1 = {k: real(v) for k, v in kw1.items()}
+            a1.update(output_fp=os.path.join(tmp, 'out1'),
+                      outmap_dir=os.path.join(tmp, 'maps'))
+            a2 = {k: real(v) for k, v in kw2.items()}
+            a2.update(output_fp=os.path.join(tmp, 'out2'),
+                      strata_dir=os.path.join(tmp, 'maps'))
+            with contextlib.redirect_stdout(io.StringIO()):
+                workflow(**a1)
+                workflow(**a2)
+            with open(a1['output_fp']) as f:
+                t1 = f.read()
+            with open(a2['output_fp']) as f:
+                t2 = f.read()
+            maps = {}
+            for fn in sorted(os.listdir(a1['outmap_dir'])):
+                with gzip.open(os.path.join(a1['outmap_dir'], fn), 'rt') as f:
+                    maps[fn[:-3]] = f.read()
+        assert len(maps) == n_samples and t2.count('\n') > 20
+        cases.append(dict(files=files, pass1=kw1, pass2=kw2,
+                          expect=dict(table1=t1, table2=t2, maps=maps)))
+    dump('cli_config5.json', cases)
+
+
 def _random_profile(rng, kind, meta=None):
     """TSV text of a random profile.  kind: 'int', 'float', 'strat' (ids
     "A|b"), 'nested' (ids "A_1_x"), with optional metadata columns."""
@@ -1296,9 +1411,15 @@ def main():
     gen_cli_random()
     gen_cli_coords()
     gen_cli_strata()
+    gen_cli_config5()
     gen_cli_medium()
     gen_tools()
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1:       # e.g. `make_golden.py gen_cli_config5`
+        if _refshim.install():
+            for name in sys.argv[1:]:
+                globals()[name]()
+    else:
+        main()

@@ -56,3 +56,15 @@ def test_product_does_not_import_oracle():
                     src = f.read()
                 assert 'oracle' not in src.replace('no CPU fallback', ''), (
                     os.path.join(dirpath, fn))
+
+
+def test_library_carries_the_digest_of_its_sources():
+    """build() must have compiled the sources as they are now: the digest in
+    the .so (wk_build_id) equals the digest of csrc/ + the header."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    from woltka_amd import _native
+    g.build_native()
+    assert g.built_digest() == g.source_digest(g._sources())
+    assert _native.build_id() == g.built_digest()

@@ -9,13 +9,13 @@ TAG=$1; WL=$2; SCALE=$3; KERN=$4
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --workload $WL --scale $SCALE --steps 20 --warmup 3 --no-cpu"
+CMD="python $R/bench.py --workload $WL --scale $SCALE --steps ${STEPS:-20} --warmup 3 --no-cpu ${EXTRA:-}"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $CMD > "$OUT/kt.log" 2>&1
 echo "kernel-trace rc=$?"
 f=$(find "$OUT/kt" -name "*kernel_stats.csv" 2>/dev/null | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv" && cut -c1-150 "$OUT/kernel_stats.csv" | head -8
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
   timeout 900 rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -- $CMD > "$OUT/pmc$i.log" 2>&1
   echo "pmc$i rc=$?"

@@ -30,7 +30,7 @@ MAX_RANK_SLOTS = MAX_JOBS * 4
 
 # every symbol the header declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    'wk_abi_version', 'wk_device_count', 'wk_create', 'wk_destroy',
+    'wk_abi_version', 'wk_build_id', 'wk_device_count', 'wk_create', 'wk_destroy',
     'wk_last_error',
     'wk_device_name', 'wk_sync', 'wk_set_option', 'wk_set_tree',
     'wk_build_rank_table', 'wk_get_rank_table', 'wk_set_genes',
@@ -82,6 +82,7 @@ def load_library():
                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint64))
     proto = {
         'wk_abi_version': (C.c_int, []),
+        'wk_build_id': (C.c_char_p, []),
         'wk_device_count': (C.c_int, []),
         'wk_create': (C.c_int, [C.c_int, C.POINTER(p)]),
         'wk_destroy': (None, [p]),
@@ -410,6 +411,11 @@ WEIGHT_L = 720720       # WK_WEIGHT_L: k = 0 keys hold multiples of 1 / L
 WEIGHT_MAX_K = 16
 KEY_K_MASK = np.uint64(0xFFF << 49)
 KEY_GROUP_SHIFT = 28        # key >> 28 = (job, k, group)
+
+
+def build_id():
+    """Digest of the sources the loaded library was compiled from."""
+    return load_library().wk_build_id().decode()
 
 
 def device_count():

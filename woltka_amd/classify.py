@@ -155,8 +155,12 @@ class Engine:
         self._anc = {}                      # slot -> downloaded rank table
         self.groups = []                    # group id -> (sample, stratum)
         self.group_ids = {}
-        self.slots_reserved = table_slots or (1 << 20)
-        self.ctx.counts_reserve(self.slots_reserved)
+        # the count table grows with what the run needs (`_ensure_table`); it
+        # is never left to fill up: a full table loses counts
+        self.slots_reserved = 0
+        self._table_fixed = table_slots
+        self._reserve(table_slots or max(1 << 20, 4 * len(self.index)))
+        self._job_base = 0                  # first job of the batch in flight
         self.genes = None
         self.gene_feature = None
         # dense subject indices (order of first appearance in the alignments)
@@ -181,6 +185,37 @@ class Engine:
         if self.tok is not None:
             self.tok.close()
         self.ctx.close()
+
+    # ------------------------------------------------------------------
+    MAX_SLOTS = 1 << 30
+
+    def _reserve(self, slots):
+        """(Re)allocate the device count table (cleared) with a power-of-two
+        number of slots >= ``slots``."""
+        n = 1024
+        while n < min(int(slots), self.MAX_SLOTS):
+            n <<= 1
+        self.ctx.counts_reserve(n)
+        self.slots_reserved = n
+
+    def _ensure_table(self, data, n_records, n_groups):
+        """Room for the keys the next chunk can add: at most one per record and
+        job, and at most one per (group of the chunk, feature, job).  Counts
+        are exact integers, so they can be folded to the host at any point
+        (`collect`) — done here when the table is more than a quarter full —
+        and the table re-allocated larger when one chunk needs it.  (The
+        reference's dicts have no size limit; a fixed table used to fail at the
+        very end of a long multi-sample run.)"""
+        n_jobs = min(len(self.jobs), nat.MAX_JOBS)
+        need = min(n_records + 1, max(1, n_groups) * (len(self.index) + 1)) \
+            * n_jobs
+        used = self.ctx.stats()['table_used']
+        if 2 * (used + need) <= self.slots_reserved and \
+                4 * used <= self.slots_reserved:
+            return
+        self.collect(data)
+        if 2 * need > self.slots_reserved and not self._table_fixed:
+            self._reserve(4 * need)
 
     # ------------------------------------------------------------------
     def load_strata(self, fp, zippers):
@@ -287,6 +322,8 @@ class Engine:
         self.genes = table
         self.ctx.set_genes(table.goff, table.start0, table.end,
                            self.gene_feature)
+        if not self._table_fixed and 4 * len(self.index) > self.slots_reserved:
+            self._reserve(4 * len(self.index))
 
     def ordinal_chunks(self, fh, fmt, excl, n, th):
         """Parse with the "ex" parsers and stage hits on the device, ``n``
@@ -310,7 +347,8 @@ class Engine:
 
     # ------------------------------------------------------------------
     def _group_array(self, n, sample_of, strata_of):
-        """Per-read group ids (int32) or None when every read is group 0."""
+        """Per-read group ids (int32 array), or one id (int) when the whole
+        chunk belongs to one (sample, no stratum) pair."""
         gid = self.group_ids
         groups = self.groups
 
@@ -327,7 +365,8 @@ class Engine:
             return g
         per_read_sample = isinstance(sample_of, list)
         if strata_of is None and not per_read_sample:
-            return np.full(n, get(sample_of, None), dtype=np.int32)
+            # one sample for the whole chunk: one group id (WK_GROUP_UNIFORM)
+            return get(sample_of, None)
         out = np.empty(n, dtype=np.int32)
         for i in range(n):
             s = sample_of[i] if per_read_sample else sample_of
@@ -409,6 +448,15 @@ class Engine:
             fresh = 1
         if len(self.groups) + fresh >= MAX_GROUPS // 2:
             self.collect(data)
+        # ... and for its count keys (before the chunk's group ids are taken:
+        # folding the table to the host starts a new set of groups)
+        if ordinal:     # a hit matches a few genes at most
+            n_rec = 4 * int((self._hits if packed is None else packed)[-1][-1])
+        elif packed is not None:
+            n_rec = int(packed[0].size)
+        else:
+            n_rec = sum(map(len, subque))
+        self._ensure_table(data, n_rec, min(max(n, 1), fresh))
         seen = None
         if sample_ids is not None:
             group, seen = self._sample_groups(sample_ids, allow)
@@ -429,12 +477,14 @@ class Engine:
         if ordinal:
             genome, beg, end, length, hoff = \
                 self._hits if packed is None else packed
+            if np.ndim(group) == 0:     # (the coord-match stage takes an array)
+                group = np.full(hoff.size - 1, group, dtype=np.int32)
             self.ctx.ordinal_stage(genome, beg, end, length, hoff, self._th,
                                    group=group)
             self.ctx.ordinal_match()
             before = self.ctx.stats()['n_reads']
-            assign = self.ctx.classify_staged(self.jobs, want_assign=want)
-            nq = self.ctx.stats()['n_reads'] - before
+            assign = self._classify_staged(data, want)
+            nq = (self.ctx.stats()['n_reads'] - before) // self._n_batches()
             if want:
                 subj, qoff = self.ctx.chunk_download()
         else:
@@ -450,11 +500,11 @@ class Engine:
                 self.ctx.set_subjects(self.subj_feature)
             # the Python parsers and the native tokenizer hand over sets;
             # trimming can merge subjects
-            assign = self.ctx.classify_chunk(
-                self.jobs, subj, qoff, group=group,
+            self.ctx.chunk_stage(
+                subj, qoff, group=group,
                 subj_is_set=(packed_is_set if packed is not None
-                             else not trimsub),
-                want_assign=want, indexed=True)
+                             else not trimsub), indexed=True)
+            assign = self._classify_staged(data, want)
             if want:    # read maps work on feature ids
                 subj = np.asarray(self.subj_feature, dtype=np.int32)[subj]
             nq = n
@@ -469,6 +519,31 @@ class Engine:
         return nq
 
     # ------------------------------------------------------------------
+    def _n_batches(self):
+        return (len(self.jobs) + nat.MAX_JOBS - 1) // nat.MAX_JOBS
+
+    def _classify_staged(self, data, want):
+        """All ranks over the staged chunk.  One launch carries at most
+        WK_MAX_JOBS jobs (3 key bits); more ranks (`--rank a,b,...` has no
+        limit in the reference, workflow.py:333-335) run in batches over the
+        same staged chunk, the counts of a batch folded to the host before the
+        next one reuses the job numbers."""
+        if len(self.jobs) <= nat.MAX_JOBS:
+            return self.ctx.classify_staged(self.jobs, want_assign=want)
+        parts = []
+        self.collect(data, keep_groups=True)
+        for lo in range(0, len(self.jobs), nat.MAX_JOBS):
+            self._job_base = lo
+            try:
+                parts.append(self.ctx.classify_staged(
+                    self.jobs[lo:lo + nat.MAX_JOBS], want_assign=want))
+                if self.sizes:
+                    self._collect_log()
+                self.collect(data, keep_groups=True)
+            finally:
+                self._job_base = 0
+        return np.concatenate(parts) if want else None
+
     def _rank_table(self, slot):
         if slot not in self._anc:
             self._anc[slot] = self.ctx.get_rank_table(slot)
@@ -592,14 +667,16 @@ class Engine:
                 break
             except OverflowError:
                 self.ctx.log_reserve(self.ctx._log_cap * 4)
-                self.ctx.classify_staged(self.jobs)
+                self.ctx.classify_staged(
+                    self.jobs[self._job_base:self._job_base + nat.MAX_JOBS])
         if not rows.size:
             return
         uniq, cnt = np.unique(rows, axis=0, return_counts=True)
         acc = self.sized
         groups = self.groups
         for (f, s, meta, g), c in zip(uniq.tolist(), cnt.tolist()):
-            key = (meta >> 16, groups[g], f, s, meta & 0xFFFF)
+            key = (self._job_base + (meta >> 16), groups[g], f, s,
+                   meta & 0xFFFF)
             acc[key] = acc.get(key, 0) + c
 
     def _finish_sized(self, data):
@@ -622,10 +699,11 @@ class Engine:
             data[rank].setdefault(sample, {})[key] = fsum(vals)
         self.sized = {}
 
-    def collect(self, data):
+    def collect(self, data, keep_groups=False):
         """Fetch the device counts, fold them into ``data`` as exact
         ``Fraction``s (sum_k n_k / k, classify.py:167-170) and clear the
-        device table."""
+        device table.  ``keep_groups``: the (sample, stratum) group ids stay
+        valid (the staged chunk is classified again under other jobs)."""
         while True:
             try:
                 keys, vals = self.ctx.counts_fetch()
@@ -665,7 +743,7 @@ class Engine:
                     if stratum is not None:
                         labels = [(stratum, x) for x in labels]
                     dst = self._units.setdefault(
-                        (self.ranks[int(cj[a])], sample), {})
+                        (self.ranks[self._job_base + int(cj[a])], sample), {})
                     if dst:
                         get = dst.get
                         for key, u in zip(labels, tot[a:b].tolist()):
@@ -679,9 +757,12 @@ class Engine:
                 name = 'Unassigned' if f == nat.FEATURE_UNASSIGNED \
                     else names[f]
                 key = name if stratum is None else (stratum, name)
-                dst = self._big.setdefault((self.ranks[j], sample), {})
+                dst = self._big.setdefault(
+                    (self.ranks[self._job_base + j], sample), {})
                 dst[key] = dst.get(key, 0) + Fraction(nn, kk)
         self.ctx.counts_clear()
+        if keep_groups:
+            return
         self.groups = []
         self.group_ids = {}
         self._epoch += 1

@@ -143,6 +143,9 @@ struct wk_ctx {
     DevBuf left_mask, left_list, first_slab;
     // weighted subject histogram (wk_weigh.hpp): 0 = off, 1 = auto, 2 = whenever applicable
     int use_weigh = 1;
+    int weigh_interleave = 0;  // thread-per-read kernel: subject s in slice s mod S instead of s div bins
+    int weigh_stream = 1;   // one lane per record (weigh_stream_kernel) when every subject is valid
+    int weigh_rpw = 0;      // reads per wave and tile of that kernel: 0 = from the mean hits per read
     DevBuf w_slab, w_hi, w_invalid;
     size_t w_hi_clean = 0;        // leading entries of w_hi known to be zero
     bool rows_any_invalid = false;  // some subject lacks an ancestor at a rank column of the current rows
@@ -272,6 +275,13 @@ extern "C" {
 
 int wk_abi_version(void) { return WK_ABI_VERSION; }
 
+#ifndef WK_BUILD_ID
+#define WK_BUILD_ID "unknown"
+#endif
+// (the tag is also what the build recipe looks for in the file's bytes)
+static const char kBuildTag[] = "WK_BUILD_ID=" WK_BUILD_ID;
+const char* wk_build_id(void) { return kBuildTag + 12; }
+
 int wk_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
@@ -337,6 +347,8 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_subjects_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_stream_kernel<5, 2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStreamMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
@@ -448,6 +460,19 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "weigh")) {  // 0 = off, 1 = auto (large multi-hit chunks), 2 = whenever the jobs allow it
         if (value < 0 || value > 2) return fail(c, WK_E_ARG, "weigh must be 0, 1 or 2");
         c->use_weigh = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "weigh_interleave")) {
+        c->weigh_interleave = value ? 1 : 0;
+        return WK_OK;
+    }
+    if (!strcmp(name, "weigh_stream")) {
+        c->weigh_stream = value ? 1 : 0;
+        return WK_OK;
+    }
+    if (!strcmp(name, "weigh_rpw")) {
+        if (value != 0 && value != 16 && value != 32 && value != 64) return fail(c, WK_E_ARG, "weigh_rpw must be 0, 16, 32 or 64");
+        c->weigh_rpw = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "tiled")) {
@@ -873,15 +898,17 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             if (weigh && c->use_weigh == 1)
                 weigh = c->n_reads >= (1 << 16) && c->n_records > c->n_reads + c->n_reads / 64;
             uint32_t w_bins = 0, w_slices = 0, w_teams = 0, w_xcd = 8, w_inv_words = 0;
+            bool w_stream = false;
             if (weigh) {
                 const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
                 if (cus % w_xcd) w_xcd = 1;
                 w_inv_words = c->rows_any_invalid ? ((uint32_t)c->n_subjects + 31u) / 32u : 0u;
-                const int64_t cap = ((int64_t)kWeighMaxLds - 4 * (int64_t)w_inv_words) / 4;
+                w_stream = c->weigh_stream && !w_inv_words;
+                const int64_t cap = w_stream ? ((int64_t)kStreamMaxLds - 16 * 4 * (int64_t)kStreamScratch) / 4
+                                             : ((int64_t)kWeighMaxLds - 4 * (int64_t)w_inv_words) / 4;
                 if (cap >= 1024) {
                     w_slices = (uint32_t)((c->n_subjects + cap - 1) / cap);
-                    w_bins = (((uint32_t)c->n_subjects + w_slices - 1) / w_slices + 63u) & ~63u;
-                    if (w_bins > cap) w_bins = (uint32_t)cap;
+                    w_bins = ((uint32_t)c->n_subjects + w_slices - 1) / w_slices;  // subject s: slice s mod S, bin s div S
                     w_teams = (cus / w_xcd) / w_slices;
                 }
                 if (!w_teams || (int64_t)w_bins * w_slices < c->n_subjects) weigh = false;
@@ -968,6 +995,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 wa.subj = a.subj;
                 wa.qoff = a.qoff;
                 wa.n_reads = (uint32_t)c->n_reads;
+                wa.n_records = (uint32_t)c->n_records;
                 wa.n_subjects = (uint32_t)c->n_subjects;
                 wa.bins = w_bins;
                 wa.n_slices = w_slices;
@@ -979,9 +1007,18 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 wa.hi = c->w_hi.as<uint32_t>();
                 wa.left_mask = c->left_mask.as<unsigned long long>();
                 wa.stat_block = a.stat_block;
+                wa.err = scalar_err(c);
                 const size_t wlds = (size_t)w_bins * 4 + (size_t)w_inv_words * 4;
                 const dim3 wgrid((unsigned)c->prop.multiProcessorCount);
-                if (w_inv_words)
+                wa.interleave = w_stream ? 0u : (uint32_t)c->weigh_interleave;
+                // reads per wave and tile of the record-parallel kernel: the run of a
+                // wave should fit its 512 prefetched positions
+                const double mean_hits = (double)c->n_records / (double)c->n_reads;
+                wa.reads_per_wave = c->weigh_rpw ? (uint32_t)c->weigh_rpw : mean_hits <= 6.5 ? 64u : mean_hits <= 13.0 ? 32u : 16u;
+                if (w_stream)
+                    hipLaunchKernelGGL((weigh_stream_kernel<5, 2>), wgrid, dim3(kWeighThreads),
+                                       (size_t)w_bins * 4 + 16 * 4 * (size_t)kStreamScratch, c->stream, wa);
+                else if (w_inv_words)
                     hipLaunchKernelGGL(weigh_subjects_kernel<false>, wgrid, dim3(kWeighThreads), wlds, c->stream, wa);
                 else
                     hipLaunchKernelGGL(weigh_subjects_kernel<true>, wgrid, dim3(kWeighThreads), wlds, c->stream, wa);
@@ -993,6 +1030,8 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 wm.n_subjects = wa.n_subjects;
                 wm.bins = w_bins;
                 wm.n_teams = n_teams;
+                wm.n_slices = w_slices;
+                wm.interleave = wa.interleave;
                 wm.rows = a.rows;
                 wm.row_w = a.row_w;
                 wm.n_jobs = n_jobs;

@@ -47,6 +47,76 @@ class FeatureIndex:
         return self.ids.get(name, default)
 
 
+class _NodeNames:
+    """Sequence view of the feature names of a ``NodeIndex`` (pre-order node
+    names, then the names interned later), without a reordered copy of the
+    node names."""
+
+    def __init__(self, index):
+        self._ix = index
+
+    def __len__(self):
+        return len(self._ix)
+
+    def __getitem__(self, i):
+        ix = self._ix
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(ix)))]
+        if i < 0:
+            i += len(ix)
+        if i < ix.n_nodes:
+            return ix._in[ix._inv[i]]
+        return ix._extra[i - ix.n_nodes]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class NodeIndex(FeatureIndex):
+    """``FeatureIndex`` of a flattened hierarchy that shares the flattening's
+    own structures instead of building a second name list and a second
+    dictionary over millions of nodes: node names stay in input order
+    (``_in``) next to the name -> input position dict (``_pos``), the
+    pre-order number of input position ``i`` is ``_pre[i]`` and ``_inv`` is the
+    inverse permutation.  Names interned later get ids ``>= n_nodes``."""
+
+    def __init__(self, names_in, pos_of, pre, inv):
+        self._in, self._pos, self._pre, self._inv = names_in, pos_of, pre, inv
+        self.n_nodes = len(names_in)
+        self._extra, self._extra_ids = [], {}
+
+    def __len__(self):
+        return self.n_nodes + len(self._extra)
+
+    @property
+    def names(self):
+        return _NodeNames(self)
+
+    @property
+    def ids(self):
+        """name -> id as a dict (materialised; tests and debugging)."""
+        d = {x: int(self._pre[i]) for x, i in self._pos.items()}
+        d.update(self._extra_ids)
+        return d
+
+    def intern(self, name):
+        i = self._pos.get(name)
+        if i is not None:
+            return int(self._pre[i])
+        j = self._extra_ids.get(name)
+        if j is None:
+            j = self.n_nodes + len(self._extra)
+            self._extra_ids[name] = j
+            self._extra.append(name)
+        return j
+
+    def get(self, name, default=-1):
+        i = self._pos.get(name)
+        if i is not None:
+            return int(self._pre[i])
+        return self._extra_ids.get(name, default)
+
+
 class Hierarchy:
     """Pre-order flattened hierarchy.
 
@@ -223,7 +293,7 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
     ids = np.arange(n, dtype=np.int64)
     inv = np.empty(n, dtype=np.int64)
     inv[pre] = ids
-    index = FeatureIndex([names[i] for i in inv.tolist()])
+    index = NodeIndex(names, tmp, pre, inv)
     parent = pre[par][inv].astype(np.int32)
     last = (pre + size - 1)[inv].astype(np.int32)
     dep = depth[inv].astype(np.int32)
@@ -231,18 +301,13 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
     rank_codes = {}
     rank_code = np.zeros(n, dtype=np.int32)
     if rankdic:
-        # codes in order of first appearance among the ranked nodes of the tree
-        at = np.fromiter(map(tmp.get, rankdic, repeat(-1)), dtype=np.int64,
-                         count=len(rankdic))
-        ranks = list(rankdic.values())
-        keep = at >= 0
-        if None in set(ranks):
-            keep &= np.fromiter((r is not None for r in ranks), dtype=bool,
-                                count=len(ranks))
-        if not keep.all():
-            ranks = [r for r, k in zip(ranks, keep.tolist()) if k]
-            at = at[keep]
-        rank_codes = {r: i + 1 for i, r in enumerate(dict.fromkeys(ranks))}
-        rank_code[pre[at]] = np.fromiter(map(rank_codes.__getitem__, ranks),
-                                         dtype=np.int32, count=len(ranks))
+        # codes in order of first appearance among the ranked nodes of the
+        # tree, found in one pass over the nodes (two C-level maps, no second
+        # name -> position lookup per ranked node)
+        ranks_in = list(map(rankdic.get, names))
+        rank_codes = {r: i + 1 for i, r in enumerate(
+            x for x in dict.fromkeys(ranks_in) if x is not None)}
+        codes_in = np.fromiter(map(rank_codes.get, ranks_in, repeat(0)),
+                               dtype=np.int32, count=n)
+        rank_code = codes_in[inv]
     return Hierarchy(index, parent, last, rank_code, rank_codes, dep)
