@@ -357,3 +357,65 @@ def test_simple_formats_match_reference(threads, block):
             else:
                 want = [(q, set(s)) for q, s in d[key]]
             assert got == want, (name, key, threads, block)
+
+
+def test_query_run_longer_than_the_stream_buffer():
+    """Stream path (pipes, compressed input): one query with far more records
+    than a block holds makes the reader grow its buffer while views of it are
+    alive — a new buffer, not a resize (which raised BufferError)."""
+    subs = [f'G{i:05d}' for i in range(4000)]
+    lines = ['a\t0\tG0\t1\t1\t10M\t*\t0\t0\t*\t*\n'] + \
+        [f'long\t0\t{s}\t1\t1\t10M\t*\t0\t0\t*\t*\n' for s in subs] + \
+        ['z\t0\tG1\t1\t1\t10M\t*\t0\t0\t*\t*\n']
+    text = ''.join(lines).encode()
+    exp = list(align.parse_align(lines, 'sam'))
+    for block in (256, 1500):
+        reads, _ = run_native(text, 2, block)
+        assert reads == exp
+
+
+SAM_OK = 'q1\t0\tG1\t10\t1\t10M\t*\t0\t0\t*\t*\n'
+
+
+@pytest.mark.parametrize('bad,extra', [
+    ('\n', False),                                          # blank line in the body
+    ('\n', True),
+    ('q2\t0\tG1\tx7\t1\t10M\t*\t0\t0\t*\t*\n', True),       # int(pos)
+    ('q2\t0\tG1\t7\t1\tM\t*\t0\t0\t*\t*\n', True),          # int('') in the CIGAR
+    ('q2\t0\tG1\t7\t1\t5Z3M\t*\t0\t0\t*\t*\n', True),       # int('Z3')
+])
+def test_malformed_sam_raises_like_the_reference(bad, extra):
+    """Where the reference's parsers raise ValueError (align.py:313, 382-385,
+    572-583) the native tokenizer must not produce counts."""
+    lines = [SAM_OK, bad, SAM_OK.replace('q1', 'q3')]
+    with pytest.raises(ValueError):
+        list(align.parse_align(lines, 'sam', None, extra))
+    with pytest.raises(ValueError):
+        run_native(''.join(lines).encode(), 2, 1 << 16, extra=extra)
+
+
+def test_sam_fields_the_reference_accepts():
+    """A negative POS is an int; CIGAR text that never reaches an M/=/X/D/N
+    operation is never converted (e.g. '*')."""
+    lines = [SAM_OK,
+             'q2\t0\tG1\t-5\t1\t10M\t*\t0\t0\t*\t*\n',
+             'q3\t0\tG2\t7\t1\t*\t*\t0\t0\t*\t*\n',
+             'q4\t0\tG2\t7\t1\t3S4M2I1D\t*\t0\t0\t*\t*\n']
+    exp = list(align.parse_align(lines, 'sam', None, True))
+    got, _ = run_native(''.join(lines).encode(), 1, 1 << 16, extra=True)
+    # (zero-length hits are dropped by the coord-match flavour, ordinal.py:231)
+    exp = [(q, [r for r in recs if r[2]]) for q, recs in exp]
+    assert got == [(q, recs) for q, recs in exp if recs]
+    assert dict(got)['q2'][0][3] == -6
+
+
+def test_b6o_ex_needs_a_float_score():
+    row = 'q1\tG1\t99.0\t100\t0\t0\t1\t100\t5\t104\t1e-9\t{}\n'
+    ok = [row.format('200'), row.format('1.5e2').replace('q1', 'q2')]
+    got, _ = run_native(''.join(ok).encode(), 1, 1 << 16, extra=True, fmt='b6o')
+    assert [q for q, _ in got] == ['q1', 'q2']
+    bad = [ok[0], row.format('high').replace('q1', 'q2')]
+    with pytest.raises(ValueError):
+        list(align.parse_align(bad, 'b6o', None, True))
+    with pytest.raises(ValueError):
+        run_native(''.join(bad).encode(), 1, 1 << 16, extra=True, fmt='b6o')

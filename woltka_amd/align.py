@@ -359,9 +359,18 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
     buf[:fill] = head
     first = True
     readinto = getattr(stream, 'readinto', None)
+
+    def grown(old, used):
+        """A buffer twice the size holding the first `used` bytes of `old` (a
+        bytearray cannot be resized while a memoryview of it is alive: the
+        views handed to the consumer may be, so a new one is allocated)."""
+        new = bytearray(2 * len(old))
+        new[:used] = memoryview(old)[:used]
+        return new
+
     while True:
         if len(buf) - fill < block_bytes // 2:
-            buf.extend(bytes(len(buf)))         # a run longer than the buffer
+            buf = grown(buf, fill)              # a run longer than the buffer
         view = memoryview(buf)
         if readinto is not None:
             got = readinto(view[fill:]) or 0
@@ -378,8 +387,9 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
                         want_samples=want_samples, fmt=fmt)
         used = res['consumed']
         if used == 0 and not final and res['off'].size == 1:
+            del view
             if fill == len(buf):
-                buf.extend(bytes(len(buf)))
+                buf = grown(buf, fill)
             continue                            # no complete run yet: read more
         first = False
         yield view[:fill], res

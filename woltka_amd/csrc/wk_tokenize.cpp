@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -111,6 +112,7 @@ struct Line {
     size_t rn;
     int flag;
     const char* pos;
+    const char* pos_end;
     const char* cigar;
     size_t cn;
     bool ok;
@@ -147,6 +149,7 @@ inline Line parse_line(const char* p, const char* e, bool extra) {
         const char* t6 = (const char*)memchr(t5 + 1, '\t', e - t5 - 1);
         if (!t6) return L;
         L.pos = t3 + 1;
+        L.pos_end = t4;
         L.cigar = t5 + 1;
         L.cn = t6 - t5 - 1;
     }
@@ -229,6 +232,26 @@ inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
             L.bad_number = true;
             return L;
         }
+        {   // score = float(x[11]) must parse as well (align.py:832)
+            const char* sb = fb(11);
+            const char* se = fe(11);
+            while (sb < se && (*sb == ' ' || (*sb >= '\t' && *sb <= '\r'))) ++sb;
+            while (se > sb && (se[-1] == ' ' || (se[-1] >= '\t' && se[-1] <= '\r'))) --se;
+            char tmp[64];
+            const size_t sn = (size_t)(se - sb);
+            char* endp = nullptr;
+            bool okf = sn > 0 && sn < sizeof tmp;
+            if (okf) {
+                memcpy(tmp, sb, sn);
+                tmp[sn] = 0;
+                (void)strtod(tmp, &endp);
+                okf = endp == tmp + sn;
+            }
+            if (!okf) {
+                L.bad_number = true;
+                return L;
+            }
+        }
         L.len = (uint32_t)n;
         L.beg = (int32_t)((a < b ? a : b) - 1);
         L.end = (int32_t)(a < b ? b : a);
@@ -248,23 +271,36 @@ inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
 
 inline bool is_row(int fmt, const Line& L) { return L.ok && !(fmt == WK_FMT_SAM && is_unmapped(L)); }
 
-// align.cigar_to_lens (align.py:550-583)
-inline void cigar_lens(const char* c, size_t n, uint32_t& aligned, uint32_t& span) {
+// align.cigar_to_lens (align.py:550-583).  false where the reference raises:
+// int() of the characters collected since the last operation runs only for
+// M = X D N, and refuses an empty string or anything but digits.
+inline bool cigar_lens(const char* c, size_t n, uint32_t& aligned, uint32_t& span) {
     uint64_t a = 0, x = 0, num = 0;
+    bool digits = false, clean = true;  // the pending number: has digits / digits only
     for (size_t i = 0; i < n; ++i) {
         const char ch = c[i];
         if (ch >= '0' && ch <= '9') {
             num = num * 10 + (ch - '0');
-        } else {
-            if (ch == 'M' || ch == '=' || ch == 'X')
-                a += num;
-            else if (ch == 'D' || ch == 'N')
+            digits = true;
+        } else if (ch == 'M' || ch == '=' || ch == 'X' || ch == 'D' || ch == 'N') {
+            if (!digits || !clean) return false;
+            if (ch == 'D' || ch == 'N')
                 x += num;
+            else
+                a += num;
             num = 0;
+            digits = false;
+        } else if (ch == 'I' || ch == 'H' || ch == 'P' || ch == 'S') {
+            num = 0;
+            digits = false;
+            clean = true;
+        } else {
+            clean = false;  // joins the pending text: int() fails at the next M = X D N
         }
     }
     aligned = (uint32_t)a;
     span = (uint32_t)(a + x);
+    return true;
 }
 
 inline const char* next_line(const char* p, const char* e) {
@@ -377,7 +413,9 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
         const char* line = p;
         p = nl ? nl + 1 : e;
         if (!L.ok) {
-            if (le == line) continue;  // empty line
+            // (an empty line inside a SAM body fails `line.split('\t', 3)`
+            // like any other short line, align.py:313; the other formats skip it)
+            if (le == line && fmt != WK_FMT_SAM) continue;
             if (fmt != WK_FMT_SAM && !L.bad_number) continue;  // not a row of this format
             out.error = 2;
             out.error_at = line - base;
@@ -412,10 +450,15 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
         }
         rc.subj = id;
         if (extra && fmt == WK_FMT_SAM) {
+            // int(pos) and cigar_to_lens raise on text that is not a number
+            // (align.py:382-385); a negative POS is a number
             long pos = 0;
-            for (const char* c = L.pos; *c >= '0' && *c <= '9'; ++c) pos = pos * 10 + (*c - '0');
-            uint32_t aligned, span;
-            cigar_lens(L.cigar, L.cn, aligned, span);
+            uint32_t aligned = 0, span = 0;
+            if (!parse_int(L.pos, L.pos_end, pos) || !cigar_lens(L.cigar, L.cn, aligned, span)) {
+                out.error = 2;
+                out.error_at = line - base;
+                return;
+            }
             if (aligned == 0 && !keep_empty) continue;  // ordinal.py:231 (range.py keeps them)
             rc.beg = (int32_t)(pos - 1);
             rc.end = (int32_t)(pos - 1 + span);
