@@ -161,6 +161,9 @@ class Engine:
         self._table_fixed = table_slots
         self._reserve(table_slots or max(1 << 20, 4 * len(self.index)))
         self._job_base = 0                  # first job of the batch in flight
+        self._final = {}                    # (rank, sample) -> (units, big) of the last `finish`
+        self._n_reads = 0                   # reads classified (bounds the mapper chunks)
+        self._replay = None
         self.genes = None
         self.gene_feature = None
         # dense subject indices (order of first appearance in the alignments)
@@ -473,7 +476,8 @@ class Engine:
         for rank in self.ranks:
             for s in seen:
                 data[rank].setdefault(s, {})
-        want = rank2dir is not None
+        want = rank2dir is not None or self._replay is not None
+        self._n_reads += n
         if ordinal:
             genome, beg, end, length, hoff = \
                 self._hits if packed is None else packed
@@ -510,6 +514,9 @@ class Engine:
             nq = n
         if self.sizes:
             self._collect_log()
+        if self._replay is not None:
+            self._replay_chunk(assign, subj, qoff, group, n)
+            return nq
         if want and names is not None:
             self._write_maps_native(assign, subj, qoff, names, sample_of,
                                     rank2dir, outzip, namedic)
@@ -517,6 +524,145 @@ class Engine:
             self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,
                              outzip, namedic)
         return nq
+
+    # ------------------------------------------------------------------
+    # Certification of the rounding and replay in the reference's order
+    # (certify.py): the device sums exactly, the reference sums binary64
+    # numbers chunk by chunk; where the two might round differently the cell
+    # is summed again the reference's way.
+    def begin_file(self):
+        """A new alignment file starts: the reference's mapper chunks count
+        queries per file (align.plain_mapper, align.py:84-115)."""
+        if self._replay is not None:
+            self._replay['pos'] = 0
+
+    def uncertified(self, digits=None, factor=None, chunk_n=1024):
+        """{rank: {sample: [keys]}} of the cells of the last `finish` that are
+        not certain to round like the reference's.  Only plain list-producing
+        assignments add fractions; every other job adds integers, which
+        binary64 adds exactly."""
+        from . import certify
+        out = {}
+        lists = {rank for rank, job in zip(self.ranks, self.jobs)
+                 if job.mode != nat.MODE_FREE and not job.flags & nat.F_UNIQ
+                 and not (job.mode == nat.MODE_RANK and (
+                     job.flags & nat.F_ABOVE or job.major > 0))}
+        for (rank, sample), (units, big) in self._final.items():
+            if rank not in lists:
+                continue
+            keys = certify.uncertified(units, big, self._n_reads,
+                                       nat.WEIGHT_L, digits, factor, chunk_n)
+            if keys:
+                out.setdefault(rank, {})[sample] = keys
+        return out
+
+    def replay_begin(self, targets, chunk_n):
+        """Next pass over the input: instead of counting, sum the addends of
+        the `targets` cells ({rank: {sample: keys}}) in read order, `chunk_n`
+        queries per partial sum (classify.counter + util.sum_dict)."""
+        self._replay = dict(targets=targets, chunk_n=int(chunk_n), pos=0,
+                            total={})
+        self._gmap_key = self._smap_key = None
+
+    def replay_end(self):
+        """{(rank, sample, key): value as the reference holds it before
+        rounding}; leaves replay mode and drops the counts of the pass."""
+        res = self._replay['total']
+        self._replay = None
+        self.ctx.counts_clear()
+        self.groups, self.group_ids = [], {}
+        self._epoch += 1
+        return res
+
+    def _replay_chunk(self, assign, subj, qoff, group, n):
+        rp = self._replay
+        base = rp['pos']
+        rp['pos'] = base + n
+        if n == 0:
+            return
+        garr = np.full(n, group, dtype=np.int64) if np.ndim(group) == 0 \
+            else np.asarray(group, dtype=np.int64)
+        unas = bool(self.jobs[0].flags & nat.F_UNASSIGNED)
+        for j, rank in enumerate(self.ranks):
+            want = rp['targets'].get(rank)
+            if not want:
+                continue
+            # (group, feature) codes of this chunk's targets
+            codes, cells = [], []
+            for g, (sample, stratum) in enumerate(self.groups):
+                for key in want.get(sample, ()):
+                    name = key
+                    if stratum is not None:
+                        if not isinstance(key, tuple) or key[0] != stratum:
+                            continue
+                        name = key[1]
+                    elif isinstance(key, tuple):
+                        continue
+                    f = nat.FEATURE_UNASSIGNED if name == 'Unassigned' \
+                        else self.index.get(name)
+                    if f >= 0:
+                        codes.append((g << 32) | f)
+                        cells.append((rank, sample, key))
+            if not codes:
+                continue
+            order = np.argsort(np.array(codes, dtype=np.int64))
+            tcodes = np.array(codes, dtype=np.int64)[order]
+
+            def match(code):
+                i = np.searchsorted(tcodes, code)
+                i[i == tcodes.size] = 0
+                return np.where(tcodes[i] == code, order[i], -1)
+            row = assign[j].astype(np.int64)
+            ok = garr >= 0
+            # integer addends: reads assigned to one feature (or 'Unassigned')
+            feat = np.where(row >= 0, row, np.where(
+                (row == nat.ASSIGN_NONE) & unas, nat.FEATURE_UNASSIGNED, -1))
+            r_int = np.flatnonzero(ok & (feat >= 0))
+            t_int = match((garr[r_int] << 32) | feat[r_int])
+            keep = t_int >= 0
+            r_all, t_all = [r_int[keep]], [t_int[keep]]
+            v_all, m_all = [np.ones(int(keep.sum()))], \
+                [np.ones(int(keep.sum()), dtype=np.int64)]
+            # list addends: m entries of 1 / k each (classify.py:167-170)
+            multi = np.flatnonzero(row == nat.ASSIGN_MULTI)
+            if multi.size:
+                m_off, m_feat, m_count = self._multi_lists(j, assign[j], subj,
+                                                           qoff)
+                per = np.diff(m_off)
+                r_l = np.repeat(multi, per)
+                # k of a read = its entries that are not None, repeats counted
+                k_read = np.add.reduceat(m_count.astype(np.int64),
+                                         m_off[:-1][per > 0]) \
+                    if m_feat.size else np.empty(0, np.int64)
+                k = np.repeat(k_read, per[per > 0])
+                okl = garr[r_l] >= 0
+                t_l = match((garr[r_l] << 32) | m_feat.astype(np.int64))
+                keep = okl & (t_l >= 0)
+                r_all.append(r_l[keep])
+                t_all.append(t_l[keep])
+                v_all.append(1.0 / k[keep])
+                m_all.append(m_count.astype(np.int64)[keep])
+            r = np.concatenate(r_all)
+            if not r.size:
+                continue
+            t = np.concatenate(t_all)
+            v = np.concatenate(v_all)
+            m = np.concatenate(m_all)
+            # target-major, then read order (a read adds its m entries in a row)
+            o = np.lexsort((r, t))
+            r, t = np.repeat(r[o], m[o]), np.repeat(t[o], m[o])
+            v = np.repeat(v[o], m[o])
+            chunk_id = (base + r) // rp['chunk_n']
+            seg = np.flatnonzero(np.concatenate((
+                [True], (t[1:] != t[:-1]) | (chunk_id[1:] != chunk_id[:-1]))))
+            ends = np.concatenate((seg[1:], [r.size]))
+            total = rp['total']
+            for a, b in zip(seg.tolist(), ends.tolist()):
+                # the chunk's dict starts at int 0 and adds in read order;
+                # numpy's cumulative sum is that left-to-right binary64 sum
+                part = float(np.cumsum(v[a:b])[-1])
+                cell = cells[int(t[a])]
+                total[cell] = total.get(cell, 0) + part
 
     # ------------------------------------------------------------------
     def _n_batches(self):
@@ -774,6 +920,11 @@ class Engine:
         (profiles of several processes are then added exactly and converted
         once, ``exact_to_numbers``)."""
         self.collect(data)
+        # (kept for the certifier, `uncertified`)
+        self._final = {k: (v, dict(self._big.get(k, {})))
+                       for k, v in self._units.items()}
+        for k, v in self._big.items():
+            self._final.setdefault(k, ({}, dict(v)))
         # units of 1/L (+ the k > 16 rationals) -> the caller's profile
         L = nat.WEIGHT_L
         for (rank, sample), cells in self._units.items():

@@ -12,6 +12,7 @@ folded into the same dict.
 
 There is no CPU fallback: ``classify()`` needs ``libwoltka_hip.so`` and a GPU.
 """
+import contextlib
 import io
 from functools import partial
 from itertools import chain
@@ -95,7 +96,8 @@ def workflow(
             namedic if name_as_id else None, root, ranks, rank2dir,
             outmap_zip, uniq, major, above, subok, sizes, unassigned, stratmap,
             exclude, chunk, cache, zippers, outcov_dir, outcov_fmt, device=dev,
-            exact=exact)
+            exact=exact,
+            rounding=(digits, scale_factor(scale) if scale else None, frac))
 
     # one process per GPU under the torch.distributed launcher: alignment
     # files (samples) shard across processes, profiles merge on the host
@@ -138,14 +140,19 @@ def classify(
         unasgd: bool = False, stratmap: dict = None, exclude: set = None,
         chunk: int = None, cache: int = 1024, zippers: dict = None,
         outcov_dir: str = None, outcov_fmt: str = None, device: int = 0,
-        exact: bool = False) -> dict:
+        exact: bool = False, rounding: tuple = None) -> dict:
     """Core of the classification workflow (workflow.py:162-353) on the GPU.
 
     ``mapper`` is ``align.plain_mapper`` (or any generator with the reference's
     mapper protocol, workflow.py:304) or an ``OrdinalMapper``.  ``cache`` (the
     reference's per-rank LRU size) is accepted and ignored: nothing is
     memoised, every read is evaluated by the kernels.  Counts are accumulated
-    as exact integers on the device, so the result does not depend on ``chunk``.
+    as exact integers on the device, so the result does not depend on ``chunk``
+    — except where the reference's own float summation decides a rounding:
+    ``rounding`` = (digits, scale factor, frac) tells which rounding follows
+    (default: to integers), and cells that are not certain to round like the
+    reference's are summed again in its order, ``chunk`` (default 1024) queries
+    at a time (certify.py).
     """
     data = {x: {} for x in ranks}
     cover = Coverage() if outcov_dir else None
@@ -178,118 +185,140 @@ def classify(
             and cover is None
         allow = set(samples) if (demux and samples) else None
         engine._exclude = exclude
-        labels = None
-        for fp in sorted(files, key=file_key):
-            # (a FilePart is one of several byte ranges of a large file that
-            # other processes share, shard.partition_files)
-            path = file_path(fp)
-            part = (fp.part, fp.parts) if isinstance(fp, FilePart) else None
-            if path == '-':
-                stream = click.get_binary_stream('stdin')
-                click.echo('Parsing alignment from stdin ', nl=False)
-            else:
-                stream = readzip_bytes(path, zippers)
-                click.echo(f'Parsing alignment file {basename(path)} ',
-                           nl=False)
-            with stream:
-                nqry, nstep = 0, -1
-                fmt_, head = fmt, b''
-                if not fmt_:
-                    head = stream.readline()
-                    fmt_ = infer_align_format(iter(
-                        [head.decode()] if head else []))[0]
-                native = native_ok and fmt_ in NATIVE_FORMATS and not (
-                    fmt_ == 'map' and (ordinal or cover is not None))
-                if part is not None and not native:
-                    # byte ranges are a feature of the native tokenizer: the
-                    # first part takes the whole file, the others nothing
-                    if part[0]:
-                        click.echo(' Done.')
-                        continue
-                    part = None
-                want_names = bool((demux and not native_demux) or
-                                  rank2dir is not None or
-                                  (stratmap and not (native and native_strata)))
-                if native:
-                    if native_strata:
-                        sample = files[fp] if files else None
-                        if sample != csample or labels is None:
-                            labels = engine.load_strata(stratmap[sample],
-                                                        zippers)
-                            csample = sample
-                    # read ids as Python strings only when the host logic
-                    # needs them (demultiplexing, Python-side strata join);
-                    # read maps alone are formatted natively from descriptors
-                    want_strings = bool((demux and not native_demux) or (
-                        stratmap and not native_strata))
-                    chunks = engine.native_chunks(
-                        stream, head, exclude, NATIVE_BLOCK, ordinal,
-                        want_names, trimsub, want_groups=native_strata,
-                        want_strings=want_strings, want_samples=native_demux,
-                        cover=cover, fmt=fmt_, part=part)
+        def one_pass(rank2dir, cover):
+            """All files through the device once (the main pass; the replay of
+            uncertified cells runs it a second time)."""
+            nonlocal csample, strata
+            labels = None
+            for fp in sorted(files, key=file_key):
+                # (a FilePart is one of several byte ranges of a large file that
+                # other processes share, shard.partition_files)
+                path = file_path(fp)
+                part = (fp.part, fp.parts) if isinstance(fp, FilePart) else None
+                engine.begin_file()
+                if path == '-':
+                    stream = click.get_binary_stream('stdin')
+                    click.echo('Parsing alignment from stdin ', nl=False)
                 else:
-                    text = io.TextIOWrapper(stream, encoding='utf-8')
-                    fh = chain([head.decode()], text) if head else text
-                    if ordinal:
-                        chunks = engine.ordinal_chunks(fh, fmt_, exclude, n,
-                                                       mapper.th)
-                    else:
-                        chunks = mapper(fh, fmt=fmt_, excl=exclude, n=n)
-                for chunk_ in chunks:
-                    packed = strata_ids = names = sample_ids = None
+                    stream = readzip_bytes(path, zippers)
+                    click.echo(f'Parsing alignment file {basename(path)} ',
+                               nl=False)
+                with stream:
+                    nqry, nstep = 0, -1
+                    fmt_, head = fmt, b''
+                    if not fmt_:
+                        head = stream.readline()
+                        fmt_ = infer_align_format(iter(
+                            [head.decode()] if head else []))[0]
+                    native = native_ok and fmt_ in NATIVE_FORMATS and not (
+                        fmt_ == 'map' and (ordinal or cover is not None))
+                    if part is not None and not native:
+                        # byte ranges are a feature of the native tokenizer: the
+                        # first part takes the whole file, the others nothing
+                        if part[0]:
+                            click.echo(' Done.')
+                            continue
+                        part = None
+                    want_names = bool((demux and not native_demux) or
+                                      rank2dir is not None or
+                                      (stratmap and not (native and native_strata)))
                     if native:
-                        qryque, packed, strata_ids, names, sample_ids, \
-                            ranges = chunk_
-                        subque = None
-                        engine._th = mapper.th if ordinal else None
-                    elif ordinal:
-                        qryque = chunk_
-                        subque = None
+                        if native_strata:
+                            sample = files[fp] if files else None
+                            if sample != csample or labels is None:
+                                labels = engine.load_strata(stratmap[sample],
+                                                            zippers)
+                                csample = sample
+                        # read ids as Python strings only when the host logic
+                        # needs them (demultiplexing, Python-side strata join);
+                        # read maps alone are formatted natively from descriptors
+                        want_strings = bool((demux and not native_demux) or (
+                            stratmap and not native_strata))
+                        chunks = engine.native_chunks(
+                            stream, head, exclude, NATIVE_BLOCK, ordinal,
+                            want_names, trimsub, want_groups=native_strata,
+                            want_strings=want_strings, want_samples=native_demux,
+                            cover=cover, fmt=fmt_, part=part)
                     else:
-                        qryque, subque = chunk_
-                    # sample of every read (demultiplexing / whitelist)
-                    if demux and sample_ids is not None:
-                        sample_of, reads = None, None
-                    elif demux:
-                        sample_of, reads = demux_labels(qryque, samples)
-                    else:
-                        sample_of = files[fp] if files else None
-                        reads = qryque
-                    # (optional) aligned ranges per (sample, subject)
-                    # (parse_ranges, workflow.py:312)
-                    if cover is not None and native:
-                        if demux:
-                            per_read = np.fromiter(
-                                (-1 if x is False else cover.sample(x)
-                                 for x in sample_of), np.int64, len(sample_of))
-                            who = np.repeat(per_read, np.diff(packed[-1]))
+                        text = io.TextIOWrapper(stream, encoding='utf-8')
+                        fh = chain([head.decode()], text) if head else text
+                        if ordinal:
+                            chunks = engine.ordinal_chunks(fh, fmt_, exclude, n,
+                                                           mapper.th)
                         else:
-                            who = cover.sample(sample_of)
-                        cover.add(who, *ranges)
-                    elif cover is not None:
-                        cover.add_queries(sample_of, subque)
-                    # stratum of every read; the strata map of a sample is read
-                    # when the sample first shows up (workflow.py:327-330)
-                    strata_of = None
-                    if stratmap and strata_ids is None:
-                        strata_of, csample, strata = strata_labels(
-                            sample_of, reads, stratmap, zippers, csample,
-                            strata)
-                    nq = engine.run_chunk(
-                        data, reads, subque, sample_of, strata_of,
-                        None if native else trimsub,
-                        rank2dir, outzip, namedic, ordinal, packed=packed,
-                        strata_ids=strata_ids, strata_labels=labels,
-                        names=names, sample_ids=sample_ids, allow=allow,
-                        packed_is_set=not trimsub and cover is None)
-                    nqry += nq
-                    istep = nqry // 1000000 - nstep
-                    if istep:
-                        click.echo('.' * istep, nl=False)
-                        nstep += istep
-            click.echo(' Done.')
-            click.echo(f'  Number of sequences classified: {nqry}.')
+                            chunks = mapper(fh, fmt=fmt_, excl=exclude, n=n)
+                    for chunk_ in chunks:
+                        packed = strata_ids = names = sample_ids = None
+                        if native:
+                            qryque, packed, strata_ids, names, sample_ids, \
+                                ranges = chunk_
+                            subque = None
+                            engine._th = mapper.th if ordinal else None
+                        elif ordinal:
+                            qryque = chunk_
+                            subque = None
+                        else:
+                            qryque, subque = chunk_
+                        # sample of every read (demultiplexing / whitelist)
+                        if demux and sample_ids is not None:
+                            sample_of, reads = None, None
+                        elif demux:
+                            sample_of, reads = demux_labels(qryque, samples)
+                        else:
+                            sample_of = files[fp] if files else None
+                            reads = qryque
+                        # (optional) aligned ranges per (sample, subject)
+                        # (parse_ranges, workflow.py:312)
+                        if cover is not None and native:
+                            if demux:
+                                per_read = np.fromiter(
+                                    (-1 if x is False else cover.sample(x)
+                                     for x in sample_of), np.int64, len(sample_of))
+                                who = np.repeat(per_read, np.diff(packed[-1]))
+                            else:
+                                who = cover.sample(sample_of)
+                            cover.add(who, *ranges)
+                        elif cover is not None:
+                            cover.add_queries(sample_of, subque)
+                        # stratum of every read; the strata map of a sample is read
+                        # when the sample first shows up (workflow.py:327-330)
+                        strata_of = None
+                        if stratmap and strata_ids is None:
+                            strata_of, csample, strata = strata_labels(
+                                sample_of, reads, stratmap, zippers, csample,
+                                strata)
+                        nq = engine.run_chunk(
+                            data, reads, subque, sample_of, strata_of,
+                            None if native else trimsub,
+                            rank2dir, outzip, namedic, ordinal, packed=packed,
+                            strata_ids=strata_ids, strata_labels=labels,
+                            names=names, sample_ids=sample_ids, allow=allow,
+                            packed_is_set=not trimsub and cover is None)
+                        nqry += nq
+                        istep = nqry // 1000000 - nstep
+                        if istep:
+                            click.echo('.' * istep, nl=False)
+                            nstep += istep
+                click.echo(' Done.')
+                click.echo(f'  Number of sequences classified: {nqry}.')
+
+        one_pass(rank2dir, cover)
         engine.finish(data, exact)
+        # Cells whose exact value lies so close to a rounding boundary that
+        # the reference's float summation might land on the other side are
+        # summed once more in the reference's own order (certify.py).
+        if not exact and not sizes and not ordinal and cover is None and \
+                mapper is plain_mapper and '-' not in map(file_path, files):
+            digits, factor, frac = rounding or (None, None, False)
+            todo = {} if frac else engine.uncertified(
+                digits, factor, chunk or 1024)
+            if todo:
+                engine.replay_begin(todo, chunk or 1024)
+                csample, strata = False, None
+                with contextlib.redirect_stdout(io.StringIO()):
+                    one_pass(None, None)
+                for (rank, sample, key), value in engine.replay_end().items():
+                    data[rank][sample][key] = value
     finally:
         engine.close()
     if cover is not None:
