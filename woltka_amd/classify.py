@@ -50,38 +50,62 @@ def _prefetch(gen, depth=2):
     th.join()
 
 
-def _append_compressed(path, data, kind, block=8 << 20):
-    """Append ``data`` (bytes of whole lines) to ``path``; gz / bz2 / xz output
-    is written as independent members compressed in parallel (all three
-    formats allow concatenated streams)."""
-    if not data:
-        open(path, 'ab').close()
-        return
-    if not kind:
-        with open(path, 'ab') as f:
-            f.write(data)
-        return
-    import bz2
-    import lzma
-    import zlib
-    from concurrent.futures import ThreadPoolExecutor
+class MapWriter:
+    """Appends blocks of whole lines to (optionally compressed) files behind
+    the caller's back: the blocks of a call are cut at line ends into pieces,
+    each piece becomes an independent gz / bz2 / xz member compressed on a
+    thread pool (all three formats allow concatenated streams; gz members carry
+    their size, pgzip.py, so that the stratified second pass inflates them in
+    parallel), and the members are appended in order once they are ready —
+    while the device and the tokenizer work on the next chunk.  `flush` waits
+    for everything."""
 
-    def gz(b):
-        c = zlib.compressobj(4, zlib.DEFLATED, 31)
-        return c.compress(b) + c.flush()
-    pack = {'gz': gz, 'bz2': bz2.compress, 'xz': lzma.compress}[kind]
-    cuts, pos = [0], 0
-    while len(data) - pos > block:
-        nl = data.rfind(b'\n', pos, pos + block) + 1
-        pos = nl if nl > pos else pos + block
-        cuts.append(pos)
-    cuts.append(len(data))
-    parts = [data[a:b] for a, b in zip(cuts, cuts[1:])]
-    with ThreadPoolExecutor(max_workers=min(32, len(parts))) as ex:
-        packed = list(ex.map(pack, parts))
-    with open(path, 'ab') as f:
-        for p in packed:
-            f.write(p)
+    def __init__(self, threads=32, block=8 << 20):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=threads)
+        self._pending = []          # [(path, [future | bytes])] in call order
+        self._block = block
+
+    def append(self, path, data, kind):
+        if not kind or not data:
+            self._pending.append((path, [data]))
+        else:
+            import bz2
+            import lzma
+            from . import pgzip
+            pack = {'gz': pgzip.member, 'bz2': bz2.compress,
+                    'xz': lzma.compress}[kind]
+            block = self._block
+            cuts, pos = [0], 0
+            while len(data) - pos > block:
+                nl = data.rfind(b'\n', pos, pos + block) + 1
+                pos = nl if nl > pos else pos + block
+                cuts.append(pos)
+            cuts.append(len(data))
+            self._pending.append((path, [
+                self._pool.submit(pack, data[a:b])
+                for a, b in zip(cuts, cuts[1:])]))
+        self._drain(False)
+
+    def _drain(self, wait):
+        while self._pending:
+            path, parts = self._pending[0]
+            if not wait and not all(isinstance(x, bytes) or x.done()
+                                    for x in parts):
+                return
+            with open(path, 'ab') as f:
+                for x in parts:
+                    f.write(x if isinstance(x, bytes) else x.result())
+            self._pending.pop(0)
+
+    def flush(self):
+        self._drain(True)
+
+    def close(self):
+        try:
+            self.flush()
+        finally:
+            self._pool.shutdown(wait=True)
 
 
 _NO_TREE_ROOT = '\x00root'      # stand-in root when no hierarchy is given
@@ -164,6 +188,7 @@ class Engine:
         self._final = {}                    # (rank, sample) -> (units, big) of the last `finish`
         self._n_reads = 0                   # reads classified (bounds the mapper chunks)
         self._replay = None
+        self._writer = None                 # MapWriter of the native read maps
         self.genes = None
         self.gene_feature = None
         # dense subject indices (order of first appearance in the alignments)
@@ -185,9 +210,14 @@ class Engine:
         self._tok_cover = np.empty(0, dtype=np.int64)
 
     def close(self):
-        if self.tok is not None:
-            self.tok.close()
-        self.ctx.close()
+        try:
+            if self._writer is not None:
+                self._writer.close()
+                self._writer = None
+        finally:
+            if self.tok is not None:
+                self.tok.close()
+            self.ctx.close()
 
     # ------------------------------------------------------------------
     MAX_SLOTS = 1 << 30
@@ -228,7 +258,9 @@ class Engine:
         from .file import readzip_bytes
         if self.tok is None:
             self.tok = nat.Tokenizer(0, self._exclude)
-        with readzip_bytes(fp, zippers) as fh:
+        from . import pgzip
+        fh = pgzip.open_parallel(fp) if fp.endswith('.gz') else None
+        with (fh if fh is not None else readzip_bytes(fp, zippers)) as fh:
             labels = self.tok.load_strata(fh)
         if not labels:
             raise ValueError('No stratification information is found in file: '
@@ -800,8 +832,10 @@ class Engine:
                                       remap[m_feat] if m_feat.size else m_feat,
                                       m_count, shown, unassigned=unas)
             outfp = join(rank2dir[rank], f'{sample}.txt')
-            _append_compressed(f'{outfp}.{outzip}' if outzip else outfp, text,
-                               outzip)
+            if self._writer is None:
+                self._writer = MapWriter()
+            self._writer.append(f'{outfp}.{outzip}' if outzip else outfp,
+                                text, outzip)
 
     def _collect_log(self):
         """Fold the contribution log of the chunk just classified.  If the log
@@ -919,6 +953,8 @@ class Engine:
         rounded ``float`` division.  ``exact`` leaves the rationals in place
         (profiles of several processes are then added exactly and converted
         once, ``exact_to_numbers``)."""
+        if self._writer is not None:
+            self._writer.flush()
         self.collect(data)
         # (kept for the certifier, `uncertified`)
         self._final = {k: (v, dict(self._big.get(k, {})))
