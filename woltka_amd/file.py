@@ -10,6 +10,7 @@ I/O — nothing here is a kernel.
 import bz2
 import glob
 import gzip
+import io
 import lzma
 from os.path import basename, dirname, isfile, join, splitext
 from shutil import which
@@ -57,6 +58,136 @@ def readzip_bytes(fp, zippers=None):
     if zippers[kind]:
         return Popen([kind, '-cdfq', fp], stdout=PIPE).stdout
     return ZIP_MODULES[kind].open(fp, 'rb')
+
+
+class AheadStream(io.RawIOBase):
+    """Binary stream whose source (a decompressor: child process or codec
+    object) is drained by a helper thread into a bounded queue of blocks.
+    Several compressed alignment files are inflated at once this way while
+    the tokenizer works on the current one (decompression alone is 63 % of the
+    reference's run time on compressed input, doc/perform.md:44-46; the
+    decompressors are single-threaded per file)."""
+
+    def __init__(self, opener, block=1 << 24, depth=8):
+        import queue
+        import threading
+        super().__init__()
+        self._q = queue.Queue(maxsize=depth)
+        self._buf = memoryview(b'')
+        self._eof = False
+        self._stop = False
+        self._err = None
+
+        def work():
+            try:
+                with opener() as src:
+                    while not self._stop:
+                        data = src.read(block)
+                        self._q.put(data)
+                        if not data:
+                            return
+            except BaseException as e:      # re-raised in the reader
+                self._err = e
+                self._q.put(b'')
+
+        self._th = threading.Thread(target=work, daemon=True)
+        self._th.start()
+
+    def _more(self):
+        """Next block into the buffer; False at the end."""
+        if self._eof:
+            return False
+        data = self._q.get()
+        if not data:
+            self._eof = True
+            if self._err is not None:
+                raise self._err
+            return False
+        self._buf = memoryview(data)
+        return True
+
+    def readinto(self, out):
+        if not len(self._buf) and not self._more():
+            return 0
+        n = min(len(out), len(self._buf))
+        out[:n] = self._buf[:n]
+        self._buf = self._buf[n:]
+        return n
+
+    def read(self, n=-1):
+        parts, got = [], 0
+        while n < 0 or got < n:
+            if not len(self._buf) and not self._more():
+                break
+            k = len(self._buf) if n < 0 else min(n - got, len(self._buf))
+            parts.append(bytes(self._buf[:k]))
+            self._buf = self._buf[k:]
+            got += k
+        return b''.join(parts)
+
+    def readline(self):
+        parts = []
+        while True:
+            if not len(self._buf) and not self._more():
+                break
+            raw = bytes(self._buf)
+            i = raw.find(b'\n')
+            if i >= 0:
+                parts.append(raw[:i + 1])
+                self._buf = self._buf[i + 1:]
+                break
+            parts.append(raw)
+            self._buf = memoryview(b'')
+        return b''.join(parts)
+
+    def readable(self):
+        return True
+
+    def close(self):
+        if self.closed:
+            return
+        self._stop = True
+        while self._th.is_alive():          # unblock a producer stuck on put()
+            try:
+                self._q.get(timeout=0.05)
+            except Exception:
+                pass
+        self._th.join()
+        super().close()
+
+
+class FilesAhead:
+    """Opens the alignment files of a run in order, with the decompressors of
+    the next `depth` compressed files already running (`AheadStream`)."""
+
+    def __init__(self, paths, zippers=None, depth=4):
+        self._paths = list(paths)
+        self._zippers = zippers
+        self._depth = depth
+        self._open = {}
+        self._next = 0
+
+    def _schedule(self, upto):
+        while self._next < min(upto, len(self._paths)):
+            fp = self._paths[self._next]
+            self._next += 1
+            if fp != '-' and splitext(fp)[1] in ZIP_BY_EXT and \
+                    fp not in self._open:
+                self._open[fp] = AheadStream(
+                    lambda fp=fp: readzip_bytes(fp, self._zippers))
+
+    def open(self, i):
+        """Binary stream of the i-th path."""
+        self._schedule(i + self._depth)
+        fp = self._paths[i]
+        stream = self._open.pop(fp, None)
+        return stream if stream is not None else readzip_bytes(
+            fp, self._zippers)
+
+    def close(self):
+        for s in self._open.values():
+            s.close()
+        self._open = {}
 
 
 def file2stem(fname, ext=None):

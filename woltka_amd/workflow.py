@@ -24,7 +24,7 @@ import numpy as np
 
 from .align import NATIVE_FORMATS, infer_align_format, plain_mapper
 from .classify import Engine, exact_to_numbers
-from .file import (id2file_from_dir, id2file_from_map, openzip, path2stem,
+from .file import (FilesAhead, id2file_from_dir, id2file_from_map, openzip, path2stem,
                    read_ids, read_map_1st, read_map_uniq, readzip, readzip_bytes,
                    stem2rank, write_readmap)
 from .ordinal import load_gene_coords
@@ -185,12 +185,25 @@ def classify(
             and cover is None
         allow = set(samples) if (demux and samples) else None
         engine._exclude = exclude
+        labels = None
+
         def one_pass(rank2dir, cover):
             """All files through the device once (the main pass; the replay of
             uncertified cells runs it a second time)."""
-            nonlocal csample, strata
+            nonlocal labels
             labels = None
-            for fp in sorted(files, key=file_key):
+            order = sorted(files, key=file_key)
+            # compressed inputs: the next files are inflated while this one is
+            # tokenised and classified
+            ahead = FilesAhead([file_path(x) for x in order], zippers)
+            try:
+                files_loop(order, ahead, rank2dir, cover)
+            finally:
+                ahead.close()
+
+        def files_loop(order, ahead, rank2dir, cover):
+            nonlocal csample, strata, labels
+            for ifile, fp in enumerate(order):
                 # (a FilePart is one of several byte ranges of a large file that
                 # other processes share, shard.partition_files)
                 path = file_path(fp)
@@ -200,7 +213,7 @@ def classify(
                     stream = click.get_binary_stream('stdin')
                     click.echo('Parsing alignment from stdin ', nl=False)
                 else:
-                    stream = readzip_bytes(path, zippers)
+                    stream = ahead.open(ifile)
                     click.echo(f'Parsing alignment file {basename(path)} ',
                                nl=False)
                 with stream:
@@ -240,7 +253,11 @@ def classify(
                             want_strings=want_strings, want_samples=native_demux,
                             cover=cover, fmt=fmt_, part=part)
                     else:
-                        text = io.TextIOWrapper(stream, encoding='utf-8')
+                        text = io.TextIOWrapper(
+                        io.BufferedReader(stream) if isinstance(
+                            stream, io.RawIOBase) and not isinstance(
+                            stream, io.BufferedIOBase) else stream,
+                        encoding='utf-8')
                         fh = chain([head.decode()], text) if head else text
                         if ordinal:
                             chunks = engine.ordinal_chunks(fh, fmt_, exclude, n,
