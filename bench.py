@@ -128,6 +128,12 @@ class FlatWorkload:
         for c in self.ctxs:
             c.classify_staged(self.jobs)
 
+    def profile_step(self):
+        """One chunk alone (the contexts' streams overlap otherwise, and the
+        events around a launch would time its neighbours as well)."""
+        self.sync()
+        self.ctx.classify_staged(self.jobs)
+
     def sync(self):
         for c in self.ctxs:
             c.sync()
@@ -158,7 +164,7 @@ class LcaWorkload:
     key = 'lca'
     dominant = 'classify'
     families = ('classify', 'weigh_merge', 'leftover', 'partition_merge')
-    symbols = {'classify': 'wk::weigh_stream_kernel<5, 2>',
+    symbols = {'classify': 'wk::weigh_bins_kernel<4>',
                'weigh_merge': 'wk::weigh_merge_kernel',
                'leftover': 'wk::classify_kernel<true, true, 0>',
                'partition_merge': 'wk::partition_merge_kernel'}
@@ -181,7 +187,16 @@ class LcaWorkload:
             ctx.build_rank_table(slot, h.rank_codes[rank])
             self.jobs.append(nat.Job(nat.MODE_RANK, slot, 0, 0, 0.0))
         ctx.counts_reserve(1 << 24)
+        # (staging derives one byte per record, the size of its read, on the
+        # device: once per staged chunk, timed here and reported next to the
+        # per-pass figures)
+        ctx.profile_kernels(True)
         stage_indexed(ctx, p)
+        try:
+            self.read_sizes_ms = ctx.last_kernel_ms('read_sizes')
+        except RuntimeError:
+            self.read_sizes_ms = None
+        ctx.profile_kernels(False)
         self.records = int(p['subj'].size)
         self.reads = int(p['qoff'].size - 1)
         # 4 B/record + 4 B/read + parent/last 8 B + 3 rank tables
@@ -663,8 +678,9 @@ def kernel_times(wl, n=10):
     ctx.profile_kernels(True)
     families = getattr(wl, 'families', (wl.dominant,))
     durs = {f: [] for f in families}
+    step = getattr(wl, 'profile_step', wl.step)
     for _ in range(n):
-        wl.step()
+        step()
         for f in families:
             try:
                 durs[f].append(ctx.last_kernel_ms(f))
@@ -685,7 +701,10 @@ def config_block(wl, seconds, passes, steps, scale, key):
         alg = wl.launch_bytes
     achieved = alg / (kern_ms * 1e-3) / 1e9
     ms_pass = seconds * 1e3 / (steps * passes)
-    return {'workload': wl.name, 'records': wl.records, 'reads': wl.reads,
+    extra = {}
+    if getattr(wl, 'read_sizes_ms', None) is not None:
+        extra['read_sizes_ms_once_per_staged_chunk'] = round(wl.read_sizes_ms, 4)
+    return {**extra, 'workload': wl.name, 'records': wl.records, 'reads': wl.reads,
             'ms_per_pass': round(ms_pass, 4),
             'value': round(wl.records / (ms_pass * 1e-3), 1),
             'timed_region_s': round(seconds, 3),

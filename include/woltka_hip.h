@@ -142,8 +142,7 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * subject histogram as its own statically pipelined kernel),
  * "single_blocks_per_cu" (grid of the first pass), "weigh" (0 off / 1 auto / 2
  * whenever the jobs allow it: plain rank jobs as one weighted histogram over
- * subject indices, csrc/wk_weigh.hpp; "weigh_stream" 0/1 picks its
- * one-lane-per-record kernel, "weigh_rpw" its reads per wave).
+ * subject indices, csrc/wk_weigh.hpp).
  * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 
@@ -366,7 +365,7 @@ int wk_tok_new_subjects(wk_tok* tok, char* blob, int32_t* off);
  * this library is launched on).  wk_timer_begin/end bracket a region;
  * wk_timer_ms returns the elapsed GPU time of the last closed region.
  * wk_last_kernel_ms returns the duration of the most recent launch of the
- * named kernel family ("classify", "leftover", "weigh_merge", "dense_merge", "partition_merge",
+ * named kernel family ("classify", "leftover", "weigh_merge", "read_sizes", "dense_merge", "partition_merge",
  * "match_count", "match_write", "scan", "rank_table", "compact"), measured with events around that launch; event
  * recording around individual kernels is enabled by wk_profile_kernels(1). */
 int wk_timer_begin(wk_ctx* ctx);

@@ -143,11 +143,16 @@ struct wk_ctx {
     DevBuf left_mask, left_list, first_slab;
     // weighted subject histogram (wk_weigh.hpp): 0 = off, 1 = auto, 2 = whenever applicable
     int use_weigh = 1;
-    int weigh_interleave = 0;  // thread-per-read kernel: subject s in slice s mod S instead of s div bins
-    int weigh_stream = 1;   // one lane per record (weigh_stream_kernel) when every subject is valid
-    int weigh_rpw = 0;      // reads per wave and tile of that kernel: 0 = from the mean hits per read
     DevBuf w_slab, w_hi, w_invalid;
     size_t w_hi_clean = 0;        // leading entries of w_hi known to be zero
+    // read size per record of the staged chunk + reads the histogram does not
+    // cover + totals: [0] derived at staging, [1] derived again with the
+    // validity bits of the current subject rows (when some subject has one set)
+    DevBuf c_rk[2], rk_left[2], rk_totals;
+    bool rk_valid[2] = {false, false};
+    int64_t rk_reads[2] = {0, 0}, rk_records[2] = {0, 0};
+    int64_t stage_serial = 0, rows_serial = 0, rk1_stage = -1, rk1_rows = -1;
+    int64_t stat_extra_reads = 0, stat_extra_records = 0;  // statistics added on the host
     bool rows_any_invalid = false;  // some subject lacks an ancestor at a rank column of the current rows
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
@@ -343,12 +348,8 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_single_kernel<false, false, kPerReadItems, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_subjects_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_subjects_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_stream_kernel<5, 2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStreamMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
@@ -370,7 +371,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4, &c->ginfo,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -460,19 +461,6 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "weigh")) {  // 0 = off, 1 = auto (large multi-hit chunks), 2 = whenever the jobs allow it
         if (value < 0 || value > 2) return fail(c, WK_E_ARG, "weigh must be 0, 1 or 2");
         c->use_weigh = (int)value;
-        return WK_OK;
-    }
-    if (!strcmp(name, "weigh_interleave")) {
-        c->weigh_interleave = value ? 1 : 0;
-        return WK_OK;
-    }
-    if (!strcmp(name, "weigh_stream")) {
-        c->weigh_stream = value ? 1 : 0;
-        return WK_OK;
-    }
-    if (!strcmp(name, "weigh_rpw")) {
-        if (value != 0 && value != 16 && value != 32 && value != 64) return fail(c, WK_E_ARG, "weigh_rpw must be 0, 16, 32 or 64");
-        c->weigh_rpw = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "tiled")) {
@@ -717,7 +705,31 @@ int wk_chunk_stage(wk_ctx* c, const int32_t* subj, const int32_t* qoff, int64_t 
     if ((rc = upload(c, c->c_subj, subj, (size_t)n_rec * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->c_qoff, qoff, ((size_t)n_reads + 1) * sizeof(int32_t)))) return rc;
     if (group && !uniform && (rc = upload(c, c->c_group, group, (size_t)n_reads * sizeof(int32_t)))) return rc;
+    // the read size of every record (what the record histogram of wk_weigh.hpp
+    // streams next to the subject indices) + the reads it does not cover
+    c->rk_valid[0] = c->rk_valid[1] = false;
+    c->stage_serial += 1;
+    unsigned long long totals[2] = {0, 0};
+    if (c->use_weigh && (subj_flags & WK_SUBJ_INDEXED) && (subj_flags & WK_SUBJ_IS_SET) && n_reads > 0 &&
+        n_reads < (1ll << 30) && n_rec < (1ll << 30)) {
+        HIP_TRY(c, c->c_rk[0].reserve((size_t)n_rec + 64));
+        HIP_TRY(c, c->rk_left[0].reserve((size_t)((n_reads + 63) / 64) * 8));
+        HIP_TRY(c, c->rk_totals.reserve(32));
+        HIP_TRY(c, hipMemsetAsync(c->rk_totals.p, 0, 32, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->c_rk[0].as<unsigned char>() + n_rec, 0, 8, c->stream));  // the sizes are read four at a time
+        KernelTimer* kt = ktimer_begin(c, "read_sizes");
+        hipLaunchKernelGGL(read_sizes_kernel<false>, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream,
+                           c->c_qoff.as<int32_t>(), (uint32_t)n_reads, (const int32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+                           c->c_rk[0].as<unsigned char>(), c->rk_left[0].as<unsigned long long>(),
+                           c->rk_totals.as<unsigned long long>());
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(totals, c->rk_totals.p, 16, hipMemcpyDeviceToHost, c->stream));
+        c->rk_valid[0] = true;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffers are only valid during the call
+    c->rk_reads[0] = (int64_t)totals[0];
+    c->rk_records[0] = (int64_t)totals[1];
     c->cur_subj = c->c_subj.as<int32_t>();
     c->cur_qoff = c->c_qoff.as<int32_t>();
     c->n_reads = n_reads;
@@ -800,6 +812,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             c->rows_w = w;
             // which subjects the weighted histogram cannot take (wk_weigh.hpp)
             c->rows_any_invalid = false;
+            c->rows_serial += 1;
             if (c->n_subjects > 0) {
                 HIP_TRY(c, c->w_invalid.reserve(((size_t)c->n_subjects / 32 + 2) * 4));
                 HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 6), 0, 8, c->stream));
@@ -897,21 +910,16 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // pass above is the faster special case of those)
             if (weigh && c->use_weigh == 1)
                 weigh = c->n_reads >= (1 << 16) && c->n_records > c->n_reads + c->n_reads / 64;
-            uint32_t w_bins = 0, w_slices = 0, w_teams = 0, w_xcd = 8, w_inv_words = 0;
-            bool w_stream = false;
+            uint32_t w_bins = 0, w_slices = 0, w_teams = 0, w_xcd = 8;
+            weigh = weigh && c->rk_valid[0] && a.subj == c->c_subj.as<int32_t>();
             if (weigh) {
                 const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
                 if (cus % w_xcd) w_xcd = 1;
-                w_inv_words = c->rows_any_invalid ? ((uint32_t)c->n_subjects + 31u) / 32u : 0u;
-                w_stream = c->weigh_stream && !w_inv_words;
-                const int64_t cap = w_stream ? ((int64_t)kStreamMaxLds - 16 * 4 * (int64_t)kStreamScratch) / 4
-                                             : ((int64_t)kWeighMaxLds - 4 * (int64_t)w_inv_words) / 4;
-                if (cap >= 1024) {
-                    w_slices = (uint32_t)((c->n_subjects + cap - 1) / cap);
-                    w_bins = ((uint32_t)c->n_subjects + w_slices - 1) / w_slices;  // subject s: slice s mod S, bin s div S
-                    w_teams = (cus / w_xcd) / w_slices;
-                }
-                if (!w_teams || (int64_t)w_bins * w_slices < c->n_subjects) weigh = false;
+                const int64_t cap = (int64_t)kBinsMaxLds / 4 - 96;
+                w_slices = (uint32_t)((c->n_subjects + cap - 1) / cap);
+                w_bins = ((uint32_t)c->n_subjects + w_slices - 1) / w_slices;  // slice = w_bins consecutive subject indices
+                w_teams = (cus / w_xcd) / w_slices;
+                if (!w_teams) weigh = false;
             }
             const int max_blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->blocks_per_cu);
             const int blocks = grid_for(c->n_reads, c->threads, max_blocks);
@@ -979,11 +987,10 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             }
             if (weigh) {
                 // ---- weighted subject histogram + per-subject merge; the reads it
-                // does not cover go to the second pass below through left_mask
+                // does not cover go to the second pass below through a mask
                 const uint32_t n_words = (uint32_t)((c->n_reads + 63) / 64);
                 const uint32_t list_seg = (((n_words + 15u) / 16u + (uint32_t)blocks - 1u) / (uint32_t)blocks) * 1024u;
                 const uint32_t n_teams = w_xcd * w_teams;
-                HIP_TRY(c, c->left_mask.reserve((size_t)n_words * 8));
                 HIP_TRY(c, c->left_list.reserve((size_t)blocks * list_seg * 4));
                 HIP_TRY(c, c->w_slab.reserve((size_t)w_slices * n_teams * w_bins * 4));
                 if ((size_t)c->n_subjects > c->w_hi_clean) {
@@ -991,47 +998,62 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                     HIP_TRY(c, hipMemsetAsync(c->w_hi.p, 0, c->w_hi.cap, c->stream));
                     c->w_hi_clean = c->w_hi.cap / 4;
                 }
-                WeighArgs wa{};
-                wa.subj = a.subj;
-                wa.qoff = a.qoff;
-                wa.n_reads = (uint32_t)c->n_reads;
-                wa.n_records = (uint32_t)c->n_records;
-                wa.n_subjects = (uint32_t)c->n_subjects;
-                wa.bins = w_bins;
-                wa.n_slices = w_slices;
-                wa.teams_per_xcd = w_teams;
-                wa.n_xcd = w_xcd;
-                wa.invalid = w_inv_words ? c->w_invalid.as<uint32_t>() : nullptr;
-                wa.invalid_words = w_inv_words;
-                wa.slab = c->w_slab.as<uint32_t>();
-                wa.hi = c->w_hi.as<uint32_t>();
-                wa.left_mask = c->left_mask.as<unsigned long long>();
-                wa.stat_block = a.stat_block;
-                wa.err = scalar_err(c);
-                const size_t wlds = (size_t)w_bins * 4 + (size_t)w_inv_words * 4;
-                const dim3 wgrid((unsigned)c->prop.multiProcessorCount);
-                wa.interleave = w_stream ? 0u : (uint32_t)c->weigh_interleave;
-                // reads per wave and tile of the record-parallel kernel: the run of a
-                // wave should fit its 512 prefetched positions
-                const double mean_hits = (double)c->n_records / (double)c->n_reads;
-                wa.reads_per_wave = c->weigh_rpw ? (uint32_t)c->weigh_rpw : mean_hits <= 6.5 ? 64u : mean_hits <= 13.0 ? 32u : 16u;
-                if (w_stream)
-                    hipLaunchKernelGGL((weigh_stream_kernel<5, 2>), wgrid, dim3(kWeighThreads),
-                                       (size_t)w_bins * 4 + 16 * 4 * (size_t)kStreamScratch, c->stream, wa);
-                else if (w_inv_words)
-                    hipLaunchKernelGGL(weigh_subjects_kernel<false>, wgrid, dim3(kWeighThreads), wlds, c->stream, wa);
-                else
-                    hipLaunchKernelGGL(weigh_subjects_kernel<true>, wgrid, dim3(kWeighThreads), wlds, c->stream, wa);
+                // which derivation of the read sizes: the one of the staging, or —
+                // some subject lacks an ancestor at a rank in use — the one that
+                // also leaves out the reads naming such a subject (once per staged
+                // chunk and set of rank columns)
+                int v = 0;
+                if (c->rows_any_invalid) {
+                    v = 1;
+                    if (!c->rk_valid[1] || c->rk1_stage != c->stage_serial || c->rk1_rows != c->rows_serial) {
+                        ktimer_end(c, kt);
+                        kt = ktimer_begin(c, "read_sizes");
+                        HIP_TRY(c, c->c_rk[1].reserve((size_t)c->n_records + 64));
+                        HIP_TRY(c, c->rk_left[1].reserve((size_t)n_words * 8));
+                        HIP_TRY(c, hipMemsetAsync(c->rk_totals.as<unsigned char>() + 16, 0, 16, c->stream));
+                        HIP_TRY(c, hipMemsetAsync(c->c_rk[1].as<unsigned char>() + c->n_records, 0, 8, c->stream));
+                        hipLaunchKernelGGL(read_sizes_kernel<true>, dim3((unsigned)((c->n_reads + 255) / 256)), dim3(256), 0,
+                                           c->stream, a.qoff, (uint32_t)c->n_reads, a.subj, c->w_invalid.as<uint32_t>(),
+                                           (uint32_t)c->n_subjects, c->c_rk[1].as<unsigned char>(),
+                                           c->rk_left[1].as<unsigned long long>(), c->rk_totals.as<unsigned long long>() + 2);
+                        ktimer_end(c, kt);
+                        HIP_TRY(c, hipGetLastError());
+                        unsigned long long totals[2] = {0, 0};
+                        HIP_TRY(c, hipMemcpyAsync(totals, c->rk_totals.as<unsigned char>() + 16, 16, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                        c->rk_reads[1] = (int64_t)totals[0];
+                        c->rk_records[1] = (int64_t)totals[1];
+                        c->rk_valid[1] = true;
+                        c->rk1_stage = c->stage_serial;
+                        c->rk1_rows = c->rows_serial;
+                        kt = ktimer_begin(c, "classify");
+                    }
+                }
+                BinsArgs ba{};
+                ba.subj = a.subj;
+                ba.rk = c->c_rk[v].as<unsigned char>();
+                ba.n_records = (uint32_t)c->n_records;
+                ba.n_subjects = (uint32_t)c->n_subjects;
+                ba.bins = w_bins;
+                ba.n_slices = w_slices;
+                ba.teams_per_xcd = w_teams;
+                ba.n_xcd = w_xcd;
+                ba.slab = c->w_slab.as<uint32_t>();
+                ba.hi = c->w_hi.as<uint32_t>();
+                ba.err = scalar_err(c);
+                hipLaunchKernelGGL((weigh_bins_kernel<4>), dim3((unsigned)c->prop.multiProcessorCount), dim3(kWeighThreads),
+                                   ((size_t)w_bins + 96) * 4, c->stream, ba);
+                // (the reads and records it covers were counted with the sizes)
+                c->stat_extra_reads += c->rk_reads[v];
+                c->stat_extra_records += c->rk_records[v];
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "weigh_merge");
                 WeighMergeArgs wm{};
-                wm.slab = wa.slab;
-                wm.hi = wa.hi;
-                wm.n_subjects = wa.n_subjects;
+                wm.slab = ba.slab;
+                wm.hi = ba.hi;
+                wm.n_subjects = ba.n_subjects;
                 wm.bins = w_bins;
                 wm.n_teams = n_teams;
-                wm.n_slices = w_slices;
-                wm.interleave = wa.interleave;
                 wm.rows = a.rows;
                 wm.row_w = a.row_w;
                 wm.n_jobs = n_jobs;
@@ -1041,11 +1063,11 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 }
                 wm.group = (uint32_t)a.group_base;
                 wm.table = a.table;
-                hipLaunchKernelGGL(weigh_merge_kernel, dim3((wa.n_subjects + 1023u) / 1024u), dim3(1024), (size_t)4096 * 16,
+                hipLaunchKernelGGL(weigh_merge_kernel, dim3((ba.n_subjects + 1023u) / 1024u), dim3(1024), (size_t)4096 * 16,
                                    c->stream, wm, 4096u);
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "leftover");
-                a.left_mask = wa.left_mask;
+                a.left_mask = c->rk_left[v].as<unsigned long long>();
                 a.n_mask_words = n_words;
                 a.list_seg = list_seg;
                 a.read_list = c->left_list.as<uint32_t>();
@@ -1228,6 +1250,7 @@ int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const
     c->th = th;
     c->has_group = group != nullptr;
     c->group_base = 0;
+    c->rk_valid[0] = c->rk_valid[1] = false;
     c->ord_valid = true;
     c->chunk_valid = false;
     return WK_OK;
@@ -1341,8 +1364,8 @@ int wk_get_stats(wk_ctx* c, wk_stats* out) {
         s[0] += part[2 * b];
         s[1] += part[2 * b + 1];
     }
-    out->n_reads = (int64_t)s[0];
-    out->n_records = (int64_t)s[1];
+    out->n_reads = (int64_t)s[0] + c->stat_extra_reads;
+    out->n_records = (int64_t)s[1] + c->stat_extra_records;
     out->n_pairs = c->stat_pairs;
     out->table_used = (int64_t)used;
     return WK_OK;
@@ -1353,6 +1376,7 @@ int wk_reset_stats(wk_ctx* c) {
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipMemsetAsync(c->stat_block.p, 0, (size_t)kStatBlocks * 16, c->stream));
     c->stat_pairs = 0;
+    c->stat_extra_reads = c->stat_extra_records = 0;
     return WK_OK;
 }
 
