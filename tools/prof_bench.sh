@@ -9,7 +9,7 @@ TAG=$1; WL=$2; SCALE=$3; KERN=$4
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --workload $WL --scale $SCALE --steps ${STEPS:-20} --warmup 3 --no-cpu ${EXTRA:-}"
+CMD="python $R/bench.py --workload $WL --scale $SCALE --steps ${STEPS:-20} --warmup 3 --headline-only --passes ${PASSES:-2} ${EXTRA:-}"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $CMD > "$OUT/kt.log" 2>&1
 echo "kernel-trace rc=$?"
 f=$(find "$OUT/kt" -name "*kernel_stats.csv" 2>/dev/null | head -1)

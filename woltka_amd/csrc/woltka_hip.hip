@@ -143,6 +143,7 @@ struct wk_ctx {
     DevBuf left_mask, left_list, first_slab;
     // weighted subject histogram (wk_weigh.hpp): 0 = off, 1 = auto, 2 = whenever applicable
     int use_weigh = 1;
+    int bins_ring = 4;  // measurement knob: load stages in flight of weigh_bins_kernel
     DevBuf w_slab, w_hi, w_invalid;
     size_t w_hi_clean = 0;        // leading entries of w_hi known to be zero
     // read size per record of the staged chunk + reads the histogram does not
@@ -350,6 +351,12 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<4>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<3>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<6>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<8>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
@@ -461,6 +468,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "weigh")) {  // 0 = off, 1 = auto (large multi-hit chunks), 2 = whenever the jobs allow it
         if (value < 0 || value > 2) return fail(c, WK_E_ARG, "weigh must be 0, 1 or 2");
         c->use_weigh = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "bins_ring")) {
+        c->bins_ring = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "tiled")) {
@@ -1041,8 +1052,16 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 ba.slab = c->w_slab.as<uint32_t>();
                 ba.hi = c->w_hi.as<uint32_t>();
                 ba.err = scalar_err(c);
-                hipLaunchKernelGGL((weigh_bins_kernel<4>), dim3((unsigned)c->prop.multiProcessorCount), dim3(kWeighThreads),
-                                   ((size_t)w_bins + 96) * 4, c->stream, ba);
+                const dim3 wgrid((unsigned)c->prop.multiProcessorCount);
+                const size_t wlds = ((size_t)w_bins + 96) * 4;
+                if (c->bins_ring == 6)
+                    hipLaunchKernelGGL((weigh_bins_kernel<6>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+                else if (c->bins_ring == 8)
+                    hipLaunchKernelGGL((weigh_bins_kernel<8>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+                else if (c->bins_ring == 3)
+                    hipLaunchKernelGGL((weigh_bins_kernel<3>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+                else
+                    hipLaunchKernelGGL((weigh_bins_kernel<4>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
                 // (the reads and records it covers were counted with the sizes)
                 c->stat_extra_reads += c->rk_reads[v];
                 c->stat_extra_records += c->rk_records[v];
