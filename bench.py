@@ -279,6 +279,7 @@ class OrdinalWorkload:
                       p['gene_feature'])
         ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
                           p['hoff'], 0.8)
+        ctx.set_uniform_group(0)            # one sample per chunk
         self.jobs = [nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)]
         ctx.counts_reserve(1 << 22)
         self.records = int(p['genome'].size)
@@ -307,8 +308,7 @@ class OrdinalWorkload:
 
     def step(self):
         self._steps += 1
-        self.ctx.ordinal_match()
-        self.ctx.classify_staged(self.jobs)
+        self.ctx.ordinal_count(self.jobs)
 
     def sync(self):
         self.ctx.sync()

@@ -257,6 +257,17 @@ int wk_ordinal_stage(wk_ctx* ctx, const int32_t* genome, const int32_t* beg,
  * min(ge, re) - max(gs, rs) >= rel (ordinal.py:555,580). */
 int wk_ordinal_match(wk_ctx* ctx);
 
+/* The same in one call for jobs that need no per-read result: matches the
+ * staged hits and adds the reads' gene sets to the count table under every
+ * job — wk_ordinal_match followed by wk_classify_staged (ordinal.flush_chunk
+ * + workflow.assign_readmap, ordinal.py:243-335, workflow.py:941-1058). */
+int wk_ordinal_count(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs);
+
+/* The chunk staged last (wk_chunk_stage / wk_ordinal_stage) has no per-read
+ * groups: every read belongs to group `group` (what WK_GROUP_UNIFORM says for
+ * wk_chunk_stage). */
+int wk_set_uniform_group(wk_ctx* ctx, int32_t group);
+
 /* Download the staged classify chunk (testing / read-map output): the
  * candidate lists as currently staged (after wk_ordinal_match: gene feature
  * ids per read, duplicates possible when several hits of a read match the same

@@ -637,3 +637,36 @@ def test_nested_genes_vs_oracle(ctx, flags):
                                            group)
             okeys, ocnt = np.unique(contrib, return_counts=True)
             assert_same_counts(keys, vals, okeys, ocnt, (flags, th))
+
+
+def test_ordinal_count_and_uniform_group(ctx):
+    """wk_ordinal_count = wk_ordinal_match + wk_classify_staged; a uniform
+    group id set after staging equals a group array with that id."""
+    rng = np.random.default_rng(12)
+    p = synth.ordinal_problem(rng, n_genomes=60, genes_per_genome=50,
+                              n_pairs=30000, multi_frac=0.2)
+    ctx.set_genes(p['genome_off'], p['gstart'], p['gend'], p['gene_feature'])
+    ctx.counts_reserve(1 << 18)
+    jobs = [nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)]
+    n_reads = p['hoff'].size - 1
+    tables = []
+    for how in ('array', 'uniform'):
+        ctx.counts_clear()
+        ctx.reset_stats()
+        if how == 'array':
+            ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
+                              p['hoff'], 0.8,
+                              group=np.full(n_reads, 9, np.int32))
+            ctx.ordinal_match()
+            ctx.classify_staged(jobs)
+        else:
+            ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
+                              p['hoff'], 0.8)
+            ctx.set_uniform_group(9)
+            ctx.ordinal_count(jobs)
+        st = ctx.stats()
+        tables.append((ctx.counts_fetch(), st['n_reads'], st['n_pairs']))
+    assert_same_counts(*tables[0][0], *tables[1][0])
+    assert tables[0][1:] == tables[1][1:]
+    _, _, grp, _ = nat.decode_keys(tables[1][0][0])
+    assert set(grp.tolist()) == {9}

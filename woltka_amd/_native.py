@@ -38,7 +38,8 @@ SYMBOLS = (
     'wk_counts_reserve', 'wk_counts_clear', 'wk_counts_fetch',
     'wk_log_reserve', 'wk_log_fetch',
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
-    'wk_ordinal_stage', 'wk_ordinal_match', 'wk_chunk_download',
+    'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
+    'wk_set_uniform_group', 'wk_chunk_download',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
     'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
@@ -110,6 +111,8 @@ def load_library():
         'wk_ordinal_stage': (C.c_int, [p, i32p, i32p, i32p, u32p, C.c_int64,
                                        i32p, C.c_int64, i32p, C.c_double]),
         'wk_ordinal_match': (C.c_int, [p]),
+        'wk_ordinal_count': (C.c_int, [p, C.POINTER(Job), C.c_int32]),
+        'wk_set_uniform_group': (C.c_int, [p, C.c_int32]),
         'wk_chunk_download': (C.c_int, [p, i32p, C.c_int64, i32p, C.c_int64,
                                         i64p, i64p]),
         'wk_get_stats': (C.c_int, [p, C.POINTER(Stats)]),
@@ -363,6 +366,15 @@ class Context:
 
     def ordinal_match(self):
         self._check(self._lib.wk_ordinal_match(self._h))
+
+    def ordinal_count(self, jobs):
+        """Match the staged hits and count the reads' gene sets under every
+        job (no per-read output)."""
+        self._check(self._lib.wk_ordinal_count(self._h, self._jobs(jobs),
+                                               len(jobs)))
+
+    def set_uniform_group(self, group):
+        self._check(self._lib.wk_set_uniform_group(self._h, int(group)))
 
     def chunk_download(self):
         """Return (subj int32[], qoff int32[]) of the staged classify chunk."""

@@ -513,13 +513,23 @@ class Engine:
         if ordinal:
             genome, beg, end, length, hoff = \
                 self._hits if packed is None else packed
-            if np.ndim(group) == 0:     # (the coord-match stage takes an array)
-                group = np.full(hoff.size - 1, group, dtype=np.int32)
-            self.ctx.ordinal_stage(genome, beg, end, length, hoff, self._th,
-                                   group=group)
-            self.ctx.ordinal_match()
             before = self.ctx.stats()['n_reads']
-            assign = self._classify_staged(data, want)
+            if np.ndim(group) == 0 and not want and \
+                    len(self.jobs) <= nat.MAX_JOBS:
+                # one sample, no read maps: match + count in one pass over the
+                # reads (wk_ordinal_count), no gene lists
+                self.ctx.ordinal_stage(genome, beg, end, length, hoff,
+                                       self._th)
+                self.ctx.set_uniform_group(group)
+                self.ctx.ordinal_count(self.jobs)
+                assign = None
+            else:
+                if np.ndim(group) == 0:  # (the coord-match stage takes an array)
+                    group = np.full(hoff.size - 1, group, dtype=np.int32)
+                self.ctx.ordinal_stage(genome, beg, end, length, hoff,
+                                       self._th, group=group)
+                self.ctx.ordinal_match()
+                assign = self._classify_staged(data, want)
             nq = (self.ctx.stats()['n_reads'] - before) // self._n_batches()
             if want:
                 subj, qoff = self.ctx.chunk_download()

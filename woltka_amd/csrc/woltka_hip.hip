@@ -311,8 +311,8 @@ int wk_create(int device, wk_ctx** out) {
     if ((e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
-        (e = c->scalars.reserve(64)) != hipSuccess ||
-        (e = hipMemsetAsync(c->scalars.p, 0, 64, c->stream)) != hipSuccess ||
+        (e = c->scalars.reserve(128)) != hipSuccess ||
+        (e = hipMemsetAsync(c->scalars.p, 0, 128, c->stream)) != hipSuccess ||
         (e = c->stat_block.reserve((size_t)kStatBlocks * 16)) != hipSuccess ||
         (e = hipMemsetAsync(c->stat_block.p, 0, (size_t)kStatBlocks * 16, c->stream)) != hipSuccess) {
         int rc = fail(nullptr, WK_E_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -1346,6 +1346,25 @@ int wk_ordinal_match(wk_ctx* c) {
     c->subj_indexed = false; // gene lists carry feature ids
     c->chunk_valid = true;
     return WK_OK;
+}
+
+int wk_set_uniform_group(wk_ctx* c, int32_t group) {
+    if (!c) return WK_E_ARG;
+    if (group < 0 || group >= (1 << WK_KEY_GROUP_BITS)) return fail(c, WK_E_ARG, "group id outside [0, %d)", 1 << WK_KEY_GROUP_BITS);
+    c->has_group = false;
+    c->group_base = group;
+    return WK_OK;
+}
+
+int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
+    // (a fused kernel — one thread per read searching its hits, the union in
+    // registers, gene weights in LDS bins — was built and measured at 6.6 ms per
+    // 107.5 M hits against 4.7 ms for these two steps: the per-read search loses
+    // the four searches a thread of match_count_kernel keeps in flight, and the
+    // 500 k-gene table needs 13 slices of bins.  DESIGN.md §4.)
+    int rc = wk_ordinal_match(c);
+    if (rc) return rc;
+    return wk_classify_staged(c, jobs, n_jobs, nullptr);
 }
 
 int wk_chunk_download(wk_ctx* c, int32_t* subj, int64_t subj_cap, int32_t* qoff, int64_t qoff_cap, int64_t* n_records,
