@@ -371,6 +371,14 @@ int wk_tok_subjects(wk_tok* tok, int32_t* n_total, int32_t* n_new,
  * marks them reported. */
 int wk_tok_new_subjects(wk_tok* tok, char* blob, int32_t* off);
 
+/* Host helper of the hierarchy flattening: DFS pre-order numbers, subtree sizes
+ * and depths of a rooted tree given as a parent array (exactly the root is its
+ * own parent; siblings keep their input order).  The device tables of
+ * wk_set_tree are these numbers applied to the reference's child -> parent
+ * dict (tree.py:302-388).  WK_E_STATE: *bad cannot reach the root (a cycle). */
+int wk_preorder(const int64_t* parent, int64_t n, int64_t expected_root /* -1: any */,
+                int64_t* pre, int64_t* size, int64_t* depth, int64_t* bad);
+
 /* ---- measurement ------------------------------------------------------- */
 /* HIP-event timing on the context's own stream (the stream every kernel of
  * this library is launched on).  wk_timer_begin/end bracket a region;

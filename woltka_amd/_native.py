@@ -48,7 +48,7 @@ SYMBOLS = (
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
-    'wk_tok_fetch_samples', 'wk_tok_new_samples')
+    'wk_tok_fetch_samples', 'wk_tok_new_samples', 'wk_preorder')
 
 
 class Job(C.Structure):
@@ -123,6 +123,8 @@ def load_library():
         'wk_profile_kernels': (C.c_int, [p, C.c_int]),
         'wk_last_kernel_ms': (C.c_int, [p, C.c_char_p,
                                         C.POINTER(C.c_double)]),
+        'wk_preorder': (C.c_int, [i64p, C.c_int64, C.c_int64, i64p, i64p, i64p,
+                                  i64p]),
         'wk_tok_create': (C.c_int, [C.c_int, C.POINTER(p)]),
         'wk_tok_destroy': (None, [p]),
         'wk_tok_last_error': (C.c_char_p, [p]),
@@ -423,6 +425,26 @@ WEIGHT_L = 720720       # WK_WEIGHT_L: k = 0 keys hold multiples of 1 / L
 WEIGHT_MAX_K = 16
 KEY_K_MASK = np.uint64(0xFFF << 49)
 KEY_GROUP_SHIFT = 28        # key >> 28 = (job, k, group)
+
+
+def preorder(par, root=-1):
+    """(pre, size, depth) of the tree `par` (int64 parent array) through the
+    native helper; raises ValueError for no / several roots and LookupError(node)
+    for a node that cannot reach the root."""
+    lib = load_library()
+    par = np.ascontiguousarray(par, dtype=np.int64)
+    n = par.size
+    pre, size, depth = (np.empty(n, np.int64), np.empty(n, np.int64),
+                        np.empty(n, np.int64))
+    bad = C.c_int64(-1)
+    rc = lib.wk_preorder(_ptr(par, C.c_int64), n, int(root),
+                         _ptr(pre, C.c_int64), _ptr(size, C.c_int64),
+                         _ptr(depth, C.c_int64), C.byref(bad))
+    if rc == E_STATE:
+        raise LookupError(int(bad.value))
+    if rc != OK:
+        raise ValueError('Hierarchy must have exactly one root.')
+    return pre, size, depth
 
 
 def build_id():

@@ -1060,4 +1060,66 @@ int wk_tok_new_subjects(wk_tok* t, char* blob, int32_t* off) {
     return WK_OK;
 }
 
+// DFS pre-order numbering of a rooted tree given as a parent array (host helper
+// of the hierarchy flattening, woltka_amd/hierarchy.py; the reference walks its
+// child -> parent dict per query instead, tree.py:391-566).  par[v] = parent of
+// v, exactly the root has par[r] == r; siblings keep their input order.
+// Outputs pre[v] (pre-order number), size[v] (subtree size), depth[v].
+// Returns WK_OK, WK_E_ARG (no / several roots, root != expected, parent out of
+// range) or WK_E_STATE with *bad = a node that cannot reach the root.
+int wk_preorder(const int64_t* par, int64_t n, int64_t expected_root, int64_t* pre, int64_t* size, int64_t* depth,
+                int64_t* bad) {
+    if (!par || n <= 0 || !pre || !size || !depth) return WK_E_ARG;
+    int64_t root = -1;
+    std::vector<int64_t> first((size_t)n + 1, 0);  // children CSR: counts, then offsets
+    for (int64_t v = 0; v < n; ++v) {
+        const int64_t p = par[v];
+        if (p < 0 || p >= n) return WK_E_ARG;
+        if (p == v) {
+            if (root >= 0) return WK_E_ARG;
+            root = v;
+        } else {
+            first[(size_t)p + 1] += 1;
+        }
+    }
+    if (root < 0 || (expected_root >= 0 && root != expected_root)) return WK_E_ARG;
+    for (int64_t v = 0; v < n; ++v) first[(size_t)v + 1] += first[(size_t)v];
+    std::vector<int64_t> kids((size_t)n > 0 ? (size_t)n - 1 : 0), fill(first.begin(), first.end() - 1);
+    for (int64_t v = 0; v < n; ++v)
+        if (par[v] != v) kids[(size_t)fill[(size_t)par[v]]++] = v;  // ascending v: input order
+    for (int64_t v = 0; v < n; ++v) depth[v] = -1;
+    // iterative DFS: a node gets its number on entry, its size on exit
+    std::vector<int64_t> stack, next;
+    stack.reserve(64);
+    next.reserve(64);
+    int64_t counter = 0;
+    stack.push_back(root);
+    next.push_back(first[(size_t)root]);
+    depth[root] = 0;
+    pre[root] = counter++;
+    while (!stack.empty()) {
+        const int64_t v = stack.back();
+        int64_t& it = next.back();
+        if (it < first[(size_t)v + 1]) {
+            const int64_t c = kids[(size_t)it++];
+            depth[c] = depth[v] + 1;
+            pre[c] = counter++;
+            stack.push_back(c);
+            next.push_back(first[(size_t)c]);
+        } else {
+            size[v] = counter - pre[v];
+            stack.pop_back();
+            next.pop_back();
+        }
+    }
+    if (counter != n) {
+        for (int64_t v = 0; v < n; ++v)
+            if (depth[v] < 0) {
+                if (bad) *bad = v;
+                return WK_E_STATE;
+            }
+    }
+    return WK_OK;
+}
+
 }  // extern "C"

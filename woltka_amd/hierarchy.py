@@ -181,6 +181,15 @@ def preorder_numbering(par, root=None):
     if selfp.size != 1 or (root is not None and selfp[0] != root):
         raise ValueError('Hierarchy must have exactly one root.')
     r = int(selfp[0])
+    if n >= 4096:
+        # large trees: one iterative DFS in the native helper (wk_preorder)
+        # instead of the level-by-level numpy passes below — same numbering
+        from . import _native
+        try:
+            pre, size, depth = _native.preorder(par, r)
+        except LookupError as e:
+            raise _Unreachable(e.args[0])
+        return pre, size, depth, r
 
     # children in CSR form, grouped by parent, siblings in input order
     kids = np.flatnonzero(par != ids)
