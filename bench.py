@@ -721,17 +721,19 @@ def config_block(wl, seconds, passes, steps, scale, key):
                                         for f, v in means.items()}}}
 
 
-def passes_for(wl, steps, target_s=1.0):
-    """Passes per step so that `steps` timed steps last about `target_s`."""
+def passes_for(wl, steps, target_s=1.25):
+    """Passes per step so that `steps` timed steps last about `target_s`
+    (at least one second of device work in the timed region)."""
     for _ in range(2):
         wl.step()
     wl.sync()
+    n = 16
     t0 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(n):              # back to back, like the timed region
         wl.step()
     wl.sync()
-    one = (time.perf_counter() - t0) / 3
-    return max(1, int(round(target_s / max(steps, 1) / max(one, 1e-6))))
+    one = (time.perf_counter() - t0) / n
+    return max(1, int(-(-target_s // (max(steps, 1) * max(one, 1e-6)))))
 
 
 def run_rank(a, rank, world, local, sync):

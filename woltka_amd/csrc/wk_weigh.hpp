@@ -46,19 +46,23 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 // ---- records that carry their read's size --------------------------------------
 // What a record needs from its read is one number, the read's size k (its
-// weight is L/k).  It is derived once per staged chunk (read_sizes_kernel:
-// one byte per record, 0 for the records of reads the histogram does not
-// cover; one bit per such read in a mask for the generic pass; done by
+// weight is L/k).  It is derived once per staged chunk (mark_reads_kernel +
+// spread_sizes_kernel: one byte per record, 0 for the records of reads the
+// histogram does not cover; one bit per such read in a mask for the generic
+// pass; done by
 // wk_chunk_stage, and again by the first classify call when the subject table
 // has subjects without an ancestor at a requested rank), so that the histogram itself is a plain stream over records: no read
 // offsets, no per-read logic, every lane busy — a 16-byte load of four subject
 // indices, a 4-byte load of their four sizes, a weight lookup and an LDS add
 // per record.
+// Step 1, one thread per read: the read's size goes to the position of its
+// first record in a zeroed byte array (0xFF = not covered), and one bit per
+// read not covered to the mask.
 template <bool kCheck>
-__global__ void __launch_bounds__(256) read_sizes_kernel(const int32_t* __restrict__ qoff, uint32_t n_reads,
+__global__ void __launch_bounds__(256) mark_reads_kernel(const int32_t* __restrict__ qoff, uint32_t n_reads,
                                                          const int32_t* __restrict__ subj,
                                                          const uint32_t* __restrict__ invalid, uint32_t n_subjects,
-                                                         unsigned char* __restrict__ rk,
+                                                         unsigned char* __restrict__ mark,
                                                          unsigned long long* __restrict__ left_mask,
                                                          unsigned long long* __restrict__ totals) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,8 +86,7 @@ __global__ void __launch_bounds__(256) read_sizes_kernel(const int32_t* __restri
     const unsigned long long left = __ballot(in & skip);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     if (lane == 0 && in) left_mask[r >> 6] = left;
-    const unsigned char code = skip ? 0 : (unsigned char)n;
-    for (uint32_t j = 0; j < n; ++j) rk[s + j] = code;
+    if (n > 0u) mark[s] = skip ? (unsigned char)0xFF : (unsigned char)n;
     // reads and records the histogram covers (statistics of the classify calls)
     unsigned long long rd = wave_sum((in & !skip & (n > 0u)) ? 1ull : 0ull);
     unsigned long long rc = wave_sum((in & !skip) ? (unsigned long long)n : 0ull);
@@ -91,6 +94,45 @@ __global__ void __launch_bounds__(256) read_sizes_kernel(const int32_t* __restri
         atomicAdd(&totals[0], rd);
         atomicAdd(&totals[1], rc);
     }
+}
+
+// Step 2, one thread per four records: a record's read starts at the nearest
+// mark at or before it — at most 15 positions back for a read of <= 16 records;
+// no mark within reach, or the mark 0xFF: not covered (size 0).  A workgroup
+// stages its marks (and the 16 before them) in LDS and writes the sizes as
+// whole dwords.
+constexpr uint32_t kSpreadTile = 4096;
+__global__ void __launch_bounds__(1024) spread_sizes_kernel(const unsigned char* __restrict__ mark,
+                                                            uint32_t n_records, unsigned char* __restrict__ rk) {
+    __shared__ __attribute__((aligned(16))) unsigned char m[16 + kSpreadTile];
+    const uint32_t base = blockIdx.x * kSpreadTile;
+    // marks [base - 16, base + tile) -> m[0, 16 + tile)
+    for (uint32_t i = threadIdx.x; i < (16u + kSpreadTile) / 4u; i += blockDim.x) {
+        const int64_t at = (int64_t)base - 16 + 4 * (int64_t)i;  // (base is a multiple of 4: aligned dwords)
+        uint32_t v = 0u;
+        if (at >= 0 && at < (int64_t)n_records) v = *reinterpret_cast<const uint32_t*>(mark + at);
+        reinterpret_cast<uint32_t*>(m)[i] = v;
+    }
+    __syncthreads();
+    const uint32_t x0 = threadIdx.x * 4u;
+    if (base + x0 >= n_records) return;
+    uint32_t out = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t x = x0 + k;
+        uint32_t size = 0u;
+        if (base + x < n_records) {
+            for (uint32_t d = 0; d < 16u; ++d) {
+                const uint32_t v = m[16u + x - d];
+                if (v) {
+                    size = (v != 0xFFu && d < v) ? v : 0u;  // (d < v: still inside that read)
+                    break;
+                }
+            }
+        }
+        out |= size << (8u * k);
+    }
+    *reinterpret_cast<uint32_t*>(rk + base + x0) = out;
 }
 
 struct BinsArgs {

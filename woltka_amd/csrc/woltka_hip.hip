@@ -149,7 +149,7 @@ struct wk_ctx {
     // read size per record of the staged chunk + reads the histogram does not
     // cover + totals: [0] derived at staging, [1] derived again with the
     // validity bits of the current subject rows (when some subject has one set)
-    DevBuf c_rk[2], rk_left[2], rk_totals;
+    DevBuf c_rk[2], rk_left[2], rk_totals, rk_mark;
     bool rk_valid[2] = {false, false};
     int64_t rk_reads[2] = {0, 0}, rk_records[2] = {0, 0};
     int64_t stage_serial = 0, rows_serial = 0, rk1_stage = -1, rk1_rows = -1;
@@ -277,6 +277,28 @@ __global__ void __launch_bounds__(256) table_compact_kernel(const unsigned long 
 
 }  // namespace
 
+// Read size per record of the staged chunk (wk_weigh.hpp): marks at the read
+// starts, then spread over the records.  `check`: leave out reads that name a
+// subject with its validity bit set.
+static int derive_read_sizes(wk_ctx* c, bool check, const int32_t* qoff, const int32_t* subj, int64_t n_reads, int64_t n_rec,
+                             unsigned char* rk, unsigned long long* left, unsigned long long* totals) {
+    HIP_TRY(c, c->rk_mark.reserve((size_t)n_rec + 64));
+    HIP_TRY(c, hipMemsetAsync(c->rk_mark.p, 0, (size_t)n_rec + 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(totals, 0, 16, c->stream));
+    const dim3 grid((unsigned)((n_reads + 255) / 256));
+    if (check)
+        hipLaunchKernelGGL(mark_reads_kernel<true>, grid, dim3(256), 0, c->stream, qoff, (uint32_t)n_reads, subj,
+                           c->w_invalid.as<uint32_t>(), (uint32_t)c->n_subjects, c->rk_mark.as<unsigned char>(), left, totals);
+    else
+        hipLaunchKernelGGL(mark_reads_kernel<false>, grid, dim3(256), 0, c->stream, qoff, (uint32_t)n_reads, subj,
+                           (const uint32_t*)nullptr, 0u, c->rk_mark.as<unsigned char>(), left, totals);
+    if (n_rec > 0)
+        hipLaunchKernelGGL(spread_sizes_kernel, dim3((unsigned)((n_rec + kSpreadTile - 1) / kSpreadTile)), dim3(1024), 0, c->stream,
+                           c->rk_mark.as<unsigned char>(), (uint32_t)n_rec, rk);
+    HIP_TRY(c, hipGetLastError());
+    return WK_OK;
+}
+
 extern "C" {
 
 int wk_abi_version(void) { return WK_ABI_VERSION; }
@@ -378,7 +400,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4, &c->ginfo,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->rk_mark, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -726,15 +748,12 @@ int wk_chunk_stage(wk_ctx* c, const int32_t* subj, const int32_t* qoff, int64_t 
         HIP_TRY(c, c->c_rk[0].reserve((size_t)n_rec + 64));
         HIP_TRY(c, c->rk_left[0].reserve((size_t)((n_reads + 63) / 64) * 8));
         HIP_TRY(c, c->rk_totals.reserve(32));
-        HIP_TRY(c, hipMemsetAsync(c->rk_totals.p, 0, 32, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->c_rk[0].as<unsigned char>() + n_rec, 0, 8, c->stream));  // the sizes are read four at a time
         KernelTimer* kt = ktimer_begin(c, "read_sizes");
-        hipLaunchKernelGGL(read_sizes_kernel<false>, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream,
-                           c->c_qoff.as<int32_t>(), (uint32_t)n_reads, (const int32_t*)nullptr, (const uint32_t*)nullptr, 0u,
-                           c->c_rk[0].as<unsigned char>(), c->rk_left[0].as<unsigned long long>(),
-                           c->rk_totals.as<unsigned long long>());
+        if ((rc = derive_read_sizes(c, false, c->c_qoff.as<int32_t>(), c->c_subj.as<int32_t>(), n_reads, n_rec,
+                                    c->c_rk[0].as<unsigned char>(), c->rk_left[0].as<unsigned long long>(),
+                                    c->rk_totals.as<unsigned long long>())))
+            return rc;
         ktimer_end(c, kt);
-        HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(totals, c->rk_totals.p, 16, hipMemcpyDeviceToHost, c->stream));
         c->rk_valid[0] = true;
     }
@@ -1021,14 +1040,14 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                         kt = ktimer_begin(c, "read_sizes");
                         HIP_TRY(c, c->c_rk[1].reserve((size_t)c->n_records + 64));
                         HIP_TRY(c, c->rk_left[1].reserve((size_t)n_words * 8));
-                        HIP_TRY(c, hipMemsetAsync(c->rk_totals.as<unsigned char>() + 16, 0, 16, c->stream));
-                        HIP_TRY(c, hipMemsetAsync(c->c_rk[1].as<unsigned char>() + c->n_records, 0, 8, c->stream));
-                        hipLaunchKernelGGL(read_sizes_kernel<true>, dim3((unsigned)((c->n_reads + 255) / 256)), dim3(256), 0,
-                                           c->stream, a.qoff, (uint32_t)c->n_reads, a.subj, c->w_invalid.as<uint32_t>(),
-                                           (uint32_t)c->n_subjects, c->c_rk[1].as<unsigned char>(),
-                                           c->rk_left[1].as<unsigned long long>(), c->rk_totals.as<unsigned long long>() + 2);
+                        {
+                            const int rc1 = derive_read_sizes(c, true, a.qoff, a.subj, c->n_reads, c->n_records,
+                                                              c->c_rk[1].as<unsigned char>(),
+                                                              c->rk_left[1].as<unsigned long long>(),
+                                                              c->rk_totals.as<unsigned long long>() + 2);
+                            if (rc1) return rc1;
+                        }
                         ktimer_end(c, kt);
-                        HIP_TRY(c, hipGetLastError());
                         unsigned long long totals[2] = {0, 0};
                         HIP_TRY(c, hipMemcpyAsync(totals, c->rk_totals.as<unsigned char>() + 16, 16, hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
