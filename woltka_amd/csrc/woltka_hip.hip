@@ -94,7 +94,9 @@ struct wk_ctx {
     bool subj_indexed = false;  // staged chunk carries subject indices
 
     // genes
-    DevBuf genome_off, gstart, gend, gpmax, gfeat, gene4, ginfo;
+    DevBuf gene4, g_grid, g_first, g_goff, g_shift;  // gene tables (wk_set_genes; wk_ordinal.hpp)
+    bool genes_set = false;
+    int grid_density = 1;  // grid cells per gene (rounded up to a power of two per genome)
     int32_t n_genomes = 0, n_genes = 0;
 
     // count table
@@ -143,6 +145,10 @@ struct wk_ctx {
     DevBuf left_mask, left_list, first_slab;
     // weighted subject histogram (wk_weigh.hpp): 0 = off, 1 = auto, 2 = whenever applicable
     int use_weigh = 1;
+    int tally_slots = 2048;  // hash-cache slots of a tally workgroup (a power of two)
+    int use_tally = 1;      // wk_ordinal_count: genes tallied per read straight from the matches
+    int match_lds = 1;      // per-genome words of the coordinate grid in LDS when they fit
+    bool listed_only = false;  // wk_classify_staged evaluates only the reads of left_mask
     int bins_ring = 4;  // measurement knob: load stages in flight of weigh_bins_kernel
     DevBuf w_slab, w_hi, w_invalid;
     size_t w_hi_clean = 0;        // leading entries of w_hi known to be zero
@@ -397,7 +403,7 @@ void wk_destroy(wk_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->genome_off, &c->gstart, &c->gend, &c->gpmax, &c->gfeat, &c->gene4, &c->ginfo,
+    DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->rk_mark, &c->assign_out, &c->fetch_k, &c->fetch_v};
@@ -445,6 +451,24 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     }
     if (!strcmp(name, "ablate")) {
         c->ablate = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "tally_slots")) {
+        if (value < 256 || value > 4096 || (value & (value - 1))) return fail(c, WK_E_ARG, "tally_slots must be a power of two in [256, 4096]");
+        c->tally_slots = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "tally")) {
+        c->use_tally = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "match_lds")) {
+        c->match_lds = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "grid_density")) {  // takes effect at the next wk_set_genes
+        if (value < 1 || value > 8) return fail(c, WK_E_ARG, "grid_density must be in [1, 8]");
+        c->grid_density = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "plog")) {  // 0 = off, 1 = auto (large chunks), 2 = always
@@ -565,8 +589,9 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
     if (n_genomes < 0 || n_genes < 0 || !genome_off || (n_genes > 0 && (!start0 || !end || !gene_feature)))
         return fail(c, WK_E_ARG, "bad gene table arguments");
     if (genome_off[0] != 0 || genome_off[n_genomes] != n_genes) return fail(c, WK_E_ARG, "genome_off must run from 0 to n_genes");
-    // running maximum of gene ends per genome (prunes the backward scan)
-    std::vector<int32_t> pmax((size_t)n_genes);
+    // gene records {start0, end, largest end before the gene, feature}: the
+    // third word stops the backward walk of a hit
+    std::vector<int32_t> packed((size_t)n_genes * 4);
     for (int32_t g = 0; g < n_genomes; ++g) {
         if (genome_off[g + 1] < genome_off[g]) return fail(c, WK_E_ARG, "genome_off is not monotone at genome %d", g);
         int32_t m = INT32_MIN;
@@ -574,36 +599,48 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
             if (i > genome_off[g] && start0[i] < start0[i - 1]) return fail(c, WK_E_ARG, "genes of genome %d are not sorted by start", g);
             if (end[i] < start0[i]) return fail(c, WK_E_ARG, "gene %d has end < start", i);
             if (gene_feature[i] < 0 || gene_feature[i] > WK_MAX_FEATURE) return fail(c, WK_E_RANGE, "gene feature id out of range");
+            packed[4 * (size_t)i] = start0[i];
+            packed[4 * (size_t)i + 1] = end[i];
+            packed[4 * (size_t)i + 2] = m;
+            packed[4 * (size_t)i + 3] = gene_feature[i];
             m = end[i] > m ? end[i] : m;
-            pmax[i] = m;
         }
     }
-    DeviceGuard guard(c->device);
-    int rc;
-    if ((rc = upload(c, c->genome_off, genome_off, ((size_t)n_genomes + 1) * sizeof(int32_t)))) return rc;
-    if ((rc = upload(c, c->gstart, start0, (size_t)n_genes * sizeof(int32_t)))) return rc;
-    if ((rc = upload(c, c->gend, end, (size_t)n_genes * sizeof(int32_t)))) return rc;
-    if ((rc = upload(c, c->gpmax, pmax.data(), (size_t)n_genes * sizeof(int32_t)))) return rc;
-    if ((rc = upload(c, c->gfeat, gene_feature, (size_t)n_genes * sizeof(int32_t)))) return rc;
-    std::vector<int32_t> packed((size_t)n_genes * 4);
-    for (int32_t i = 0; i < n_genes; ++i) {
-        packed[4 * (size_t)i] = start0[i];
-        packed[4 * (size_t)i + 1] = end[i];
-        packed[4 * (size_t)i + 2] = pmax[i];
-        packed[4 * (size_t)i + 3] = gene_feature[i];
-    }
-    if ((rc = upload(c, c->gene4, packed.data(), packed.size() * sizeof(int32_t)))) return rc;
-    std::vector<int32_t> info((size_t)n_genomes * 4);
+    // grid per genome: `cells` (a power of two, about grid_density per gene)
+    // equal ranges of width 2^shift from the smallest start0 on;
+    // grid[off + c] = first gene whose cell is >= c, for c = 0 .. cells
+    std::vector<int32_t> first((size_t)n_genomes + 1, 0), goff((size_t)n_genomes + 1, 0);
+    std::vector<unsigned char> shift((size_t)n_genomes + 1, 0);
+    std::vector<int32_t> grid;
+    grid.reserve((size_t)n_genes * 2 * (size_t)c->grid_density + (size_t)n_genomes * 2 + 1);
     for (int32_t g = 0; g < n_genomes; ++g) {
         const int32_t lo = genome_off[g], n = genome_off[g + 1] - lo;
-        info[4 * (size_t)g] = lo;
-        info[4 * (size_t)g + 1] = n;
-        info[4 * (size_t)g + 2] = n ? start0[lo] : 0;
-        const int64_t span = n ? (int64_t)start0[lo + n - 1] - start0[lo] : 0;
-        const float scale = span > 0 ? (float)(n - 1) / (float)span : 0.f;
-        memcpy(&info[4 * (size_t)g + 3], &scale, 4);
+        goff[g] = (int32_t)grid.size();
+        if (n == 0) continue;  // no cells: no hit of this genome matches
+        first[g] = start0[lo];
+        const uint64_t span = (uint64_t)((int64_t)start0[lo + n - 1] - (int64_t)start0[lo]);
+        uint64_t cells = 1;
+        while (cells < (uint64_t)n * (uint64_t)c->grid_density) cells <<= 1;
+        int sh = 0;
+        while ((span >> sh) >= cells) sh += 1;
+        shift[g] = (unsigned char)sh;
+        if (grid.size() + cells + 1 >= (1ull << 31)) return fail(c, WK_E_RANGE, "gene tables too large for the coordinate grid");
+        int32_t i = lo;
+        for (uint64_t cell = 0; cell <= cells; ++cell) {
+            while (i < lo + n && (((uint64_t)((int64_t)start0[i] - (int64_t)start0[lo])) >> sh) < cell) i += 1;
+            grid.push_back(i);
+        }
     }
-    if ((rc = upload(c, c->ginfo, info.data(), info.size() * sizeof(int32_t)))) return rc;
+    goff[n_genomes] = (int32_t)grid.size();
+    if (grid.empty()) grid.push_back(0);
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = upload(c, c->gene4, packed.data(), packed.size() * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->g_grid, grid.data(), grid.size() * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->g_first, first.data(), first.size() * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->g_goff, goff.data(), goff.size() * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->g_shift, shift.data(), shift.size()))) return rc;
+    c->genes_set = true;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_genomes = n_genomes;
     c->n_genes = n_genes;
@@ -913,7 +950,9 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // candidate (config 3: 10.6 -> 7.7 ms); a chunk without any pays one
             // streaming pass over the offsets.
             const bool feature_chunk = !c->subj_indexed;
-            const bool split = c->use_split && c->n_reads < (1ll << 30) && c->n_records < (1ll << 30) &&
+            // (ext: the caller evaluates only the reads of its own bit mask — wk_ordinal_count's leftovers)
+            const bool ext = c->listed_only;
+            const bool split = !ext && c->use_split && c->n_reads < (1ll << 30) && c->n_records < (1ll << 30) &&
                                (feature_chunk ? a.n_cols >= 0 : (a.row_w == 4 && c->n_subjects < (1 << 28)));
             // ... and with a small subject table the first pass only histograms
             // subject indices; the assigners run once per subject afterwards
@@ -925,7 +964,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             constexpr int kHotBins = 24576;
             // weighted subject histogram (wk_weigh.hpp): plain assigners only, every
             // read a set of subject indices, one group, no per-read output
-            bool weigh = c->use_weigh && c->subj_indexed && c->subj_is_set && !c->has_group && !out_assign && !sized &&
+            bool weigh = !ext && c->use_weigh && c->subj_indexed && c->subj_is_set && !c->has_group && !out_assign && !sized &&
                          c->n_reads < (1ll << 30) && c->n_records < (1ll << 30) && c->n_subjects > 0;
             for (int j = 0; j < n_jobs && weigh; ++j) {
                 if (jobs[j].mode == WK_MODE_NONE)
@@ -1216,7 +1255,18 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
             // one evaluator per kind of candidates (see classify_kernel's kPath)
             const int path = (a.rows != nullptr && a.row_w == 4) ? 0 : a.rows != nullptr ? 1 : 2;
             const dim3 grid(blocks), block(c->threads);
-            const bool listed = split || weigh;
+            if (ext) {
+                const uint32_t n_words = (uint32_t)((c->n_reads + 63) / 64);
+                const uint32_t list_seg = (((n_words + 15u) / 16u + (uint32_t)blocks - 1u) / (uint32_t)blocks) * 1024u;
+                HIP_TRY(c, c->left_list.reserve((size_t)blocks * list_seg * 4));
+                a.left_mask = c->left_mask.as<unsigned long long>();
+                a.n_mask_words = n_words;
+                a.list_seg = list_seg;
+                a.read_list = c->left_list.as<uint32_t>();
+                a.resume = 0;
+                a.slab16 = 0;
+            }
+            const bool listed = split || weigh || ext;
             if (listed && path == 0)
                 hipLaunchKernelGGL((classify_kernel<true, true, 0>), grid, block, lds, c->stream, a, (uint32_t)lds_slots);
             else if (listed && path == 1)
@@ -1294,46 +1344,60 @@ int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const
     return WK_OK;
 }
 
-int wk_ordinal_match(wk_ctx* c) {
-    if (!c) return WK_E_ARG;
-    if (!c->ord_valid) return fail(c, WK_E_STATE, "no ordinal chunk staged");
-    if (c->genome_off.p == nullptr) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
-    DeviceGuard guard(c->device);
-    const int64_t n_hits = c->n_hits;
-    const int64_t n_tiles = (n_hits + kMatchTile - 1) / kMatchTile;
-    HIP_TRY(c, c->o_cnt.reserve((size_t)(n_hits ? n_hits : 1) * 4));
-    HIP_TRY(c, c->o_poff.reserve((size_t)(n_hits ? n_hits : 1) * 4));
-    HIP_TRY(c, c->o_ub.reserve((size_t)(n_hits ? n_hits : 1) * 4));
-    HIP_TRY(c, c->o_first2.reserve((size_t)(n_hits ? n_hits : 1) * 8));
-    HIP_TRY(c, c->o_tile_sum.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
-    HIP_TRY(c, c->o_tile_off.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
-    HIP_TRY(c, c->o_qoff.reserve(((size_t)c->o_reads + 1) * 4));
-
+// Launch of match_hits_kernel: per-genome words in LDS when they fit.
+static int launch_match_hits(wk_ctx* c, bool counts) {
     MatchArgs a{};
     a.genome = c->o_genome.as<int32_t>();
     a.beg = c->o_beg.as<int32_t>();
     a.end = c->o_end.as<int32_t>();
     a.len = c->o_len.as<uint32_t>();
-    a.n_hits = n_hits;
+    a.n_hits = c->n_hits;
     a.th = c->th;
-    a.genome_off = c->genome_off.as<int32_t>();
-    a.gstart = c->gstart.as<int32_t>();
-    a.gend = c->gend.as<int32_t>();
-    a.gpmax = c->gpmax.as<int32_t>();
-    a.gfeat = c->gfeat.as<int32_t>();
     a.gene4 = c->gene4.as<int4>();
-    a.ginfo = c->ginfo.as<int4>();
+    a.grid = c->g_grid.as<int32_t>();
+    a.gfirst = c->g_first.as<int32_t>();
+    a.goff = c->g_goff.as<int32_t>();
+    a.gshift = c->g_shift.as<unsigned char>();
     a.n_genomes = c->n_genomes;
     a.ablate = c->ablate;
+    const int64_t n_tiles = (c->n_hits + kMatchTile - 1) / kMatchTile;
+    const int64_t rounds = (n_tiles + kMatchGroup - 1) / kMatchGroup;
+    // 9 bytes per genome; three workgroups of 512 threads per CU while the
+    // registers (80 without the counts) and the LDS copies allow
+    const size_t info = ((size_t)c->n_genomes * 2 + 1) * 4 + (size_t)c->n_genomes + 16;
+    const bool in_lds = c->match_lds && info <= (size_t)150 * 1024;
+    const int by_regs = counts ? 2 : 3;
+    const int per_cu = !in_lds ? by_regs : std::max(1, std::min(by_regs, (int)((size_t)156 * 1024 / info)));
+    const dim3 grid((unsigned)std::min<int64_t>(rounds, (int64_t)c->prop.multiProcessorCount * per_cu));
+    const dim3 block(kMatchThreads * kMatchGroup);
+    int2* f2 = c->o_first2.as<int2>();
+    int32_t* start = c->o_ub.as<int32_t>();
+    int32_t* cnt = c->o_cnt.as<int32_t>();
+    unsigned long long* ts = c->o_tile_sum.as<unsigned long long>();
+    if (in_lds && counts)
+        hipLaunchKernelGGL((match_hits_kernel<true, true>), grid, block, info, c->stream, a, f2, start, cnt, ts);
+    else if (in_lds)
+        hipLaunchKernelGGL((match_hits_kernel<true, false>), grid, block, info, c->stream, a, f2, start, cnt, ts);
+    else if (counts)
+        hipLaunchKernelGGL((match_hits_kernel<false, true>), grid, block, 0, c->stream, a, f2, start, cnt, ts);
+    else
+        hipLaunchKernelGGL((match_hits_kernel<false, false>), grid, block, 0, c->stream, a, f2, start, cnt, ts);
+    HIP_TRY(c, hipGetLastError());
+    return WK_OK;
+}
 
+// Gene lists per read from the matches (offset scan, lists, read offsets);
+// `matched`: match_hits_kernel already ran with counts.
+static int materialise_gene_lists(wk_ctx* c) {
+    const int64_t n_hits = c->n_hits;
+    const int64_t n_tiles = (n_hits + kMatchTile - 1) / kMatchTile;
+    HIP_TRY(c, c->o_poff.reserve((size_t)(n_hits ? n_hits : 1) * 4));
+    HIP_TRY(c, c->o_tile_off.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
+    HIP_TRY(c, c->o_qoff.reserve(((size_t)c->o_reads + 1) * 4));
     unsigned long long total = 0;
     HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
     if (n_hits > 0) {
-        KernelTimer* kt = ktimer_begin(c, "match_count");
-        hipLaunchKernelGGL(match_count_kernel, dim3((unsigned)n_tiles), dim3(kMatchThreads), 0, c->stream, a,
-                           c->o_cnt.as<int32_t>(), c->o_ub.as<int32_t>(), c->o_first2.as<int2>(), c->o_tile_sum.as<unsigned long long>());
-        ktimer_end(c, kt);
-        kt = ktimer_begin(c, "scan");
+        KernelTimer* kt = ktimer_begin(c, "scan");
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->o_tile_sum.as<unsigned long long>(),
                            c->o_tile_off.as<unsigned long long>(), n_tiles, scalar_u64(c, 3));
         ktimer_end(c, kt);
@@ -1342,6 +1406,13 @@ int wk_ordinal_match(wk_ctx* c) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (total >= (1ull << 31)) return fail(c, WK_E_RANGE, "more than 2^31 read-gene pairs in one chunk; stage fewer hits");
         HIP_TRY(c, c->o_pairs.reserve((size_t)(total ? total : 1) * 4));
+        MatchArgs a{};
+        a.beg = c->o_beg.as<int32_t>();
+        a.end = c->o_end.as<int32_t>();
+        a.len = c->o_len.as<uint32_t>();
+        a.n_hits = n_hits;
+        a.th = c->th;
+        a.gene4 = c->gene4.as<int4>();
         kt = ktimer_begin(c, "match_write");
         hipLaunchKernelGGL(match_write_kernel, dim3((unsigned)n_tiles), dim3(kMatchThreads), 0, c->stream, a,
                            c->o_cnt.as<int32_t>(), c->o_ub.as<int32_t>(), c->o_first2.as<int2>(), c->o_tile_off.as<unsigned long long>(), c->o_poff.as<int32_t>(),
@@ -1367,6 +1438,31 @@ int wk_ordinal_match(wk_ctx* c) {
     return WK_OK;
 }
 
+static int reserve_match_buffers(wk_ctx* c) {
+    const int64_t n_hits = c->n_hits;
+    const int64_t n_tiles = (n_hits + kMatchTile - 1) / kMatchTile;
+    HIP_TRY(c, c->o_cnt.reserve((size_t)(n_hits ? n_hits : 1) * 4));
+    HIP_TRY(c, c->o_ub.reserve((size_t)(n_hits ? n_hits : 1) * 4));
+    HIP_TRY(c, c->o_first2.reserve((size_t)(n_hits ? n_hits : 1) * 8));
+    HIP_TRY(c, c->o_tile_sum.reserve((size_t)(n_tiles ? n_tiles : 1) * 8));
+    return WK_OK;
+}
+
+int wk_ordinal_match(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    if (!c->ord_valid) return fail(c, WK_E_STATE, "no ordinal chunk staged");
+    if (!c->genes_set) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
+    DeviceGuard guard(c->device);
+    int rc = reserve_match_buffers(c);
+    if (rc) return rc;
+    if (c->n_hits > 0) {
+        KernelTimer* kt = ktimer_begin(c, "match_count");
+        if ((rc = launch_match_hits(c, true))) return rc;
+        ktimer_end(c, kt);
+    }
+    return materialise_gene_lists(c);
+}
+
 int wk_set_uniform_group(wk_ctx* c, int32_t group) {
     if (!c) return WK_E_ARG;
     if (group < 0 || group >= (1 << WK_KEY_GROUP_BITS)) return fail(c, WK_E_ARG, "group id outside [0, %d)", 1 << WK_KEY_GROUP_BITS);
@@ -1376,14 +1472,81 @@ int wk_set_uniform_group(wk_ctx* c, int32_t group) {
 }
 
 int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
-    // (a fused kernel — one thread per read searching its hits, the union in
-    // registers, gene weights in LDS bins — was built and measured at 6.6 ms per
-    // 107.5 M hits against 4.7 ms for these two steps: the per-read search loses
-    // the four searches a thread of match_count_kernel keeps in flight, and the
-    // 500 k-gene table needs 13 slices of bins.  DESIGN.md §4.)
-    int rc = wk_ordinal_match(c);
+    if (!c) return WK_E_ARG;
+    if (!c->ord_valid) return fail(c, WK_E_STATE, "no ordinal chunk staged");
+    if (!c->genes_set) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
+    if (n_jobs < 1 || n_jobs > WK_MAX_JOBS || !jobs) return fail(c, WK_E_ARG, "n_jobs must be in [1, %d]", WK_MAX_JOBS);
+    // the genes themselves are counted (rank none, one group, no size
+    // normalisation): tallied per read straight from the matches
+    bool tally = c->use_tally && !c->has_group && c->slots > 0 && c->n_hits > 0 && c->o_reads > 0;
+    for (int j = 0; j < n_jobs && tally; ++j)
+        tally = jobs[j].mode == WK_MODE_NONE && !(jobs[j].flags & (WK_F_UNIQ | WK_F_SIZED));
+    if (!tally) {
+        int rc = wk_ordinal_match(c);
+        if (rc) return rc;
+        return wk_classify_staged(c, jobs, n_jobs, nullptr);
+    }
+    DeviceGuard guard(c->device);
+    int rc = reserve_match_buffers(c);
     if (rc) return rc;
-    return wk_classify_staged(c, jobs, n_jobs, nullptr);
+    // (without the per-hit counts: they are only needed for reads the tally
+    // leaves over, and then the matching runs once more)
+    KernelTimer* kt = ktimer_begin(c, "match_count");
+    if ((rc = launch_match_hits(c, false))) return rc;
+    ktimer_end(c, kt);
+    const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * 2);
+    const int64_t n_words = (c->o_reads + 63) / 64;
+    TallyArgs t{};
+    t.hoff = c->o_hoff.as<int32_t>();
+    t.first2 = c->o_first2.as<int2>();
+    t.n_reads = c->o_reads;
+    t.n_jobs = n_jobs;
+    for (int j = 0; j < n_jobs; ++j) t.job_index[j] = j;
+    t.group = c->group_base;
+    t.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
+    // distinct keys: the genes (256 merge tables of 8192 slots hold ~1.3 M at a comfortable load)
+    t.log_parts = c->log_parts_opt ? (uint32_t)c->log_parts_opt : ((int64_t)c->n_genes * n_jobs <= 256 * 5120 ? 256u : kLogPartsMax);
+    const int64_t streams = (int64_t)blocks * t.log_parts;
+    // every gene of a hit is one entry: hits with a gene rarely have two
+    int64_t cap = 3 * (c->n_hits * (int64_t)n_jobs / streams + 1) + 16;
+    cap = std::max<int64_t>(16, std::min<int64_t>(cap, c->plog_max_bytes / 8 / streams));
+    t.plog_cap = (uint32_t)cap;
+    HIP_TRY(c, c->plog.reserve((size_t)streams * t.plog_cap * 8));
+    HIP_TRY(c, c->plog_cnt.reserve((size_t)streams * 4));
+    HIP_TRY(c, c->left_mask.reserve((size_t)n_words * 8));
+    t.plog = c->plog.as<unsigned long long>();
+    t.plog_cnt = c->plog_cnt.as<uint32_t>();
+    t.stat_block = c->stat_block.as<unsigned long long>();
+    t.left_mask = c->left_mask.as<unsigned long long>();
+    t.n_left = scalar_u64(c, 7);
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 7), 0, 16, c->stream));
+    kt = ktimer_begin(c, "classify");
+    // LDS per workgroup (two per CU): 32 KiB hash cache + log cursors + 32 KiB of gene sets
+    const uint32_t tally_slots = (uint32_t)std::max(256, std::min(c->tally_slots, 4096));
+    const size_t tally_lds = (size_t)tally_slots * 16 + (size_t)t.log_parts * 4 + (size_t)kTallyQueue * 4 + (size_t)kTallySlots * kTallyThreads * 4;
+    hipLaunchKernelGGL(ordinal_tally_kernel, dim3(blocks), dim3(kTallyThreads), tally_lds, c->stream, t, tally_slots);
+    ktimer_end(c, kt);
+    kt = ktimer_begin(c, "partition_merge");
+    hipLaunchKernelGGL(partition_merge_kernel, dim3(t.log_parts), dim3(1024), (size_t)8192 * 16, c->stream,
+                       c->plog.as<unsigned long long>(), c->plog_cnt.as<uint32_t>(), (uint32_t)blocks, t.plog_cap, 8192u, t.table);
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long left_pairs[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(left_pairs, scalar_u64(c, 7), 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->chunk_valid = false;
+    if (left_pairs[0] == 0) {
+        c->stat_pairs += (int64_t)left_pairs[1];
+        return WK_OK;
+    }
+    // reads the tally left out (many genes per hit / per read): their gene
+    // lists through the generic evaluator
+    if ((rc = launch_match_hits(c, true))) return rc;
+    if ((rc = materialise_gene_lists(c))) return rc;
+    c->listed_only = true;
+    rc = wk_classify_staged(c, jobs, n_jobs, nullptr);
+    c->listed_only = false;
+    return rc;
 }
 
 int wk_chunk_download(wk_ctx* c, int32_t* subj, int64_t subj_cap, int32_t* qoff, int64_t qoff_cap, int64_t* n_records,
