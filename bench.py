@@ -183,7 +183,7 @@ class LcaWorkload:
         h = p['hier']
         ctx.set_tree(h.parent, h.last, h.rank_code)
         self.jobs = []
-        for slot, rank in enumerate(self.ranks):
+        for slot, rank in enumerate(r for r in self.ranks if r != 'free'):
             ctx.build_rank_table(slot, h.rank_codes[rank])
             self.jobs.append(nat.Job(nat.MODE_RANK, slot, 0, 0, 0.0))
         ctx.counts_reserve(1 << 24)

@@ -349,8 +349,8 @@ struct TallyArgs {
     unsigned long long* n_left;  // [2]: reads left over, pairs of the tallied reads
 };
 
-constexpr uint32_t kTallyThreads = 1024;
-constexpr uint32_t kTallyQueue = 4096;  // reads with several hits wait here until a full workgroup's worth is queued
+constexpr uint32_t kTallyThreads = 512;
+constexpr uint32_t kTallyQueue = 3072;  // reads with several hits wait here until a full workgroup's worth is queued
 
 __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -372,13 +372,13 @@ __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs 
     lds_cache_init(cache);  // (ends with a barrier)
     const bool one_job = a.n_jobs == 1;
     const uint32_t job0 = (uint32_t)a.job_index[0];
+    auto add_key = [&](uint64_t key, uint32_t n) { cached_add(cache, a.table, key, (unsigned long long)weight_of(n)); };
     auto add = [&](int32_t feature, uint32_t n) {
-        const unsigned long long w = weight_of(n);
         if (one_job) {
-            cached_add(cache, a.table, make_key(job0, 0u, (uint32_t)a.group, (uint32_t)feature), w);
+            add_key(make_key(job0, 0u, (uint32_t)a.group, (uint32_t)feature), n);
         } else {
             for (int32_t jb = 0; jb < a.n_jobs; ++jb)
-                cached_add(cache, a.table, make_key((uint32_t)a.job_index[jb], 0u, (uint32_t)a.group, (uint32_t)feature), w);
+                add_key(make_key((uint32_t)a.job_index[jb], 0u, (uint32_t)a.group, (uint32_t)feature), n);
         }
     };
     unsigned long long my_reads = 0, my_records = 0, my_left = 0;
@@ -393,8 +393,10 @@ __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs 
         int32_t* const mine = sets + threadIdx.x;
         int n = 0, total = 0;
         bool left = nh > kTallyHits;
+        // (the first three hits' matches in flight together)
+        const int2 p0 = a.first2[h0], p1 = a.first2[h0 + 1], p2 = nh > 2 ? a.first2[h0 + 2] : make_int2(-1, -1);
         for (int32_t i = 0; i < nh && !left; ++i) {
-            const int2 g2 = a.first2[h0 + i];
+            const int2 g2 = i == 0 ? p0 : i == 1 ? p1 : i == 2 ? p2 : a.first2[h0 + i];
             if (g2.y == -2) left = true;
             const int32_t cand[2] = {g2.x, g2.y};
 #pragma unroll

@@ -96,7 +96,7 @@ struct wk_ctx {
     // genes
     DevBuf gene4, g_grid, g_first, g_goff, g_shift;  // gene tables (wk_set_genes; wk_ordinal.hpp)
     bool genes_set = false;
-    int grid_density = 1;  // grid cells per gene (rounded up to a power of two per genome)
+    int grid_density = 2;  // grid cells per gene (rounded up to a power of two per genome)
     int32_t n_genomes = 0, n_genes = 0;
 
     // count table
@@ -145,7 +145,8 @@ struct wk_ctx {
     DevBuf left_mask, left_list, first_slab;
     // weighted subject histogram (wk_weigh.hpp): 0 = off, 1 = auto, 2 = whenever applicable
     int use_weigh = 1;
-    int tally_slots = 2048;  // hash-cache slots of a tally workgroup (a power of two)
+    int tally_per_cu = 3;    // tally workgroups (512 threads) per CU
+    int tally_slots = 1024;  // hash-cache slots of a tally workgroup (a power of two)
     int use_tally = 1;      // wk_ordinal_count: genes tallied per read straight from the matches
     int match_lds = 1;      // per-genome words of the coordinate grid in LDS when they fit
     bool listed_only = false;  // wk_classify_staged evaluates only the reads of left_mask
@@ -389,6 +390,10 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&match_hits_kernel<true, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&match_hits_kernel<true, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&partition_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess) {
         int rc = fail(nullptr, WK_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
@@ -451,6 +456,11 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     }
     if (!strcmp(name, "ablate")) {
         c->ablate = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "tally_per_cu")) {
+        if (value < 1 || value > 4) return fail(c, WK_E_ARG, "tally_per_cu must be in [1, 4]");
+        c->tally_per_cu = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "tally_slots")) {
@@ -1494,7 +1504,7 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     KernelTimer* kt = ktimer_begin(c, "match_count");
     if ((rc = launch_match_hits(c, false))) return rc;
     ktimer_end(c, kt);
-    const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * 2);
+    const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->tally_per_cu);
     const int64_t n_words = (c->o_reads + 63) / 64;
     TallyArgs t{};
     t.hoff = c->o_hoff.as<int32_t>();
@@ -1521,7 +1531,7 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     t.n_left = scalar_u64(c, 7);
     HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 7), 0, 16, c->stream));
     kt = ktimer_begin(c, "classify");
-    // LDS per workgroup (two per CU): 32 KiB hash cache + log cursors + 32 KiB of gene sets
+    // LDS per workgroup (three per CU): 16 KiB hash cache + log cursors + 12 KiB queue + 16 KiB of gene sets
     const uint32_t tally_slots = (uint32_t)std::max(256, std::min(c->tally_slots, 4096));
     const size_t tally_lds = (size_t)tally_slots * 16 + (size_t)t.log_parts * 4 + (size_t)kTallyQueue * 4 + (size_t)kTallySlots * kTallyThreads * 4;
     hipLaunchKernelGGL(ordinal_tally_kernel, dim3(blocks), dim3(kTallyThreads), tally_lds, c->stream, t, tally_slots);
