@@ -266,7 +266,9 @@ class OrdinalWorkload:
     """configs[3]: coord-match + gene histogram."""
     key = 'ordinal'
     dominant = 'match_count'
-    symbols = {}
+    symbols = {'match_count': 'wk::match_hits_kernel<true, false>',
+               'classify': 'wk::ordinal_tally_kernel',
+               'partition_merge': 'wk::partition_merge_kernel'}
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -289,8 +291,9 @@ class OrdinalWorkload:
         self.alg_bytes = 20 * self.records + 16 * p['gstart'].size + \
             int(6.4 * self.records)
         self.launch_bytes = self.alg_bytes
-        self.families = ('match_count', 'match_write', 'classify', 'leftover',
-                         'partition_merge')
+        # match_hits -> ordinal_tally -> partition_merge (wk_ordinal_count; the
+        # gene-list kernels only run for reads the tally leaves over)
+        self.families = ('match_count', 'classify', 'partition_merge')
         self._steps = 0
 
     def family_bytes(self, family):
@@ -298,13 +301,15 @@ class OrdinalWorkload:
         p = self.prob
         pairs = int(self.ctx.stats()['n_pairs']) // max(1, self._steps)
         tables = 16 * p['gstart'].size
-        if family == 'match_count':     # hits in, count + bound out
-            return 16 * self.records + tables + 8 * self.records
+        if family == 'match_count':     # hits in, first two matches out (+ grid)
+            return 16 * self.records + tables + 8 * self.records + \
+                8 * p['gstart'].size
         if family == 'match_write':     # hits + counts in, offsets + pairs out
             return 24 * self.records + tables + 4 * self.records + 4 * pairs
         if family == 'partition_merge':
             return 0
-        return 4 * pairs + 4 * (self.reads + 1)     # classify over gene lists
+        # tally: read offsets + the matches of every hit in, log entries out
+        return 4 * (self.reads + 1) + 8 * self.records + 8 * pairs
 
     def step(self):
         self._steps += 1
@@ -777,7 +782,11 @@ def run_rank(a, rank, world, local, sync):
                    'passes_per_step': passes,
                    'ms_per_pass': block['ms_per_pass'],
                    'timed_region_s': round(elapsed, 3),
-                   'sharding': f'samples x {world} GPUs, no collective'},
+                   'sharding': f'samples x {world} GPUs, no collective',
+                   # derived once when the chunk is staged (outside the passes:
+                   # a real run pays it once per chunk, next to one pass)
+                   'read_sizes_ms_once_per_staged_chunk':
+                       block.get('read_sizes_ms_once_per_staged_chunk')},
         'roofline': block['roofline'],
         'device': ctx.device_name,
         'checksum': checksum,
