@@ -142,7 +142,12 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * subject histogram as its own statically pipelined kernel),
  * "single_blocks_per_cu" (grid of the first pass), "weigh" (0 off / 1 auto / 2
  * whenever the jobs allow it: plain rank jobs as one weighted histogram over
- * subject indices, csrc/wk_weigh.hpp).
+ * subject indices, csrc/wk_weigh.hpp), "bins_ring" (3/4/6/8 tiles in flight in
+ * that histogram), "tally" (0/1: wk_ordinal_count counts rank-none jobs
+ * straight from the matches), "tally_slots" / "tally_per_cu" (LDS cache slots
+ * and workgroups per CU of that kernel), "grid_density" (1..8 grid cells per
+ * gene; takes effect at the next wk_set_genes), "match_lds" (0/1: per-genome
+ * words of the coordinate grid in LDS).
  * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 
@@ -259,8 +264,13 @@ int wk_ordinal_match(wk_ctx* ctx);
 
 /* The same in one call for jobs that need no per-read result: matches the
  * staged hits and adds the reads' gene sets to the count table under every
- * job — wk_ordinal_match followed by wk_classify_staged (ordinal.flush_chunk
- * + workflow.assign_readmap, ordinal.py:243-335, workflow.py:941-1058). */
+ * job (ordinal.flush_chunk + workflow.assign_readmap, ordinal.py:243-335,
+ * workflow.py:941-1058).  When every job is a plain WK_MODE_NONE job and the
+ * chunk has one group (the genes themselves are the profile's features:
+ * classify.assign_none + classify.counter, classify.py:32-51, 144-171) the
+ * genes are counted per read straight from the matches, without gene lists;
+ * otherwise this is wk_ordinal_match followed by wk_classify_staged.  The
+ * staged classify chunk is not valid afterwards. */
 int wk_ordinal_count(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs);
 
 /* The chunk staged last (wk_chunk_stage / wk_ordinal_stage) has no per-read
