@@ -299,6 +299,15 @@ typedef struct wk_tok wk_tok;
 int wk_tok_create(int n_threads /* <= 0: all hardware threads */, wk_tok** out);
 void wk_tok_destroy(wk_tok* tok);
 const char* wk_tok_last_error(const wk_tok* tok);
+/* SAM, "ex" flavour with an exclusion set, after the final block of a file:
+ * the text of the reads that parse_sam_file_ex_ft's closing statements yield
+ * once more when the last query of the file was dropped (they do not look at
+ * `keep`, align.py:542-547): the lines still in its pool, under the last
+ * query's name.  Empty when the last query was kept.  Tokenising this text as
+ * one more block (exclusion switched off) reproduces the reference's output.
+ * cap = 0 asks for the length. */
+int wk_tok_sam_tail(wk_tok* tok, char* buf, int64_t cap, int64_t* len);
+
 /* Subjects to exclude (align.py:443-469): names are blob[off[i]..off[i+1]). */
 int wk_tok_set_exclude(wk_tok* tok, const char* blob, const int32_t* off,
                        int32_t n);

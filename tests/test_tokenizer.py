@@ -16,7 +16,7 @@ def run_native(text, threads, block, excl=None, extra=False, fmt='sam'):
     reads = []
     for buf, res in align.native_sam_blocks(io.BytesIO(text), tok, block,
                                             extra=extra, want_names=True,
-                                            fmt=fmt):
+                                            fmt=fmt, exclude=excl):
         names.extend(tok.new_subjects())
         q = Tokenizer.query_names(buf, res['qname'])
         off = res['off'].tolist()
@@ -75,6 +75,112 @@ def test_extra_matches_python_parser(threads, block):
                 exp.append((q, recs))
         got, _ = run_native(text, threads, block, extra=True)
         assert got == exp
+
+
+def _ex_expected(lines, excl):
+    exp = []
+    for q, recs in align.parse_align(lines, 'sam', excl, extra=True):
+        recs = [r for r in recs if r[2]]
+        if recs:
+            exp.append((q, recs))
+    return exp
+
+
+@pytest.mark.parametrize('threads,block', [(1, 1 << 20), (5, 512), (3, 150)])
+def test_extra_with_exclusion_matches_python_parser(threads, block):
+    """The "extra + exclude" flavour natively, including what the reference's
+    parse_sam_file_ex_ft yields at the end of a file whose last query was
+    dropped (align.py:542-547; the Python parser is pinned to it by the golden
+    parser vectors): the pool of the last query that was not excluded at its
+    first line, under the last query's name."""
+    v = load_vectors('parsers.json')
+    for name in ('real', 'synth'):
+        lines = v[name]['lines']
+        excl = set(v[name]['excl'])
+        got, _ = run_native(''.join(lines).encode(), threads, block,
+                            excl=excl, extra=True)
+        assert got == _ex_expected(lines, excl)
+    rng = np.random.default_rng(threads * 1000 + block)
+    subjects = [f'G{i}' for i in range(12)]
+    flags = (0, 16, 99, 147, 83, 163, 256)
+    for case in range(60):
+        excl = set(rng.choice(subjects, int(rng.integers(1, 5)),
+                              replace=False).tolist())
+        lines = ['@HD\tVN:1.0\n'] if case % 2 else []
+        n_q = int(rng.integers(1, 40))
+        for q in range(n_q):
+            for _ in range(int(rng.integers(1, 6))):
+                s = subjects[int(rng.integers(0, len(subjects)))]
+                if rng.random() < 0.05:
+                    s = '*'
+                cigar = ('50M', '10M5D20M', '30S', '25M2I25M', '*')[
+                    int(rng.integers(0, 5))]
+                lines.append(f'Q{q}\t{flags[int(rng.integers(0, 7))]}\t{s}\t'
+                             f'{int(rng.integers(1, 5000))}\t42\t{cigar}\t*\t0'
+                             f'\t0\t*\t*\n')
+        # the interesting endings: one or several trailing queries that are
+        # excluded at their first line, or half way
+        for t in range(int(rng.integers(0, 4))):
+            x = sorted(excl)[0]
+            keep_first = rng.random() < 0.5
+            if keep_first:
+                lines.append(f'T{t}\t0\tG11x\t7\t42\t20M\t*\t0\t0\t*\t*\n')
+            lines.append(f'T{t}\t0\t{x}\t9\t42\t20M\t*\t0\t0\t*\t*\n')
+            lines.append(f'T{t}\t0\tG11y\t11\t42\t20M\t*\t0\t0\t*\t*\n')
+        text = ''.join(lines).encode()
+        if case % 3 == 0:
+            text = text.rstrip(b'\n')
+        got, _ = run_native(text, threads, block, excl=excl, extra=True)
+        assert got == _ex_expected(lines, excl), (case, lines[-6:])
+
+
+def test_final_flush_of_a_dropped_last_query():
+    row = '{}\t{}\t{}\t{}\t42\t20M\t*\t0\t0\t*\t*\n'
+    lines = [row.format('A', 99, 'G1', 5), row.format('A', 147, 'G2', 50),
+             row.format('B', 0, 'X', 9),            # dropped at its first line
+             row.format('C', 0, 'X', 9)]            # ... so is the last query
+    exp = [('A/1', [('G1', None, 20, 4, 24)]), ('A/2', [('G2', None, 20, 49, 69)]),
+           ('C/1', [('G1', None, 20, 4, 24)]), ('C/2', [('G2', None, 20, 49, 69)])]
+    assert _ex_expected(lines, {'X'}) == exp
+    for threads, block in ((1, 1 << 20), (4, 64)):
+        got, _ = run_native(''.join(lines).encode(), threads, block,
+                            excl={'X'}, extra=True)
+        assert got == exp
+    # dropped half way: what it had collected comes out under its own name
+    lines = [row.format('A', 0, 'G1', 5), row.format('B', 0, 'G2', 7),
+             row.format('B', 0, 'X', 9), row.format('B', 0, 'G3', 11)]
+    exp = [('A', [('G1', None, 20, 4, 24)]), ('B', [('G2', None, 20, 6, 26)])]
+    assert _ex_expected(lines, {'X'}) == exp
+    got, _ = run_native(''.join(lines).encode(), 2, 64, excl={'X'}, extra=True)
+    assert got == exp
+    # the last query kept: nothing extra
+    lines = [row.format('A', 0, 'X', 5), row.format('B', 0, 'G2', 7)]
+    got, _ = run_native(''.join(lines).encode(), 1, 64, excl={'X'}, extra=True)
+    assert got == [('B', [('G2', None, 20, 6, 26)])] == _ex_expected(lines, {'X'})
+
+
+def test_extra_with_exclusion_other_formats():
+    """b6o / paf: their "ex + exclude" parsers look at `keep` before the last
+    yield (align.py:975-981, 1207-1213): no extra reads."""
+    v = load_vectors('parsers.json')
+    rng = np.random.default_rng(3)
+    lines = []
+    for q in range(50):
+        for _ in range(int(rng.integers(1, 5))):
+            s = f'G{int(rng.integers(0, 8))}'
+            a, b = sorted(rng.integers(1, 9000, 2).tolist())
+            lines.append(f'Q{q}\t{s}\t98.5\t{b - a + 1}\t0\t0\t1\t100\t{a}\t{b}'
+                         f'\t1e-5\t200.0\n')
+    lines.append('QL\tG1\t98.5\t50\t0\t0\t1\t50\t10\t59\t1e-5\t99.0\n')
+    excl = {'G1', 'G5'}
+    exp = [(q, [r for r in recs if r[2]])
+           for q, recs in align.parse_align(lines, 'b6o', excl, extra=True)]
+    exp = [(q, [(s, None, ln, b, e) for s, _, ln, b, e in recs])
+           for q, recs in exp if recs]
+    got, _ = run_native(''.join(lines).encode(), 3, 700, excl=excl,
+                        extra=True, fmt='b6o')
+    assert got == exp
+    del v
 
 
 def test_no_trailing_newline_and_empty():

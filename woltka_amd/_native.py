@@ -43,7 +43,8 @@ SYMBOLS = (
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
     'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
-    'wk_tok_set_exclude', 'wk_tok_sam', 'wk_tok_text', 'wk_tok_boundary',
+    'wk_tok_set_exclude', 'wk_tok_sam_tail', 'wk_tok_sam', 'wk_tok_text',
+    'wk_tok_boundary',
     'wk_tok_fetch',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
@@ -129,6 +130,8 @@ def load_library():
         'wk_tok_destroy': (None, [p]),
         'wk_tok_last_error': (C.c_char_p, [p]),
         'wk_tok_set_exclude': (C.c_int, [p, C.c_char_p, i32p, C.c_int32]),
+        'wk_tok_sam_tail': (C.c_int, [p, C.c_char_p, C.c_int64,
+                                      C.POINTER(C.c_int64)]),
         'wk_tok_sam': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.c_int, C.c_int, i64p, i64p, i64p]),
         'wk_tok_boundary': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64,
@@ -500,12 +503,30 @@ class Tokenizer:
             raise RuntimeError('wk_tok_create failed')
         self._h = h
         if exclude:
-            names = [x.encode() for x in sorted(exclude)]
-            off = np.zeros(len(names) + 1, dtype=np.int32)
-            np.cumsum([len(x) for x in names], out=off[1:])
-            blob = b''.join(names)
-            self._check(self._lib.wk_tok_set_exclude(
-                self._h, blob, _ptr(off, C.c_int32), len(names)))
+            self.set_exclude(exclude)
+
+    def set_exclude(self, exclude):
+        """Subjects whose queries are dropped (an empty set: none)."""
+        names = [x.encode() for x in sorted(exclude or ())]
+        off = np.zeros(len(names) + 1, dtype=np.int32)
+        np.cumsum([len(x) for x in names], out=off[1:])
+        blob = b''.join(names)
+        self._check(self._lib.wk_tok_set_exclude(
+            self._h, blob, _ptr(off, C.c_int32), len(names)))
+
+    def sam_tail(self):
+        """After the final block of a SAM file parsed with ``extra`` and an
+        exclusion set: the text of the reads the reference's parser yields
+        once more when the file's last query was dropped (align.py:542-547);
+        b'' otherwise."""
+        n = C.c_int64(0)
+        self._check(self._lib.wk_tok_sam_tail(self._h, None, 0, C.byref(n)))
+        if n.value == 0:
+            return b''
+        buf = C.create_string_buffer(n.value)
+        self._check(self._lib.wk_tok_sam_tail(self._h, buf, n.value,
+                                              C.byref(n)))
+        return buf.raw[:n.value]
 
     def _check(self, rc):
         if rc == OK:

@@ -330,9 +330,31 @@ def pack_queries(subque, index, trim=None):
 NATIVE_FORMATS = ('sam', 'map', 'b6o', 'paf')
 
 
+def _tail_block(tok, exclude, extra, want_names, want_groups, want_samples,
+                fmt):
+    """The reads `parse_sam_file_ex_ft` yields once more at the end of a file
+    whose last query was dropped (its closing statements do not look at
+    `keep`, align.py:542-547), as one more (buffer, result) block; None when
+    there is none."""
+    if not (extra and exclude and fmt == 'sam'):
+        return None
+    text = tok.sam_tail()
+    if not text:
+        return None
+    tok.set_exclude(())
+    try:
+        buf = memoryview(bytearray(text))
+        res = tok.parse(buf, first=False, final=True, extra=extra,
+                        want_names=want_names, want_groups=want_groups,
+                        want_samples=want_samples, fmt=fmt)
+    finally:
+        tok.set_exclude(exclude)
+    return buf, res
+
+
 def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
                       want_names=False, head=b'', want_groups=False,
-                      want_samples=False, fmt='sam', part=None):
+                      want_samples=False, fmt='sam', part=None, exclude=None):
     """Feed a binary alignment stream (SAM by default; map / b6o / paf via
     ``fmt``) through the native tokenizer (``_native.Tokenizer``) block by
     block.
@@ -350,7 +372,7 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
     if mm is not None:
         yield from _blocks_mmap(mm, len(head), tok, block_bytes, extra,
                                 want_names, want_groups, want_samples, fmt,
-                                part)
+                                part, exclude)
         return
     if part is not None:
         raise ValueError('A byte range needs a regular uncompressed file.')
@@ -394,6 +416,10 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
         first = False
         yield view[:fill], res
         if final:
+            tail = _tail_block(tok, exclude, extra, want_names, want_groups,
+                               want_samples, fmt)
+            if tail is not None:
+                yield tail
             return
         # the consumer (possibly a block behind, in another thread) still
         # reads read ids out of this buffer: continue in a fresh one
@@ -424,7 +450,8 @@ def _try_mmap(stream):
 
 
 def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
-                 want_groups=False, want_samples=False, fmt='sam', part=None):
+                 want_groups=False, want_samples=False, fmt='sam', part=None,
+                 exclude=None):
     """Tokenise a memory-mapped file in place.  ``start`` bytes were already
     read from the stream for format sniffing; the map covers the whole file,
     so they are simply parsed again from offset 0.  ``part`` = (i, n) restricts
@@ -456,6 +483,11 @@ def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
             first = False
             yield view[pos:end], res
             if final:
+                if size == len(mm):             # the end of the file itself
+                    tail = _tail_block(tok, exclude, extra, want_names,
+                                       want_groups, want_samples, fmt)
+                    if tail is not None:
+                        yield tail
                 break
             pos += used
             span = block_bytes

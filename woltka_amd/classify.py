@@ -291,7 +291,8 @@ class Engine:
                                               head=head,
                                               want_groups=want_groups,
                                               want_samples=want_samples,
-                                              fmt=fmt, part=part):
+                                              fmt=fmt, part=part,
+                                              exclude=exclude):
                 # the dictionary growth belongs to this block: fetch it before
                 # the tokenizer moves on
                 yield buf, res, tok.new_subjects(), \

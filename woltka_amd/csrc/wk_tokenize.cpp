@@ -103,6 +103,16 @@ struct Local {
     NameTable fresh;             // names not yet in the global table
     int error = 0;               // 1 = both mate bits, 2 = malformed line
     size_t error_at = 0;
+    // SAM, "ex" flavour with an exclusion set: what parse_sam_file_ex_ft's
+    // variables hold at the end of the range (align.py:509-547) — the last
+    // query, whether it is kept, and the lines whose records sit in `pool`:
+    // those of the last run that was not excluded at its first line, up to the
+    // record that excluded it (a later run excluded at its first line leaves
+    // the pool alone)
+    bool any_run = false, fin_keep = true, have_pool = false;
+    const char* fin_q = nullptr;
+    size_t fin_qn = 0;
+    std::vector<std::pair<const char*, const char*>> pool_lines;
 };
 
 struct Line {
@@ -321,6 +331,9 @@ struct wk_tok {
     std::vector<uint64_t> qname;
     int32_t reported = 0;  // subjects already handed to the caller
     bool in_header = false; // still inside the leading '@' lines of a file
+    // state of parse_sam_file_ex_ft's variables after the text seen so far (see Local)
+    bool tail_keep = true;
+    std::string tail_this, tail_lines;
     // stratification of the current sample: read id -> stratum (file.read_map_uniq
     // + workflow.read_strata, file.py:368-385, workflow.py:912-938)
     // (sharded by the top hash bits so that a map of tens of millions of reads is
@@ -349,6 +362,7 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
                     bool want_groups, bool want_samples, Local& out) {
     const bool extra = (extra_bits & 1) != 0, keep_empty = (extra_bits & 2) != 0;
     const bool filt = T->exclude.size() > 0;
+    const bool track_pool = extra && filt && fmt == WK_FMT_SAM;
     static const char* const kSuffix[3] = {"", "/1", "/2"};
     std::string keybuf;
     // current run state
@@ -422,11 +436,13 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
             return;
         }
         if (fmt == WK_FMT_SAM && is_unmapped(L)) continue;
+        bool run_start = false;
         if (!(cur && L.qn == cur_n && memcmp(L.q, cur, cur_n) == 0)) {
             flush();
             cur = L.q;
             cur_n = L.qn;
             keep = true;
+            run_start = true;
         } else if (!keep) {
             continue;
         }
@@ -434,6 +450,13 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
         if (filt && T->exclude.find(L.r, L.rn, hv) >= 0) {
             keep = false;
             continue;
+        }
+        if (track_pool) {
+            if (run_start) {  // `pool = ([], [], [])` (align.py:526)
+                out.pool_lines.clear();
+                out.have_pool = true;
+            }
+            out.pool_lines.emplace_back(line, le);
         }
         const int mate = fmt == WK_FMT_SAM ? (L.flag >> 6) & 3 : 0;
         if (mate == 3) {
@@ -470,6 +493,12 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
             rc.len = L.len;
         }
         pool[mate].push_back(rc);
+    }
+    if (track_pool && cur) {
+        out.any_run = true;
+        out.fin_keep = keep;
+        out.fin_q = cur;
+        out.fin_qn = cur_n;
     }
     flush();
 }
@@ -526,6 +555,39 @@ void wk_tok_destroy(wk_tok* t) { delete t; }
 
 const char* wk_tok_last_error(const wk_tok* t) { return t ? t->err.c_str() : "null tokenizer"; }
 
+int wk_tok_sam_tail(wk_tok* t, char* buf, int64_t cap, int64_t* len) {
+    if (!t || !len || cap < 0 || (cap > 0 && !buf)) return WK_E_ARG;
+    // parse_sam_file_ex_ft's last three statements yield `pool` under the last
+    // query's name without looking at `keep` (align.py:542-547): when the last
+    // query of the file was dropped, that is one more yield — of whatever the
+    // pool still holds.  The text returned here makes the tokenizer produce
+    // exactly those reads: the pool's lines with the last query's name.
+    std::string text;
+    if (!t->tail_keep) {
+        const char* p = t->tail_lines.data();
+        const char* e = p + t->tail_lines.size();
+        while (p < e) {
+            const char* nl = (const char*)memchr(p, '\n', e - p);
+            const char* le = nl ? nl : e;
+            const char* tab = (const char*)memchr(p, '\t', le - p);
+            if (tab) {
+                text += t->tail_this;
+                text.append(tab, le);
+                text.push_back('\n');
+            }
+            p = nl ? nl + 1 : e;
+        }
+    }
+    *len = (int64_t)text.size();
+    if ((int64_t)text.size() > cap) {
+        if (cap == 0) return WK_OK;  // size query
+        t->err = "buffer too small for the tail text";
+        return WK_E_CAPACITY;
+    }
+    if (!text.empty()) memcpy(buf, text.data(), text.size());
+    return WK_OK;
+}
+
 int wk_tok_set_exclude(wk_tok* t, const char* blob, const int32_t* off, int32_t n) {
     if (!t || n < 0 || (n > 0 && (!blob || !off))) return WK_E_ARG;
     t->exclude = NameTable();
@@ -575,7 +637,12 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
     const char* b = buf;
     const char* e = buf + len;
     // header: leading '@' lines (align.py:295-300); it may span several blocks
-    if (first_block) t->in_header = fmt == WK_FMT_SAM;
+    if (first_block) {
+        t->in_header = fmt == WK_FMT_SAM;
+        t->tail_keep = true;
+        t->tail_this.clear();
+        t->tail_lines.clear();
+    }
     while (t->in_header && b < e) {
         if (*b != '@') {
             t->in_header = false;
@@ -669,6 +736,18 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
             t->err = msg;
             return loc[i].error == 1 ? WK_E_RANGE : WK_E_ARG;
         }
+    for (int i = 0; i < T; ++i) {  // (ranges in text order)
+        if (!loc[i].any_run) continue;
+        t->tail_keep = loc[i].fin_keep;
+        t->tail_this.assign(loc[i].fin_q, loc[i].fin_qn);
+        if (loc[i].have_pool) {
+            t->tail_lines.clear();
+            for (const auto& ln : loc[i].pool_lines) {
+                t->tail_lines.append(ln.first, ln.second);
+                t->tail_lines.push_back('\n');
+            }
+        }
+    }
     // merge fresh names in thread order (= order of first appearance in the text)
     std::vector<std::vector<int32_t>> remap(T);
     for (int i = 0; i < T; ++i) {

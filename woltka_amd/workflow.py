@@ -167,16 +167,18 @@ def classify(
     csample, strata = False, None
     try:
         # SAM, BLAST tabular, PAF and simple map input go through the native
-        # multi-threaded tokenizer; the "extra + exclude" flavour (the
-        # reference's SAM parser for it has a quirk reproduced only by the
-        # Python one) and anything else use the Python parsers.  Query names
-        # are materialised only when something needs them.
+        # multi-threaded tokenizer (every flavour: plain / "extra", with or
+        # without an exclusion set — the reference's SAM parser for
+        # "extra + exclude" yields its pool once more at the end of a file
+        # whose last query was dropped, align.py:542-547: the tokenizer tracks
+        # that pool, align._tail_block); anything else uses the Python
+        # parsers.  Query names are materialised only when something needs
+        # them.
         if cover is not None and ordinal:
             raise ValueError('Subject coverage (--outcov) needs subject-level '
                              'alignments; it cannot be combined with --coords.')
         native_ok = (mapper is plain_mapper or mapper is range_mapper or
-                     ordinal) and not ((ordinal or cover is not None) and
-                                       exclude)
+                     ordinal)
         # stratification without demultiplexing is joined natively (read id ->
         # stratum inside the tokenizer)
         native_strata = bool(stratmap) and not demux
