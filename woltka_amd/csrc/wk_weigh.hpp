@@ -65,34 +65,50 @@ __global__ void __launch_bounds__(256) mark_reads_kernel(const int32_t* __restri
                                                          unsigned char* __restrict__ mark,
                                                          unsigned long long* __restrict__ left_mask,
                                                          unsigned long long* __restrict__ totals) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = r < n_reads;
-    uint32_t s = 0, n = 0;
-    if (in) {
-        s = (uint32_t)qoff[r];
-        n = (uint32_t)qoff[r + 1] - s;
-    }
-    // not covered: more than 16 candidates (1/k is not a multiple of 1/L), or —
-    // kCheck: some subject of the table has the bit — a candidate without an
-    // ancestor at one of the ranks (None entries change k, classify.py:167-168)
-    bool skip = n > (uint32_t)WK_WEIGHT_MAX_K;
-    if constexpr (kCheck) {
-        if (!skip)
-            for (uint32_t j = 0; j < n; ++j) {
-                const uint32_t c = (uint32_t)subj[s + j];
-                if (c < n_subjects) skip |= (invalid[c >> 5] >> (c & 31u)) & 1u;
-            }
-    }
-    const unsigned long long left = __ballot(in & skip);
+    // (persistent grid: the totals are summed in registers and cost one pair of
+    // device atomics per workgroup — a pair per wave, 1.5 M atomics on two
+    // addresses at 50 M reads, used to be 18 of this kernel's 19 ms)
+    unsigned long long rd = 0, rc = 0;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    if (lane == 0 && in) left_mask[r >> 6] = left;
-    if (n > 0u) mark[s] = skip ? (unsigned char)0xFF : (unsigned char)n;
-    // reads and records the histogram covers (statistics of the classify calls)
-    unsigned long long rd = wave_sum((in & !skip & (n > 0u)) ? 1ull : 0ull);
-    unsigned long long rc = wave_sum((in & !skip) ? (unsigned long long)n : 0ull);
+    const uint32_t n_round = (n_reads + 63u) & ~63u;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_round; r += gridDim.x * blockDim.x) {
+        const bool in = r < n_reads;
+        uint32_t s = 0, n = 0;
+        if (in) {
+            s = (uint32_t)qoff[r];
+            n = (uint32_t)qoff[r + 1] - s;
+        }
+        // not covered: more than 16 candidates (1/k is not a multiple of 1/L), or —
+        // kCheck: some subject of the table has the bit — a candidate without an
+        // ancestor at one of the ranks (None entries change k, classify.py:167-168)
+        bool skip = n > (uint32_t)WK_WEIGHT_MAX_K;
+        if constexpr (kCheck) {
+            if (!skip)
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint32_t c = (uint32_t)subj[s + j];
+                    if (c < n_subjects) skip |= (invalid[c >> 5] >> (c & 31u)) & 1u;
+                }
+        }
+        const unsigned long long left = __ballot(in & skip);
+        if (lane == 0 && in) left_mask[r >> 6] = left;
+        if (n > 0u) mark[s] = skip ? (unsigned char)0xFF : (unsigned char)n;
+        // reads and records the histogram covers (statistics of the classify calls)
+        rd += (in & !skip & (n > 0u)) ? 1ull : 0ull;
+        rc += (in & !skip) ? (unsigned long long)n : 0ull;
+    }
+    __shared__ unsigned long long acc[2];
+    if (threadIdx.x == 0) acc[0] = acc[1] = 0ull;
+    __syncthreads();
+    rd = wave_sum(rd);
+    rc = wave_sum(rc);
     if (lane == 0 && (rd | rc)) {
-        atomicAdd(&totals[0], rd);
-        atomicAdd(&totals[1], rc);
+        atomicAdd(&acc[0], rd);
+        atomicAdd(&acc[1], rc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && (acc[0] | acc[1])) {
+        atomicAdd(&totals[0], acc[0]);
+        atomicAdd(&totals[1], acc[1]);
     }
 }
 
@@ -116,19 +132,26 @@ __global__ void __launch_bounds__(1024) spread_sizes_kernel(const unsigned char*
     __syncthreads();
     const uint32_t x0 = threadIdx.x * 4u;
     if (base + x0 >= n_records) return;
+    // the 20 marks m[x0 .. x0 + 19] = positions x0 - 16 .. x0 + 3 as five words;
+    // one bit per mark that is set
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(m) + threadIdx.x;
+    uint32_t nz = 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 5u; ++q) {
+        const uint32_t w = mw[q];
+        const uint32_t hi = (((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;  // bit 7 of every non-zero byte
+        nz |= (((hi >> 7) & 1u) | ((hi >> 14) & 2u) | ((hi >> 21) & 4u) | ((hi >> 28) & 8u)) << (4u * q);
+    }
     uint32_t out = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t x = x0 + k;
+        const uint32_t p = 16u + k;                      // this record's place in the window
+        const uint32_t at = nz & ((2u << p) - 1u);       // marks at or before it
         uint32_t size = 0u;
-        if (base + x < n_records) {
-            for (uint32_t d = 0; d < 16u; ++d) {
-                const uint32_t v = m[16u + x - d];
-                if (v) {
-                    size = (v != 0xFFu && d < v) ? v : 0u;  // (d < v: still inside that read)
-                    break;
-                }
-            }
+        if (at && base + x0 + k < n_records) {
+            const uint32_t h = 31u - (uint32_t)__clz((int)at);  // the nearest one
+            const uint32_t d = p - h, v = m[x0 + h];
+            size = (d < 16u && v != 0xFFu && d < v) ? v : 0u;    // (d < v: still inside that read)
         }
         out |= size << (8u * k);
     }

@@ -292,7 +292,7 @@ static int derive_read_sizes(wk_ctx* c, bool check, const int32_t* qoff, const i
     HIP_TRY(c, c->rk_mark.reserve((size_t)n_rec + 64));
     HIP_TRY(c, hipMemsetAsync(c->rk_mark.p, 0, (size_t)n_rec + 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(totals, 0, 16, c->stream));
-    const dim3 grid((unsigned)((n_reads + 255) / 256));
+    const dim3 grid((unsigned)std::min<int64_t>((n_reads + 255) / 256, (int64_t)c->prop.multiProcessorCount * 8));
     if (check)
         hipLaunchKernelGGL(mark_reads_kernel<true>, grid, dim3(256), 0, c->stream, qoff, (uint32_t)n_reads, subj,
                            c->w_invalid.as<uint32_t>(), (uint32_t)c->n_subjects, c->rk_mark.as<unsigned char>(), left, totals);
