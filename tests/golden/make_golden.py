@@ -780,7 +780,16 @@ def gen_cli_random(seed=47, n_cases=56):
     dump('cli_random.json', cases)
 
 
-def gen_cli_coords(seed=53, n_cases=18):
+def gen_cli_coords_excl(seed=59, n_cases=16):
+    """`--coords` together with `--exclude`: the "extra + exclude" parsers
+    (align.py:481-547, 919-981, 1152-1213), with files whose last query names an
+    excluded subject at its first record or half way — the case in which
+    parse_sam_file_ex_ft yields its pool once more (align.py:542-547)."""
+    gen_cli_coords(seed, n_cases, with_exclude=True, name='cli_coords_excl.json')
+
+
+def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
+                   name='cli_coords.json'):
     """Coord-match (`--coords`) on random small inputs: reads placed over /
     next to genes of the bundled coordinates file, three formats with
     coordinates, random overlap thresholds, optional gene-length normalisation
@@ -833,7 +842,29 @@ def gen_cli_coords(seed=53, n_cases=18):
                         lines.append(f'{q}\t{ln}\t0\t{ln}\t+\t{s}\t9999999\t'
                                      f'{pos - 1}\t{pos - 1 + ln}\t{ln}\t{ln}\t'
                                      f'60\n')
+            if with_exclude:
+                # a tail of queries on an excluded subject (`subjects[0]`): from
+                # their first record, or after a record elsewhere
+                for ti in range(rng.randint(0, 3)):
+                    q = f't{ti:04d}'
+                    first_kept = rng.random() < 0.5
+                    for s in ([subjects[1]] if first_kept else []) + \
+                            [subjects[0], subjects[2]]:
+                        gs, ge = rng.choice(genes[s])
+                        pos = max(1, gs + rng.randint(-50, ge - gs))
+                        if fmt == 'sam':
+                            lines.append(f'{q}\t{rng.choice([0, 99, 147])}\t{s}\t'
+                                         f'{pos}\t255\t100M\t=\t0\t0\t*\t*\n')
+                        elif fmt == 'b6o':
+                            lines.append(f'{q}\t{s}\t99.0\t100\t0\t0\t1\t100\t'
+                                         f'{pos}\t{pos + 99}\t1e-9\t200\n')
+                        else:
+                            lines.append(f'{q}\t100\t0\t100\t+\t{s}\t9999999\t'
+                                         f'{pos - 1}\t{pos + 99}\t100\t100\t60\n')
             files[f'aln/S{si + 1}.{ext[fmt]}'] = ''.join(lines)
+        if with_exclude:
+            kw['exclude'] = ','.join(subjects[:1] + rng.sample(subjects[3:], 1)
+                                     if len(subjects) > 3 else subjects[:1])
         kw['input_fp'] = 'aln'
         kw['overlap'] = rng.choice([50, 80, 80, 100])
         r = rng.random()
@@ -882,7 +913,7 @@ def gen_cli_coords(seed=53, n_cases=18):
                     outs = {'out': f.read()}
         cases.append(dict(files=files, kwargs=kw, want_maps=False,
                           expect={'tables': outs}))
-    dump('cli_coords.json', cases)
+    dump(name, cases)
 
 
 MEDIUM = [
@@ -1410,6 +1441,7 @@ def main():
     gen_coverage()
     gen_cli_random()
     gen_cli_coords()
+    gen_cli_coords_excl()
     gen_cli_strata()
     gen_cli_config5()
     gen_cli_medium()

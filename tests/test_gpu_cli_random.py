@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 _BIG = 'big_' if os.environ.get('WOLTKA_BIG_SWEEP') else ''    # one-off sweeps
 CASES = load_vectors(_BIG + 'cli_random.json') + \
-    load_vectors(_BIG + 'cli_coords.json')
+    load_vectors(_BIG + 'cli_coords.json') + \
+    ([] if _BIG else load_vectors('cli_coords_excl.json'))
 TAX = join(DATA, 'taxonomy')
 FUN = join(DATA, 'function')
 
