@@ -676,16 +676,22 @@ def timed_steps(wl, steps, warmup, passes, sync):
     return sync.allmax(elapsed)
 
 
-def kernel_times(wl, n=10):
+def kernel_times(wl, n=6, burst=8):
     """HIP events around each launch on the library's stream (first context),
-    averaged over a separate loop of launches."""
+    averaged over a separate loop of launches.  The brackets that are read are
+    those of the last step of a burst of back-to-back steps: with the stream
+    kept busy an event pair encloses the kernel alone — read after a single
+    step from an idle stream it also encloses the host's way from the first
+    event to the launch (weigh_bins: 361 us against the 320 us rocprofv3
+    reports for the same launches)."""
     ctx = wl.ctx
     ctx.profile_kernels(True)
     families = getattr(wl, 'families', (wl.dominant,))
     durs = {f: [] for f in families}
     step = getattr(wl, 'profile_step', wl.step)
     for _ in range(n):
-        step()
+        for _ in range(burst):
+            step()
         for f in families:
             try:
                 durs[f].append(ctx.last_kernel_ms(f))

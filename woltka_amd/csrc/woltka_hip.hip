@@ -1122,6 +1122,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 ba.err = scalar_err(c);
                 const dim3 wgrid((unsigned)c->prop.multiProcessorCount);
                 const size_t wlds = ((size_t)w_bins + 96) * 4;
+                kt = ktimer_begin(c, "classify");  // (again: the bracket starts at the launch, not at the host's decisions above)
                 if (c->bins_ring == 6)
                     hipLaunchKernelGGL((weigh_bins_kernel<6>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
                 else if (c->bins_ring == 8)
