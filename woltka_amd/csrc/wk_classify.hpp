@@ -84,6 +84,15 @@ struct ClassifyArgs {
     unsigned long long* log_cursor;
     int64_t log_cap;
     uint32_t ablate;  // measurement builds only (-DWK_ABLATE): 1 = drop counts, 2 = skip flush
+    // `--rank free` over subject rows without a walk up the tree: row column
+    // free_col holds the subject's rank among the subjects of the tree (by
+    // pre-order id), free_sparse[k * free_m + i] = the shallowest (= smallest id:
+    // they are ancestors of one subject, hence comparable) of the LCAs of the
+    // rank-adjacent subject pairs i .. i + 2^k - 1.  LCA(set) = LCA(smallest,
+    // largest rank) = min of two entries.  Null: walk (lca_of_range).
+    const int32_t* free_sparse;
+    int32_t free_m;
+    int32_t free_col;
     // second pass (classify_kernel after classify_single_kernel): merges the
     // first pass's slab (first_*), compacts its workgroup's share of left_mask
     // into read_list[blockIdx.x * list_seg ...] and walks that list
@@ -131,6 +140,11 @@ __global__ void __launch_bounds__(256) rank_table_kernel(const Node* __restrict_
 struct RowCols {
     const int32_t* anc[WK_MAX_JOBS];
     int32_t n_cols;
+    // column `by_subject` (or -1) is not looked up by the subject's feature in a
+    // per-node table but copied from a per-subject array: the subject's rank
+    // among the subjects of the tree (free_rank, see ClassifyArgs::free_sparse)
+    int32_t by_subject;
+    const int32_t* subject_col;
 };
 __global__ void __launch_bounds__(256) subject_rows_kernel(const int32_t* __restrict__ feature_of_subject,
                                                            int32_t n_subjects, int32_t n_nodes, RowCols cols,
@@ -140,8 +154,12 @@ __global__ void __launch_bounds__(256) subject_rows_kernel(const int32_t* __rest
     const int32_t f = feature_of_subject[s];
     int32_t* row = rows + (int64_t)s * w;
     row[0] = f;
-    for (int32_t c = 0; c < w - 1; ++c)
-        row[1 + c] = (c < cols.n_cols && f >= 0 && f < n_nodes) ? cols.anc[c][f] : -1;
+    for (int32_t c = 0; c < w - 1; ++c) {
+        if (c == cols.by_subject)
+            row[1 + c] = cols.subject_col[s];
+        else
+            row[1 + c] = (c < cols.n_cols && f >= 0 && f < n_nodes) ? cols.anc[c][f] : -1;
+    }
 }
 
 // Lowest common ancestor of a set of hierarchy nodes given only the smallest
@@ -431,7 +449,19 @@ __device__ __forceinline__ void process_read(const ClassifyArgs& a, const LdsCac
                 else
                     res = (first < a.n_nodes) ? a.nodes[first].parent : WK_ASSIGN_NONE;
             } else if (smax < a.n_nodes) {
-                const int32_t u = lca_of_range(a.nodes, smin, smax);
+                int32_t u;
+                if (C::kHasCols && a.free_sparse) {
+                    JobDev by_rank = job;
+                    by_rank.col = a.free_col;
+                    const ColStats cs = rank_stats(cand, sc, by_rank, n);
+                    const uint32_t len = (uint32_t)(cs.tmax - cs.tmin);  // (> 0: the subjects differ)
+                    const uint32_t lv = 31u - (uint32_t)__clz((int)len);
+                    const int32_t x = a.free_sparse[(size_t)lv * a.free_m + cs.tmin];
+                    const int32_t y = a.free_sparse[(size_t)lv * a.free_m + cs.tmax - (1u << lv)];
+                    u = x < y ? x : y;
+                } else {
+                    u = lca_of_range(a.nodes, smin, smax);
+                }
                 res = (u == 0) ? WK_ASSIGN_NONE : u;
             }
         } else {

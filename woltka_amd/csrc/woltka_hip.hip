@@ -80,6 +80,14 @@ struct wk_ctx {
     bool rank_tab_valid[WK_MAX_JOBS * 4] = {};
     int64_t rank_tab_nodes[WK_MAX_JOBS * 4] = {};  // nodes that carry the slot's rank (distinct results a job can have)
     std::vector<int32_t> rank_code_host;           // host copy of the rank codes (for those counts)
+    // host copies of the tree and the subject table + what `--rank free` looks up
+    // instead of walking (ClassifyArgs::free_sparse): subjects ranked by pre-order
+    // id, LCAs of rank-adjacent subjects as a sparse table; rebuilt when either changes
+    std::vector<int32_t> parent_host, last_host, subj_feat_host;
+    int tree_serial = 0, subj_serial = 0, free_tree = -1, free_subj = -1;
+    DevBuf f_rank, f_sparse;
+    uint32_t f_m = 0;
+    int use_free_sparse = 1;
     int log_parts_opt = 0;                         // 0 = auto, else 256 / 1024
 
     // compact subject table (optional)
@@ -284,6 +292,43 @@ __global__ void __launch_bounds__(256) table_compact_kernel(const unsigned long 
 
 }  // namespace
 
+// Tables behind ClassifyArgs::free_sparse for the current tree and subject
+// table (host side: 100 k subjects x ~17 levels).
+static int ensure_free_tables(wk_ctx* c) {
+    if (c->free_tree == c->tree_serial && c->free_subj == c->subj_serial) return WK_OK;
+    const int32_t n = c->n_subjects, n_nodes = c->n_nodes;
+    const std::vector<int32_t>& feat = c->subj_feat_host;
+    std::vector<int32_t> order;
+    order.reserve((size_t)n);
+    for (int32_t s = 0; s < n; ++s)
+        if (feat[s] < n_nodes) order.push_back(s);
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return feat[x] < feat[y] || (feat[x] == feat[y] && x < y); });
+    const uint32_t m = (uint32_t)order.size();
+    std::vector<int32_t> rank((size_t)std::max(n, 1), -1);
+    for (uint32_t i = 0; i < m; ++i) rank[order[i]] = (int32_t)i;
+    uint32_t levels = 1;
+    while (m > 1 && (2u << (levels - 1)) <= m - 1) levels += 1;  // the longest range of pairs has m - 1 of them
+    const size_t row = std::max<uint32_t>(m, 1u);
+    std::vector<int32_t> sparse(row * levels, 0x7FFFFFFF);
+    for (uint32_t i = 0; i + 1 < m; ++i) {  // LCA of neighbours: the lowest ancestor of the first whose subtree holds the second
+        int32_t u = feat[order[i]];
+        const int32_t hi = feat[order[i + 1]];
+        while (c->last_host[u] < hi) u = c->parent_host[u];
+        sparse[i] = u;
+    }
+    for (uint32_t k = 1; k < levels; ++k)
+        for (uint32_t i = 0; i + (1u << k) <= m - 1; ++i)
+            sparse[k * row + i] = std::min(sparse[(k - 1) * row + i], sparse[(k - 1) * row + i + (1u << (k - 1))]);
+    int rc;
+    if ((rc = upload(c, c->f_rank, rank.data(), rank.size() * 4))) return rc;
+    if ((rc = upload(c, c->f_sparse, sparse.data(), sparse.size() * 4))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors are about to go out of scope
+    c->f_m = (uint32_t)row;
+    c->free_tree = c->tree_serial;
+    c->free_subj = c->subj_serial;
+    return WK_OK;
+}
+
 // Read size per record of the staged chunk (wk_weigh.hpp): marks at the read
 // starts, then spread over the records.  `check`: leave out reads that name a
 // subject with its validity bit set.
@@ -411,7 +456,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->rk_mark, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->rk_mark, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
@@ -456,6 +501,11 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     }
     if (!strcmp(name, "ablate")) {
         c->ablate = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "free_sparse")) {  // 0: `--rank free` walks up the tree per read
+        c->use_free_sparse = (int)value;
+        c->rows_sig.clear();
         return WK_OK;
     }
     if (!strcmp(name, "tally_per_cu")) {
@@ -559,6 +609,9 @@ int wk_set_tree(wk_ctx* c, const int32_t* parent, const int32_t* last, const int
     if ((rc = upload(c, c->rank_code, rank_code, (size_t)n * sizeof(int32_t)))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // `packed` is about to go out of scope
     c->rank_code_host.assign(rank_code, rank_code + n);
+    c->parent_host.assign(parent, parent + n);
+    c->last_host.assign(last, last + n);
+    c->tree_serial += 1;
     c->n_nodes = n;
     c->rows_sig.clear();
     for (bool& v : c->rank_tab_valid) v = false;
@@ -672,6 +725,8 @@ int wk_set_subjects(wk_ctx* c, const int32_t* feature_of_subject, int32_t n) {
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_subjects = n;
+    c->subj_feat_host.assign(feature_of_subject, feature_of_subject + n);
+    c->subj_serial += 1;
     c->rows_sig.clear();  // rows are rebuilt on the next classify call
     return WK_OK;
 }
@@ -872,6 +927,26 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 cols.anc[col] = c->rank_tab[jobs[j].rank_slot].as<int32_t>();
             }
             a.jobs[j].col = col;
+        }
+        // `--rank free`: one more column with the subject's rank among the
+        // subjects of the tree, when it fits the 4-column row
+        bool any_free = false;
+        for (int j = 0; j < n_jobs; ++j) any_free |= jobs[j].mode == WK_MODE_FREE;
+        cols.by_subject = -1;
+        int free_col = -1;
+        if (any_free && c->use_free_sparse && cols.n_cols < 3 && c->n_subjects > 0 && c->n_nodes > 0) {
+            int rc2 = ensure_free_tables(c);
+            if (rc2) return rc2;
+            free_col = cols.n_cols++;
+            sig.push_back(-2);
+            sig.push_back(c->free_tree);
+            sig.push_back(c->free_subj);
+            cols.anc[free_col] = nullptr;
+            cols.by_subject = free_col;
+            cols.subject_col = c->f_rank.as<int32_t>();
+            a.free_sparse = c->f_sparse.as<int32_t>();
+            a.free_m = (int32_t)c->f_m;
+            a.free_col = free_col;
         }
         int w = 4;  // {feature, <= 3 rank columns}: the kernel's single-pass fast path
         while (w < 1 + cols.n_cols) w <<= 1;
