@@ -147,7 +147,9 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * straight from the matches), "tally_slots" / "tally_per_cu" (LDS cache slots
  * and workgroups per CU of that kernel), "grid_density" (1..8 grid cells per
  * gene; takes effect at the next wk_set_genes), "match_lds" (0/1: per-genome
- * words of the coordinate grid in LDS).
+ * words of the coordinate grid in LDS), "free_sparse" (0/1: `--rank free` on
+ * chunks of subject indices looks the LCA up in a sparse table over the
+ * subjects instead of walking up the tree).
  * Results never depend on them. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 
