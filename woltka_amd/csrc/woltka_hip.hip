@@ -934,7 +934,8 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
         for (int j = 0; j < n_jobs; ++j) any_free |= jobs[j].mode == WK_MODE_FREE;
         cols.by_subject = -1;
         int free_col = -1;
-        if (any_free && c->use_free_sparse && cols.n_cols < 3 && c->n_subjects > 0 && c->n_nodes > 0) {
+        // (the table has n log n entries: subject tables beyond 4 M keep the walk)
+        if (any_free && c->use_free_sparse && cols.n_cols < 3 && c->n_subjects > 0 && c->n_subjects <= (1 << 22) && c->n_nodes > 0) {
             int rc2 = ensure_free_tables(c);
             if (rc2) return rc2;
             free_col = cols.n_cols++;
