@@ -175,9 +175,12 @@ constexpr uint32_t kBinsMaxLds = 160 * 1024 - 1024;
 template <int kRing = 4>
 __global__ void __launch_bounds__(kWeighThreads) weigh_bins_kernel(BinsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* bins = reinterpret_cast<uint32_t*>(smem);  // [a.bins] + 64 idle bins + 32 weights
-    uint32_t* idle = bins + a.bins;                      // adds of 0 by lanes without a record of this slice
-    uint32_t* lut = idle + 64;                           // lut[k] = L / k, lut[0] = 0
+    // LDS: 32 weights (lut[k] = L / k, lut[0] = 0) in static LDS — their
+    // address is a constant of the instruction, no base register to add —,
+    // the bins, 64 idle bins behind them for the lanes without a record of
+    // this slice
+    __shared__ uint32_t lut[32];
+    uint32_t* bins = reinterpret_cast<uint32_t*>(smem);
 
     const uint32_t xcd = blockIdx.x % a.n_xcd, m = blockIdx.x / a.n_xcd;
     if (m >= a.teams_per_xcd * a.n_slices) return;  // no whole team left on this XCD
@@ -216,6 +219,7 @@ __global__ void __launch_bounds__(kWeighThreads) weigh_bins_kernel(BinsArgs a) {
     auto add = [&](const Stage& x) {
         const uint32_t c[4] = {(uint32_t)x.c.x, (uint32_t)x.c.y, (uint32_t)x.c.z, (uint32_t)x.c.w};
         uint32_t w[4], at[4], old[4];
+        bool in[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = lut[(x.k4 >> (8 * j)) & 31u];
 #pragma unroll
@@ -223,22 +227,23 @@ __global__ void __launch_bounds__(kWeighThreads) weigh_bins_kernel(BinsArgs a) {
             const uint32_t idx = c[j] - lo;
             const bool mine = idx < span;
             if (last_slice) outside |= (w[j] != 0u) & (c[j] >= a.n_subjects);
-            // a lane without a record of this slice adds 0 to a bin of its own:
-            // every lane takes part in every add, so the number of LDS
-            // operations in flight is known to hipcc and it waits for the oldest
-            // ones only, instead of draining the LDS queue at every use
+            // a lane without a record of this slice adds to an idle bin of its
+            // own (what piles up there is never read): every lane takes part in
+            // every add, so the number of LDS operations in flight is known to
+            // hipcc and it waits for the oldest ones only, instead of draining
+            // the LDS queue at every use
             at[j] = mine ? idx : idle_addr;
-            w[j] = mine ? w[j] : 0u;
+            in[j] = mine;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) old[j] = atomicAdd(&bins[at[j]], w[j]);
         bool wrapped = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wrapped |= old[j] + w[j] < old[j];
+        for (int j = 0; j < 4; ++j) wrapped |= in[j] & (old[j] + w[j] < old[j]);
         if (wrapped) {  // rare: a 32-bit bin passed 2^32
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (old[j] + w[j] < old[j]) atomicAdd(&a.hi[c[j]], 1u);
+                if (in[j] & (old[j] + w[j] < old[j])) atomicAdd(&a.hi[c[j]], 1u);
         }
     };
 
