@@ -158,3 +158,38 @@ def test_weigh_auto_equals_generic(ctx):
         tables.append(ctx.counts_fetch())
     ctx.set_option('weigh', 1)
     assert_same_counts(*tables[0], *tables[1])
+
+
+def test_weigh_reads_longer_than_a_tile_image(ctx):
+    """Runs of 4,000-record reads in the middle of tiles of 1024 reads:
+    read_sizes_kernel's LDS image of a tile (16 KiB of records) is too short,
+    the reads behind the long ones write their sizes straight to HBM; with and
+    without subjects that lack a rank (the checking variant)."""
+    rng = np.random.default_rng(31)
+    prob = synth.lca_problem(rng, n_nodes=120000, n_subjects=30000,
+                             n_reads=150000)
+    prob = _as_sets(prob, rng)
+    qoff = prob['qoff'].astype(np.int64)
+    subj = prob['subj']
+    pool = np.unique(subj)
+    parts, sizes, at = [], [], 0
+    cuts = {1500: 4000, 1501: 4000, 1502: 3900, 1503: 4000, 1504: 4095, 1505: 17,
+            1506: 2, 70000: 3000, 70001: 4000, 70003: 16, 149998: 4000,
+            149999: 4000}
+    for r in range(qoff.size - 1):
+        if r in cuts:
+            parts.append(np.sort(rng.choice(pool, cuts[r], replace=False)))
+        else:
+            parts.append(subj[qoff[r]:qoff[r + 1]])
+        sizes.append(parts[-1].size)
+    q = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=q[1:])
+    prob = dict(prob, subj=np.concatenate(parts).astype(np.int32),
+                qoff=q.astype(np.int32))
+    h = prob['hier']
+    _run(ctx, prob, _plain_specs(h)[:2])
+    upper = np.flatnonzero(h.rank_code == h.rank_codes['family'])
+    hit = rng.random(prob['subj'].size) < 0.05
+    s2 = prob['subj'].copy()
+    s2[hit] = upper[rng.integers(0, upper.size, int(hit.sum()))]
+    _run(ctx, _as_sets(dict(prob, subj=s2), rng), _plain_specs(h))

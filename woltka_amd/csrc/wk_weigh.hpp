@@ -46,8 +46,8 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 // ---- records that carry their read's size --------------------------------------
 // What a record needs from its read is one number, the read's size k (its
-// weight is L/k).  It is derived once per staged chunk (mark_reads_kernel +
-// spread_sizes_kernel: one byte per record, 0 for the records of reads the
+// weight is L/k).  It is derived once per staged chunk (read_sizes_kernel:
+// one byte per record, 0 for the records of reads the
 // histogram does not cover; one bit per such read in a mask for the generic
 // pass; done by
 // wk_chunk_stage, and again by the first classify call when the subject table
@@ -55,25 +55,37 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 // offsets, no per-read logic, every lane busy — a 16-byte load of four subject
 // indices, a 4-byte load of their four sizes, a weight lookup and an LDS add
 // per record.
-// Step 1, one thread per read: the read's size goes to the position of its
-// first record in a zeroed byte array (0xFF = not covered), and one bit per
-// read not covered to the mask.
+// One thread per read, a workgroup per tile of kSizeTile consecutive reads:
+// the tile's records are one contiguous range, so every thread writes its
+// read's size into an LDS image of that range (zero for reads that are
+// not covered) and the workgroup stores the image with whole dwords — the
+// bytes of a dword shared with a neighbouring tile one by one.  Reads that do
+// not fit the image (a tile with very long reads) are written straight to HBM
+// by their thread.  One bit per read not covered goes to the mask.
+constexpr uint32_t kSizeTile = 1024;                              // reads per tile = threads per workgroup
+constexpr uint32_t kSizeImage = kSizeTile * WK_WEIGHT_MAX_K + 8;  // bytes of records a tile of covered reads can span (+ alignment)
 template <bool kCheck>
-__global__ void __launch_bounds__(256) mark_reads_kernel(const int32_t* __restrict__ qoff, uint32_t n_reads,
-                                                         const int32_t* __restrict__ subj,
-                                                         const uint32_t* __restrict__ invalid, uint32_t n_subjects,
-                                                         unsigned char* __restrict__ mark,
-                                                         unsigned long long* __restrict__ left_mask,
-                                                         unsigned long long* __restrict__ totals) {
-    // (persistent grid: the totals are summed in registers and cost one pair of
-    // device atomics per workgroup — a pair per wave, 1.5 M atomics on two
-    // addresses at 50 M reads, used to be 18 of this kernel's 19 ms)
+__global__ void __launch_bounds__(kSizeTile) read_sizes_kernel(const int32_t* __restrict__ qoff, uint32_t n_reads,
+                                                              const int32_t* __restrict__ subj,
+                                                              const uint32_t* __restrict__ invalid, uint32_t n_subjects,
+                                                              unsigned char* __restrict__ rk,
+                                                              unsigned long long* __restrict__ left_mask,
+                                                              unsigned long long* __restrict__ totals) {
+    __shared__ __attribute__((aligned(16))) unsigned char image[kSizeImage];
+    __shared__ unsigned long long acc[2];
+    if (threadIdx.x == 0) acc[0] = acc[1] = 0ull;
     unsigned long long rd = 0, rc = 0;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t n_round = (n_reads + 63u) & ~63u;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_round; r += gridDim.x * blockDim.x) {
-        const bool in = r < n_reads;
-        uint32_t s = 0, n = 0;
+    const uint32_t n_tiles = (n_reads + kSizeTile - 1) / kSizeTile;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t r0 = tile * kSizeTile, r1 = min(r0 + kSizeTile, n_reads);
+        const uint32_t g0 = (uint32_t)qoff[r0], g1 = (uint32_t)qoff[r1];  // the tile's records
+        const uint32_t shift = g0 & 3u;  // image[shift + i] <-> rk[g0 + i]: dwords of the image are dwords of rk
+        for (uint32_t i = threadIdx.x; i < kSizeImage / 4u; i += kSizeTile) reinterpret_cast<uint32_t*>(image)[i] = 0u;
+        __syncthreads();
+        const uint32_t r = r0 + threadIdx.x;
+        const bool in = r < r1;
+        uint32_t s = g0, n = 0;
         if (in) {
             s = (uint32_t)qoff[r];
             n = (uint32_t)qoff[r + 1] - s;
@@ -91,14 +103,37 @@ __global__ void __launch_bounds__(256) mark_reads_kernel(const int32_t* __restri
         }
         const unsigned long long left = __ballot(in & skip);
         if (lane == 0 && in) left_mask[r >> 6] = left;
-        if (n > 0u) mark[s] = skip ? (unsigned char)0xFF : (unsigned char)n;
+        const unsigned char size = skip ? (unsigned char)0 : (unsigned char)n;
+        const uint32_t at = shift + (s - g0);
+        if (at + n <= kSizeImage) {
+            if (size)
+                for (uint32_t j = 0; j < n; ++j) image[at + j] = size;
+        } else {  // (rare: a very long read, or a read behind one — what is past the image goes straight to HBM)
+            for (uint32_t j = 0; j < n; ++j) {
+                if (at + j < kSizeImage)
+                    image[at + j] = size;
+                else
+                    rk[s + j] = size;
+            }
+        }
         // reads and records the histogram covers (statistics of the classify calls)
         rd += (in & !skip & (n > 0u)) ? 1ull : 0ull;
         rc += (in & !skip) ? (unsigned long long)n : 0ull;
+        __syncthreads();
+        // image -> rk: dwords that lie inside [g0, g1) whole, the others byte by byte
+        const uint32_t span = min(g1 - g0, kSizeImage - shift);
+        const uint32_t first = g0 - shift;  // (a multiple of 4)
+        for (uint32_t i = threadIdx.x; 4u * i < shift + span; i += kSizeTile) {
+            const uint32_t lo = first + 4u * i;
+            if (lo >= g0 && lo + 4u <= g0 + span) {
+                *reinterpret_cast<uint32_t*>(rk + lo) = reinterpret_cast<const uint32_t*>(image)[i];
+            } else {
+                for (uint32_t b = 0; b < 4u; ++b)
+                    if (lo + b >= g0 && lo + b < g0 + span) rk[lo + b] = image[4u * i + b];
+            }
+        }
+        __syncthreads();
     }
-    __shared__ unsigned long long acc[2];
-    if (threadIdx.x == 0) acc[0] = acc[1] = 0ull;
-    __syncthreads();
     rd = wave_sum(rd);
     rc = wave_sum(rc);
     if (lane == 0 && (rd | rc)) {
@@ -110,52 +145,6 @@ __global__ void __launch_bounds__(256) mark_reads_kernel(const int32_t* __restri
         atomicAdd(&totals[0], acc[0]);
         atomicAdd(&totals[1], acc[1]);
     }
-}
-
-// Step 2, one thread per four records: a record's read starts at the nearest
-// mark at or before it — at most 15 positions back for a read of <= 16 records;
-// no mark within reach, or the mark 0xFF: not covered (size 0).  A workgroup
-// stages its marks (and the 16 before them) in LDS and writes the sizes as
-// whole dwords.
-constexpr uint32_t kSpreadTile = 4096;
-__global__ void __launch_bounds__(1024) spread_sizes_kernel(const unsigned char* __restrict__ mark,
-                                                            uint32_t n_records, unsigned char* __restrict__ rk) {
-    __shared__ __attribute__((aligned(16))) unsigned char m[16 + kSpreadTile];
-    const uint32_t base = blockIdx.x * kSpreadTile;
-    // marks [base - 16, base + tile) -> m[0, 16 + tile)
-    for (uint32_t i = threadIdx.x; i < (16u + kSpreadTile) / 4u; i += blockDim.x) {
-        const int64_t at = (int64_t)base - 16 + 4 * (int64_t)i;  // (base is a multiple of 4: aligned dwords)
-        uint32_t v = 0u;
-        if (at >= 0 && at < (int64_t)n_records) v = *reinterpret_cast<const uint32_t*>(mark + at);
-        reinterpret_cast<uint32_t*>(m)[i] = v;
-    }
-    __syncthreads();
-    const uint32_t x0 = threadIdx.x * 4u;
-    if (base + x0 >= n_records) return;
-    // the 20 marks m[x0 .. x0 + 19] = positions x0 - 16 .. x0 + 3 as five words;
-    // one bit per mark that is set
-    const uint32_t* mw = reinterpret_cast<const uint32_t*>(m) + threadIdx.x;
-    uint32_t nz = 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < 5u; ++q) {
-        const uint32_t w = mw[q];
-        const uint32_t hi = (((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;  // bit 7 of every non-zero byte
-        nz |= (((hi >> 7) & 1u) | ((hi >> 14) & 2u) | ((hi >> 21) & 4u) | ((hi >> 28) & 8u)) << (4u * q);
-    }
-    uint32_t out = 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t p = 16u + k;                      // this record's place in the window
-        const uint32_t at = nz & ((2u << p) - 1u);       // marks at or before it
-        uint32_t size = 0u;
-        if (at && base + x0 + k < n_records) {
-            const uint32_t h = 31u - (uint32_t)__clz((int)at);  // the nearest one
-            const uint32_t d = p - h, v = m[x0 + h];
-            size = (d < 16u && v != 0xFFu && d < v) ? v : 0u;    // (d < v: still inside that read)
-        }
-        out |= size << (8u * k);
-    }
-    *reinterpret_cast<uint32_t*>(rk + base + x0) = out;
 }
 
 struct BinsArgs {

@@ -164,7 +164,7 @@ struct wk_ctx {
     // read size per record of the staged chunk + reads the histogram does not
     // cover + totals: [0] derived at staging, [1] derived again with the
     // validity bits of the current subject rows (when some subject has one set)
-    DevBuf c_rk[2], rk_left[2], rk_totals, rk_mark;
+    DevBuf c_rk[2], rk_left[2], rk_totals;
     bool rk_valid[2] = {false, false};
     int64_t rk_reads[2] = {0, 0}, rk_records[2] = {0, 0};
     int64_t stage_serial = 0, rows_serial = 0, rk1_stage = -1, rk1_rows = -1;
@@ -334,19 +334,16 @@ static int ensure_free_tables(wk_ctx* c) {
 // subject with its validity bit set.
 static int derive_read_sizes(wk_ctx* c, bool check, const int32_t* qoff, const int32_t* subj, int64_t n_reads, int64_t n_rec,
                              unsigned char* rk, unsigned long long* left, unsigned long long* totals) {
-    HIP_TRY(c, c->rk_mark.reserve((size_t)n_rec + 64));
-    HIP_TRY(c, hipMemsetAsync(c->rk_mark.p, 0, (size_t)n_rec + 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(totals, 0, 16, c->stream));
-    const dim3 grid((unsigned)std::min<int64_t>((n_reads + 255) / 256, (int64_t)c->prop.multiProcessorCount * 8));
+    HIP_TRY(c, hipMemsetAsync(rk + n_rec, 0, 8, c->stream));  // the sizes are read four at a time
+    const int64_t n_tiles = (n_reads + kSizeTile - 1) / kSizeTile;
+    const dim3 grid((unsigned)std::min<int64_t>(n_tiles, (int64_t)c->prop.multiProcessorCount * 2));
     if (check)
-        hipLaunchKernelGGL(mark_reads_kernel<true>, grid, dim3(256), 0, c->stream, qoff, (uint32_t)n_reads, subj,
-                           c->w_invalid.as<uint32_t>(), (uint32_t)c->n_subjects, c->rk_mark.as<unsigned char>(), left, totals);
+        hipLaunchKernelGGL(read_sizes_kernel<true>, grid, dim3(kSizeTile), 0, c->stream, qoff, (uint32_t)n_reads, subj,
+                           c->w_invalid.as<uint32_t>(), (uint32_t)c->n_subjects, rk, left, totals);
     else
-        hipLaunchKernelGGL(mark_reads_kernel<false>, grid, dim3(256), 0, c->stream, qoff, (uint32_t)n_reads, subj,
-                           (const uint32_t*)nullptr, 0u, c->rk_mark.as<unsigned char>(), left, totals);
-    if (n_rec > 0)
-        hipLaunchKernelGGL(spread_sizes_kernel, dim3((unsigned)((n_rec + kSpreadTile - 1) / kSpreadTile)), dim3(1024), 0, c->stream,
-                           c->rk_mark.as<unsigned char>(), (uint32_t)n_rec, rk);
+        hipLaunchKernelGGL(read_sizes_kernel<false>, grid, dim3(kSizeTile), 0, c->stream, qoff, (uint32_t)n_reads, subj,
+                           (const uint32_t*)nullptr, 0u, rk, left, totals);
     HIP_TRY(c, hipGetLastError());
     return WK_OK;
 }
@@ -456,7 +453,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->rk_mark, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
