@@ -43,9 +43,16 @@ def sam_of(prob, names, path):
                 f.write(f'R{r:07d}\t0\t{names[s]}\t1\t42\t50M\t*\t0\t0\t*\t*\n')
 
 
-@pytest.mark.parametrize('chunk', [None, 100])
+@pytest.mark.parametrize('chunk,block', [(None, None), (100, None),
+                                         (None, 1 << 16), (77, 1 << 15)])
 def test_replayed_sums_equal_the_reference_order_float_sums(tmp_path,
-                                                            monkeypatch, chunk):
+                                                            monkeypatch, chunk,
+                                                            block):
+    """`block`: bytes of text per device chunk — small ones cut the mapper's
+    chunks of `chunk` queries in the middle, their partial sums continue in
+    the next device chunk."""
+    if block:
+        monkeypatch.setattr(wf, 'NATIVE_BLOCK', block)
     rng = np.random.default_rng(77)
     prob = synth.as_sets(synth.lca_problem(rng, n_nodes=3000, n_subjects=300,
                                            n_reads=30000, max_hits=7))

@@ -10,6 +10,7 @@ owns one GPU context, the flattened hierarchy and one *job* per requested rank;
 Count keys carry a *group* = index of a (sample, stratum) pair, so one device
 table serves demultiplexed and stratified runs alike.
 """
+import os
 from fractions import Fraction
 from os.path import join
 
@@ -21,7 +22,7 @@ from .file import openzip, write_readmap
 from .hierarchy import FeatureIndex, flatten_hierarchy
 from .ordinal import pack_hits
 
-def _prefetch(gen, depth=2):
+def _prefetch(gen, depth=int(os.environ.get('WOLTKA_PREFETCH', 2))):
     """Run generator ``gen`` in a helper thread, ``depth`` items ahead: the
     native tokenizer (which releases the GIL) parses block i+1 while block i is
     staged and classified on the GPU."""
@@ -577,6 +578,7 @@ class Engine:
         """A new alignment file starts: the reference's mapper chunks count
         queries per file (align.plain_mapper, align.py:84-115)."""
         if self._replay is not None:
+            self._replay_close()
             self._replay['pos'] = 0
 
     def uncertified(self, digits=None, factor=None, chunk_n=1024):
@@ -604,18 +606,28 @@ class Engine:
         the `targets` cells ({rank: {sample: keys}}) in read order, `chunk_n`
         queries per partial sum (classify.counter + util.sum_dict)."""
         self._replay = dict(targets=targets, chunk_n=int(chunk_n), pos=0,
-                            total={})
+                            total={}, open={})
         self._gmap_key = self._smap_key = None
 
     def replay_end(self):
         """{(rank, sample, key): value as the reference holds it before
         rounding}; leaves replay mode and drops the counts of the pass."""
+        self._replay_close()
         res = self._replay['total']
         self._replay = None
         self.ctx.counts_clear()
         self.groups, self.group_ids = [], {}
         self._epoch += 1
         return res
+
+    def _replay_close(self):
+        """The mapper chunks in progress end (a file ends): their partial sums
+        go into the running totals (util.sum_dict, util.py:92-94)."""
+        rp = self._replay
+        total = rp['total']
+        for cell, (_, part) in rp['open'].items():
+            total[cell] = total.get(cell, 0) + part
+        rp['open'] = {}
 
     def _replay_chunk(self, assign, subj, qoff, group, n):
         rp = self._replay
@@ -699,13 +711,23 @@ class Engine:
             seg = np.flatnonzero(np.concatenate((
                 [True], (t[1:] != t[:-1]) | (chunk_id[1:] != chunk_id[:-1]))))
             ends = np.concatenate((seg[1:], [r.size]))
-            total = rp['total']
+            total, open_ = rp['total'], rp['open']
             for a, b in zip(seg.tolist(), ends.tolist()):
                 # the chunk's dict starts at int 0 and adds in read order;
-                # numpy's cumulative sum is that left-to-right binary64 sum
-                part = float(np.cumsum(v[a:b])[-1])
+                # numpy's cumulative sum is that left-to-right binary64 sum.
+                # A mapper chunk can continue in the next device chunk: its
+                # partial sum stays open until another mapper chunk (or file)
+                # begins, and only then goes into the running total
                 cell = cells[int(t[a])]
-                total[cell] = total.get(cell, 0) + part
+                cid = int(chunk_id[a])
+                held = open_.get(cell)
+                if held is not None and held[0] == cid:
+                    part = float(np.cumsum(np.concatenate(([held[1]], v[a:b])))[-1])
+                else:
+                    if held is not None:
+                        total[cell] = total.get(cell, 0) + held[1]
+                    part = float(np.cumsum(v[a:b])[-1])
+                open_[cell] = (cid, part)
 
     # ------------------------------------------------------------------
     def _n_batches(self):

@@ -14,6 +14,7 @@ There is no CPU fallback: ``classify()`` needs ``libwoltka_hip.so`` and a GPU.
 """
 import contextlib
 import io
+import os
 from functools import partial
 from itertools import chain
 from os import makedirs
@@ -36,7 +37,10 @@ from .tree import (fill_root, read_columns, read_lineage, read_names,
                    read_newick, read_nodes)
 
 DEVICE_CHUNK = 2 ** 20      # queries per device chunk unless --chunk is given
-NATIVE_BLOCK = 1 << 27      # bytes of SAM text per native tokenizer call
+# bytes of alignment text per native tokenizer call (= per staged chunk): 256 MiB
+# halves the per-block host work of 128 MiB (config 3 end to end: 217 -> 259 M
+# records/s while streaming); the environment variable is a measurement knob
+NATIVE_BLOCK = int(os.environ.get('WOLTKA_NATIVE_BLOCK', 1 << 28))
 
 
 class OrdinalMapper:
