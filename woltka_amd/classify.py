@@ -353,9 +353,8 @@ class Engine:
         names = table.feature_names(prefix)
         if trimsub:
             names = [x.rsplit(trimsub, 1)[0] for x in names]
-        intern = self.index.intern
-        self.gene_feature = np.fromiter((intern(x) for x in names),
-                                        dtype=np.int32, count=len(names))
+        self.gene_feature = np.asarray(self.index.intern_many(list(names)),
+                                       dtype=np.int32)
         self.genes = table
         self.ctx.set_genes(table.goff, table.start0, table.end,
                            self.gene_feature)
@@ -940,6 +939,7 @@ class Engine:
             tot = np.zeros(cells.size, dtype=np.int64)
             np.add.at(tot, inv, units[~big])
             names = self.index.names
+            names_of = self.index.names_of
             if cells.size:
                 run_of = cells >> np.uint64(nat.KEY_GROUP_SHIFT)    # (job, k=0, group)
                 cuts = np.flatnonzero(run_of[1:] != run_of[:-1]) + 1
@@ -950,9 +950,9 @@ class Engine:
                     sample, stratum = self.groups[int(cg[a])]
                     feats = cf[a:b].tolist()
                     if feats[-1] == nat.FEATURE_UNASSIGNED:     # the largest id
-                        labels = [names[f] for f in feats[:-1]] + ['Unassigned']
+                        labels = names_of(feats[:-1]) + ['Unassigned']
                     else:
-                        labels = [names[f] for f in feats]
+                        labels = names_of(feats)
                     if stratum is not None:
                         labels = [(stratum, x) for x in labels]
                     dst = self._units.setdefault(
@@ -996,9 +996,27 @@ class Engine:
             self._final.setdefault(k, ({}, dict(v)))
         # units of 1/L (+ the k > 16 rationals) -> the caller's profile
         L = nat.WEIGHT_L
+        had_fractions = bool(self._big)
         for (rank, sample), cells in self._units.items():
             dst = data[rank].setdefault(sample, {})
             extra = self._big.pop((rank, sample), {})
+            if not exact and not extra and not dst and len(cells) > 64:
+                # the usual profile in bulk: int when integral, else one
+                # correctly rounded division (binary64 division of two exactly
+                # represented integers, like Python's int / int below 2^53)
+                try:
+                    u = np.fromiter(cells.values(), dtype=np.int64,
+                                    count=len(cells))
+                except OverflowError:
+                    u = None
+                if u is not None and int(u.max()) < (1 << 53) and \
+                        int(u.min()) >= 0:
+                    q, r = np.divmod(u, L)
+                    whole = (r == 0).tolist()
+                    dst.update(zip(cells, (
+                        i if w else f for i, f, w in zip(
+                            q.tolist(), (u / L).tolist(), whole))))
+                    continue
             for key, u in cells.items():
                 if exact or key in extra:
                     v = Fraction(u, L) + extra.pop(key, 0)
@@ -1019,7 +1037,8 @@ class Engine:
             self._finish_sized(data)
         if exact:
             return
-        exact_to_numbers(data)
+        if had_fractions:       # (else every cell is an int or a float already)
+            exact_to_numbers(data)
 
 
 def exact_to_numbers(data):
@@ -1028,6 +1047,6 @@ def exact_to_numbers(data):
     for profile in data.values():
         for sample in profile.values():
             for key, v in sample.items():
-                if isinstance(v, Fraction):
+                if type(v) is Fraction:
                     sample[key] = v.numerator if v.denominator == 1 \
                         else v.numerator / v.denominator
