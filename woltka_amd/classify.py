@@ -855,8 +855,7 @@ class Engine:
             remap = np.zeros(int(used.max()) + 1 if used.size else 1,
                              dtype=np.int32)
             remap[used] = np.arange(used.size, dtype=np.int32)
-            inames = self.index.names
-            shown = [inames[f] for f in used.tolist()]
+            shown = self.index.names_of(used.tolist())
             if namedic:
                 shown = [namedic.get(x, x) for x in shown]
             row2 = np.where(row >= 0, remap[np.maximum(row, 0)], row)
