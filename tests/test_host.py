@@ -264,3 +264,28 @@ def test_workflow_argument_handling(tmp_path):
     tree, rankdic, namedic, root = workflow.build_hierarchy(
         map_fps=[os.path.join(DATA, 'taxonomy', 'nucl', 'nucl2g.txt')])
     assert set(rankdic.values()) == {'g'} and root == '1'
+
+
+def test_index_bulk_forms_equal_the_single_ones():
+    """NodeIndex / FeatureIndex: intern_many and names_of against intern and
+    names[i] (nodes, names interned later, repeats inside one call)."""
+    import random
+    from woltka_amd import hierarchy as H
+    rng = random.Random(5)
+    n = 500
+    tree = {'n0': 'n0'}
+    for i in range(1, n):
+        tree[f'n{i}'] = f'n{rng.randrange(i)}'
+    h = H.flatten_hierarchy(tree, {f'n{i}': 'genus' for i in range(0, n, 7)}, 'n0')
+    a, b = h.index, H.flatten_hierarchy(tree, None, 'n0').index
+    asked = [rng.choice([f'n{rng.randrange(n)}', f'x{rng.randrange(40)}'])
+             for _ in range(3000)]
+    assert a.intern_many(asked) == [b.intern(x) for x in asked]
+    assert a.intern_many(['n3', 'n9']) == [b.intern('n3'), b.intern('n9')]
+    ids = [rng.randrange(len(a)) for _ in range(2000)]
+    assert a.names_of(ids) == [b.names[i] for i in ids]
+    assert a.names_of([]) == []
+    assert a.names_of(list(range(n, len(a)))) == [b.names[i] for i in range(n, len(b))]
+    f, g = H.FeatureIndex(['p', 'q']), H.FeatureIndex(['p', 'q'])
+    assert f.intern_many(['q', 'z', 'p', 'z', 'y']) == [g.intern(x) for x in ['q', 'z', 'p', 'z', 'y']]
+    assert f.names_of([0, 3, 2]) == [g.names[i] for i in [0, 3, 2]]
