@@ -546,7 +546,7 @@ int wk_tok_create(int n_threads, wk_tok** out) {
         n_threads = (int)std::thread::hardware_concurrency();
         if (n_threads <= 0) n_threads = 1;
     }
-    t->n_threads = std::min(n_threads, 64);  // beyond this, thread start-up outweighs the work per block
+    t->n_threads = std::min(n_threads, 256);  // (the default the host picks is lower: classify.tokenizer_threads)
     *out = t;
     return WK_OK;
 }
