@@ -381,17 +381,64 @@ WORKLOADS = {'flat': FlatWorkload, 'lca': LcaWorkload,
 # synthetic text (end-to-end leg, parse-inclusive CPU baseline)
 # --------------------------------------------------------------------------
 
-def write_sam_lca(path, prob, n_reads, block=4_000_000):
-    """SAM text of the first `n_reads` reads of a packed config-3 problem, one
-    line per alignment record (trimmed as doc/perform.md:122-128 recommends:
-    SEQ / QUAL '*'), formatted with numpy (fixed-width decimal fields).
-    Returns (records, bytes)."""
-    qoff = prob['qoff']
-    n_rec = int(qoff[n_reads])
-    read_of = np.repeat(np.arange(n_reads, dtype=np.int64),
-                        np.diff(qoff[:n_reads + 1]))
-    subj = prob['subj'][:n_rec].astype(np.int64)
-    tmpl = np.frombuffer(b'R000000000\t0\tT0000000\t1\t42\t150M\t*\t0\t0\t*\t*\n',
+_SYNTH = None
+
+
+def _synth_lib():
+    """tools/native/libwk_synth.so (multi-threaded text writer; measurement
+    tooling built by __graft_entry__.build), or None."""
+    global _SYNTH
+    if _SYNTH is None:
+        import ctypes as C
+        fp = os.path.join(ROOT, 'tools', 'native', 'libwk_synth.so')
+        try:
+            lib = C.CDLL(fp)
+            i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+            lib.wk_synth_sam.restype = C.c_int64
+            lib.wk_synth_sam.argtypes = [C.c_char_p, C.c_int64, i64p, C.c_char,
+                                         i32p, i32p, C.c_char, C.c_int, i32p,
+                                         i32p, C.c_int]
+            _SYNTH = lib
+        except OSError:
+            _SYNTH = False
+    return _SYNTH or None
+
+
+def write_sam(path, read_id, subject, qprefix=b'R', sprefix=b'T', swidth=7,
+              flag=None, pos=None, alen=None, block=4_000_000):
+    """SAM text, one line per alignment record (trimmed as doc/perform.md:
+    122-128 recommends: SEQ / QUAL '*'):
+    ``<q><read id:09d> flag <s><subject:0{swidth}d> pos 42 <len>M * 0 0 * *``;
+    flag / pos / len default to 0 / 1 / 150.  Written by the native helper on
+    all threads when it is built, else with numpy (fixed-width fields only).
+    Returns the file size."""
+    import ctypes as C
+    n_rec = int(read_id.size)
+    read_id = np.ascontiguousarray(read_id, dtype=np.int64)
+    subject = np.ascontiguousarray(subject, dtype=np.int32)
+    lib = _synth_lib()
+    if lib is not None:
+        def ptr(a, t):
+            return None if a is None else \
+                np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(
+                    C.POINTER(t))
+        keep = [None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+                for a in (flag, pos, alen)]
+        size = lib.wk_synth_sam(
+            path.encode(), n_rec, read_id.ctypes.data_as(C.POINTER(C.c_int64)),
+            qprefix, ptr(keep[0], C.c_int32),
+            subject.ctypes.data_as(C.POINTER(C.c_int32)), sprefix, swidth,
+            ptr(keep[1], C.c_int32), ptr(keep[2], C.c_int32),
+            min(os.cpu_count() or 1, 64))
+        if size < 0:
+            raise OSError(f'writing {path} failed')
+        return int(size)
+    if flag is not None or pos is not None or alen is not None:
+        raise RuntimeError('tools/native/libwk_synth.so is missing (run '
+                           '__graft_entry__.build()): the numpy writer knows '
+                           'fixed-width lines only')
+    tmpl = np.frombuffer(qprefix + b'0' * 9 + b'\t0\t' + sprefix +
+                         b'0' * swidth + b'\t1\t42\t150M\t*\t0\t0\t*\t*\n',
                          dtype=np.uint8)
     size = 0
     with open(path, 'wb') as f:
@@ -399,14 +446,24 @@ def write_sam_lca(path, prob, n_reads, block=4_000_000):
         for lo in range(0, n_rec, block):
             hi = min(n_rec, lo + block)
             lines = np.tile(tmpl, (hi - lo, 1))
-            r, s = read_of[lo:hi], subj[lo:hi]
+            r, sj = read_id[lo:hi], subject[lo:hi].astype(np.int64)
             for k in range(9):
                 lines[:, 1 + k] = 48 + (r // 10 ** (8 - k)) % 10
-            for k in range(7):
-                lines[:, 14 + k] = 48 + (s // 10 ** (6 - k)) % 10
+            for k in range(swidth):
+                lines[:, 14 + k] = 48 + (sj // 10 ** (swidth - 1 - k)) % 10
             f.write(lines.tobytes())
             size += lines.size
-    return n_rec, size + 23
+    return size + 23
+
+
+def write_sam_lca(path, prob, n_reads):
+    """SAM text of the first `n_reads` reads of a packed config-3 problem.
+    Returns (records, bytes)."""
+    qoff = prob['qoff']
+    n_rec = int(qoff[n_reads])
+    read_of = np.repeat(np.arange(n_reads, dtype=np.int64),
+                        np.diff(qoff[:n_reads + 1]))
+    return n_rec, write_sam(path, read_of, prob['subj'][:n_rec])
 
 
 def write_nodes_dmp(path, hier):
@@ -418,68 +475,161 @@ def write_nodes_dmp(path, hier):
                      for v in range(hier.n_nodes))
 
 
+def write_ordinal_inputs(tmp, prob, n_reads):
+    """Paired SAM with coordinates + the gene coordinates file of a config-4
+    problem (first `n_reads` reads = mates).  Returns (sam, coords, records,
+    bytes)."""
+    hoff = prob['hoff']
+    n_rec = int(hoff[n_reads])
+    read_of = np.repeat(np.arange(n_reads, dtype=np.int64),
+                        np.diff(hoff[:n_reads + 1]))
+    first = np.arange(n_rec) == hoff[read_of]
+    # mates of a pair share the QNAME (flags 99 / 147); secondary hits add 256
+    flag = np.where(read_of & 1, 147, 99) + np.where(first, 0, 256)
+    sam = os.path.join(tmp, 'S1.sam')
+    size = write_sam(sam, read_of >> 1, prob['genome'][:n_rec], b'P', b'G', 6,
+                     flag=flag, pos=prob['beg'][:n_rec].astype(np.int64) + 1,
+                     alen=prob['length'][:n_rec])
+    coords = os.path.join(tmp, 'coords.txt')
+    goff = prob['genome_off'].tolist()
+    gs, ge = prob['gstart'].tolist(), prob['gend'].tolist()
+    gf = prob['gene_feature'].tolist()
+    with open(coords, 'w') as f:
+        for g in range(len(goff) - 1):
+            f.write(f'>G{g:06d}\n')
+            f.writelines(f'g{gf[j]}\t{gs[j] + 1}\t{ge[j]}\n'
+                         for j in range(goff[g], goff[g + 1]))
+    return sam, coords, n_rec, size
+
+
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
 
 
-def e2e_leg(wl, device, frac=0.4, workdir=None):
-    """`workflow.classify` from SAM text + nodes.dmp on local disk (page
-    cache) to the profile dict: tokenizer, H2D staging, kernels and the
-    folding of the counts are all inside the timed region; so is the one-off
-    flattening of the 2 M-node hierarchy (reported separately as setup_s).
-    The text holds the first `frac` of the headline workload's reads."""
-    from woltka_amd import classify as C
-    from woltka_amd import workflow
-    n_reads = max(1000, int(wl.reads * frac))
-    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
-        sam = os.path.join(tmp, 'S1.sam')
-        nodes = os.path.join(tmp, 'nodes.dmp')
-        t0 = time.perf_counter()
-        n_rec, n_bytes = write_sam_lca(sam, wl.prob, n_reads)
-        write_nodes_dmp(nodes, wl.prob['hier'])
-        t_gen = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        tree, rankdic, namedic, root = quiet(workflow.build_hierarchy,
-                                             nodes_fps=[nodes])
-        t_read = time.perf_counter() - t0
-        mapper, chunk = quiet(workflow.build_mapper)
-        setup = {'t': 0.0}
-        orig_init = C.Engine.__init__
+class Phases:
+    """Wall time of the parts of one `workflow.workflow` call: hierarchy /
+    coordinate files read, device tables built (Engine setup), records
+    streamed, counts folded, tables written."""
+    PARTS = (('workflow', 'build_hierarchy', 'hierarchy_s'),
+             ('workflow', 'build_mapper', 'mapper_s'),
+             ('classify', 'Engine.__init__', 'engine_s'),
+             ('classify', 'Engine.set_genes', 'engine_s'),
+             ('classify', 'Engine.finish', 'fold_s'),
+             ('workflow', 'write_profiles', 'write_s'))
 
-        def timed_init(this, *a, **k):
-            t = time.perf_counter()
-            try:
-                return orig_init(this, *a, **k)
-            finally:
-                setup['t'] += time.perf_counter() - t
-        C.Engine.__init__ = timed_init
+    def __init__(self):
+        import importlib
+        self.t = {}
+        self._undo = []
+        for mod, name, key in self.PARTS:
+            m = importlib.import_module(f'woltka_amd.{mod}')
+            owner = m
+            parts = name.split('.')
+            for x in parts[:-1]:
+                owner = getattr(owner, x)
+            orig = getattr(owner, parts[-1])
+
+            def timed(*a, _orig=orig, _key=key, **k):
+                t0 = time.perf_counter()
+                try:
+                    return _orig(*a, **k)
+                finally:
+                    self.t[_key] = self.t.get(_key, 0.0) + \
+                        time.perf_counter() - t0
+            setattr(owner, parts[-1], timed)
+            self._undo.append((owner, parts[-1], orig))
+
+    def close(self):
+        for owner, name, orig in self._undo:
+            setattr(owner, name, orig)
+
+
+def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=2,
+            sync=None):
+    """The whole `woltka classify` call — `workflow.workflow` from file paths
+    (SAM text in the page cache, nodes.dmp / gene coordinates) to the written
+    TSV tables — inside one clock: hierarchy / coordinate files read, device
+    tables built, tokenizer + H2D + kernels, counts folded, tables written.
+    `kind` = 'lca' (configs[2]: 2M-node nodes.dmp, --rank phylum,genus,species)
+    or 'ordinal' (configs[3]: --coords, --overlap 80).  With `sync` (N > 1)
+    all ranks start together and the slowest one's time counts."""
+    from woltka_amd import workflow
+    n_reads = max(1000, int(reads * frac))
+    inf = float('inf')
+    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
+        indir = os.path.join(tmp, 'in')
+        os.makedirs(indir)
+        t0 = time.perf_counter()
+        failed = None
+        try:
+            if kind == 'lca':
+                sam = os.path.join(indir, 'S1.sam')
+                n_rec, n_bytes = write_sam_lca(sam, prob, n_reads)
+                nodes = os.path.join(tmp, 'nodes.dmp')
+                write_nodes_dmp(nodes, prob['hier'])
+                kw = dict(nodes_fps=[nodes], ranks='phylum,genus,species')
+                out = os.path.join(tmp, 'out')
+            else:
+                _, coords, n_rec, n_bytes = write_ordinal_inputs(indir, prob,
+                                                                 n_reads)
+                os.replace(coords, os.path.join(tmp, 'coords.txt'))
+                kw = dict(coords_fp=os.path.join(tmp, 'coords.txt'),
+                          overlap=80)
+                out = os.path.join(tmp, 'out.tsv')
+        except Exception as e:      # (the other ranks must not wait for us)
+            failed = e
+        if sync is not None and sync.allmax(0.0 if failed is None else 1.0):
+            raise failed or RuntimeError('another rank could not write its '
+                                         'input files')
+        if failed is not None:
+            raise failed
+        t_gen = time.perf_counter() - t0
+        ph = Phases()
         try:
             best = None
-            for rep in range(2):            # second run: page cache warm
-                setup['t'] = 0.0
+            for rep in range(reps):
+                ph.t = {}
+                if sync is not None:
+                    sync.barrier()
                 t0 = time.perf_counter()
-                data = quiet(workflow.classify, mapper, {sam: 'S1'}, ['S1'],
-                             fmt='sam', tree=tree, rankdic=rankdic, root=root,
-                             ranks=list(wl.ranks), chunk=chunk, device=device)
-                dt = time.perf_counter() - t0
+                try:
+                    quiet(workflow.workflow, indir, out, input_fmt='sam',
+                          output_fmt=False, device=device, **kw)
+                    dt = time.perf_counter() - t0
+                except Exception as e:
+                    failed, dt = e, inf
+                if sync is not None:
+                    dt = sync.allmax(dt)
+                if dt == inf:
+                    raise failed or RuntimeError('another rank failed')
                 if best is None or dt < best[0]:
-                    best = (dt, setup['t'])
+                    best = (dt, dict(ph.t))
         finally:
-            C.Engine.__init__ = orig_init
-        dt, t_setup = best
-        cells = sum(len(v.get('S1', ())) for v in data.values())
+            ph.close()
+        dt, parts = best
+        tables = [os.path.join(out, x) for x in sorted(os.listdir(out))] \
+            if os.path.isdir(out) else [out]
+        cells = sum(sum(1 for ln in open(fp) if not ln.startswith('#'))
+                    for fp in tables)
+    stream = dt - sum(parts.values())
+    what = {'lca': '2M-node nodes.dmp, --rank phylum,genus,species, three '
+                   'TSV tables',
+            'ordinal': '--coords (5k genomes x 500k genes) --overlap 80, one '
+                       'TSV table'}[kind]
     return {'value': round(n_rec / dt, 1), 'unit': 'records/s',
-            'records': n_rec, 'reads': n_reads, 'text_bytes': n_bytes,
-            'seconds': round(dt, 3), 'setup_s': round(t_setup, 3),
-            'value_streaming': round(n_rec / max(dt - t_setup, 1e-9), 1),
-            'hierarchy_files_read_s': round(t_read, 2),
-            'text_generated_s': round(t_gen, 1), 'cells': cells,
-            'what': ('workflow.classify on SAM text in the page cache (first '
-                     f'{frac:g} of the headline reads, 2M-node nodes.dmp): '
-                     'tokenizer + H2D + kernels + count folding timed; '
-                     'setup_s = hierarchy dicts -> device tables, inside '
-                     '`seconds`')}
+            'records': n_rec, 'reads': n_reads, 'frac_of_config': frac,
+            'text_bytes': n_bytes, 'seconds': round(dt, 3),
+            'phases_s': {k: round(v, 3) for k, v in sorted(parts.items())},
+            'streaming_s': round(stream, 3),
+            'value_streaming': round(n_rec / max(stream, 1e-9), 1),
+            'text_generated_s': round(t_gen, 1), 'table_rows': cells,
+            'tokenizer_threads': __import__(
+                'woltka_amd.classify', fromlist=['x']).tokenizer_threads(),
+            'what': (f'workflow.workflow (= `woltka classify`) from file paths '
+                     f'to written tables, SAM text in the page cache: {what}; '
+                     'everything inside `seconds` (best of '
+                     f'{reps} runs)')}
 
 
 # --------------------------------------------------------------------------
@@ -764,6 +914,8 @@ def run_rank(a, rank, world, local, sync):
     elapsed = timed_steps(wl, a.steps, a.warmup, passes, sync)
     checksum = wl.check()
     if rank != 0:
+        if not (a.headline_only or a.no_e2e) and a.workload == 'lca':
+            e2e_ranks(a, None, wl, dev, world, sync)
         wl.close()
         ctx.close()
         return None
@@ -797,11 +949,35 @@ def run_rank(a, rank, world, local, sync):
         'device': ctx.device_name,
         'checksum': checksum,
     }
-    if world > 1 or a.headline_only:
+    if a.headline_only:
         wl.close()
         ctx.close()
         return line
-    configs = {}
+    if world > 1:
+        if not a.no_e2e and a.workload == 'lca':
+            e2e_ranks(a, line, wl, dev, world, sync)
+        wl.close()
+        ctx.close()
+        return line
+    return side_blocks(a, line, wl, ctx, dev)
+
+
+def e2e_scale_for(world, frac, per_rank_bytes=14e9):
+    """Largest fraction <= `frac` of the configuration whose text (page
+    cache) + packed problem fit this host's free memory `world` times."""
+    try:
+        import psutil
+        free = psutil.virtual_memory().available
+    except Exception:
+        return frac
+    fit = 0.5 * free / (world * per_rank_bytes)
+    return frac if fit >= frac else max(0.02, round(fit, 2))
+
+
+def side_blocks(a, line, wl, ctx, dev):
+    """N = 1: the other configurations, the end-to-end legs and the CPU
+    baseline, added to the headline's JSON line."""
+    configs, e2e = {}, {}
     if a.workload == 'lca':
         try:
             free = LcaFreeWorkload(ctx, 0, a.scale, share=wl)
@@ -812,10 +988,13 @@ def run_rank(a, rank, world, local, sync):
             ctx.counts_clear()
         except Exception as e:      # a side block must not cost the headline
             configs['lca_free'] = {'error': repr(e)}
-        try:
-            line['e2e'] = e2e_leg(wl, dev, workdir=a.tmp)
-        except Exception as e:
-            line['e2e'] = {'error': repr(e)}
+        if not a.no_e2e:
+            try:
+                e2e['lca'] = e2e_leg('lca', wl.prob, wl.reads, dev,
+                                     frac=e2e_scale_for(1, a.e2e_frac),
+                                     workdir=a.tmp)
+            except Exception as e:
+                e2e['lca'] = {'error': repr(e)}
     if not a.no_cpu:
         try:
             line['cpu_baseline'] = cpu_baseline(wl, workdir=a.tmp)
@@ -836,12 +1015,52 @@ def run_rank(a, rank, world, local, sync):
             configs[key] = config_block(w2, t, p2, a.steps, a.scale, key)
             if key == 'ordinal' and not a.no_cpu:
                 configs[key]['cpu_baseline'] = cpu_baseline(w2, 8.0)
+            prob, reads = (w2.prob, w2.reads) if key == 'ordinal' else (None, 0)
             w2.close()
             c2.close()
             del w2
+            if key == 'ordinal' and not a.no_e2e:
+                try:
+                    e2e['ordinal'] = e2e_leg(
+                        'ordinal', prob, reads, dev,
+                        frac=e2e_scale_for(1, a.e2e_frac), workdir=a.tmp)
+                except Exception as e:
+                    e2e['ordinal'] = {'error': repr(e)}
+            del prob
         except Exception as e:
             configs[key] = {'error': repr(e)}
     line['configs'] = configs
+    if e2e:
+        line['e2e'] = e2e
+        # the north star's end-to-end figures: whole `woltka classify` calls
+        line['e2e_value'] = e2e.get('lca', {}).get('value')
+        line['e2e_ordinal_value'] = e2e.get('ordinal', {}).get('value')
+    return line
+
+
+def e2e_ranks(a, line, wl, dev, world, sync):
+    """N > 1: every rank runs the whole `woltka classify` call on its own
+    sample files at the same time (the host's tokenizer threads are shared
+    among the ranks: classify.tokenizer_threads); aggregate = records of all
+    ranks / slowest rank's wall time."""
+    frac = e2e_scale_for(world, a.e2e_frac)
+    if world > 1:
+        frac = sync.allmax(-frac) * -1.0        # every rank the same size
+    try:
+        leg = e2e_leg('lca', wl.prob, wl.reads, dev, frac=frac, workdir=a.tmp,
+                      sync=sync)
+        err = 0.0
+    except Exception as e:
+        leg, err = {'error': repr(e)}, 1.0
+    if sync.allmax(err) > 0:
+        leg = leg if 'error' in leg else {'error': 'another rank failed'}
+    elif line is not None:
+        leg['value_per_rank'] = leg['value']
+        leg['value'] = round(leg['value'] * world, 1)
+        leg['ranks'] = world
+    if line is not None:
+        line['e2e'] = {'lca': leg}
+        line['e2e_value'] = leg.get('value')
     return line
 
 
@@ -908,6 +1127,11 @@ def parse_args(argv=None):
                          'depend on them)')
     ap.add_argument('--no-cpu', action='store_true',
                     help='skip the CPU baseline leg')
+    ap.add_argument('--no-e2e', action='store_true',
+                    help='skip the end-to-end legs')
+    ap.add_argument('--e2e-frac', type=float, default=1.0,
+                    help='fraction of the configuration the end-to-end legs '
+                         'read (default: all of it, memory permitting)')
     ap.add_argument('--headline-only', action='store_true',
                     help='skip the per-config blocks, the end-to-end leg and '
                          'the CPU baseline')

@@ -400,6 +400,71 @@ int wk_tok_new_subjects(wk_tok* tok, char* blob, int32_t* off);
 int wk_preorder(const int64_t* parent, int64_t n, int64_t expected_root /* -1: any */,
                 int64_t* pre, int64_t* size, int64_t* depth, int64_t* bad);
 
+/* ---- native hierarchy ingest (host, multi-threaded) ---------------------- */
+/* Replaces the per-line Python of the hierarchy readers and what follows them
+ * in workflow.build_hierarchy (workflow.py:698-815): tree.read_nodes
+ * (tree.py:73-101), tree.read_names (tree.py:48-70), file.read_map_1st
+ * (file.py:388-406), util.update_dict (util.py:46-75), tree.fill_root
+ * (tree.py:302-388), and the flattening of the dicts to the arrays wk_set_tree
+ * takes.  A wk_hier holds the three dicts of the reference — child -> parent,
+ * node -> rank, node -> name — as one symbol table; every wk_hier_add_text /
+ * wk_hier_update is one util.update_dict(dic, other): a key that an earlier
+ * update set to another value fails with WK_E_STATE and the reference's
+ * message ("Conflicting values found for ..."), a key repeated inside one file
+ * takes its last value. */
+typedef struct wk_hier wk_hier;
+#define WK_HIER_NODES 0 /* tree.read_nodes: "id | parent | rank |" or "id parent [rank]" */
+#define WK_HIER_MAP 1   /* file.read_map_1st: first two columns, key -> parent           */
+#define WK_HIER_NAMES 2 /* tree.read_names: names.dmp (scientific names) or "id name"    */
+#define WK_HIER_PARENT 0 /* fields: tree[key]    */
+#define WK_HIER_RANK 1   /*         rankdic[key] */
+#define WK_HIER_NAME 2   /*         namedic[key] */
+int wk_hier_create(int n_threads /* <= 0: all hardware threads */, wk_hier** out);
+void wk_hier_destroy(wk_hier* h);
+const char* wk_hier_last_error(const wk_hier* h);
+/* One whole file of text.  `rank` (WK_HIER_MAP only, may be NULL): the rank
+ * given to every value of the map ("map as rank", workflow.py:789-805).
+ * WK_E_ARG = text the native readers leave to the Python readers (a byte
+ * >= 0x80 where str.rstrip() looks, a bare '\r', a "\t|" inside a field):
+ * nothing was changed, read the file in Python and use wk_hier_update;
+ * WK_E_RANGE = a line with fewer than two fields (the reference's IndexError). */
+int wk_hier_add_text(wk_hier* h, int kind, const char* buf, int64_t len,
+                     const char* rank);
+/* util.update_dict(dic, other) with `other` as arrays: key i =
+ * kblob[koff[i]..koff[i+1]), value i likewise (WK_HIER_PARENT: is_none[i] != 0
+ * means None; is_none may be NULL). */
+int wk_hier_update(wk_hier* h, int field, const char* kblob, const int64_t* koff,
+                   const char* vblob, const int64_t* voff,
+                   const uint8_t* is_none, int64_t n);
+/* tree.fill_root + flattening: parents that are not keys join the tree; one
+ * crown becomes the root, several get a new root named by the smallest unused
+ * positive integer; nodes are numbered in DFS pre-order.  WK_E_STATE: no root
+ * (a pure cycle) or a node that cannot reach the root.  No update afterwards. */
+int wk_hier_finish(wk_hier* h, int64_t* n_nodes, int32_t* n_ranks);
+/* The arrays of wk_set_tree (+ depth), n_nodes each; NULL skips one. */
+int wk_hier_arrays(const wk_hier* h, int32_t* parent, int32_t* last,
+                   int32_t* rank_code, int32_t* depth);
+/* *root_id = 0 (the root's pre-order id) or -1 for an empty tree. */
+int wk_hier_root(const wk_hier* h, int32_t* root_id);
+/* Pre-order ids of names (-1: not a node): name i = blob[off[i]..off[i+1]). */
+int wk_hier_lookup(const wk_hier* h, const char* blob, const int64_t* off,
+                   int64_t n, int32_t* out);
+/* Names of pre-order ids: off[n + 1] always; bytes when blob != NULL. */
+int wk_hier_node_names(const wk_hier* h, const int32_t* ids, int64_t n,
+                       char* blob, int64_t cap, int64_t* off);
+/* One entry of a dict: *len = -1 when the key is absent, else the value's
+ * length (copied to out when it fits cap). */
+int wk_hier_get(const wk_hier* h, int field, const char* key, int64_t klen,
+                char* out, int64_t cap, int64_t* len);
+int64_t wk_hier_size(const wk_hier* h, int field); /* len(dict) */
+/* All keys of a dict: off[size + 1] always; bytes when blob != NULL. */
+int wk_hier_keys(const wk_hier* h, int field, char* blob, int64_t cap,
+                 int64_t* off);
+/* Rank vocabulary (rank code = index + 1; n_ranks from wk_hier_finish) and the
+ * number of keys that carry each rank. */
+int wk_hier_ranks(const wk_hier* h, char* blob, int64_t cap, int64_t* off,
+                  int64_t* used);
+
 /* ---- measurement ------------------------------------------------------- */
 /* HIP-event timing on the context's own stream (the stream every kernel of
  * this library is launched on).  wk_timer_begin/end bracket a region;

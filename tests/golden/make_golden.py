@@ -1426,6 +1426,183 @@ def gen_tools(seed=71, n_cases=170):
 
 
 
+def gen_hierarchy_build(seed=83, n_cases=90):
+    """workflow.build_hierarchy of the reference on random sets of hierarchy
+    files: nodes tables (NCBI .dmp and plain, repeated keys, odd white space,
+    "\t|" in odd places, CRLF and bare CR line ends, non-ASCII text), names
+    tables, simple maps (with and without map-as-rank), lineage / columns /
+    Newick files next to them; forests with missing parents and several
+    crowns; files that contradict each other (AssertionError) and lines with
+    too few fields (IndexError).  Expected: the four return values, or the
+    exception."""
+    import contextlib
+    import io
+    import tempfile
+    from woltka.workflow import build_hierarchy
+    rng = random.Random(seed)
+    ranks = ['no rank', 'superkingdom', 'phylum', 'class', 'genus', 'species']
+
+    def ident(i):
+        return rng.choice([f'{i}', f'T{i}', f'tax {i}', f'{i:04d}'])
+
+    def nodes_text(ids, kind, quirk):
+        """A nodes table over `ids` (a forest: parent drawn from earlier ids,
+        sometimes itself, sometimes a name that is no key)."""
+        lines = []
+        for k, x in enumerate(ids):
+            r = rng.random()
+            if k == 0 or r < 0.05:
+                par = x
+            elif r < 0.10:
+                par = f'ghost{rng.randrange(3)}'
+            else:
+                par = ids[rng.randrange(k)]
+            rank = rng.choice(ranks)
+            if kind == 'dmp':
+                line = f'{x}\t|\t{par}\t|\t{rank}\t|\tXX\t|\t0\t|'
+            elif kind == 'plain3':
+                line = f'{x}\t{par}\t{rank}'
+            else:
+                line = f'{x}\t{par}'
+            lines.append(line)
+        if quirk == 'repeat' and len(ids) > 2:      # a key twice: last wins
+            x = ids[rng.randrange(1, len(ids))]
+            lines.append(f'{x}\t{ids[0]}\tgenus' if kind != 'dmp'
+                         else f'{x}\t|\t{ids[0]}\t|\tgenus\t|')
+        if quirk == 'space':
+            lines = [ln + rng.choice(['', ' ', '\t', ' \t ', '\x0b', '\x1c'])
+                     for ln in lines]
+        if quirk == 'bar':          # "\t|" glued to text, doubled, leading
+            lines.append('\t|q1\t|\t|\t' + ids[0] + '\t|\tphylum')
+            lines.append('q2\t|x\t' + ids[0])
+        if quirk == 'short':
+            lines.insert(rng.randrange(len(lines) + 1),
+                         rng.choice(['', 'lonely', ' ', 'a\t|']))
+        if quirk == 'nbsp':
+            lines[-1] += ' '
+        if quirk == 'utf8':
+            lines.append(f'café\t{ids[0]}\tgenus' if kind != 'dmp'
+                         else f'café\t|\t{ids[0]}\t|\tgenus\t|')
+        end = '\n'
+        if quirk == 'crlf':
+            end = '\r\n'
+        text = end.join(lines) + (end if rng.random() < 0.8 else '')
+        if quirk == 'cr':           # a bare CR is a line end for Python
+            text = text.replace('\n', '\r', 1)
+        return text
+
+    def names_text(ids, kind):
+        lines = []
+        for x in ids:
+            if rng.random() < 0.2:
+                continue
+            if kind == 'dmp':
+                if rng.random() < 0.3:
+                    lines.append(f'{x}\t|\tsyn of {x}\t|\t\t|\tsynonym\t|')
+                lines.append(f'{x}\t|\tName {x}\t|\t\t|\tscientific name\t|')
+                if rng.random() < 0.2:
+                    lines.append(f'{x}\t|\tcommon {x}\t|\t\t|\tcommon name\t|')
+            else:
+                lines.append(f'{x}\tName {x}' + rng.choice(['', '\textra']))
+        return '\n'.join(lines) + '\n'
+
+    def map_text(subjects, ids, quirk):
+        lines = []
+        for sname in subjects:
+            t = rng.choice(ids)
+            lines.append(f'{sname}\t{t}' + rng.choice(['', '\tmore\tcols',
+                                                      ' ', '\t']))
+        if quirk == 'notab':
+            lines.insert(1, 'no tab here')
+            lines.append('')
+        if quirk == 'repeat':
+            lines.append(f'{subjects[0]}\t{ids[-1]}')
+        if quirk == 'emptykey':
+            lines.append(f'\t{ids[0]}')
+        return '\n'.join(lines) + '\n'
+
+    cases = []
+    for ci in range(n_cases):
+        n = rng.choice([1, 3, 8, 30, 120])
+        ids = []
+        while len(ids) < n:
+            x = ident(len(ids) + 1)
+            if x not in ids:
+                ids.append(x)
+        files = {}          # name -> text
+        args = dict(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
+                    columns_fps=[], map_fps=[], map_rank=None)
+        shape = rng.choice(['nodes', 'nodes', 'nodes+names', 'nodes+map',
+                            'two_nodes', 'conflict', 'map_only', 'maps_rank',
+                            'nodes+lineage', 'nodes+newick', 'names_conflict',
+                            'empty'])
+        kind = rng.choice(['dmp', 'plain3', 'plain2'])
+        quirk = rng.choice(['none', 'none', 'repeat', 'space', 'bar', 'short',
+                            'nbsp', 'utf8', 'crlf', 'cr'])
+        if shape != 'map_only' and shape != 'maps_rank' and shape != 'empty':
+            files['nodes.dmp'] = nodes_text(ids, kind, quirk)
+            args['nodes_fps'].append('nodes.dmp')
+        if shape == 'nodes+names' or shape == 'names_conflict':
+            files['names.dmp'] = names_text(ids, rng.choice(['dmp', 'plain']))
+            args['names_fps'].append('names.dmp')
+            if shape == 'names_conflict':
+                files['names2.txt'] = f'{ids[0]}\tAnother name\n' + \
+                    names_text(ids[1:], 'plain')
+                args['names_fps'].append('names2.txt')
+        if shape in ('nodes+map', 'map_only', 'maps_rank'):
+            subjects = [f'G{i:03d}' for i in range(rng.choice([1, 5, 40]))]
+            mq = rng.choice(['none', 'notab', 'repeat', 'emptykey'])
+            files['genus.map'] = map_text(subjects, ids, mq)
+            args['map_fps'].append('genus.map')
+            if shape == 'maps_rank':
+                files['tax2phylum.txt'] = map_text(ids, ['P1', 'P2', 'P3'], 'none')
+                args['map_fps'].append('tax2phylum.txt')
+            args['map_rank'] = rng.choice([None, True, False])
+        if shape == 'two_nodes' or shape == 'conflict':
+            extra = [f'E{i}' for i in range(rng.choice([1, 4]))]
+            more = [f'{x}\t{rng.choice(ids)}\tspecies' for x in extra]
+            # the same key again: same value (fine) or another (AssertionError)
+            k = ids[-1]
+            first = files['nodes.dmp'].replace('\r\n', '\n').replace('\r', '\n')
+            val = None
+            for ln in first.split('\n'):
+                x = ln.rstrip().replace('\t|', '').split('\t')
+                if x[0] == k and len(x) > 1:
+                    val = x[1]
+            if shape == 'conflict':
+                more.append(f'{k}\t{val}-not')
+            elif val is not None:
+                more.append(f'{k}\t{val}')
+            files['more_nodes.tsv'] = '\n'.join(more) + '\n'
+            args['nodes_fps'].append('more_nodes.tsv')
+        if shape == 'nodes+lineage':
+            files['lineages.txt'] = ''.join(
+                f'S{i}\tk__K{i % 2}; p__P{i % 3};g__; s__Sp{i}\n'
+                for i in range(rng.choice([2, 9])))
+            args['lineage_fps'].append('lineages.txt')
+        if shape == 'nodes+newick':
+            files['tree.nwk'] = '((a,b)ab,(c,d)cd)nwkroot;\n'
+            args['newick_fps'].append('tree.nwk')
+        with tempfile.TemporaryDirectory() as tmp:
+            for name, text in files.items():
+                with open(os.path.join(tmp, name), 'w', newline='',
+                          encoding='utf-8') as f:
+                    f.write(text)
+            kw = {k: ([os.path.join(tmp, x) for x in v]
+                      if isinstance(v, list) else v) for k, v in args.items()}
+            try:
+                with contextlib.redirect_stdout(io.StringIO()) as out:
+                    tree, rankdic, namedic, root = build_hierarchy(**kw)
+                exp = dict(tree=tree, rankdic=rankdic, namedic=namedic,
+                           root=root,
+                           stdout=out.getvalue().replace(tmp, '<tmp>'))
+            except (AssertionError, IndexError, ValueError) as e:
+                exp = dict(error=type(e).__name__, message=str(e))
+        cases.append(dict(files=files, args=args, expect=exp, shape=shape,
+                          kind=kind, quirk=quirk))
+    dump('hierarchy_build.json', cases)
+
+
 def main():
     if not _refshim.install():
         print('reference tree not present: nothing to do')
@@ -1446,6 +1623,7 @@ def main():
     gen_cli_config5()
     gen_cli_medium()
     gen_tools()
+    gen_hierarchy_build()
 
 
 if __name__ == '__main__':

@@ -49,7 +49,11 @@ SYMBOLS = (
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
-    'wk_tok_fetch_samples', 'wk_tok_new_samples', 'wk_preorder')
+    'wk_tok_fetch_samples', 'wk_tok_new_samples', 'wk_preorder',
+    'wk_hier_create', 'wk_hier_destroy', 'wk_hier_last_error',
+    'wk_hier_add_text', 'wk_hier_update', 'wk_hier_finish', 'wk_hier_arrays',
+    'wk_hier_root', 'wk_hier_lookup', 'wk_hier_node_names', 'wk_hier_get',
+    'wk_hier_size', 'wk_hier_keys', 'wk_hier_ranks')
 
 
 class Job(C.Structure):
@@ -152,6 +156,24 @@ def load_library():
                                         i32p, i32p, C.c_char_p, i64p, C.c_int32,
                                         C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                         i64p]),
+        'wk_hier_create': (C.c_int, [C.c_int, C.POINTER(p)]),
+        'wk_hier_destroy': (None, [p]),
+        'wk_hier_last_error': (C.c_char_p, [p]),
+        'wk_hier_add_text': (C.c_int, [p, C.c_int, C.c_void_p, C.c_int64,
+                                       C.c_char_p]),
+        'wk_hier_update': (C.c_int, [p, C.c_int, C.c_char_p, i64p, C.c_char_p,
+                                     i64p, C.POINTER(C.c_uint8), C.c_int64]),
+        'wk_hier_finish': (C.c_int, [p, i64p, i32p]),
+        'wk_hier_arrays': (C.c_int, [p, i32p, i32p, i32p, i32p]),
+        'wk_hier_root': (C.c_int, [p, i32p]),
+        'wk_hier_lookup': (C.c_int, [p, C.c_char_p, i64p, C.c_int64, i32p]),
+        'wk_hier_node_names': (C.c_int, [p, i32p, C.c_int64, C.c_void_p,
+                                         C.c_int64, i64p]),
+        'wk_hier_get': (C.c_int, [p, C.c_int, C.c_char_p, C.c_int64,
+                                  C.c_void_p, C.c_int64, i64p]),
+        'wk_hier_size': (C.c_int64, [p, C.c_int]),
+        'wk_hier_keys': (C.c_int, [p, C.c_int, C.c_void_p, C.c_int64, i64p]),
+        'wk_hier_ranks': (C.c_int, [p, C.c_void_p, C.c_int64, i64p, i64p]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -719,3 +741,167 @@ def format_readmap(buf, qname, assign, m_off, m_feat, m_count, names,
             *args, C.c_void_p(out.ctypes.data), n.value, C.byref(n)) != OK:
         raise RuntimeError('wk_format_readmap failed')
     return out.tobytes()
+
+
+HIER_NODES, HIER_MAP, HIER_NAMES = 0, 1, 2
+HIER_PARENT, HIER_RANK, HIER_NAME = 0, 1, 2
+
+
+def _blob(strings):
+    """(bytes, int64 offsets) of a sequence of str."""
+    enc = [x.encode() for x in strings]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    if enc:
+        np.cumsum(np.fromiter(map(len, enc), np.int64, len(enc)), out=off[1:])
+    return b''.join(enc), off
+
+
+def _split(raw, off):
+    """list of str from a bytes blob and its offsets."""
+    o = off.tolist()
+    return [raw[a:b].decode() for a, b in zip(o, o[1:])]
+
+
+class HierarchyBuilder:
+    """Native hierarchy ingest (``wk_hier_*``; host side, needs no GPU): the
+    reference's three dicts — child -> parent, node -> rank, node -> name — as
+    one native symbol table.  ``add_text`` / ``update`` are one
+    ``util.update_dict`` each; ``finish`` is ``tree.fill_root`` + flattening."""
+
+    class Refused(Exception):
+        """The native reader leaves this text to the Python reader."""
+
+    def __init__(self, n_threads=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        if self._lib.wk_hier_create(int(n_threads), C.byref(h)) != OK:
+            raise RuntimeError('wk_hier_create failed')
+        self._h = h
+        self.n_nodes = None
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.wk_hier_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self._lib.wk_hier_last_error(self._h).decode()
+        if rc == E_STATE and msg.startswith('Conflicting'):
+            raise AssertionError(msg)       # util.update_dict (util.py:46-75)
+        if rc == E_RANGE and 'index' in msg:
+            raise IndexError(msg)           # x[1] of a short line (tree.py:96)
+        raise ValueError(msg)
+
+    def add_text(self, kind, buf, rank=None):
+        """One file's bytes (bytes-like).  Raises ``Refused`` when the text
+        has to go through the Python reader."""
+        mv = memoryview(buf)
+        n = mv.nbytes
+        raw = np.frombuffer(mv, dtype=np.uint8) if n else None
+        try:
+            addr = C.c_void_p(raw.ctypes.data) if n \
+                else C.cast(C.c_char_p(b''), C.c_void_p)
+            rc = self._lib.wk_hier_add_text(
+                self._h, kind, addr, n,
+                None if rank is None else rank.encode())
+        finally:            # (no export of the caller's buffer outlives the call)
+            del raw
+            mv.release()
+        if rc == E_ARG:
+            raise self.Refused()
+        self._check(rc)
+
+    def update(self, field, pairs):
+        """``update_dict`` with a dict (values may be None for the tree)."""
+        keys = list(pairs)
+        vals = [pairs[k] for k in keys]
+        none = np.fromiter((v is None for v in vals), np.uint8, len(vals))
+        kblob, koff = _blob(keys)
+        vblob, voff = _blob(['' if v is None else v for v in vals])
+        self._check(self._lib.wk_hier_update(
+            self._h, field, kblob, _ptr(koff, C.c_int64), vblob,
+            _ptr(voff, C.c_int64), _ptr(none, C.c_uint8), len(keys)))
+
+    def finish(self):
+        n, nr = C.c_int64(0), C.c_int32(0)
+        self._check(self._lib.wk_hier_finish(self._h, C.byref(n),
+                                             C.byref(nr)))
+        self.n_nodes, self.n_ranks = n.value, nr.value
+        return self.n_nodes
+
+    def arrays(self):
+        """(parent, last, rank_code, depth), int32, pre-order."""
+        out = [np.empty(self.n_nodes, np.int32) for _ in range(4)]
+        self._check(self._lib.wk_hier_arrays(
+            self._h, *(_ptr(a, C.c_int32) for a in out)))
+        return out
+
+    def ranks(self):
+        """(rank names in code order — code = index + 1 —, keys per rank)."""
+        off = np.zeros(self.n_ranks + 1, np.int64)
+        used = np.zeros(self.n_ranks, np.int64)
+        self._check(self._lib.wk_hier_ranks(self._h, None, 0,
+                                            _ptr(off, C.c_int64), None))
+        blob = C.create_string_buffer(max(1, int(off[-1])))
+        self._check(self._lib.wk_hier_ranks(
+            self._h, blob, int(off[-1]), _ptr(off, C.c_int64),
+            _ptr(used, C.c_int64)))
+        return _split(blob.raw, off), used.tolist()
+
+    def lookup(self, names):
+        """Pre-order ids (int32 array, -1 = not a node) of a list of str."""
+        blob, off = _blob(names)
+        out = np.empty(len(names), np.int32)
+        self._check(self._lib.wk_hier_lookup(
+            self._h, blob, _ptr(off, C.c_int64), len(names),
+            _ptr(out, C.c_int32)))
+        return out
+
+    def node_names(self, ids):
+        """Names (list of str) of pre-order ids."""
+        ids = _arr(ids, np.int32)
+        off = np.zeros(ids.size + 1, np.int64)
+        self._check(self._lib.wk_hier_node_names(
+            self._h, _ptr(ids, C.c_int32), ids.size, None, 0,
+            _ptr(off, C.c_int64)))
+        blob = C.create_string_buffer(max(1, int(off[-1])))
+        self._check(self._lib.wk_hier_node_names(
+            self._h, _ptr(ids, C.c_int32), ids.size, blob, int(off[-1]),
+            _ptr(off, C.c_int64)))
+        return _split(blob.raw, off)
+
+    def get(self, field, key):
+        """Value of one dict entry (str), or None when the key is absent."""
+        k = key.encode()
+        n = C.c_int64(0)
+        buf = C.create_string_buffer(256)
+        self._check(self._lib.wk_hier_get(self._h, field, k, len(k), buf, 256,
+                                          C.byref(n)))
+        if n.value < 0:
+            return None
+        if n.value > 256:
+            buf = C.create_string_buffer(n.value)
+            self._check(self._lib.wk_hier_get(self._h, field, k, len(k), buf,
+                                              n.value, C.byref(n)))
+        return buf.raw[:n.value].decode()
+
+    def size(self, field):
+        return int(self._lib.wk_hier_size(self._h, field))
+
+    def keys(self, field):
+        n = self.size(field)
+        off = np.zeros(n + 1, np.int64)
+        self._check(self._lib.wk_hier_keys(self._h, field, None, 0,
+                                           _ptr(off, C.c_int64)))
+        blob = C.create_string_buffer(max(1, int(off[-1])))
+        self._check(self._lib.wk_hier_keys(self._h, field, blob,
+                                           int(off[-1]), _ptr(off, C.c_int64)))
+        return _split(blob.raw, off)

@@ -141,8 +141,17 @@ class Engine:
         self.ctx = nat.Context(device)
         self.ranks = list(ranks)
         self.use_tree = bool(tree)
-        if tree:
-            self.hier = flatten_hierarchy(tree, rankdic, root)
+        native = getattr(tree, 'native', None)
+        if tree and native is not None and (
+                rankdic is None or getattr(rankdic, 'native', None) is native):
+            # the dicts are views of a natively built table
+            # (workflow.build_hierarchy): its pre-order arrays as they are
+            self.hier = native.hierarchy()
+        elif tree:
+            self.hier = flatten_hierarchy(
+                dict(tree) if native is not None else tree,
+                dict(rankdic) if getattr(rankdic, 'native', None) is not None
+                else rankdic, root)
         else:
             # `free` on an empty hierarchy still has defined results
             # (classify.py:73-78): keep a lone root so that every subject is
@@ -554,9 +563,8 @@ class Engine:
                 subj, qoff = packed
             known = len(self.subj_feature)
             if len(self.subjects) > known:
-                intern = self.index.intern
-                self.subj_feature.extend(
-                    intern(x) for x in self.subjects.names[known:])
+                self.subj_feature.extend(self.index.intern_many(
+                    self.subjects.names[known:]))
                 self.ctx.set_subjects(self.subj_feature)
             # the Python parsers and the native tokenizer hand over sets;
             # trimming can merge subjects

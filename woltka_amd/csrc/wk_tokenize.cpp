@@ -27,65 +27,12 @@
 #include <vector>
 
 #include "../../include/woltka_hip.h"
+#include "wk_names.hpp"
 
 namespace {
 
-inline uint64_t hash_bytes(const char* p, size_t n) {
-    uint64_t h = 0xcbf29ce484222325ull ^ (n * 0x9E3779B97F4A7C15ull);
-    while (n >= 8) {
-        uint64_t v;
-        memcpy(&v, p, 8);
-        h = (h ^ v) * 0x100000001b3ull;
-        h ^= h >> 29;
-        p += 8;
-        n -= 8;
-    }
-    uint64_t v = 0;
-    memcpy(&v, p, n);
-    h = (h ^ v) * 0x100000001b3ull;
-    return h ^ (h >> 32);
-}
-
-// string -> id table; names live in an arena (stable across calls)
-struct NameTable {
-    std::vector<int32_t> slot;  // id or -1
-    std::vector<uint64_t> hash;
-    std::vector<uint32_t> off, len;  // per id
-    std::string arena;
-    size_t mask = 0;
-    NameTable() { rehash(1 << 12); }
-    void rehash(size_t n) {
-        slot.assign(n, -1);
-        mask = n - 1;
-        for (int32_t id = 0; id < (int32_t)off.size(); ++id) {
-            size_t h = hash[id] & mask;
-            while (slot[h] >= 0) h = (h + 1) & mask;
-            slot[h] = id;
-        }
-    }
-    int32_t find(const char* p, size_t n, uint64_t hv) const {
-        size_t h = hv & mask;
-        for (;;) {
-            const int32_t id = slot[h];
-            if (id < 0) return -1;
-            if (hash[id] == hv && len[id] == n && memcmp(arena.data() + off[id], p, n) == 0) return id;
-            h = (h + 1) & mask;
-        }
-    }
-    int32_t add(const char* p, size_t n, uint64_t hv) {
-        if ((off.size() + 1) * 2 > slot.size()) rehash(slot.size() * 2);
-        const int32_t id = (int32_t)off.size();
-        off.push_back((uint32_t)arena.size());
-        len.push_back((uint32_t)n);
-        hash.push_back(hv);
-        arena.append(p, n);
-        size_t h = hv & mask;
-        while (slot[h] >= 0) h = (h + 1) & mask;
-        slot[h] = id;
-        return id;
-    }
-    int32_t size() const { return (int32_t)off.size(); }
-};
+using wkh::hash_bytes;
+using wkh::NameTable;
 
 struct Record {
     int32_t subj;  // global id >= 0, or -(1 + local new-name id)

@@ -375,3 +375,192 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
                                dtype=np.int32, count=n)
         rank_code = codes_in[inv]
     return Hierarchy(index, parent, last, rank_code, rank_codes, dep)
+
+
+# --------------------------------------------------------------------------
+# native ingest: the reference's dicts as views of one native symbol table
+# --------------------------------------------------------------------------
+
+from collections.abc import Mapping  # noqa: E402
+
+
+class _DictView(Mapping):
+    """One of the three dicts of ``workflow.build_hierarchy`` (child -> parent,
+    node -> rank, node -> name; workflow.py:698-815) as a read-only view of a
+    ``NativeTaxonomy``: entries are looked up one at a time in the native
+    table; iterating materialises the keys."""
+
+    def __init__(self, native, field):
+        self.native = native
+        self._field = field
+        self._len = None
+
+    def __getitem__(self, key):
+        v = self.native.builder.get(self._field, key) \
+            if isinstance(key, str) else None
+        if v is None:
+            raise KeyError(key)
+        return v
+
+    def get(self, key, default=None):
+        v = self.native.builder.get(self._field, key) \
+            if isinstance(key, str) else None
+        return default if v is None else v
+
+    def __contains__(self, key):
+        return isinstance(key, str) and \
+            self.native.builder.get(self._field, key) is not None
+
+    def __len__(self):
+        if self._len is None:
+            self._len = self.native.builder.size(self._field)
+        return self._len
+
+    def __iter__(self):
+        return iter(self.native.builder.keys(self._field))
+
+    def __repr__(self):
+        return f'<{type(self).__name__} of {len(self)} entries>'
+
+
+class _NativeNames:
+    """``index.names`` of a ``NativeIndex``: names by feature id."""
+
+    def __init__(self, index):
+        self._ix = index
+        self._seen = {}
+
+    def __len__(self):
+        return len(self._ix)
+
+    def __getitem__(self, i):
+        ix = self._ix
+        if isinstance(i, slice):
+            return ix.names_of(list(range(*i.indices(len(ix)))))
+        if i < 0:
+            i += len(ix)
+        if i >= ix.n_nodes:
+            return ix._extra[i - ix.n_nodes]
+        name = self._seen.get(i)
+        if name is None:
+            if len(self._seen) > 1 << 16:
+                self._seen.clear()
+            name = self._seen[i] = ix._b.node_names([i])[0]
+        return name
+
+    def __iter__(self):
+        return iter(self[:])
+
+
+class NativeIndex(FeatureIndex):
+    """``FeatureIndex`` over the native symbol table: ids ``[0, n_nodes)`` are
+    pre-order node ids resolved natively, names interned later (subjects that
+    are not nodes) get ids ``>= n_nodes`` in a small Python dict."""
+
+    def __init__(self, builder, n_nodes):
+        self._b = builder
+        self.n_nodes = n_nodes
+        self._extra, self._extra_ids = [], {}
+
+    def __len__(self):
+        return self.n_nodes + len(self._extra)
+
+    @property
+    def names(self):
+        return _NativeNames(self)
+
+    @property
+    def ids(self):
+        """name -> id as a dict (materialised; tests and debugging)."""
+        names = self._b.node_names(np.arange(self.n_nodes, dtype=np.int32))
+        d = dict(zip(names, range(self.n_nodes)))
+        d.update(self._extra_ids)
+        return d
+
+    def _new(self, name):
+        j = self._extra_ids.get(name)
+        if j is None:
+            j = self.n_nodes + len(self._extra)
+            self._extra_ids[name] = j
+            self._extra.append(name)
+        return j
+
+    def intern(self, name):
+        i = int(self._b.lookup([name])[0])
+        return i if i >= 0 else self._new(name)
+
+    def get(self, name, default=-1):
+        i = int(self._b.lookup([name])[0])
+        return i if i >= 0 else self._extra_ids.get(name, default)
+
+    def intern_many(self, names):
+        names = list(names)
+        out = self._b.lookup(names).tolist()
+        for k, i in enumerate(out):
+            if i < 0:
+                out[k] = self._new(names[k])
+        return out
+
+    def names_of(self, ids):
+        if not len(ids):
+            return []
+        arr = np.asarray(ids, dtype=np.int64)
+        n = self.n_nodes
+        node = arr < n
+        if node.all():
+            return self._b.node_names(arr.astype(np.int32))
+        out = np.empty(arr.size, dtype=object)
+        if node.any():
+            out[node] = self._b.node_names(arr[node].astype(np.int32))
+        out[~node] = list(map(self._extra.__getitem__,
+                              (arr[~node] - n).tolist()))
+        return out.tolist()
+
+
+class NativeTaxonomy:
+    """A classification hierarchy built by the native ingest
+    (``_native.HierarchyBuilder``: csrc/wk_hierarchy.cpp).  ``tree``,
+    ``rankdic`` and ``namedic`` are dict views with the reference's meaning
+    (after ``fill_root``), ``root`` the root's name; ``hierarchy()`` hands the
+    pre-order arrays to the device path without any per-node Python object."""
+
+    def __init__(self, n_threads=0):
+        from . import _native
+        self._nat = _native
+        self.builder = _native.HierarchyBuilder(n_threads)
+        self.tree = _DictView(self, _native.HIER_PARENT)
+        self.rankdic = _DictView(self, _native.HIER_RANK)
+        self.namedic = _DictView(self, _native.HIER_NAME)
+        self.root = None
+        self.n_nodes = None
+        self._hier = None
+
+    def add_text(self, kind, buf, rank=None):
+        self.builder.add_text(kind, buf, rank)
+
+    def update(self, field, pairs):
+        if pairs:
+            self.builder.update(field, pairs)
+
+    def finish(self):
+        self.n_nodes = self.builder.finish()
+        self.rank_names, used = self.builder.ranks()
+        # ranks some key carries: `set(rankdic.values())` (workflow.py:665-669)
+        self.ranks_in_use = {r for r, n in zip(self.rank_names, used) if n}
+        self.rank_codes = {r: i + 1 for i, r in enumerate(self.rank_names)}
+        self.root = self.builder.node_names([0])[0] if self.n_nodes else None
+        return self
+
+    def hierarchy(self):
+        if self._hier is None:
+            parent, last, rank_code, depth = self.builder.arrays()
+            self._hier = Hierarchy(NativeIndex(self.builder, self.n_nodes),
+                                   parent, last, rank_code,
+                                   dict(self.rank_codes), depth)
+        else:
+            # a fresh index per engine: names interned later are per job
+            h = self._hier
+            self._hier = Hierarchy(NativeIndex(self.builder, self.n_nodes),
+                                   h.parent, h.last, h.rank_code,
+                                   h.rank_codes, h.depth)
+        return self._hier

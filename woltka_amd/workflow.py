@@ -591,7 +591,9 @@ def prepare_ranks(ranks=None, outmap_dir=None, tree=None, rankdic=None):
     subject counting otherwise.  Several ranks get one map directory each."""
     chosen = ranks.split(',') if ranks else ['free' if tree else 'none']
     if ranks and rankdic is not None:
-        known = set(rankdic.values()) | {'none', 'free'}
+        native = getattr(rankdic, 'native', None)
+        known = (set(rankdic.values()) if native is None
+                 else set(native.ranks_in_use)) | {'none', 'free'}
         unknown = sorted(set(chosen) - known)
         if unknown:
             raise ValueError(f'Ranks {", ".join(unknown)} are not found in '
@@ -613,33 +615,59 @@ def prepare_ranks(ranks=None, outmap_dir=None, tree=None, rankdic=None):
 def build_hierarchy(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
                     columns_fps=[], map_fps=[], map_rank=None, zippers=None):
     """Read all hierarchy files into (tree, rankdic, namedic, root)
-    (workflow.py:698-815)."""
-    tree, rankdic, namedic = {}, {}, {}
+    (workflow.py:698-815).  The three dicts are views of one native table
+    (``hierarchy.NativeTaxonomy``): nodes / names / map files are parsed by the
+    native ingest on all threads (csrc/wk_hierarchy.cpp), the formats with
+    few lines (Newick, lineage strings, rank columns) and text the native
+    readers refuse go through the Python readers of ``tree.py`` and are
+    merged into the same table; merging (``util.update_dict``) and
+    ``fill_root`` happen natively."""
+    from . import _native as nat
+    from .classify import tokenizer_threads
+    from .hierarchy import NativeTaxonomy
+    tax = NativeTaxonomy(tokenizer_threads())
     is_build = any([names_fps, nodes_fps, newick_fps, lineage_fps,
                     columns_fps, map_fps])
     if is_build:
         click.echo('Constructing classification system...')
 
-    def each(fps, label, reader):
+    def python_read(fp, reader):
+        with readzip(fp, zippers) as f:
+            return reader(f)
+
+    def native_read(fp, kind, rank=None):
+        """True when the native reader took the file."""
+        try:
+            with _file_bytes(fp, zippers) as buf:
+                tax.add_text(kind, buf, rank)
+            return True
+        except nat.HierarchyBuilder.Refused:
+            return False
+
+    def each(fps, label):
         for fp in fps:
             click.echo(f'  Parsing {label}: {basename(fp)}...', nl=False)
-            with readzip(fp, zippers) as f:
-                yield reader(f)
+            yield fp
             click.echo(' Done.')
 
-    for names in each(names_fps, 'taxon names file', read_names):
-        _update(namedic, names)
-    for tree_, rankdic_ in each(nodes_fps, 'taxon nodes file', read_nodes):
-        _update(tree, tree_)
-        _update(rankdic, rankdic_)
-    for tree_ in each(newick_fps, 'Newick tree file', read_newick):
-        _update(tree, tree_)
-    for tree_, rankdic_ in each(lineage_fps, 'lineage file', read_lineage):
-        _update(tree, tree_)
-        _update(rankdic, rankdic_)
-    for tree_, rankdic_ in each(columns_fps, 'columns file', read_columns):
-        _update(tree, tree_)
-        _update(rankdic, rankdic_)
+    for fp in each(names_fps, 'taxon names file'):
+        if not native_read(fp, nat.HIER_NAMES):
+            tax.update(nat.HIER_NAME, python_read(fp, read_names))
+    for fp in each(nodes_fps, 'taxon nodes file'):
+        if not native_read(fp, nat.HIER_NODES):
+            tree_, rankdic_ = python_read(fp, read_nodes)
+            tax.update(nat.HIER_PARENT, tree_)
+            tax.update(nat.HIER_RANK, rankdic_)
+    for fp in each(newick_fps, 'Newick tree file'):
+        tax.update(nat.HIER_PARENT, python_read(fp, read_newick))
+    for fp in each(lineage_fps, 'lineage file'):
+        tree_, rankdic_ = python_read(fp, read_lineage)
+        tax.update(nat.HIER_PARENT, tree_)
+        tax.update(nat.HIER_RANK, rankdic_)
+    for fp in each(columns_fps, 'columns file'):
+        tree_, rankdic_ = python_read(fp, read_columns)
+        tax.update(nat.HIER_PARENT, tree_)
+        tax.update(nat.HIER_RANK, rankdic_)
     if map_rank is None:
         map_rank = bool(map_fps) and not any([
             nodes_fps, newick_fps, lineage_fps, columns_fps])
@@ -647,18 +675,42 @@ def build_hierarchy(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
         click.echo('  Will extract rank name from map filename.')
     for fp in map_fps:
         click.echo(f'  Parsing simple map file: {basename(fp)}...', nl=False)
-        with readzip(fp, zippers) as f:
-            map_ = dict(read_map_1st(f))
-        _update(tree, map_)
-        if map_rank:
-            rank = stem2rank(path2stem(fp))
-            _update(rankdic, {k: rank for k in set(map_.values())})
+        rank = stem2rank(path2stem(fp)) if map_rank else None
+        if not native_read(fp, nat.HIER_MAP, rank):
+            map_ = dict(python_read(fp, read_map_1st))
+            tax.update(nat.HIER_PARENT, map_)
+            if map_rank:
+                tax.update(nat.HIER_RANK, {k: rank for k in set(map_.values())})
         click.echo(' Done.')
-    root = fill_root(tree)
+    tax.finish()
     if is_build:
         click.echo('Classification system constructed.')
-        click.echo(f'  Total number of classification units: {len(tree)}.')
-    return tree, rankdic, namedic, root
+        click.echo(f'  Total number of classification units: {tax.n_nodes}.')
+    return tax.tree, tax.rankdic, tax.namedic, tax.root
+
+
+@contextlib.contextmanager
+def _file_bytes(fp, zippers=None):
+    """The bytes of a (possibly compressed) file as a buffer: a plain file is
+    memory-mapped, a compressed one inflated into memory."""
+    import mmap
+    from os.path import splitext
+    from .file import ZIP_BY_EXT
+    if ZIP_BY_EXT.get(splitext(fp)[1]) is None:
+        with open(fp, 'rb') as f:
+            if os.fstat(f.fileno()).st_size == 0:
+                yield b''
+                return
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            view = memoryview(mm)
+            try:
+                yield view
+            finally:
+                view.release()
+                mm.close()
+    else:
+        with readzip_bytes(fp, zippers) as f:
+            yield f.read()
 
 
 def read_strata(strata_fp, zippers=None):
