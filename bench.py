@@ -72,18 +72,40 @@ def measured_traffic(workload, scale):
 # workloads
 # --------------------------------------------------------------------------
 
-def stage_indexed(ctx, prob):
-    """Stage a packed problem the way the host packer does: subjects as dense
-    indices (order of first appearance) + the subject -> feature table, one
-    sample (= one uniform group id) per chunk."""
+def subject_indices(prob):
+    """(feature of every subject, subject index of every record): subjects as
+    dense indices in order of first appearance, like the host packer."""
     feats, first, sidx = np.unique(prob['subj'], return_index=True,
                                    return_inverse=True)
     order = np.argsort(first)               # first-appearance order
     rank_of = np.empty_like(order)
     rank_of[order] = np.arange(order.size)
-    ctx.set_subjects(feats[order].astype(np.int32))
-    ctx.chunk_stage(rank_of[sidx].astype(np.int32), prob['qoff'], group=0,
-                    subj_is_set=True, indexed=True)
+    return feats[order].astype(np.int32), rank_of[sidx].astype(np.int32)
+
+
+def stage_indexed(ctx, prob):
+    """Stage a packed problem the way the host packer does: subject indices +
+    the subject -> feature table, one sample (= one uniform group id) per
+    chunk."""
+    feats, sidx = subject_indices(prob)
+    ctx.set_subjects(feats)
+    ctx.chunk_stage(sidx, prob['qoff'], group=0, subj_is_set=True,
+                    indexed=True)
+    return sidx
+
+
+def packed_words(sidx, qoff):
+    """The records as the native tokenizer hands them over
+    (wk_tok_fetch_packed): subject index | position in the read << 23 | size of
+    the read << 27 (every read of these workloads has <= 16 records)."""
+    off = qoff.astype(np.int64)
+    size = np.diff(off)
+    assert int(size.max()) <= 16
+    words = sidx.astype(np.uint32)
+    words |= (np.arange(words.size, dtype=np.int64) -
+              np.repeat(off[:-1], size)).astype(np.uint32) << np.uint32(23)
+    words |= np.repeat(size, size).astype(np.uint32) << np.uint32(27)
+    return words
 
 
 class FlatWorkload:
@@ -164,18 +186,21 @@ class LcaWorkload:
     key = 'lca'
     dominant = 'classify'
     families = ('classify', 'weigh_merge', 'leftover', 'partition_merge')
-    symbols = {'classify': 'wk::weigh_bins_kernel<4>',
+    symbols = {'classify': 'wk::weigh_bins_kernel<4, true>',
                'weigh_merge': 'wk::weigh_merge_kernel',
                'leftover': 'wk::classify_kernel<true, true, 0>',
                'partition_merge': 'wk::partition_merge_kernel'}
     ranks = ('phylum', 'genus', 'species')
+    packed = True
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
         rng = np.random.default_rng(seed)
         n_reads = int(50_000_000 * scale)
         self.name = (f'synthetic SAM {n_reads / 1e6:g}M reads x <=16 hits, '
-                     '2M-node taxonomy, ranks phylum,genus,species')
+                     '2M-node taxonomy, ranks phylum,genus,species; one '
+                     'sample, records packed by the tokenizer, appended in '
+                     'chunks of 6M reads, one classify launch per sample')
         # (reads are sets of subjects, as the plain parsers produce them)
         self.prob = p = synth.as_sets(synth.lca_problem(
             rng, n_nodes=2_000_000, n_subjects=100_000, n_reads=n_reads,
@@ -187,25 +212,41 @@ class LcaWorkload:
             ctx.build_rank_table(slot, h.rank_codes[rank])
             self.jobs.append(nat.Job(nat.MODE_RANK, slot, 0, 0, 0.0))
         ctx.counts_reserve(1 << 24)
-        # (staging derives one byte per record, the size of its read, on the
-        # device: once per staged chunk, timed here and reported next to the
-        # per-pass figures)
-        ctx.profile_kernels(True)
-        stage_indexed(ctx, p)
-        try:
-            self.read_sizes_ms = ctx.last_kernel_ms('read_sizes')
-        except RuntimeError:
-            self.read_sizes_ms = None
-        ctx.profile_kernels(False)
+        # the general staging (subject indices + read offsets: what the
+        # `--rank free` block below classifies) ...
+        sidx = stage_indexed(ctx, p)
         self.records = int(p['subj'].size)
         self.reads = int(p['qoff'].size - 1)
+        if self.packed:
+            # ... and the product's route for plain ranks: the packed records
+            # of the native tokenizer, appended chunk by chunk as the sample
+            # is read (here: blocks of the size `workflow` stages) and
+            # classified by ONE launch of the weighted histogram over the
+            # whole sample (wk_words_flush).  "words_keep": the records stay
+            # for the next timed pass.
+            words = packed_words(sidx, p['qoff'])
+            ctx.set_option('words_keep', 1)
+            if not ctx.words_begin(self.jobs, 0):
+                raise RuntimeError('the job set does not take packed records')
+            step = 6_000_000
+            off = p['qoff']
+            for lo in range(0, self.reads, step):
+                hi = min(self.reads, lo + step)
+                ctx.words_append(words[int(off[lo]):int(off[hi])], hi - lo)
+            del words
+        del sidx
         # 4 B/record + 4 B/read + parent/last 8 B + 3 rank tables
+        # (kept as the roofline's numerator so that rounds compare; the packed
+        # route itself streams 4 B/record and reads no offsets: DESIGN §3.0)
         self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
                           8 * h.n_nodes + 3 * 4 * h.n_nodes)
         self.launch_bytes = self.alg_bytes
 
     def step(self):
-        self.ctx.classify_staged(self.jobs)
+        if self.packed:
+            self.ctx.words_flush()
+        else:
+            self.ctx.classify_staged(self.jobs)
 
     def sync(self):
         self.ctx.sync()
@@ -240,6 +281,7 @@ class LcaFreeWorkload(LcaWorkload):
     """configs[2], the `--rank free` variant: lowest common ancestor of every
     multi-hit read (one pass, one job)."""
     key = 'lca_free'
+    packed = False
     families = ('classify', 'leftover', 'partition_merge')
     symbols = {'classify': 'wk::classify_single_kernel<true, true, 2, false, true>',
                'leftover': 'wk::classify_kernel<true, true, 0>',
@@ -863,8 +905,6 @@ def config_block(wl, seconds, passes, steps, scale, key):
     achieved = alg / (kern_ms * 1e-3) / 1e9
     ms_pass = seconds * 1e3 / (steps * passes)
     extra = {}
-    if getattr(wl, 'read_sizes_ms', None) is not None:
-        extra['read_sizes_ms_once_per_staged_chunk'] = round(wl.read_sizes_ms, 4)
     return {**extra, 'workload': wl.name, 'records': wl.records, 'reads': wl.reads,
             'ms_per_pass': round(ms_pass, 4),
             'value': round(wl.records / (ms_pass * 1e-3), 1),
@@ -940,11 +980,7 @@ def run_rank(a, rank, world, local, sync):
                    'passes_per_step': passes,
                    'ms_per_pass': block['ms_per_pass'],
                    'timed_region_s': round(elapsed, 3),
-                   'sharding': f'samples x {world} GPUs, no collective',
-                   # derived once when the chunk is staged (outside the passes:
-                   # a real run pays it once per chunk, next to one pass)
-                   'read_sizes_ms_once_per_staged_chunk':
-                       block.get('read_sizes_ms_once_per_staged_chunk')},
+                   'sharding': f'samples x {world} GPUs, no collective'},
         'roofline': block['roofline'],
         'device': ctx.device_name,
         'checksum': checksum,

@@ -147,7 +147,9 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * straight from the matches), "tally_slots" / "tally_per_cu" (LDS cache slots
  * and workgroups per CU of that kernel), "grid_density" (1..8 grid cells per
  * gene; takes effect at the next wk_set_genes), "match_lds" (0/1: per-genome
- * words of the coordinate grid in LDS), "free_sparse" (0/1: `--rank free` on
+ * words of the coordinate grid in LDS), "words_keep" (0/1, measurement: wk_words_flush classifies the accumulated
+ * packed records but leaves them in place, so that a benchmark can time
+ * repeated passes over one resident batch), "free_sparse" (0/1: `--rank free` on
  * chunks of subject indices looks the LCA up in a sparse table over the
  * subjects instead of walking up the tree).
  * Results never depend on them. */
@@ -236,6 +238,35 @@ int wk_chunk_stage(wk_ctx* ctx, const int32_t* subj, const int32_t* qoff,
  * (job-major): feature id, or WK_ASSIGN_*. */
 int wk_classify_staged(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
                        int32_t* out_assign);
+
+/* ---- packed records, accumulated over the chunks of one sample ------------
+ * The native tokenizer hands the plain flavour's records over as one word each
+ * (wk_tok_fetch_packed): subject index (23 bits) | position of the record in
+ * its read << 23 (4 bits) | size of its read << 27 (1..16).  For the plain
+ * assigners — classify.assign_none / assign_rank without --uniq, --major,
+ * --above, followed by classify.counter (classify.py:32-51, 81-127, 144-171)
+ * — that word is all the device needs (wk_weigh.hpp): the chunks of a sample
+ * (workflow.py:304-335 loops over them) are appended to one device buffer as
+ * they are tokenised, asynchronously from pinned memory, and classified by one
+ * launch when the sample ends (wk_words_flush; wk_counts_fetch flushes too).
+ *
+ * wk_words_begin declares the jobs and the group (sample) of the records that
+ * follow; *ok = 0 means this job set / subject table needs the general path
+ * (wk_chunk_stage + wk_classify_staged) — e.g. a subject without an ancestor
+ * at a requested rank (its reads change k, classify.py:167-168).  Records
+ * accumulated under other jobs or another group are classified first.
+ * wk_words_append copies one chunk; with slot >= 0 the copy is only enqueued
+ * and `words` (pinned: wk_host_alloc) must stay untouched until
+ * wk_words_wait(slot) returns; slot = -1 copies before returning. */
+int wk_host_alloc(wk_ctx* ctx, size_t bytes, void** out);
+int wk_host_free(wk_ctx* ctx, void* p);
+int wk_words_begin(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
+                   int32_t group, int* ok);
+int wk_words_append(wk_ctx* ctx, const uint32_t* words, int64_t n_records,
+                    int64_t n_reads, int slot);
+int wk_words_wait(wk_ctx* ctx, int slot);
+int wk_words_flush(wk_ctx* ctx);
+int wk_words_pending(wk_ctx* ctx, int64_t* n_records, int64_t* n_reads);
 
 /* Convenience: stage + classify in one call from host buffers. */
 int wk_classify_chunk(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
@@ -347,6 +378,16 @@ int wk_tok_boundary(int fmt, int extra, const char* buf, int64_t len,
  * (byte offset in buf << 24) | (length << 2) | mate.  NULL skips an array. */
 int wk_tok_fetch(wk_tok* tok, int32_t* subj, int32_t* off, int32_t* beg,
                  int32_t* end, uint32_t* len, uint64_t* qname);
+/* The plain flavour's records in the form the weighted histogram of the device
+ * streams (wk_words_append): packed[i] = subject index | position of record i
+ * in its read << 23 | size << 27, size = the number of records of its read
+ * (the k of classify.counter, classify.py:167-170) when that is <=
+ * WK_WEIGHT_MAX_K, else position and size are 0; *n_big = reads with more
+ * records than that.  Filled by all tokenizer threads straight from
+ * their own buffers (no intermediate copy): `packed`, `off` and `qname` may be
+ * pinned staging memory.  WK_E_RANGE beyond 2^23 subjects. */
+int wk_tok_fetch_packed(wk_tok* tok, uint32_t* packed, int32_t* off,
+                        uint64_t* qname, int64_t* n_big);
 /* `want_names` of wk_tok_sam is a bit set: 1 = QNAME descriptors, 2 = stratum of
  * every read (read id = QNAME + "" | "/1" | "/2" looked up in the table loaded
  * with wk_tok_strata_load; -1 = not found: the read is skipped by the

@@ -525,3 +525,48 @@ def test_b6o_ex_needs_a_float_score():
         list(align.parse_align(bad, 'b6o', None, True))
     with pytest.raises(ValueError):
         run_native(''.join(bad).encode(), 1, 1 << 16, extra=True, fmt='b6o')
+
+
+@pytest.mark.parametrize('threads,block', [(1, 1 << 20), (4, 3000), (7, 700)])
+def test_packed_words_equal_the_plain_arrays(threads, block):
+    """wk_tok_fetch_packed: subject | position << 23 | size << 27 per record,
+    against the subject / offset arrays of the same blocks; a block with a
+    read of more than 16 subjects comes back the general way."""
+    import random
+    rng = random.Random(block)
+    lines = ['@HD\tVN:1.0\n']
+    for q in range(600):
+        k = rng.choice([1, 1, 2, 5, 16])
+        for s in rng.sample(range(300), k):
+            lines.append(f'q{q}\t0\tS{s}\t1\t42\t10M\t*\t0\t0\t*\t*\n')
+        if rng.random() < 0.1:          # a duplicate subject: sets on the device
+            lines.append(lines[-1])
+    text = ''.join(lines).encode()
+    plain = []
+    tok = Tokenizer(threads)
+    for buf, res in align.native_sam_blocks(io.BytesIO(text), tok, block):
+        plain.append((res['subj'].copy(), res['off'].copy()))
+    tok.close()
+    tok = Tokenizer(threads)
+    bufs = [np.zeros(1 << 16, np.uint32) for _ in range(64)]
+    it = iter(bufs)
+    got = []
+    for buf, res in align.native_sam_blocks(io.BytesIO(text), tok, block,
+                                            packed_buf=lambda: next(it)):
+        assert 'words' in res
+        got.append((res['words'].copy(), res['n_reads']))
+    tok.close()
+    assert len(got) == len(plain)
+    for (w, n_reads), (subj, off) in zip(got, plain):
+        assert n_reads == off.size - 1 and w.size == subj.size
+        assert ((w & 0x7FFFFF) == subj).all()
+        size = np.repeat(np.diff(off), np.diff(off))
+        pos = np.arange(subj.size) - np.repeat(off[:-1], np.diff(off))
+        assert ((w >> 27) == size).all() and (((w >> 23) & 15) == pos).all()
+    # a read of 17 subjects: that block falls back to subject / offset arrays
+    big = ''.join(f'big\t0\tS{s}\t1\t42\t10M\t*\t0\t0\t*\t*\n' for s in range(17))
+    tok = Tokenizer(threads)
+    res = tok.parse(memoryview(text + big.encode()), first=True, final=True,
+                    packed_out=np.zeros(1 << 16, np.uint32))
+    assert 'words' not in res and int(np.diff(res['off']).max()) == 17
+    tok.close()

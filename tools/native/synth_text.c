@@ -51,7 +51,7 @@ static char* put_uint(char* p, uint32_t v) { return put_fixed(p, v, udigits(v));
 static int64_t line_len(const Job* j, int64_t i) {
     /* q + 9 + \t + flag + \t + s + swidth + \t + pos + \t42\t + len + "M\t*\t0\t0\t*\t*\n" */
     return 1 + 9 + 1 + udigits(j->flag ? (uint32_t)j->flag[i] : 0u) + 1 + 1 + j->swidth + 1 +
-           udigits(j->pos ? (uint32_t)j->pos[i] : 1u) + 4 + udigits(j->alen ? (uint32_t)j->alen[i] : 150u) + 13;
+           udigits(j->pos ? (uint32_t)j->pos[i] : 1u) + 4 + udigits(j->alen ? (uint32_t)j->alen[i] : 150u) + 12;
 }
 
 static void* size_job(void* arg) {
@@ -89,8 +89,8 @@ static void* write_job(void* arg) {
         memcpy(p, "\t42\t", 4);
         p += 4;
         p = put_uint(p, j->alen ? (uint32_t)j->alen[i] : 150u);
-        memcpy(p, tail, 13);
-        p += 13;
+        memcpy(p, tail, 12);
+        p += 12;
         if ((size_t)(p - buf) >= cap || i + 1 == j->hi) {
             size_t left = (size_t)(p - buf);
             const char* q = buf;

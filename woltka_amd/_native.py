@@ -40,12 +40,14 @@ SYMBOLS = (
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
     'wk_set_uniform_group', 'wk_chunk_download',
+    'wk_host_alloc', 'wk_host_free', 'wk_words_begin', 'wk_words_append',
+    'wk_words_wait', 'wk_words_flush', 'wk_words_pending',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
     'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
     'wk_tok_set_exclude', 'wk_tok_sam_tail', 'wk_tok_sam', 'wk_tok_text',
     'wk_tok_boundary',
-    'wk_tok_fetch',
+    'wk_tok_fetch', 'wk_tok_fetch_packed',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
@@ -120,6 +122,14 @@ def load_library():
         'wk_set_uniform_group': (C.c_int, [p, C.c_int32]),
         'wk_chunk_download': (C.c_int, [p, i32p, C.c_int64, i32p, C.c_int64,
                                         i64p, i64p]),
+        'wk_host_alloc': (C.c_int, [p, C.c_size_t, C.POINTER(C.c_void_p)]),
+        'wk_host_free': (C.c_int, [p, C.c_void_p]),
+        'wk_words_begin': (C.c_int, [p, C.POINTER(Job), C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_int)]),
+        'wk_words_append': (C.c_int, [p, u32p, C.c_int64, C.c_int64, C.c_int]),
+        'wk_words_wait': (C.c_int, [p, C.c_int]),
+        'wk_words_flush': (C.c_int, [p]),
+        'wk_words_pending': (C.c_int, [p, i64p, i64p]),
         'wk_get_stats': (C.c_int, [p, C.POINTER(Stats)]),
         'wk_reset_stats': (C.c_int, [p]),
         'wk_timer_begin': (C.c_int, [p]),
@@ -144,6 +154,7 @@ def load_library():
                                   C.c_int, C.c_int, C.c_int, i64p, i64p,
                                   i64p]),
         'wk_tok_fetch': (C.c_int, [p, i32p, i32p, i32p, i32p, u32p, u64p]),
+        'wk_tok_fetch_packed': (C.c_int, [p, u32p, i32p, u64p, i64p]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
         'wk_tok_fetch_groups': (C.c_int, [p, i32p]),
@@ -400,6 +411,45 @@ class Context:
         self._check(self._lib.wk_ordinal_count(self._h, self._jobs(jobs),
                                                len(jobs)))
 
+    # -- packed records accumulated over a sample's chunks ------------------
+    WORD_SUBJ_BITS, WORD_POS_SHIFT, WORD_SIZE_SHIFT = 23, 23, 27
+    STAGE_SLOTS = 8
+
+    def host_alloc(self, n, dtype=np.uint32):
+        """A pinned host array of ``n`` elements (owned by the context)."""
+        dt = np.dtype(dtype)
+        out = C.c_void_p()
+        self._check(self._lib.wk_host_alloc(self._h, int(n) * dt.itemsize,
+                                            C.byref(out)))
+        buf = (C.c_char * (int(n) * dt.itemsize)).from_address(out.value)
+        arr = np.frombuffer(buf, dtype=dt, count=int(n))
+        return arr
+
+    def words_begin(self, jobs, group):
+        ok = C.c_int(0)
+        self._check(self._lib.wk_words_begin(self._h, self._jobs(jobs),
+                                             len(jobs), int(group),
+                                             C.byref(ok)))
+        return bool(ok.value)
+
+    def words_append(self, words, n_reads, slot=-1):
+        words = _arr(words, np.uint32)
+        self._check(self._lib.wk_words_append(
+            self._h, _ptr(words, C.c_uint32), words.size, int(n_reads),
+            int(slot)))
+
+    def words_wait(self, slot):
+        self._check(self._lib.wk_words_wait(self._h, int(slot)))
+
+    def words_flush(self):
+        self._check(self._lib.wk_words_flush(self._h))
+
+    def words_pending(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.wk_words_pending(self._h, C.byref(a),
+                                               C.byref(b)))
+        return a.value, b.value
+
     def set_uniform_group(self, group):
         self._check(self._lib.wk_set_uniform_group(self._h, int(group)))
 
@@ -639,7 +689,7 @@ class Tokenizer:
 
     def parse(self, buf, first=False, final=False, extra=False,
               want_names=False, want_groups=False, want_samples=False,
-              fmt='sam'):
+              fmt='sam', packed_out=None):
         """Tokenize ``buf`` (bytes-like) of alignment format ``fmt``
         (sam / map / b6o / paf).  Returns a dict with ``consumed``,
         ``subj``, ``off`` (+ ``beg``/``end``/``len`` with ``extra``,
@@ -660,6 +710,22 @@ class Tokenizer:
             int(bool(want_names)) | (2 if want_groups else 0) |
             (4 if want_samples else 0),
             C.byref(consumed), C.byref(nrd), C.byref(nrec)))
+        if packed_out is not None and not extra and not want_names and \
+                not want_groups and not want_samples and \
+                nrec.value <= packed_out.size:
+            # the records as packed words, written by all tokenizer threads
+            # straight into the caller's (pinned) buffer; blocks with reads
+            # of more than 16 records take the general route below
+            n_big = C.c_int64(0)
+            rc = self._lib.wk_tok_fetch_packed(
+                self._h, _ptr(packed_out, C.c_uint32), None, None,
+                C.byref(n_big))
+            if rc == OK and n_big.value == 0:
+                return {'consumed': consumed.value,
+                        'words': packed_out[:nrec.value],
+                        'n_reads': nrd.value}
+            if rc not in (OK, E_RANGE):
+                self._check(rc)
         out = {'consumed': consumed.value,
                'subj': np.empty(nrec.value, np.int32),
                'off': np.empty(nrd.value + 1, np.int32)}

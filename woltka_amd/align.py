@@ -354,7 +354,8 @@ def _tail_block(tok, exclude, extra, want_names, want_groups, want_samples,
 
 def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
                       want_names=False, head=b'', want_groups=False,
-                      want_samples=False, fmt='sam', part=None, exclude=None):
+                      want_samples=False, fmt='sam', part=None, exclude=None,
+                      packed_buf=None):
     """Feed a binary alignment stream (SAM by default; map / b6o / paf via
     ``fmt``) through the native tokenizer (``_native.Tokenizer``) block by
     block.
@@ -368,11 +369,14 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
     A regular uncompressed file is memory-mapped and tokenised in place (no
     copies); pipes and codec streams are read into one reusable buffer.
     """
+    # ``packed_buf``: a callable handing out one (pinned) uint32 buffer per
+    # block; blocks whose records fit come back as packed words
+    # (``result['words']``, the buffer itself) instead of ``subj`` / ``off``
     mm = _try_mmap(stream)
     if mm is not None:
         yield from _blocks_mmap(mm, len(head), tok, block_bytes, extra,
                                 want_names, want_groups, want_samples, fmt,
-                                part, exclude)
+                                part, exclude, packed_buf)
         return
     if part is not None:
         raise ValueError('A byte range needs a regular uncompressed file.')
@@ -412,9 +416,10 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
             return
         res = tok.parse(view[:fill], first=first, final=final, extra=extra,
                         want_names=want_names, want_groups=want_groups,
-                        want_samples=want_samples, fmt=fmt)
+                        want_samples=want_samples, fmt=fmt,
+                        packed_out=packed_buf() if packed_buf else None)
         used = res['consumed']
-        if used == 0 and not final and res['off'].size == 1:
+        if used == 0 and not final and _n_reads(res) == 0:
             del view
             if fill == len(buf):
                 buf = grown(buf, fill)
@@ -459,9 +464,13 @@ def _try_mmap(stream):
         return None
 
 
+def _n_reads(res):
+    return res['n_reads'] if 'words' in res else res['off'].size - 1
+
+
 def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
                  want_groups=False, want_samples=False, fmt='sam', part=None,
-                 exclude=None):
+                 exclude=None, packed_buf=None):
     """Tokenise a memory-mapped file in place.  ``start`` bytes were already
     read from the stream for format sniffing; the map covers the whole file,
     so they are simply parsed again from offset 0.  ``part`` = (i, n) restricts
@@ -492,9 +501,10 @@ def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
             res = tok.parse(view[pos:end], first=first, final=final,
                             extra=extra, want_names=want_names,
                             want_groups=want_groups,
-                            want_samples=want_samples, fmt=fmt)
+                            want_samples=want_samples, fmt=fmt,
+                            packed_out=packed_buf() if packed_buf else None)
             used = res['consumed']
-            if used == 0 and not final and res['off'].size == 1:
+            if used == 0 and not final and _n_reads(res) == 0:
                 span *= 2
                 continue
             first = False

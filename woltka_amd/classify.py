@@ -122,6 +122,39 @@ class MapWriter:
             self._pool.shutdown(wait=True)
 
 
+class WordRing:
+    """Pinned host buffers for the packed records of the native tokenizer
+    (``_native.Context.host_alloc``): the tokenizer thread fills one while
+    earlier ones wait in the prefetch queue or are being copied to the device
+    (``wk_words_append`` only enqueues the copy).  ``current()`` blocks until a
+    buffer is free, ``take()`` hands the current one to a block, the consumer
+    gives it back with ``release()`` once its copy has finished."""
+
+    def __init__(self, ctx, slots, capacity):
+        import queue
+        self._ctx, self.capacity = ctx, int(capacity)
+        self._bufs = [None] * slots         # allocated on first use
+        self._free = queue.Queue()
+        for i in range(slots):
+            self._free.put(i)
+        self._cur = None
+
+    def current(self):
+        if self._cur is None:
+            self._cur = self._free.get()
+        i = self._cur
+        if self._bufs[i] is None:
+            self._bufs[i] = self._ctx.host_alloc(self.capacity, np.uint32)
+        return self._bufs[i]
+
+    def take(self):
+        i, self._cur = self._cur, None
+        return i
+
+    def release(self, slot):
+        self._free.put(slot)
+
+
 _NO_TREE_ROOT = '\x00root'      # stand-in root when no hierarchy is given
 MAX_GROUPS = 1 << nat.KEY_GROUP_BITS
 
@@ -231,6 +264,25 @@ class Engine:
         self._tok_identity = True
         self._tok_genome = np.empty(0, dtype=np.int32)
         self._tok_cover = np.empty(0, dtype=np.int64)
+        self._ring, self._ring_prev = None, None    # packed-record staging
+
+    def words_eligible(self):
+        """Can chunks go to the device as packed words, accumulated per
+        sample (``wk_words_*``)?  The plain assigners only — what
+        ``wk_words_begin`` checks once more against the subject table."""
+        if self.sizes or self._replay is not None or \
+                len(self.jobs) > nat.MAX_JOBS or not self._tok_identity or \
+                os.environ.get('WOLTKA_NO_WORDS'):
+            return False
+        for job in self.jobs:
+            if job.flags & (nat.F_UNIQ | nat.F_SIZED):
+                return False
+            if job.mode == nat.MODE_RANK and (job.flags & nat.F_ABOVE or
+                                              job.major > 0):
+                return False
+            if job.mode not in (nat.MODE_NONE, nat.MODE_RANK):
+                return False
+        return True
 
     def close(self):
         try:
@@ -293,7 +345,7 @@ class Engine:
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,
                       want_strings=True, want_samples=False, cover=None,
-                      fmt='sam', part=None):
+                      fmt='sam', part=None, words=False):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed, strata ids, name descriptors, sample ids,
         ranges) where packed = (subj, qoff) of subject indices, or for
@@ -305,6 +357,12 @@ class Engine:
         if self.tok is None:
             self.tok = nat.Tokenizer(tokenizer_threads(), exclude)
         tok = self.tok
+        ring = None
+        if words:
+            if self._ring is None:
+                # records of a block: a line has at least ~24 bytes
+                self._ring = WordRing(self.ctx, 5, block_bytes // 24 + 4096)
+            ring = self._ring
 
         def blocks():
             for buf, res in native_sam_blocks(stream, tok, block_bytes,
@@ -315,7 +373,11 @@ class Engine:
                                               want_groups=want_groups,
                                               want_samples=want_samples,
                                               fmt=fmt, part=part,
-                                              exclude=exclude):
+                                              exclude=exclude,
+                                              packed_buf=ring.current
+                                              if ring else None):
+                if 'words' in res:
+                    res['slot'] = ring.take()
                 # the dictionary growth belongs to this block: fetch it before
                 # the tokenizer moves on
                 yield buf, res, tok.new_subjects(), \
@@ -346,6 +408,14 @@ class Engine:
                             ids, np.arange(base, base + ids.size)):
                         self._tok_identity = False
                     self._tok_map = np.concatenate([self._tok_map, ids])
+            if 'words' in res:
+                del buf
+                if res['n_reads']:
+                    yield None, ('words', res['words'], res['n_reads'],
+                                 res['slot']), None, None, None, None
+                else:
+                    ring.release(res['slot'])
+                continue
             reads = nat.Tokenizer.query_names(buf, res['qname']) \
                 if (want_names and want_strings) else None
             names = (buf, res['qname']) if (want_names and not want_strings) \
@@ -494,6 +564,8 @@ class Engine:
         reference would report for it (workflow.py:305).  ``packed`` carries
         arrays produced by the native tokenizer instead of ``subque`` / staged
         hits."""
+        if packed is not None and isinstance(packed[0], str):
+            return self._run_words(data, packed, sample_of)
         n = len(reads) if packed is None else packed[-1].size - 1
         # room for the (sample, stratum) groups this chunk can add
         if sample_ids is not None:
@@ -588,6 +660,65 @@ class Engine:
             self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,
                              outzip, namedic)
         return nq
+
+    def _run_words(self, data, packed, sample):
+        """One chunk of packed records (``('words', array, n_reads, slot)``
+        from `native_chunks`): appended to the sample's records on the device,
+        which are classified by one launch when the sample ends
+        (``wk_words_flush`` — any fetch of the counts flushes)."""
+        _, words, n, slot = packed
+        ring = self._ring
+        if (sample, None) not in self.group_ids:
+            # a new sample: room for its group id and for the keys it can add
+            # (one per job and taxon, at most one per subject) — checked once
+            # per sample, not per chunk: looking at the table waits for the
+            # device
+            if len(self.groups) + 1 >= MAX_GROUPS // 2:
+                self.collect(data)
+            self._ensure_table(data, max(len(self.subjects), 1 << 16) + 1, 1)
+        group = self._group_array(n, sample, None)
+        for rank in self.ranks:
+            data[rank].setdefault(sample, {})
+        self._n_reads += n
+        known = len(self.subj_feature)
+        if len(self.subjects) > known:
+            self.subj_feature.extend(self.index.intern_many(
+                self.subjects.names[known:]))
+            self.ctx.set_subjects(self.subj_feature)
+            # (a key per job and subject at most; the table is never left to
+            # fill up)
+            if 4 * len(self.subjects) * len(self.jobs) > self.slots_reserved \
+                    and not self._table_fixed:
+                self.collect(data, keep_groups=True)
+                self._reserve(8 * len(self.subjects) * len(self.jobs))
+        if self.ctx.words_begin(self.jobs, group):
+            self.ctx.words_append(words, n, slot)
+            # the buffer of the chunk before this one has been copied by now
+            if self._ring_prev is not None:
+                self.ctx.words_wait(self._ring_prev)
+                ring.release(self._ring_prev)
+            self._ring_prev = slot
+            return n
+        # the general route (a subject without an ancestor at some rank):
+        # subject indices and read offsets out of the words
+        w = np.array(words)                 # (off the pinned buffer)
+        ring.release(slot)
+        subj = (w & np.uint32((1 << nat.Context.WORD_SUBJ_BITS) - 1)
+                ).astype(np.int32)
+        starts = np.flatnonzero((w >> np.uint32(nat.Context.WORD_POS_SHIFT)) &
+                                np.uint32(15) == 0)
+        qoff = np.concatenate((starts, [w.size])).astype(np.int32)
+        self.ctx.chunk_stage(subj, qoff, group=group, subj_is_set=True,
+                             indexed=True)
+        self._classify_staged(data, False)
+        return n
+
+    def _words_done(self):
+        """The last staging buffer in flight goes back to the ring."""
+        if self._ring_prev is not None:
+            self.ctx.words_wait(self._ring_prev)
+            self._ring.release(self._ring_prev)
+            self._ring_prev = None
 
     # ------------------------------------------------------------------
     # Certification of the rounding and replay in the reference's order
@@ -1008,6 +1139,7 @@ class Engine:
         once, ``exact_to_numbers``)."""
         if self._writer is not None:
             self._writer.flush()
+        self._words_done()
         self.collect(data)
         # (kept for the certifier, `uncertified`)
         self._final = {k: (v, dict(self._big.get(k, {})))

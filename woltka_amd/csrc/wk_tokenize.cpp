@@ -17,11 +17,18 @@
 // indices wk_set_subjects expects).  A block of text is cut into byte ranges at
 // run boundaries, one range per thread; ranges are tokenised independently and
 // concatenated, so the output does not depend on the thread count.
+#include <immintrin.h>
+
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,9 +47,72 @@ struct Record {
     uint32_t len;
 };
 
+// Read-only lookup structure over the subject dictionary for the tokenizer
+// threads: one 16-byte slot per name {hash, id, offset of the name's bytes}, the
+// bytes behind a 4-byte length in an arena of their own — a hit costs one slot
+// and one short compare (NameTable: slot -> hash[] -> len[] -> arena).
+struct FastDict {
+    struct Slot {
+        uint64_t hash;
+        int32_t id;  // -1 = empty
+        uint32_t off;
+    };
+    std::vector<Slot> slot;
+    std::string arena;
+    size_t mask = 0;
+    int32_t count = 0;
+    FastDict() { resize(1 << 12); }
+    void resize(size_t n) {
+        std::vector<Slot> old;
+        old.swap(slot);
+        slot.assign(n, Slot{0, -1, 0});
+        mask = n - 1;
+        for (const Slot& x : old)
+            if (x.id >= 0) place(x);
+    }
+    void place(const Slot& x) {
+        size_t h = x.hash & mask;
+        while (slot[h].id >= 0) h = (h + 1) & mask;
+        slot[h] = x;
+    }
+    void insert(const char* p, size_t n, uint64_t hv, int32_t id) {
+        if ((size_t)(count + 1) * 2 > slot.size()) resize(slot.size() * 2);
+        const uint32_t ln = (uint32_t)n;
+        const uint32_t off = (uint32_t)arena.size();
+        arena.append(reinterpret_cast<const char*>(&ln), 4);
+        arena.append(p, n);
+        place(Slot{hv, id, off});
+        count += 1;
+    }
+    void prefetch(uint64_t hv) const { __builtin_prefetch(&slot[hv & mask]); }
+    int32_t find(const char* p, size_t n, uint64_t hv) const {
+        size_t h = hv & mask;
+        for (;;) {
+            const Slot& x = slot[h];
+            if (x.id < 0) return -1;
+            if (x.hash == hv) {
+                uint32_t ln;
+                memcpy(&ln, arena.data() + x.off, 4);
+                if (ln == n && memcmp(arena.data() + x.off + 4, p, n) == 0) return x.id;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+    void clear() {
+        slot.assign(slot.size(), Slot{0, -1, 0});
+        arena.clear();
+        count = 0;
+    }
+};
+
+// What one tokenizer thread produces for its byte range; kept between calls so
+// that the buffers are allocated (and their pages touched) once.
 struct Local {
-    std::vector<Record> rec;     // records of emitted reads, read-major
-    std::vector<int32_t> rend;   // per read: end offset into rec
+    // records of emitted reads, read-major: plain flavour `subj` only, "ex"
+    // flavour `rec`
+    std::vector<int32_t> subj;   // global id >= 0, or -(1 + local new-name id)
+    std::vector<Record> rec;
+    std::vector<int32_t> rend;   // per read: end offset into the records
     std::vector<uint64_t> qname; // per read: (offset << 24) | (len << 2) | mate
     std::vector<int32_t> group;  // per read: stratum id or -1 (want_groups)
     std::vector<int32_t> sample; // per read: sample id >= 0, or -(1 + local new-name id) (want_samples)
@@ -60,6 +130,27 @@ struct Local {
     const char* fin_q = nullptr;
     size_t fin_qn = 0;
     std::vector<std::pair<const char*, const char*>> pool_lines;
+    int64_t n_big = 0;  // reads with more than WK_WEIGHT_MAX_K records
+    void reset() {
+        subj.clear();
+        rec.clear();
+        rend.clear();
+        qname.clear();
+        group.clear();
+        sample.clear();
+        if (fresh.size()) fresh = NameTable();
+        if (fresh_samples.size()) fresh_samples = NameTable();
+        error = 0;
+        error_at = 0;
+        any_run = false;
+        fin_keep = true;
+        have_pool = false;
+        fin_q = nullptr;
+        fin_qn = 0;
+        pool_lines.clear();
+        n_big = 0;
+    }
+    size_t n_records(bool extra) const { return extra ? rec.size() : subj.size(); }
 };
 
 struct Line {
@@ -77,7 +168,13 @@ struct Line {
     int32_t beg, end;
     uint32_t len;
     bool bad_number;  // a field Python's int() would refuse (the reference raises)
+    // the line itself (without its newline) and the hash of its subject name
+    const char* line;
+    const char* le;
+    uint64_t rh;
 };
+
+constexpr size_t kScanSlack = 64;  // bytes the vector scanner wants ahead of a line start
 
 // split the first 3 (or 6) tab-separated fields of [p, e)
 inline Line parse_line(const char* p, const char* e, bool extra) {
@@ -267,15 +364,113 @@ inline const char* next_line(const char* p, const char* e) {
 
 }  // namespace
 
+// WOLTKA_TOK_TIMING=1 in the environment: time per phase, summed over the
+// tokenizer's life and printed when it is destroyed (measurement)
+struct TokLap {
+    static bool enabled() {
+        static const bool on = getenv("WOLTKA_TOK_TIMING") != nullptr;
+        return on;
+    }
+    double* acc;
+    std::chrono::steady_clock::time_point t;
+    explicit TokLap(double* a) : acc(a) {
+        if (enabled()) t = std::chrono::steady_clock::now();
+    }
+    void operator()(int phase) {
+        if (!enabled()) return;
+        const auto n = std::chrono::steady_clock::now();
+        acc[phase] += std::chrono::duration<double, std::milli>(n - t).count();
+        t = n;
+    }
+};
+enum { LAP_CUTS, LAP_TOKENIZE, LAP_MERGE, LAP_FETCH, LAP_N };
+
+// Worker threads that live as long as the tokenizer: a block is tokenised in
+// two or three parallel steps, and a step of a few milliseconds does not pay
+// for creating its threads.
+class WorkPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable wake, done;
+    const std::function<void(int)>* job = nullptr;
+    int n_items = 0, next = 0, running = 0;
+    uint64_t epoch = 0;
+    bool stop = false;
+
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            wake.wait(lk, [&] { return stop || epoch != seen; });
+            if (stop) return;
+            seen = epoch;
+            while (next < n_items) {
+                const int i = next++;
+                lk.unlock();
+                (*job)(i);
+                lk.lock();
+            }
+            if (--running == 0) done.notify_all();
+        }
+    }
+
+  public:
+    explicit WorkPool(int n) {
+        for (int i = 0; i < n; ++i) workers.emplace_back([this] { loop(); });
+    }
+    ~WorkPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (auto& w : workers) w.join();
+    }
+    int size() const { return (int)workers.size(); }
+    // fn(0) .. fn(n - 1), each once, on the workers; returns when all are done
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (n == 1 || workers.empty()) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(m);
+        job = &fn;
+        n_items = n;
+        next = 0;
+        running = (int)workers.size();
+        ++epoch;
+        wake.notify_all();
+        done.wait(lk, [&] { return running == 0; });
+        job = nullptr;
+    }
+};
+
 struct wk_tok {
     int n_threads = 1;
     NameTable names;     // global subject dictionary (sidx = id)
+    FastDict dict;       // the same names, laid out for the tokenizer threads' lookups
     NameTable exclude;
     std::string err;
-    // outputs of the last call
-    std::vector<int32_t> subj, off, beg, end;
-    std::vector<uint32_t> len;
-    std::vector<uint64_t> qname;
+    WorkPool* pool = nullptr;
+    // results of the last call, per thread range, until they are fetched
+    std::vector<Local> loc;
+    int n_loc = 0;
+    bool last_extra = false;
+    int last_want = 0;
+    std::vector<std::vector<int32_t>> remap, sremap;  // fresh name ids -> global ids, per range
+    std::vector<int64_t> rbase, qbase;
+    int64_t tot_reads = 0, tot_rec = 0, tot_big = 0;
+    int (*produce_sam)(const char*&, const char*, bool, const FastDict&, Line*, int) = nullptr;
+    double lap_ms[LAP_N] = {0, 0, 0, 0};
+    int64_t lap_calls = 0, lap_bytes = 0;
+    ~wk_tok() {
+        if (TokLap::enabled() && lap_calls)
+            fprintf(stderr, "[wk_tok] %d threads, %lld calls, %.1f MB: cuts %.1f ms, tokenize %.1f ms, merge %.1f ms, fetch %.1f ms\n",
+                    n_threads, (long long)lap_calls, lap_bytes / 1e6, lap_ms[LAP_CUTS], lap_ms[LAP_TOKENIZE], lap_ms[LAP_MERGE],
+                    lap_ms[LAP_FETCH]);
+        delete pool;
+    }
     int32_t reported = 0;  // subjects already handed to the caller
     bool in_header = false; // still inside the leading '@' lines of a file
     // state of parse_sam_file_ex_ft's variables after the text seen so far (see Local)
@@ -295,151 +490,237 @@ struct wk_tok {
         const int32_t id = strata_keys[sh].find(p, n, hv);
         return id < 0 ? -1 : strata_of[sh][id];
     }
-    std::vector<int32_t> group;      // per read of the last call: stratum id or -1
     // demultiplexing (workflow.demultiplex, workflow.py:844-909): sample = text
     // before the first '_' of the read id, if anything follows it
     NameTable samples;
-    std::vector<int32_t> sample;     // per read of the last call
     int32_t samples_reported = 0;
 };
 
 namespace {
 
+// the vector scanners of SAM lines (wk_tok_scan.inc), one per instruction set
+#define WK_SCAN_W 16
+#define WK_SCAN_NAME produce_sam_sse2
+#define WK_SCAN_ATTR
+#include "wk_tok_scan.inc"
+#undef WK_SCAN_W
+#undef WK_SCAN_NAME
+#undef WK_SCAN_ATTR
+#define WK_SCAN_W 32
+#define WK_SCAN_NAME produce_sam_avx2
+#define WK_SCAN_ATTR __attribute__((target("avx2")))
+#include "wk_tok_scan.inc"
+#undef WK_SCAN_W
+#undef WK_SCAN_NAME
+#undef WK_SCAN_ATTR
+
+// Lines of any format through the memchr parsers (parse_row): what the vector
+// scanner leaves over at the end of a range, and every format but SAM.
+int produce_rows(int fmt, const char*& pos, const char* e, bool extra, const FastDict& dict, Line* out, int max) {
+    const char* p = pos;
+    int n = 0;
+    while (n < max && p < e) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+        const char* le = nl ? nl : e;
+        Line L = parse_row(fmt, p, le, extra);
+        L.line = p;
+        L.le = le;
+        p = nl ? nl + 1 : e;
+        if (L.ok) {
+            if (fmt == WK_FMT_SAM && is_unmapped(L)) continue;
+            L.rh = hash_bytes(L.r, L.rn);
+            dict.prefetch(L.rh);
+        }
+        out[n++] = L;
+    }
+    pos = p;
+    return n;
+}
+
+inline bool same_name(const char* a, size_t an, const char* b, size_t bn) {
+    return an == bn && memcmp(a, b, an) == 0;
+}
+
+template <bool kExtra>
 void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, const char* e, int extra_bits, bool want_names,
                     bool want_groups, bool want_samples, Local& out) {
-    const bool extra = (extra_bits & 1) != 0, keep_empty = (extra_bits & 2) != 0;
+    const bool keep_empty = (extra_bits & 2) != 0;
     const bool filt = T->exclude.size() > 0;
-    const bool track_pool = extra && filt && fmt == WK_FMT_SAM;
+    const bool track_pool = kExtra && filt && fmt == WK_FMT_SAM;
     static const char* const kSuffix[3] = {"", "/1", "/2"};
     std::string keybuf;
+    // room for the range's records up front (a trimmed SAM line is ~40 bytes)
+    {
+        const size_t guess = (size_t)(e - b) / 36 + 1024;
+        if (kExtra)
+            out.rec.reserve(guess);
+        else
+            out.subj.reserve(guess);
+        out.rend.reserve(guess / 2 + 1024);
+    }
     // current run state
     const char* cur = nullptr;
     size_t cur_n = 0;
     bool keep = true;
-    std::vector<Record> pool[3];
+    std::vector<Record> pool_x[3];  // "ex" flavour
+    std::vector<int32_t> pool_s[3]; // plain flavour: subject ids
+    auto emit_read = [&](int m) {
+        if (want_names) out.qname.push_back(((uint64_t)(cur - base) << 24) | ((uint64_t)cur_n << 2) | (uint64_t)m);
+        if (want_samples) {
+            // query.partition('_'): sample = left part if the right part
+            // (which includes a mate suffix) is not empty, else ''
+            const char* us = (const char*)memchr(cur, '_', cur_n);
+            size_t sn = 0;
+            if (us && ((size_t)(us - cur) + 1 < cur_n || m != 0)) sn = (size_t)(us - cur);
+            const uint64_t hv = hash_bytes(cur, sn);
+            int32_t id = T->samples.find(cur, sn, hv);
+            if (id < 0) {
+                int32_t f = out.fresh_samples.find(cur, sn, hv);
+                if (f < 0) f = out.fresh_samples.add(cur, sn, hv);
+                id = -(1 + f);
+            }
+            out.sample.push_back(id);
+        }
+        if (want_groups) {  // stratum of read id = QNAME + mate suffix
+            keybuf.assign(cur, cur_n);
+            keybuf.append(kSuffix[m]);
+            out.group.push_back(T->strata_find(keybuf.data(), keybuf.size()));
+        }
+    };
     auto flush = [&]() {
         if (!cur || !keep) {
-            for (auto& p : pool) p.clear();
+            for (int m = 0; m < 3; ++m) {
+                pool_x[m].clear();
+                pool_s[m].clear();
+            }
             return;
         }
         for (int m = 0; m < 3; ++m) {
-            if (pool[m].empty()) continue;
-            if (!extra && pool[m].size() > 1) {
-                // the plain parsers collect subject *sets* (align.py:258-330):
-                // duplicates go here, so the device never has to look for them
-                auto& v = pool[m];
-                if (v.size() <= 64) {
-                    size_t w = 1;
-                    for (size_t i = 1; i < v.size(); ++i) {
-                        bool dup = false;
-                        for (size_t j = 0; j < w && !dup; ++j) dup = v[j].subj == v[i].subj;
-                        if (!dup) v[w++] = v[i];
+            if (kExtra) {
+                auto& v = pool_x[m];
+                if (v.empty()) continue;
+                out.rec.insert(out.rec.end(), v.begin(), v.end());
+                out.rend.push_back((int32_t)out.rec.size());
+                out.n_big += v.size() > (size_t)WK_WEIGHT_MAX_K;
+                emit_read(m);
+                v.clear();
+            } else {
+                auto& v = pool_s[m];
+                if (v.empty()) continue;
+                size_t w = v.size();
+                if (w > 1) {
+                    // the plain parsers collect subject *sets* (align.py:258-330):
+                    // duplicates go here, so the device never has to look for them
+                    if (w <= 64) {
+                        w = 1;
+                        for (size_t i = 1; i < v.size(); ++i) {
+                            bool dup = false;
+                            for (size_t j = 0; j < w && !dup; ++j) dup = v[j] == v[i];
+                            if (!dup) v[w++] = v[i];
+                        }
+                    } else {
+                        std::sort(v.begin(), v.end());
+                        w = (size_t)(std::unique(v.begin(), v.end()) - v.begin());
                     }
-                    v.resize(w);
-                } else {
-                    std::sort(v.begin(), v.end(), [](const Record& x, const Record& y) { return x.subj < y.subj; });
-                    v.erase(std::unique(v.begin(), v.end(), [](const Record& x, const Record& y) { return x.subj == y.subj; }), v.end());
                 }
+                out.subj.insert(out.subj.end(), v.begin(), v.begin() + (ptrdiff_t)w);
+                out.rend.push_back((int32_t)out.subj.size());
+                out.n_big += w > (size_t)WK_WEIGHT_MAX_K;
+                emit_read(m);
+                v.clear();
             }
-            out.rec.insert(out.rec.end(), pool[m].begin(), pool[m].end());
-            out.rend.push_back((int32_t)out.rec.size());
-            if (want_names) out.qname.push_back(((uint64_t)(cur - base) << 24) | ((uint64_t)cur_n << 2) | (uint64_t)m);
-            if (want_samples) {
-                // query.partition('_'): sample = left part if the right part
-                // (which includes a mate suffix) is not empty, else ''
-                const char* us = (const char*)memchr(cur, '_', cur_n);
-                size_t sn = 0;
-                if (us && ((size_t)(us - cur) + 1 < cur_n || m != 0)) sn = (size_t)(us - cur);
-                const uint64_t hv = hash_bytes(cur, sn);
-                int32_t id = T->samples.find(cur, sn, hv);
-                if (id < 0) {
-                    int32_t f = out.fresh_samples.find(cur, sn, hv);
-                    if (f < 0) f = out.fresh_samples.add(cur, sn, hv);
-                    id = -(1 + f);
-                }
-                out.sample.push_back(id);
-            }
-            if (want_groups) {  // stratum of read id = QNAME + mate suffix
-                keybuf.assign(cur, cur_n);
-                keybuf.append(kSuffix[m]);
-                out.group.push_back(T->strata_find(keybuf.data(), keybuf.size()));
-            }
-            pool[m].clear();
         }
     };
-    for (const char* p = b; p < e;) {
-        const char* nl = (const char*)memchr(p, '\n', e - p);
-        const char* le = nl ? nl : e;
-        const Line L = parse_row(fmt, p, le, extra);
-        const char* line = p;
-        p = nl ? nl + 1 : e;
-        if (!L.ok) {
-            // (an empty line inside a SAM body fails `line.split('\t', 3)`
-            // like any other short line, align.py:313; the other formats skip it)
-            if (le == line && fmt != WK_FMT_SAM) continue;
-            if (fmt != WK_FMT_SAM && !L.bad_number) continue;  // not a row of this format
-            out.error = 2;
-            out.error_at = line - base;
-            return;
-        }
-        if (fmt == WK_FMT_SAM && is_unmapped(L)) continue;
-        bool run_start = false;
-        if (!(cur && L.qn == cur_n && memcmp(L.q, cur, cur_n) == 0)) {
-            flush();
-            cur = L.q;
-            cur_n = L.qn;
-            keep = true;
-            run_start = true;
-        } else if (!keep) {
-            continue;
-        }
-        const uint64_t hv = hash_bytes(L.r, L.rn);
-        if (filt && T->exclude.find(L.r, L.rn, hv) >= 0) {
-            keep = false;
-            continue;
-        }
-        if (track_pool) {
-            if (run_start) {  // `pool = ([], [], [])` (align.py:526)
-                out.pool_lines.clear();
-                out.have_pool = true;
+    constexpr int kBatch = 16;
+    Line batch[kBatch];
+    const char* p = b;
+    bool vector_scan = fmt == WK_FMT_SAM && T->produce_sam != nullptr;
+    while (p < e) {
+        int n = 0;
+        if (vector_scan) {
+            n = T->produce_sam(p, e, kExtra, T->dict, batch, kBatch);
+            if (n == 0 && p < e && (size_t)(e - p) < kScanSlack + 64) vector_scan = false;  // the last lines of the range
+            if (n == 0 && vector_scan) {
+                // (a line longer than the scanner could finish near the end: the memchr parser takes over)
+                vector_scan = false;
             }
-            out.pool_lines.emplace_back(line, le);
         }
-        const int mate = fmt == WK_FMT_SAM ? (L.flag >> 6) & 3 : 0;
-        if (mate == 3) {
-            out.error = 1;
-            out.error_at = line - base;
-            return;
-        }
-        Record rc{};
-        int32_t id = T->names.find(L.r, L.rn, hv);
-        if (id < 0) {
-            int32_t f = out.fresh.find(L.r, L.rn, hv);
-            if (f < 0) f = out.fresh.add(L.r, L.rn, hv);
-            id = -(1 + f);
-        }
-        rc.subj = id;
-        if (extra && fmt == WK_FMT_SAM) {
-            // int(pos) and cigar_to_lens raise on text that is not a number
-            // (align.py:382-385); a negative POS is a number
-            long pos = 0;
-            uint32_t aligned = 0, span = 0;
-            if (!parse_int(L.pos, L.pos_end, pos) || !cigar_lens(L.cigar, L.cn, aligned, span)) {
+        if (!vector_scan && n == 0) n = produce_rows(fmt, p, e, kExtra, T->dict, batch, kBatch);
+        for (int li = 0; li < n; ++li) {
+            const Line& L = batch[li];
+            const char* line = L.line;
+            const char* le = L.le;
+            if (!L.ok) {
+                // (an empty line inside a SAM body fails `line.split('\t', 3)`
+                // like any other short line, align.py:313; the other formats skip it)
+                if (le == line && fmt != WK_FMT_SAM) continue;
+                if (fmt != WK_FMT_SAM && !L.bad_number) continue;  // not a row of this format
                 out.error = 2;
-                out.error_at = line - base;
+                out.error_at = (size_t)(line - base);
                 return;
             }
-            if (aligned == 0 && !keep_empty) continue;  // ordinal.py:231 (range.py keeps them)
-            rc.beg = (int32_t)(pos - 1);
-            rc.end = (int32_t)(pos - 1 + span);
-            rc.len = aligned;
-        } else if (extra) {
-            if (L.len == 0 && !keep_empty) continue;
-            rc.beg = L.beg;
-            rc.end = L.end;
-            rc.len = L.len;
+            bool run_start = false;
+            if (!(cur && same_name(L.q, L.qn, cur, cur_n))) {
+                flush();
+                cur = L.q;
+                cur_n = L.qn;
+                keep = true;
+                run_start = true;
+            } else if (!keep) {
+                continue;
+            }
+            const uint64_t hv = L.rh;
+            if (filt && T->exclude.find(L.r, L.rn, hv) >= 0) {
+                keep = false;
+                continue;
+            }
+            if (track_pool) {
+                if (run_start) {  // `pool = ([], [], [])` (align.py:526)
+                    out.pool_lines.clear();
+                    out.have_pool = true;
+                }
+                out.pool_lines.emplace_back(line, le);
+            }
+            const int mate = fmt == WK_FMT_SAM ? (L.flag >> 6) & 3 : 0;
+            if (mate == 3) {
+                out.error = 1;
+                out.error_at = (size_t)(line - base);
+                return;
+            }
+            int32_t id = T->dict.find(L.r, L.rn, hv);
+            if (id < 0) {
+                int32_t f = out.fresh.find(L.r, L.rn, hv);
+                if (f < 0) f = out.fresh.add(L.r, L.rn, hv);
+                id = -(1 + f);
+            }
+            if (!kExtra) {
+                pool_s[mate].push_back(id);
+                continue;
+            }
+            Record rc{};
+            rc.subj = id;
+            if (fmt == WK_FMT_SAM) {
+                // int(pos) and cigar_to_lens raise on text that is not a number
+                // (align.py:382-385); a negative POS is a number
+                long pos = 0;
+                uint32_t aligned = 0, span = 0;
+                if (!parse_int(L.pos, L.pos_end, pos) || !cigar_lens(L.cigar, L.cn, aligned, span)) {
+                    out.error = 2;
+                    out.error_at = (size_t)(line - base);
+                    return;
+                }
+                if (aligned == 0 && !keep_empty) continue;  // ordinal.py:231 (range.py keeps them)
+                rc.beg = (int32_t)(pos - 1);
+                rc.end = (int32_t)(pos - 1 + span);
+                rc.len = aligned;
+            } else {
+                if (L.len == 0 && !keep_empty) continue;
+                rc.beg = L.beg;
+                rc.end = L.end;
+                rc.len = L.len;
+            }
+            pool_x[mate].push_back(rc);
         }
-        pool[mate].push_back(rc);
     }
     if (track_pool && cur) {
         out.any_run = true;
@@ -494,6 +775,13 @@ int wk_tok_create(int n_threads, wk_tok** out) {
         if (n_threads <= 0) n_threads = 1;
     }
     t->n_threads = std::min(n_threads, 256);  // (the default the host picks is lower: classify.tokenizer_threads)
+    t->pool = new (std::nothrow) WorkPool(t->n_threads > 1 ? t->n_threads : 0);
+    if (!t->pool) {
+        delete t;
+        return WK_E_HIP;
+    }
+    t->produce_sam = __builtin_cpu_supports("avx2") ? produce_sam_avx2 : produce_sam_sse2;
+    if (getenv("WOLTKA_TOK_SCALAR")) t->produce_sam = nullptr;  // measurement: the memchr parsers only
     *out = t;
     return WK_OK;
 }
@@ -611,14 +899,10 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
         if (!last_nl || t->in_header) {
             *consumed = b - buf;
             *n_reads = *n_records = 0;
-            t->subj.clear();
-            t->off.assign(1, 0);
-            t->qname.clear();
-            t->group.clear();
-            t->sample.clear();
-            t->beg.clear();
-            t->end.clear();
-            t->len.clear();
+            t->n_loc = 0;
+            t->tot_reads = t->tot_rec = t->tot_big = 0;
+            t->last_extra = ex;
+            t->last_want = want_names;
             return WK_OK;
         }
         stop = last_nl;
@@ -647,6 +931,9 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
         }
         if (run_start) stop = run_start;
     }
+    TokLap lap(t->lap_ms);
+    t->lap_calls += 1;
+    t->lap_bytes += stop - b;
     const int64_t span = stop - b;
     int T = t->n_threads;
     if (span < (int64_t)T * (1 << 16)) T = (int)std::max<int64_t>(1, span >> 16);
@@ -661,26 +948,31 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
     }
     for (int i = 1; i <= T; ++i)
         if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1];
-    std::vector<Local> loc(T);
-    if (T == 1) {
-        tokenize_range(t, fmt, buf, cut[0], cut[1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
-                       (want_names & 4) != 0, loc[0]);
-    } else {
-        std::vector<std::thread> th;
-        th.reserve(T);
-        for (int i = 0; i < T; ++i)
-            th.emplace_back([&, i] {
-                tokenize_range(t, fmt, buf, cut[i], cut[i + 1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
-                               (want_names & 4) != 0, loc[i]);
-            });
-        for (auto& x : th) x.join();
-    }
+    if ((int)t->loc.size() < T) t->loc.resize((size_t)T);
+    std::vector<Local>& loc = t->loc;
+    t->n_loc = T;
+    t->last_extra = ex;
+    t->last_want = want_names;
+    const std::function<void(int)> work = [&](int i) {
+        loc[i].reset();
+        if (ex)
+            tokenize_range<true>(t, fmt, buf, cut[i], cut[i + 1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
+                                 (want_names & 4) != 0, loc[i]);
+        else
+            tokenize_range<false>(t, fmt, buf, cut[i], cut[i + 1], extra, (want_names & 1) != 0, (want_names & 2) != 0,
+                                  (want_names & 4) != 0, loc[i]);
+    };
+    lap(LAP_CUTS);
+    t->pool->run(T, work);
+    lap(LAP_TOKENIZE);
     for (int i = 0; i < T; ++i)
         if (loc[i].error) {
             char msg[160];
             snprintf(msg, sizeof msg, loc[i].error == 1 ? "SAM flag with both mate bits set at byte %zu" : "malformed alignment line at byte %zu",
                      loc[i].error_at);
             t->err = msg;
+            t->n_loc = 0;
+            t->tot_reads = t->tot_rec = t->tot_big = 0;
             return loc[i].error == 1 ? WK_E_RANGE : WK_E_ARG;
         }
     for (int i = 0; i < T; ++i) {  // (ranges in text order)
@@ -696,117 +988,154 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
         }
     }
     // merge fresh names in thread order (= order of first appearance in the text)
-    std::vector<std::vector<int32_t>> remap(T);
-    for (int i = 0; i < T; ++i) {
-        const NameTable& f = loc[i].fresh;
-        remap[i].resize(f.size());
-        for (int32_t k = 0; k < f.size(); ++k) {
-            const char* p = f.arena.data() + f.off[k];
-            int32_t id = t->names.find(p, f.len[k], f.hash[k]);
-            if (id < 0) id = t->names.add(p, f.len[k], f.hash[k]);
-            remap[i][k] = id;
-        }
-    }
-    std::vector<std::vector<int32_t>> sremap(T);
-    for (int i = 0; i < T; ++i) {
-        const NameTable& f = loc[i].fresh_samples;
-        sremap[i].resize(f.size());
-        for (int32_t k = 0; k < f.size(); ++k) {
-            const char* p = f.arena.data() + f.off[k];
-            int32_t id = t->samples.find(p, f.len[k], f.hash[k]);
-            if (id < 0) id = t->samples.add(p, f.len[k], f.hash[k]);
-            sremap[i][k] = id;
-        }
-    }
     // first appearance order must not depend on the thread count: names that were
     // fresh in several ranges were added by the earliest range, which is also
     // where they first appear in the text.  Within one range `fresh` ids follow
     // the text order.  (A name fresh in range i is absent from all earlier ranges
     // only if those did not see it at all.)
-    int64_t tot_reads = 0, tot_rec = 0;
-    for (int i = 0; i < T; ++i) {
-        tot_reads += (int64_t)loc[i].rend.size();
-        tot_rec += (int64_t)loc[i].rec.size();
+    if ((int)t->remap.size() < T) {
+        t->remap.resize((size_t)T);
+        t->sremap.resize((size_t)T);
     }
+    for (int i = 0; i < T; ++i) {
+        const NameTable& f = loc[i].fresh;
+        std::vector<int32_t>& rm = t->remap[i];
+        rm.resize((size_t)f.size());
+        for (int32_t k = 0; k < f.size(); ++k) {
+            const char* p = f.arena.data() + f.off[k];
+            int32_t id = t->names.find(p, f.len[k], f.hash[k]);
+            if (id < 0) {
+                id = t->names.add(p, f.len[k], f.hash[k]);
+                t->dict.insert(p, f.len[k], f.hash[k], id);
+            }
+            rm[k] = id;
+        }
+    }
+    for (int i = 0; i < T; ++i) {
+        const NameTable& f = loc[i].fresh_samples;
+        std::vector<int32_t>& rm = t->sremap[i];
+        rm.resize((size_t)f.size());
+        for (int32_t k = 0; k < f.size(); ++k) {
+            const char* p = f.arena.data() + f.off[k];
+            int32_t id = t->samples.find(p, f.len[k], f.hash[k]);
+            if (id < 0) id = t->samples.add(p, f.len[k], f.hash[k]);
+            rm[k] = id;
+        }
+    }
+    int64_t tot_reads = 0, tot_rec = 0, tot_big = 0;
+    t->rbase.assign((size_t)T + 1, 0);
+    t->qbase.assign((size_t)T + 1, 0);
+    for (int i = 0; i < T; ++i) {
+        t->rbase[i + 1] = t->rbase[i] + (int64_t)loc[i].n_records(ex);
+        t->qbase[i + 1] = t->qbase[i] + (int64_t)loc[i].rend.size();
+        tot_big += loc[i].n_big;
+    }
+    tot_reads = t->qbase[T];
+    tot_rec = t->rbase[T];
     if (tot_rec >= (1ll << 31)) {
         t->err = "more than 2^31 records in one block; pass smaller blocks";
+        t->n_loc = 0;
         return WK_E_RANGE;
     }
-    t->subj.resize(tot_rec);
-    t->off.resize(tot_reads + 1);
-    t->qname.resize((want_names & 1) ? tot_reads : 0);
-    t->group.resize((want_names & 2) ? tot_reads : 0);
-    t->sample.resize((want_names & 4) ? tot_reads : 0);
-    if (extra) {
-        t->beg.resize(tot_rec);
-        t->end.resize(tot_rec);
-        t->len.resize(tot_rec);
-    } else {
-        t->beg.clear();
-        t->end.clear();
-        t->len.clear();
-    }
-    t->off[0] = 0;
-    std::vector<int64_t> rbase(T + 1, 0), qbase(T + 1, 0);
-    for (int i = 0; i < T; ++i) {
-        rbase[i + 1] = rbase[i] + (int64_t)loc[i].rec.size();
-        qbase[i + 1] = qbase[i] + (int64_t)loc[i].rend.size();
-    }
-    auto copy_out = [&](int i) {
-        const Local& L = loc[i];
-        const int64_t rb = rbase[i], qb = qbase[i];
-        for (size_t k = 0; k < L.rec.size(); ++k) {
-            const Record& rc = L.rec[k];
-            t->subj[rb + k] = rc.subj >= 0 ? rc.subj : remap[i][-(rc.subj + 1)];
-            if (extra) {
-                t->beg[rb + k] = rc.beg;
-                t->end[rb + k] = rc.end;
-                t->len[rb + k] = rc.len;
-            }
-        }
-        for (size_t k = 0; k < L.rend.size(); ++k) t->off[qb + k + 1] = (int32_t)(rb + L.rend[k]);
-        if (want_names & 1)
-            for (size_t k = 0; k < L.qname.size(); ++k) t->qname[qb + k] = L.qname[k];
-        if (want_names & 2)
-            for (size_t k = 0; k < L.group.size(); ++k) t->group[qb + k] = L.group[k];
-        if (want_names & 4)
-            for (size_t k = 0; k < L.sample.size(); ++k)
-                t->sample[qb + k] = L.sample[k] >= 0 ? L.sample[k] : sremap[i][-(L.sample[k] + 1)];
-    };
-    if (T == 1) {
-        copy_out(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < T; ++i) th.emplace_back(copy_out, i);
-        for (auto& x : th) x.join();
-    }
+    t->tot_reads = tot_reads;
+    t->tot_rec = tot_rec;
+    t->tot_big = tot_big;
+    lap(LAP_MERGE);
     *consumed = stop - buf;
     *n_reads = tot_reads;
     *n_records = tot_rec;
     return WK_OK;
 }
 
+// The results of the last wk_tok_text, scattered from the thread ranges' own
+// buffers straight into the caller's arrays (pinned staging buffers, for
+// instance) by all threads.
+static int fetch_results(wk_tok* t, int32_t* subj, uint32_t* packed, int32_t* off, int32_t* beg, int32_t* end, uint32_t* len,
+                         uint64_t* qname, int32_t* group, int32_t* sample) {
+    const int T = t->n_loc;
+    if (off) off[0] = 0;
+    if (T == 0) return WK_OK;
+    const bool ex = t->last_extra;
+    std::vector<Local>& loc = t->loc;
+    const std::function<void(int)> work = [&](int i) {
+        const Local& L = loc[i];
+        const int64_t rb = t->rbase[i], qb = t->qbase[i];
+        const std::vector<int32_t>& rm = t->remap[i];
+        if (ex) {
+            for (size_t k = 0; k < L.rec.size(); ++k) {
+                const Record& rc = L.rec[k];
+                if (subj) subj[rb + (int64_t)k] = rc.subj >= 0 ? rc.subj : rm[(size_t)(-(rc.subj + 1))];
+                if (beg) beg[rb + (int64_t)k] = rc.beg;
+                if (end) end[rb + (int64_t)k] = rc.end;
+                if (len) len[rb + (int64_t)k] = rc.len;
+            }
+        } else if (subj) {
+            for (size_t k = 0; k < L.subj.size(); ++k) {
+                const int32_t v = L.subj[k];
+                subj[rb + (int64_t)k] = v >= 0 ? v : rm[(size_t)(-(v + 1))];
+            }
+        }
+        if (packed && !ex) {
+            // subject index | position in the read << 23 | size of the read << 27
+            // (both 0 for a read of more than WK_WEIGHT_MAX_K records: the
+            // weighted histogram leaves it out)
+            size_t lo = 0;
+            for (size_t r = 0; r < L.rend.size(); ++r) {
+                const size_t hi = (size_t)L.rend[r];
+                const uint32_t n = (uint32_t)(hi - lo);
+                const bool small = n <= (uint32_t)WK_WEIGHT_MAX_K;
+                const uint32_t tag = small ? n << 27 : 0u;
+                for (size_t k = lo; k < hi; ++k) {
+                    const int32_t v = L.subj[k];
+                    packed[rb + (int64_t)k] =
+                        (uint32_t)(v >= 0 ? v : rm[(size_t)(-(v + 1))]) | tag | (small ? (uint32_t)(k - lo) << 23 : 0u);
+                }
+                lo = hi;
+            }
+        }
+        if (off)
+            for (size_t k = 0; k < L.rend.size(); ++k) off[qb + (int64_t)k + 1] = (int32_t)(rb + L.rend[k]);
+        if (qname && (t->last_want & 1)) memcpy(qname + qb, L.qname.data(), L.qname.size() * 8);
+        if (group && (t->last_want & 2)) memcpy(group + qb, L.group.data(), L.group.size() * 4);
+        if (sample && (t->last_want & 4)) {
+            const std::vector<int32_t>& sm = t->sremap[i];
+            for (size_t k = 0; k < L.sample.size(); ++k)
+                sample[qb + (int64_t)k] = L.sample[k] >= 0 ? L.sample[k] : sm[(size_t)(-(L.sample[k] + 1))];
+        }
+    };
+    TokLap lap(t->lap_ms);
+    t->pool->run(T, work);
+    lap(LAP_FETCH);
+    return WK_OK;
+}
+
 int wk_tok_fetch(wk_tok* t, int32_t* subj, int32_t* off, int32_t* beg, int32_t* end, uint32_t* len, uint64_t* qname) {
     if (!t) return WK_E_ARG;
-    if (subj && !t->subj.empty()) memcpy(subj, t->subj.data(), t->subj.size() * 4);
-    if (off && !t->off.empty()) memcpy(off, t->off.data(), t->off.size() * 4);
-    if (beg && !t->beg.empty()) memcpy(beg, t->beg.data(), t->beg.size() * 4);
-    if (end && !t->end.empty()) memcpy(end, t->end.data(), t->end.size() * 4);
-    if (len && !t->len.empty()) memcpy(len, t->len.data(), t->len.size() * 4);
-    if (qname && !t->qname.empty()) memcpy(qname, t->qname.data(), t->qname.size() * 8);
-    return WK_OK;
+    return fetch_results(t, subj, nullptr, off, beg, end, len, qname, nullptr, nullptr);
+}
+
+int wk_tok_fetch_packed(wk_tok* t, uint32_t* packed, int32_t* off, uint64_t* qname, int64_t* n_big) {
+    if (!t) return WK_E_ARG;
+    if (t->last_extra && t->n_loc) {
+        t->err = "packed records exist for the plain flavour only";
+        return WK_E_STATE;
+    }
+    if (t->names.size() > (1 << 23)) {
+        t->err = "more than 2^23 subjects: the packed record has 23 bits for the subject index";
+        return WK_E_RANGE;
+    }
+    if (n_big) *n_big = t->n_loc ? t->tot_big : 0;
+    return fetch_results(t, nullptr, packed, off, nullptr, nullptr, nullptr, qname, nullptr, nullptr);
 }
 
 int wk_tok_fetch_groups(wk_tok* t, int32_t* group) {
     if (!t) return WK_E_ARG;
-    if (group && !t->group.empty()) memcpy(group, t->group.data(), t->group.size() * 4);
-    return WK_OK;
+    return fetch_results(t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, group, nullptr);
 }
 
 int wk_tok_fetch_samples(wk_tok* t, int32_t* sample) {
     if (!t) return WK_E_ARG;
-    if (sample && !t->sample.empty()) memcpy(sample, t->sample.data(), t->sample.size() * 4);
-    return WK_OK;
+    return fetch_results(t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sample);
 }
 
 // Names of the samples first seen since the last call: sizes with blob == NULL

@@ -147,9 +147,17 @@ __global__ void __launch_bounds__(kSizeTile) read_sizes_kernel(const int32_t* __
     }
 }
 
+// Packed records (what the native tokenizer emits, wk_tok_fetch_packed):
+// subject index | position of the record in its read << 23 | size of its read
+// << 27 (size 0: a read of more than WK_WEIGHT_MAX_K records — such reads are
+// staged the other way).  One word per record is all the histogram streams.
+constexpr uint32_t kWordSubjBits = 23;
+constexpr uint32_t kWordSubjMask = (1u << kWordSubjBits) - 1u;
+constexpr uint32_t kWordSizeShift = 27;
+
 struct BinsArgs {
-    const int32_t* subj;        // [n_records] subject indices
-    const unsigned char* rk;    // [n_records] read size 1..16, or 0: not covered
+    const int32_t* subj;        // [n_records] subject indices, or packed records (kPacked)
+    const unsigned char* rk;    // [n_records] read size 1..16, or 0: not covered (not kPacked)
     uint32_t n_records;
     uint32_t n_subjects;
     uint32_t bins, n_slices, teams_per_xcd, n_xcd;
@@ -161,7 +169,7 @@ struct BinsArgs {
 constexpr uint32_t kBinsTile = kWeighThreads * 4;  // records per workgroup and round
 constexpr uint32_t kBinsMaxLds = 160 * 1024 - 1024;
 
-template <int kRing = 4>
+template <int kRing = 4, bool kPacked = false>
 __global__ void __launch_bounds__(kWeighThreads) weigh_bins_kernel(BinsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: 32 weights (lut[k] = L / k, lut[0] = 0) in static LDS — their
@@ -201,16 +209,24 @@ __global__ void __launch_bounds__(kWeighThreads) weigh_bins_kernel(BinsArgs a) {
         const uint32_t i = tile * kBinsTile + threadIdx.x * 4u;  // (past the end: offsets beyond the buffers)
         const bool ok = tile < n_tiles;
         x.c = __builtin_amdgcn_raw_buffer_load_b128(subj_rsrc, (int)(ok ? i << 2 : 0xFFFFFFF0u), 0, 0);
-        x.k4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rk_rsrc, (int)(ok ? i : 0xFFFFFFF0u), 0, 0);
+        if constexpr (!kPacked) x.k4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rk_rsrc, (int)(ok ? i : 0xFFFFFFF0u), 0, 0);
     };
     const uint32_t idle_addr = a.bins + (threadIdx.x & 63u);
     bool outside = false;
     auto add = [&](const Stage& x) {
-        const uint32_t c[4] = {(uint32_t)x.c.x, (uint32_t)x.c.y, (uint32_t)x.c.z, (uint32_t)x.c.w};
+        uint32_t c[4] = {(uint32_t)x.c.x, (uint32_t)x.c.y, (uint32_t)x.c.z, (uint32_t)x.c.w};
         uint32_t w[4], at[4], old[4];
         bool in[4];
+        if constexpr (kPacked) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = lut[(x.k4 >> (8 * j)) & 31u];
+            for (int j = 0; j < 4; ++j) {
+                w[j] = lut[c[j] >> kWordSizeShift];  // (records past the end load as 0: size 0, weight 0)
+                c[j] &= kWordSubjMask;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = lut[(x.k4 >> (8 * j)) & 31u];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t idx = c[j] - lo;

@@ -170,6 +170,18 @@ struct wk_ctx {
     int64_t stage_serial = 0, rows_serial = 0, rk1_stage = -1, rk1_rows = -1;
     int64_t stat_extra_reads = 0, stat_extra_records = 0;  // statistics added on the host
     bool rows_any_invalid = false;  // some subject lacks an ancestor at a rank column of the current rows
+    // packed records of the native tokenizer accumulated over the chunks of one
+    // sample (wk_words_*): one launch of the weighted histogram at the end
+    DevBuf c_words;
+    int64_t w_records = 0, w_reads = 0;  // accumulated so far
+    std::vector<wk_job> w_jobs;          // the job set they will be classified under
+    int32_t w_group = 0;
+    bool w_open = false;
+    int words_keep = 0;  // measurement: wk_words_flush leaves the accumulated records in place
+    static constexpr int kStageSlots = 8;
+    hipEvent_t slot_ev[kStageSlots] = {};
+    bool slot_busy[kStageSlots] = {};
+    std::vector<void*> host_blocks;      // wk_host_alloc
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
 };
@@ -348,7 +360,87 @@ static int derive_read_sizes(wk_ctx* c, bool check, const int32_t* qoff, const i
     return WK_OK;
 }
 
+// Subject rows {feature, ancestor at rank column 0, 1, ...} for a job set over
+// the current subject table (rebuilt when the subjects or the rank tables
+// changed), the jobs' columns, and which subjects the weighted histogram cannot
+// take (c->rows_any_invalid).
+static int build_subject_rows(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, ClassifyArgs& a) {
+    // (re)build the compact subject rows for this set of rank tables
+    if (c->n_subjects <= 0 && c->n_records > 0) return fail(c, WK_E_STATE, "chunk carries subject indices but no subject table is set (wk_set_subjects)");
+    std::vector<int> sig;
+    RowCols cols{};
+    for (int j = 0; j < n_jobs; ++j) {
+        if (jobs[j].mode != WK_MODE_RANK) continue;
+        int col = -1;
+        for (int q = 0; q < cols.n_cols; ++q)
+            if (sig[q] == jobs[j].rank_slot) col = q;
+        if (col < 0) {
+            col = cols.n_cols++;
+            sig.push_back(jobs[j].rank_slot);
+            cols.anc[col] = c->rank_tab[jobs[j].rank_slot].as<int32_t>();
+        }
+        a.jobs[j].col = col;
+    }
+    // `--rank free`: one more column with the subject's rank among the
+    // subjects of the tree, when it fits the 4-column row
+    bool any_free = false;
+    for (int j = 0; j < n_jobs; ++j) any_free |= jobs[j].mode == WK_MODE_FREE;
+    cols.by_subject = -1;
+    int free_col = -1;
+    // (the table has n log n entries: subject tables beyond 4 M keep the walk)
+    if (any_free && c->use_free_sparse && cols.n_cols < 3 && c->n_subjects > 0 && c->n_subjects <= (1 << 22) && c->n_nodes > 0) {
+        int rc2 = ensure_free_tables(c);
+        if (rc2) return rc2;
+        free_col = cols.n_cols++;
+        sig.push_back(-2);
+        sig.push_back(c->free_tree);
+        sig.push_back(c->free_subj);
+        cols.anc[free_col] = nullptr;
+        cols.by_subject = free_col;
+        cols.subject_col = c->f_rank.as<int32_t>();
+        a.free_sparse = c->f_sparse.as<int32_t>();
+        a.free_m = (int32_t)c->f_m;
+        a.free_col = free_col;
+    }
+    int w = 4;  // {feature, <= 3 rank columns}: the kernel's single-pass fast path
+    while (w < 1 + cols.n_cols) w <<= 1;
+    sig.push_back(-1);
+    sig.push_back(c->n_subjects);
+    if (sig != c->rows_sig || w != c->rows_w) {
+        HIP_TRY(c, c->subj_rows.reserve((size_t)std::max(c->n_subjects, 1) * w * sizeof(int32_t)));
+        if (c->n_subjects > 0) {
+            hipLaunchKernelGGL(subject_rows_kernel, dim3((c->n_subjects + 255) / 256), dim3(256), 0, c->stream,
+                               c->subj_feat.as<int32_t>(), c->n_subjects, c->n_nodes, cols, w,
+                               c->subj_rows.as<int32_t>());
+            HIP_TRY(c, hipGetLastError());
+        }
+        c->rows_sig = sig;
+        c->rows_w = w;
+        // which subjects the weighted histogram cannot take (wk_weigh.hpp)
+        c->rows_any_invalid = false;
+        c->rows_serial += 1;
+        if (c->n_subjects > 0) {
+            HIP_TRY(c, c->w_invalid.reserve(((size_t)c->n_subjects / 32 + 2) * 4));
+            HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 6), 0, 8, c->stream));
+            hipLaunchKernelGGL(subject_invalid_kernel, dim3((c->n_subjects + 255) / 256), dim3(256), 0, c->stream,
+                               c->subj_rows.as<int32_t>(), w, cols.n_cols, c->n_subjects,
+                               c->w_invalid.as<uint32_t>(), reinterpret_cast<uint32_t*>(scalar_u64(c, 6)));
+            HIP_TRY(c, hipGetLastError());
+            uint32_t any = 0;
+            HIP_TRY(c, hipMemcpyAsync(&any, scalar_u64(c, 6), 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->rows_any_invalid = any != 0;
+        }
+    }
+    a.rows = c->subj_rows.as<int32_t>();
+    a.row_w = w;
+    a.n_subjects = c->n_subjects;
+    return WK_OK;
+}
+
 extern "C" {
+
+int wk_words_flush(wk_ctx* c);
 
 int wk_abi_version(void) { return WK_ABI_VERSION; }
 
@@ -422,6 +514,12 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<4>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<4, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<6, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<8, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<3>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<6>),
@@ -455,6 +553,10 @@ void wk_destroy(wk_ctx* c) {
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
+    c->c_words.release();
+    for (void* hp : c->host_blocks) (void)hipHostFree(hp);
+    for (hipEvent_t ev : c->slot_ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (DevBuf& b : c->rank_tab) b.release();
     for (auto& kv : c->ktimers) {
         if (kv.second.a) (void)hipEventDestroy(kv.second.a);
@@ -573,6 +675,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         c->use_weigh = (int)value;
         return WK_OK;
     }
+    if (!strcmp(name, "words_keep")) {
+        c->words_keep = value ? 1 : 0;
+        return WK_OK;
+    }
     if (!strcmp(name, "bins_ring")) {
         c->bins_ring = (int)value;
         return WK_OK;
@@ -595,6 +701,10 @@ int wk_set_tree(wk_ctx* c, const int32_t* parent, const int32_t* last, const int
     if (n < 0 || (n > 0 && (!parent || !last || !rank_code))) return fail(c, WK_E_ARG, "bad tree arguments");
     if ((int64_t)n > (int64_t)WK_MAX_FEATURE) return fail(c, WK_E_RANGE, "too many hierarchy nodes");
     DeviceGuard guard(c->device);
+    {
+        const int rcw = wk_words_flush(c);  // (records accumulated under the old tree)
+        if (rcw) return rcw;
+    }
     for (int32_t v = 0; v < n; ++v) {  // validate the pre-order contract the kernels rely on
         const bool ok = (v == 0) ? (parent[0] == 0) : (parent[v] >= 0 && parent[v] < v);
         if (!ok || last[v] < v || last[v] >= n) return fail(c, WK_E_ARG, "node %d violates the pre-order contract (parent %d, last %d)", v, parent[v], last[v]);
@@ -718,7 +828,14 @@ int wk_set_subjects(wk_ctx* c, const int32_t* feature_of_subject, int32_t n) {
     }
     c->max_subject_feature = mx;
     DeviceGuard guard(c->device);
-    int rc = upload(c, c->subj_feat, feature_of_subject, (size_t)n * sizeof(int32_t));
+    int rc;
+    // accumulated packed records name subjects of the old table: they stay
+    // valid only if the new table extends it
+    if (c->w_open && c->w_records > 0 &&
+        (n < c->n_subjects || memcmp(feature_of_subject, c->subj_feat_host.data(), (size_t)c->n_subjects * 4) != 0) &&
+        (rc = wk_words_flush(c)))
+        return rc;
+    rc = upload(c, c->subj_feat, feature_of_subject, (size_t)n * sizeof(int32_t));
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_subjects = n;
@@ -734,6 +851,10 @@ int wk_counts_clear(wk_ctx* c) {
     if (!c) return WK_E_ARG;
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved");
     DeviceGuard guard(c->device);
+    if (!c->words_keep) {  // accumulated records are counts that have not been added yet
+        c->w_records = c->w_reads = 0;
+        c->w_open = false;
+    }
     HIP_TRY(c, hipMemsetAsync(c->tkeys.p, 0xFF, c->slots * sizeof(uint64_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->tvals.p, 0, c->slots * sizeof(uint64_t), c->stream));
     return WK_OK;
@@ -760,8 +881,9 @@ int wk_counts_fetch(wk_ctx* c, uint64_t* keys, int64_t* counts, int64_t cap, int
     if (!c || !n) return WK_E_ARG;
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved");
     DeviceGuard guard(c->device);
-    int rc = check_device_errors(c);
+    int rc = c->words_keep ? WK_OK : wk_words_flush(c);  // records still accumulated (wk_words_append) are counted now
     if (rc) return rc;
+    if ((rc = check_device_errors(c))) return rc;
     HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 4), 0, sizeof(unsigned long long), c->stream));
     const int blocks = grid_for((int64_t)c->slots, 256, 2048);
     hipLaunchKernelGGL(table_count_kernel, dim3(blocks), dim3(256), 0, c->stream, c->tkeys.as<unsigned long long>(),
@@ -909,76 +1031,8 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
         a.jobs[j] = d;
     }
     if (c->subj_indexed) {
-        // (re)build the compact subject rows for this set of rank tables
-        if (c->n_subjects <= 0 && c->n_records > 0) return fail(c, WK_E_STATE, "chunk carries subject indices but no subject table is set (wk_set_subjects)");
-        std::vector<int> sig;
-        RowCols cols{};
-        for (int j = 0; j < n_jobs; ++j) {
-            if (jobs[j].mode != WK_MODE_RANK) continue;
-            int col = -1;
-            for (int q = 0; q < cols.n_cols; ++q)
-                if (sig[q] == jobs[j].rank_slot) col = q;
-            if (col < 0) {
-                col = cols.n_cols++;
-                sig.push_back(jobs[j].rank_slot);
-                cols.anc[col] = c->rank_tab[jobs[j].rank_slot].as<int32_t>();
-            }
-            a.jobs[j].col = col;
-        }
-        // `--rank free`: one more column with the subject's rank among the
-        // subjects of the tree, when it fits the 4-column row
-        bool any_free = false;
-        for (int j = 0; j < n_jobs; ++j) any_free |= jobs[j].mode == WK_MODE_FREE;
-        cols.by_subject = -1;
-        int free_col = -1;
-        // (the table has n log n entries: subject tables beyond 4 M keep the walk)
-        if (any_free && c->use_free_sparse && cols.n_cols < 3 && c->n_subjects > 0 && c->n_subjects <= (1 << 22) && c->n_nodes > 0) {
-            int rc2 = ensure_free_tables(c);
-            if (rc2) return rc2;
-            free_col = cols.n_cols++;
-            sig.push_back(-2);
-            sig.push_back(c->free_tree);
-            sig.push_back(c->free_subj);
-            cols.anc[free_col] = nullptr;
-            cols.by_subject = free_col;
-            cols.subject_col = c->f_rank.as<int32_t>();
-            a.free_sparse = c->f_sparse.as<int32_t>();
-            a.free_m = (int32_t)c->f_m;
-            a.free_col = free_col;
-        }
-        int w = 4;  // {feature, <= 3 rank columns}: the kernel's single-pass fast path
-        while (w < 1 + cols.n_cols) w <<= 1;
-        sig.push_back(-1);
-        sig.push_back(c->n_subjects);
-        if (sig != c->rows_sig || w != c->rows_w) {
-            HIP_TRY(c, c->subj_rows.reserve((size_t)std::max(c->n_subjects, 1) * w * sizeof(int32_t)));
-            if (c->n_subjects > 0) {
-                hipLaunchKernelGGL(subject_rows_kernel, dim3((c->n_subjects + 255) / 256), dim3(256), 0, c->stream,
-                                   c->subj_feat.as<int32_t>(), c->n_subjects, c->n_nodes, cols, w,
-                                   c->subj_rows.as<int32_t>());
-                HIP_TRY(c, hipGetLastError());
-            }
-            c->rows_sig = sig;
-            c->rows_w = w;
-            // which subjects the weighted histogram cannot take (wk_weigh.hpp)
-            c->rows_any_invalid = false;
-            c->rows_serial += 1;
-            if (c->n_subjects > 0) {
-                HIP_TRY(c, c->w_invalid.reserve(((size_t)c->n_subjects / 32 + 2) * 4));
-                HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 6), 0, 8, c->stream));
-                hipLaunchKernelGGL(subject_invalid_kernel, dim3((c->n_subjects + 255) / 256), dim3(256), 0, c->stream,
-                                   c->subj_rows.as<int32_t>(), w, cols.n_cols, c->n_subjects,
-                                   c->w_invalid.as<uint32_t>(), reinterpret_cast<uint32_t*>(scalar_u64(c, 6)));
-                HIP_TRY(c, hipGetLastError());
-                uint32_t any = 0;
-                HIP_TRY(c, hipMemcpyAsync(&any, scalar_u64(c, 6), 4, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                c->rows_any_invalid = any != 0;
-            }
-        }
-        a.rows = c->subj_rows.as<int32_t>();
-        a.row_w = w;
-        a.n_subjects = c->n_subjects;
+        const int rc_rows = build_subject_rows(c, jobs, n_jobs, a);
+        if (rc_rows) return rc_rows;
     } else {
         // chunk of feature ids: rank columns for the first pass of the split
         // (at most three distinct ranks, like a subject row)
@@ -1398,6 +1452,235 @@ int wk_classify_chunk(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, const int32
     return wk_classify_staged(c, jobs, n_jobs, out_assign);
 }
 
+// ---- packed records accumulated over the chunks of a sample ---------------------
+
+int wk_host_alloc(wk_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    void* p = nullptr;
+    HIP_TRY(c, hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    c->host_blocks.push_back(p);
+    *out = p;
+    return WK_OK;
+}
+
+int wk_host_free(wk_ctx* c, void* p) {
+    if (!c || !p) return WK_E_ARG;
+    auto it = std::find(c->host_blocks.begin(), c->host_blocks.end(), p);
+    if (it == c->host_blocks.end()) return fail(c, WK_E_ARG, "not a block of wk_host_alloc");
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->host_blocks.erase(it);
+    HIP_TRY(c, hipHostFree(p));
+    return WK_OK;
+}
+
+// Can the weighted histogram alone classify records under these jobs?  Plain
+// assigners only (see wk_weigh.hpp) and — checked against the current subject
+// table — every subject with an ancestor at every rank in use.
+static int words_jobs_ok(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, ClassifyArgs& a, bool* ok) {
+    *ok = false;
+    if (!c->use_weigh || c->n_subjects <= 0 || c->n_subjects > (int32_t)kWordSubjMask + 1) return WK_OK;
+    a = ClassifyArgs{};
+    a.n_jobs = n_jobs;
+    for (int j = 0; j < n_jobs; ++j) {
+        const wk_job& jb = jobs[j];
+        if (jb.flags & (WK_F_UNIQ | WK_F_SIZED)) return WK_OK;
+        if (jb.mode == WK_MODE_RANK) {
+            if ((jb.flags & WK_F_ABOVE) || jb.major > 0.0) return WK_OK;
+            if (c->n_nodes <= 0) return fail(c, WK_E_STATE, "job %d needs a hierarchy (wk_set_tree)", j);
+            if (jb.rank_slot < 0 || jb.rank_slot >= (int)(sizeof c->rank_tab / sizeof c->rank_tab[0]) || !c->rank_tab_valid[jb.rank_slot])
+                return fail(c, WK_E_STATE, "job %d: rank slot %d has not been built", j, jb.rank_slot);
+        } else if (jb.mode != WK_MODE_NONE) {
+            return WK_OK;
+        }
+        JobDev d{};
+        d.mode = jb.mode;
+        d.flags = jb.flags;
+        d.major = jb.major;
+        a.jobs[j] = d;
+    }
+    const int rc = build_subject_rows(c, jobs, n_jobs, a);
+    if (rc) return rc;
+    *ok = !c->rows_any_invalid;
+    return WK_OK;
+}
+
+static bool same_jobs(const std::vector<wk_job>& have, const wk_job* jobs, int32_t n) {
+    if ((int32_t)have.size() != n) return false;
+    for (int32_t j = 0; j < n; ++j)
+        if (have[j].mode != jobs[j].mode || have[j].rank_slot != jobs[j].rank_slot || have[j].flags != jobs[j].flags ||
+            have[j].major != jobs[j].major)
+            return false;
+    return true;
+}
+
+int wk_words_flush(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    if (!c->w_open || c->w_records == 0) {
+        c->w_open = false;
+        c->w_records = c->w_reads = 0;
+        return WK_OK;
+    }
+    if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
+    DeviceGuard guard(c->device);
+    ClassifyArgs a{};
+    bool ok = false;
+    int rc = words_jobs_ok(c, c->w_jobs.data(), (int32_t)c->w_jobs.size(), a, &ok);
+    if (rc) return rc;
+    // (wk_words_append refuses records once a subject without an ancestor at a
+    // rank in use shows up, so the rows that are valid now were valid for all of them)
+    if (!ok) return fail(c, WK_E_STATE, "accumulated records cannot be classified by the weighted histogram any more");
+    const int32_t n_jobs = (int32_t)c->w_jobs.size();
+    const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
+    uint32_t w_xcd = 8;
+    if (cus % w_xcd) w_xcd = 1;
+    const int64_t cap = (int64_t)kBinsMaxLds / 4 - 96;
+    const uint32_t w_slices = (uint32_t)((c->n_subjects + cap - 1) / cap);
+    const uint32_t w_bins = ((uint32_t)c->n_subjects + w_slices - 1) / w_slices;
+    const uint32_t w_teams = (cus / w_xcd) / w_slices;
+    if (!w_teams) return fail(c, WK_E_RANGE, "subject table too large for the weighted histogram");
+    const uint32_t n_teams = w_xcd * w_teams;
+    HIP_TRY(c, c->w_slab.reserve((size_t)w_slices * n_teams * w_bins * 4));
+    if ((size_t)c->n_subjects > c->w_hi_clean) {
+        HIP_TRY(c, c->w_hi.reserve((size_t)c->n_subjects * 4 + ((size_t)c->n_subjects * 4) / 2));
+        HIP_TRY(c, hipMemsetAsync(c->w_hi.p, 0, c->w_hi.cap, c->stream));
+        c->w_hi_clean = c->w_hi.cap / 4;
+    }
+    BinsArgs ba{};
+    ba.subj = c->c_words.as<int32_t>();
+    ba.rk = nullptr;
+    ba.n_records = (uint32_t)c->w_records;
+    ba.n_subjects = (uint32_t)c->n_subjects;
+    ba.bins = w_bins;
+    ba.n_slices = w_slices;
+    ba.teams_per_xcd = w_teams;
+    ba.n_xcd = w_xcd;
+    ba.slab = c->w_slab.as<uint32_t>();
+    ba.hi = c->w_hi.as<uint32_t>();
+    ba.err = scalar_err(c);
+    const dim3 wgrid(cus);
+    const size_t wlds = ((size_t)w_bins + 96) * 4;
+    KernelTimer* kt = ktimer_begin(c, "classify");
+    if (c->bins_ring == 6)
+        hipLaunchKernelGGL((weigh_bins_kernel<6, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+    else if (c->bins_ring == 8)
+        hipLaunchKernelGGL((weigh_bins_kernel<8, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+    else
+        hipLaunchKernelGGL((weigh_bins_kernel<4, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+    ktimer_end(c, kt);
+    kt = ktimer_begin(c, "weigh_merge");
+    WeighMergeArgs wm{};
+    wm.slab = ba.slab;
+    wm.hi = ba.hi;
+    wm.n_subjects = ba.n_subjects;
+    wm.bins = w_bins;
+    wm.n_teams = n_teams;
+    wm.rows = a.rows;
+    wm.row_w = a.row_w;
+    wm.n_jobs = n_jobs;
+    for (int j = 0; j < n_jobs; ++j) {
+        wm.mode[j] = a.jobs[j].mode;
+        wm.col[j] = a.jobs[j].col;
+    }
+    wm.group = (uint32_t)c->w_group;
+    wm.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
+    hipLaunchKernelGGL(weigh_merge_kernel, dim3((ba.n_subjects + 1023u) / 1024u), dim3(1024), (size_t)4096 * 16, c->stream, wm, 4096u);
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    c->stat_extra_reads += c->w_reads;
+    c->stat_extra_records += c->w_records;
+    if (c->words_keep) return WK_OK;  // (bench: repeated passes over the resident batch)
+    c->w_records = c->w_reads = 0;
+    c->w_open = false;
+    return WK_OK;
+}
+
+int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group, int* ok) {
+    if (!c || !ok) return WK_E_ARG;
+    *ok = 0;
+    if (!jobs || n_jobs < 1 || n_jobs > WK_MAX_JOBS) return fail(c, WK_E_ARG, "n_jobs must be in [1,%d]", WK_MAX_JOBS);
+    if (group < 0 || group >= (1 << WK_KEY_GROUP_BITS)) return fail(c, WK_E_ARG, "group id outside [0, %d)", 1 << WK_KEY_GROUP_BITS);
+    DeviceGuard guard(c->device);
+    // records accumulated under other jobs / another group are classified first
+    if (c->w_open && c->w_records > 0 && (group != c->w_group || !same_jobs(c->w_jobs, jobs, n_jobs))) {
+        const int rc = wk_words_flush(c);
+        if (rc) return rc;
+    }
+    ClassifyArgs a{};
+    bool good = false;
+    int rc = words_jobs_ok(c, jobs, n_jobs, a, &good);
+    if (rc) return rc;
+    if (!good) {
+        // (what is there was appended while every subject was valid: classify it now)
+        if (c->w_open && c->w_records > 0 && (rc = wk_words_flush(c))) return rc;
+        c->w_open = false;
+        return WK_OK;
+    }
+    c->w_jobs.assign(jobs, jobs + n_jobs);
+    c->w_group = group;
+    c->w_open = true;
+    *ok = 1;
+    return WK_OK;
+}
+
+int wk_words_append(wk_ctx* c, const uint32_t* words, int64_t n_records, int64_t n_reads, int slot) {
+    if (!c) return WK_E_ARG;
+    if (n_records < 0 || n_reads < 0 || (n_records > 0 && !words)) return fail(c, WK_E_ARG, "bad packed record arguments");
+    if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
+    if (slot < -1 || slot >= wk_ctx::kStageSlots) return fail(c, WK_E_ARG, "slot must be -1 or in [0, %d)", wk_ctx::kStageSlots);
+    DeviceGuard guard(c->device);
+    if (c->w_records + n_records >= (1ll << 30)) {  // the histogram addresses bytes with 32 bits
+        ClassifyArgs a{};
+        const std::vector<wk_job> jobs = c->w_jobs;
+        const int32_t group = c->w_group;
+        int rc = wk_words_flush(c);
+        if (rc) return rc;
+        int ok = 0;
+        if ((rc = wk_words_begin(c, jobs.data(), (int32_t)jobs.size(), group, &ok))) return rc;
+        if (!ok) return fail(c, WK_E_STATE, "job set no longer accepted");
+        if (n_records >= (1ll << 30)) return fail(c, WK_E_RANGE, "more than 2^30 records in one block");
+    }
+    const size_t need = (size_t)(c->w_records + n_records) * 4 + 64;
+    if (need > c->c_words.cap) {
+        // grow: a new buffer (twice the need) takes over what is there
+        DevBuf bigger;
+        HIP_TRY(c, bigger.reserve(need * 2));
+        if (c->w_records > 0) HIP_TRY(c, hipMemcpyAsync(bigger.p, c->c_words.p, (size_t)c->w_records * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->c_words.release();
+        c->c_words = bigger;
+    }
+    if (n_records > 0)
+        HIP_TRY(c, hipMemcpyAsync(c->c_words.as<uint32_t>() + c->w_records, words, (size_t)n_records * 4, hipMemcpyHostToDevice, c->stream));
+    if (slot >= 0) {
+        if (!c->slot_ev[slot]) HIP_TRY(c, hipEventCreateWithFlags(&c->slot_ev[slot], hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->slot_ev[slot], c->stream));
+        c->slot_busy[slot] = true;
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer is only valid during the call
+    }
+    c->w_records += n_records;
+    c->w_reads += n_reads;
+    return WK_OK;
+}
+
+int wk_words_wait(wk_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= wk_ctx::kStageSlots) return WK_E_ARG;
+    if (!c->slot_busy[slot]) return WK_OK;
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipEventSynchronize(c->slot_ev[slot]));
+    c->slot_busy[slot] = false;
+    return WK_OK;
+}
+
+int wk_words_pending(wk_ctx* c, int64_t* n_records, int64_t* n_reads) {
+    if (!c) return WK_E_ARG;
+    if (n_records) *n_records = c->w_open ? c->w_records : 0;
+    if (n_reads) *n_reads = c->w_open ? c->w_reads : 0;
+    return WK_OK;
+}
+
 // ---- ordinal -------------------------------------------------------------------
 
 int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const int32_t* end, const uint32_t* len,
@@ -1668,8 +1951,8 @@ int wk_get_stats(wk_ctx* c, wk_stats* out) {
         s[0] += part[2 * b];
         s[1] += part[2 * b + 1];
     }
-    out->n_reads = (int64_t)s[0] + c->stat_extra_reads;
-    out->n_records = (int64_t)s[1] + c->stat_extra_records;
+    out->n_reads = (int64_t)s[0] + c->stat_extra_reads + (c->w_open ? c->w_reads : 0);
+    out->n_records = (int64_t)s[1] + c->stat_extra_records + (c->w_open ? c->w_records : 0);
     out->n_pairs = c->stat_pairs;
     out->table_used = (int64_t)used;
     return WK_OK;

@@ -253,11 +253,18 @@ def classify(
                         # read maps alone are formatted natively from descriptors
                         want_strings = bool((demux and not native_demux) or (
                             stratmap and not native_strata))
+                        # plain assigners, one sample per file, nothing per
+                        # read: the records cross as packed words and the
+                        # sample is classified by one launch at its end
+                        words = not (ordinal or cover is not None or
+                                     want_names or native_strata or demux or
+                                     trimsub or rank2dir is not None) and \
+                            engine.words_eligible()
                         chunks = engine.native_chunks(
                             stream, head, exclude, NATIVE_BLOCK, ordinal,
                             want_names, trimsub, want_groups=native_strata,
                             want_strings=want_strings, want_samples=native_demux,
-                            cover=cover, fmt=fmt_, part=part)
+                            cover=cover, fmt=fmt_, part=part, words=words)
                     else:
                         text = io.TextIOWrapper(
                         io.BufferedReader(stream) if isinstance(
