@@ -158,3 +158,37 @@ def test_stratified_two_pass_through_the_replay(tmp_path, monkeypatch):
             wf.workflow(**a2)
         assert (sub / 'out1').read_text() == case['expect']['table1'], i
         assert (sub / 'out2').read_text() == case['expect']['table2'], i
+
+
+def test_sharded_run_replays_the_samples_a_process_holds_whole(tmp_path,
+                                                               monkeypatch):
+    """Under torch.distributed every process classifies with exact=True
+    (rationals, merged on the host).  The samples it holds whole are certified
+    / replayed there all the same: with every cell declared
+    uncertified, the cells of a whole sample come back as the reference-order
+    binary64 sums — equal to the single-process run's — while a sample this
+    process sees only a byte range of (FilePart) keeps its exact rationals."""
+    from fractions import Fraction
+    from woltka_amd.shard import FilePart
+    rng = np.random.default_rng(78)
+    prob = synth.as_sets(synth.lca_problem(rng, n_nodes=2000, n_subjects=200,
+                                           n_reads=20000, max_hits=7))
+    h = prob['hier']
+    names = h.index.names
+    tree = {names[v]: names[int(h.parent[v])] for v in range(h.n_nodes)}
+    inv = {c: r for r, c in h.rank_codes.items()}
+    rankdic = {names[v]: inv[int(c)] for v, c in enumerate(h.rank_code) if c}
+    a, b = tmp_path / 'A.sam', tmp_path / 'B.sam'
+    sam_of(prob, names, a)
+    sam_of(prob, names, b)
+    monkeypatch.setattr(C.Engine, 'uncertified', all_cells)
+    kw = dict(fmt='sam', tree=tree, rankdic=rankdic, root=names[0],
+              ranks=['genus'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        single = wf.classify(wf.plain_mapper, {str(a): 'A'}, ['A'], **kw)
+        shard = wf.classify(wf.plain_mapper,
+                            {str(a): 'A', FilePart(str(b), 0, 2): 'B'},
+                            ['A', 'B'], exact=True, **kw)
+    assert shard['genus']['A'] == single['genus']['A']
+    assert any(isinstance(v, float) for v in shard['genus']['A'].values())
+    assert all(isinstance(v, Fraction) for v in shard['genus']['B'].values())

@@ -423,6 +423,8 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
             del view
             if fill == len(buf):
                 buf = grown(buf, fill)
+            if ramp is not None:                # (a run longer than the ramp
+                ramp = min(block_bytes, ramp * 4)   # block: read faster)
             continue                            # no complete run yet: read more
         first = False
         yield view[:fill], res

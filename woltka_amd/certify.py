@@ -80,13 +80,15 @@ def certified(x, n_chunks, digits=None, factor=None, chunk_n=1024,
 
 
 def uncertified(units, big, n_reads, unit, digits=None, factor=None,
-                chunk_n=1024):
+                chunk_n=1024, n_files=1):
     """Keys of the cells of one (rank, sample) that are not certified.
     `units`: {key: integer units of 1 / unit}; `big`: {key: Fraction} extra
     exact parts (reads with more than 16 candidates); `n_reads`: reads the
-    sample's files hold (bounds the number of mapper chunks)."""
+    sample's files hold, `n_files`: how many files those are — the mapper
+    starts a new chunk with every file (align.plain_mapper, align.py:84-115),
+    so together they bound the number of mapper chunks."""
     import numpy as np
-    n_chunks = ceil(n_reads / max(1, chunk_n)) + 1
+    n_chunks = ceil(n_reads / max(1, chunk_n)) + max(1, n_files)
     keys = list(units)
     suspects = [k for k in big if k not in units]
     p10 = 10 ** (digits or 0)

@@ -74,15 +74,20 @@ class MapWriter:
     while the device and the tokenizer work on the next chunk.  `flush` waits
     for everything."""
 
-    def __init__(self, threads=32, block=8 << 20):
+    def __init__(self, threads=32, block=8 << 20, cap=1 << 30):
         from concurrent.futures import ThreadPoolExecutor
         self._pool = ThreadPoolExecutor(max_workers=threads)
         self._pending = []          # [(path, [future | bytes])] in call order
         self._block = block
+        self._held = []             # input bytes of the calls still pending
+        self._cap = cap
 
     def append(self, path, data, kind):
         if not kind or not data:
             self._pending.append((path, [data]))
+            self._held.append(len(data))
+            self._drain(False)
+            return
         else:
             import bz2
             import lzma
@@ -99,9 +104,14 @@ class MapWriter:
             self._pending.append((path, [
                 self._pool.submit(pack, data[a:b])
                 for a, b in zip(cuts, cuts[1:])]))
+        self._held.append(len(data))
+        # text waiting to be compressed and written stays bounded: beyond the
+        # cap the caller waits for the oldest members
         self._drain(False)
+        while self._pending and sum(self._held) > self._cap:
+            self._drain(True, one=True)
 
-    def _drain(self, wait):
+    def _drain(self, wait, one=False):
         while self._pending:
             path, parts = self._pending[0]
             if not wait and not all(isinstance(x, bytes) or x.done()
@@ -111,6 +121,9 @@ class MapWriter:
                 for x in parts:
                     f.write(x if isinstance(x, bytes) else x.result())
             self._pending.pop(0)
+            self._held.pop(0)
+            if one:
+                return
 
     def flush(self):
         self._drain(True)
@@ -243,6 +256,7 @@ class Engine:
         self._job_base = 0                  # first job of the batch in flight
         self._final = {}                    # (rank, sample) -> (units, big) of the last `finish`
         self._n_reads = 0                   # reads classified (bounds the mapper chunks)
+        self._n_files = 0                   # alignment files begun (each restarts the mapper's chunks)
         self._replay = None
         self._writer = None                 # MapWriter of the native read maps
         self.genes = None
@@ -731,6 +745,8 @@ class Engine:
         if self._replay is not None:
             self._replay_close()
             self._replay['pos'] = 0
+        else:
+            self._n_files += 1
 
     def uncertified(self, digits=None, factor=None, chunk_n=1024):
         """{rank: {sample: [keys]}} of the cells of the last `finish` that are
@@ -747,7 +763,8 @@ class Engine:
             if rank not in lists:
                 continue
             keys = certify.uncertified(units, big, self._n_reads,
-                                       nat.WEIGHT_L, digits, factor, chunk_n)
+                                       nat.WEIGHT_L, digits, factor, chunk_n,
+                                       n_files=max(1, self._n_files))
             if keys:
                 out.setdefault(rank, {})[sample] = keys
         return out
@@ -767,6 +784,9 @@ class Engine:
         res = self._replay['total']
         self._replay = None
         self.ctx.counts_clear()
+        # (the pass counted on the device as well, and a full table may have
+        # been folded to the host on the way: none of that is wanted)
+        self._units, self._big = {}, {}
         self.groups, self.group_ids = [], {}
         self._epoch += 1
         return res

@@ -1528,9 +1528,12 @@ int wk_words_flush(wk_ctx* c) {
     bool ok = false;
     int rc = words_jobs_ok(c, c->w_jobs.data(), (int32_t)c->w_jobs.size(), a, &ok);
     if (rc) return rc;
-    // (wk_words_append refuses records once a subject without an ancestor at a
-    // rank in use shows up, so the rows that are valid now were valid for all of them)
-    if (!ok) return fail(c, WK_E_STATE, "accumulated records cannot be classified by the weighted histogram any more");
+    // (`ok` may be false by now: a subject without an ancestor at a rank in use
+    // joined the table after these records.  wk_words_begin stops accepting
+    // records the moment that happens, so every subject the accumulated records
+    // name has a valid row — rows of old subjects do not change when the table
+    // grows — and the new ones carry no weight.)
+    (void)ok;
     const int32_t n_jobs = (int32_t)c->w_jobs.size();
     const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
     uint32_t w_xcd = 8;

@@ -20,6 +20,8 @@ stratified ids ``stratum|feature``, values printed with ``str()``.  A BIOM
 file is converted to this tuple when read and back when written; one code path
 serves both formats.
 """
+from itertools import repeat
+
 from .file import openzip
 from .tree import lineage_str
 
@@ -47,7 +49,22 @@ def prep_table(profile, samples=None, tree=None, rankdic=None, namedic=None,
     if tree:
         metacols.append('Lineage')
     data, features, metadata = [], [], []
-    for key in sorted(allkeys(profile)):
+    keys = sorted(allkeys(profile))
+    if not metacols and not (namedic and name_as_id) and \
+            all(type(k) is str for k in keys):
+        # the usual profile — plain feature ids, no metadata columns — without
+        # a Python loop body per feature: C-level lookups per sample, rows
+        # that are all zero dropped (table.py:115)
+        cols = [list(map(profile[s].get, keys, repeat(0))) for s in samples]
+        if len(cols) == 1:
+            kept = [(k, [v]) for k, v in zip(keys, cols[0]) if v]
+        else:
+            kept = [(k, list(row)) for k, row in zip(keys, zip(*cols))
+                    if any(row)]
+        features = [k for k, _ in kept]
+        data = [row for _, row in kept]
+        return data, features, samples, [{} for _ in features]
+    for key in keys:
         row = [profile[s][key] if key in profile[s] else 0 for s in samples]
         if not any(row):
             continue
@@ -82,6 +99,14 @@ def write_tsv(table, fh):
             fields.append('\t'.join(extra))
         fh.write('\t'.join(fields) + '\n')
     line('#FeatureID', samples, metacols)
+    if not metacols:
+        if len(samples) == 1:
+            fh.writelines(f'{feature}\t{counts[0]}\n'
+                          for feature, counts in zip(features, data))
+        else:
+            fh.writelines(feature + '\t' + '\t'.join(map(str, counts)) + '\n'
+                          for feature, counts in zip(features, data))
+        return
     for feature, counts, meta in zip(features, data, metadata or
                                      [None] * len(features)):
         line(feature, map(str, counts), meta.values() if metacols else ())

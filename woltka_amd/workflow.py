@@ -337,11 +337,29 @@ def classify(
         # Cells whose exact value lies so close to a rounding boundary that
         # the reference's float summation might land on the other side are
         # summed once more in the reference's own order (certify.py).
-        if not exact and not sizes and not ordinal and cover is None and \
-                mapper is plain_mapper and '-' not in map(file_path, files):
+        # Under torch.distributed (`exact`: the profiles of the processes
+        # are added as exact rationals) a process certifies the samples it
+        # holds whole — only it sees their records; a sample cut into byte
+        # ranges over several processes (FilePart) or demultiplexed out of
+        # files of several processes cannot be replayed by one of them and
+        # keeps its exact value.
+        whole = None
+        if exact:
+            whole = set()
+            if isinstance(files, dict) and not demux:
+                cut = {s for fp, s in files.items() if isinstance(fp, FilePart)}
+                whole = {s for fp, s in files.items()
+                         if not isinstance(fp, FilePart)} - cut
+        if (not exact or whole) and not sizes and not ordinal and \
+                cover is None and mapper is plain_mapper and \
+                '-' not in map(file_path, files):
             digits, factor, frac = rounding or (None, None, False)
             todo = {} if frac else engine.uncertified(
                 digits, factor, chunk or 1024)
+            if whole is not None:
+                todo = {r: {s: k for s, k in per.items() if s in whole}
+                        for r, per in todo.items()}
+                todo = {r: per for r, per in todo.items() if per}
             if todo:
                 engine.replay_begin(todo, chunk or 1024)
                 csample, strata = False, None
@@ -780,11 +798,17 @@ def round_half_snap(value, digits=None):
 
 
 def round_profiles(data, digits=None):
-    """Round cells, drop zeros (workflow.py:1106-1119, util.round_dict)."""
+    """Round cells, drop zeros (workflow.py:1106-1119, util.round_dict).  An
+    ``int`` cell rounds to itself (``round(v * 2) / 2 == v``), so only the
+    other cells go through the rule."""
     for profile in data.values():
         for sample in profile.values():
             dead = []
             for feature, value in sample.items():
+                if type(value) is int and not digits:
+                    if not value:
+                        dead.append(feature)
+                    continue
                 r = round_half_snap(value, digits)
                 if r:
                     sample[feature] = r
