@@ -998,12 +998,15 @@ def run_rank(a, rank, world, local, sync):
     return side_blocks(a, line, wl, ctx, dev)
 
 
-def e2e_scale_for(world, frac, per_rank_bytes=14e9):
+def e2e_scale_for(world, frac, per_rank_bytes=14e9, workdir=None):
     """Largest fraction <= `frac` of the configuration whose text (page
-    cache) + packed problem fit this host's free memory `world` times."""
+    cache / work directory) + packed problem fit this host `world` times."""
     try:
         import psutil
+        import shutil
         free = psutil.virtual_memory().available
+        if workdir:
+            free = min(free, 1.6 * shutil.disk_usage(workdir).free)
     except Exception:
         return frac
     fit = 0.5 * free / (world * per_rank_bytes)
@@ -1027,7 +1030,7 @@ def side_blocks(a, line, wl, ctx, dev):
         if not a.no_e2e:
             try:
                 e2e['lca'] = e2e_leg('lca', wl.prob, wl.reads, dev,
-                                     frac=e2e_scale_for(1, a.e2e_frac),
+                                     frac=e2e_scale_for(1, a.e2e_frac, workdir=a.tmp),
                                      workdir=a.tmp)
             except Exception as e:
                 e2e['lca'] = {'error': repr(e)}
@@ -1059,7 +1062,8 @@ def side_blocks(a, line, wl, ctx, dev):
                 try:
                     e2e['ordinal'] = e2e_leg(
                         'ordinal', prob, reads, dev,
-                        frac=e2e_scale_for(1, a.e2e_frac), workdir=a.tmp)
+                        frac=e2e_scale_for(1, a.e2e_frac, workdir=a.tmp),
+                        workdir=a.tmp)
                 except Exception as e:
                     e2e['ordinal'] = {'error': repr(e)}
             del prob
@@ -1079,7 +1083,7 @@ def e2e_ranks(a, line, wl, dev, world, sync):
     sample files at the same time (the host's tokenizer threads are shared
     among the ranks: classify.tokenizer_threads); aggregate = records of all
     ranks / slowest rank's wall time."""
-    frac = e2e_scale_for(world, a.e2e_frac)
+    frac = e2e_scale_for(world, a.e2e_frac, workdir=a.tmp)
     if world > 1:
         frac = sync.allmax(-frac) * -1.0        # every rank the same size
     try:
@@ -1172,8 +1176,22 @@ def parse_args(argv=None):
                     help='skip the per-config blocks, the end-to-end leg and '
                          'the CPU baseline')
     ap.add_argument('--tmp', default=None,
-                    help='directory for the synthetic text files')
-    return ap.parse_args(argv)
+                    help='directory for the synthetic text files (default: '
+                         '/dev/shm or the temporary directory, whichever has '
+                         'more room)')
+    a = ap.parse_args(argv)
+    if a.tmp is None:
+        import shutil
+        best = None
+        for d in ('/dev/shm', tempfile.gettempdir()):
+            try:
+                free = shutil.disk_usage(d).free
+            except OSError:
+                continue
+            if os.access(d, os.W_OK) and (best is None or free > best[0]):
+                best = (free, d)
+        a.tmp = best[1] if best else None
+    return a
 
 
 def main():
