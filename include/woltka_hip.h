@@ -378,6 +378,15 @@ int wk_tok_boundary(int fmt, int extra, const char* buf, int64_t len,
  * (byte offset in buf << 24) | (length << 2) | mate.  NULL skips an array. */
 int wk_tok_fetch(wk_tok* tok, int32_t* subj, int32_t* off, int32_t* beg,
                  int32_t* end, uint32_t* len, uint64_t* qname);
+/* *got bytes of [offset, offset + len) of the open file `fd` into dst, read by
+ * all tokenizer threads (pread on slices); short only at the end of the file. */
+int wk_tok_read(wk_tok* tok, int fd, int64_t offset, char* dst, int64_t len,
+                int64_t* got);
+/* Translate subject indices on their way out (wk_tok_fetch's `subj`):
+ * subj[i] = map[dictionary id], -1 for ids >= n.  The coord-match stages genome
+ * indices of the gene tables (wk_ordinal_stage), which the host derives from the
+ * names of wk_tok_new_subjects; map == NULL switches the translation off. */
+int wk_tok_set_subject_map(wk_tok* tok, const int32_t* map, int32_t n);
 /* The plain flavour's records in the form the weighted histogram of the device
  * streams (wk_words_append): packed[i] = subject index | position of record i
  * in its read << 23 | size << 27, size = the number of records of its read
@@ -505,6 +514,25 @@ int wk_hier_keys(const wk_hier* h, int field, char* blob, int64_t cap,
  * number of keys that carry each rank. */
 int wk_hier_ranks(const wk_hier* h, char* blob, int64_t cap, int64_t* off,
                   int64_t* used);
+
+/* ---- native gene coordinates reader (host) -------------------------------- */
+/* ordinal.load_gene_coords + encode_genes (ordinal.py:338-473): ">name" /
+ * "# name" lines start a nucleotide (a doubled marker is ignored), other lines
+ * are "gene <tab> beg <tab> end"; start0 = min(beg, end) - 1, end = max(beg,
+ * end); genes of a nucleotide stably sorted by start0; isdup = a gene id was
+ * seen twice.  WK_E_ARG: the reference's error (message: wk_coords_error);
+ * WK_E_STATE: text left to the Python reader (non-ASCII white space, numbers
+ * beyond plain digits, a bare '\r', coordinates before the first nucleotide). */
+typedef struct wk_coords wk_coords;
+int wk_coords_parse(const char* buf, int64_t len, wk_coords** out);
+const char* wk_coords_error(const wk_coords* c);
+int wk_coords_sizes(const wk_coords* c, int32_t* n_genomes, int32_t* n_genes,
+                    int64_t* genome_bytes, int64_t* gene_bytes, int* isdup);
+/* goff[n_genomes + 1], start0/end[n_genes], names as blob + off[n + 1]. */
+int wk_coords_fetch(const wk_coords* c, int32_t* goff, int32_t* start0,
+                    int32_t* end, char* genome_blob, int64_t* genome_off,
+                    char* gene_blob, int64_t* gene_off);
+void wk_coords_free(wk_coords* c);
 
 /* ---- measurement ------------------------------------------------------- */
 /* HIP-event timing on the context's own stream (the stream every kernel of

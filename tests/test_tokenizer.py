@@ -552,7 +552,7 @@ def test_packed_words_equal_the_plain_arrays(threads, block):
     it = iter(bufs)
     got = []
     for buf, res in align.native_sam_blocks(io.BytesIO(text), tok, block,
-                                            packed_buf=lambda: next(it)):
+                                            sink=lambda *a: {'packed': next(it)}):
         assert 'words' in res
         got.append((res['words'].copy(), res['n_reads']))
     tok.close()
@@ -567,6 +567,6 @@ def test_packed_words_equal_the_plain_arrays(threads, block):
     big = ''.join(f'big\t0\tS{s}\t1\t42\t10M\t*\t0\t0\t*\t*\n' for s in range(17))
     tok = Tokenizer(threads)
     res = tok.parse(memoryview(text + big.encode()), first=True, final=True,
-                    packed_out=np.zeros(1 << 16, np.uint32))
+                    sink=lambda *a: {'packed': np.zeros(1 << 16, np.uint32)})
     assert 'words' not in res and int(np.diff(res['off']).max()) == 17
     tok.close()

@@ -47,7 +47,8 @@ SYMBOLS = (
     'wk_tok_create', 'wk_tok_destroy', 'wk_tok_last_error',
     'wk_tok_set_exclude', 'wk_tok_sam_tail', 'wk_tok_sam', 'wk_tok_text',
     'wk_tok_boundary',
-    'wk_tok_fetch', 'wk_tok_fetch_packed',
+    'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
+    'wk_tok_read',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
@@ -55,7 +56,9 @@ SYMBOLS = (
     'wk_hier_create', 'wk_hier_destroy', 'wk_hier_last_error',
     'wk_hier_add_text', 'wk_hier_update', 'wk_hier_finish', 'wk_hier_arrays',
     'wk_hier_root', 'wk_hier_lookup', 'wk_hier_node_names', 'wk_hier_get',
-    'wk_hier_size', 'wk_hier_keys', 'wk_hier_ranks')
+    'wk_hier_size', 'wk_hier_keys', 'wk_hier_ranks',
+    'wk_coords_parse', 'wk_coords_error', 'wk_coords_sizes',
+    'wk_coords_fetch', 'wk_coords_free')
 
 
 class Job(C.Structure):
@@ -155,6 +158,9 @@ def load_library():
                                   i64p]),
         'wk_tok_fetch': (C.c_int, [p, i32p, i32p, i32p, i32p, u32p, u64p]),
         'wk_tok_fetch_packed': (C.c_int, [p, u32p, i32p, u64p, i64p]),
+        'wk_tok_set_subject_map': (C.c_int, [p, i32p, C.c_int32]),
+        'wk_tok_read': (C.c_int, [p, C.c_int, C.c_int64, C.c_void_p, C.c_int64,
+                                  i64p]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
         'wk_tok_fetch_groups': (C.c_int, [p, i32p]),
@@ -185,6 +191,13 @@ def load_library():
         'wk_hier_size': (C.c_int64, [p, C.c_int]),
         'wk_hier_keys': (C.c_int, [p, C.c_int, C.c_void_p, C.c_int64, i64p]),
         'wk_hier_ranks': (C.c_int, [p, C.c_void_p, C.c_int64, i64p, i64p]),
+        'wk_coords_parse': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(p)]),
+        'wk_coords_error': (C.c_char_p, [p]),
+        'wk_coords_sizes': (C.c_int, [p, i32p, i32p, i64p, i64p,
+                                      C.POINTER(C.c_int)]),
+        'wk_coords_fetch': (C.c_int, [p, i32p, i32p, i32p, C.c_void_p, i64p,
+                                      C.c_void_p, i64p]),
+        'wk_coords_free': (None, [p]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -687,14 +700,51 @@ class Tokenizer:
             raise ValueError('wk_tok_boundary failed')
         return out.value
 
+    def read_into(self, fd, offset, view):
+        """Fill ``view`` (writable bytes-like) from file descriptor ``fd`` at
+        ``offset`` with all tokenizer threads; returns the bytes read (short
+        only at the end of the file)."""
+        mv = memoryview(view)
+        n = mv.nbytes
+        if n == 0:
+            return 0
+        raw = np.frombuffer(mv, dtype=np.uint8)
+        got = C.c_int64(0)
+        try:
+            self._check(self._lib.wk_tok_read(
+                self._h, int(fd), int(offset), C.c_void_p(raw.ctypes.data), n,
+                C.byref(got)))
+        finally:
+            del raw
+            mv.release()
+        return got.value
+
+    def set_subject_map(self, table):
+        """Translate subject ids at fetch time: ``subj`` comes out as
+        ``table[id]`` (-1 beyond the table); ``None`` switches it off."""
+        if table is None:
+            self._check(self._lib.wk_tok_set_subject_map(self._h, None, 0))
+            return
+        table = _arr(table, np.int32)
+        self._check(self._lib.wk_tok_set_subject_map(
+            self._h, _ptr(table, C.c_int32), table.size))
+
     def parse(self, buf, first=False, final=False, extra=False,
               want_names=False, want_groups=False, want_samples=False,
-              fmt='sam', packed_out=None):
+              fmt='sam', sink=None):
         """Tokenize ``buf`` (bytes-like) of alignment format ``fmt``
         (sam / map / b6o / paf).  Returns a dict with ``consumed``,
         ``subj``, ``off`` (+ ``beg``/``end``/``len`` with ``extra``,
         ``qname`` descriptors with ``want_names``, ``group`` = stratum ids with
-        ``want_groups``)."""
+        ``want_groups``).
+
+        ``sink(tok, n_reads, n_records)`` is called between tokenising and
+        fetching and may return the arrays the results are written into
+        (pinned staging buffers): ``{'packed': uint32[]}`` asks for the plain
+        flavour's records as packed words (``result['words']``; blocks with a
+        read of more than 16 records come back the general way), ``{'subj',
+        'off', 'beg', 'end', 'len'}`` for the arrays themselves; anything it
+        returns is marked ``result['sunk']``."""
         mv = memoryview(buf)
         n = mv.nbytes
         addr = C.c_void_p(np.frombuffer(mv, dtype=np.uint8).ctypes.data) \
@@ -710,6 +760,8 @@ class Tokenizer:
             int(bool(want_names)) | (2 if want_groups else 0) |
             (4 if want_samples else 0),
             C.byref(consumed), C.byref(nrd), C.byref(nrec)))
+        bufs = sink(self, nrd.value, nrec.value) if sink is not None else None
+        packed_out = bufs.get('packed') if bufs else None
         if packed_out is not None and not extra and not want_names and \
                 not want_groups and not want_samples and \
                 nrec.value <= packed_out.size:
@@ -721,18 +773,31 @@ class Tokenizer:
                 self._h, _ptr(packed_out, C.c_uint32), None, None,
                 C.byref(n_big))
             if rc == OK and n_big.value == 0:
-                return {'consumed': consumed.value,
+                return {'consumed': consumed.value, 'sunk': True,
                         'words': packed_out[:nrec.value],
                         'n_reads': nrd.value}
             if rc not in (OK, E_RANGE):
                 self._check(rc)
-        out = {'consumed': consumed.value,
-               'subj': np.empty(nrec.value, np.int32),
-               'off': np.empty(nrd.value + 1, np.int32)}
-        if extra:
-            out['beg'] = np.empty(nrec.value, np.int32)
-            out['end'] = np.empty(nrec.value, np.int32)
-            out['len'] = np.empty(nrec.value, np.uint32)
+        out = {'consumed': consumed.value}
+        sunk = bool(bufs) and 'subj' in bufs and \
+            bufs['subj'].size >= nrec.value and \
+            bufs['off'].size >= nrd.value + 1 and \
+            (not extra or min(bufs[k].size for k in ('beg', 'end', 'len'))
+             >= nrec.value)
+        if sunk:
+            out['sunk'] = True
+            out['subj'] = bufs['subj'][:nrec.value]
+            out['off'] = bufs['off'][:nrd.value + 1]
+            if extra:
+                for k in ('beg', 'end', 'len'):
+                    out[k] = bufs[k][:nrec.value]
+        else:
+            out['subj'] = np.empty(nrec.value, np.int32)
+            out['off'] = np.empty(nrd.value + 1, np.int32)
+            if extra:
+                out['beg'] = np.empty(nrec.value, np.int32)
+                out['end'] = np.empty(nrec.value, np.int32)
+                out['len'] = np.empty(nrec.value, np.uint32)
         if want_names:
             out['qname'] = np.empty(nrd.value, np.uint64)
         self._check(self._lib.wk_tok_fetch(
@@ -971,3 +1036,44 @@ class HierarchyBuilder:
         self._check(self._lib.wk_hier_keys(self._h, field, blob,
                                            int(off[-1]), _ptr(off, C.c_int64)))
         return _split(blob.raw, off)
+
+
+def parse_gene_coords(buf):
+    """Gene coordinates text (bytes-like) through ``wk_coords_parse``.
+    Returns (goff, start0, end, genome names, (gene blob, gene offsets),
+    isdup), or None when the text is left to the Python reader; raises
+    ValueError with the reference's message for a malformed file."""
+    lib = load_library()
+    mv = memoryview(buf)
+    n = mv.nbytes
+    raw = np.frombuffer(mv, dtype=np.uint8) if n else None
+    h = C.c_void_p()
+    try:
+        addr = C.c_void_p(raw.ctypes.data) if n \
+            else C.cast(C.c_char_p(b''), C.c_void_p)
+        rc = lib.wk_coords_parse(addr, n, C.byref(h))
+        if rc == E_STATE:
+            return None
+        if rc != OK:
+            raise ValueError(lib.wk_coords_error(h).decode(errors='replace'))
+        ng, nn, gb, nb, dup = (C.c_int32(), C.c_int32(), C.c_int64(),
+                               C.c_int64(), C.c_int())
+        lib.wk_coords_sizes(h, C.byref(ng), C.byref(nn), C.byref(gb),
+                            C.byref(nb), C.byref(dup))
+        goff = np.empty(ng.value + 1, np.int32)
+        start0, end = np.empty(nn.value, np.int32), np.empty(nn.value, np.int32)
+        gblob = C.create_string_buffer(max(1, gb.value))
+        nblob = C.create_string_buffer(max(1, nb.value))
+        g_off = np.empty(ng.value + 1, np.int64)
+        n_off = np.empty(nn.value + 1, np.int64)
+        lib.wk_coords_fetch(h, _ptr(goff, C.c_int32), _ptr(start0, C.c_int32),
+                            _ptr(end, C.c_int32), gblob, _ptr(g_off, C.c_int64),
+                            nblob, _ptr(n_off, C.c_int64))
+        return (goff, start0, end, _split(gblob.raw, g_off),
+                (nblob.raw[:nb.value], n_off), bool(dup.value))
+    finally:
+        if h:
+            lib.wk_coords_free(h)
+        del raw
+        mv.release()
+

@@ -355,7 +355,7 @@ def _tail_block(tok, exclude, extra, want_names, want_groups, want_samples,
 def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
                       want_names=False, head=b'', want_groups=False,
                       want_samples=False, fmt='sam', part=None, exclude=None,
-                      packed_buf=None):
+                      sink=None):
     """Feed a binary alignment stream (SAM by default; map / b6o / paf via
     ``fmt``) through the native tokenizer (``_native.Tokenizer``) block by
     block.
@@ -369,14 +369,19 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
     A regular uncompressed file is memory-mapped and tokenised in place (no
     copies); pipes and codec streams are read into one reusable buffer.
     """
-    # ``packed_buf``: a callable handing out one (pinned) uint32 buffer per
-    # block; blocks whose records fit come back as packed words
-    # (``result['words']``, the buffer itself) instead of ``subj`` / ``off``
+    # ``sink``: see ``Tokenizer.parse`` — called per block between tokenising
+    # and fetching, may hand out the (pinned) arrays the results go to
+    reader = _parallel_reader(stream, tok, part)
+    if reader is not None:
+        yield from _blocks_pread(reader, tok, block_bytes, extra, want_names,
+                                 want_groups, want_samples, fmt, exclude, sink,
+                                 len(head))
+        return
     mm = _try_mmap(stream)
     if mm is not None:
         yield from _blocks_mmap(mm, len(head), tok, block_bytes, extra,
                                 want_names, want_groups, want_samples, fmt,
-                                part, exclude, packed_buf)
+                                part, exclude, sink)
         return
     if part is not None:
         raise ValueError('A byte range needs a regular uncompressed file.')
@@ -417,7 +422,7 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
         res = tok.parse(view[:fill], first=first, final=final, extra=extra,
                         want_names=want_names, want_groups=want_groups,
                         want_samples=want_samples, fmt=fmt,
-                        packed_out=packed_buf() if packed_buf else None)
+                        sink=sink)
         used = res['consumed']
         if used == 0 and not final and _n_reads(res) == 0:
             del view
@@ -448,6 +453,102 @@ def native_sam_blocks(stream, tok, block_bytes=1 << 26, extra=False,
         fill = rest
 
 
+def _parallel_reader(stream, tok, part):
+    """(fd, size) of a regular file whose blocks all tokenizer threads read
+    with pread (``Tokenizer.read_into``) instead of mapping it — the mapping's
+    page faults and the unmapping are paid by the tokenizer threads, and by
+    every process of a node at once; WOLTKA_READ=mmap keeps the map (byte
+    ranges of one file, ``part``, always use it)."""
+    import io
+    import os
+    import stat
+    if part is not None or os.environ.get('WOLTKA_READ', 'pread') != 'pread':
+        return None
+    if not isinstance(stream, (io.BufferedReader, io.FileIO)):
+        return None
+    try:
+        fd = stream.fileno()
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_size == 0:
+            return None
+        return fd, st.st_size
+    except (OSError, ValueError, io.UnsupportedOperation):
+        return None
+
+
+def _blocks_pread(reader, tok, block_bytes, extra, want_names, want_groups,
+                  want_samples, fmt, exclude, sink, start):
+    """Tokenise a regular file block by block through buffers filled by all
+    tokenizer threads.  Three buffers rotate (a consumer that keeps read ids
+    gets fresh ones instead: its blocks stay alive); the unfinished last run
+    of a block is copied to the front of the next."""
+    del start                   # (sniffed bytes are read again from offset 0)
+    fd, size = reader
+    ramp = None if getattr(tok, 'warm', False) else min(block_bytes, 1 << 20)
+    keep = bool(want_names)     # consumers hold on to the text
+    pool = []
+
+    def buffer(n):
+        # (uninitialised memory: the reads fill it; a bytearray would be
+        # zeroed first, which costs as much as tokenising the block)
+        import numpy as np
+        if not keep:
+            for i, b in enumerate(pool):
+                if len(b) >= n:
+                    return pool.pop(i)
+        return np.empty(n, dtype=np.uint8)
+
+    pos, first = 0, True
+    carry = b''
+    recycle = []                # buffers handed out, oldest first
+    while pos < size or carry:
+        span = ramp or block_bytes
+        want = min(span, size - pos)
+        buf = buffer(len(carry) + want)
+        view = memoryview(buf).cast('B')
+        view[:len(carry)] = carry
+        got = tok.read_into(fd, pos, view[len(carry):len(carry) + want]) \
+            if want else 0
+        fill = len(carry) + got
+        pos += got
+        final = pos >= size or (want and got == 0)
+        res = tok.parse(view[:fill], first=first, final=final, extra=extra,
+                        want_names=want_names, want_groups=want_groups,
+                        want_samples=want_samples, fmt=fmt, sink=sink)
+        used = res['consumed']
+        if used == 0 and not final and _n_reads(res) == 0:
+            # no complete run yet: keep everything, read more
+            carry = bytes(view[:fill])
+            del view
+            if ramp is not None:
+                ramp = min(block_bytes, ramp * 4)
+            else:
+                block_bytes *= 2
+            if not keep:
+                pool.append(buf)
+            continue
+        first = False
+        carry = bytes(view[used:fill]) if not final else b''
+        yield view[:fill], res
+        if not keep:
+            # the consumer is at most a few blocks behind (prefetch depth):
+            # a buffer comes back into use after four others
+            recycle.append(buf)
+            if len(recycle) > 4:
+                pool.append(recycle.pop(0))
+        del view
+        if final:
+            tail = _tail_block(tok, exclude, extra, want_names, want_groups,
+                               want_samples, fmt)
+            if tail is not None:
+                yield tail
+            return
+        if ramp is not None:
+            ramp = min(block_bytes, ramp * 4)
+            if ramp == block_bytes:
+                tok.warm, ramp = True, None
+
+
 def _try_mmap(stream):
     """mmap of a regular file opened in binary mode, else None."""
     import io
@@ -472,7 +573,7 @@ def _n_reads(res):
 
 def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
                  want_groups=False, want_samples=False, fmt='sam', part=None,
-                 exclude=None, packed_buf=None):
+                 exclude=None, sink=None):
     """Tokenise a memory-mapped file in place.  ``start`` bytes were already
     read from the stream for format sniffing; the map covers the whole file,
     so they are simply parsed again from offset 0.  ``part`` = (i, n) restricts
@@ -504,7 +605,7 @@ def _blocks_mmap(mm, start, tok, block_bytes, extra, want_names,
                             extra=extra, want_names=want_names,
                             want_groups=want_groups,
                             want_samples=want_samples, fmt=fmt,
-                            packed_out=packed_buf() if packed_buf else None)
+                            sink=sink)
             used = res['consumed']
             if used == 0 and not final and _n_reads(res) == 0:
                 span *= 2

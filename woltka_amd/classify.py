@@ -135,17 +135,24 @@ class MapWriter:
             self._pool.shutdown(wait=True)
 
 
-class WordRing:
-    """Pinned host buffers for the packed records of the native tokenizer
-    (``_native.Context.host_alloc``): the tokenizer thread fills one while
-    earlier ones wait in the prefetch queue or are being copied to the device
-    (``wk_words_append`` only enqueues the copy).  ``current()`` blocks until a
-    buffer is free, ``take()`` hands the current one to a block, the consumer
-    gives it back with ``release()`` once its copy has finished."""
+class _Staged(tuple):
+    """Arrays of a block that live in a ``StageRing`` slot."""
+    slot = None
 
-    def __init__(self, ctx, slots, capacity):
+
+class StageRing:
+    """Pinned host buffers for what the native tokenizer hands over
+    (``_native.Context.host_alloc``): the tokenizer threads write a block's
+    results straight into one set of arrays — no page of a fresh allocation to
+    fault in, and the copy to the device reads pinned memory — while earlier
+    sets wait in the prefetch queue or are being copied.  ``layout`` =
+    {name: (dtype, elements)}.  ``current()`` blocks until a set is free,
+    ``take()`` hands the current one to a block, the consumer gives it back
+    with ``release()`` once the device has it."""
+
+    def __init__(self, ctx, slots, layout):
         import queue
-        self._ctx, self.capacity = ctx, int(capacity)
+        self._ctx, self.layout = ctx, dict(layout)
         self._bufs = [None] * slots         # allocated on first use
         self._free = queue.Queue()
         for i in range(slots):
@@ -157,7 +164,8 @@ class WordRing:
             self._cur = self._free.get()
         i = self._cur
         if self._bufs[i] is None:
-            self._bufs[i] = self._ctx.host_alloc(self.capacity, np.uint32)
+            self._bufs[i] = {k: self._ctx.host_alloc(n, dt)
+                             for k, (dt, n) in self.layout.items()}
         return self._bufs[i]
 
     def take(self):
@@ -279,6 +287,7 @@ class Engine:
         self._tok_genome = np.empty(0, dtype=np.int32)
         self._tok_cover = np.empty(0, dtype=np.int64)
         self._ring, self._ring_prev = None, None    # packed-record staging
+        self._oring = None                          # coord-match staging
 
     def words_eligible(self):
         """Can chunks go to the device as packed words, accumulated per
@@ -375,10 +384,43 @@ class Engine:
         if words:
             if self._ring is None:
                 # records of a block: a line has at least ~24 bytes
-                self._ring = WordRing(self.ctx, 5, block_bytes // 24 + 4096)
+                self._ring = StageRing(self.ctx, 5, {
+                    'packed': (np.uint32, block_bytes // 24 + 4096)})
             ring = self._ring
+        elif ordinal and cover is None and not want_names and \
+                not want_groups and not want_samples and \
+                not os.environ.get('WOLTKA_NO_PINNED'):
+            if self._oring is None:
+                n = block_bytes // 24 + 4096
+                self._oring = StageRing(self.ctx, 4, {
+                    'subj': (np.int32, n), 'beg': (np.int32, n),
+                    'end': (np.int32, n), 'len': (np.uint32, n),
+                    'off': (np.int32, n + 1)})
+            ring = self._oring
+        state = {'fresh': []}
+
+        def sink(tok_, n_reads, n_records):
+            """Between tokenising and fetching a block: the dictionary growth
+            belongs to this block (fetched before the tokenizer moves on); the
+            coord-match has the tokenizer translate subject ids into genome
+            indices of the gene tables on the way out."""
+            state['fresh'] = fresh = tok_.new_subjects()
+            if ordinal:
+                if fresh:
+                    gidx = self.genes.genome_index.get
+                    self._tok_genome = np.concatenate([
+                        self._tok_genome,
+                        np.fromiter((gidx(x, -1) for x in fresh), np.int32,
+                                    len(fresh))])
+                    tok_.set_subject_map(self._tok_genome)
+                elif not state.get('mapped'):
+                    tok_.set_subject_map(self._tok_genome)
+                state['mapped'] = True
+            return ring.current() if ring is not None else None
 
         def blocks():
+            if not ordinal:
+                tok.set_subject_map(None)
             for buf, res in native_sam_blocks(stream, tok, block_bytes,
                                               extra=3 if cover is not None
                                               else int(ordinal),
@@ -387,14 +429,11 @@ class Engine:
                                               want_groups=want_groups,
                                               want_samples=want_samples,
                                               fmt=fmt, part=part,
-                                              exclude=exclude,
-                                              packed_buf=ring.current
-                                              if ring else None):
-                if 'words' in res:
+                                              exclude=exclude, sink=sink):
+                if res.get('sunk'):
                     res['slot'] = ring.take()
-                # the dictionary growth belongs to this block: fetch it before
-                # the tokenizer moves on
-                yield buf, res, tok.new_subjects(), \
+                fresh, state['fresh'] = state['fresh'], []
+                yield buf, res, fresh, \
                     (tok.new_samples() if want_samples else [])
 
         for buf, res, fresh, fresh_samples in _prefetch(blocks()):
@@ -406,11 +445,7 @@ class Engine:
                                 len(fresh))])
             if fresh:
                 if ordinal:
-                    gidx = self.genes.genome_index.get
-                    self._tok_genome = np.concatenate([
-                        self._tok_genome,
-                        np.fromiter((gidx(x, -1) for x in fresh), np.int32,
-                                    len(fresh))])
+                    pass        # (translated by the tokenizer: `sink` above)
                 else:
                     base = self._tok_map.size
                     intern = self.subjects.intern
@@ -436,8 +471,11 @@ class Engine:
                 else None
             del buf
             if ordinal:
-                packed = (self._tok_genome[res['subj']], res['beg'],
-                          res['end'], res['len'], res['off'])
+                packed = (res['subj'], res['beg'], res['end'], res['len'],
+                          res['off'])
+                if 'slot' in res:       # pinned buffers: given back once staged
+                    packed = _Staged(packed)
+                    packed.slot = res['slot']
             else:
                 subj = res['subj'] if self._tok_identity \
                     else self._tok_map[res['subj']]
@@ -447,6 +485,8 @@ class Engine:
             if res['off'].size > 1:
                 yield reads, packed, res.get('group'), names, \
                     res.get('sample'), ranges
+            elif 'slot' in res:
+                ring.release(res['slot'])
 
     # ------------------------------------------------------------------
     def set_genes(self, table, prefix, trimsub=None):
@@ -629,6 +669,7 @@ class Engine:
                 # reads (wk_ordinal_count), no gene lists
                 self.ctx.ordinal_stage(genome, beg, end, length, hoff,
                                        self._th)
+                self._release_staged(packed)
                 self.ctx.set_uniform_group(group)
                 self.ctx.ordinal_count(self.jobs)
                 assign = None
@@ -637,6 +678,7 @@ class Engine:
                     group = np.full(hoff.size - 1, group, dtype=np.int32)
                 self.ctx.ordinal_stage(genome, beg, end, length, hoff,
                                        self._th, group=group)
+                self._release_staged(packed)
                 self.ctx.ordinal_match()
                 assign = self._classify_staged(data, want)
             nq = (self.ctx.stats()['n_reads'] - before) // self._n_batches()
@@ -726,6 +768,14 @@ class Engine:
                              indexed=True)
         self._classify_staged(data, False)
         return n
+
+    def _release_staged(self, packed):
+        """The staging call has copied the block (it waits for its copies):
+        its pinned buffers go back to the ring."""
+        slot = getattr(packed, 'slot', None)
+        if slot is not None:
+            self._oring.release(slot)
+            packed.slot = None
 
     def _words_done(self):
         """The last staging buffer in flight goes back to the ring."""

@@ -1,0 +1,198 @@
+// wk_coords.cpp — native reader of gene coordinate files (host side).
+//
+// ordinal.load_gene_coords + encode_genes of the reference (woltka/ordinal.py:
+// 338-473) without a Python object per line: ">name" / "# name" lines start a
+// nucleotide (a doubled marker is a super-group label and is ignored), other
+// lines are "gene <tab> beg <tab> end" (1-based, inclusive, either strand
+// order); start0 = min(beg, end) - 1, end = max(beg, end) (ordinal.py:459-465);
+// the genes of a nucleotide are sorted by start0, stably; a name seen again
+// replaces its earlier genes but keeps its place; `isdup` = some gene id was
+// seen twice (ordinal.py:413-417).  Text whose reading depends on Python's str
+// / int rules beyond plain ASCII digits — non-ASCII white space, "1_000", a
+// bare '\r', a marker as the very last byte — is refused (WK_E_STATE): the
+// Python reader (woltka_amd/ordinal.py) takes the file and raises or accepts
+// like the reference.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/woltka_hip.h"
+#include "wk_names.hpp"
+
+using wkh::hash_bytes;
+using wkh::NameTable;
+
+struct wk_coords {
+    std::vector<int32_t> goff, start0, end;
+    std::string genome_blob, gene_blob;
+    std::vector<int64_t> genome_off, gene_off;
+    int isdup = 0;
+    std::string err;
+};
+
+namespace {
+
+inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
+
+// int(text) for optional white space, optional sign, ASCII digits; false = not
+// that simple (the Python reader decides)
+inline bool simple_int(const char* p, const char* e, long long& v) {
+    while (p < e && py_space((unsigned char)*p)) ++p;
+    while (e > p && py_space((unsigned char)e[-1])) --e;
+    bool neg = false;
+    if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
+    if (p >= e || e - p > 18) return false;
+    long long x = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        x = x * 10 + (*p - '0');
+    }
+    v = neg ? -x : x;
+    return true;
+}
+
+struct Gene {
+    const char* name;
+    uint32_t nlen;
+    long long lo, hi;
+};
+
+struct Nucl {
+    const char* name;
+    uint32_t nlen;
+    std::vector<Gene> genes;
+};
+
+}  // namespace
+
+extern "C" {
+
+int wk_coords_parse(const char* buf, int64_t len, wk_coords** out) {
+    if (!out || len < 0 || (len > 0 && !buf)) return WK_E_ARG;
+    wk_coords* c = new (std::nothrow) wk_coords();
+    if (!c) return WK_E_HIP;
+    *out = c;
+    std::vector<Nucl> nucls;
+    NameTable index;  // nucleotide name -> position in `nucls`
+    NameTable used;   // gene ids seen (until the first repeat)
+    int cur = -1;
+    bool isdup = false;
+    const char* p = buf;
+    const char* e = buf + len;
+    while (p < e) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+        const char* le = nl ? nl : e;
+        const char* line = p;
+        p = nl ? nl + 1 : e;
+        const char* cr = (const char*)memchr(line, '\r', (size_t)(le - line));
+        if (cr && !(cr + 1 == le && nl)) return WK_E_STATE;
+        if (le > line && (unsigned char)le[-1] >= 0x80) return WK_E_STATE;
+        // `line` of the Python loop = [line, le) + "\n" (if nl); line[0] is '\n' for an empty one
+        const char c0 = line < le ? *line : '\n';
+        if (c0 == '>' || c0 == '#') {
+            // line[1]: the next byte, '\n' at the line's end, nothing at the end of the file
+            if (line + 1 >= le && !nl) return WK_E_STATE;  // (IndexError in the reference)
+            const char c1 = line + 1 < le ? line[1] : '\n';
+            if (c1 == c0) continue;
+            const char* nb = line + 1;
+            const char* ne = le;
+            if (nb < ne && (unsigned char)*nb >= 0x80) return WK_E_STATE;
+            while (nb < ne && py_space((unsigned char)*nb)) ++nb;
+            while (ne > nb && py_space((unsigned char)ne[-1])) --ne;
+            const uint64_t hv = hash_bytes(nb, (size_t)(ne - nb));
+            int32_t id = index.find(nb, (size_t)(ne - nb), hv);
+            if (id < 0) {
+                id = index.add(nb, (size_t)(ne - nb), hv);
+                nucls.push_back(Nucl{nb, (uint32_t)(ne - nb), {}});
+            } else {
+                nucls[(size_t)id].genes.clear();  // `coords[nucl] = []`
+            }
+            cur = id;
+            continue;
+        }
+        // gene, beg, end = line.rstrip().split('\t')
+        const char* re = le;
+        while (re > line && py_space((unsigned char)re[-1])) --re;
+        const char* t1 = (const char*)memchr(line, '\t', (size_t)(re - line));
+        const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(re - t1 - 1)) : nullptr;
+        if (!t1 || !t2 || memchr(t2 + 1, '\t', (size_t)(re - t2 - 1))) {
+            c->err = "Cannot extract coordinates from line: \"" + std::string(line, (size_t)(le - line)) + (nl ? "\n" : "") + "\".";
+            return WK_E_ARG;
+        }
+        if (cur < 0) return WK_E_STATE;  // coordinates before any nucleotide: the Python reader's business
+        long long b = 0, en = 0;
+        if (!simple_int(t1 + 1, t2, b) || !simple_int(t2 + 1, re, en)) return WK_E_STATE;
+        nucls[(size_t)cur].genes.push_back(Gene{line, (uint32_t)(t1 - line), std::min(b, en) - 1, std::max(b, en)});
+        if (!isdup) {
+            const uint64_t hv = hash_bytes(line, (size_t)(t1 - line));
+            if (used.find(line, (size_t)(t1 - line), hv) >= 0)
+                isdup = true;
+            else
+                used.add(line, (size_t)(t1 - line), hv);
+        }
+    }
+    if (nucls.empty()) {
+        c->err = "No coordinate was read from file.";
+        return WK_E_ARG;
+    }
+    c->isdup = isdup ? 1 : 0;
+    c->goff.push_back(0);
+    c->genome_off.push_back(0);
+    c->gene_off.push_back(0);
+    std::vector<uint32_t> order;
+    for (const Nucl& n : nucls) {
+        order.resize(n.genes.size());
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return n.genes[x].lo < n.genes[y].lo; });
+        for (uint32_t i : order) {
+            const Gene& g = n.genes[i];
+            if (g.hi > 2147483647ll || g.lo < -1) {
+                c->err = "Gene coordinates beyond 2^31 - 1 are not supported by the device tables.";
+                return WK_E_ARG;
+            }
+            c->start0.push_back((int32_t)g.lo);
+            c->end.push_back((int32_t)g.hi);
+            c->gene_blob.append(g.name, g.nlen);
+            c->gene_off.push_back((int64_t)c->gene_blob.size());
+        }
+        c->goff.push_back((int32_t)c->start0.size());
+        c->genome_blob.append(n.name, n.nlen);
+        c->genome_off.push_back((int64_t)c->genome_blob.size());
+    }
+    return WK_OK;
+}
+
+const char* wk_coords_error(const wk_coords* c) { return c ? c->err.c_str() : ""; }
+
+int wk_coords_sizes(const wk_coords* c, int32_t* n_genomes, int32_t* n_genes, int64_t* genome_bytes, int64_t* gene_bytes,
+                    int* isdup) {
+    if (!c) return WK_E_ARG;
+    if (n_genomes) *n_genomes = (int32_t)c->goff.size() - 1;
+    if (n_genes) *n_genes = (int32_t)c->start0.size();
+    if (genome_bytes) *genome_bytes = (int64_t)c->genome_blob.size();
+    if (gene_bytes) *gene_bytes = (int64_t)c->gene_blob.size();
+    if (isdup) *isdup = c->isdup;
+    return WK_OK;
+}
+
+int wk_coords_fetch(const wk_coords* c, int32_t* goff, int32_t* start0, int32_t* end, char* genome_blob, int64_t* genome_off,
+                    char* gene_blob, int64_t* gene_off) {
+    if (!c) return WK_E_ARG;
+    if (goff) memcpy(goff, c->goff.data(), c->goff.size() * 4);
+    if (start0 && !c->start0.empty()) memcpy(start0, c->start0.data(), c->start0.size() * 4);
+    if (end && !c->end.empty()) memcpy(end, c->end.data(), c->end.size() * 4);
+    if (genome_blob && !c->genome_blob.empty()) memcpy(genome_blob, c->genome_blob.data(), c->genome_blob.size());
+    if (genome_off) memcpy(genome_off, c->genome_off.data(), c->genome_off.size() * 8);
+    if (gene_blob && !c->gene_blob.empty()) memcpy(gene_blob, c->gene_blob.data(), c->gene_blob.size());
+    if (gene_off) memcpy(gene_off, c->gene_off.data(), c->gene_off.size() * 8);
+    return WK_OK;
+}
+
+void wk_coords_free(wk_coords* c) { delete c; }
+
+
+}  // extern "C"

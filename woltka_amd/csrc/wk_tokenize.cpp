@@ -18,6 +18,7 @@
 // run boundaries, one range per thread; ranges are tokenised independently and
 // concatenated, so the output does not depend on the thread count.
 #include <immintrin.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -462,6 +463,10 @@ struct wk_tok {
     std::vector<int64_t> rbase, qbase;
     int64_t tot_reads = 0, tot_rec = 0, tot_big = 0;
     int (*produce_sam)(const char*&, const char*, bool, const FastDict&, Line*, int) = nullptr;
+    // optional translation of subject ids at fetch time (wk_tok_set_subject_map):
+    // the coord-match wants genome indices, not dictionary ids
+    std::vector<int32_t> subj_map;
+    bool use_map = false;
     double lap_ms[LAP_N] = {0, 0, 0, 0};
     int64_t lap_calls = 0, lap_bytes = 0;
     ~wk_tok() {
@@ -1061,10 +1066,15 @@ static int fetch_results(wk_tok* t, int32_t* subj, uint32_t* packed, int32_t* of
         const Local& L = loc[i];
         const int64_t rb = t->rbase[i], qb = t->qbase[i];
         const std::vector<int32_t>& rm = t->remap[i];
+        const int32_t* map = t->use_map ? t->subj_map.data() : nullptr;
+        const int32_t map_n = (int32_t)t->subj_map.size();
         if (ex) {
             for (size_t k = 0; k < L.rec.size(); ++k) {
                 const Record& rc = L.rec[k];
-                if (subj) subj[rb + (int64_t)k] = rc.subj >= 0 ? rc.subj : rm[(size_t)(-(rc.subj + 1))];
+                if (subj) {
+                    const int32_t id = rc.subj >= 0 ? rc.subj : rm[(size_t)(-(rc.subj + 1))];
+                    subj[rb + (int64_t)k] = !map ? id : (id < map_n ? map[id] : -1);
+                }
                 if (beg) beg[rb + (int64_t)k] = rc.beg;
                 if (end) end[rb + (int64_t)k] = rc.end;
                 if (len) len[rb + (int64_t)k] = rc.len;
@@ -1072,7 +1082,8 @@ static int fetch_results(wk_tok* t, int32_t* subj, uint32_t* packed, int32_t* of
         } else if (subj) {
             for (size_t k = 0; k < L.subj.size(); ++k) {
                 const int32_t v = L.subj[k];
-                subj[rb + (int64_t)k] = v >= 0 ? v : rm[(size_t)(-(v + 1))];
+                const int32_t id = v >= 0 ? v : rm[(size_t)(-(v + 1))];
+                subj[rb + (int64_t)k] = !map ? id : (id < map_n ? map[id] : -1);
             }
         }
         if (packed && !ex) {
@@ -1106,6 +1117,53 @@ static int fetch_results(wk_tok* t, int32_t* subj, uint32_t* packed, int32_t* of
     TokLap lap(t->lap_ms);
     t->pool->run(T, work);
     lap(LAP_FETCH);
+    return WK_OK;
+}
+
+// [offset, offset + len) of file `fd` into dst, read by all worker threads
+// (pread on slices): a block of a few hundred MB arrives at memory speed instead
+// of one thread's copy rate, and — unlike a memory map of the file — leaves no
+// page of the input to be mapped and unmapped by the tokenizer threads.
+int wk_tok_read(wk_tok* t, int fd, int64_t offset, char* dst, int64_t len, int64_t* got) {
+    if (!t || fd < 0 || offset < 0 || len < 0 || (len > 0 && !dst) || !got) return WK_E_ARG;
+    *got = 0;
+    if (len == 0) return WK_OK;
+    const int64_t slice = 4ll << 20;
+    const int n = (int)((len + slice - 1) / slice);
+    std::vector<int64_t> done((size_t)n, 0);
+    std::atomic<int> failed{0};
+    const std::function<void(int)> work = [&](int i) {
+        const int64_t lo = (int64_t)i * slice, hi = std::min(len, lo + slice);
+        int64_t at = lo;
+        while (at < hi) {
+            const ssize_t r = pread(fd, dst + at, (size_t)(hi - at), (off_t)(offset + at));
+            if (r < 0) {
+                failed.store(1);
+                break;
+            }
+            if (r == 0) break;  // end of file
+            at += r;
+        }
+        done[(size_t)i] = at - lo;
+    };
+    t->pool->run(n, work);
+    if (failed.load()) {
+        t->err = "reading the alignment file failed";
+        return WK_E_ARG;
+    }
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        total += done[(size_t)i];
+        if (done[(size_t)i] < std::min(len, (int64_t)(i + 1) * slice) - (int64_t)i * slice) break;  // short slice: the file ends here
+    }
+    *got = total;
+    return WK_OK;
+}
+
+int wk_tok_set_subject_map(wk_tok* t, const int32_t* map, int32_t n) {
+    if (!t || n < 0 || (n > 0 && !map)) return WK_E_ARG;
+    t->use_map = map != nullptr;
+    t->subj_map.assign(map, map + n);
     return WK_OK;
 }
 

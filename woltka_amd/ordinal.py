@@ -55,6 +55,43 @@ class GeneTable:
         return dict(zip(self.feature_names(prefix), lens))
 
 
+class NativeGeneTable(GeneTable):
+    """``GeneTable`` filled by the native reader (csrc/wk_coords.cpp): the
+    gene ids stay one blob of bytes + offsets until something asks for them
+    as Python strings."""
+
+    def __init__(self, genomes, goff, start0, end, blob, off, isdup):
+        super().__init__(genomes, goff, start0, end, None, isdup)
+        self.name_blob, self.name_off = blob, off
+
+    @property
+    def names(self):
+        if self._names is None:
+            raw, o = self.name_blob, self.name_off.tolist()
+            self._names = [raw[a:b].decode() for a, b in zip(o, o[1:])]
+        return self._names
+
+    @names.setter
+    def names(self, value):
+        self._names = value
+
+
+def load_gene_coords_file(fp, zippers=None):
+    """``load_gene_coords`` of a (possibly compressed) file: the native reader
+    takes it unless its text needs Python's str / int rules (then the reader
+    below does, raising or accepting like the reference)."""
+    from . import _native
+    from .file import readzip
+    from .workflow import _file_bytes
+    with _file_bytes(fp, zippers) as buf:
+        res = _native.parse_gene_coords(buf)
+    if res is None:
+        with readzip(fp, zippers) as fh:
+            return load_gene_coords(fh, sort=True)
+    goff, start0, end, genomes, (blob, off), isdup = res
+    return NativeGeneTable(genomes, goff, start0, end, blob, off, isdup)
+
+
 def load_gene_coords(fh, sort=True):
     """Read a gene coordinates file into a ``GeneTable``
     (ordinal.load_gene_coords, ordinal.py:338-430).

@@ -28,7 +28,7 @@ from .classify import Engine, exact_to_numbers
 from .file import (FilesAhead, id2file_from_dir, id2file_from_map, openzip, path2stem,
                    read_ids, read_map_1st, read_map_uniq, readzip, readzip_bytes,
                    stem2rank, write_readmap)
-from .ordinal import load_gene_coords
+from .ordinal import load_gene_coords, load_gene_coords_file  # noqa: F401
 from .ranges import Coverage, range_mapper, write_coverage
 from .shard import (FilePart, classify_sharded, env_rank, file_key,
                     file_path)
@@ -82,6 +82,27 @@ def workflow(
         no_exe: bool = False, device: int = 0) -> dict:
     """Main classification workflow (command-line arguments in, profile out);
     same steps in the same order as the reference (workflow.py:109-159)."""
+    # (the run builds millions of small containers — table rows, profile
+    # cells — and no reference cycles: the cyclic collector's passes over them
+    # cost more than the classification; paused for the call)
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _workflow(**{k: v for k, v in locals().items()
+                            if k not in ('gc', 'gc_was_on')})
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _workflow(input_fp, output_fp, input_fmt, input_ext, samples, demux,
+              exclude, trimsub, nodes_fps, newick_fps, lineage_fps,
+              columns_fps, map_fps, map_rank, names_fps, ranks, uniq, major,
+              above, subok, coords_fp, overlap, strata_dir, sizes, frac, scale,
+              digits, output_fmt, unassigned, name_as_id, add_rank,
+              add_lineage, outmap_dir, outmap_zip, outcov_dir, outcov_fmt,
+              chunk, cache, no_exe, device):
     zippers = None if no_exe else {}
     samples, files, demux = parse_samples(input_fp, input_ext, samples, demux)
     exclude = parse_exclude(exclude)
@@ -581,8 +602,7 @@ def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
     unless the user set it (the device default is chosen in ``classify``)."""
     if coords_fp:
         click.echo('Reading gene coordinates...', nl=False)
-        with readzip(coords_fp, zippers) as fh:
-            table = load_gene_coords(fh, sort=True)
+        table = load_gene_coords_file(coords_fp, zippers)
         click.echo(' Done.')
         click.echo(f'  Total number of host sequences: {len(table)}.')
         return OrdinalMapper(table, th=overlap and overlap / 100), chunk
