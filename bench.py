@@ -1105,6 +1105,9 @@ def e2e_ranks(a, line, wl, dev, world, sync):
 
 
 def _child(a, rank, world, bar, shared, conn):
+    # (what torch.distributed.run would set: the ranks of this node share the
+    # host's CPUs — classify.tokenizer_threads)
+    os.environ.setdefault('LOCAL_WORLD_SIZE', str(world))
     try:
         line = run_rank(a, rank, world, rank, MpSync(rank, bar, shared))
         conn.send(('ok', line))

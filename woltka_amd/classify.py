@@ -22,17 +22,49 @@ from .file import openzip, write_readmap
 from .hierarchy import FeatureIndex, flatten_hierarchy
 from .ordinal import pack_hits
 
+def cpu_budget():
+    """CPUs this process may use: the hardware threads of its affinity mask,
+    or — when the container's CPU bandwidth is capped (cgroup cpu.max /
+    cfs_quota) — the cap, whichever is smaller.  (The MI355X boxes of this
+    project show 256 hardware threads and a cap of 16 CPUs: threads beyond
+    twice the cap only run into the throttle.)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:       # cgroup v2
+            q, period = f.read().split()[:2]
+            if q != 'max':
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                q = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                period = int(f.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.5)))
+    return n
+
+
 def tokenizer_threads():
-    """Threads of the native tokenizer: the host's hardware threads shared
-    among the processes of this node (one per GPU under torch.distributed.run),
-    at most 64 — 96 / 128 / 192 threads on a 256-thread host changed nothing
-    (config 3 end to end: 0.38-0.46 s against 0.40 s).  WOLTKA_TOK_THREADS
-    overrides."""
+    """Threads of the native tokenizer: twice the CPUs this process may use
+    (`cpu_budget`; phases that wait — page faults, the serial steps of a block
+    — leave room for a second thread per CPU: 32 threads gave 1.2x the rate of
+    16 under a cap of 16 CPUs, 64 and 128 gave less), shared among the
+    processes of this node (one per GPU under torch.distributed.run), at most
+    64.  WOLTKA_TOK_THREADS overrides."""
     forced = os.environ.get('WOLTKA_TOK_THREADS')
     if forced:
         return max(1, int(forced))
     local = int(os.environ.get('LOCAL_WORLD_SIZE') or 1)
-    return max(1, min((os.cpu_count() or 1) // max(local, 1), 64))
+    return max(1, min(2 * cpu_budget() // max(local, 1), 64))
 
 
 def _prefetch(gen, depth=int(os.environ.get('WOLTKA_PREFETCH', 2))):
@@ -288,6 +320,7 @@ class Engine:
         self._tok_cover = np.empty(0, dtype=np.int64)
         self._ring, self._ring_prev = None, None    # packed-record staging
         self._oring = None                          # coord-match staging
+        self._deferred_from = None                  # see take_deferred
 
     def words_eligible(self):
         """Can chunks go to the device as packed words, accumulated per
@@ -340,6 +373,13 @@ class Engine:
         n_jobs = min(len(self.jobs), nat.MAX_JOBS)
         need = min(n_records + 1, max(1, n_groups) * (len(self.index) + 1)) \
             * n_jobs
+        # every key the groups met so far (and this chunk's) could ever hold:
+        # when even that fits with room to spare the table need not be asked
+        # (asking waits for the device)
+        most = (len(self.groups) + max(1, n_groups)) * (len(self.index) + 2) \
+            * n_jobs
+        if 2 * most <= self.slots_reserved:
+            return
         used = self.ctx.stats()['table_used']
         if 2 * (used + need) <= self.slots_reserved and \
                 4 * used <= self.slots_reserved:
@@ -662,18 +702,24 @@ class Engine:
         if ordinal:
             genome, beg, end, length, hoff = \
                 self._hits if packed is None else packed
-            before = self.ctx.stats()['n_reads']
             if np.ndim(group) == 0 and not want and \
                     len(self.jobs) <= nat.MAX_JOBS:
                 # one sample, no read maps: match + count in one pass over the
-                # reads (wk_ordinal_count), no gene lists
+                # reads (wk_ordinal_count), no gene lists.  How many queries
+                # matched a gene ("Number of sequences classified",
+                # workflow.py:305,344) is asked once per file
+                # (`take_deferred`), not per chunk: the answer waits for the
+                # device.
+                if self._deferred_from is None:
+                    self._deferred_from = self.ctx.stats()['n_reads']
                 self.ctx.ordinal_stage(genome, beg, end, length, hoff,
                                        self._th)
                 self._release_staged(packed)
                 self.ctx.set_uniform_group(group)
                 self.ctx.ordinal_count(self.jobs)
-                assign = None
+                assign, nq = None, 0
             else:
+                before = self.ctx.stats()['n_reads']
                 if np.ndim(group) == 0:  # (the coord-match stage takes an array)
                     group = np.full(hoff.size - 1, group, dtype=np.int32)
                 self.ctx.ordinal_stage(genome, beg, end, length, hoff,
@@ -681,7 +727,8 @@ class Engine:
                 self._release_staged(packed)
                 self.ctx.ordinal_match()
                 assign = self._classify_staged(data, want)
-            nq = (self.ctx.stats()['n_reads'] - before) // self._n_batches()
+                nq = (self.ctx.stats()['n_reads'] - before) \
+                    // self._n_batches()
             if want:
                 subj, qoff = self.ctx.chunk_download()
         else:
@@ -767,6 +814,17 @@ class Engine:
         self.ctx.chunk_stage(subj, qoff, group=group, subj_is_set=True,
                              indexed=True)
         self._classify_staged(data, False)
+        return n
+
+    def take_deferred(self):
+        """Queries classified since the last call that `run_chunk` has not
+        reported yet (the coord-match tally route counts them on the
+        device)."""
+        if self._deferred_from is None:
+            return 0
+        n = (self.ctx.stats()['n_reads'] - self._deferred_from) \
+            // self._n_batches()
+        self._deferred_from = None
         return n
 
     def _release_staged(self, packed):

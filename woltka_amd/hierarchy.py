@@ -137,6 +137,10 @@ class NodeIndex(FeatureIndex):
         if None not in pos:
             return self._pre[np.fromiter(pos, dtype=np.int64,
                                          count=len(pos))].tolist()
+        if not self._extra_ids and pos.count(None) == len(pos):
+            fresh = self._intern_fresh(names)
+            if fresh is not None:
+                return fresh
         out = list(map(self._extra_ids.get, names))
         pre = self._pre
         n_nodes, extra, extra_ids = self.n_nodes, self._extra, self._extra_ids
@@ -152,6 +156,19 @@ class NodeIndex(FeatureIndex):
                     extra.append(name)
                 out[k] = j
         return out
+
+    def _intern_fresh(self, names):
+        """Ids of names none of which is a node, when nothing has been
+        interned yet and the names are distinct (the half million gene ids of
+        a coordinates file): consecutive ids from C-level calls; None when the
+        names repeat."""
+        base = self.n_nodes + len(self._extra)
+        ids = dict(zip(names, range(base, base + len(names))))
+        if len(ids) != len(names):
+            return None
+        self._extra_ids = ids
+        self._extra.extend(names)
+        return list(range(base, base + len(names)))
 
     def names_of(self, ids):
         """Names of a list of ids (bulk form of ``names[i]``)."""
@@ -495,7 +512,16 @@ class NativeIndex(FeatureIndex):
 
     def intern_many(self, names):
         names = list(names)
-        out = self._b.lookup(names).tolist()
+        found = self._b.lookup(names)
+        if not self._extra_ids and names and int(found.max()) < 0:
+            # no node among them, nothing interned yet: consecutive ids
+            base = self.n_nodes
+            ids = dict(zip(names, range(base, base + len(names))))
+            if len(ids) == len(names):
+                self._extra_ids = ids
+                self._extra.extend(names)
+                return list(range(base, base + len(names)))
+        out = found.tolist()
         for k, i in enumerate(out):
             if i < 0:
                 out[k] = self._new(names[k])

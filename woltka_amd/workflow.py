@@ -350,6 +350,12 @@ def classify(
                         if istep:
                             click.echo('.' * istep, nl=False)
                             nstep += istep
+                    # (queries the device counted and `run_chunk` has not
+                    # reported: the dots they are owed come now — the text is
+                    # the same, a dot per million and one at the first chunk)
+                    nqry += engine.take_deferred()
+                    if nstep >= 0:      # (at least one chunk was classified)
+                        click.echo('.' * (nqry // 1000000 - nstep), nl=False)
                 click.echo(' Done.')
                 click.echo(f'  Number of sequences classified: {nqry}.')
 
