@@ -92,6 +92,7 @@ extern "C" {
 #define WK_ASSIGN_EMPTY (-3) /* read has no candidates (skipped altogether)  */
 
 typedef struct wk_ctx wk_ctx;
+typedef struct wk_tok wk_tok; /* the native tokenizer (below) */
 
 /* One classification job = one rank of `--rank a,b,c` evaluated in the same
  * pass over the records (the reference loops `for rank in ranks`,
@@ -268,6 +269,29 @@ int wk_words_wait(wk_ctx* ctx, int slot);
 int wk_words_flush(wk_ctx* ctx);
 int wk_words_pending(wk_ctx* ctx, int64_t* n_records, int64_t* n_reads);
 
+/* ---- SAM tokenizer on the device (plain flavour) --------------------------
+ * align.parse_sam_file + plain_mapper (align.py:258-347, 47-115) on the GPU
+ * (csrc/wk_dtok.hpp): the host only moves the text (pread into pinned memory,
+ * one copy to HBM); lines are split, runs of equal QNAME grouped into reads
+ * by mate, subjects looked up in `tok`'s dictionary, and the reads' records
+ * appended as packed words to the sample's accumulated records (wk_words_*).
+ * text[begin, stop) must be whole lines ending at a run boundary
+ * (wk_tok_sam_span).
+ *
+ * wk_dtok_scan copies and parses the block; subjects the dictionary does not
+ * know are interned into `tok` in text order (wk_tok_new_subjects reports
+ * them: the ids are those the host tokenizer would have assigned).  *status:
+ * 0 = parsed, 1 = the block has something the kernels leave to the host
+ * tokenizer (a short or malformed line, both mate bits, an exclusion set):
+ * tokenise it with wk_tok_text instead.  wk_dtok_emit — after wk_words_begin
+ * accepted the jobs for the grown subject table — groups and appends the
+ * records; *status 1 = a read of more than WK_WEIGHT_MAX_K subjects: nothing
+ * was appended, the host tokenizer takes the block. */
+int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
+                 int64_t stop, int64_t* n_lines, int* status);
+int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
+                 int* status);
+
 /* Convenience: stage + classify in one call from host buffers. */
 int wk_classify_chunk(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
                       const int32_t* subj, const int32_t* qoff,
@@ -328,7 +352,6 @@ int wk_reset_stats(wk_ctx* ctx);
  * 550-583; ordinal.py:219-237) for SAM input.  Host-only: no device is needed.
  * A tokenizer owns the subject dictionary (RNAME -> dense subject index in
  * order of first appearance, the indices wk_set_subjects expects). */
-typedef struct wk_tok wk_tok;
 int wk_tok_create(int n_threads /* <= 0: all hardware threads */, wk_tok** out);
 void wk_tok_destroy(wk_tok* tok);
 const char* wk_tok_last_error(const wk_tok* tok);
@@ -378,6 +401,17 @@ int wk_tok_boundary(int fmt, int extra, const char* buf, int64_t len,
  * (byte offset in buf << 24) | (length << 2) | mate.  NULL skips an array. */
 int wk_tok_fetch(wk_tok* tok, int32_t* subj, int32_t* off, int32_t* beg,
                  int32_t* end, uint32_t* len, uint64_t* qname);
+/* [*begin, *stop) of a block of SAM text that can be tokenised now: behind the
+ * leading '@' header lines (`in_header`: the block starts inside them, as the
+ * first block of a file does) up to — unless `final_block` — the start of the
+ * last run of equal query ids, which may continue in the next block (what
+ * wk_tok_text does with a block before tokenising it; align.py:295-300, 325).
+ * WK_E_STATE: nothing complete yet (*stop == *begin). */
+int wk_tok_sam_span(const char* buf, int64_t len, int final_block, int in_header,
+                    int64_t* begin, int64_t* stop, int* in_header_after);
+/* The header state wk_tok_text continues from, for callers that had the device
+ * tokenizer (wk_dtok_*) take the blocks before. */
+int wk_tok_set_header_state(wk_tok* tok, int in_header);
 /* *got bytes of [offset, offset + len) of the open file `fd` into dst, read by
  * all tokenizer threads (pread on slices); short only at the end of the file. */
 int wk_tok_read(wk_tok* tok, int fd, int64_t offset, char* dst, int64_t len,

@@ -48,7 +48,8 @@ SYMBOLS = (
     'wk_tok_set_exclude', 'wk_tok_sam_tail', 'wk_tok_sam', 'wk_tok_text',
     'wk_tok_boundary',
     'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
-    'wk_tok_read',
+    'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_set_header_state',
+    'wk_dtok_scan', 'wk_dtok_emit',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
@@ -161,6 +162,12 @@ def load_library():
         'wk_tok_set_subject_map': (C.c_int, [p, i32p, C.c_int32]),
         'wk_tok_read': (C.c_int, [p, C.c_int, C.c_int64, C.c_void_p, C.c_int64,
                                   i64p]),
+        'wk_tok_sam_span': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                      i64p, i64p, C.POINTER(C.c_int)]),
+        'wk_tok_set_header_state': (C.c_int, [p, C.c_int]),
+        'wk_dtok_scan': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
+                                   i64p, C.POINTER(C.c_int)]),
+        'wk_dtok_emit': (C.c_int, [p, i64p, i64p, C.POINTER(C.c_int)]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
         'wk_tok_fetch_groups': (C.c_int, [p, i32p]),
@@ -463,6 +470,30 @@ class Context:
                                                C.byref(b)))
         return a.value, b.value
 
+    # -- SAM tokenizer on the device -----------------------------------------
+    def dtok_scan(self, tok, buf, begin, stop):
+        """Copy and parse ``buf[begin:stop]`` (whole lines ending at a run
+        boundary: ``Tokenizer.sam_span``) on the device.  Returns (status,
+        n_lines): status 0 = parsed (new subjects are in ``tok``), 1 = the
+        host tokenizer takes this block."""
+        raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+        n, st = C.c_int64(0), C.c_int(1)
+        addr = C.c_void_p(raw.ctypes.data) if raw.size \
+            else C.cast(C.c_char_p(b''), C.c_void_p)
+        self._check(self._lib.wk_dtok_scan(self._h, tok._h, addr, int(begin),
+                                           int(stop), C.byref(n), C.byref(st)))
+        return st.value, n.value
+
+    def dtok_emit(self):
+        """Group the scanned block's lines into reads and append their
+        records to the accumulated packed records.  Returns (status, reads,
+        records); status 1 = nothing appended (a read of more than 16
+        subjects): the host tokenizer takes the block."""
+        a, b, st = C.c_int64(0), C.c_int64(0), C.c_int(1)
+        self._check(self._lib.wk_dtok_emit(self._h, C.byref(a), C.byref(b),
+                                           C.byref(st)))
+        return st.value, a.value, b.value
+
     def set_uniform_group(self, group):
         self._check(self._lib.wk_set_uniform_group(self._h, int(group)))
 
@@ -699,6 +730,23 @@ class Tokenizer:
         if rc != OK:
             raise ValueError('wk_tok_boundary failed')
         return out.value
+
+    @staticmethod
+    def sam_span(buf, final, in_header):
+        """(ok, begin, stop, in_header_after) of a block of SAM text: the part
+        that can be tokenised now (``wk_tok_sam_span``)."""
+        raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+        b, s, h = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        addr = C.c_void_p(raw.ctypes.data) if raw.size \
+            else C.cast(C.c_char_p(b''), C.c_void_p)
+        rc = load_library().wk_tok_sam_span(addr, raw.size, int(bool(final)),
+                                            int(bool(in_header)), C.byref(b),
+                                            C.byref(s), C.byref(h))
+        return rc == OK, b.value, s.value, bool(h.value)
+
+    def set_header_state(self, in_header):
+        self._check(self._lib.wk_tok_set_header_state(self._h,
+                                                      int(bool(in_header))))
 
     def read_into(self, fd, offset, view):
         """Fill ``view`` (writable bytes-like) from file descriptor ``fd`` at

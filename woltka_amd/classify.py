@@ -320,6 +320,7 @@ class Engine:
         self._tok_cover = np.empty(0, dtype=np.int64)
         self._ring, self._ring_prev = None, None    # packed-record staging
         self._oring = None                          # coord-match staging
+        self._tring, self._reader = None, None      # device tokenizer: text staging, reader threads
         self._deferred_from = None                  # see take_deferred
 
     def words_eligible(self):
@@ -348,6 +349,8 @@ class Engine:
         finally:
             if self.tok is not None:
                 self.tok.close()
+            if self._reader is not None:
+                self._reader.close()
             self.ctx.close()
 
     # ------------------------------------------------------------------
@@ -420,6 +423,14 @@ class Engine:
         if self.tok is None:
             self.tok = nat.Tokenizer(tokenizer_threads(), exclude)
         tok = self.tok
+        if words and fmt == 'sam' and not exclude and part is None and \
+                not os.environ.get('WOLTKA_NO_DTOK'):
+            from .align import _parallel_reader
+            reader = _parallel_reader(stream, tok, None)
+            if reader is not None:
+                # the text goes to the GPU as it is: tokenised there
+                yield from self._device_chunks(reader, block_bytes)
+                return
         ring = None
         if words:
             if self._ring is None:
@@ -659,6 +670,8 @@ class Engine:
         arrays produced by the native tokenizer instead of ``subque`` / staged
         hits."""
         if packed is not None and isinstance(packed[0], str):
+            if packed[0] == 'dtok':
+                return self._run_dtok(data, packed, sample_of)
             return self._run_words(data, packed, sample_of)
         n = len(reads) if packed is None else packed[-1].size - 1
         # room for the (sample, stratum) groups this chunk can add
@@ -763,6 +776,156 @@ class Engine:
             self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,
                              outzip, namedic)
         return nq
+
+    DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
+
+    def _device_chunks(self, reader, host_block):
+        """A SAM file through the tokenizer on the device (csrc/wk_dtok.hpp):
+        a helper thread reads blocks into pinned buffers (pread by its own
+        threads) and cuts them where the last run of equal query ids starts;
+        this thread has the device copy, parse and — in `_run_dtok`, once the
+        subjects the block brought are registered — group and append them.
+        Blocks the kernels leave to the host tokenizer (malformed lines, both
+        mate bits, reads of more than 16 subjects) are tokenised on the host
+        as before.  Yields what `native_chunks` yields."""
+        import queue
+        fd, size = reader
+        tok = self.tok
+        if self._reader is None:
+            self._reader = nat.Tokenizer(max(2, tokenizer_threads() // 2))
+        rd = self._reader
+        block = self.DTOK_BLOCK
+        if self._tring is None:
+            self._tring = StageRing(self.ctx, 4, {
+                'text': (np.uint8, block + (1 << 20))})
+        ring = self._tring
+        free = queue.Queue()
+
+        def blocks():
+            pos, carry, in_header, first = 0, b'', True, True
+            # small blocks first while the dictionary is cold: a block's
+            # unknown subjects are listed per record and interned on the host
+            ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
+            span = ramp or block
+            while pos < size or carry:
+                want = min(span, size - pos)
+                need = len(carry) + want
+                slot, buf = None, None
+                if need <= ring.layout['text'][1]:
+                    buf = ring.current()['text']
+                    slot = ring.take()
+                else:                       # (a run longer than a block)
+                    buf = np.empty(need, dtype=np.uint8)
+                view = memoryview(buf).cast('B')
+                view[:len(carry)] = carry
+                got = rd.read_into(fd, pos, view[len(carry):need]) \
+                    if want else 0
+                fill = len(carry) + got
+                pos += got
+                final = pos >= size or (want and not got)
+                ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                    view[:fill], final, in_header)
+                if not ok and not final:    # no complete run yet: read more
+                    carry = bytes(view[:fill])
+                    span *= 2
+                    if slot is not None:
+                        ring.release(slot)
+                    continue
+                if ramp is not None:
+                    ramp = min(block, ramp * 4)
+                    if ramp == block:
+                        tok.warm, ramp = True, None
+                span = ramp or block
+                carry = b'' if final else bytes(view[stop:fill])
+                yield slot, buf, fill, begin, stop, first, final, in_header, hdr
+                in_header, first = hdr, False
+                if final:
+                    return
+
+        for item in _prefetch(blocks()):
+            slot, buf, fill, begin, stop, first, final, hdr_in, hdr = item
+            try:
+                status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop)
+                fresh = tok.new_subjects()
+                if fresh:
+                    base = self._tok_map.size
+                    ids = np.fromiter(map(self.subjects.intern, fresh),
+                                      np.int32, len(fresh))
+                    if self._tok_identity and not np.array_equal(
+                            ids, np.arange(base, base + ids.size)):
+                        self._tok_identity = False
+                    self._tok_map = np.concatenate([self._tok_map, ids])
+                if status == 0 and self._tok_identity:
+                    if n_lines:
+                        yield None, ('dtok', (buf, fill, first, final, hdr_in,
+                                              hdr)), None, None, None, None
+                    tok.set_header_state(hdr)
+                else:
+                    yield from self._host_block(buf, fill, first, final,
+                                                hdr_in)
+            finally:
+                if slot is not None:
+                    ring.release(slot)
+
+    def _host_block(self, buf, fill, first, final, hdr_in):
+        """One block of the device route through the host tokenizer after
+        all (the general arrays)."""
+        tok = self.tok
+        tok.set_header_state(hdr_in)
+        res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
+                        final=final, fmt='sam')
+        fresh = tok.new_subjects()
+        if fresh:
+            ids = np.fromiter(map(self.subjects.intern, fresh), np.int32,
+                              len(fresh))
+            self._tok_map = np.concatenate([self._tok_map, ids])
+        if res['off'].size > 1:
+            subj = res['subj'] if self._tok_identity \
+                else self._tok_map[res['subj']]
+            yield None, (subj, res['off']), None, None, None, None
+
+    def _run_dtok(self, data, packed, sample):
+        """A block the device has scanned: register the subjects it brought,
+        have the job set accepted for them, then group and append its records
+        (`wk_dtok_emit`).  If the weighted histogram cannot take the block —
+        a subject without an ancestor at a requested rank, a read of more than
+        16 subjects — the host tokenizer parses it for the general route."""
+        buf, fill, first, final, hdr_in, hdr = packed[1]
+        if (sample, None) not in self.group_ids:
+            if len(self.groups) + 1 >= MAX_GROUPS // 2:
+                self.collect(data)
+            self._ensure_table(data, max(len(self.subjects), 1 << 16) + 1, 1)
+        group = self._group_array(1, sample, None)
+        for rank in self.ranks:
+            data[rank].setdefault(sample, {})
+        self._sync_subjects(data)
+        if self.ctx.words_begin(self.jobs, group):
+            status, n_reads, _ = self.ctx.dtok_emit()
+            if status == 0:
+                self._n_reads += n_reads
+                return n_reads
+        n = 0
+        for _, (subj, qoff), *_ in self._host_block(buf, fill, first, final,
+                                                    hdr_in):
+            self._sync_subjects(data)
+            n += self.run_chunk(data, None, None, sample, None, None, None,
+                                None, None, False, packed=(subj, qoff),
+                                packed_is_set=True)
+        self.tok.set_header_state(hdr)
+        return n
+
+    def _sync_subjects(self, data):
+        """Subjects the tokenizer has met since the last call: their features
+        to the device (and room for their keys)."""
+        known = len(self.subj_feature)
+        if len(self.subjects) > known:
+            self.subj_feature.extend(self.index.intern_many(
+                self.subjects.names[known:]))
+            self.ctx.set_subjects(self.subj_feature)
+            if 4 * len(self.subjects) * len(self.jobs) > self.slots_reserved \
+                    and not self._table_fixed:
+                self.collect(data, keep_groups=True)
+                self._reserve(8 * len(self.subjects) * len(self.jobs))
 
     def _run_words(self, data, packed, sample):
         """One chunk of packed records (``('words', array, n_reads, slot)``

@@ -1,0 +1,306 @@
+// wk_dtok.hpp — SAM tokenizer on the device (plain flavour).
+//
+// The host tokenizer (wk_tokenize.cpp) spends ~60 ns of CPU per alignment
+// record; a node's ranks share its CPUs, so with the text parsed on the host
+// the end-to-end rate of N GPUs is the rate of one.  Here the host only moves
+// bytes — pread into pinned memory, one copy to HBM — and the GPU does what
+// align.parse_sam_file + plain_mapper do per line (woltka/align.py:258-347,
+// 47-115): split QNAME / FLAG / RNAME, skip unmapped records before the
+// QNAME-change test, group runs of equal QNAME into up to three reads by mate
+// ((FLAG >> 6) & 3), keep each read's subjects as a set, and look the subject
+// up in the dictionary.  The output is the packed record stream of
+// wk_weigh.hpp (subject | position << 23 | size << 27), appended straight to
+// the sample's accumulated records (wk_words_*): the text never becomes
+// anything else on the host.
+//
+// Kernels (a block of text = lines ending at a run boundary, cut by the host):
+//   dtok_count / dtok_lines   positions of the line starts (two passes + scan)
+//   dtok_parse                a thread per line: fields, FLAG, dictionary probe
+//   dtok_runs                 a thread per line: does its QNAME start a run?
+//   dtok_emit                 a thread per run: per-mate subject sets -> words
+// Anything the kernels are not sure to treat like the reference — a short or
+// malformed line, both mate bits, a read of more than 16 subjects — sets a flag
+// and the host tokenizer takes the block instead.  Subjects the dictionary
+// does not know yet are listed; the host interns them in text order (so the
+// subject indices are those the host tokenizer would have assigned) and the
+// parse runs again.
+#pragma once
+#include "wk_device.hpp"
+#include "wk_weigh.hpp"
+
+namespace wk {
+
+constexpr uint32_t kDtokThreads = 256;
+constexpr uint32_t kDtokTile = kDtokThreads * 16;  // bytes per workgroup and round
+
+// flags of a block (OR-ed into DtokState::flags)
+constexpr uint32_t kDtokShortLine = 1;   // fewer than four fields / FLAG not a number
+constexpr uint32_t kDtokBothMates = 2;   // FLAG with both mate bits
+constexpr uint32_t kDtokBigRead = 4;     // a read of more than WK_WEIGHT_MAX_K subjects
+constexpr uint32_t kDtokUnknownFull = 8; // more unknown subjects than the list holds
+constexpr uint32_t kDtokLongName = 16;   // a QNAME longer than the per-line word can say
+
+// per-line result of dtok_parse
+constexpr int32_t kLineUnknown = -1;   // subject not in the dictionary
+constexpr int32_t kLineUnmapped = -2;  // RNAME "*"
+constexpr int32_t kLineBad = -3;
+
+struct DtokState {  // device scalars of one block
+    uint32_t flags;
+    uint32_t n_unknown;
+    unsigned long long n_out;    // words emitted by dtok_emit
+    unsigned long long n_reads;  // reads (non-empty mate groups) emitted
+};
+
+struct DictSlot {
+    unsigned long long hash;
+    int32_t id;  // -1 = empty
+    uint32_t off;
+};
+
+struct DtokArgs {
+    const unsigned char* text;  // [n] + 64 readable bytes behind
+    uint32_t n;
+    const uint32_t* line_start;  // [n_lines + 1], line_start[n_lines] = n (+1 if the last line has no newline)
+    uint32_t n_lines;
+    int32_t* lsubj;    // [n_lines]
+    uint32_t* lmeta;   // [n_lines] QNAME length | mate << 28
+    const DictSlot* dict;
+    uint32_t dict_mask;
+    const unsigned char* arena;  // [len:4][bytes] per name
+    uint2* unknown;              // (offset, length) of RNAMEs not in the dictionary
+    uint32_t unknown_cap;
+    unsigned char* is_start;     // [n_lines]
+    DtokState* state;
+    uint32_t* out;      // packed records
+    uint32_t out_cap;
+};
+
+__device__ __forceinline__ uint32_t count_newlines16(const uint4 v) {
+    auto cnt = [](uint32_t w) {
+        const uint32_t x = w ^ 0x0A0A0A0Au;                       // bytes equal to '\n' become 0
+        const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 where the byte was 0
+        return (uint32_t)__popc(z);
+    };
+    return cnt(v.x) + cnt(v.y) + cnt(v.z) + cnt(v.w);
+}
+
+// newlines per tile of kDtokTile bytes
+__global__ void __launch_bounds__(kDtokThreads) dtok_count_kernel(const unsigned char* __restrict__ text, uint32_t n,
+                                                                 unsigned long long* __restrict__ tile_count) {
+    __shared__ uint32_t wsum[kDtokThreads / kWave];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t p = tile * kDtokTile + threadIdx.x * 16u;
+    uint32_t c = 0;
+    if (p + 16u <= n) {
+        c = count_newlines16(*reinterpret_cast<const uint4*>(text + p));
+    } else if (p < n) {
+        for (uint32_t i = p; i < n; ++i) c += text[i] == '\n';
+    }
+    unsigned long long s = wave_sum((unsigned long long)c);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = (uint32_t)s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < kDtokThreads / kWave; ++w) t += wsum[w];
+        tile_count[tile] = t;
+    }
+}
+
+// line_start[1 + k] = position behind the k-th newline (line_start[0] = 0 is
+// written by the host side); tile_off = exclusive scan of tile_count
+__global__ void __launch_bounds__(kDtokThreads) dtok_lines_kernel(const unsigned char* __restrict__ text, uint32_t n,
+                                                                 const unsigned long long* __restrict__ tile_off,
+                                                                 uint32_t* __restrict__ line_start) {
+    __shared__ uint32_t scan[kDtokThreads];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t p = tile * kDtokTile + threadIdx.x * 16u;
+    unsigned char b[16];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        b[i] = (p + (uint32_t)i < n) ? text[p + (uint32_t)i] : (unsigned char)0;
+        c += b[i] == '\n';
+    }
+    scan[threadIdx.x] = c;
+    __syncthreads();
+    // inclusive scan over the workgroup (Hillis-Steele: 8 steps of 256 threads)
+    for (uint32_t d = 1; d < kDtokThreads; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t at = (uint32_t)tile_off[tile] + scan[threadIdx.x] - c + 1u;  // (+1: line 0 starts at 0)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (b[i] == '\n') line_start[at++] = p + (uint32_t)i + 1u;
+}
+
+// the host's hash of a name (wkh::hash_bytes), byte for byte
+__device__ __forceinline__ unsigned long long dtok_hash(const unsigned char* p, uint32_t n) {
+    unsigned long long h = 0xcbf29ce484222325ull ^ ((unsigned long long)n * 0x9E3779B97F4A7C15ull);
+    while (n >= 8) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= (unsigned long long)p[i] << (8 * i);
+        h = (h ^ v) * 0x100000001b3ull;
+        h ^= h >> 29;
+        p += 8;
+        n -= 8;
+    }
+    unsigned long long v = 0;
+    for (uint32_t i = 0; i < n; ++i) v |= (unsigned long long)p[i] << (8 * i);
+    h = (h ^ v) * 0x100000001b3ull;
+    return h ^ (h >> 32);
+}
+
+// a thread per line: QNAME / FLAG / RNAME, mate, subject id
+__global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines) return;
+    const uint32_t lo = a.line_start[i];
+    uint32_t hi = a.line_start[i + 1];  // behind the line's newline (or n + 1 for a last line without one)
+    hi = hi > lo ? hi - 1u : lo;        // the newline itself / the end of the text
+    if (hi > a.n) hi = a.n;
+    // the first three tabs
+    uint32_t tab[3];
+    int nt = 0;
+    for (uint32_t p = lo; p < hi && nt < 3; ++p)
+        if (a.text[p] == '\t') tab[nt++] = p;
+    if (nt < 3) {  // not `qname, flag, rname, _ = line.split('\t', 3)` (align.py:313)
+        a.lsubj[i] = kLineBad;
+        a.lmeta[i] = 0;
+        atomicOr(&a.state->flags, kDtokShortLine);
+        return;
+    }
+    uint32_t flag = 0;
+    bool digits = true;
+    for (uint32_t p = tab[0] + 1u; p < tab[1]; ++p) {
+        const uint32_t d = (uint32_t)a.text[p] - (uint32_t)'0';
+        digits &= d <= 9u;
+        flag = flag * 10u + d;
+    }
+    const uint32_t qn = tab[0] - lo;
+    if (!digits || tab[1] - tab[0] > 7u || qn >= (1u << 28)) {
+        a.lsubj[i] = kLineBad;
+        a.lmeta[i] = 0;
+        atomicOr(&a.state->flags, !digits || tab[1] - tab[0] > 7u ? kDtokShortLine : kDtokLongName);
+        return;
+    }
+    const uint32_t rb = tab[1] + 1u, rn = tab[2] - rb;
+    if (rn == 1u && a.text[rb] == '*') {  // unmapped: skipped before anything else (align.py:318-319)
+        a.lsubj[i] = kLineUnmapped;
+        a.lmeta[i] = qn;
+        return;
+    }
+    const uint32_t mate = (flag >> 6) & 3u;
+    if (mate == 3u) atomicOr(&a.state->flags, kDtokBothMates);
+    a.lmeta[i] = qn | (mate << 28);
+    // dictionary
+    const unsigned long long hv = dtok_hash(a.text + rb, rn);
+    uint32_t h = (uint32_t)hv & a.dict_mask;
+    int32_t id = kLineUnknown;
+    for (;;) {
+        const DictSlot s = a.dict[h];
+        if (s.id < 0) break;
+        if (s.hash == hv) {
+            const unsigned char* nm = a.arena + s.off;
+            const uint32_t ln = (uint32_t)nm[0] | ((uint32_t)nm[1] << 8) | ((uint32_t)nm[2] << 16) | ((uint32_t)nm[3] << 24);
+            bool same = ln == rn;
+            for (uint32_t k = 0; same && k < rn; ++k) same = nm[4 + k] == a.text[rb + k];
+            if (same) {
+                id = s.id;
+                break;
+            }
+        }
+        h = (h + 1u) & a.dict_mask;
+    }
+    a.lsubj[i] = id;
+    if (id == kLineUnknown) {
+        const uint32_t at = atomicAdd(&a.state->n_unknown, 1u);
+        if (at < a.unknown_cap)
+            a.unknown[at] = make_uint2(rb, rn);
+        else
+            atomicOr(&a.state->flags, kDtokUnknownFull);
+    }
+}
+
+// a thread per line: does the line start a run of equal QNAMEs?  (Compared
+// with the previous *mapped* line: unmapped records do not split a run.)
+__global__ void __launch_bounds__(kDtokThreads) dtok_runs_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines) return;
+    unsigned char start = 0;
+    if (a.lsubj[i] >= 0) {
+        int64_t j = (int64_t)i - 1;
+        while (j >= 0 && a.lsubj[j] < 0) --j;  // (only kLineUnmapped can be there: other codes send the block to the host)
+        if (j < 0) {
+            start = 1;
+        } else {
+            const uint32_t qn = a.lmeta[i] & 0x0FFFFFFFu, pn = a.lmeta[j] & 0x0FFFFFFFu;
+            bool same = qn == pn;
+            const unsigned char* x = a.text + a.line_start[i];
+            const unsigned char* y = a.text + a.line_start[j];
+            for (uint32_t k = 0; same && k < qn; ++k) same = x[k] == y[k];
+            start = same ? 0 : 1;
+        }
+    }
+    a.is_start[i] = start;
+}
+
+// a thread per run: the run's mapped lines into up to three subject sets (by
+// mate), each set one read: its records go out as packed words
+__global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    int32_t set[3][WK_WEIGHT_MAX_K];
+    uint32_t cnt[3] = {0, 0, 0};
+    bool big = false;
+    if (i < a.n_lines && a.is_start[i]) {
+        uint32_t j = i;
+        do {
+            const int32_t s = a.lsubj[j];
+            if (s >= 0) {
+                const uint32_t m = a.lmeta[j] >> 28;
+                if (m < 3u) {
+                    bool dup = false;
+                    for (uint32_t k = 0; k < cnt[m]; ++k) dup |= set[m][k] == s;
+                    if (!dup) {
+                        if (cnt[m] < (uint32_t)WK_WEIGHT_MAX_K)
+                            set[m][cnt[m]++] = s;
+                        else
+                            big = true;
+                    }
+                }
+            }
+            ++j;
+        } while (j < a.n_lines && !a.is_start[j]);
+    }
+    if (big) atomicOr(&a.state->flags, kDtokBigRead);
+    const uint32_t total = cnt[0] + cnt[1] + cnt[2];
+    const uint32_t reads = (cnt[0] != 0u) + (cnt[1] != 0u) + (cnt[2] != 0u);
+    // one reservation per wave: exclusive scan of `total` over the lanes
+    uint32_t incl = total;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, kWave);
+        if ((int)lane >= d) incl += v;
+    }
+    const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
+    unsigned long long rd = wave_sum((unsigned long long)reads);
+    unsigned long long base = 0;
+    if (lane == 0) {
+        if (wave_total) base = atomicAdd(&a.state->n_out, (unsigned long long)wave_total);
+        if (rd) atomicAdd(&a.state->n_reads, rd);
+    }
+    base = __shfl(base, 0, kWave);
+    if (!total) return;
+    unsigned long long at = base + incl - total;
+    if (at + total > a.out_cap) return;  // (cannot happen: the buffer holds a word per line)
+    for (uint32_t m = 0; m < 3u; ++m)
+        for (uint32_t k = 0; k < cnt[m]; ++k)
+            a.out[at++] = (uint32_t)set[m][k] | (k << kWordSubjBits) | (cnt[m] << kWordSizeShift);
+}
+
+}  // namespace wk

@@ -767,6 +767,61 @@ const char* run_boundary(int fmt, bool extra, const char* base, const char* p, c
     return e;
 }
 
+// The part of a block that can be tokenised now: behind the leading '@' lines
+// of a SAM file (`in_header`: still inside them; updated) up to — unless the
+// block is final — the start of the last run of equal query ids (it may
+// continue in the next block).  false: nothing complete yet (b = what was
+// consumed: header lines).
+bool block_span(int fmt, bool ex, const char* buf, int64_t len, bool final_block, bool& in_header, const char*& b, const char*& stop) {
+    b = buf;
+    const char* e = buf + len;
+    while (in_header && b < e) {
+        if (*b != '@') {
+            in_header = false;
+            break;
+        }
+        const char* nl = (const char*)memchr(b, '\n', e - b);
+        if (!nl && !final_block) break;  // partial header line: wait for more text
+        b = nl ? nl + 1 : e;
+    }
+    // only whole lines; unless final, stop before the last run (it may continue)
+    stop = e;
+    if (final_block) return true;
+    const char* last_nl = nullptr;
+    for (const char* p = e; p > b; --p)
+        if (p[-1] == '\n') {
+            last_nl = p;
+            break;
+        }
+    if (!last_nl || in_header) return false;
+    stop = last_nl;
+    // start of the last run: walk back over lines while the QNAME stays the same
+    const char* run_start = nullptr;
+    const char* q_last = nullptr;
+    size_t qn_last = 0;
+    const char* s = stop;
+    while (s > b) {
+        const char* ls = s - 1;
+        const char* q = ls;
+        while (q > b && q[-1] != '\n') --q;
+        Line L = parse_row(fmt, q, ls, ex);
+        if (is_row(fmt, L)) {
+            if (!q_last) {
+                q_last = L.q;
+                qn_last = L.qn;
+                run_start = q;
+            } else if (L.qn == qn_last && memcmp(L.q, q_last, qn_last) == 0) {
+                run_start = q;
+            } else {
+                break;
+            }
+        }
+        s = q;
+    }
+    if (run_start) stop = run_start;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -874,8 +929,6 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
     }
     if (fmt == WK_FMT_MAP) extra = 0;  // no "ex" flavour (align.py:236)
     const bool ex = (extra & 1) != 0;
-    const char* b = buf;
-    const char* e = buf + len;
     // header: leading '@' lines (align.py:295-300); it may span several blocks
     if (first_block) {
         t->in_header = fmt == WK_FMT_SAM;
@@ -883,58 +936,16 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
         t->tail_this.clear();
         t->tail_lines.clear();
     }
-    while (t->in_header && b < e) {
-        if (*b != '@') {
-            t->in_header = false;
-            break;
-        }
-        const char* nl = (const char*)memchr(b, '\n', e - b);
-        if (!nl && !final_block) break;  // partial header line: wait for more text
-        b = nl ? nl + 1 : e;
-    }
-    // only whole lines; unless final, stop before the last run (it may continue)
-    const char* stop = e;
-    if (!final_block) {
-        const char* last_nl = nullptr;
-        for (const char* p = e; p > b; --p)
-            if (p[-1] == '\n') {
-                last_nl = p;
-                break;
-            }
-        if (!last_nl || t->in_header) {
-            *consumed = b - buf;
-            *n_reads = *n_records = 0;
-            t->n_loc = 0;
-            t->tot_reads = t->tot_rec = t->tot_big = 0;
-            t->last_extra = ex;
-            t->last_want = want_names;
-            return WK_OK;
-        }
-        stop = last_nl;
-        // start of the last run: walk back over lines while the QNAME stays the same
-        const char* run_start = nullptr;
-        const char* q_last = nullptr;
-        size_t qn_last = 0;
-        const char* s = stop;
-        while (s > b) {
-            const char* ls = s - 1;
-            const char* q = ls;
-            while (q > b && q[-1] != '\n') --q;
-            Line L = parse_row(fmt, q, ls, ex);
-            if (is_row(fmt, L)) {
-                if (!q_last) {
-                    q_last = L.q;
-                    qn_last = L.qn;
-                    run_start = q;
-                } else if (L.qn == qn_last && memcmp(L.q, q_last, qn_last) == 0) {
-                    run_start = q;
-                } else {
-                    break;
-                }
-            }
-            s = q;
-        }
-        if (run_start) stop = run_start;
+    const char* b = buf;
+    const char* stop = buf + len;
+    if (!block_span(fmt, ex, buf, len, final_block != 0, t->in_header, b, stop)) {
+        *consumed = b - buf;
+        *n_reads = *n_records = 0;
+        t->n_loc = 0;
+        t->tot_reads = t->tot_rec = t->tot_big = 0;
+        t->last_extra = ex;
+        t->last_want = want_names;
+        return WK_OK;
     }
     TokLap lap(t->lap_ms);
     t->lap_calls += 1;
@@ -1533,6 +1544,54 @@ int wk_preorder(const int64_t* par, int64_t n, int64_t expected_root, int64_t* p
             }
     }
     return WK_OK;
+}
+
+// [*begin, *stop) of a block of SAM text that can be tokenised now: behind the
+// leading '@' lines (in_header: the block starts inside them — the first block of
+// a file, or one after a header-only block) up to the start of the last run of
+// equal query ids unless `final_block`.  Stateless: what wk_tok_text does with a
+// block before tokenising it, for callers that feed the device tokenizer.
+int wk_tok_sam_span(const char* buf, int64_t len, int final_block, int in_header, int64_t* begin, int64_t* stop,
+                    int* in_header_after) {
+    if (!buf || len < 0 || !begin || !stop || !in_header_after) return WK_E_ARG;
+    bool hdr = in_header != 0;
+    const char* b = buf;
+    const char* s = buf + len;
+    const bool ok = block_span(WK_FMT_SAM, false, buf, len, final_block != 0, hdr, b, s);
+    *begin = b - buf;
+    *stop = ok ? s - buf : b - buf;
+    *in_header_after = hdr ? 1 : 0;
+    return ok ? WK_OK : WK_E_STATE;
+}
+
+// The header state wk_tok_text continues from (blocks the device tokenizer took
+// are not seen by it).
+int wk_tok_set_header_state(wk_tok* t, int in_header) {
+    if (!t) return WK_E_ARG;
+    t->in_header = in_header != 0;
+    return WK_OK;
+}
+
+// ---- internal: what the device tokenizer (woltka_hip.hip) needs of a wk_tok ------
+
+int wkx_tok_device_ok(const wk_tok* t) { return t->exclude.size() == 0 ? 1 : 0; }
+
+int32_t wkx_tok_n_names(const wk_tok* t) { return t->names.size(); }
+
+void wkx_tok_name(const wk_tok* t, int32_t id, const char** p, uint32_t* len, uint64_t* hash) {
+    *p = t->names.ptr(id);
+    *len = t->names.len[(size_t)id];
+    *hash = t->names.hash[(size_t)id];
+}
+
+int32_t wkx_tok_intern(wk_tok* t, const char* p, uint32_t len) {
+    const uint64_t hv = hash_bytes(p, len);
+    int32_t id = t->names.find(p, len, hv);
+    if (id < 0) {
+        id = t->names.add(p, len, hv);
+        t->dict.insert(p, len, hv, id);
+    }
+    return id;
 }
 
 }  // extern "C"

@@ -15,7 +15,9 @@
 #include "../../include/woltka_hip.h"
 #include "wk_classify.hpp"
 #include "wk_device.hpp"
+#include "wk_dtok.hpp"
 #include "wk_ordinal.hpp"
+#include "wk_tok_internal.h"
 #include "wk_weigh.hpp"
 
 using namespace wk;
@@ -182,6 +184,12 @@ struct wk_ctx {
     hipEvent_t slot_ev[kStageSlots] = {};
     bool slot_busy[kStageSlots] = {};
     std::vector<void*> host_blocks;      // wk_host_alloc
+    // device tokenizer (wk_dtok.hpp): the block scanned last and the dictionary mirror
+    DevBuf d_text, d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_unknown, d_state, d_dict, d_arena;
+    uint32_t dt_n = 0, dt_lines = 0, dt_dict_mask = 0;
+    int32_t dt_dict_names = -1;  // names of the tokenizer the mirror holds
+    const wk_tok* dt_dict_tok = nullptr;
+    bool dt_ready = false;
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
 };
@@ -441,6 +449,7 @@ static int build_subject_rows(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, Cla
 extern "C" {
 
 int wk_words_flush(wk_ctx* c);
+int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group, int* ok);
 
 int wk_abi_version(void) { return WK_ABI_VERSION; }
 
@@ -554,6 +563,9 @@ void wk_destroy(wk_ctx* c) {
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     c->c_words.release();
+    for (DevBuf* b : {&c->d_text, &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_unknown,
+                      &c->d_state, &c->d_dict, &c->d_arena})
+        b->release();
     for (void* hp : c->host_blocks) (void)hipHostFree(hp);
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -1627,32 +1639,48 @@ int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group,
     return WK_OK;
 }
 
+// Room for n_more records behind the accumulated ones.
+static int words_room(wk_ctx* c, int64_t n_more) {
+    const size_t need = (size_t)(c->w_records + n_more) * 4 + 64;
+    if (need <= c->c_words.cap) return WK_OK;
+    // grow: a new buffer (twice the need) takes over what is there
+    DevBuf bigger;
+    HIP_TRY(c, bigger.reserve(need * 2));
+    if (c->w_records > 0) HIP_TRY(c, hipMemcpyAsync(bigger.p, c->c_words.p, (size_t)c->w_records * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->c_words.release();
+    c->c_words = bigger;
+    return WK_OK;
+}
+
+// The accumulated records would pass 2^30 (the histogram addresses bytes with
+// 32 bits): classify what is there and open the same job set again.
+static int words_roll(wk_ctx* c, int64_t n_more) {
+    if (c->w_records + n_more < (1ll << 30)) return WK_OK;
+    const std::vector<wk_job> jobs = c->w_jobs;
+    const int32_t group = c->w_group;
+    int rc = wk_words_flush(c);
+    if (rc) return rc;
+    int ok = 0;
+    if ((rc = wk_words_begin(c, jobs.data(), (int32_t)jobs.size(), group, &ok))) return rc;
+    if (!ok) return fail(c, WK_E_STATE, "job set no longer accepted");
+    if (n_more >= (1ll << 30)) return fail(c, WK_E_RANGE, "more than 2^30 records in one block");
+    return WK_OK;
+}
+
 int wk_words_append(wk_ctx* c, const uint32_t* words, int64_t n_records, int64_t n_reads, int slot) {
     if (!c) return WK_E_ARG;
     if (n_records < 0 || n_reads < 0 || (n_records > 0 && !words)) return fail(c, WK_E_ARG, "bad packed record arguments");
     if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
     if (slot < -1 || slot >= wk_ctx::kStageSlots) return fail(c, WK_E_ARG, "slot must be -1 or in [0, %d)", wk_ctx::kStageSlots);
     DeviceGuard guard(c->device);
-    if (c->w_records + n_records >= (1ll << 30)) {  // the histogram addresses bytes with 32 bits
-        ClassifyArgs a{};
-        const std::vector<wk_job> jobs = c->w_jobs;
-        const int32_t group = c->w_group;
-        int rc = wk_words_flush(c);
-        if (rc) return rc;
-        int ok = 0;
-        if ((rc = wk_words_begin(c, jobs.data(), (int32_t)jobs.size(), group, &ok))) return rc;
-        if (!ok) return fail(c, WK_E_STATE, "job set no longer accepted");
-        if (n_records >= (1ll << 30)) return fail(c, WK_E_RANGE, "more than 2^30 records in one block");
+    {
+        const int rcr = words_roll(c, n_records);
+        if (rcr) return rcr;
     }
-    const size_t need = (size_t)(c->w_records + n_records) * 4 + 64;
-    if (need > c->c_words.cap) {
-        // grow: a new buffer (twice the need) takes over what is there
-        DevBuf bigger;
-        HIP_TRY(c, bigger.reserve(need * 2));
-        if (c->w_records > 0) HIP_TRY(c, hipMemcpyAsync(bigger.p, c->c_words.p, (size_t)c->w_records * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->c_words.release();
-        c->c_words = bigger;
+    {
+        const int rcw = words_room(c, n_records);
+        if (rcw) return rcw;
     }
     if (n_records > 0)
         HIP_TRY(c, hipMemcpyAsync(c->c_words.as<uint32_t>() + c->w_records, words, (size_t)n_records * 4, hipMemcpyHostToDevice, c->stream));
@@ -1681,6 +1709,176 @@ int wk_words_pending(wk_ctx* c, int64_t* n_records, int64_t* n_reads) {
     if (!c) return WK_E_ARG;
     if (n_records) *n_records = c->w_open ? c->w_records : 0;
     if (n_reads) *n_reads = c->w_open ? c->w_reads : 0;
+    return WK_OK;
+}
+
+// ---- SAM tokenizer on the device --------------------------------------------------
+
+// The dictionary of `tok` as the kernels probe it: open addressing, 16-byte slots
+// {hash, id, offset}, the names behind 4-byte lengths in one arena.
+static int dtok_mirror_dict(wk_ctx* c, const wk_tok* tok) {
+    const int32_t n = wkx_tok_n_names(tok);
+    if (c->dt_dict_tok == tok && c->dt_dict_names == n) return WK_OK;
+    uint32_t slots = 1024;
+    while (slots < 2u * (uint32_t)n + 2u) slots <<= 1;
+    std::vector<DictSlot> tab(slots, DictSlot{0ull, -1, 0u});
+    std::string arena;
+    arena.reserve((size_t)n * 16 + 16);
+    for (int32_t id = 0; id < n; ++id) {
+        const char* p;
+        uint32_t len;
+        uint64_t hv;
+        wkx_tok_name(tok, id, &p, &len, &hv);
+        const uint32_t off = (uint32_t)arena.size();
+        arena.append(reinterpret_cast<const char*>(&len), 4);
+        arena.append(p, len);
+        uint32_t h = (uint32_t)hv & (slots - 1);
+        while (tab[h].id >= 0) h = (h + 1) & (slots - 1);
+        tab[h] = DictSlot{(unsigned long long)hv, id, off};
+    }
+    arena.append(16, '\0');
+    int rc;
+    if ((rc = upload(c, c->d_dict, tab.data(), tab.size() * sizeof(DictSlot)))) return rc;
+    if ((rc = upload(c, c->d_arena, arena.data(), arena.size()))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->dt_dict_mask = slots - 1;
+    c->dt_dict_names = n;
+    c->dt_dict_tok = tok;
+    return WK_OK;
+}
+
+static DtokArgs dtok_args(wk_ctx* c) {
+    DtokArgs a{};
+    a.text = c->d_text.as<unsigned char>();
+    a.n = c->dt_n;
+    a.line_start = c->d_lines.as<uint32_t>();
+    a.n_lines = c->dt_lines;
+    a.lsubj = c->d_lsubj.as<int32_t>();
+    a.lmeta = c->d_lmeta.as<uint32_t>();
+    a.dict = c->d_dict.as<DictSlot>();
+    a.dict_mask = c->dt_dict_mask;
+    a.arena = c->d_arena.as<unsigned char>();
+    a.unknown = c->d_unknown.as<uint2>();
+    a.unknown_cap = (uint32_t)(c->d_unknown.cap / 8);
+    a.is_start = c->d_start.as<unsigned char>();
+    a.state = c->d_state.as<DtokState>();
+    return a;
+}
+
+int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int64_t* n_lines, int* status) {
+    if (!c || !tok || !text || begin < 0 || stop < begin || !n_lines || !status) return WK_E_ARG;
+    *status = 1;
+    *n_lines = 0;
+    c->dt_ready = false;
+    if (!wkx_tok_device_ok(tok)) return WK_OK;  // an exclusion set: the host tokenizer's business
+    const int64_t n64 = stop - begin;
+    if (n64 >= (1ll << 31) - 64) return WK_OK;
+    DeviceGuard guard(c->device);
+    const uint32_t n = (uint32_t)n64;
+    c->dt_n = n;
+    c->dt_lines = 0;
+    if (n == 0) {
+        *status = 0;
+        c->dt_ready = true;
+        return WK_OK;
+    }
+    const char* src = text + begin;
+    HIP_TRY(c, c->d_text.reserve((size_t)n + 64));
+    HIP_TRY(c, hipMemcpyAsync(c->d_text.p, src, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_text.as<unsigned char>() + n, 0, 64, c->stream));
+    // line starts: newlines per tile -> offsets -> positions
+    const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
+    HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
+    HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
+    HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+    KernelTimer* kt = ktimer_begin(c, "dtok_lines");
+    hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_text.as<unsigned char>(), n,
+                       c->d_tiles.as<unsigned long long>());
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
+                       c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+    unsigned long long n_newlines = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_newlines, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const bool open_end = src[n - 1] != '\n';  // a last line without newline
+    const uint32_t lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
+    HIP_TRY(c, c->d_lines.reserve(((size_t)lines + 2) * 4));
+    HIP_TRY(c, c->d_lsubj.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->d_lmeta.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->d_start.reserve((size_t)lines + 64));
+    if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
+    HIP_TRY(c, hipMemsetAsync(c->d_lines.p, 0, 4, c->stream));  // line 0 starts at 0
+    hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_text.as<unsigned char>(), n,
+                       c->d_tile_off.as<unsigned long long>(), c->d_lines.as<uint32_t>());
+    if (open_end) {
+        const uint32_t end = n + 1;  // as if a newline followed the text
+        HIP_TRY(c, hipMemcpyAsync(c->d_lines.as<uint32_t>() + lines, &end, 4, hipMemcpyHostToDevice, c->stream));
+    }
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    c->dt_lines = lines;
+    // parse; subjects the dictionary does not know are interned in text order, then once more
+    for (int round = 0; round < 3; ++round) {
+        int rc = dtok_mirror_dict(c, tok);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_state.p, 0, sizeof(DtokState), c->stream));
+        const DtokArgs a = dtok_args(c);
+        kt = ktimer_begin(c, "dtok_parse");
+        hipLaunchKernelGGL(dtok_parse_kernel, dim3((lines + kDtokThreads - 1) / kDtokThreads), dim3(kDtokThreads), 0, c->stream, a);
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+        DtokState st{};
+        HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (st.flags) return WK_OK;  // status 1: the host tokenizer takes the block
+        if (st.n_unknown == 0) {
+            *status = 0;
+            *n_lines = lines;
+            c->dt_ready = true;
+            return WK_OK;
+        }
+        std::vector<uint2> unk(st.n_unknown);
+        HIP_TRY(c, hipMemcpyAsync(unk.data(), c->d_unknown.p, (size_t)st.n_unknown * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::sort(unk.begin(), unk.end(), [](const uint2& x, const uint2& y) { return x.x < y.x; });
+        for (const uint2& u : unk) (void)wkx_tok_intern(tok, src + u.x, u.y);
+    }
+    return fail(c, WK_E_STATE, "device tokenizer: subjects still unknown after interning them");
+}
+
+int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
+    if (!c || !n_reads || !n_records || !status) return WK_E_ARG;
+    *status = 1;
+    *n_reads = *n_records = 0;
+    if (!c->dt_ready) return fail(c, WK_E_STATE, "no block scanned (wk_dtok_scan)");
+    if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
+    c->dt_ready = false;
+    if (c->dt_lines == 0) {
+        *status = 0;
+        return WK_OK;
+    }
+    DeviceGuard guard(c->device);
+    int rc = words_roll(c, c->dt_lines);
+    if (rc) return rc;
+    if ((rc = words_room(c, c->dt_lines))) return rc;
+    DtokArgs a = dtok_args(c);
+    a.out = c->c_words.as<uint32_t>() + c->w_records;
+    a.out_cap = c->dt_lines;
+    const dim3 grid((c->dt_lines + kDtokThreads - 1) / kDtokThreads);
+    KernelTimer* kt = ktimer_begin(c, "dtok_emit");
+    hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+    hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    DtokState st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (st.flags) return WK_OK;  // a read of more than 16 subjects: nothing counts as appended
+    c->w_records += (int64_t)st.n_out;
+    c->w_reads += (int64_t)st.n_reads;
+    *n_reads = (int64_t)st.n_reads;
+    *n_records = (int64_t)st.n_out;
+    *status = 0;
     return WK_OK;
 }
 
