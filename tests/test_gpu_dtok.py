@@ -29,10 +29,12 @@ def _run(tmp_path, tag, host, **kw):
             workflow.workflow(output_fp=out, output_fmt=False, **kw)
     finally:
         os.environ.pop('WOLTKA_NO_DTOK', None)
-    files = [os.path.join(out, x) for x in sorted(os.listdir(out))] \
-        if os.path.isdir(out) else [out]
-    return {os.path.basename(fp): open(fp, 'rb').read() for fp in files}, \
-        log.getvalue()
+    if os.path.isdir(out):
+        tables = {x: open(os.path.join(out, x), 'rb').read()
+                  for x in sorted(os.listdir(out))}
+    else:
+        tables = {'table': open(out, 'rb').read()}
+    return tables, log.getvalue()
 
 
 def _random_sam(rng, n_queries, subjects, paired, unmapped, long_names,
