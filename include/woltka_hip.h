@@ -287,6 +287,10 @@ int wk_words_pending(wk_ctx* ctx, int64_t* n_records, int64_t* n_reads);
  * accepted the jobs for the grown subject table — groups and appends the
  * records; *status 1 = a read of more than WK_WEIGHT_MAX_K subjects: nothing
  * was appended, the host tokenizer takes the block. */
+/* Start the copy of a block's text on a copy stream (pinned `text`): the
+ * wk_dtok_scan of the same block then only waits for it, and the copy of block
+ * i + 1 overlaps the kernels of block i.  One block ahead at most. */
+int wk_dtok_copy(wk_ctx* ctx, const char* text, int64_t begin, int64_t stop);
 int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
                  int64_t stop, int64_t* n_lines, int* status);
 int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,

@@ -1,10 +1,8 @@
 #!/bin/bash
-# where the end-to-end time of the device-tokenizer route goes: kernel trace of
-# one `woltka classify` run + block-size sweep
+# kernel trace of one `woltka classify` run through the device tokenizer
 out=gpurun_out/${1:-r03p}
 mkdir -p $out
-timeout 900 python -m pytest tests/test_gpu_dtok.py -x -q > $out/pytest.log 2>&1
-echo "pytest rc=$?"; tail -6 $out/pytest.log
+R=$GRAFT_REPO_ROOT
 python - <<'PY' > $out/gen.log 2>&1
 import sys, os, numpy as np
 sys.path.insert(0, '.')
@@ -16,10 +14,9 @@ os.makedirs('/dev/shm/e2e/in', exist_ok=True)
 print(bench.write_sam_lca('/dev/shm/e2e/in/S1.sam', p, 50_000_000))
 bench.write_nodes_dmp('/dev/shm/e2e/nodes.dmp', p['hier'])
 PY
-cat $out/gen.log
-cat > /tmp/run_e2e.py <<'PY'
+cat > /tmp/run_e2e.py <<PY
 import sys, time, io, contextlib
-sys.path.insert(0, '.')
+sys.path.insert(0, '$R')
 from woltka_amd import workflow
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     t0 = time.perf_counter()
@@ -28,14 +25,9 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
                           nodes_fps=['/dev/shm/e2e/nodes.dmp'], ranks='phylum,genus,species')
     print(f'e2e {time.perf_counter() - t0:.3f} s', flush=True)
 PY
-for blk in 16777216 67108864 268435456; do
-  echo "== DTOK block $blk"; WOLTKA_DTOK_BLOCK=$blk python /tmp/run_e2e.py 3
-done
-echo "== host tokenizer (mmap)"; WOLTKA_NO_DTOK=1 WOLTKA_READ=mmap python /tmp/run_e2e.py 2
-echo "== host tokenizer (pread)"; WOLTKA_NO_DTOK=1 python /tmp/run_e2e.py 2
+python /tmp/run_e2e.py 2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o e2e -- python /tmp/run_e2e.py 1 > $GRAFT_REPO_ROOT/$out/rocprof.log 2>&1
-cd $GRAFT_REPO_ROOT
-find $out/prof -name "*kernel_stats*" | head -3
-f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f"
-rm -rf /dev/shm/e2e
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o e2e -- python /tmp/run_e2e.py 1 > $R/$out/rocprof.log 2>&1
+cd $R
+f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $out/e2e_kernel_stats.csv && head -16 "$f"
+rm -rf $out/prof /dev/shm/e2e

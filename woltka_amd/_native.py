@@ -49,7 +49,7 @@ SYMBOLS = (
     'wk_tok_boundary',
     'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
     'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_set_header_state',
-    'wk_dtok_scan', 'wk_dtok_emit',
+    'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
@@ -165,6 +165,7 @@ def load_library():
         'wk_tok_sam_span': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       i64p, i64p, C.POINTER(C.c_int)]),
         'wk_tok_set_header_state': (C.c_int, [p, C.c_int]),
+        'wk_dtok_copy': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64]),
         'wk_dtok_scan': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
                                    i64p, C.POINTER(C.c_int)]),
         'wk_dtok_emit': (C.c_int, [p, i64p, i64p, C.POINTER(C.c_int)]),
@@ -471,6 +472,14 @@ class Context:
         return a.value, b.value
 
     # -- SAM tokenizer on the device -----------------------------------------
+    def dtok_copy(self, buf, begin, stop):
+        """Start copying ``buf[begin:stop]`` (pinned) to the device; the
+        ``dtok_scan`` of the same block finds it there."""
+        raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+        if raw.size:
+            self._check(self._lib.wk_dtok_copy(
+                self._h, C.c_void_p(raw.ctypes.data), int(begin), int(stop)))
+
     def dtok_scan(self, tok, buf, begin, stop):
         """Copy and parse ``buf[begin:stop]`` (whole lines ending at a run
         boundary: ``Tokenizer.sam_span``) on the device.  Returns (status,

@@ -796,7 +796,7 @@ class Engine:
         rd = self._reader
         block = self.DTOK_BLOCK
         if self._tring is None:
-            self._tring = StageRing(self.ctx, 4, {
+            self._tring = StageRing(self.ctx, 5, {
                 'text': (np.uint8, block + (1 << 20))})
         ring = self._tring
         free = queue.Queue()
@@ -842,7 +842,7 @@ class Engine:
                 if final:
                     return
 
-        for item in _prefetch(blocks()):
+        def one(item):
             slot, buf, fill, begin, stop, first, final, hdr_in, hdr = item
             try:
                 status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop)
@@ -866,6 +866,18 @@ class Engine:
             finally:
                 if slot is not None:
                     ring.release(slot)
+
+        # the copy of a block's text to the device starts one block ahead:
+        # it overlaps the kernels of the block before
+        prev = None
+        for item in _prefetch(blocks()):
+            if item[0] is not None:         # (pinned: an asynchronous copy)
+                self.ctx.dtok_copy(item[1], item[3], item[4])
+            if prev is not None:
+                yield from one(prev)
+            prev = item
+        if prev is not None:
+            yield from one(prev)
 
     def _host_block(self, buf, fill, first, final, hdr_in):
         """One block of the device route through the host tokenizer after

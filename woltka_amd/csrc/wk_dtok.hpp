@@ -17,7 +17,8 @@
 //   dtok_count / dtok_lines   positions of the line starts (two passes + scan)
 //   dtok_parse                a thread per line: fields, FLAG, dictionary probe
 //   dtok_runs                 a thread per line: does its QNAME start a run?
-//   dtok_emit                 a thread per run: per-mate subject sets -> words
+//   dtok_first / dtok_emit    a thread per line: first line of its read with its
+//                             subject? -> position and size in the read -> word
 // Anything the kernels are not sure to treat like the reference — a short or
 // malformed line, both mate bits, a read of more than 16 subjects — sets a flag
 // and the host tokenizer takes the block instead.  Subjects the dictionary
@@ -71,6 +72,7 @@ struct DtokArgs {
     uint2* unknown;              // (offset, length) of RNAMEs not in the dictionary
     uint32_t unknown_cap;
     unsigned char* is_start;     // [n_lines]
+    unsigned char* is_first;     // [n_lines] first line of its read that names its subject
     DtokState* state;
     uint32_t* out;      // packed records
     uint32_t out_cap;
@@ -249,58 +251,69 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_runs_kernel(DtokArgs a) {
     a.is_start[i] = start;
 }
 
-// a thread per run: the run's mapped lines into up to three subject sets (by
-// mate), each set one read: its records go out as packed words
+// a thread per mapped line: is it the first line of its read (run, mate) that
+// names its subject?  (The plain parsers collect subject sets, align.py:309.)
+// Walks back to the run's start.
+__global__ void __launch_bounds__(kDtokThreads) dtok_first_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines) return;
+    const int32_t s = a.lsubj[i];
+    unsigned char first = 0;
+    if (s >= 0) {
+        const uint32_t m = a.lmeta[i] >> 28;
+        first = 1;
+        if (!a.is_start[i]) {
+            uint32_t j = i;
+            do {
+                --j;
+                if (a.lsubj[j] == s && (a.lmeta[j] >> 28) == m) {
+                    first = 0;
+                    break;
+                }
+            } while (!a.is_start[j]);  // (a mapped line before i starts the run: j never passes 0)
+        }
+    }
+    a.is_first[i] = first;
+}
+
+// a thread per line: the first lines of a read (dtok_first_kernel) are its
+// records — position = first lines of the same read before it, size = all of
+// them — and go out as packed words, appended in no particular order (the
+// histogram does not care).
 __global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    int32_t set[3][WK_WEIGHT_MAX_K];
-    uint32_t cnt[3] = {0, 0, 0};
-    bool big = false;
-    if (i < a.n_lines && a.is_start[i]) {
-        uint32_t j = i;
-        do {
-            const int32_t s = a.lsubj[j];
-            if (s >= 0) {
-                const uint32_t m = a.lmeta[j] >> 28;
-                if (m < 3u) {
-                    bool dup = false;
-                    for (uint32_t k = 0; k < cnt[m]; ++k) dup |= set[m][k] == s;
-                    if (!dup) {
-                        if (cnt[m] < (uint32_t)WK_WEIGHT_MAX_K)
-                            set[m][cnt[m]++] = s;
-                        else
-                            big = true;
-                    }
-                }
-            }
-            ++j;
-        } while (j < a.n_lines && !a.is_start[j]);
+    bool rec = false, big = false;
+    uint32_t word = 0, pos = 0;
+    if (i < a.n_lines && a.is_first[i]) {
+        rec = true;
+        const uint32_t m = a.lmeta[i] >> 28;
+        if (!a.is_start[i]) {
+            uint32_t j = i;
+            do {
+                --j;
+                pos += (a.is_first[j] && (a.lmeta[j] >> 28) == m) ? 1u : 0u;
+            } while (!a.is_start[j]);
+        }
+        uint32_t size = pos + 1u;
+        for (uint32_t j = i + 1u; j < a.n_lines && !a.is_start[j]; ++j)
+            size += (a.is_first[j] && (a.lmeta[j] >> 28) == m) ? 1u : 0u;
+        big = size > (uint32_t)WK_WEIGHT_MAX_K;
+        word = (uint32_t)a.lsubj[i] | ((pos & 15u) << kWordSubjBits) | ((size & 31u) << kWordSizeShift);
     }
     if (big) atomicOr(&a.state->flags, kDtokBigRead);
-    const uint32_t total = cnt[0] + cnt[1] + cnt[2];
-    const uint32_t reads = (cnt[0] != 0u) + (cnt[1] != 0u) + (cnt[2] != 0u);
-    // one reservation per wave: exclusive scan of `total` over the lanes
-    uint32_t incl = total;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t v = __shfl_up(incl, d, kWave);
-        if ((int)lane >= d) incl += v;
-    }
-    const uint32_t wave_total = __shfl(incl, kWave - 1, kWave);
-    unsigned long long rd = wave_sum((unsigned long long)reads);
+    // one reservation per wave
+    const unsigned long long mask = __ballot(rec);
+    const unsigned long long reads = __ballot(rec && pos == 0u);
     unsigned long long base = 0;
     if (lane == 0) {
-        if (wave_total) base = atomicAdd(&a.state->n_out, (unsigned long long)wave_total);
-        if (rd) atomicAdd(&a.state->n_reads, rd);
+        if (mask) base = atomicAdd(&a.state->n_out, (unsigned long long)__popcll(mask));
+        if (reads) atomicAdd(&a.state->n_reads, (unsigned long long)__popcll(reads));
     }
     base = __shfl(base, 0, kWave);
-    if (!total) return;
-    unsigned long long at = base + incl - total;
-    if (at + total > a.out_cap) return;  // (cannot happen: the buffer holds a word per line)
-    for (uint32_t m = 0; m < 3u; ++m)
-        for (uint32_t k = 0; k < cnt[m]; ++k)
-            a.out[at++] = (uint32_t)set[m][k] | (k << kWordSubjBits) | (cnt[m] << kWordSizeShift);
+    if (!rec) return;
+    const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+    if (at < a.out_cap) a.out[at] = word;
 }
 
 }  // namespace wk

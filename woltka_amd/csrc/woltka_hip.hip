@@ -185,11 +185,18 @@ struct wk_ctx {
     bool slot_busy[kStageSlots] = {};
     std::vector<void*> host_blocks;      // wk_host_alloc
     // device tokenizer (wk_dtok.hpp): the block scanned last and the dictionary mirror
-    DevBuf d_text, d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_unknown, d_state, d_dict, d_arena;
+    DevBuf d_textbuf[2], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
     uint32_t dt_n = 0, dt_lines = 0, dt_dict_mask = 0;
     int32_t dt_dict_names = -1;  // names of the tokenizer the mirror holds
     const wk_tok* dt_dict_tok = nullptr;
     bool dt_ready = false;
+    // the text of a block is copied on a stream of its own into one of two
+    // buffers while the kernels work on the other (wk_dtok_copy)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    const char* copy_src[2] = {nullptr, nullptr};
+    uint32_t copy_n[2] = {0, 0};
+    int copy_next = 0, dt_cur = 0;
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
 };
@@ -563,10 +570,13 @@ void wk_destroy(wk_ctx* c) {
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     c->c_words.release();
-    for (DevBuf* b : {&c->d_text, &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_unknown,
+    for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown,
                       &c->d_state, &c->d_dict, &c->d_arena})
         b->release();
     for (void* hp : c->host_blocks) (void)hipHostFree(hp);
+    for (hipEvent_t ev : c->copy_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (DevBuf& b : c->rank_tab) b.release();
@@ -1749,7 +1759,7 @@ static int dtok_mirror_dict(wk_ctx* c, const wk_tok* tok) {
 
 static DtokArgs dtok_args(wk_ctx* c) {
     DtokArgs a{};
-    a.text = c->d_text.as<unsigned char>();
+    a.text = c->d_textbuf[c->dt_cur].as<unsigned char>();
     a.n = c->dt_n;
     a.line_start = c->d_lines.as<uint32_t>();
     a.n_lines = c->dt_lines;
@@ -1761,8 +1771,33 @@ static DtokArgs dtok_args(wk_ctx* c) {
     a.unknown = c->d_unknown.as<uint2>();
     a.unknown_cap = (uint32_t)(c->d_unknown.cap / 8);
     a.is_start = c->d_start.as<unsigned char>();
+    a.is_first = c->d_first.as<unsigned char>();
     a.state = c->d_state.as<DtokState>();
     return a;
+}
+
+// Start copying text[begin, stop) of a block to the device on the copy stream;
+// the wk_dtok_scan of the same block finds it there.  At most one block ahead of
+// the one being scanned (two buffers).
+int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
+    if (!c || !text || begin < 0 || stop < begin) return WK_E_ARG;
+    const int64_t n64 = stop - begin;
+    if (n64 == 0 || n64 >= (1ll << 31) - 64) return WK_OK;
+    DeviceGuard guard(c->device);
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t& ev : c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int k = c->copy_next;
+    c->copy_next ^= 1;
+    const uint32_t n = (uint32_t)n64;
+    HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
+    HIP_TRY(c, hipMemcpyAsync(c->d_textbuf[k].p, text + begin, n, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->copy_stream));
+    c->copy_src[k] = text + begin;
+    c->copy_n[k] = n;
+    return WK_OK;
 }
 
 int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int64_t* n_lines, int* status) {
@@ -1783,9 +1818,22 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
         return WK_OK;
     }
     const char* src = text + begin;
-    HIP_TRY(c, c->d_text.reserve((size_t)n + 64));
-    HIP_TRY(c, hipMemcpyAsync(c->d_text.p, src, n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_text.as<unsigned char>() + n, 0, 64, c->stream));
+    // the block's text: copied ahead by wk_dtok_copy (then the kernels only wait
+    // for that copy), or copied now
+    int k = -1;
+    for (int q = 0; q < 2; ++q)
+        if (c->copy_src[q] == src && c->copy_n[q] == n) k = q;
+    if (k >= 0) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));
+    } else {
+        k = c->copy_next;
+        c->copy_next ^= 1;
+        HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
+        HIP_TRY(c, hipMemcpyAsync(c->d_textbuf[k].p, src, n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
+    }
+    c->copy_src[k] = nullptr;  // (the buffer's tag is used up)
+    c->dt_cur = k;
     // line starts: newlines per tile -> offsets -> positions
     const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
     HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
@@ -1793,7 +1841,7 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
     HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
     KernelTimer* kt = ktimer_begin(c, "dtok_lines");
-    hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_text.as<unsigned char>(), n,
+    hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
                        c->d_tiles.as<unsigned long long>());
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
                        c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
@@ -1806,9 +1854,10 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     HIP_TRY(c, c->d_lsubj.reserve(((size_t)lines + 1) * 4));
     HIP_TRY(c, c->d_lmeta.reserve(((size_t)lines + 1) * 4));
     HIP_TRY(c, c->d_start.reserve((size_t)lines + 64));
+    HIP_TRY(c, c->d_first.reserve((size_t)lines + 64));
     if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
     HIP_TRY(c, hipMemsetAsync(c->d_lines.p, 0, 4, c->stream));  // line 0 starts at 0
-    hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_text.as<unsigned char>(), n,
+    hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
                        c->d_tile_off.as<unsigned long long>(), c->d_lines.as<uint32_t>());
     if (open_end) {
         const uint32_t end = n + 1;  // as if a newline followed the text
@@ -1867,6 +1916,7 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     const dim3 grid((c->dt_lines + kDtokThreads - 1) / kDtokThreads);
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+    hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
