@@ -818,13 +818,17 @@ class Engine:
                     buf = np.empty(need, dtype=np.uint8)
                 view = memoryview(buf).cast('B')
                 view[:len(carry)] = carry
+                t0 = time.perf_counter()
                 got = rd.read_into(fd, pos, view[len(carry):need]) \
                     if want else 0
+                lap['read'] += time.perf_counter() - t0
                 fill = len(carry) + got
                 pos += got
                 final = pos >= size or (want and not got)
+                t0 = time.perf_counter()
                 ok, begin, stop, hdr = nat.Tokenizer.sam_span(
                     view[:fill], final, in_header)
+                lap['span'] += time.perf_counter() - t0
                 if not ok and not final:    # no complete run yet: read more
                     carry = bytes(view[:fill])
                     span *= 2
@@ -842,10 +846,18 @@ class Engine:
                 if final:
                     return
 
+        import time
+        lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0, 'read': 0.0,
+               'span': 0.0, 'blocks': 0}
+        timing = bool(os.environ.get('WOLTKA_DTOK_TIMING'))
+
         def one(item):
             slot, buf, fill, begin, stop, first, final, hdr_in, hdr = item
             try:
+                t0 = time.perf_counter()
                 status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop)
+                lap['scan'] += time.perf_counter() - t0
+                lap['blocks'] += 1
                 fresh = tok.new_subjects()
                 if fresh:
                     base = self._tok_map.size
@@ -870,14 +882,30 @@ class Engine:
         # the copy of a block's text to the device starts one block ahead:
         # it overlaps the kernels of the block before
         prev = None
-        for item in _prefetch(blocks()):
+        t_all = time.perf_counter()
+        it = _prefetch(blocks())
+        while True:
+            t0 = time.perf_counter()
+            item = next(it, None)
+            lap['wait'] += time.perf_counter() - t0
+            if item is None:
+                break
             if item[0] is not None:         # (pinned: an asynchronous copy)
+                t0 = time.perf_counter()
                 self.ctx.dtok_copy(item[1], item[3], item[4])
+                lap['copy'] += time.perf_counter() - t0
             if prev is not None:
                 yield from one(prev)
             prev = item
         if prev is not None:
             yield from one(prev)
+        if timing:
+            import sys
+            tot = time.perf_counter() - t_all
+            print('[dtok] %d blocks, %.3f s: waiting for text %.3f, copy calls '
+                  '%.3f, scan calls %.3f; reader: pread %.3f, span %.3f'
+                  % (lap['blocks'], tot, lap['wait'], lap['copy'], lap['scan'],
+                     lap['read'], lap['span']), file=sys.stderr)
 
     def _host_block(self, buf, fill, first, final, hdr_in):
         """One block of the device route through the host tokenizer after
