@@ -292,9 +292,21 @@ int wk_words_pending(wk_ctx* ctx, int64_t* n_records, int64_t* n_reads);
  * i + 1 overlaps the kernels of block i.  One block ahead at most. */
 int wk_dtok_copy(wk_ctx* ctx, const char* text, int64_t begin, int64_t stop);
 int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
-                 int64_t stop, int64_t* n_lines, int* status);
+                 int64_t stop, int extra, int64_t* n_lines, int* status);
 int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
                  int* status);
+/* `extra` != 0 — the "ex" flavour (align.parse_sam_file_ex + ordinal_mapper,
+ * align.py:350-406, ordinal.py:167-240): wk_dtok_scan also takes POS and CIGAR
+ * (start, end, aligned length per line; text beyond [+-]digits and
+ * (digits op)+ goes back to the host: status 1), and wk_dtok_stage_hits
+ * leaves the block's hits staged exactly as wk_ordinal_stage would have: hits
+ * of zero length dropped, the hits of a read (query, mate) contiguous, reads in
+ * the order the parser yields them; genome_of_subject[id] = index into the
+ * gene tables for tokenizer subject id (-1: none).  wk_ordinal_count /
+ * wk_ordinal_match follow. */
+int wk_dtok_stage_hits(wk_ctx* ctx, const int32_t* genome_of_subject,
+                       int32_t n_subjects, double th, int64_t* n_reads,
+                       int64_t* n_hits, int* status);
 
 /* Convenience: stage + classify in one call from host buffers. */
 int wk_classify_chunk(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,

@@ -147,3 +147,116 @@ def test_device_tokenizer_at_size(tmp_path):
     assert calls and all(st == 0 for st, _, _ in calls)
     assert sum(r for _, r, _ in calls) == 250_000
     assert sum(n for _, _, n in calls) == int(p['qoff'][250_000])
+
+
+def _random_coords_sam(rng, n_queries, n_genomes=40, weird=False):
+    """A gene coordinates file and a paired SAM with coordinates on its
+    genomes (+ genomes without genes, clipped / deleted / zero-length CIGARs,
+    secondary hits that interleave the mates of a pair)."""
+    coords, lens = [], {}
+    for g in range(n_genomes):
+        name = f'G{g:03d}'
+        n = rng.randrange(1, 30)
+        pos, lines = 1, []
+        for k in range(n):
+            a = pos + rng.randrange(0, 60)
+            b = a + rng.randrange(30, 400)
+            lines.append(f'{name}_{k}\t{a}\t{b}' if rng.random() < 0.5
+                         else f'{name}_{k}\t{b}\t{a}')
+            pos = b - rng.randrange(0, 50)
+        coords.append(f'>{name}\n' + '\n'.join(lines) + '\n')
+        lens[name] = pos + 200
+    sam = ['@HD\tVN:1.0']
+    cigars = ['100M', '50M', '30M2D30M', '10S80M', '40M5I40M', '20M100N20M',
+              '90=10X', '25S', '75M25H']
+    if weird:
+        cigars += ['*']
+    for q in range(n_queries):
+        g = rng.choice(list(lens) + ['Gnone'])
+        p = rng.randrange(1, lens.get(g, 500))
+        hits = [(99, g, p), (147, g, p + rng.randrange(0, 150))]
+        for _ in range(rng.choice([0, 0, 0, 1, 2])):   # secondary alignments
+            g2 = rng.choice(list(lens))
+            hits.insert(rng.randrange(len(hits) + 1),
+                        (rng.choice([355, 403]), g2,
+                         rng.randrange(1, lens[g2])))
+        for flag, gg, pp in hits:
+            sam.append(f'pair{q}\t{flag}\t{gg}\t{pp}\t42\t{rng.choice(cigars)}'
+                       '\t=\t1\t0\t*\t*')
+    return ''.join(coords), '\n'.join(sam) + '\n'
+
+
+@pytest.mark.parametrize('block', [1 << 26, 1 << 15])
+@pytest.mark.parametrize('weird', [False, True])
+def test_device_tokenizer_coord_match_equals_host(tmp_path, monkeypatch,
+                                                  block, weird):
+    """--coords through the "ex" flavour of the device tokenizer vs the host
+    tokenizer; `weird` adds '*' CIGARs (their blocks go back to the host)."""
+    from woltka_amd import classify as C
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    rng = random.Random(block + weird)
+    coords, sam = _random_coords_sam(rng, 3000, weird=weird)
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    (indir / 'S1.sam').write_text(sam)
+    (indir / 'S2.sam').write_text(sam[:len(sam) // 3].rsplit('\n', 1)[0] + '\n')
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    for overlap in (80, 50):
+        kw = dict(input_fp=str(indir), input_fmt='sam', coords_fp=str(cfp),
+                  overlap=overlap)
+        a, log_a = _run(tmp_path, f'd{overlap}', False, **kw)
+        b, log_b = _run(tmp_path, f'h{overlap}', True, **kw)
+        assert a == b and log_a == log_b
+        assert len(a['table']) > 500
+
+
+def test_device_ex_really_runs(tmp_path):
+    """The coord-match run above must have gone through wk_dtok_stage_hits."""
+    from woltka_amd import _native as nat
+    rng = random.Random(9)
+    coords, sam = _random_coords_sam(rng, 2000)
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    (indir / 'S1.sam').write_text(sam)
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    calls = []
+    orig = nat.Context.dtok_stage_hits
+
+    def spy(self, *a):
+        res = orig(self, *a)
+        calls.append(res)
+        return res
+    nat.Context.dtok_stage_hits = spy
+    try:
+        a, _ = _run(tmp_path, 'd', False, input_fp=str(indir),
+                    input_fmt='sam', coords_fp=str(cfp))
+    finally:
+        nat.Context.dtok_stage_hits = orig
+    assert calls and all(st == 0 for st, _, _ in calls)
+    assert sum(h for _, _, h in calls) > 3000
+
+
+@pytest.mark.parametrize('bad', ['pairX\t99\tG001\tabc\t42\t50M\t=\t1\t0\t*\t*',
+                                 'pairX\t99\tG001\t5\t42\t5Q0M\t=\t1\t0\t*\t*',
+                                 'pairX\t99\tG001\t5\t42\tM\t=\t1\t0\t*\t*'])
+def test_device_ex_malformed_numbers_raise_like_the_host(tmp_path, bad):
+    rng = random.Random(4)
+    coords, sam = _random_coords_sam(rng, 300)
+    lines = sam.split('\n')
+    lines.insert(len(lines) // 2, bad)
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    (indir / 'S1.sam').write_text('\n'.join(lines))
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    kw = dict(input_fp=str(indir), input_fmt='sam', coords_fp=str(cfp))
+    errs = []
+    for host in (False, True):
+        try:
+            _run(tmp_path, f'e{host}', host, **kw)
+            errs.append(None)
+        except Exception as e:      # noqa: BLE001
+            errs.append((type(e), str(e)))
+    assert errs[0] == errs[1] and errs[0] is not None

@@ -49,7 +49,7 @@ SYMBOLS = (
     'wk_tok_boundary',
     'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
     'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_set_header_state',
-    'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit',
+    'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
@@ -167,7 +167,9 @@ def load_library():
         'wk_tok_set_header_state': (C.c_int, [p, C.c_int]),
         'wk_dtok_copy': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64]),
         'wk_dtok_scan': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
-                                   i64p, C.POINTER(C.c_int)]),
+                                   C.c_int, i64p, C.POINTER(C.c_int)]),
+        'wk_dtok_stage_hits': (C.c_int, [p, i32p, C.c_int32, C.c_double, i64p,
+                                         i64p, C.POINTER(C.c_int)]),
         'wk_dtok_emit': (C.c_int, [p, i64p, i64p, C.POINTER(C.c_int)]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
@@ -480,7 +482,17 @@ class Context:
             self._check(self._lib.wk_dtok_copy(
                 self._h, C.c_void_p(raw.ctypes.data), int(begin), int(stop)))
 
-    def dtok_scan(self, tok, buf, begin, stop):
+    def dtok_stage_hits(self, genome_of_subject, th):
+        """The scanned block's hits ("ex" flavour) as the staged coord-match
+        chunk.  Returns (status, reads, hits)."""
+        g = _arr(genome_of_subject, np.int32)
+        a, b, st = C.c_int64(0), C.c_int64(0), C.c_int(1)
+        self._check(self._lib.wk_dtok_stage_hits(
+            self._h, _ptr(g, C.c_int32), g.size, float(th), C.byref(a),
+            C.byref(b), C.byref(st)))
+        return st.value, a.value, b.value
+
+    def dtok_scan(self, tok, buf, begin, stop, extra=False):
         """Copy and parse ``buf[begin:stop]`` (whole lines ending at a run
         boundary: ``Tokenizer.sam_span``) on the device.  Returns (status,
         n_lines): status 0 = parsed (new subjects are in ``tok``), 1 = the
@@ -490,7 +502,8 @@ class Context:
         addr = C.c_void_p(raw.ctypes.data) if raw.size \
             else C.cast(C.c_char_p(b''), C.c_void_p)
         self._check(self._lib.wk_dtok_scan(self._h, tok._h, addr, int(begin),
-                                           int(stop), C.byref(n), C.byref(st)))
+                                           int(stop), int(bool(extra)),
+                                           C.byref(n), C.byref(st)))
         return st.value, n.value
 
     def dtok_emit(self):

@@ -423,13 +423,17 @@ class Engine:
         if self.tok is None:
             self.tok = nat.Tokenizer(tokenizer_threads(), exclude)
         tok = self.tok
-        if words and fmt == 'sam' and not exclude and part is None and \
-                not os.environ.get('WOLTKA_NO_DTOK'):
+        device_ex = ordinal and cover is None and not want_names and \
+            not want_groups and not want_samples and \
+            len(self.jobs) <= nat.MAX_JOBS
+        if (words or device_ex) and fmt == 'sam' and not exclude and \
+                part is None and not os.environ.get('WOLTKA_NO_DTOK'):
             from .align import _parallel_reader
             reader = _parallel_reader(stream, tok, None)
             if reader is not None:
                 # the text goes to the GPU as it is: tokenised there
-                yield from self._device_chunks(reader, block_bytes)
+                yield from self._device_chunks(reader, block_bytes,
+                                               ordinal=bool(ordinal))
                 return
         ring = None
         if words:
@@ -672,6 +676,8 @@ class Engine:
         if packed is not None and isinstance(packed[0], str):
             if packed[0] == 'dtok':
                 return self._run_dtok(data, packed, sample_of)
+            if packed[0] == 'dhits':
+                return self._run_dhits(data, packed, sample_of)
             return self._run_words(data, packed, sample_of)
         n = len(reads) if packed is None else packed[-1].size - 1
         # room for the (sample, stratum) groups this chunk can add
@@ -779,7 +785,7 @@ class Engine:
 
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
 
-    def _device_chunks(self, reader, host_block):
+    def _device_chunks(self, reader, host_block, ordinal=False):
         """A SAM file through the tokenizer on the device (csrc/wk_dtok.hpp):
         a helper thread reads blocks into pinned buffers (pread by its own
         threads) and cuts them where the last run of equal query ids starts;
@@ -855,10 +861,28 @@ class Engine:
             slot, buf, fill, begin, stop, first, final, hdr_in, hdr = item
             try:
                 t0 = time.perf_counter()
-                status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop)
+                status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop,
+                                                     extra=ordinal)
                 lap['scan'] += time.perf_counter() - t0
                 lap['blocks'] += 1
                 fresh = tok.new_subjects()
+                if ordinal:
+                    if fresh:       # genome indices of the gene tables
+                        gidx = self.genes.genome_index.get
+                        self._tok_genome = np.concatenate([
+                            self._tok_genome,
+                            np.fromiter((gidx(x, -1) for x in fresh),
+                                        np.int32, len(fresh))])
+                    if status == 0:
+                        if n_lines:
+                            yield None, ('dhits', (buf, fill, first, final,
+                                                   hdr_in, hdr)), \
+                                None, None, None, None
+                        tok.set_header_state(hdr)
+                    else:
+                        yield from self._host_block(buf, fill, first, final,
+                                                    hdr_in, True)
+                    return
                 if fresh:
                     base = self._tok_map.size
                     ids = np.fromiter(map(self.subjects.intern, fresh),
@@ -907,11 +931,30 @@ class Engine:
                   % (lap['blocks'], tot, lap['wait'], lap['copy'], lap['scan'],
                      lap['read'], lap['span']), file=sys.stderr)
 
-    def _host_block(self, buf, fill, first, final, hdr_in):
+    def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False):
         """One block of the device route through the host tokenizer after
         all (the general arrays)."""
         tok = self.tok
         tok.set_header_state(hdr_in)
+        if ordinal:
+            tok.set_subject_map(self._tok_genome)
+            res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
+                            final=final, extra=True, fmt='sam')
+            fresh = tok.new_subjects()
+            if fresh:       # (names met for the first time in this block:
+                gidx = self.genes.genome_index.get      # map them, once more)
+                self._tok_genome = np.concatenate([
+                    self._tok_genome,
+                    np.fromiter((gidx(x, -1) for x in fresh), np.int32,
+                                len(fresh))])
+                tok.set_subject_map(self._tok_genome)
+                tok.set_header_state(hdr_in)
+                res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
+                                final=final, extra=True, fmt='sam')
+            if res['off'].size > 1:
+                yield None, (res['subj'], res['beg'], res['end'], res['len'],
+                             res['off']), None, None, None, None
+            return
         res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
                         final=final, fmt='sam')
         fresh = tok.new_subjects()
@@ -923,6 +966,33 @@ class Engine:
             subj = res['subj'] if self._tok_identity \
                 else self._tok_map[res['subj']]
             yield None, (subj, res['off']), None, None, None, None
+
+    def _run_dhits(self, data, packed, sample):
+        """A block the device has scanned for the coord-match: its hits are
+        staged on the device (`wk_dtok_stage_hits`) and matched + counted like
+        a chunk of `wk_ordinal_stage`."""
+        buf, fill, first, final, hdr_in, hdr = packed[1]
+        self._ensure_table(data, 4 * (fill // 24 + 1), 1)
+        group = self._group_array(1, sample, None)
+        for rank in self.ranks:
+            data[rank].setdefault(sample, {})
+        if self._deferred_from is None:
+            self._deferred_from = self.ctx.stats()['n_reads']
+        status, n_reads, _ = self.ctx.dtok_stage_hits(self._tok_genome,
+                                                      self._th)
+        if status == 0:
+            self._n_reads += n_reads
+            if n_reads:
+                self.ctx.set_uniform_group(group)
+                self.ctx.ordinal_count(self.jobs)
+            return 0
+        n = 0
+        for _, arrays, *_ in self._host_block(buf, fill, first, final, hdr_in,
+                                              True):
+            n += self.run_chunk(data, None, None, sample, None, None, None,
+                                None, None, True, packed=arrays)
+        self.tok.set_header_state(hdr)
+        return n
 
     def _run_dtok(self, data, packed, sample):
         """A block the device has scanned: register the subjects it brought,

@@ -76,7 +76,21 @@ struct DtokArgs {
     DtokState* state;
     uint32_t* out;      // packed records
     uint32_t out_cap;
+    // "ex" flavour (coord-match): per line POS - 1, reference end, aligned length
+    int32_t* lbeg;
+    int32_t* lend;
+    uint32_t* llen;
+    unsigned long long* line_scan;  // [n_lines] exclusive prefix of (hits | leaders << 32) over the lines
+    const int32_t* gmap;            // subject id -> genome index of the gene tables (-1: no genes)
+    uint32_t n_gmap;
+    int32_t* o_genome;              // the staged hits (wk_ordinal_stage's arrays) ...
+    int32_t* o_beg;
+    int32_t* o_end;
+    uint32_t* o_len;
+    int32_t* o_hoff;                // ... and the reads' offsets
 };
+
+constexpr uint32_t kDtokBadNumber = 32;  // POS / CIGAR text the kernels leave to the host's Python-exact parsers
 
 __device__ __forceinline__ uint32_t count_newlines16(const uint4 v) {
     auto cnt = [](uint32_t w) {
@@ -157,7 +171,9 @@ __device__ __forceinline__ unsigned long long dtok_hash(const unsigned char* p, 
     return h ^ (h >> 32);
 }
 
-// a thread per line: QNAME / FLAG / RNAME, mate, subject id
+// a thread per line: QNAME / FLAG / RNAME, mate, subject id; kEx: also POS and
+// CIGAR -> start, end, aligned length (align.py:376-398, 572-583)
+template <bool kEx>
 __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_lines) return;
@@ -165,12 +181,13 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
     uint32_t hi = a.line_start[i + 1];  // behind the line's newline (or n + 1 for a last line without one)
     hi = hi > lo ? hi - 1u : lo;        // the newline itself / the end of the text
     if (hi > a.n) hi = a.n;
-    // the first three tabs
-    uint32_t tab[3];
+    // the first three (six) tabs
+    constexpr int kTabs = kEx ? 6 : 3;
+    uint32_t tab[kTabs];
     int nt = 0;
-    for (uint32_t p = lo; p < hi && nt < 3; ++p)
+    for (uint32_t p = lo; p < hi && nt < kTabs; ++p)
         if (a.text[p] == '\t') tab[nt++] = p;
-    if (nt < 3) {  // not `qname, flag, rname, _ = line.split('\t', 3)` (align.py:313)
+    if (nt < kTabs) {  // not `qname, flag, rname, _ = line.split('\t', 3)` (align.py:313; 6 for the "ex" parser)
         a.lsubj[i] = kLineBad;
         a.lmeta[i] = 0;
         atomicOr(&a.state->flags, kDtokShortLine);
@@ -225,6 +242,150 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
             a.unknown[at] = make_uint2(rb, rn);
         else
             atomicOr(&a.state->flags, kDtokUnknownFull);
+    }
+    if constexpr (kEx) {
+        // POS: [+-]digits (anything else int() may or may not accept: the host decides)
+        uint32_t p = tab[2] + 1u;
+        const uint32_t pe = tab[3];
+        bool neg = false, ok = true;
+        if (p < pe && (a.text[p] == '-' || a.text[p] == '+')) neg = a.text[p++] == '-';
+        ok = p < pe && pe - p <= 10u;
+        long long pos = 0;
+        for (; ok && p < pe; ++p) {
+            const uint32_t d = (uint32_t)a.text[p] - (uint32_t)'0';
+            ok = d <= 9u;
+            pos = pos * 10 + (long long)d;
+        }
+        if (neg) pos = -pos;
+        // CIGAR: (digits op)+, ops M = X (aligned), D N (reference only), I S H P (neither)
+        unsigned long long aligned = 0, extra = 0, num = 0;
+        bool have = false;
+        for (uint32_t q = tab[4] + 1u; ok && q < tab[5]; ++q) {
+            const unsigned char ch = a.text[q];
+            if (ch >= '0' && ch <= '9') {
+                num = num * 10ull + (unsigned long long)(ch - '0');
+                have = true;
+                ok = num < (1ull << 40);
+            } else if (ch == 'M' || ch == '=' || ch == 'X') {
+                ok = have;
+                aligned += num;
+                num = 0;
+                have = false;
+            } else if (ch == 'D' || ch == 'N') {
+                ok = have;
+                extra += num;
+                num = 0;
+                have = false;
+            } else if (ch == 'I' || ch == 'S' || ch == 'H' || ch == 'P') {
+                num = 0;
+                have = false;
+            } else {
+                ok = false;
+            }
+        }
+        ok = ok && !have;  // (digits without an operation: the host's parser has its own opinion)
+        const long long beg = pos - 1, end = pos - 1 + (long long)(aligned + extra);
+        ok = ok && beg >= -2147483647ll && end <= 2147483647ll && aligned < (1ull << 32);
+        if (!ok) {
+            atomicOr(&a.state->flags, kDtokBadNumber);
+            return;
+        }
+        a.lbeg[i] = (int32_t)beg;
+        a.lend[i] = (int32_t)end;
+        a.llen[i] = (uint32_t)aligned;
+    }
+}
+
+// ---- "ex" flavour: the lines' hits as the staged chunk of the coord-match --------
+// A hit = a mapped line of aligned length > 0 (ordinal.py:231).  The hits of a
+// read — run of equal QNAME, mate — are contiguous in the output, reads ordered
+// by (run, mate), hits in text order: what ordinal_mapper builds (ordinal.py:
+// 219-237 over parse_sam_file_ex's pools).  Hits only move inside their run, so
+// a hit's place = hits before its run + hits of lower mates in the run + earlier
+// hits of its own read; a read's index likewise from its first hit.
+
+// is the line a hit / the first hit of its read?  -> tile totals for the scan
+__global__ void __launch_bounds__(kDtokThreads) dtok_hits_kernel(DtokArgs a, unsigned long long* __restrict__ tile_count) {
+    __shared__ unsigned long long wsum[kDtokThreads / kWave];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < a.n_lines && a.lsubj[i] >= 0 && a.llen[i] > 0u) {
+        const uint32_t m = a.lmeta[i] >> 28;
+        bool leader = true;
+        if (!a.is_start[i]) {
+            uint32_t j = i;
+            do {
+                --j;
+                if (a.lsubj[j] >= 0 && a.llen[j] > 0u && (a.lmeta[j] >> 28) == m) {
+                    leader = false;
+                    break;
+                }
+            } while (!a.is_start[j]);
+        }
+        v = 1ull | (leader ? 1ull << 32 : 0ull);
+    }
+    if (i < a.n_lines) a.line_scan[i] = v;  // (replaced by its exclusive prefix in dtok_scan_lines_kernel)
+    const unsigned long long s = wave_sum(v);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (uint32_t w = 0; w < kDtokThreads / kWave; ++w) t += wsum[w];
+        tile_count[blockIdx.x] = t;
+    }
+}
+
+// line_scan[i] (flags) -> exclusive prefix over all lines; is_first[i] keeps the flags (bit 0 hit, bit 1 leader)
+__global__ void __launch_bounds__(kDtokThreads) dtok_scan_lines_kernel(DtokArgs a, const unsigned long long* __restrict__ tile_off) {
+    __shared__ unsigned long long scan[kDtokThreads];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long v = i < a.n_lines ? a.line_scan[i] : 0ull;
+    scan[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < kDtokThreads; d <<= 1) {
+        const unsigned long long u = threadIdx.x >= d ? scan[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        scan[threadIdx.x] += u;
+        __syncthreads();
+    }
+    if (i < a.n_lines) {
+        a.line_scan[i] = tile_off[blockIdx.x] + scan[threadIdx.x] - v;
+        a.is_first[i] = (unsigned char)((v & 1ull) | ((v >> 32) << 1));
+    }
+}
+
+__global__ void __launch_bounds__(kDtokThreads) dtok_place_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines || !(a.is_first[i] & 1u)) return;
+    const uint32_t m = a.lmeta[i] >> 28;
+    // the run: back to its start, forward to its end
+    uint32_t s = i, before = 0, mine = 0, groups_before = 0;
+    bool seen[3] = {false, false, false};
+    while (!a.is_start[s]) {
+        --s;
+        if (a.is_first[s] & 1u) {
+            const uint32_t q = a.lmeta[s] >> 28;
+            before += q < m ? 1u : 0u;
+            mine += q == m ? 1u : 0u;
+            if (q < 3u) seen[q] = true;
+        }
+    }
+    for (uint32_t j = i + 1u; j < a.n_lines && !a.is_start[j]; ++j)
+        if (a.is_first[j] & 1u) {
+            const uint32_t q = a.lmeta[j] >> 28;
+            before += q < m ? 1u : 0u;
+            if (q < 3u) seen[q] = true;
+        }
+    const unsigned long long base = a.line_scan[s];  // hits / reads before the run
+    const uint32_t at = (uint32_t)base + before + mine;
+    const int32_t sid = a.lsubj[i];
+    a.o_genome[at] = (uint32_t)sid < a.n_gmap ? a.gmap[sid] : -1;
+    a.o_beg[at] = a.lbeg[i];
+    a.o_end[at] = a.lend[i];
+    a.o_len[at] = a.llen[i];
+    if (a.is_first[i] & 2u) {  // the read's first hit: its offset
+        for (uint32_t q = 0; q < m && q < 3u; ++q) groups_before += seen[q] ? 1u : 0u;
+        a.o_hoff[(uint32_t)(base >> 32) + groups_before] = (int32_t)at;
     }
 }
 

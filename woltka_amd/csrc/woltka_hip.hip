@@ -186,6 +186,8 @@ struct wk_ctx {
     std::vector<void*> host_blocks;      // wk_host_alloc
     // device tokenizer (wk_dtok.hpp): the block scanned last and the dictionary mirror
     DevBuf d_textbuf[2], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
+    DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
+    bool dt_extra = false;
     uint32_t dt_n = 0, dt_lines = 0, dt_dict_mask = 0;
     int32_t dt_dict_names = -1;  // names of the tokenizer the mirror holds
     const wk_tok* dt_dict_tok = nullptr;
@@ -570,7 +572,7 @@ void wk_destroy(wk_ctx* c) {
                       &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     c->c_words.release();
-    for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown,
+    for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
                       &c->d_state, &c->d_dict, &c->d_arena})
         b->release();
     for (void* hp : c->host_blocks) (void)hipHostFree(hp);
@@ -1773,6 +1775,10 @@ static DtokArgs dtok_args(wk_ctx* c) {
     a.is_start = c->d_start.as<unsigned char>();
     a.is_first = c->d_first.as<unsigned char>();
     a.state = c->d_state.as<DtokState>();
+    a.lbeg = c->d_lbeg.as<int32_t>();
+    a.lend = c->d_lend.as<int32_t>();
+    a.llen = c->d_llen.as<uint32_t>();
+    a.line_scan = c->d_lscan.as<unsigned long long>();
     return a;
 }
 
@@ -1800,11 +1806,12 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     return WK_OK;
 }
 
-int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int64_t* n_lines, int* status) {
+int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int extra, int64_t* n_lines, int* status) {
     if (!c || !tok || !text || begin < 0 || stop < begin || !n_lines || !status) return WK_E_ARG;
     *status = 1;
     *n_lines = 0;
     c->dt_ready = false;
+    c->dt_extra = extra != 0;
     if (!wkx_tok_device_ok(tok)) return WK_OK;  // an exclusion set: the host tokenizer's business
     const int64_t n64 = stop - begin;
     if (n64 >= (1ll << 31) - 64) return WK_OK;
@@ -1855,6 +1862,12 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     HIP_TRY(c, c->d_lmeta.reserve(((size_t)lines + 1) * 4));
     HIP_TRY(c, c->d_start.reserve((size_t)lines + 64));
     HIP_TRY(c, c->d_first.reserve((size_t)lines + 64));
+    if (extra) {
+        HIP_TRY(c, c->d_lbeg.reserve(((size_t)lines + 1) * 4));
+        HIP_TRY(c, c->d_lend.reserve(((size_t)lines + 1) * 4));
+        HIP_TRY(c, c->d_llen.reserve(((size_t)lines + 1) * 4));
+        HIP_TRY(c, c->d_lscan.reserve(((size_t)lines + 1) * 8));
+    }
     if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
     HIP_TRY(c, hipMemsetAsync(c->d_lines.p, 0, 4, c->stream));  // line 0 starts at 0
     hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
@@ -1873,7 +1886,10 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
         HIP_TRY(c, hipMemsetAsync(c->d_state.p, 0, sizeof(DtokState), c->stream));
         const DtokArgs a = dtok_args(c);
         kt = ktimer_begin(c, "dtok_parse");
-        hipLaunchKernelGGL(dtok_parse_kernel, dim3((lines + kDtokThreads - 1) / kDtokThreads), dim3(kDtokThreads), 0, c->stream, a);
+        if (extra)
+            hipLaunchKernelGGL(dtok_parse_kernel<true>, dim3((lines + kDtokThreads - 1) / kDtokThreads), dim3(kDtokThreads), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(dtok_parse_kernel<false>, dim3((lines + kDtokThreads - 1) / kDtokThreads), dim3(kDtokThreads), 0, c->stream, a);
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
         DtokState st{};
@@ -1899,7 +1915,7 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     if (!c || !n_reads || !n_records || !status) return WK_E_ARG;
     *status = 1;
     *n_reads = *n_records = 0;
-    if (!c->dt_ready) return fail(c, WK_E_STATE, "no block scanned (wk_dtok_scan)");
+    if (!c->dt_ready || c->dt_extra) return fail(c, WK_E_STATE, "no block scanned for the plain flavour (wk_dtok_scan)");
     if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
     c->dt_ready = false;
     if (c->dt_lines == 0) {
@@ -1928,6 +1944,70 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     c->w_reads += (int64_t)st.n_reads;
     *n_reads = (int64_t)st.n_reads;
     *n_records = (int64_t)st.n_out;
+    *status = 0;
+    return WK_OK;
+}
+
+// The scanned block's hits ("ex" flavour) as the staged chunk of the coord-match:
+// what wk_ordinal_stage would have been given.
+int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_subjects, double th, int64_t* n_reads,
+                       int64_t* n_hits, int* status) {
+    if (!c || !n_reads || !n_hits || !status || n_subjects < 0 || (n_subjects > 0 && !genome_of_subject)) return WK_E_ARG;
+    *status = 1;
+    *n_reads = *n_hits = 0;
+    if (!c->dt_ready || !c->dt_extra) return fail(c, WK_E_STATE, "no block scanned for the \"ex\" flavour (wk_dtok_scan)");
+    if (!(th > 0.0)) return fail(c, WK_E_ARG, "overlap threshold must be positive");
+    c->dt_ready = false;
+    DeviceGuard guard(c->device);
+    const uint32_t lines = c->dt_lines;
+    int rc;
+    if ((rc = upload(c, c->d_gmap, genome_of_subject, (size_t)std::max(n_subjects, 1) * 4))) return rc;
+    HIP_TRY(c, c->o_genome.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->o_beg.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->o_end.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->o_len.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->o_hoff.reserve(((size_t)lines + 2) * 4));
+    unsigned long long totals = 0;
+    if (lines > 0) {
+        DtokArgs a = dtok_args(c);
+        a.gmap = c->d_gmap.as<int32_t>();
+        a.n_gmap = (uint32_t)n_subjects;
+        a.o_genome = c->o_genome.as<int32_t>();
+        a.o_beg = c->o_beg.as<int32_t>();
+        a.o_end = c->o_end.as<int32_t>();
+        a.o_len = c->o_len.as<uint32_t>();
+        a.o_hoff = c->o_hoff.as<int32_t>();
+        const uint32_t n_tiles = (lines + kDtokThreads - 1) / kDtokThreads;
+        HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+        const dim3 grid(n_tiles);
+        KernelTimer* kt = ktimer_begin(c, "dtok_emit");
+        hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        hipLaunchKernelGGL(dtok_hits_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tiles.as<unsigned long long>());
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
+                           c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+        hipLaunchKernelGGL(dtok_scan_lines_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tile_off.as<unsigned long long>());
+        hipLaunchKernelGGL(dtok_place_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    const int64_t hits = (int64_t)(totals & 0xFFFFFFFFull), reads = (int64_t)(totals >> 32);
+    const int32_t end = (int32_t)hits;
+    HIP_TRY(c, hipMemcpyAsync(c->o_hoff.as<int32_t>() + reads, &end, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_hits = hits;
+    c->o_reads = reads;
+    c->th = th;
+    c->has_group = false;
+    c->group_base = 0;
+    c->rk_valid[0] = c->rk_valid[1] = false;
+    c->ord_valid = true;
+    c->chunk_valid = false;
+    *n_reads = reads;
+    *n_hits = hits;
     *status = 0;
     return WK_OK;
 }
