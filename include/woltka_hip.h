@@ -351,6 +351,12 @@ int wk_ordinal_count(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs);
  * wk_chunk_stage). */
 int wk_set_uniform_group(wk_ctx* ctx, int32_t group);
 
+/* After wk_ordinal_match: poff[n_hits + 1], the offsets of every hit's genes in
+ * the gene lists wk_chunk_download returns (the genes of a read are the
+ * concatenation of its hits' genes) — which hit matched which gene
+ * (ordinal.flush_chunk's (read, gene) pairs, ordinal.py:321-332). */
+int wk_ordinal_hit_offsets(wk_ctx* ctx, int32_t* poff, int64_t cap);
+
 /* Download the staged classify chunk (testing / read-map output): the
  * candidate lists as currently staged (after wk_ordinal_match: gene feature
  * ids per read, duplicates possible when several hits of a read match the same
@@ -578,10 +584,12 @@ int wk_coords_parse(const char* buf, int64_t len, wk_coords** out);
 const char* wk_coords_error(const wk_coords* c);
 int wk_coords_sizes(const wk_coords* c, int32_t* n_genomes, int32_t* n_genes,
                     int64_t* genome_bytes, int64_t* gene_bytes, int* isdup);
-/* goff[n_genomes + 1], start0/end[n_genes], names as blob + off[n + 1]. */
+/* goff[n_genomes + 1], start0/end/findex[n_genes] (findex = the gene's place
+ * among its nucleotide's lines: the index in encode_genes' codes), names as
+ * blob + off[n + 1]. */
 int wk_coords_fetch(const wk_coords* c, int32_t* goff, int32_t* start0,
-                    int32_t* end, char* genome_blob, int64_t* genome_off,
-                    char* gene_blob, int64_t* gene_off);
+                    int32_t* end, int32_t* findex, char* genome_blob,
+                    int64_t* genome_off, char* gene_blob, int64_t* gene_off);
 void wk_coords_free(wk_coords* c);
 
 /* ---- measurement ------------------------------------------------------- */

@@ -788,8 +788,19 @@ def gen_cli_coords_excl(seed=59, n_cases=16):
     gen_cli_coords(seed, n_cases, with_exclude=True, name='cli_coords_excl.json')
 
 
+def gen_cli_coords_maps():
+    """`--coords` with `--outmap`: the read maps list the queries in the
+    order ordinal.flush_chunk's `res` dict met them (ordinal.py:290-335) —
+    genome by genome, within a genome in the order of the sweep's matches (more
+    than five hits of the chunk on the genome) or read by read (up to five) —
+    chunk by chunk (`--chunk` small, so that several chunks and both matchers
+    occur)."""
+    gen_cli_coords(seed=67, n_cases=16, with_maps=True,
+                   name='cli_coords_maps.json')
+
+
 def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
-                   name='cli_coords.json'):
+                   name='cli_coords.json', with_maps=False):
     """Coord-match (`--coords`) on random small inputs: reads placed over /
     next to genes of the bundled coordinates file, three formats with
     coordinates, random overlap thresholds, optional gene-length normalisation
@@ -817,7 +828,7 @@ def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
         files, kw = {}, {'output_fmt': False, 'coords_fp': '$FUN/coords.txt.xz'}
         for si in range(rng.randint(1, 3)):
             lines = ['@HD\tVN:1.0\n'] if fmt == 'sam' else []
-            for qi in range(rng.randint(15, 60)):
+            for qi in range(rng.randint(15, 60) * (4 if with_maps else 1)):
                 q = f'r{qi:04d}'
                 paired = fmt == 'sam' and rng.random() < 0.5
                 for h in range(rng.choice([1, 1, 2, 3])):
@@ -882,6 +893,11 @@ def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
             kw['unassigned'] = True
         if rng.random() < 0.3:
             kw['chunk'] = rng.choice([5, 40])
+        if with_maps:
+            kw['chunk'] = rng.choice([None, 7, 30, 90, 400])
+            if kw['chunk'] is None:
+                del kw['chunk']
+            kw.pop('sizes', None)
         with tempfile.TemporaryDirectory() as tmp:
             for rel, text in files.items():
                 os.makedirs(os.path.dirname(os.path.join(tmp, rel)),
@@ -899,7 +915,10 @@ def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
                 return v
             args = {k: real(v) for k, v in kw.items()}
             args['output_fp'] = os.path.join(tmp, 'out')
+            if with_maps:
+                args['outmap_dir'] = os.path.join(tmp, 'maps')
             import contextlib
+            import gzip
             import io
             with contextlib.redirect_stdout(io.StringIO()):
                 workflow(**args)
@@ -911,8 +930,18 @@ def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
             else:
                 with open(args['output_fp']) as f:
                     outs = {'out': f.read()}
-        cases.append(dict(files=files, kwargs=kw, want_maps=False,
-                          expect={'tables': outs}))
+            expect = {'tables': outs}
+            if with_maps:
+                maps = {}
+                for root, _, fns in os.walk(args['outmap_dir']):
+                    for fn in fns:
+                        rel = os.path.relpath(os.path.join(root, fn),
+                                              args['outmap_dir'])
+                        with gzip.open(os.path.join(root, fn), 'rt') as f:
+                            maps[rel] = f.read()
+                expect['maps'] = maps
+        cases.append(dict(files=files, kwargs=kw, want_maps=with_maps,
+                          expect=expect))
     dump(name, cases)
 
 
@@ -1619,6 +1648,7 @@ def main():
     gen_cli_random()
     gen_cli_coords()
     gen_cli_coords_excl()
+    gen_cli_coords_maps()
     gen_cli_strata()
     gen_cli_config5()
     gen_cli_medium()

@@ -39,7 +39,7 @@ SYMBOLS = (
     'wk_log_reserve', 'wk_log_fetch',
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
-    'wk_set_uniform_group', 'wk_chunk_download',
+    'wk_set_uniform_group', 'wk_chunk_download', 'wk_ordinal_hit_offsets',
     'wk_host_alloc', 'wk_host_free', 'wk_words_begin', 'wk_words_append',
     'wk_words_wait', 'wk_words_flush', 'wk_words_pending',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
@@ -124,6 +124,7 @@ def load_library():
         'wk_ordinal_match': (C.c_int, [p]),
         'wk_ordinal_count': (C.c_int, [p, C.POINTER(Job), C.c_int32]),
         'wk_set_uniform_group': (C.c_int, [p, C.c_int32]),
+        'wk_ordinal_hit_offsets': (C.c_int, [p, i32p, C.c_int64]),
         'wk_chunk_download': (C.c_int, [p, i32p, C.c_int64, i32p, C.c_int64,
                                         i64p, i64p]),
         'wk_host_alloc': (C.c_int, [p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -205,8 +206,8 @@ def load_library():
         'wk_coords_error': (C.c_char_p, [p]),
         'wk_coords_sizes': (C.c_int, [p, i32p, i32p, i64p, i64p,
                                       C.POINTER(C.c_int)]),
-        'wk_coords_fetch': (C.c_int, [p, i32p, i32p, i32p, C.c_void_p, i64p,
-                                      C.c_void_p, i64p]),
+        'wk_coords_fetch': (C.c_int, [p, i32p, i32p, i32p, i32p, C.c_void_p,
+                                      i64p, C.c_void_p, i64p]),
         'wk_coords_free': (None, [p]),
     }
     for name, (res, args) in proto.items():
@@ -515,6 +516,14 @@ class Context:
         self._check(self._lib.wk_dtok_emit(self._h, C.byref(a), C.byref(b),
                                            C.byref(st)))
         return st.value, a.value, b.value
+
+    def ordinal_hit_offsets(self, n_hits):
+        """Offsets of every hit's genes in the staged gene lists
+        (``chunk_download``): int32[n_hits + 1]."""
+        out = np.empty(n_hits + 1, dtype=np.int32)
+        self._check(self._lib.wk_ordinal_hit_offsets(
+            self._h, _ptr(out, C.c_int32), out.size))
+        return out
 
     def set_uniform_group(self, group):
         self._check(self._lib.wk_set_uniform_group(self._h, int(group)))
@@ -1132,15 +1141,16 @@ def parse_gene_coords(buf):
                             C.byref(nb), C.byref(dup))
         goff = np.empty(ng.value + 1, np.int32)
         start0, end = np.empty(nn.value, np.int32), np.empty(nn.value, np.int32)
+        findex = np.empty(nn.value, np.int32)
         gblob = C.create_string_buffer(max(1, gb.value))
         nblob = C.create_string_buffer(max(1, nb.value))
         g_off = np.empty(ng.value + 1, np.int64)
         n_off = np.empty(nn.value + 1, np.int64)
         lib.wk_coords_fetch(h, _ptr(goff, C.c_int32), _ptr(start0, C.c_int32),
-                            _ptr(end, C.c_int32), gblob, _ptr(g_off, C.c_int64),
-                            nblob, _ptr(n_off, C.c_int64))
+                            _ptr(end, C.c_int32), _ptr(findex, C.c_int32), gblob,
+                            _ptr(g_off, C.c_int64), nblob, _ptr(n_off, C.c_int64))
         return (goff, start0, end, _split(gblob.raw, g_off),
-                (nblob.raw[:nb.value], n_off), bool(dup.value))
+                (nblob.raw[:nb.value], n_off), bool(dup.value), findex)
     finally:
         if h:
             lib.wk_coords_free(h)

@@ -27,7 +27,7 @@ using wkh::hash_bytes;
 using wkh::NameTable;
 
 struct wk_coords {
-    std::vector<int32_t> goff, start0, end;
+    std::vector<int32_t> goff, start0, end, findex;  // findex: the gene's place in its nucleotide's lines (the index encode_genes puts into its codes, ordinal.py:459-465)
     std::string genome_blob, gene_blob;
     std::vector<int64_t> genome_off, gene_off;
     int isdup = 0;
@@ -155,6 +155,7 @@ int wk_coords_parse(const char* buf, int64_t len, wk_coords** out) {
                 return WK_E_ARG;
             }
             c->start0.push_back((int32_t)g.lo);
+            c->findex.push_back((int32_t)i);
             c->end.push_back((int32_t)g.hi);
             c->gene_blob.append(g.name, g.nlen);
             c->gene_off.push_back((int64_t)c->gene_blob.size());
@@ -179,12 +180,13 @@ int wk_coords_sizes(const wk_coords* c, int32_t* n_genomes, int32_t* n_genes, in
     return WK_OK;
 }
 
-int wk_coords_fetch(const wk_coords* c, int32_t* goff, int32_t* start0, int32_t* end, char* genome_blob, int64_t* genome_off,
-                    char* gene_blob, int64_t* gene_off) {
+int wk_coords_fetch(const wk_coords* c, int32_t* goff, int32_t* start0, int32_t* end, int32_t* findex, char* genome_blob,
+                    int64_t* genome_off, char* gene_blob, int64_t* gene_off) {
     if (!c) return WK_E_ARG;
     if (goff) memcpy(goff, c->goff.data(), c->goff.size() * 4);
     if (start0 && !c->start0.empty()) memcpy(start0, c->start0.data(), c->start0.size() * 4);
     if (end && !c->end.empty()) memcpy(end, c->end.data(), c->end.size() * 4);
+    if (findex && !c->findex.empty()) memcpy(findex, c->findex.data(), c->findex.size() * 4);
     if (genome_blob && !c->genome_blob.empty()) memcpy(genome_blob, c->genome_blob.data(), c->genome_blob.size());
     if (genome_off) memcpy(genome_off, c->genome_off.data(), c->genome_off.size() * 8);
     if (gene_blob && !c->gene_blob.empty()) memcpy(gene_blob, c->gene_blob.data(), c->gene_blob.size());

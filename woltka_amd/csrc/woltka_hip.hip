@@ -2161,6 +2161,17 @@ int wk_ordinal_match(wk_ctx* c) {
     return materialise_gene_lists(c);
 }
 
+int wk_ordinal_hit_offsets(wk_ctx* c, int32_t* poff, int64_t cap) {
+    if (!c || !poff) return WK_E_ARG;
+    if (!c->chunk_valid || c->cur_subj != c->o_pairs.as<int32_t>()) return fail(c, WK_E_STATE, "no gene lists staged (wk_ordinal_match)");
+    if (cap < c->n_hits + 1) return fail(c, WK_E_CAPACITY, "need %lld offsets", (long long)c->n_hits + 1);
+    DeviceGuard guard(c->device);
+    if (c->n_hits) HIP_TRY(c, hipMemcpyAsync(poff, c->o_poff.p, (size_t)c->n_hits * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    poff[c->n_hits] = (int32_t)c->n_records;
+    return WK_OK;
+}
+
 int wk_set_uniform_group(wk_ctx* c, int32_t group) {
     if (!c) return WK_E_ARG;
     if (group < 0 || group >= (1 << WK_KEY_GROUP_BITS)) return fail(c, WK_E_ARG, "group id outside [0, %d)", 1 << WK_KEY_GROUP_BITS);

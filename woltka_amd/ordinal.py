@@ -22,7 +22,12 @@ class GeneTable:
     written in the file.
     """
 
-    def __init__(self, genomes, goff, start0, end, names, isdup):
+    def __init__(self, genomes, goff, start0, end, names, isdup,
+                 findex=None):
+        # findex[i] = the gene's place among its nucleotide's lines in the
+        # file: the index encode_genes packs into its codes (ordinal.py:459-
+        # 465), which orders simultaneous events of the reference's sweep
+        self.findex = findex
         self.genomes = genomes
         self.genome_index = {g: i for i, g in enumerate(genomes)}
         self.goff = goff
@@ -60,8 +65,9 @@ class NativeGeneTable(GeneTable):
     gene ids stay one blob of bytes + offsets until something asks for them
     as Python strings."""
 
-    def __init__(self, genomes, goff, start0, end, blob, off, isdup):
-        super().__init__(genomes, goff, start0, end, None, isdup)
+    def __init__(self, genomes, goff, start0, end, blob, off, isdup,
+                 findex=None):
+        super().__init__(genomes, goff, start0, end, None, isdup, findex)
         self.name_blob, self.name_off = blob, off
 
     @property
@@ -88,8 +94,9 @@ def load_gene_coords_file(fp, zippers=None):
     if res is None:
         with readzip(fp, zippers) as fh:
             return load_gene_coords(fh, sort=True)
-    goff, start0, end, genomes, (blob, off), isdup = res
-    return NativeGeneTable(genomes, goff, start0, end, blob, off, isdup)
+    goff, start0, end, genomes, (blob, off), isdup, findex = res
+    return NativeGeneTable(genomes, goff, start0, end, blob, off, isdup,
+                           findex)
 
 
 def load_gene_coords(fh, sort=True):
@@ -131,7 +138,7 @@ def load_gene_coords(fh, sort=True):
         raise ValueError('No coordinate was read from file.')
 
     genomes, goff, names = [], [0], []
-    starts, ends = [], []
+    starts, ends, findex = [], [], []
     for nucl, (gids, begs, endz) in per.items():
         try:
             b = np.array([int(x) for x in begs], dtype=np.int64)
@@ -145,6 +152,7 @@ def load_gene_coords(fh, sort=True):
         names.extend(gids[i] for i in order.tolist())
         starts.append(lo[order])
         ends.append(hi[order])
+        findex.append(order.astype(np.int32))
         goff.append(goff[-1] + order.size)
     start0 = np.concatenate(starts) if starts else np.empty(0, np.int64)
     end = np.concatenate(ends) if ends else np.empty(0, np.int64)
@@ -153,7 +161,8 @@ def load_gene_coords(fh, sort=True):
                          'by the device tables.')
     return GeneTable(genomes, np.array(goff, dtype=np.int32),
                      start0.astype(np.int32), end.astype(np.int32), names,
-                     bool(isdup))
+                     bool(isdup),
+                     np.concatenate(findex) if findex else np.empty(0, np.int32))
 
 
 def pack_hits(pairs, table):

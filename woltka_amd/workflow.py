@@ -272,8 +272,11 @@ def classify(
                         # read ids as Python strings only when the host logic
                         # needs them (demultiplexing, Python-side strata join);
                         # read maps alone are formatted natively from descriptors
+                        # (coord-match read maps: the reference's listing
+                        # order is worked out on the host, per mapper chunk)
                         want_strings = bool((demux and not native_demux) or (
-                            stratmap and not native_strata))
+                            stratmap and not native_strata) or (
+                            ordinal and rank2dir is not None))
                         # plain assigners, one sample per file, nothing per
                         # read: the records cross as packed words and the
                         # sample is classified by one launch at its end
@@ -286,6 +289,8 @@ def classify(
                             want_names, trimsub, want_groups=native_strata,
                             want_strings=want_strings, want_samples=native_demux,
                             cover=cover, fmt=fmt_, part=part, words=words)
+                        if ordinal and rank2dir is not None:
+                            chunks = engine.regroup_hits(chunks, n)
                     else:
                         text = io.TextIOWrapper(
                         io.BufferedReader(stream) if isinstance(
