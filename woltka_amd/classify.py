@@ -994,6 +994,8 @@ class Engine:
             if n_reads:
                 self.ctx.set_uniform_group(group)
                 self.ctx.ordinal_count(self.jobs)
+                if self.sizes:
+                    self._collect_log()
             return 0
         n = 0
         for _, arrays, *_ in self._host_block(buf, fill, first, final, hdr_in,
