@@ -769,6 +769,12 @@ class Engine:
                 self.subj_feature.extend(self.index.intern_many(
                     self.subjects.names[known:]))
                 self.ctx.set_subjects(self.subj_feature)
+            # reads of more candidates than the count keys can say (k <= 4095)
+            # are evaluated here, with exact rationals (classify.counter takes
+            # any k, classify.py:156-171), and leave the chunk as empty reads
+            if qoff.size > 1 and not want and not self.sizes and \
+                    int(np.diff(qoff).max()) > nat.MAX_K:
+                subj, qoff = self._fold_huge_reads(subj, qoff, group)
             # the Python parsers and the native tokenizer hand over sets;
             # trimming can merge subjects
             self.ctx.chunk_stage(
@@ -1099,6 +1105,87 @@ class Engine:
                              indexed=True)
         self._classify_staged(data, False)
         return n
+
+    def _fold_huge_reads(self, subj, qoff, group):
+        """Reads with more than MAX_K candidate records: every job's assigner
+        and the counter restated on the host for them (classify.py:32-127,
+        144-171, 300-317; tree.py:467-566 via the pre-order arrays), their
+        counts added as exact rationals; returns the chunk with those reads
+        emptied.  (Read maps and size-normalised jobs keep the device's loud
+        error for such reads.)"""
+        sizes = np.diff(qoff.astype(np.int64))
+        huge = np.flatnonzero(sizes > nat.MAX_K)
+        feats_of = np.asarray(self.subj_feature, dtype=np.int64)
+        h = self.hier
+        n_nodes = h.n_nodes
+        unas = bool(self.jobs[0].flags & nat.F_UNASSIGNED)
+
+        def lca(ids):
+            lo, hi = min(ids), max(ids)
+            if hi >= n_nodes:
+                return None             # a taxon that is not in the tree
+            a = lo
+            while h.last[a] < hi:
+                a = int(h.parent[a])
+            return None if a == 0 else a
+
+        for r in huge.tolist():
+            g = int(group) if np.ndim(group) == 0 else int(group[r])
+            if g < 0:
+                continue
+            sample, stratum = self.groups[g]
+            feats = list(dict.fromkeys(
+                feats_of[subj[qoff[r]:qoff[r + 1]]].tolist()))
+            for j, (rank, job) in enumerate(zip(self.ranks, self.jobs)):
+                res = None              # feature id, None, or a list
+                if job.mode == nat.MODE_NONE:
+                    res = feats[0] if len(feats) == 1 else (
+                        None if job.flags & nat.F_UNIQ else feats)
+                elif job.mode == nat.MODE_FREE:
+                    if len(feats) == 1:
+                        f = feats[0]
+                        res = f if job.flags & nat.F_SUBOK else (
+                            int(h.parent[f]) if f < n_nodes else None)
+                    else:
+                        res = lca(feats)
+                else:
+                    anc = self._rank_table(self.slots[j])
+                    taxa = [int(anc[f]) if f < n_nodes else -1 for f in feats]
+                    tset = set(taxa)
+                    if len(tset) == 1:
+                        res = taxa[0] if taxa[0] >= 0 else None
+                    elif job.major > 0:
+                        tally = {}
+                        for t in taxa:
+                            tally[t] = tally.get(t, 0) + 1
+                        top = max(tally, key=tally.get)
+                        res = top if tally[top] >= len(taxa) * job.major \
+                            and top >= 0 else None
+                    elif job.flags & nat.F_ABOVE:
+                        res = None if -1 in tset else lca(list(tset))
+                    elif job.flags & nat.F_UNIQ:
+                        res = None
+                    else:
+                        res = [t for t in taxa if t >= 0]
+                dst = self._big.setdefault((rank, sample), {})
+
+                def add(f, value):
+                    name = 'Unassigned' if f is None else self.index.names[f]
+                    key = name if stratum is None else (stratum, name)
+                    dst[key] = dst.get(key, 0) + value
+                if isinstance(res, list):
+                    for f in res:
+                        add(f, Fraction(1, len(res)))
+                elif res is not None:
+                    add(res, Fraction(1))
+                elif unas:
+                    add(None, Fraction(1))
+        keep = np.ones(sizes.size, dtype=bool)
+        keep[huge] = False
+        sizes2 = np.where(keep, sizes, 0)
+        qoff2 = np.zeros(qoff.size, dtype=np.int32)
+        np.cumsum(sizes2, out=qoff2[1:])
+        return subj[np.repeat(keep, sizes)], qoff2
 
     def take_deferred(self):
         """Queries classified since the last call that `run_chunk` has not
