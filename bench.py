@@ -587,7 +587,7 @@ class Phases:
             setattr(owner, name, orig)
 
 
-def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=2,
+def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
             sync=None):
     """The whole `woltka classify` call — `workflow.workflow` from file paths
     (SAM text in the page cache, nodes.dmp / gene coordinates) to the written

@@ -66,7 +66,7 @@ def test_one_launch_over_250M_records():
         for j in range(3):
             assert int(vals[job == j].astype(object).sum()) == \
                 n_reads * nat.WEIGHT_L
-        assert int(vals.max()) > (1 << 32) * nat.WEIGHT_L // 16
+        assert int(vals.max()) > 1 << 32        # (units of 1 / L: bins wrapped)
         st = c.stats()
         assert st['n_reads'] == n_reads and st['n_records'] == words.size
         # the first 1/16 both ways

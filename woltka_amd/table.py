@@ -57,12 +57,14 @@ def prep_table(profile, samples=None, tree=None, rankdic=None, namedic=None,
         # that are all zero dropped (table.py:115)
         cols = [list(map(profile[s].get, keys, repeat(0))) for s in samples]
         if len(cols) == 1:
-            kept = [(k, [v]) for k, v in zip(keys, cols[0]) if v]
+            vals = cols[0]
+            features = [k for k, v in zip(keys, vals) if v]
+            data = [[v] for v in vals if v]
         else:
             kept = [(k, list(row)) for k, row in zip(keys, zip(*cols))
                     if any(row)]
-        features = [k for k, _ in kept]
-        data = [row for _, row in kept]
+            features = [k for k, _ in kept]
+            data = [row for _, row in kept]
         return data, features, samples, [{} for _ in features]
     for key in keys:
         row = [profile[s][key] if key in profile[s] else 0 for s in samples]
