@@ -43,6 +43,8 @@ def test_huge_reads_equal_the_oracle(opts):
     subque.insert(200, tuple(rng.sample(species, 4096)))
     one_genus = [x for x in species if tree[x] == 'g7']
     subque.append(tuple(one_genus + rng.sample(species, 4100 - len(one_genus))))
+    # (the parsers hand over sets: align.py:309)
+    subque = [tuple(dict.fromkeys(x)) for x in subque]
     qryque = [f'q{i}' for i in range(len(subque))]
     ranks = ['none', 'free', 'genus', 'phylum']
     eng = Engine(tree, rankdic, 'root', ranks, uniq=opts.get('uniq', False),
