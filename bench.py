@@ -283,8 +283,7 @@ class LcaFreeWorkload(LcaWorkload):
     key = 'lca_free'
     packed = False
     families = ('classify', 'leftover', 'partition_merge')
-    symbols = {'classify': 'wk::classify_single_kernel<true, true, 2, false, true>',
-               'leftover': 'wk::classify_kernel<true, true, 0>',
+    symbols = {'classify': 'wk::free_stream_kernel',
                'partition_merge': 'wk::partition_merge_kernel'}
     ranks = ('free',)
 
@@ -302,6 +301,22 @@ class LcaFreeWorkload(LcaWorkload):
         self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
                           8 * h.n_nodes)
         self.launch_bytes = self.alg_bytes
+        # the product's route: the packed records (feature ids), one launch of
+        # the free-rank stream per sample (csrc/wk_free.hpp)
+        sidx = subject_indices(self.prob)[1]
+        words = packed_words(sidx, self.prob['qoff'])
+        del sidx
+        ctx.set_option('words_keep', 0)
+        ctx.counts_clear()
+        ctx.set_option('words_keep', 1)
+        if not ctx.words_begin(self.jobs, 0):
+            raise RuntimeError('the free-rank stream refused the job')
+        step = 6_000_000
+        off = self.prob['qoff']
+        for lo in range(0, self.reads, step):
+            hi = min(self.reads, lo + step)
+            ctx.words_append(words[int(off[lo]):int(off[hi])], hi - lo)
+        self.packed = True
 
 
 class OrdinalWorkload:

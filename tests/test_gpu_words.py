@@ -169,3 +169,81 @@ def test_words_api_conservation_and_wraps(ctx):
         assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, 0, 0, 0.6)], 0)
         with pytest.raises(RuntimeError):
             c.words_append(words[:10], 1)
+
+
+@pytest.mark.parametrize('opts', [dict(), dict(unassigned=True),
+                                  dict(subok=True)])
+@pytest.mark.parametrize('dtok', [True, False])
+def test_free_rank_stream_equals_general_route(tmp_path, opts, dtok):
+    """`--rank free` alone goes through the free-rank stream over packed
+    records (csrc/wk_free.hpp) — with the device tokenizer and with the host
+    tokenizer — and must write what the general evaluator writes.  The second
+    sample has subjects that are not in the tree (with --subok the stream is
+    refused for it: a stranger is its own result there)."""
+    import bench
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    p = _problem(31, 300_000)
+    bench.write_sam_lca(str(indir / 'S1.sam'), p, 300_000)
+    sam = str(indir / 'S2.sam')
+    bench.write_sam_lca(sam, p, 80_000)
+    with open(sam, 'ab') as f:
+        for i in range(3000):
+            f.write(b'X%06d\t0\tstranger_%d\t1\t42\t150M\t*\t0\t0\t*\t*\n'
+                    % (i, i % 5))
+            if i % 3:
+                f.write(b'X%06d\t0\tT%07d\t1\t42\t150M\t*\t0\t0\t*\t*\n'
+                        % (i, int(p['subj'][i])))
+    nodes = str(tmp_path / 'nodes.dmp')
+    bench.write_nodes_dmp(nodes, p['hier'])
+    kw = dict(input_fp=str(indir), input_fmt='sam', nodes_fps=[nodes],
+              ranks='free', **opts)
+    if not dtok:
+        os.environ['WOLTKA_NO_DTOK'] = '1'
+    try:
+        a, log_a = _run(tmp_path, 'w', False, **kw)
+        b, log_b = _run(tmp_path, 'g', True, **kw)
+    finally:
+        os.environ.pop('WOLTKA_NO_DTOK', None)
+    assert list(a.values()) == list(b.values()) and log_a == log_b
+    assert len(next(iter(a.values()))) > 1000
+
+
+def test_free_rank_stream_is_taken(ctx):
+    """wk_words_begin accepts one free job (feature words), refuses it next to
+    other jobs, and its flush equals the general evaluator on the same chunk."""
+    from woltka_amd import _native as nat
+    from woltka_amd import synth
+    rng = np.random.default_rng(6)
+    p = synth.as_sets(synth.lca_problem(rng, n_nodes=30000, n_subjects=2000,
+                                        n_reads=1_000_000, with_names=False,
+                                        offtree_frac=0.01))
+    h = p['hier']
+    feats, sidx = np.unique(p['subj'], return_inverse=True)
+    off = p['qoff'].astype(np.int64)
+    size = np.diff(off)
+    assert int(size.max()) <= 16
+    words = (sidx.astype(np.uint32) |
+             ((np.arange(sidx.size) - np.repeat(off[:-1], size)).astype(np.uint32) << np.uint32(23)) |
+             (np.repeat(size, size).astype(np.uint32) << np.uint32(27)))
+    for flags in (0, nat.F_UNASSIGNED):
+        with nat.Context(0) as c:
+            c.set_tree(h.parent, h.last, h.rank_code)
+            c.build_rank_table(0, h.rank_codes['genus'])
+            c.set_subjects(feats.astype(np.int32))
+            c.counts_reserve(1 << 18)
+            free = [nat.Job(nat.MODE_FREE, 0, flags, 0, 0.0)]
+            assert not c.words_begin(free + [nat.Job(nat.MODE_RANK, 0, 0, 0, 0.0)], 0)
+            assert c.words_begin(free, 2)
+            c.words_append(words, off.size - 1)
+            a = nat.canonical_counts(*c.counts_fetch())
+            st = c.stats()
+            assert st['n_reads'] == off.size - 1 and st['n_records'] == words.size
+            c.counts_clear()
+            c.reset_stats()
+            c.chunk_stage(sidx.astype(np.int32), p['qoff'], group=2,
+                          subj_is_set=True, indexed=True)
+            c.classify_staged(free)
+            b = nat.canonical_counts(*c.counts_fetch())
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            assert a[0].size > 500

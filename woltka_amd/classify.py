@@ -331,6 +331,9 @@ class Engine:
                 len(self.jobs) > nat.MAX_JOBS or not self._tok_identity or \
                 os.environ.get('WOLTKA_NO_WORDS'):
             return False
+        if len(self.jobs) == 1 and self.jobs[0].mode == nat.MODE_FREE:
+            # `--rank free` alone: the free-rank stream (csrc/wk_free.hpp)
+            return self.use_tree
         for job in self.jobs:
             if job.flags & (nat.F_UNIQ | nat.F_SIZED):
                 return False

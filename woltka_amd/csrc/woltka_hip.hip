@@ -16,6 +16,7 @@
 #include "wk_classify.hpp"
 #include "wk_device.hpp"
 #include "wk_dtok.hpp"
+#include "wk_free.hpp"
 #include "wk_ordinal.hpp"
 #include "wk_tok_internal.h"
 #include "wk_weigh.hpp"
@@ -179,6 +180,7 @@ struct wk_ctx {
     std::vector<wk_job> w_jobs;          // the job set they will be classified under
     int32_t w_group = 0;
     bool w_open = false;
+    int w_mode = 0;  // 0: subject indices for the weighted histogram, 1: feature ids for the free-rank stream (wk_free.hpp)
     int words_keep = 0;  // measurement: wk_words_flush leaves the accumulated records in place
     static constexpr int kStageSlots = 8;
     hipEvent_t slot_ev[kStageSlots] = {};
@@ -544,6 +546,8 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<8>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
@@ -1502,9 +1506,20 @@ int wk_host_free(wk_ctx* c, void* p) {
 // Can the weighted histogram alone classify records under these jobs?  Plain
 // assigners only (see wk_weigh.hpp) and — checked against the current subject
 // table — every subject with an ancestor at every rank in use.
-static int words_jobs_ok(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, ClassifyArgs& a, bool* ok) {
+static int words_jobs_ok(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, ClassifyArgs& a, bool* ok, int* mode = nullptr) {
     *ok = false;
+    if (mode) *mode = 0;
     if (!c->use_weigh || c->n_subjects <= 0 || c->n_subjects > (int32_t)kWordSubjMask + 1) return WK_OK;
+    // one `--rank free` job: the free-rank stream over feature ids (wk_free.hpp)
+    if (n_jobs == 1 && jobs[0].mode == WK_MODE_FREE && !(jobs[0].flags & WK_F_SIZED)) {
+        if (c->n_nodes <= 0 || (uint32_t)c->n_nodes >= kFreeMissing) return WK_OK;
+        if (jobs[0].flags & WK_F_SUBOK)  // a subject that is no node is its own result under --subok: not a feature the stream can carry
+            for (int32_t f : c->subj_feat_host)
+                if (f >= c->n_nodes) return WK_OK;
+        if (mode) *mode = 1;
+        *ok = true;
+        return WK_OK;
+    }
     a = ClassifyArgs{};
     a.n_jobs = n_jobs;
     for (int j = 0; j < n_jobs; ++j) {
@@ -1548,6 +1563,45 @@ int wk_words_flush(wk_ctx* c) {
     }
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
+    if (c->w_mode == 1) {
+        // ---- one free-rank job: the stream over feature ids + the merge of its miss log
+        const int blocks = c->prop.multiProcessorCount;
+        FreeArgs fa{};
+        fa.words = c->c_words.as<uint32_t>();
+        fa.n_records = (uint32_t)c->w_records;
+        fa.nodes = c->nodes.as<Node>();
+        fa.n_nodes = (uint32_t)c->n_nodes;
+        fa.job = 0;
+        fa.group = (uint32_t)c->w_group;
+        fa.subok = (c->w_jobs[0].flags & WK_F_SUBOK) ? 1u : 0u;
+        fa.unassigned = (c->w_jobs[0].flags & WK_F_UNASSIGNED) ? 1u : 0u;
+        fa.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
+        // distinct results: nodes of the tree; 256 merge tables of 8192 slots hold ~1.3 M keys comfortably
+        fa.log_parts = c->log_parts_opt ? (uint32_t)c->log_parts_opt : ((int64_t)c->n_nodes <= 256 * 5120 ? 256u : kLogPartsMax);
+        const int64_t streams = (int64_t)blocks * fa.log_parts;
+        int64_t cap = 3 * (c->w_reads / streams + 1) + 16;  // one entry per read at most
+        cap = std::max<int64_t>(16, std::min<int64_t>(cap, c->plog_max_bytes / 8 / streams));
+        fa.plog_cap = (uint32_t)cap;
+        HIP_TRY(c, c->plog.reserve((size_t)streams * fa.plog_cap * 8));
+        HIP_TRY(c, c->plog_cnt.reserve((size_t)streams * 4));
+        fa.plog = c->plog.as<unsigned long long>();
+        fa.plog_cnt = c->plog_cnt.as<uint32_t>();
+        fa.stat_block = c->stat_block.as<unsigned long long>();
+        const uint32_t lds_slots = 8192;
+        KernelTimer* kt = ktimer_begin(c, "classify");
+        hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(kFreeThreads), (size_t)lds_slots * 16 + (size_t)fa.log_parts * 4,
+                           c->stream, fa, lds_slots);
+        ktimer_end(c, kt);
+        kt = ktimer_begin(c, "partition_merge");
+        hipLaunchKernelGGL(partition_merge_kernel, dim3(fa.log_parts), dim3(1024), (size_t)8192 * 16, c->stream,
+                           c->plog.as<unsigned long long>(), c->plog_cnt.as<uint32_t>(), (uint32_t)blocks, fa.plog_cap, 8192u, fa.table);
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+        if (c->words_keep) return WK_OK;
+        c->w_records = c->w_reads = 0;
+        c->w_open = false;
+        return WK_OK;
+    }
     ClassifyArgs a{};
     bool ok = false;
     int rc = words_jobs_ok(c, c->w_jobs.data(), (int32_t)c->w_jobs.size(), a, &ok);
@@ -1636,7 +1690,8 @@ int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group,
     }
     ClassifyArgs a{};
     bool good = false;
-    int rc = words_jobs_ok(c, jobs, n_jobs, a, &good);
+    int mode = 0;
+    int rc = words_jobs_ok(c, jobs, n_jobs, a, &good, &mode);
     if (rc) return rc;
     if (!good) {
         // (what is there was appended while every subject was valid: classify it now)
@@ -1646,8 +1701,19 @@ int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group,
     }
     c->w_jobs.assign(jobs, jobs + n_jobs);
     c->w_group = group;
+    c->w_mode = mode;
     c->w_open = true;
     *ok = 1;
+    return WK_OK;
+}
+
+// Free-rank accumulation: the subject fields of words [first, first + n) become feature ids.
+static int words_translate(wk_ctx* c, int64_t first, int64_t n) {
+    if (c->w_mode != 1 || n <= 0) return WK_OK;
+    hipLaunchKernelGGL(words_to_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       c->c_words.as<uint32_t>() + first, (uint32_t)n, c->subj_feat.as<int32_t>(), (uint32_t)c->n_subjects,
+                       (uint32_t)c->n_nodes, scalar_err(c));
+    HIP_TRY(c, hipGetLastError());
     return WK_OK;
 }
 
@@ -1700,9 +1766,12 @@ int wk_words_append(wk_ctx* c, const uint32_t* words, int64_t n_records, int64_t
         if (!c->slot_ev[slot]) HIP_TRY(c, hipEventCreateWithFlags(&c->slot_ev[slot], hipEventDisableTiming));
         HIP_TRY(c, hipEventRecord(c->slot_ev[slot], c->stream));
         c->slot_busy[slot] = true;
-    } else {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer is only valid during the call
     }
+    {
+        const int rct = words_translate(c, c->w_records, n_records);
+        if (rct) return rct;
+    }
+    if (slot < 0) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer is only valid during the call
     c->w_records += n_records;
     c->w_reads += n_reads;
     return WK_OK;
@@ -1940,6 +2009,7 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (st.flags) return WK_OK;  // a read of more than 16 subjects: nothing counts as appended
+    if ((rc = words_translate(c, c->w_records, (int64_t)st.n_out))) return rc;
     c->w_records += (int64_t)st.n_out;
     c->w_reads += (int64_t)st.n_reads;
     *n_reads = (int64_t)st.n_reads;
