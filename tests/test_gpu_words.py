@@ -164,7 +164,8 @@ def test_words_api_conservation_and_wraps(ctx):
         k3, v3 = nat.canonical_counts(*c.counts_fetch())
         assert np.array_equal(k1, k3) and np.array_equal(v1, v3)
         # job sets the histogram does not take
-        assert not c.words_begin([nat.Job(nat.MODE_FREE, 0, 0, 0, 0.0)], 0)
+        assert not c.words_begin([nat.Job(nat.MODE_FREE, 0, 0, 0, 0.0),
+                                  nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)], 0)
         assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, nat.F_UNIQ, 0, 0.0)], 0)
         assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, 0, 0, 0.6)], 0)
         with pytest.raises(RuntimeError):

@@ -35,6 +35,12 @@ struct FreeArgs {
     uint32_t n_records;
     const Node* nodes;
     uint32_t n_nodes;
+    // the lowest common ancestor without a walk: node_rank[v] = rank
+    // of node v among the subjects ordered by pre-order id (-1: no subject), and the
+    // sparse table over the LCAs of rank-adjacent subjects
+    const int32_t* node_rank;
+    const int32_t* sparse;   // [levels][sparse_m]
+    uint32_t sparse_m;
     uint32_t job, group;
     uint32_t subok, unassigned;
     CountTable table;
@@ -43,6 +49,8 @@ struct FreeArgs {
     uint32_t plog_cap, log_parts;
     unsigned long long* stat_block;
 };
+
+constexpr int kFreeWindows = 8;  // windows a wave has in flight: their dependent gathers overlap
 
 __global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -64,36 +72,68 @@ __global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, u
     // window w looks at records [48 w - 16, 48 w + 48) and owns [48 w, 48 w + 48)
     const uint32_t n_windows = (a.n_records + kFreeStride - 1) / kFreeStride;
     unsigned long long my_reads = 0, my_records = 0;
-    for (uint32_t w = wave0; w < n_windows; w += waves) {
-        const int64_t idx = (int64_t)w * kFreeStride - 16 + (int64_t)lane;
-        const uint32_t word = (idx >= 0 && idx < (int64_t)a.n_records) ? a.words[idx] : 0u;
-        const uint32_t size = word >> kWordSizeShift, pos = (word >> kWordSubjBits) & 15u;
-        uint32_t mn = word & kWordSubjMask, mx = mn;
-        // segmented inclusive min / max over the lanes of a read (its records are
-        // consecutive, lane - d belongs to the same read iff pos >= d)
+    for (uint32_t w0 = wave0 * kFreeWindows; w0 < n_windows; w0 += waves * kFreeWindows) {
+        uint32_t word[kFreeWindows], mn[kFreeWindows], mx[kFreeWindows];
+        int32_t res[kFreeWindows];       // result node, -1 = none (yet)
+        int32_t p[kFreeWindows], q[kFreeWindows];
+        bool owner[kFreeWindows], multi[kFreeWindows];
 #pragma unroll
-        for (uint32_t d = 1; d < 16u; d <<= 1) {
-            const uint32_t pmn = __shfl_up(mn, d, kWave), pmx = __shfl_up(mx, d, kWave);
-            if (pos >= d && lane >= d) {
-                mn = pmn < mn ? pmn : mn;
-                mx = pmx > mx ? pmx : mx;
+        for (int u = 0; u < kFreeWindows; ++u) {
+            const int64_t idx = (int64_t)(w0 + u) * kFreeStride - 16 + (int64_t)lane;
+            word[u] = (w0 + u < n_windows && idx >= 0 && idx < (int64_t)a.n_records) ? a.words[idx] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kFreeWindows; ++u) {
+            const uint32_t size = word[u] >> kWordSizeShift, pos = (word[u] >> kWordSubjBits) & 15u;
+            mn[u] = mx[u] = word[u] & kWordSubjMask;
+            // segmented inclusive min / max over the lanes of a read (its records are
+            // consecutive, lane - d belongs to the same read iff pos >= d)
+#pragma unroll
+            for (uint32_t d = 1; d < 16u; d <<= 1) {
+                const uint32_t pmn = __shfl_up(mn[u], d, kWave), pmx = __shfl_up(mx[u], d, kWave);
+                if (pos >= d && lane >= d) {
+                    mn[u] = pmn < mn[u] ? pmn : mn[u];
+                    mx[u] = pmx > mx[u] ? pmx : mx[u];
+                }
+            }
+            owner[u] = size != 0u && pos + 1u == size && lane >= 16u;
+            // (a missing subject carries the largest value of the field: it is the maximum)
+            multi[u] = owner[u] && size > 1u && mx[u] != kFreeMissing && mn[u] != mx[u];
+            my_records += (size != 0u && lane >= 16u) ? 1ull : 0ull;
+            my_reads += owner[u] ? 1ull : 0ull;
+            res[u] = -1;
+            p[u] = q[u] = -1;
+        }
+        // first round of gathers: the parent of a sole subject, the ranks of the extremes
+#pragma unroll
+        for (int u = 0; u < kFreeWindows; ++u) {
+            if (!owner[u]) continue;
+            const uint32_t size = word[u] >> kWordSizeShift;
+            if (size == 1u) {
+                if (mn[u] != kFreeMissing) res[u] = a.subok ? (int32_t)mn[u] : a.nodes[mn[u]].parent;
+            } else if (multi[u]) {
+                p[u] = a.node_rank[mn[u]];
+                q[u] = a.node_rank[mx[u]];
+            } else if (mx[u] != kFreeMissing) {
+                res[u] = mn[u] == 0u ? -1 : (int32_t)mn[u];  // the same node several times (cannot happen with sets): itself, None if the root
             }
         }
-        const bool owner = size != 0u && pos + 1u == size && lane >= 16u;
-        my_records += (size != 0u && lane >= 16u) ? 1ull : 0ull;
-        if (owner) {
-            my_reads += 1;
-            // (a missing subject carries the largest value of the field: it is the maximum)
-            int32_t res = -1;
-            if (size == 1u) {
-                if (mn != kFreeMissing) res = a.subok ? (int32_t)mn : a.nodes[mn].parent;
-            } else if (mx != kFreeMissing) {
-                uint32_t anc = mn;
-                while ((uint32_t)a.nodes[anc].last < mx) anc = (uint32_t)a.nodes[anc].parent;
-                res = anc == 0u ? -1 : (int32_t)anc;
-            }
-            if (res >= 0)
-                cached_add(cache, a.table, make_key(a.job, 0u, a.group, (uint32_t)res), (unsigned long long)WK_WEIGHT_L);
+        // second round: the shallowest LCA of rank-adjacent subjects over [p, q)
+#pragma unroll
+        for (int u = 0; u < kFreeWindows; ++u) {
+            if (!multi[u]) continue;
+            const uint32_t span = (uint32_t)(q[u] - p[u]);  // >= 1
+            const uint32_t k = 31u - (uint32_t)__clz((int)span);
+            const int32_t* row = a.sparse + (size_t)k * a.sparse_m;
+            const int32_t x = row[p[u]], y = row[(uint32_t)q[u] - (1u << k)];
+            const int32_t anc = x < y ? x : y;
+            res[u] = anc == 0 ? -1 : anc;
+        }
+#pragma unroll
+        for (int u = 0; u < kFreeWindows; ++u) {
+            if (!owner[u]) continue;
+            if (res[u] >= 0)
+                cached_add(cache, a.table, make_key(a.job, 0u, a.group, (uint32_t)res[u]), (unsigned long long)WK_WEIGHT_L);
             else if (a.unassigned)
                 cached_add(cache, a.table, make_key(a.job, 0u, a.group, (uint32_t)WK_FEATURE_UNASSIGNED),
                            (unsigned long long)WK_WEIGHT_L);

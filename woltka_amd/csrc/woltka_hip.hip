@@ -88,7 +88,7 @@ struct wk_ctx {
     // id, LCAs of rank-adjacent subjects as a sparse table; rebuilt when either changes
     std::vector<int32_t> parent_host, last_host, subj_feat_host;
     int tree_serial = 0, subj_serial = 0, free_tree = -1, free_subj = -1;
-    DevBuf f_rank, f_sparse;
+    DevBuf f_rank, f_sparse, f_node_rank;  // (f_node_rank: the same ranks by node id, for the free-rank stream)
     uint32_t f_m = 0;
     int use_free_sparse = 1;
     int log_parts_opt = 0;                         // 0 = auto, else 256 / 1024
@@ -350,9 +350,12 @@ static int ensure_free_tables(wk_ctx* c) {
     for (uint32_t k = 1; k < levels; ++k)
         for (uint32_t i = 0; i + (1u << k) <= m - 1; ++i)
             sparse[k * row + i] = std::min(sparse[(k - 1) * row + i], sparse[(k - 1) * row + i + (1u << (k - 1))]);
+    std::vector<int32_t> node_rank((size_t)std::max(n_nodes, 1), -1);
+    for (uint32_t i = 0; i < m; ++i) node_rank[(size_t)feat[order[i]]] = (int32_t)i;  // (subjects that share a node: the last of them; their LCAs with the neighbours are that node either way)
     int rc;
     if ((rc = upload(c, c->f_rank, rank.data(), rank.size() * 4))) return rc;
     if ((rc = upload(c, c->f_sparse, sparse.data(), sparse.size() * 4))) return rc;
+    if ((rc = upload(c, c->f_node_rank, node_rank.data(), node_rank.size() * 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors are about to go out of scope
     c->f_m = (uint32_t)row;
     c->free_tree = c->tree_serial;
@@ -573,7 +576,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_node_rank, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     c->c_words.release();
     for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
@@ -1566,7 +1569,14 @@ int wk_words_flush(wk_ctx* c) {
     if (c->w_mode == 1) {
         // ---- one free-rank job: the stream over feature ids + the merge of its miss log
         const int blocks = c->prop.multiProcessorCount;
+        {
+            const int rcf = ensure_free_tables(c);
+            if (rcf) return rcf;
+        }
         FreeArgs fa{};
+        fa.node_rank = c->f_node_rank.as<int32_t>();
+        fa.sparse = c->f_sparse.as<int32_t>();
+        fa.sparse_m = c->f_m;
         fa.words = c->c_words.as<uint32_t>();
         fa.n_records = (uint32_t)c->w_records;
         fa.nodes = c->nodes.as<Node>();
