@@ -304,19 +304,23 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
 // a hit's place = hits before its run + hits of lower mates in the run + earlier
 // hits of its own read; a read's index likewise from its first hit.
 
-// is the line a hit / the first hit of its read?  -> tile totals for the scan
+// is the line a hit / the first hit of its read?  -> tile totals for the scan.
+// kEx: a hit is a mapped line of aligned length > 0; else (plain flavour, ordered
+// emission) a line dtok_first_kernel marked: the first of its read with its subject.
+template <bool kEx>
 __global__ void __launch_bounds__(kDtokThreads) dtok_hits_kernel(DtokArgs a, unsigned long long* __restrict__ tile_count) {
     __shared__ unsigned long long wsum[kDtokThreads / kWave];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0;
-    if (i < a.n_lines && a.lsubj[i] >= 0 && a.llen[i] > 0u) {
+    auto hit = [&](uint32_t x) { return kEx ? (a.lsubj[x] >= 0 && a.llen[x] > 0u) : (a.is_first[x] != 0); };
+    if (i < a.n_lines && hit(i)) {
         const uint32_t m = a.lmeta[i] >> 28;
         bool leader = true;
         if (!a.is_start[i]) {
             uint32_t j = i;
             do {
                 --j;
-                if (a.lsubj[j] >= 0 && a.llen[j] > 0u && (a.lmeta[j] >> 28) == m) {
+                if (hit(j) && (a.lmeta[j] >> 28) == m) {
                     leader = false;
                     break;
                 }
@@ -475,6 +479,38 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
     if (!rec) return;
     const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
     if (at < a.out_cap) a.out[at] = word;
+}
+
+// Plain flavour, ordered emission: the records of a read contiguous and in
+// position order (what the free-rank stream needs, wk_free.hpp) — placed like the
+// hits above: records before the run + records of lower mates in the run + the
+// record's position in its read.
+__global__ void __launch_bounds__(kDtokThreads) dtok_place_words_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines || !(a.is_first[i] & 1u)) return;
+    const uint32_t m = a.lmeta[i] >> 28;
+    uint32_t s = i, before = 0, pos = 0, size = 1;
+    while (!a.is_start[s]) {
+        --s;
+        if (a.is_first[s] & 1u) {
+            const uint32_t q = a.lmeta[s] >> 28;
+            before += q < m ? 1u : 0u;
+            pos += q == m ? 1u : 0u;
+        }
+    }
+    for (uint32_t j = i + 1u; j < a.n_lines && !a.is_start[j]; ++j)
+        if (a.is_first[j] & 1u) {
+            const uint32_t q = a.lmeta[j] >> 28;
+            before += q < m ? 1u : 0u;
+            size += q == m ? 1u : 0u;
+        }
+    size += pos;
+    if (size > (uint32_t)WK_WEIGHT_MAX_K) {
+        atomicOr(&a.state->flags, kDtokBigRead);
+        return;
+    }
+    const uint32_t at = (uint32_t)a.line_scan[s] + before + pos;
+    if (at < a.out_cap) a.out[at] = (uint32_t)a.lsubj[i] | (pos << kWordSubjBits) | (size << kWordSizeShift);
 }
 
 }  // namespace wk

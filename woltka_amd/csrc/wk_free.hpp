@@ -50,21 +50,32 @@ struct FreeArgs {
     unsigned long long* stat_block;
 };
 
-constexpr int kFreeWindows = 8;  // windows a wave has in flight: their dependent gathers overlap
 
-__global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, uint32_t lds_slots) {
+// The results go straight to the partitioned log (one LDS counter bump and one
+// 8-byte store each; partition_merge_kernel counts them): a read's result is one
+// of ~10^5 nodes, an LDS hash cache of 8 k slots in front of the log would miss
+// nearly always and its probes were the larger half of the first version's time.
+// Without the cache the kernel needs 1-4 KB of LDS and runs several workgroups
+// per CU: more dependent gather chains in flight.
+template <int kWin>
+__global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long acc[2];
-    LdsCache cache{};
-    cache.base = reinterpret_cast<unsigned long long*>(smem);
-    cache.bmask = lds_slots / 4 - 1;
-    cache.plog_cur = reinterpret_cast<uint32_t*>(smem + (size_t)lds_slots * 16);
-    cache.plog = a.plog + (size_t)blockIdx.x * a.log_parts * a.plog_cap;
-    cache.plog_cap = a.plog_cap;
-    cache.plog_shift = (uint32_t)__clz((int)a.log_parts) + 1u;
-    for (uint32_t i = threadIdx.x; i < a.log_parts; i += blockDim.x) cache.plog_cur[i] = 0u;
+    uint32_t* const plog_cur = reinterpret_cast<uint32_t*>(smem);
+    unsigned long long* const plog = a.plog + (size_t)blockIdx.x * a.log_parts * a.plog_cap;
+    const uint32_t plog_shift = (uint32_t)__clz((int)a.log_parts) + 1u;
+    for (uint32_t i = threadIdx.x; i < a.log_parts; i += blockDim.x) plog_cur[i] = 0u;
     if (threadIdx.x < 2) acc[threadIdx.x] = 0ull;
-    lds_cache_init(cache);  // (ends with a barrier)
+    __syncthreads();
+    auto count = [&](uint32_t feature) {
+        const uint64_t key = make_key(a.job, 0u, a.group, feature);
+        const uint32_t part = (hash_key(key) * 0x9E3779B1u) >> plog_shift;
+        const uint32_t pos = atomicAdd(&plog_cur[part], 1u);
+        if (pos < a.plog_cap)
+            plog[(size_t)part * a.plog_cap + pos] = key | (1ull << 49);  // k = 1: one whole read (weight L under the k = 0 key)
+        else
+            table_add(a.table, key, (unsigned long long)WK_WEIGHT_L);
+    };
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
@@ -72,18 +83,18 @@ __global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, u
     // window w looks at records [48 w - 16, 48 w + 48) and owns [48 w, 48 w + 48)
     const uint32_t n_windows = (a.n_records + kFreeStride - 1) / kFreeStride;
     unsigned long long my_reads = 0, my_records = 0;
-    for (uint32_t w0 = wave0 * kFreeWindows; w0 < n_windows; w0 += waves * kFreeWindows) {
-        uint32_t word[kFreeWindows], mn[kFreeWindows], mx[kFreeWindows];
-        int32_t res[kFreeWindows];       // result node, -1 = none (yet)
-        int32_t p[kFreeWindows], q[kFreeWindows];
-        bool owner[kFreeWindows], multi[kFreeWindows];
+    for (uint32_t w0 = wave0 * kWin; w0 < n_windows; w0 += waves * kWin) {
+        uint32_t word[kWin], mn[kWin], mx[kWin];
+        int32_t res[kWin];       // result node, -1 = none (yet)
+        int32_t p[kWin], q[kWin];
+        bool owner[kWin], multi[kWin];
 #pragma unroll
-        for (int u = 0; u < kFreeWindows; ++u) {
+        for (int u = 0; u < kWin; ++u) {
             const int64_t idx = (int64_t)(w0 + u) * kFreeStride - 16 + (int64_t)lane;
             word[u] = (w0 + u < n_windows && idx >= 0 && idx < (int64_t)a.n_records) ? a.words[idx] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < kFreeWindows; ++u) {
+        for (int u = 0; u < kWin; ++u) {
             const uint32_t size = word[u] >> kWordSizeShift, pos = (word[u] >> kWordSubjBits) & 15u;
             mn[u] = mx[u] = word[u] & kWordSubjMask;
             // segmented inclusive min / max over the lanes of a read (its records are
@@ -106,7 +117,7 @@ __global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, u
         }
         // first round of gathers: the parent of a sole subject, the ranks of the extremes
 #pragma unroll
-        for (int u = 0; u < kFreeWindows; ++u) {
+        for (int u = 0; u < kWin; ++u) {
             if (!owner[u]) continue;
             const uint32_t size = word[u] >> kWordSizeShift;
             if (size == 1u) {
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, u
         }
         // second round: the shallowest LCA of rank-adjacent subjects over [p, q)
 #pragma unroll
-        for (int u = 0; u < kFreeWindows; ++u) {
+        for (int u = 0; u < kWin; ++u) {
             if (!multi[u]) continue;
             const uint32_t span = (uint32_t)(q[u] - p[u]);  // >= 1
             const uint32_t k = 31u - (uint32_t)__clz((int)span);
@@ -130,13 +141,12 @@ __global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, u
             res[u] = anc == 0 ? -1 : anc;
         }
 #pragma unroll
-        for (int u = 0; u < kFreeWindows; ++u) {
+        for (int u = 0; u < kWin; ++u) {
             if (!owner[u]) continue;
             if (res[u] >= 0)
-                cached_add(cache, a.table, make_key(a.job, 0u, a.group, (uint32_t)res[u]), (unsigned long long)WK_WEIGHT_L);
+                count((uint32_t)res[u]);
             else if (a.unassigned)
-                cached_add(cache, a.table, make_key(a.job, 0u, a.group, (uint32_t)WK_FEATURE_UNASSIGNED),
-                           (unsigned long long)WK_WEIGHT_L);
+                count((uint32_t)WK_FEATURE_UNASSIGNED);
         }
     }
     my_reads = wave_sum(my_reads);
@@ -145,13 +155,13 @@ __global__ void __launch_bounds__(kFreeThreads) free_stream_kernel(FreeArgs a, u
         atomicAdd(&acc[0], my_reads);
         atomicAdd(&acc[1], my_records);
     }
-    lds_cache_flush(cache, a.table);  // (starts with a barrier)
+    __syncthreads();
     if (threadIdx.x == 0) {
         a.stat_block[2 * blockIdx.x] += acc[0];
         a.stat_block[2 * blockIdx.x + 1] += acc[1];
     }
     for (uint32_t i = threadIdx.x; i < a.log_parts; i += blockDim.x) {
-        const uint32_t n = cache.plog_cur[i];
+        const uint32_t n = plog_cur[i];
         a.plog_cnt[(size_t)blockIdx.x * a.log_parts + i] = n < a.plog_cap ? n : a.plog_cap;
     }
 }

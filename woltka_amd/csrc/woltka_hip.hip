@@ -181,6 +181,7 @@ struct wk_ctx {
     int32_t w_group = 0;
     bool w_open = false;
     int w_mode = 0;  // 0: subject indices for the weighted histogram, 1: feature ids for the free-rank stream (wk_free.hpp)
+    int free_per_cu = 2, free_windows = 4;  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
     int words_keep = 0;  // measurement: wk_words_flush leaves the accumulated records in place
     static constexpr int kStageSlots = 8;
     hipEvent_t slot_ev[kStageSlots] = {};
@@ -549,8 +550,6 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<8>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
@@ -704,6 +703,16 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "weigh")) {  // 0 = off, 1 = auto (large multi-hit chunks), 2 = whenever the jobs allow it
         if (value < 0 || value > 2) return fail(c, WK_E_ARG, "weigh must be 0, 1 or 2");
         c->use_weigh = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "free_per_cu")) {
+        if (value < 1 || value > 8) return fail(c, WK_E_ARG, "free_per_cu must be in [1, 8]");
+        c->free_per_cu = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "free_windows")) {
+        if (value != 2 && value != 4 && value != 8) return fail(c, WK_E_ARG, "free_windows must be 2, 4 or 8");
+        c->free_windows = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "words_keep")) {
@@ -1568,7 +1577,7 @@ int wk_words_flush(wk_ctx* c) {
     DeviceGuard guard(c->device);
     if (c->w_mode == 1) {
         // ---- one free-rank job: the stream over feature ids + the merge of its miss log
-        const int blocks = c->prop.multiProcessorCount;
+        const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->free_per_cu);
         {
             const int rcf = ensure_free_tables(c);
             if (rcf) return rcf;
@@ -1597,10 +1606,13 @@ int wk_words_flush(wk_ctx* c) {
         fa.plog = c->plog.as<unsigned long long>();
         fa.plog_cnt = c->plog_cnt.as<uint32_t>();
         fa.stat_block = c->stat_block.as<unsigned long long>();
-        const uint32_t lds_slots = 8192;
         KernelTimer* kt = ktimer_begin(c, "classify");
-        hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(kFreeThreads), (size_t)lds_slots * 16 + (size_t)fa.log_parts * 4,
-                           c->stream, fa, lds_slots);
+        if (c->free_windows == 8)
+            hipLaunchKernelGGL(free_stream_kernel<8>, dim3(blocks), dim3(kFreeThreads), (size_t)fa.log_parts * 4, c->stream, fa);
+        else if (c->free_windows == 2)
+            hipLaunchKernelGGL(free_stream_kernel<2>, dim3(blocks), dim3(kFreeThreads), (size_t)fa.log_parts * 4, c->stream, fa);
+        else
+            hipLaunchKernelGGL(free_stream_kernel<4>, dim3(blocks), dim3(kFreeThreads), (size_t)fa.log_parts * 4, c->stream, fa);
         ktimer_end(c, kt);
         kt = ktimer_begin(c, "partition_merge");
         hipLaunchKernelGGL(partition_merge_kernel, dim3(fa.log_parts), dim3(1024), (size_t)8192 * 16, c->stream,
@@ -2012,12 +2024,34 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
-    hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+    unsigned long long totals = 0;
+    if (c->w_mode == 1) {
+        // the free-rank stream wants the records of a read next to each other, in
+        // position order: placed by prefix sums instead of appended wave by wave
+        const uint32_t n_tiles = grid.x;
+        HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, c->d_lscan.reserve(((size_t)c->dt_lines + 1) * 8));
+        a.line_scan = c->d_lscan.as<unsigned long long>();
+        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+        hipLaunchKernelGGL(dtok_hits_kernel<false>, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tiles.as<unsigned long long>());
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
+                           c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+        hipLaunchKernelGGL(dtok_scan_lines_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tile_off.as<unsigned long long>());
+        hipLaunchKernelGGL(dtok_place_words_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        HIP_TRY(c, hipMemcpyAsync(&totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+    }
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
     DtokState st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->w_mode == 1) {
+        st.n_out = totals & 0xFFFFFFFFull;
+        st.n_reads = totals >> 32;
+    }
     if (st.flags) return WK_OK;  // a read of more than 16 subjects: nothing counts as appended
     if ((rc = words_translate(c, c->w_records, (int64_t)st.n_out))) return rc;
     c->w_records += (int64_t)st.n_out;
@@ -2064,7 +2098,7 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
         const dim3 grid(n_tiles);
         KernelTimer* kt = ktimer_begin(c, "dtok_emit");
         hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
-        hipLaunchKernelGGL(dtok_hits_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tiles.as<unsigned long long>());
+        hipLaunchKernelGGL(dtok_hits_kernel<true>, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tiles.as<unsigned long long>());
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
                            c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
         hipLaunchKernelGGL(dtok_scan_lines_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tile_off.as<unsigned long long>());
