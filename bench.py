@@ -282,9 +282,9 @@ class LcaFreeWorkload(LcaWorkload):
     multi-hit read (one pass, one job)."""
     key = 'lca_free'
     packed = False
-    families = ('classify', 'leftover', 'partition_merge')
+    families = ('classify', 'free_counts')
     symbols = {'classify': 'wk::free_stream_kernel',
-               'partition_merge': 'wk::partition_merge_kernel'}
+               'free_counts': 'wk::free_counts_kernel'}
     ranks = ('free',)
 
     def __init__(self, ctx, seed, scale=1.0, share=None):

@@ -148,8 +148,8 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * straight from the matches), "tally_slots" / "tally_per_cu" (LDS cache slots
  * and workgroups per CU of that kernel), "grid_density" (1..8 grid cells per
  * gene; takes effect at the next wk_set_genes), "match_lds" (0/1: per-genome
- * words of the coordinate grid in LDS), "free_per_cu" / "free_windows" (workgroups per CU and windows in flight per wave
- * of the free-rank stream, csrc/wk_free.hpp), "words_keep" (0/1, measurement: wk_words_flush classifies the accumulated
+ * words of the coordinate grid in LDS), "free_per_cu" / "free_threads" / "free_slots" (launch shape of the free-rank
+ * stream, csrc/wk_free.hpp: workgroups per CU, threads and LDS cache slots per workgroup), "words_keep" (0/1, measurement: wk_words_flush classifies the accumulated
  * packed records but leaves them in place, so that a benchmark can time
  * repeated passes over one resident batch), "free_sparse" (0/1: `--rank free` on
  * chunks of subject indices looks the LCA up in a sparse table over the

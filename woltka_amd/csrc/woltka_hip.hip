@@ -88,7 +88,10 @@ struct wk_ctx {
     // id, LCAs of rank-adjacent subjects as a sparse table; rebuilt when either changes
     std::vector<int32_t> parent_host, last_host, subj_feat_host;
     int tree_serial = 0, subj_serial = 0, free_tree = -1, free_subj = -1;
-    DevBuf f_rank, f_sparse, f_node_rank;  // (f_node_rank: the same ranks by node id, for the free-rank stream)
+    DevBuf f_rank, f_sparse, f_rblocks, f_dsparse, f_dparent, f_dself, f_rnode;  // (f_rblocks ...: the same over the distinct subject nodes, for the free-rank stream)
+    uint32_t f_dm = 0, f_results = 0;
+    DevBuf f_dense;  // reads per result node of the free-rank stream
+    int f_dense_tree = -1;
     uint32_t f_m = 0;
     int use_free_sparse = 1;
     int log_parts_opt = 0;                         // 0 = auto, else 256 / 1024
@@ -181,7 +184,7 @@ struct wk_ctx {
     int32_t w_group = 0;
     bool w_open = false;
     int w_mode = 0;  // 0: subject indices for the weighted histogram, 1: feature ids for the free-rank stream (wk_free.hpp)
-    int free_per_cu = 2, free_windows = 4;  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
+    int free_per_cu = 2, free_threads = 1024, free_slots = 4096;  // launch shape of the free-rank stream (measurement knobs)  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
     int words_keep = 0;  // measurement: wk_words_flush leaves the accumulated records in place
     static constexpr int kStageSlots = 8;
     hipEvent_t slot_ev[kStageSlots] = {};
@@ -351,12 +354,60 @@ static int ensure_free_tables(wk_ctx* c) {
     for (uint32_t k = 1; k < levels; ++k)
         for (uint32_t i = 0; i + (1u << k) <= m - 1; ++i)
             sparse[k * row + i] = std::min(sparse[(k - 1) * row + i], sparse[(k - 1) * row + i + (1u << (k - 1))]);
-    std::vector<int32_t> node_rank((size_t)std::max(n_nodes, 1), -1);
-    for (uint32_t i = 0; i < m; ++i) node_rank[(size_t)feat[order[i]]] = (int32_t)i;  // (subjects that share a node: the last of them; their LCAs with the neighbours are that node either way)
+    // the same over the distinct subject nodes, for the free-rank stream
+    // (wk_free.hpp), whose records name nodes: rank blocks, the parents, the table
+    std::vector<int32_t> dn;  // distinct nodes, ascending
+    dn.reserve(m);
+    for (uint32_t i = 0; i < m; ++i)
+        if (dn.empty() || dn.back() != feat[order[i]]) dn.push_back(feat[order[i]]);
+    const uint32_t md = (uint32_t)dn.size();
+    std::vector<RankBlock> blocks((size_t)n_nodes / 64 + 1, RankBlock{0ull, 0u, 0u});
+    for (int32_t v : dn) blocks[(size_t)v >> 6].bits |= 1ull << (v & 63);
+    for (size_t b = 1; b < blocks.size(); ++b) blocks[b].before = blocks[b - 1].before + (uint32_t)__builtin_popcountll(blocks[b - 1].bits);
+    uint32_t dlevels = 1;
+    while (md > 1 && (2u << (dlevels - 1)) <= md - 1) dlevels += 1;
+    const size_t drow = std::max<uint32_t>(md, 1u);
+    // ... in terms of *result ids*: the nodes a read can be assigned to are the
+    // subject nodes and their ancestors (a few hundred thousand of a 2 M-node
+    // tree), numbered in pre-order — so that the smallest id is still the
+    // shallowest ancestor, and the root is 0 — to keep the stream's counters
+    // (one per possible result) small enough to stay in the L2s
+    std::vector<int32_t> rid((size_t)std::max(n_nodes, 1), -1);
+    for (int32_t v : dn)
+        for (int32_t u = v; rid[(size_t)u] < 0; u = c->parent_host[u]) {
+            rid[(size_t)u] = 0;
+            if (c->parent_host[u] == u) break;
+        }
+    std::vector<int32_t> rnode;
+    for (int32_t v = 0; v < n_nodes; ++v)
+        if (rid[(size_t)v] == 0) {
+            rid[(size_t)v] = (int32_t)rnode.size();
+            rnode.push_back(v);
+        }
+    if (rnode.empty()) rnode.push_back(0);
+    std::vector<int32_t> dsparse(drow * dlevels, 0x7FFFFFFF), dparent(drow, -1), dself(drow, -1);
+    for (uint32_t i = 0; i < md; ++i) {
+        dparent[i] = rid[(size_t)c->parent_host[dn[i]]];
+        dself[i] = rid[(size_t)dn[i]];
+    }
+    for (uint32_t i = 0; i + 1 < md; ++i) {
+        int32_t u = dn[i];
+        while (c->last_host[u] < dn[i + 1]) u = c->parent_host[u];
+        dsparse[i] = rid[(size_t)u];
+    }
+    for (uint32_t k = 1; k < dlevels; ++k)
+        for (uint32_t i = 0; i + (1u << k) <= md - 1; ++i)
+            dsparse[k * drow + i] = std::min(dsparse[(k - 1) * drow + i], dsparse[(k - 1) * drow + i + (1u << (k - 1))]);
     int rc;
     if ((rc = upload(c, c->f_rank, rank.data(), rank.size() * 4))) return rc;
     if ((rc = upload(c, c->f_sparse, sparse.data(), sparse.size() * 4))) return rc;
-    if ((rc = upload(c, c->f_node_rank, node_rank.data(), node_rank.size() * 4))) return rc;
+    if ((rc = upload(c, c->f_rblocks, blocks.data(), blocks.size() * sizeof(RankBlock)))) return rc;
+    if ((rc = upload(c, c->f_dsparse, dsparse.data(), dsparse.size() * 4))) return rc;
+    if ((rc = upload(c, c->f_dparent, dparent.data(), dparent.size() * 4))) return rc;
+    if ((rc = upload(c, c->f_dself, dself.data(), dself.size() * 4))) return rc;
+    if ((rc = upload(c, c->f_rnode, rnode.data(), rnode.size() * 4))) return rc;
+    c->f_results = (uint32_t)rnode.size();
+    c->f_dm = (uint32_t)drow;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors are about to go out of scope
     c->f_m = (uint32_t)row;
     c->free_tree = c->tree_serial;
@@ -508,7 +559,9 @@ int wk_create(int device, wk_ctx** out) {
     }
     // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
     // (160 KiB per CU minus the kernels' few bytes of static LDS)
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 0>),
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
@@ -575,7 +628,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_node_rank, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_rblocks, &c->f_dsparse, &c->f_dparent, &c->f_dself, &c->f_rnode, &c->f_dense, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     c->c_words.release();
     for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
@@ -710,9 +763,14 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         c->free_per_cu = (int)value;
         return WK_OK;
     }
-    if (!strcmp(name, "free_windows")) {
-        if (value != 2 && value != 4 && value != 8) return fail(c, WK_E_ARG, "free_windows must be 2, 4 or 8");
-        c->free_windows = (int)value;
+    if (!strcmp(name, "free_threads")) {
+        if (value != 256 && value != 512 && value != 1024) return fail(c, WK_E_ARG, "free_threads must be 256, 512 or 1024");
+        c->free_threads = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "free_slots")) {
+        if (value < 256 || value > 8192 || (value & (value - 1))) return fail(c, WK_E_ARG, "free_slots must be a power of two in [256, 8192]");
+        c->free_slots = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "words_keep")) {
@@ -1576,47 +1634,42 @@ int wk_words_flush(wk_ctx* c) {
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
     if (c->w_mode == 1) {
-        // ---- one free-rank job: the stream over feature ids + the merge of its miss log
+        // ---- one free-rank job: the stream over feature ids, then its dense counters into the count table
         const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->free_per_cu);
         {
             const int rcf = ensure_free_tables(c);
             if (rcf) return rcf;
         }
         FreeArgs fa{};
-        fa.node_rank = c->f_node_rank.as<int32_t>();
-        fa.sparse = c->f_sparse.as<int32_t>();
-        fa.sparse_m = c->f_m;
+        fa.rblocks = c->f_rblocks.as<RankBlock>();
+        fa.sparse = c->f_dsparse.as<int32_t>();
+        fa.parent_d = c->f_dparent.as<int32_t>();
+        fa.self_d = c->f_dself.as<int32_t>();
+        fa.sparse_m = c->f_dm;
         fa.words = c->c_words.as<uint32_t>();
         fa.n_records = (uint32_t)c->w_records;
-        fa.nodes = c->nodes.as<Node>();
-        fa.n_nodes = (uint32_t)c->n_nodes;
         fa.job = 0;
         fa.group = (uint32_t)c->w_group;
         fa.subok = (c->w_jobs[0].flags & WK_F_SUBOK) ? 1u : 0u;
         fa.unassigned = (c->w_jobs[0].flags & WK_F_UNASSIGNED) ? 1u : 0u;
-        fa.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
-        // distinct results: nodes of the tree; 256 merge tables of 8192 slots hold ~1.3 M keys comfortably
-        fa.log_parts = c->log_parts_opt ? (uint32_t)c->log_parts_opt : ((int64_t)c->n_nodes <= 256 * 5120 ? 256u : kLogPartsMax);
-        const int64_t streams = (int64_t)blocks * fa.log_parts;
-        int64_t cap = 3 * (c->w_reads / streams + 1) + 16;  // one entry per read at most
-        cap = std::max<int64_t>(16, std::min<int64_t>(cap, c->plog_max_bytes / 8 / streams));
-        fa.plog_cap = (uint32_t)cap;
-        HIP_TRY(c, c->plog.reserve((size_t)streams * fa.plog_cap * 8));
-        HIP_TRY(c, c->plog_cnt.reserve((size_t)streams * 4));
-        fa.plog = c->plog.as<unsigned long long>();
-        fa.plog_cnt = c->plog_cnt.as<uint32_t>();
+        const CountTable table{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
+        // the dense counters of the results (zero between flushes: free_counts_kernel clears what it moves)
+        const size_t dense_bytes = ((size_t)c->f_results + 1) * 4;
+        if (c->f_dense.cap < dense_bytes || c->f_dense_tree != c->tree_serial) {  // (otherwise zero: more results never make the cleared range smaller)
+            HIP_TRY(c, c->f_dense.reserve(dense_bytes));
+            HIP_TRY(c, hipMemsetAsync(c->f_dense.p, 0, c->f_dense.cap, c->stream));
+            c->f_dense_tree = c->tree_serial;
+        }
+        fa.dense = c->f_dense.as<uint32_t>();
+        fa.n_results = c->f_results;
         fa.stat_block = c->stat_block.as<unsigned long long>();
         KernelTimer* kt = ktimer_begin(c, "classify");
-        if (c->free_windows == 8)
-            hipLaunchKernelGGL(free_stream_kernel<8>, dim3(blocks), dim3(kFreeThreads), (size_t)fa.log_parts * 4, c->stream, fa);
-        else if (c->free_windows == 2)
-            hipLaunchKernelGGL(free_stream_kernel<2>, dim3(blocks), dim3(kFreeThreads), (size_t)fa.log_parts * 4, c->stream, fa);
-        else
-            hipLaunchKernelGGL(free_stream_kernel<4>, dim3(blocks), dim3(kFreeThreads), (size_t)fa.log_parts * 4, c->stream, fa);
+        const size_t lds = (size_t)c->free_slots * 8 + (size_t)(c->free_threads / 64) * kFreeWaveLds;
+        hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, (uint32_t)c->free_slots);
         ktimer_end(c, kt);
-        kt = ktimer_begin(c, "partition_merge");
-        hipLaunchKernelGGL(partition_merge_kernel, dim3(fa.log_parts), dim3(1024), (size_t)8192 * 16, c->stream,
-                           c->plog.as<unsigned long long>(), c->plog_cnt.as<uint32_t>(), (uint32_t)blocks, fa.plog_cap, 8192u, fa.table);
+        kt = ktimer_begin(c, "free_counts");
+        hipLaunchKernelGGL(free_counts_kernel, dim3((c->f_results + 256) / 256), dim3(256), 0, c->stream, fa.dense, fa.n_results,
+                           c->f_rnode.as<int32_t>(), fa.job, fa.group, table);
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
         if (c->words_keep) return WK_OK;
