@@ -324,8 +324,8 @@ class OrdinalWorkload:
     key = 'ordinal'
     dominant = 'match_count'
     symbols = {'match_count': 'wk::match_hits_kernel<true, false>',
-               'classify': 'wk::ordinal_tally_kernel',
-               'partition_merge': 'wk::partition_merge_kernel'}
+               'classify': 'wk::ordinal_tally_kernel<true>',
+               'partition_merge': 'wk::range_merge_kernel'}
 
     def __init__(self, ctx, seed, scale=1.0):
         self.ctx = ctx
@@ -348,7 +348,7 @@ class OrdinalWorkload:
         self.alg_bytes = 20 * self.records + 16 * p['gstart'].size + \
             int(6.4 * self.records)
         self.launch_bytes = self.alg_bytes
-        # match_hits -> ordinal_tally -> partition_merge (wk_ordinal_count; the
+        # match_hits -> ordinal_tally -> range_merge (wk_ordinal_count; the
         # gene-list kernels only run for reads the tally leaves over)
         self.families = ('match_count', 'classify', 'partition_merge')
         self._steps = 0
@@ -363,10 +363,10 @@ class OrdinalWorkload:
                 8 * p['gstart'].size
         if family == 'match_write':     # hits + counts in, offsets + pairs out
             return 24 * self.records + tables + 4 * self.records + 4 * pairs
-        if family == 'partition_merge':
-            return 0
+        if family == 'partition_merge':  # the log's 4-byte entries in
+            return 4 * pairs
         # tally: read offsets + the matches of every hit in, log entries out
-        return 4 * (self.reads + 1) + 8 * self.records + 8 * pairs
+        return 4 * (self.reads + 1) + 8 * self.records + 4 * pairs
 
     def step(self):
         self._steps += 1

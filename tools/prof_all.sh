@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 kernel stats + PMC passes (tools/prof_bench.sh) of every bench
+# workload; results under gpurun_out/<tag>_<workload>/
+#   tools/prof_all.sh <tag> [workloads...]
+tag=${1:-r03prof}; shift
+wls=${*:-"lca lca_free ordinal flat"}
+for wl in $wls; do
+  case $wl in
+    lca) kern=weigh_bins ;;
+    lca_free) kern=free_stream ;;
+    ordinal) kern=match_hits ;;
+    flat) kern=count_subjects ;;
+  esac
+  echo "== $wl ($kern)"
+  bash tools/prof_bench.sh ${tag}_$wl $wl 1.0 $kern 2>&1 | tail -12
+done

@@ -1333,17 +1333,30 @@ __global__ void __launch_bounds__(1024) partition_merge_kernel(const unsigned lo
     cache.bmask = lds_slots / 4 - 1;
     lds_cache_init(cache);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
-    for (uint32_t row = wave; row < n_rows; row += n_waves) {  // one stream per wave at a time
-        const uint32_t n = plog_cnt[(size_t)row * n_parts + part];
+    // one stream per wave at a time; streams are short, so the next one's length is
+    // fetched while this one is counted and its entries are loaded four to a lane
+    // before the first is used (kEmptyKey is no entry: a lane past the end)
+    uint32_t n = wave < n_rows ? plog_cnt[(size_t)wave * n_parts + part] : 0u;
+    for (uint32_t row = wave; row < n_rows; row += n_waves) {
+        const uint32_t next = row + n_waves;
+        const uint32_t n_next = next < n_rows ? plog_cnt[(size_t)next * n_parts + part] : 0u;
         const unsigned long long* src = plog + ((size_t)row * n_parts + part) * plog_cap;
-        for (uint32_t i = lane; i < n; i += 64) {
-            // an entry with k in [1, 16] is one contribution to the weighted key
-            const unsigned long long e = src[i];
-            const uint32_t k = (uint32_t)(e >> 49) & (uint32_t)WK_MAX_K;
-            const bool weighted = k >= 1u && k <= (uint32_t)WK_WEIGHT_MAX_K;
-            cached_add(cache, table, weighted ? (e & ~kKeyKMask) : e,
-                       weighted ? (unsigned long long)weight_of(k) : 1ull);
+        for (uint32_t i = lane; i < n; i += 256) {
+            unsigned long long ev[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) ev[u] = i + 64 * u < n ? src[i + 64 * u] : kEmptyKey;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                if (ev[u] == kEmptyKey) continue;
+                // an entry with k in [1, 16] is one contribution to the weighted key
+                const unsigned long long e = ev[u];
+                const uint32_t k = (uint32_t)(e >> 49) & (uint32_t)WK_MAX_K;
+                const bool weighted = k >= 1u && k <= (uint32_t)WK_WEIGHT_MAX_K;
+                cached_add(cache, table, weighted ? (e & ~kKeyKMask) : e,
+                           weighted ? (unsigned long long)weight_of(k) : 1ull);
+            }
         }
+        n = n_next;
     }
     lds_cache_flush(cache, table);
 }

@@ -344,6 +344,8 @@ struct TallyArgs {
     uint32_t* plog_cnt;        // [gridDim.x][log_parts]
     uint32_t plog_cap;
     uint32_t log_parts;
+    uint32_t* plog32;          // kRange: the log as 4-byte entries, gene | n << 28
+                               // (partition = the gene's low bits: log_parts is a power of two)
     unsigned long long* stat_block;
     unsigned long long* left_mask;  // [ceil(n_reads / 64)]
     unsigned long long* n_left;  // [2]: reads left over, pairs of the tallied reads
@@ -352,6 +354,15 @@ struct TallyArgs {
 constexpr uint32_t kTallyThreads = 512;
 constexpr uint32_t kTallyQueue = 3072;  // reads with several hits wait here until a full workgroup's worth is queued
 
+// kRange (one job; gene ids below 2^28, at most 4096 per partition): the genes of
+// a chunk are ~10^5..10^6 keys, so an LDS hash cache in front of the log holds
+// next to none of them and its probes are most of this kernel's time.  Every
+// {gene, n} goes to the log instead, as one 4-byte entry, into the partition its
+// low bits name (neighbouring genes — one abundant genome — spread over all
+// partitions; partitions by gene *range* were 4x slower: a few streams overflow
+// and their cursors serialise); range_merge_kernel then adds a partition up in a
+// dense LDS array indexed by the high bits — no hashing on either side.
+template <bool kRange>
 __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long acc[3];
@@ -369,12 +380,20 @@ __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs 
     for (uint32_t i = threadIdx.x; i < a.log_parts; i += blockDim.x) cache.plog_cur[i] = 0u;
     if (threadIdx.x < 3) acc[threadIdx.x] = 0ull;
     if (threadIdx.x == 0) q_n = 0u;
-    lds_cache_init(cache);  // (ends with a barrier)
+    lds_cache_init(cache);  // (ends with a barrier; lds_slots = 0 under kRange: no cache)
     const bool one_job = a.n_jobs == 1;
     const uint32_t job0 = (uint32_t)a.job_index[0];
+    uint32_t* const plog32 = a.plog32 + (size_t)blockIdx.x * a.log_parts * a.plog_cap;
     auto add_key = [&](uint64_t key, uint32_t n) { cached_add(cache, a.table, key, (unsigned long long)weight_of(n)); };
     auto add = [&](int32_t feature, uint32_t n) {
-        if (one_job) {
+        if constexpr (kRange) {
+            const uint32_t part = (uint32_t)feature & (a.log_parts - 1u);
+            const uint32_t pos = atomicAdd(&cache.plog_cur[part], 1u);
+            if (pos < a.plog_cap)
+                plog32[(size_t)part * a.plog_cap + pos] = (uint32_t)feature | (n << 28);
+            else  // the stream is full: count in HBM directly
+                table_add(a.table, make_key(job0, 0u, (uint32_t)a.group, (uint32_t)feature), (unsigned long long)weight_of(n));
+        } else if (one_job) {
             add_key(make_key(job0, 0u, (uint32_t)a.group, (uint32_t)feature), n);
         } else {
             for (int32_t jb = 0; jb < a.n_jobs; ++jb)
@@ -486,7 +505,10 @@ __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs 
         atomicAdd(&acc[1], my_records);
         atomicAdd(&acc[2], my_left);
     }
-    lds_cache_flush(cache, a.table);  // (starts with a barrier)
+    if constexpr (kRange)
+        __syncthreads();
+    else
+        lds_cache_flush(cache, a.table);  // (starts with a barrier)
     if (threadIdx.x == 0) {
         a.stat_block[2 * blockIdx.x] += acc[0];
         a.stat_block[2 * blockIdx.x + 1] += acc[1];
@@ -497,6 +519,42 @@ __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs 
         const uint32_t n = cache.plog_cur[i];
         a.plog_cnt[(size_t)blockIdx.x * a.log_parts + i] = n < a.plog_cap ? n : a.plog_cap;
     }
+}
+
+// The log of ordinal_tally_kernel<true>: workgroup p adds up the entries of
+// partition p — the genes g with g mod n_parts = p — from every stream in a dense
+// LDS array of weights indexed by g / n_parts, and puts the genes that were hit
+// into the count table.
+__global__ void __launch_bounds__(1024) range_merge_kernel(const uint32_t* __restrict__ plog32, const uint32_t* __restrict__ plog_cnt,
+                                                           uint32_t n_rows, uint32_t plog_cap, uint32_t span, uint32_t job,
+                                                           uint32_t group, CountTable table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* const sum = reinterpret_cast<unsigned long long*>(smem);
+    const uint32_t part = blockIdx.x, n_parts = gridDim.x, shift = 31u - (uint32_t)__clz((int)n_parts);
+    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) sum[i] = 0ull;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    // one stream per wave at a time; a stream is short (~n_hits / (rows x parts)
+    // entries), so the next one's length is fetched while this one is added up,
+    // and its entries are loaded four to a lane before the first is used
+    uint32_t n = wave < n_rows ? plog_cnt[(size_t)wave * n_parts + part] : 0u;
+    for (uint32_t row = wave; row < n_rows; row += n_waves) {
+        const uint32_t next = row + n_waves;
+        const uint32_t n_next = next < n_rows ? plog_cnt[(size_t)next * n_parts + part] : 0u;
+        const uint32_t* src = plog32 + ((size_t)row * n_parts + part) * plog_cap;
+        for (uint32_t i = lane; i < n; i += 256) {
+            uint32_t e[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) e[u] = i + 64 * u < n ? src[i + 64 * u] : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                if (e[u]) atomicAdd(&sum[(e[u] & 0x0FFFFFFFu) >> shift], (unsigned long long)weight_of(e[u] >> 28));
+        }
+        n = n_next;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x)
+        if (sum[i]) table_add(table, make_key(job, 0u, group, (i << shift) | part), sum[i]);
 }
 
 }  // namespace wk

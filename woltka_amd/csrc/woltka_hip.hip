@@ -185,6 +185,8 @@ struct wk_ctx {
     bool w_open = false;
     int w_mode = 0;  // 0: subject indices for the weighted histogram, 1: feature ids for the free-rank stream (wk_free.hpp)
     int free_per_cu = 2, free_threads = 1024, free_slots = 4096;  // launch shape of the free-rank stream (measurement knobs)  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
+    int32_t max_gene_feature = 0;
+    int use_range_log = 1;  // (0: the hashed miss log for the gene tally too; measurement)
     int words_keep = 0;  // measurement: wk_words_flush leaves the accumulated records in place
     static constexpr int kStageSlots = 8;
     hipEvent_t slot_ev[kStageSlots] = {};
@@ -763,6 +765,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         c->free_per_cu = (int)value;
         return WK_OK;
     }
+    if (!strcmp(name, "range_log")) {
+        c->use_range_log = value != 0;
+        return WK_OK;
+    }
     if (!strcmp(name, "free_threads")) {
         if (value != 256 && value != 512 && value != 1024) return fail(c, WK_E_ARG, "free_threads must be 256, 512 or 1024");
         c->free_threads = (int)value;
@@ -912,6 +918,8 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_genomes = n_genomes;
     c->n_genes = n_genes;
+    c->max_gene_feature = 0;
+    for (int32_t i = 0; i < n_genes; ++i) c->max_gene_feature = std::max(c->max_gene_feature, gene_feature[i]);
     return WK_OK;
 }
 
@@ -2380,32 +2388,52 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     for (int j = 0; j < n_jobs; ++j) t.job_index[j] = j;
     t.group = c->group_base;
     t.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
+    // one job over gene ids with at most 4096 per partition: the dense log (wk_ordinal.hpp)
+    const uint32_t range_parts = ((int64_t)c->max_gene_feature >> 8) < 4096 ? 256u : kLogPartsMax;
+    const uint32_t range_span = (uint32_t)(c->max_gene_feature / (int32_t)range_parts) + 1u;
+    const bool by_range = c->use_range_log && n_jobs == 1 && range_span <= 4096u && c->max_gene_feature < (1 << 28);
     // distinct keys: the genes (256 merge tables of 8192 slots hold ~1.3 M at a comfortable load)
-    t.log_parts = c->log_parts_opt ? (uint32_t)c->log_parts_opt : ((int64_t)c->n_genes * n_jobs <= 256 * 5120 ? 256u : kLogPartsMax);
+    if (by_range)
+        t.log_parts = range_parts;
+    else
+        t.log_parts = c->log_parts_opt ? (uint32_t)c->log_parts_opt : ((int64_t)c->n_genes * n_jobs <= 256 * 5120 ? 256u : kLogPartsMax);
     const int64_t streams = (int64_t)blocks * t.log_parts;
+    const size_t entry = by_range ? 4 : 8;
     // every gene of a hit is one entry: hits with a gene rarely have two
     int64_t cap = 3 * (c->n_hits * (int64_t)n_jobs / streams + 1) + 16;
-    cap = std::max<int64_t>(16, std::min<int64_t>(cap, c->plog_max_bytes / 8 / streams));
+    cap = std::max<int64_t>(16, std::min<int64_t>(cap, c->plog_max_bytes / (int64_t)entry / streams));
     t.plog_cap = (uint32_t)cap;
-    HIP_TRY(c, c->plog.reserve((size_t)streams * t.plog_cap * 8));
+    HIP_TRY(c, c->plog.reserve((size_t)streams * t.plog_cap * entry));
     HIP_TRY(c, c->plog_cnt.reserve((size_t)streams * 4));
     HIP_TRY(c, c->left_mask.reserve((size_t)n_words * 8));
     t.plog = c->plog.as<unsigned long long>();
+    t.plog32 = c->plog.as<uint32_t>();
     t.plog_cnt = c->plog_cnt.as<uint32_t>();
     t.stat_block = c->stat_block.as<unsigned long long>();
     t.left_mask = c->left_mask.as<unsigned long long>();
     t.n_left = scalar_u64(c, 7);
     HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 7), 0, 16, c->stream));
     kt = ktimer_begin(c, "classify");
-    // LDS per workgroup (three per CU): 16 KiB hash cache + log cursors + 12 KiB queue + 16 KiB of gene sets
-    const uint32_t tally_slots = (uint32_t)std::max(256, std::min(c->tally_slots, 4096));
-    const size_t tally_lds = (size_t)tally_slots * 16 + (size_t)t.log_parts * 4 + (size_t)kTallyQueue * 4 + (size_t)kTallySlots * kTallyThreads * 4;
-    hipLaunchKernelGGL(ordinal_tally_kernel, dim3(blocks), dim3(kTallyThreads), tally_lds, c->stream, t, tally_slots);
-    ktimer_end(c, kt);
-    kt = ktimer_begin(c, "partition_merge");
-    hipLaunchKernelGGL(partition_merge_kernel, dim3(t.log_parts), dim3(1024), (size_t)8192 * 16, c->stream,
-                       c->plog.as<unsigned long long>(), c->plog_cnt.as<uint32_t>(), (uint32_t)blocks, t.plog_cap, 8192u, t.table);
-    ktimer_end(c, kt);
+    if (by_range) {
+        // LDS per workgroup: log cursors + 12 KiB queue + 16 KiB of gene sets
+        const size_t tally_lds = (size_t)t.log_parts * 4 + (size_t)kTallyQueue * 4 + (size_t)kTallySlots * kTallyThreads * 4;
+        hipLaunchKernelGGL(ordinal_tally_kernel<true>, dim3(blocks), dim3(kTallyThreads), tally_lds, c->stream, t, 0u);
+        ktimer_end(c, kt);
+        kt = ktimer_begin(c, "partition_merge");
+        hipLaunchKernelGGL(range_merge_kernel, dim3(t.log_parts), dim3(1024), (size_t)8 * range_span, c->stream, t.plog32,
+                           t.plog_cnt, (uint32_t)blocks, t.plog_cap, range_span, 0u, (uint32_t)t.group, t.table);
+        ktimer_end(c, kt);
+    } else {
+        // LDS per workgroup (three per CU): 16 KiB hash cache + log cursors + 12 KiB queue + 16 KiB of gene sets
+        const uint32_t tally_slots = (uint32_t)std::max(256, std::min(c->tally_slots, 4096));
+        const size_t tally_lds = (size_t)tally_slots * 16 + (size_t)t.log_parts * 4 + (size_t)kTallyQueue * 4 + (size_t)kTallySlots * kTallyThreads * 4;
+        hipLaunchKernelGGL(ordinal_tally_kernel<false>, dim3(blocks), dim3(kTallyThreads), tally_lds, c->stream, t, tally_slots);
+        ktimer_end(c, kt);
+        kt = ktimer_begin(c, "partition_merge");
+        hipLaunchKernelGGL(partition_merge_kernel, dim3(t.log_parts), dim3(1024), (size_t)8192 * 16, c->stream,
+                           c->plog.as<unsigned long long>(), c->plog_cnt.as<uint32_t>(), (uint32_t)blocks, t.plog_cap, 8192u, t.table);
+        ktimer_end(c, kt);
+    }
     HIP_TRY(c, hipGetLastError());
     unsigned long long left_pairs[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(left_pairs, scalar_u64(c, 7), 16, hipMemcpyDeviceToHost, c->stream));
