@@ -133,6 +133,51 @@ def test_rounding_matches_reference():
         workflow.scale_factor('abc')
 
 
+def test_rounding_in_bulk_equals_the_cell_rule():
+    """Samples of more than 256 plain numbers are rounded in numpy
+    (workflow._round_bulk): the same cells, values, types and order as
+    util.round_dict's rule (woltka/util.py:342-348) cell by cell — and the
+    golden values of the reference, repeated past the threshold."""
+    import random
+    rnd = random.Random(7)
+
+    def by_cell(sample):
+        out = {}
+        for k, x in sample.items():
+            r = x if type(x) is int else workflow.round_half_snap(x)
+            if r:
+                out[k] = r
+        return out
+    for trial in range(60):
+        sample = {}
+        for i in range(rnd.choice([257, 1000, 4000])):
+            c = rnd.random()
+            if c < 0.2:
+                x = rnd.randint(0, 5)
+            elif c < 0.4:
+                x = rnd.randint(0, 10 ** 6) / 2
+            elif c < 0.6:
+                x = rnd.randint(0, 60) / rnd.choice([3, 5, 6, 7, 12])
+            elif c < 0.75:      # around the snap threshold of a half
+                x = rnd.randint(0, 10) + 0.5 + rnd.choice([-1, 1]) * rnd.choice(
+                    [1e-7, 9e-8, 1.1e-7, 1e-8, 2e-7])
+            else:
+                x = rnd.random() * rnd.choice([1, 1e3, 1e9, 4e15 if trial % 5 == 0 else 1e12])
+            sample[f'f{i}'] = x
+        exp = by_cell(sample)
+        data = {'r': {'s': dict(sample)}}
+        workflow.round_profiles(data)
+        got = data['r']['s']
+        assert list(got.items()) == list(exp.items())
+        assert all(type(x) is int for x in got.values())
+    v = load_vectors('glue.json')
+    many = {f'{i}_{rep}': x for rep in range(40) for i, x in enumerate(v['values'])}
+    data = {'r': {'s': dict(many)}}
+    workflow.round_profiles(data)
+    exp = v['rounds']['None']
+    assert data['r']['s'] == {f'{i}_{rep}': exp[i] for rep in range(40) for i in exp}
+
+
 def test_gene_coords_match_reference():
     v = load_vectors('host.json')
     small = v['small']

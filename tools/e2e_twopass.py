@@ -15,11 +15,13 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from woltka_amd import workflow  # noqa: E402
 from woltka_amd.synth import zipf_draw  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reads', type=int, default=2_000_000)
+    ap.add_argument('--samples', type=int, default=1)
     ap.add_argument('--dir', default=tempfile.gettempdir())
     a = ap.parse_args()
     d = os.path.join(a.dir, f'twopass_{a.reads}')
@@ -31,14 +33,12 @@ def main():
     with open(os.path.join(d, 'genus.map'), 'w') as f:
         for s in range(n_subj):
             f.write(f'G{s:09d}\tGenus{genus[s]:05d}\n')
-    sub = zipf_draw(rng, n_subj, a.reads)
-    fp = os.path.join(d, 'aln', 'S1.sam')
-    with open(fp, 'wb') as f:
-        for lo in range(0, a.reads, 1_000_000):
-            hi = min(a.reads, lo + 1_000_000)
-            f.write(b''.join(b'R%09d\t0\tG%09d\t%d\t42\t150M\t*\t0\t0\t*\t*\n'
-                             % (i, s, 1 + i % 4000000)
-                             for i, s in zip(range(lo, hi), sub[lo:hi].tolist())))
+    import bench
+    for k in range(a.samples):
+        sub = zipf_draw(rng, n_subj, a.reads)
+        bench.write_sam(os.path.join(d, 'aln', f'S{k + 1}.sam'), np.arange(a.reads, dtype=np.int64), sub,
+                        sprefix=b'G', swidth=9, pos=1 + np.arange(a.reads, dtype=np.int64) % 4000000)
+    total = a.reads * a.samples
 
     def run(**kw):
         t0 = time.perf_counter()
@@ -49,12 +49,12 @@ def main():
 
     t1, d1 = run(out=os.path.join(d, 'genus.tsv'), map_fps=[os.path.join(d, 'genus.map')],
                  map_rank=None, ranks='genus', outmap_dir=os.path.join(d, 'maps'))
-    print(f'pass 1 (genus + --outmap): {a.reads / t1 / 1e6:.2f} M records/s in {t1:.2f} s')
+    print(f'pass 1 (genus + --outmap): {total / t1 / 1e6:.2f} M records/s in {t1:.2f} s ({a.samples} x {a.reads} reads)')
     t2, d2 = run(out=os.path.join(d, 'strat.tsv'), ranks='none',
                  strata_dir=os.path.join(d, 'maps'))
-    print(f'pass 2 (none + --stratify): {a.reads / t2 / 1e6:.2f} M records/s in {t2:.2f} s')
-    tot1 = sum(d1['genus']['S1'].values())
-    tot2 = sum(d2['none']['S1'].values())
+    print(f'pass 2 (none + --stratify): {total / t2 / 1e6:.2f} M records/s in {t2:.2f} s')
+    tot1 = sum(sum(v.values()) for v in d1['genus'].values())
+    tot2 = sum(sum(v.values()) for v in d2['none'].values())
     print('counted', tot1, tot2)
     shutil.rmtree(d, ignore_errors=True)
 

@@ -212,6 +212,49 @@ _NO_TREE_ROOT = '\x00root'      # stand-in root when no hierarchy is given
 MAX_GROUPS = 1 << nat.KEY_GROUP_BITS
 
 
+# The first HIP call of a process sets the runtime up (~0.1 s): `workflow` starts
+# it on a thread while the hierarchy and the gene coordinates are read, and the
+# engine picks the context up (`open_context_ahead`, `_take_context`).
+_ahead = {}
+
+
+def open_context_ahead(device):
+    """Create the device context of `device` on a thread; ``Engine`` takes it.
+    Errors surface where the engine would have met them."""
+    import threading
+    if device in _ahead:
+        return
+    box = {}
+
+    def work():
+        try:
+            box['ctx'] = nat.Context(device)
+        except Exception as e:          # raised again by _take_context
+            box['err'] = e
+    th = threading.Thread(target=work, name='wk-context', daemon=True)
+    _ahead[device] = (th, box)
+    th.start()
+
+
+def _take_context(device):
+    th, box = _ahead.pop(device, (None, None))
+    if th is None:
+        return nat.Context(device)
+    th.join()
+    if 'err' in box:
+        raise box['err']
+    return box['ctx']
+
+
+def drop_context_ahead():
+    """Close contexts opened ahead that no engine took (an error on the way)."""
+    for device in list(_ahead):
+        try:
+            _take_context(device).close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One classification job on one GPU.
 
@@ -224,7 +267,7 @@ class Engine:
     def __init__(self, tree, rankdic, root, ranks, uniq=False, major=None,
                  above=False, subok=False, unasgd=False, device=0,
                  table_slots=None, sizes=None, major_frac=None):
-        self.ctx = nat.Context(device)
+        self.ctx = _take_context(device)
         self.ranks = list(ranks)
         self.use_tree = bool(tree)
         native = getattr(tree, 'native', None)

@@ -51,7 +51,7 @@ def prep_table(profile, samples=None, tree=None, rankdic=None, namedic=None,
     data, features, metadata = [], [], []
     keys = sorted(allkeys(profile))
     if not metacols and not (namedic and name_as_id) and \
-            all(type(k) is str for k in keys):
+            set(map(type, keys)) <= {str}:
         # the usual profile — plain feature ids, no metadata columns — without
         # a Python loop body per feature: C-level lookups per sample, rows
         # that are all zero dropped (table.py:115)

@@ -107,6 +107,30 @@ def _workflow(input_fp, output_fp, input_fmt, input_ext, samples, demux,
     samples, files, demux = parse_samples(input_fp, input_ext, samples, demux)
     exclude = parse_exclude(exclude)
     stratmap = parse_strata(strata_dir, samples)
+    # (the device context comes up while the inputs below are read)
+    from . import classify as _classify
+    if env_rank()[2] == 1:
+        _classify.open_context_ahead(device)
+    try:
+        return _workflow_with_context(
+            samples, files, demux, exclude, stratmap, zippers, output_fp,
+            input_fmt, trimsub, nodes_fps, newick_fps, lineage_fps,
+            columns_fps, map_fps, map_rank, names_fps, ranks, uniq, major,
+            above, subok, coords_fp, overlap, sizes, frac, scale, digits,
+            output_fmt, unassigned, name_as_id, add_rank, add_lineage,
+            outmap_dir, outmap_zip, outcov_dir, outcov_fmt, chunk, cache,
+            device)
+    finally:
+        _classify.drop_context_ahead()
+
+
+def _workflow_with_context(
+        samples, files, demux, exclude, stratmap, zippers, output_fp,
+        input_fmt, trimsub, nodes_fps, newick_fps, lineage_fps, columns_fps,
+        map_fps, map_rank, names_fps, ranks, uniq, major, above, subok,
+        coords_fp, overlap, sizes, frac, scale, digits, output_fmt,
+        unassigned, name_as_id, add_rank, add_lineage, outmap_dir, outmap_zip,
+        outcov_dir, outcov_fmt, chunk, cache, device):
     tree, rankdic, namedic, root = build_hierarchy(
         names_fps, nodes_fps, newick_fps, lineage_fps, columns_fps, map_fps,
         map_rank, zippers)
@@ -828,12 +852,43 @@ def round_half_snap(value, digits=None):
     return round(value, digits)
 
 
+def _round_bulk(sample):
+    """`round_half_snap` (no digits) over a whole sample in numpy; False when
+    the cells are not plain numbers below 2^52.  Binary64 arithmetic is the
+    same in both (``* 2`` and ``/ 2`` are exact, ``round`` of a float and
+    ``rint`` both round half to even)."""
+    import numpy as np
+    vals = list(sample.values())
+    if not set(map(type, vals)) <= {int, float}:
+        return False
+    try:
+        v = np.array(vals, dtype=np.float64)
+    except (OverflowError, ValueError):
+        return False
+    if not np.all(np.abs(v) < 2.0 ** 52):   # (also False for nan / inf)
+        return False
+    near = np.rint(v * 2) / 2
+    r = np.where(np.abs(v - near) <= 1e-7, np.rint(near), np.rint(v))
+    r = r.astype(np.int64)
+    keep = r != 0
+    keys = list(sample)
+    sample.clear()
+    if keep.all():
+        sample.update(zip(keys, r.tolist()))
+    else:
+        from itertools import compress
+        sample.update(zip(compress(keys, keep.tolist()), r[keep].tolist()))
+    return True
+
+
 def round_profiles(data, digits=None):
     """Round cells, drop zeros (workflow.py:1106-1119, util.round_dict).  An
     ``int`` cell rounds to itself (``round(v * 2) / 2 == v``), so only the
     other cells go through the rule."""
     for profile in data.values():
         for sample in profile.values():
+            if not digits and len(sample) > 256 and _round_bulk(sample):
+                continue
             dead = []
             for feature, value in sample.items():
                 if type(value) is int and not digits:
