@@ -319,6 +319,46 @@ class LcaFreeWorkload(LcaWorkload):
         self.packed = True
 
 
+class LcaOptionWorkload(LcaWorkload):
+    """configs[2] under an assignment option that looks at whole reads —
+    `--above`, `--major 80`, `--uniq` at rank genus: the product's route, the
+    per-read stream over the packed records (csrc/wk_free.hpp, the records
+    carry the subjects' ancestors at the rank), one launch per sample."""
+    dominant = 'classify'
+    families = ('classify', 'free_counts')
+    symbols = {'classify': 'wk::free_stream_kernel',
+               'free_counts': 'wk::free_counts_kernel'}
+
+    def __init__(self, ctx, option, share):
+        self.ctx, self.prob = ctx, share.prob
+        self.records, self.reads = share.records, share.reads
+        self.key = f'lca_{option}'
+        self.name = share.name.replace('ranks phylum,genus,species',
+                                       f'rank genus --{option}')
+        h = self.prob['hier']
+        ctx.build_rank_table(1, h.rank_codes['genus'])
+        flags = {'above': nat.F_ABOVE, 'uniq': nat.F_UNIQ, 'major': 0}[option]
+        self.jobs = [nat.Job(nat.MODE_RANK, 1, flags, 0,
+                             0.8 if option == 'major' else 0.0)]
+        self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
+                          8 * h.n_nodes + 4 * h.n_nodes)
+        self.launch_bytes = self.alg_bytes
+        sidx = subject_indices(self.prob)[1]
+        words = packed_words(sidx, self.prob['qoff'])
+        del sidx
+        ctx.set_option('words_keep', 0)
+        ctx.counts_clear()
+        ctx.set_option('words_keep', 1)
+        if not ctx.words_begin(self.jobs, 0):
+            raise RuntimeError('the per-read stream refused the job')
+        step = 6_000_000
+        off = self.prob['qoff']
+        for lo in range(0, self.reads, step):
+            hi = min(self.reads, lo + step)
+            ctx.words_append(words[int(off[lo]):int(off[hi])], hi - lo)
+        self.packed = True
+
+
 class OrdinalWorkload:
     """configs[3]: coord-match + gene histogram."""
     key = 'ordinal'
@@ -1042,6 +1082,16 @@ def side_blocks(a, line, wl, ctx, dev):
             ctx.counts_clear()
         except Exception as e:      # a side block must not cost the headline
             configs['lca_free'] = {'error': repr(e)}
+        for option in ('above', 'major', 'uniq'):
+            try:
+                opt = LcaOptionWorkload(ctx, option, wl)
+                p2 = passes_for(opt, a.steps, 0.5)
+                t = timed_steps(opt, a.steps, 1, p2, NoSync())
+                configs[opt.key] = config_block(opt, t, p2, a.steps, a.scale,
+                                                opt.key)
+                ctx.counts_clear()
+            except Exception as e:
+                configs[f'lca_{option}'] = {'error': repr(e)}
         if not a.no_e2e:
             try:
                 e2e['lca'] = e2e_leg('lca', wl.prob, wl.reads, dev,

@@ -166,8 +166,12 @@ def test_words_api_conservation_and_wraps(ctx):
         # job sets the histogram does not take
         assert not c.words_begin([nat.Job(nat.MODE_FREE, 0, 0, 0, 0.0),
                                   nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)], 0)
-        assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, nat.F_UNIQ, 0, 0.0)], 0)
-        assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, 0, 0, 0.6)], 0)
+        # (one rank job that looks at whole reads goes to the per-read stream;
+        # next to other jobs, or with a threshold that two values can reach, not)
+        assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, nat.F_UNIQ, 0, 0.0),
+                                  nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)], 0)
+        assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, 0, 0, 0.5)], 0)
+        assert not c.words_begin([nat.Job(nat.MODE_RANK, 0, nat.F_UNIQ | nat.F_SIZED, 0, 0.0)], 0)
         with pytest.raises(RuntimeError):
             c.words_append(words[:10], 1)
 
@@ -208,6 +212,92 @@ def test_free_rank_stream_equals_general_route(tmp_path, opts, dtok):
         os.environ.pop('WOLTKA_NO_DTOK', None)
     assert list(a.values()) == list(b.values()) and log_a == log_b
     assert len(next(iter(a.values()))) > 1000
+
+
+@pytest.mark.parametrize('opts', [dict(uniq=True), dict(above=True),
+                                  dict(major=80), dict(major=51, unassigned=True),
+                                  dict(above=True, unassigned=True)])
+@pytest.mark.parametrize('dtok', [True, False])
+def test_rank_option_stream_equals_general_route(tmp_path, opts, dtok):
+    """One rank under --uniq / --above / --major goes through the per-read
+    stream over packed records (csrc/wk_free.hpp, mode 2: the records carry
+    the subjects' ancestors at the rank) and must write what the general
+    evaluator writes; the second sample has subjects outside the tree."""
+    import bench
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    p = _problem(37, 300_000)
+    bench.write_sam_lca(str(indir / 'S1.sam'), p, 300_000)
+    sam = str(indir / 'S2.sam')
+    bench.write_sam_lca(sam, p, 80_000)
+    with open(sam, 'ab') as f:
+        for i in range(3000):
+            f.write(b'X%06d\t0\tstranger_%d\t1\t42\t150M\t*\t0\t0\t*\t*\n'
+                    % (i, i % 5))
+            if i % 3:
+                f.write(b'X%06d\t0\tT%07d\t1\t42\t150M\t*\t0\t0\t*\t*\n'
+                        % (i, int(p['subj'][i])))
+    nodes = str(tmp_path / 'nodes.dmp')
+    bench.write_nodes_dmp(nodes, p['hier'])
+    for rank in ('genus', 'phylum'):
+        kw = dict(input_fp=str(indir), input_fmt='sam', nodes_fps=[nodes],
+                  ranks=rank, **opts)
+        if not dtok:
+            os.environ['WOLTKA_NO_DTOK'] = '1'
+        try:
+            a, log_a = _run(tmp_path, 'w', False, **kw)
+            b, log_b = _run(tmp_path, 'g', True, **kw)
+        finally:
+            os.environ.pop('WOLTKA_NO_DTOK', None)
+        assert list(a.values()) == list(b.values()) and log_a == log_b
+        assert len(next(iter(a.values()))) > 5
+
+
+def test_rank_option_stream_is_taken(ctx):
+    """wk_words_begin accepts one rank job under --uniq / --above / --major
+    > 0.5 (mode 2 of the per-read stream) and its flush equals the general
+    evaluator on the same chunk, also after the subject table has grown."""
+    from woltka_amd import _native as nat
+    from woltka_amd import synth
+    rng = np.random.default_rng(8)
+    p = synth.as_sets(synth.lca_problem(rng, n_nodes=30000, n_subjects=2000,
+                                        n_reads=1_000_000, with_names=False,
+                                        offtree_frac=0.01))
+    h = p['hier']
+    feats, sidx = np.unique(p['subj'], return_inverse=True)
+    off = p['qoff'].astype(np.int64)
+    size = np.diff(off)
+    words = (sidx.astype(np.uint32) |
+             ((np.arange(sidx.size) - np.repeat(off[:-1], size)).astype(np.uint32) << np.uint32(23)) |
+             (np.repeat(size, size).astype(np.uint32) << np.uint32(27)))
+    half = off.size // 2
+    for rank in ('genus', 'class'):
+        for flags, major in ((nat.F_UNIQ, 0.0), (nat.F_ABOVE, 0.0), (0, 0.8),
+                             (nat.F_UNASSIGNED, 0.51),
+                             (nat.F_ABOVE | nat.F_UNASSIGNED, 0.0)):
+            with nat.Context(0) as c:
+                c.set_tree(h.parent, h.last, h.rank_code)
+                c.build_rank_table(2, h.rank_codes[rank])
+                c.counts_reserve(1 << 18)
+                jobs = [nat.Job(nat.MODE_RANK, 2, flags, 0, major)]
+                # the first half while only the subjects seen so far are known
+                seen = int(sidx[:int(off[half])].max()) + 1
+                c.set_subjects(feats[:seen].astype(np.int32))
+                assert c.words_begin(jobs, 2)
+                c.words_append(words[:int(off[half])], half)
+                c.set_subjects(feats.astype(np.int32))
+                assert c.words_begin(jobs, 2)
+                c.words_append(words[int(off[half]):], off.size - 1 - half)
+                a = nat.canonical_counts(*c.counts_fetch())
+                st = c.stats()
+                assert st['n_reads'] == off.size - 1 and st['n_records'] == words.size
+                c.counts_clear()
+                c.chunk_stage(sidx.astype(np.int32), p['qoff'], group=2,
+                              subj_is_set=True, indexed=True)
+                c.classify_staged(jobs)
+                b = nat.canonical_counts(*c.counts_fetch())
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                assert a[0].size > 3
 
 
 def test_free_rank_stream_is_taken(ctx):

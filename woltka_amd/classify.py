@@ -377,6 +377,14 @@ class Engine:
         if len(self.jobs) == 1 and self.jobs[0].mode == nat.MODE_FREE:
             # `--rank free` alone: the free-rank stream (csrc/wk_free.hpp)
             return self.use_tree
+        if len(self.jobs) == 1 and self.jobs[0].mode == nat.MODE_RANK and \
+                not self.jobs[0].flags & nat.F_SIZED:
+            # one rank under --uniq / --above / --major above one half: the
+            # same stream over the subjects' ancestors at the rank
+            job = self.jobs[0]
+            if job.major > 0.5 or (job.major <= 0 and job.flags & (
+                    nat.F_UNIQ | nat.F_ABOVE)):
+                return self.use_tree
         for job in self.jobs:
             if job.flags & (nat.F_UNIQ | nat.F_SIZED):
                 return False

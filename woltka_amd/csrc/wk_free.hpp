@@ -16,6 +16,14 @@
 // in every word make the stream self-describing: the last record of a read
 // says where the read began — no offsets, no per-read gathers of candidate
 // rows (round 2's evaluator: 225 M 16-byte row gathers, 1.5 ms).
+//
+// The same stream serves one rank job under an option that looks at whole reads
+// (classify.assign_rank, classify.py:81-141: --uniq, --above, --major): the
+// records then hold each subject's ancestor at the rank (kFreeMissing: none), a
+// read whose records agree goes there, and one whose records differ goes to
+// their LCA (--above; nowhere if a record has no ancestor at the rank), to the
+// value that reaches the threshold (--major: one vote per subject, "none" is a
+// value that can win and then assigns nothing) or nowhere (--uniq).
 #pragma once
 #include "wk_classify.hpp"
 #include "wk_device.hpp"
@@ -50,6 +58,9 @@ struct FreeArgs {
     uint32_t sparse_m;
     uint32_t job, group;
     uint32_t subok, unassigned;
+    // a rank job under --uniq / --above / --major instead of the free-rank job:
+    uint32_t by_rank, above;
+    double major;  // > 0.5 (a value that reaches it is the only one that can), or 0
     // reads per result id ([n_results]: 'Unassigned'), all zero between launches:
     // free_counts_kernel moves them to the count table and clears them
     uint32_t* dense;  // [n_results + 1]
@@ -230,14 +241,42 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
             // (a missing subject carries the largest value of the field: it is the maximum)
             unsigned long long e = 0;
             bool put = on;
-            if (mx == kFreeMissing)
+            if (a.by_rank) {
+                uint32_t to = kFreeMissing;  // where the read goes without a look at the tree
+                bool lca = false;
+                if (mn == mx) {
+                    to = mn;
+                } else if (a.major > 0.0) {
+                    // the only value that can reach a threshold above one half:
+                    // Boyer-Moore's candidate, then its votes
+                    uint32_t cand = 0, lead = 0, votes = 0;
+                    for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
+                        if (i < size) {
+                            const uint32_t f = stage[at - i] & kWordSubjMask;
+                            if (lead == 0u) cand = f;
+                            lead += (f == cand) ? 1u : (uint32_t)-1;
+                        }
+                    for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
+                        if (i < size) votes += ((stage[at - i] & kWordSubjMask) == cand) ? 1u : 0u;
+                    if ((double)votes >= (double)size * a.major) to = cand;
+                } else if (a.above) {
+                    lca = mx != kFreeMissing;
+                }
+                if (lca)
+                    e = kLca | ((unsigned long long)mx << 32) | mn;
+                else if (to != kFreeMissing)
+                    e = kSelf | to;
+                else
+                    e = (unsigned long long)a.n_results, put = on && a.unassigned != 0u;
+            } else if (mx == kFreeMissing) {
                 e = (unsigned long long)a.n_results, put = on && a.unassigned != 0u;
-            else if (size == 1u)
+            } else if (size == 1u) {
                 e = (a.subok ? kSelf : kParent) | mn;
-            else if (mn != mx)
+            } else if (mn != mx) {
                 e = kLca | ((unsigned long long)mx << 32) | mn;
-            else  // the same node several times (cannot happen with sets): itself, None if the root
+            } else {  // the same node several times (cannot happen with sets): itself, None if the root
                 e = kSelf | (1ull << 32) | mn;
+            }
             const unsigned long long mask = __ballot(put);
             if (put) queue[(tail + (uint32_t)__popcll(mask & below)) & (kFreeQueue - 1)] = e;
             tail += (uint32_t)__popcll(mask);

@@ -81,6 +81,7 @@ struct wk_ctx {
     int32_t n_nodes = 0;
     DevBuf rank_tab[WK_MAX_JOBS * 4];
     bool rank_tab_valid[WK_MAX_JOBS * 4] = {};
+    int32_t rank_tab_code[WK_MAX_JOBS * 4] = {};
     int64_t rank_tab_nodes[WK_MAX_JOBS * 4] = {};  // nodes that carry the slot's rank (distinct results a job can have)
     std::vector<int32_t> rank_code_host;           // host copy of the rank codes (for those counts)
     // host copies of the tree and the subject table + what `--rank free` looks up
@@ -183,7 +184,12 @@ struct wk_ctx {
     std::vector<wk_job> w_jobs;          // the job set they will be classified under
     int32_t w_group = 0;
     bool w_open = false;
-    int w_mode = 0;  // 0: subject indices for the weighted histogram, 1: feature ids for the free-rank stream (wk_free.hpp)
+    int w_mode = 0;  // 0: subject indices for the weighted histogram; the stream of wk_free.hpp: 1: feature ids (one free-rank job), 2: ancestors at the job's rank (one rank job under --uniq / --above / --major)
+    DevBuf w_subj_t;                  // mode 2: ancestor at the rank per subject (-1: none)
+    std::vector<int32_t> w_subj_t_host;
+    int w_subj_t_slot = -1, w_subj_t_tree = -1, w_subj_t_rank = -1;  // what w_subj_t_host was made for
+    int rank_serial = 0;              // bumped by wk_build_rank_table
+    int st_mode = -1, st_slot = -1, st_tree = -1, st_subj = -1, st_rank = -1;  // what the stream's tables (f_rblocks ...) were made for
     int free_per_cu = 2, free_threads = 1024, free_slots = 4096;  // launch shape of the free-rank stream (measurement knobs)  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
     int32_t max_gene_feature = 0;
     int use_range_log = 1;  // (0: the hashed miss log for the gene tally too; measurement)
@@ -329,39 +335,60 @@ __global__ void __launch_bounds__(256) table_compact_kernel(const unsigned long 
 
 }  // namespace
 
-// Tables behind ClassifyArgs::free_sparse for the current tree and subject
-// table (host side: 100 k subjects x ~17 levels).
-static int ensure_free_tables(wk_ctx* c) {
-    if (c->free_tree == c->tree_serial && c->free_subj == c->subj_serial) return WK_OK;
-    const int32_t n = c->n_subjects, n_nodes = c->n_nodes;
-    const std::vector<int32_t>& feat = c->subj_feat_host;
-    std::vector<int32_t> order;
-    order.reserve((size_t)n);
-    for (int32_t s = 0; s < n; ++s)
-        if (feat[s] < n_nodes) order.push_back(s);
-    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return feat[x] < feat[y] || (feat[x] == feat[y] && x < y); });
-    const uint32_t m = (uint32_t)order.size();
-    std::vector<int32_t> rank((size_t)std::max(n, 1), -1);
-    for (uint32_t i = 0; i < m; ++i) rank[order[i]] = (int32_t)i;
-    uint32_t levels = 1;
-    while (m > 1 && (2u << (levels - 1)) <= m - 1) levels += 1;  // the longest range of pairs has m - 1 of them
-    const size_t row = std::max<uint32_t>(m, 1u);
-    std::vector<int32_t> sparse(row * levels, 0x7FFFFFFF);
-    for (uint32_t i = 0; i + 1 < m; ++i) {  // LCA of neighbours: the lowest ancestor of the first whose subtree holds the second
-        int32_t u = feat[order[i]];
-        const int32_t hi = feat[order[i + 1]];
-        while (c->last_host[u] < hi) u = c->parent_host[u];
-        sparse[i] = u;
+// tree.find_rank (tree.py:467-510) for the subjects, on the host: ancestor (or
+// self) of each subject's node with the rank code of `slot`, -1 if none — what
+// rank_table_kernel holds for all nodes.  Kept up to date as subjects are added.
+static int ensure_subject_ancestors(wk_ctx* c, int slot) {
+    std::vector<int32_t>& t = c->w_subj_t_host;
+    if (c->w_subj_t_slot != slot || c->w_subj_t_tree != c->tree_serial || c->w_subj_t_rank != c->rank_serial) t.clear();
+    if ((int32_t)t.size() > c->n_subjects) t.clear();
+    const size_t have = t.size();
+    if (have == (size_t)c->n_subjects && c->w_subj_t_slot == slot) return WK_OK;
+    const int32_t code = c->rank_tab_code[slot];
+    t.resize((size_t)c->n_subjects, -1);
+    for (size_t s = have; s < t.size(); ++s) {
+        int32_t u = c->subj_feat_host[s], res = -1;
+        if (u < c->n_nodes)
+            for (;;) {
+                if (c->rank_code_host[u] == code) {
+                    res = u;
+                    break;
+                }
+                const int32_t p = c->parent_host[u];
+                if (p == u) break;
+                u = p;
+            }
+        t[s] = res;
     }
-    for (uint32_t k = 1; k < levels; ++k)
-        for (uint32_t i = 0; i + (1u << k) <= m - 1; ++i)
-            sparse[k * row + i] = std::min(sparse[(k - 1) * row + i], sparse[(k - 1) * row + i + (1u << (k - 1))]);
-    // the same over the distinct subject nodes, for the free-rank stream
-    // (wk_free.hpp), whose records name nodes: rank blocks, the parents, the table
+    c->w_subj_t_slot = slot;
+    c->w_subj_t_tree = c->tree_serial;
+    c->w_subj_t_rank = c->rank_serial;
+    const int rc = upload(c, c->w_subj_t, t.data(), t.size() * 4);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WK_OK;
+}
+
+// Tables of the per-read stream (wk_free.hpp) over the nodes its records can
+// name: the subjects' nodes (mode 1, `--rank free`) or their ancestors at the
+// job's rank (mode 2).
+static int ensure_stream_tables(wk_ctx* c, int mode, int slot) {
+    if (mode == 2) {
+        const int rc = ensure_subject_ancestors(c, slot);
+        if (rc) return rc;
+    }
+    if (c->st_mode == mode && c->st_slot == slot && c->st_tree == c->tree_serial && c->st_subj == c->subj_serial &&
+        c->st_rank == c->rank_serial)
+        return WK_OK;
+    const int32_t n_nodes = c->n_nodes;
+    const std::vector<int32_t>& of = mode == 2 ? c->w_subj_t_host : c->subj_feat_host;
     std::vector<int32_t> dn;  // distinct nodes, ascending
-    dn.reserve(m);
-    for (uint32_t i = 0; i < m; ++i)
-        if (dn.empty() || dn.back() != feat[order[i]]) dn.push_back(feat[order[i]]);
+    dn.reserve(of.size());
+    for (int32_t v : of)
+        if (v >= 0 && v < n_nodes) dn.push_back(v);
+    std::sort(dn.begin(), dn.end());
+    dn.erase(std::unique(dn.begin(), dn.end()), dn.end());
+    // rank blocks, the parents, the table of neighbours' LCAs
     const uint32_t md = (uint32_t)dn.size();
     std::vector<RankBlock> blocks((size_t)n_nodes / 64 + 1, RankBlock{0ull, 0u, 0u});
     for (int32_t v : dn) blocks[(size_t)v >> 6].bits |= 1ull << (v & 63);
@@ -401,15 +428,52 @@ static int ensure_free_tables(wk_ctx* c) {
         for (uint32_t i = 0; i + (1u << k) <= md - 1; ++i)
             dsparse[k * drow + i] = std::min(dsparse[(k - 1) * drow + i], dsparse[(k - 1) * drow + i + (1u << (k - 1))]);
     int rc;
-    if ((rc = upload(c, c->f_rank, rank.data(), rank.size() * 4))) return rc;
-    if ((rc = upload(c, c->f_sparse, sparse.data(), sparse.size() * 4))) return rc;
     if ((rc = upload(c, c->f_rblocks, blocks.data(), blocks.size() * sizeof(RankBlock)))) return rc;
     if ((rc = upload(c, c->f_dsparse, dsparse.data(), dsparse.size() * 4))) return rc;
     if ((rc = upload(c, c->f_dparent, dparent.data(), dparent.size() * 4))) return rc;
     if ((rc = upload(c, c->f_dself, dself.data(), dself.size() * 4))) return rc;
     if ((rc = upload(c, c->f_rnode, rnode.data(), rnode.size() * 4))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors are about to go out of scope
     c->f_results = (uint32_t)rnode.size();
     c->f_dm = (uint32_t)drow;
+    c->st_mode = mode;
+    c->st_slot = slot;
+    c->st_tree = c->tree_serial;
+    c->st_subj = c->subj_serial;
+    c->st_rank = c->rank_serial;
+    return WK_OK;
+}
+
+// Tables behind ClassifyArgs::free_sparse for the current tree and subject
+// table (host side: 100 k subjects x ~17 levels).
+static int ensure_free_tables(wk_ctx* c) {
+    if (c->free_tree == c->tree_serial && c->free_subj == c->subj_serial) return WK_OK;
+    const int32_t n = c->n_subjects, n_nodes = c->n_nodes;
+    const std::vector<int32_t>& feat = c->subj_feat_host;
+    std::vector<int32_t> order;
+    order.reserve((size_t)n);
+    for (int32_t s = 0; s < n; ++s)
+        if (feat[s] < n_nodes) order.push_back(s);
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return feat[x] < feat[y] || (feat[x] == feat[y] && x < y); });
+    const uint32_t m = (uint32_t)order.size();
+    std::vector<int32_t> rank((size_t)std::max(n, 1), -1);
+    for (uint32_t i = 0; i < m; ++i) rank[order[i]] = (int32_t)i;
+    uint32_t levels = 1;
+    while (m > 1 && (2u << (levels - 1)) <= m - 1) levels += 1;  // the longest range of pairs has m - 1 of them
+    const size_t row = std::max<uint32_t>(m, 1u);
+    std::vector<int32_t> sparse(row * levels, 0x7FFFFFFF);
+    for (uint32_t i = 0; i + 1 < m; ++i) {  // LCA of neighbours: the lowest ancestor of the first whose subtree holds the second
+        int32_t u = feat[order[i]];
+        const int32_t hi = feat[order[i + 1]];
+        while (c->last_host[u] < hi) u = c->parent_host[u];
+        sparse[i] = u;
+    }
+    for (uint32_t k = 1; k < levels; ++k)
+        for (uint32_t i = 0; i + (1u << k) <= m - 1; ++i)
+            sparse[k * row + i] = std::min(sparse[(k - 1) * row + i], sparse[(k - 1) * row + i + (1u << (k - 1))]);
+    int rc;
+    if ((rc = upload(c, c->f_rank, rank.data(), rank.size() * 4))) return rc;
+    if ((rc = upload(c, c->f_sparse, sparse.data(), sparse.size() * 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors are about to go out of scope
     c->f_m = (uint32_t)row;
     c->free_tree = c->tree_serial;
@@ -630,7 +694,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_rblocks, &c->f_dsparse, &c->f_dparent, &c->f_dself, &c->f_rnode, &c->f_dense, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_rblocks, &c->f_dsparse, &c->f_dparent, &c->f_dself, &c->f_rnode, &c->f_dense, &c->w_subj_t, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     c->c_words.release();
     for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
@@ -842,6 +906,8 @@ int wk_build_rank_table(wk_ctx* c, int32_t slot, int32_t code) {
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
     c->rank_tab_valid[slot] = true;
+    c->rank_tab_code[slot] = code;
+    c->rank_serial += 1;
     c->rank_tab_nodes[slot] = std::count(c->rank_code_host.begin(), c->rank_code_host.end(), code);
     c->rows_sig.clear();
     return WK_OK;
@@ -1598,6 +1664,18 @@ static int words_jobs_ok(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, Classify
         *ok = true;
         return WK_OK;
     }
+    // one rank job that looks at whole reads (--uniq, --above, --major above one half): the same stream over the
+    // subjects' ancestors at the rank
+    if (n_jobs == 1 && jobs[0].mode == WK_MODE_RANK && !(jobs[0].flags & WK_F_SIZED) &&
+        (jobs[0].major > 0.5 || (jobs[0].major <= 0.0 && (jobs[0].flags & (WK_F_UNIQ | WK_F_ABOVE))))) {
+        if (c->n_nodes <= 0 || (uint32_t)c->n_nodes >= kFreeMissing) return WK_OK;
+        const int slot = jobs[0].rank_slot;
+        if (slot < 0 || slot >= (int)(sizeof c->rank_tab / sizeof c->rank_tab[0]) || !c->rank_tab_valid[slot])
+            return fail(c, WK_E_STATE, "job 0: rank slot %d has not been built", slot);
+        if (mode) *mode = 2;
+        *ok = true;
+        return WK_OK;
+    }
     a = ClassifyArgs{};
     a.n_jobs = n_jobs;
     for (int j = 0; j < n_jobs; ++j) {
@@ -1641,11 +1719,12 @@ int wk_words_flush(wk_ctx* c) {
     }
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
-    if (c->w_mode == 1) {
-        // ---- one free-rank job: the stream over feature ids, then its dense counters into the count table
+    if (c->w_mode != 0) {
+        // ---- one free-rank job, or one rank job that looks at whole reads: the stream over node ids, then its dense
+        // counters into the count table
         const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->free_per_cu);
         {
-            const int rcf = ensure_free_tables(c);
+            const int rcf = ensure_stream_tables(c, c->w_mode, c->w_mode == 2 ? c->w_jobs[0].rank_slot : -1);
             if (rcf) return rcf;
         }
         FreeArgs fa{};
@@ -1660,6 +1739,9 @@ int wk_words_flush(wk_ctx* c) {
         fa.group = (uint32_t)c->w_group;
         fa.subok = (c->w_jobs[0].flags & WK_F_SUBOK) ? 1u : 0u;
         fa.unassigned = (c->w_jobs[0].flags & WK_F_UNASSIGNED) ? 1u : 0u;
+        fa.by_rank = c->w_mode == 2 ? 1u : 0u;
+        fa.above = (c->w_jobs[0].flags & WK_F_ABOVE) ? 1u : 0u;
+        fa.major = c->w_mode == 2 ? c->w_jobs[0].major : 0.0;
         const CountTable table{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
         // the dense counters of the results (zero between flushes: free_counts_kernel clears what it moves)
         const size_t dense_bytes = ((size_t)c->f_results + 1) * 4;
@@ -1792,9 +1874,15 @@ int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group,
 
 // Free-rank accumulation: the subject fields of words [first, first + n) become feature ids.
 static int words_translate(wk_ctx* c, int64_t first, int64_t n) {
-    if (c->w_mode != 1 || n <= 0) return WK_OK;
+    if (c->w_mode == 0 || n <= 0) return WK_OK;
+    const int32_t* node_of = c->subj_feat.as<int32_t>();
+    if (c->w_mode == 2) {  // (ancestors at the rank: -1 reads as "no node" like an id beyond the tree)
+        const int rc = ensure_subject_ancestors(c, c->w_jobs[0].rank_slot);
+        if (rc) return rc;
+        node_of = c->w_subj_t.as<int32_t>();
+    }
     hipLaunchKernelGGL(words_to_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                       c->c_words.as<uint32_t>() + first, (uint32_t)n, c->subj_feat.as<int32_t>(), (uint32_t)c->n_subjects,
+                       c->c_words.as<uint32_t>() + first, (uint32_t)n, node_of, (uint32_t)c->n_subjects,
                        (uint32_t)c->n_nodes, scalar_err(c));
     HIP_TRY(c, hipGetLastError());
     return WK_OK;
@@ -2086,8 +2174,8 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     unsigned long long totals = 0;
-    if (c->w_mode == 1) {
-        // the free-rank stream wants the records of a read next to each other, in
+    if (c->w_mode != 0) {
+        // the per-read stream wants the records of a read next to each other, in
         // position order: placed by prefix sums instead of appended wave by wave
         const uint32_t n_tiles = grid.x;
         HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
@@ -2109,7 +2197,7 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     DtokState st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->w_mode == 1) {
+    if (c->w_mode != 0) {
         st.n_out = totals & 0xFFFFFFFFull;
         st.n_reads = totals >> 32;
     }
