@@ -148,7 +148,8 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * straight from the matches), "tally_slots" / "tally_per_cu" (LDS cache slots
  * and workgroups per CU of that kernel), "grid_density" (1..8 grid cells per
  * gene; takes effect at the next wk_set_genes), "match_lds" (0/1: per-genome
- * words of the coordinate grid in LDS), "free_per_cu" / "free_threads" / "free_slots" (launch shape of the free-rank
+ * words of the coordinate grid in LDS), "range_log" (0: the coord-match tally keeps the hashed miss log instead of 4-byte entries by gene stripe,
+ * csrc/wk_ordinal.hpp), "free_per_cu" / "free_threads" / "free_slots" (launch shape of the free-rank
  * stream, csrc/wk_free.hpp: workgroups per CU, threads and LDS cache slots per workgroup), "words_keep" (0/1, measurement: wk_words_flush classifies the accumulated
  * packed records but leaves them in place, so that a benchmark can time
  * repeated passes over one resident batch), "free_sparse" (0/1: `--rank free` on
@@ -251,6 +252,10 @@ int wk_classify_staged(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
  * (workflow.py:304-335 loops over them) are appended to one device buffer as
  * they are tokenised, asynchronously from pinned memory, and classified by one
  * launch when the sample ends (wk_words_flush; wk_counts_fetch flushes too).
+ * Two more job sets are taken, by the per-read stream of csrc/wk_free.hpp: one
+ * `--rank free` job (classify.assign_free, classify.py:54-78), and one rank job
+ * under --uniq, --above or --major above one half (classify.assign_rank,
+ * classify.py:81-141 with classify.majority, classify.py:300-317).
  *
  * wk_words_begin declares the jobs and the group (sample) of the records that
  * follow; *ok = 0 means this job set / subject table needs the general path
