@@ -167,6 +167,20 @@ class MapWriter:
             self._pool.shutdown(wait=True)
 
 
+class _BySubject:
+    """Subject indices of a chunk's records + the subject -> feature table they
+    index: the records' features, taken when somebody asks (`resolve`)."""
+
+    def __init__(self, index, table):
+        self.index = index if isinstance(index, np.ndarray) and \
+            index.flags.owndata and not isinstance(index, _Staged) \
+            else np.array(index)
+        self.table = table
+
+    def resolve(self):
+        return self.table[self.index]
+
+
 class _Staged(tuple):
     """Arrays of a block that live in a ``StageRing`` slot."""
     slot = None
@@ -342,6 +356,8 @@ class Engine:
         self._n_files = 0                   # alignment files begun (each restarts the mapper's chunks)
         self._replay = None
         self._writer = None                 # MapWriter of the native read maps
+        self._map_pool, self._map_seq, self._map_jobs = None, None, []   # their formatting threads
+        self._subj_feat_arr = None
         self.genes = None
         self.gene_feature = None
         # dense subject indices (order of first appearance in the alignments)
@@ -397,6 +413,13 @@ class Engine:
 
     def close(self):
         try:
+            if self._map_pool is not None:
+                try:
+                    self._maps_done()
+                finally:
+                    self._map_pool.shutdown(wait=True)
+                    self._map_seq.shutdown(wait=True)
+                    self._map_pool = self._map_seq = None
             if self._writer is not None:
                 self._writer.close()
                 self._writer = None
@@ -827,6 +850,7 @@ class Engine:
             # are evaluated here, with exact rationals (classify.counter takes
             # any k, classify.py:156-171), and leave the chunk as empty reads
             if qoff.size > 1 and not want and not self.sizes and \
+                    subj.size - n >= nat.MAX_K and \
                     int(np.diff(qoff).max()) > nat.MAX_K:
                 subj, qoff = self._fold_huge_reads(subj, qoff, group)
             # the Python parsers and the native tokenizer hand over sets;
@@ -836,8 +860,10 @@ class Engine:
                 subj_is_set=(packed_is_set if packed is not None
                              else not trimsub), indexed=True)
             assign = self._classify_staged(data, want)
-            if want:    # read maps work on feature ids
-                subj = np.asarray(self.subj_feature, dtype=np.int32)[subj]
+            if want and (names is None or self._replay is not None):
+                subj = self._subject_features()[subj]   # read maps work on feature ids
+            elif want:                  # (the native formatter's thread does it)
+                subj = _BySubject(subj, self._subject_features())
             nq = n
         if self.sizes:
             self._collect_log()
@@ -845,12 +871,57 @@ class Engine:
             self._replay_chunk(assign, subj, qoff, group, n)
             return nq
         if want and names is not None:
-            self._write_maps_native(assign, subj, qoff, names, sample_of,
-                                    rank2dir, outzip, namedic)
+            # formatted on helper threads (numpy and the native formatter run
+            # without the GIL), several chunks at a time, while this thread
+            # stages the next chunk; one more thread appends the texts in
+            # chunk order.  Arrays that borrow memory (staging slots, a
+            # mapped file) are copied first: their owners move on.
+            if self._map_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._map_pool = ThreadPoolExecutor(max_workers=self.MAP_THREADS)
+                self._map_seq = ThreadPoolExecutor(max_workers=1)
+            self._maps_done(keep=self.MAP_THREADS)      # (bounds what is held)
+            for j, mode in enumerate(self.modes):   # (device calls stay on this thread)
+                if mode == nat.MODE_RANK:
+                    self._rank_table(self.slots[j])
+
+            def own(a):
+                if isinstance(a, _BySubject):
+                    return a
+                return a if isinstance(a, np.ndarray) and a.flags.owndata \
+                    and not isinstance(a, _Staged) else np.array(a)
+            job = self._map_pool.submit(
+                self._format_maps_native, [own(a) for a in assign], own(subj),
+                own(qoff), tuple(own(a) for a in names), sample_of, rank2dir,
+                outzip, namedic)
+            self._map_jobs.append(self._map_seq.submit(self._append_maps, job))
         elif want:
+            self._maps_done()
             self._write_maps(assign, subj, qoff, reads, sample_of, rank2dir,
                              outzip, namedic, order=map_order)
         return nq
+
+    MAP_THREADS = 4
+
+    def _append_maps(self, job):
+        """(on the sequencing thread) the texts of one chunk to their files."""
+        for path, text, kind in job.result():
+            if self._writer is None:
+                self._writer = MapWriter()
+            self._writer.append(path, text, kind)
+
+    def _maps_done(self, keep=0):
+        """Wait until at most `keep` chunks' read maps are still on their way
+        to the files (errors surface here)."""
+        while len(self._map_jobs) > keep:
+            self._map_jobs.pop(0).result()
+
+    def _subject_features(self):
+        """`subj_feature` as an array (kept until the list grows)."""
+        if self._subj_feat_arr is None or \
+                self._subj_feat_arr.size != len(self.subj_feature):
+            self._subj_feat_arr = np.asarray(self.subj_feature, dtype=np.int32)
+        return self._subj_feat_arr
 
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
 
@@ -1667,11 +1738,15 @@ class Engine:
         np.cumsum(np.bincount(read_i, minlength=multi.size), out=m_off[1:])
         return m_off, tax[o].astype(np.int32), count[o].astype(np.int32)
 
-    def _write_maps_native(self, assign, subj, qoff, names, sample,
-                           rank2dir, outzip, namedic):
+    def _format_maps_native(self, assign, subj, qoff, names, sample,
+                            rank2dir, outzip, namedic):
         """Read maps of one (non-demultiplexed) chunk through the native
-        formatter; compression runs on a thread pool, one member per block."""
+        formatter: [(path, text, compression)] per rank, for `MapWriter`
+        (compression runs on its thread pool, one member per block)."""
         buf, qname = names
+        if isinstance(subj, _BySubject):
+            subj = subj.resolve()
+        out = []
         unas = bool(self.jobs[0].flags & nat.F_UNASSIGNED)
         for j, rank in enumerate(self.ranks):
             row = assign[j]
@@ -1688,10 +1763,8 @@ class Engine:
                                       remap[m_feat] if m_feat.size else m_feat,
                                       m_count, shown, unassigned=unas)
             outfp = join(rank2dir[rank], f'{sample}.txt')
-            if self._writer is None:
-                self._writer = MapWriter()
-            self._writer.append(f'{outfp}.{outzip}' if outzip else outfp,
-                                text, outzip)
+            out.append((f'{outfp}.{outzip}' if outzip else outfp, text, outzip))
+        return out
 
     def _collect_log(self):
         """Fold the contribution log of the chunk just classified.  If the log
@@ -1810,6 +1883,7 @@ class Engine:
         rounded ``float`` division.  ``exact`` leaves the rationals in place
         (profiles of several processes are then added exactly and converted
         once, ``exact_to_numbers``)."""
+        self._maps_done()
         if self._writer is not None:
             self._writer.flush()
         self._words_done()
