@@ -267,6 +267,13 @@ int wk_classify_staged(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
  * wk_words_wait(slot) returns; slot = -1 copies before returning. */
 int wk_host_alloc(wk_ctx* ctx, size_t bytes, void** out);
 int wk_host_free(wk_ctx* ctx, void* p);
+/* Memory of the caller — a read-only mapping of an alignment file — pinned in
+ * place (hipHostRegister, read-only), so that wk_dtok_copy takes the text from
+ * the page cache without a copy on the host; `p` page-aligned.  A failure
+ * (WK_E_HIP) leaves nothing registered: the caller reads the file into pinned
+ * buffers instead.  Ranges still registered are released by wk_destroy. */
+int wk_host_register(wk_ctx* ctx, const void* p, size_t bytes);
+int wk_host_unregister(wk_ctx* ctx, const void* p);
 int wk_words_begin(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,
                    int32_t group, int* ok);
 int wk_words_append(wk_ctx* ctx, const uint32_t* words, int64_t n_records,

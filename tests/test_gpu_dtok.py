@@ -71,12 +71,18 @@ def _random_sam(rng, n_queries, subjects, paired, unmapped, long_names,
     dict(paired=False, unmapped=False, long_names=True, big=True),
 ])
 @pytest.mark.parametrize('block', [1 << 26, 1 << 16])
+@pytest.mark.parametrize('mapped', [False, True])
 def test_device_tokenizer_equals_host_tokenizer(tmp_path, monkeypatch, case,
-                                                block):
+                                                block, mapped):
     """Small device blocks cut the file in many places; `big` plants a read of
-    23 subjects (its block goes back to the host tokenizer)."""
+    23 subjects (its block goes back to the host tokenizer).  `mapped`: the
+    file is pinned in place in pieces of 16 KB instead of read into pinned
+    buffers, so that most blocks' copies span several registrations."""
     from woltka_amd import classify as C
     monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_MIN', 0 if mapped else 1 << 40)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_PIECE', 1 << 14)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_RATE', 0.0)
     rng = random.Random(len(str(case)) + block)
     tax = os.path.join(ROOT, 'tests', 'golden', 'data', 'taxonomy')
     # subjects of the bundled taxonomy's map (nodes of the tree) + strangers
@@ -112,6 +118,50 @@ def test_lines_the_kernels_leave_to_the_host(tmp_path, bad, err):
     with pytest.raises(err):
         _run(tmp_path, 'x', False, input_fp=str(indir), input_fmt='sam',
              ranks='none')
+
+
+def test_mapped_route_is_taken(tmp_path, monkeypatch):
+    """A file above `HOSTREG_MIN` is mapped and registered piece by piece
+    (wk_host_register), every piece is released again, and the tables equal
+    the pread route's."""
+    import bench
+    from woltka_amd import _native as nat
+    from woltka_amd import classify as C
+    from woltka_amd import synth
+    rng = np.random.default_rng(23)
+    p = synth.as_sets(synth.lca_problem(rng, n_nodes=60000, n_subjects=5000,
+                                        n_reads=200_000, with_names=False))
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    bench.write_sam_lca(str(indir / 'S1.sam'), p, 200_000)
+    nodes = str(tmp_path / 'nodes.dmp')
+    bench.write_nodes_dmp(nodes, p['hier'])
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', 1 << 22)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_PIECE', 1 << 21)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_RATE', 0.0)
+    calls = {'reg': 0, 'unreg': 0}
+    reg, unreg = nat.Context.host_register, nat.Context.host_unregister
+
+    def spy_reg(self, address, n):
+        ok = reg(self, address, n)
+        calls['reg'] += bool(ok)
+        return ok
+
+    def spy_unreg(self, address):
+        calls['unreg'] += 1
+        return unreg(self, address)
+    monkeypatch.setattr(nat.Context, 'host_register', spy_reg)
+    monkeypatch.setattr(nat.Context, 'host_unregister', spy_unreg)
+    kw = dict(input_fp=str(indir), input_fmt='sam', nodes_fps=[nodes],
+              ranks='phylum,genus')
+    monkeypatch.setattr(C.Engine, 'HOSTREG_MIN', 0)
+    a, log_a = _run(tmp_path, 'm', False, **kw)
+    size = os.path.getsize(str(indir / 'S1.sam'))
+    assert calls['reg'] == -(-size // (1 << 21)) and calls['unreg'] == calls['reg']
+    monkeypatch.setattr(C.Engine, 'HOSTREG_MIN', 1 << 40)
+    b, log_b = _run(tmp_path, 'p', False, **kw)
+    assert calls['reg'] == calls['unreg'] == -(-size // (1 << 21))
+    assert a == b and log_a == log_b
 
 
 def test_device_tokenizer_at_size(tmp_path):

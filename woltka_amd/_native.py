@@ -40,7 +40,8 @@ SYMBOLS = (
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
     'wk_set_uniform_group', 'wk_chunk_download', 'wk_ordinal_hit_offsets',
-    'wk_host_alloc', 'wk_host_free', 'wk_words_begin', 'wk_words_append',
+    'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
+    'wk_words_begin', 'wk_words_append',
     'wk_words_wait', 'wk_words_flush', 'wk_words_pending',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
     'wk_timer_ms', 'wk_profile_kernels', 'wk_last_kernel_ms',
@@ -129,6 +130,8 @@ def load_library():
                                         i64p, i64p]),
         'wk_host_alloc': (C.c_int, [p, C.c_size_t, C.POINTER(C.c_void_p)]),
         'wk_host_free': (C.c_int, [p, C.c_void_p]),
+        'wk_host_register': (C.c_int, [p, C.c_void_p, C.c_size_t]),
+        'wk_host_unregister': (C.c_int, [p, C.c_void_p]),
         'wk_words_begin': (C.c_int, [p, C.POINTER(Job), C.c_int32, C.c_int32,
                                      C.POINTER(C.c_int)]),
         'wk_words_append': (C.c_int, [p, u32p, C.c_int64, C.c_int64, C.c_int]),
@@ -448,6 +451,16 @@ class Context:
         buf = (C.c_char * (int(n) * dt.itemsize)).from_address(out.value)
         arr = np.frombuffer(buf, dtype=dt, count=int(n))
         return arr
+
+    def host_register(self, address, n):
+        """Pin ``n`` bytes of the caller's (read-only, page-aligned) memory in
+        place for asynchronous copies; False if the runtime refuses."""
+        return self._lib.wk_host_register(self._h, C.c_void_p(int(address)),
+                                          int(n)) == OK
+
+    def host_unregister(self, address):
+        self._check(self._lib.wk_host_unregister(self._h,
+                                                 C.c_void_p(int(address))))
 
     def words_begin(self, jobs, group):
         ok = C.c_int(0)

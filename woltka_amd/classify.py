@@ -924,6 +924,9 @@ class Engine:
         return self._subj_feat_arr
 
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
+    HOSTREG_PIECE = 256 << 20   # a file is pinned in place in pieces of this size (a multiple of the page size)
+    HOSTREG_MIN = 64 << 20      # smaller files are read into pinned buffers
+    HOSTREG_RATE = 40e9         # bytes/s of the first piece's pinning below which the file is read instead
 
     def _device_chunks(self, reader, host_block, ordinal=False):
         """A SAM file through the tokenizer on the device (csrc/wk_dtok.hpp):
@@ -992,6 +995,91 @@ class Engine:
                 if final:
                     return
 
+        # The same blocks without a copy on the host: the file mapped read-only
+        # and pinned in place piece by piece (wk_host_register), so that the
+        # device copies the text straight from the page cache.  The host then
+        # only looks at a block's ends (header lines, the last run) and at the
+        # names of subjects it has not met.
+        PIECE = self.HOSTREG_PIECE
+        mapped = {'reg': [], 'base': 0, 'done': 0}
+
+        def pieces_until(upto):
+            reg, base = mapped['reg'], mapped['base']
+            for i in range(min(len(reg), -(-upto // PIECE))):
+                if reg[i] == 0:
+                    t0 = time.perf_counter()
+                    ok = self.ctx.host_register(
+                        base + i * PIECE, min(PIECE, size - i * PIECE))
+                    lap['read'] += time.perf_counter() - t0
+                    reg[i] = 1 if ok else -1
+            done = mapped['done']               # text the device has copied
+            for i in range(min(len(reg), done // PIECE)):
+                if reg[i] == 1:
+                    self.ctx.host_unregister(base + i * PIECE)
+                    reg[i] = 2
+
+        def blocks_mapped(arr):
+            pos, in_header, first = 0, True, True
+            ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
+            span = ramp or block
+            while pos < size:
+                end = min(size, pos + span)
+                final = end >= size
+                view = arr[pos:end]
+                t0 = time.perf_counter()
+                ok, begin, stop, hdr = nat.Tokenizer.sam_span(view, final,
+                                                              in_header)
+                lap['span'] += time.perf_counter() - t0
+                if not ok and not final:    # no complete run yet: look further
+                    span *= 2
+                    continue
+                if ramp is not None:
+                    ramp = min(block, ramp * 4)
+                    if ramp == block:
+                        tok.warm, ramp = True, None
+                span = ramp or block
+                pieces_until(pos + stop)
+                yield ('map', pos + stop), view, end - pos, begin, stop, \
+                    first, final, in_header, hdr
+                in_header, first = hdr, False
+                if final:
+                    return
+                pos += stop
+
+        def open_mapped():
+            """The file as a pinned read-only array, or None (small file, no
+            mapping, the runtime refuses: the pread route then)."""
+            if size < self.HOSTREG_MIN or os.environ.get('WOLTKA_NO_HOSTREG'):
+                return None
+            import mmap
+            try:
+                mm = mmap.mmap(fd, size, flags=mmap.MAP_SHARED,
+                               prot=mmap.PROT_READ)
+            except (OSError, ValueError):
+                return None
+            arr = np.frombuffer(mm, dtype=np.uint8)
+            mapped['base'] = arr.ctypes.data
+            mapped['reg'] = [0] * (-(-size // PIECE))
+            mapped['done'] = 0
+            t0 = time.perf_counter()
+            pieces_until(1)
+            rate = min(PIECE, size) / max(time.perf_counter() - t0, 1e-9)
+            if mapped['reg'][0] != 1:
+                mapped['reg'] = []
+                return None
+            # pinning the pages of a tmpfs file runs at ~20 GB/s, on one thread
+            # whatever the number of threads that ask (the cache of a disk
+            # file: ~160 GB/s), and unmapping it costs as much again: such a
+            # file is read into pinned buffers faster, with 2 and with 16
+            # threads (measured with 1-8 processes per box,
+            # tools/e2e_mapped_vs_pread.py, tools/ubench/host_register*.py)
+            if rate < self.HOSTREG_RATE and \
+                    not os.environ.get('WOLTKA_HOSTREG'):
+                self.ctx.host_unregister(mapped['base'])
+                mapped['reg'] = []
+                return None
+            return arr
+
         import time
         lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0, 'read': 0.0,
                'span': 0.0, 'blocks': 0}
@@ -1040,36 +1128,56 @@ class Engine:
                     yield from self._host_block(buf, fill, first, final,
                                                 hdr_in)
             finally:
-                if slot is not None:
+                if isinstance(slot, tuple):     # (mapped: copied up to here)
+                    mapped['done'] = max(mapped['done'], slot[1])
+                elif slot is not None:
                     ring.release(slot)
 
         # the copy of a block's text to the device starts one block ahead:
         # it overlaps the kernels of the block before
         prev = None
         t_all = time.perf_counter()
-        it = _prefetch(blocks())
-        while True:
-            t0 = time.perf_counter()
-            item = next(it, None)
-            lap['wait'] += time.perf_counter() - t0
-            if item is None:
-                break
-            if item[0] is not None:         # (pinned: an asynchronous copy)
+        whole = open_mapped()
+        it = _prefetch(blocks() if whole is None else blocks_mapped(whole))
+        try:
+            while True:
                 t0 = time.perf_counter()
-                self.ctx.dtok_copy(item[1], item[3], item[4])
-                lap['copy'] += time.perf_counter() - t0
+                item = next(it, None)
+                lap['wait'] += time.perf_counter() - t0
+                if item is None:
+                    break
+                if item[0] is not None:         # (pinned: an asynchronous copy)
+                    t0 = time.perf_counter()
+                    self.ctx.dtok_copy(item[1], item[3], item[4])
+                    lap['copy'] += time.perf_counter() - t0
+                if prev is not None:
+                    yield from one(prev)
+                prev = item
             if prev is not None:
                 yield from one(prev)
-            prev = item
-        if prev is not None:
-            yield from one(prev)
+        finally:
+            if whole is not None:
+                # (every copy has been waited for by the kernels of its block;
+                # a consumer that stopped early may have left one in flight)
+                t0 = time.perf_counter()
+                self.ctx.sync()
+                lap['rest'] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                for i, state in enumerate(mapped['reg']):
+                    if state == 1:
+                        self.ctx.host_unregister(mapped['base'] + i * PIECE)
+                mapped['reg'] = []
+                del whole
+                lap['unreg'] = time.perf_counter() - t0
         if timing:
             import sys
             tot = time.perf_counter() - t_all
             print('[dtok] %d blocks, %.3f s: waiting for text %.3f, copy calls '
-                  '%.3f, scan calls %.3f; reader: pread %.3f, span %.3f'
+                  '%.3f, scan calls %.3f; reader: pread / register %.3f, span '
+                  '%.3f; last sync %.3f, unregister %.3f'
                   % (lap['blocks'], tot, lap['wait'], lap['copy'], lap['scan'],
-                     lap['read'], lap['span']), file=sys.stderr)
+                     lap['read'], lap['span'], lap['rest'],
+                     lap.get('unreg', 0.0)), file=sys.stderr)
 
     def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False):
         """One block of the device route through the host tokenizer after

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -184,6 +185,13 @@ struct wk_ctx {
     std::vector<wk_job> w_jobs;          // the job set they will be classified under
     int32_t w_group = 0;
     bool w_open = false;
+    // host memory of others registered for asynchronous copies (wk_host_register): a copy may not span two of them
+    struct HostReg {
+        const char* p;
+        size_t n;
+    };
+    std::mutex reg_mu;
+    std::vector<HostReg> regs;
     int w_mode = 0;  // 0: subject indices for the weighted histogram; the stream of wk_free.hpp: 1: feature ids (one free-rank job), 2: ancestors at the job's rank (one rank job under --uniq / --above / --major)
     DevBuf w_subj_t;                  // mode 2: ancestor at the rank per subject (-1: none)
     std::vector<int32_t> w_subj_t_host;
@@ -701,6 +709,8 @@ void wk_destroy(wk_ctx* c) {
                       &c->d_state, &c->d_dict, &c->d_arena})
         b->release();
     for (void* hp : c->host_blocks) (void)hipHostFree(hp);
+    for (const wk_ctx::HostReg& r : c->regs) (void)hipHostUnregister(const_cast<char*>(r.p));
+    c->regs.clear();
     for (hipEvent_t ev : c->copy_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -2025,6 +2035,52 @@ static DtokArgs dtok_args(wk_ctx* c) {
 // Start copying text[begin, stop) of a block to the device on the copy stream;
 // the wk_dtok_scan of the same block finds it there.  At most one block ahead of
 // the one being scanned (two buffers).
+// hipMemcpyAsync host -> device of [src, src + n), cut where registered ranges
+// (wk_host_register) begin and end: one copy may not span two registrations.
+static hipError_t copy_text_async(wk_ctx* c, void* dst, const char* src, size_t n, hipStream_t stream) {
+    std::vector<size_t> cuts{0, n};
+    {
+        std::lock_guard<std::mutex> lock(c->reg_mu);
+        for (const wk_ctx::HostReg& r : c->regs) {
+            if (r.p > src && r.p < src + n) cuts.push_back((size_t)(r.p - src));
+            if (r.p + r.n > src && r.p + r.n < src + n) cuts.push_back((size_t)(r.p + r.n - src));
+        }
+    }
+    std::sort(cuts.begin(), cuts.end());
+    for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+        if (cuts[i + 1] == cuts[i]) continue;
+        const hipError_t e = hipMemcpyAsync((char*)dst + cuts[i], src + cuts[i], cuts[i + 1] - cuts[i], hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+int wk_host_register(wk_ctx* c, const void* p, size_t bytes) {
+    if (!c || !p || !bytes) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterReadOnly);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, WK_E_HIP, "hipHostRegister(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lock(c->reg_mu);
+    c->regs.push_back(wk_ctx::HostReg{(const char*)p, bytes});
+    return WK_OK;
+}
+
+int wk_host_unregister(wk_ctx* c, const void* p) {
+    if (!c || !p) return WK_E_ARG;
+    {
+        std::lock_guard<std::mutex> lock(c->reg_mu);
+        auto it = std::find_if(c->regs.begin(), c->regs.end(), [&](const wk_ctx::HostReg& r) { return r.p == (const char*)p; });
+        if (it == c->regs.end()) return fail(c, WK_E_ARG, "not a registered range");
+        c->regs.erase(it);
+    }
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipHostUnregister(const_cast<void*>(p)));
+    return WK_OK;
+}
+
 int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     if (!c || !text || begin < 0 || stop < begin) return WK_E_ARG;
     const int64_t n64 = stop - begin;
@@ -2038,7 +2094,7 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     c->copy_next ^= 1;
     const uint32_t n = (uint32_t)n64;
     HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
-    HIP_TRY(c, hipMemcpyAsync(c->d_textbuf[k].p, text + begin, n, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, text + begin, n, c->copy_stream));
     HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->copy_stream));
     c->copy_src[k] = text + begin;
@@ -2076,7 +2132,7 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
         k = c->copy_next;
         c->copy_next ^= 1;
         HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
-        HIP_TRY(c, hipMemcpyAsync(c->d_textbuf[k].p, src, n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
     }
     c->copy_src[k] = nullptr;  // (the buffer's tag is used up)
