@@ -115,3 +115,71 @@ def test_above_major_uniq_at_50M_records(flags, major):
     assert np.array_equal(tables[0][0], tables[1][0])
     assert np.array_equal(tables[0][1], tables[1][1])
     assert tables[0][0].size > 1000
+
+
+def test_per_read_stream_over_250M_records():
+    """`--rank free` and one rank under --uniq / --above / --major through the
+    per-read stream (csrc/wk_free.hpp) at the size `bench.py` times it: one
+    launch over 250 M packed records.  At that size: a read adds L units or
+    nothing (all of them with 'Unassigned' on), `--above` assigns at least the
+    reads `--major` assigns, which assigns at least those `--uniq` assigns; and
+    the first 1/8 of the reads give the same table through the general
+    evaluator (wk_chunk_stage + wk_classify_staged)."""
+    rng = np.random.default_rng(1003)
+    p = synth.as_sets(synth.lca_problem(rng, n_nodes=2_000_000,
+                                        n_subjects=100_000,
+                                        n_reads=50_000_000, with_names=False))
+    h = p['hier']
+    feats, first, sidx = np.unique(p['subj'], return_index=True,
+                                   return_inverse=True)
+    order = np.argsort(first)
+    rank_of = np.empty_like(order)
+    rank_of[order] = np.arange(order.size)
+    sidx = rank_of[sidx].astype(np.int32)
+    feats = feats[order].astype(np.int32)
+    qoff = p['qoff']
+    n_reads = qoff.size - 1
+    words = _words(sidx, qoff)
+    L = nat.WEIGHT_L
+    m = n_reads // 8
+    e = int(qoff[m])
+    assigned = {}
+    with nat.Context(0) as c:
+        c.set_tree(h.parent, h.last, h.rank_code)
+        c.build_rank_table(0, h.rank_codes['genus'])
+        c.set_subjects(feats)
+        c.counts_reserve(1 << 22)
+        cases = {'free': nat.Job(nat.MODE_FREE, 0, 0, 0, 0.0),
+                 'free_u': nat.Job(nat.MODE_FREE, 0, nat.F_UNASSIGNED, 0, 0.0),
+                 'uniq': nat.Job(nat.MODE_RANK, 0, nat.F_UNIQ, 0, 0.0),
+                 'major': nat.Job(nat.MODE_RANK, 0, 0, 0, 0.8),
+                 'above': nat.Job(nat.MODE_RANK, 0, nat.F_ABOVE, 0, 0.0),
+                 'above_u': nat.Job(nat.MODE_RANK, 0,
+                                    nat.F_ABOVE | nat.F_UNASSIGNED, 0, 0.0)}
+        for name, job in cases.items():
+            c.counts_clear()
+            c.reset_stats()
+            assert c.words_begin([job], 0), name
+            step = 6_000_000
+            for lo in range(0, n_reads, step):
+                hi = min(n_reads, lo + step)
+                c.words_append(words[int(qoff[lo]):int(qoff[hi])], hi - lo)
+            keys, vals = nat.canonical_counts(*c.counts_fetch())    # one launch
+            st = c.stats()
+            assert st['n_reads'] == n_reads and st['n_records'] == words.size
+            assert np.all(vals % L == 0)
+            assigned[name] = int(vals.astype(object).sum()) // L
+            # the first 1/8 both ways
+            c.counts_clear()
+            assert c.words_begin([job], 0)
+            c.words_append(words[:e], m)
+            a = nat.canonical_counts(*c.counts_fetch())
+            c.counts_clear()
+            c.chunk_stage(sidx[:e], qoff[:m + 1], group=0, subj_is_set=True,
+                          indexed=True)
+            c.classify_staged([job])
+            b = nat.canonical_counts(*c.counts_fetch())
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), name
+    assert assigned['free_u'] == n_reads and assigned['above_u'] == n_reads
+    assert assigned['uniq'] <= assigned['major'] <= assigned['above'] < n_reads
+    assert assigned['uniq'] > n_reads // 2 and assigned['free'] > n_reads // 2
