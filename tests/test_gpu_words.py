@@ -239,14 +239,16 @@ def test_rank_option_stream_equals_general_route(tmp_path, opts, dtok):
                         % (i, int(p['subj'][i])))
     nodes = str(tmp_path / 'nodes.dmp')
     bench.write_nodes_dmp(nodes, p['hier'])
-    for rank in ('genus', 'phylum'):
+    # (several ranks: the records are rewritten per job when a sample is classified)
+    for rank in ('genus', 'phylum', 'phylum,genus,species', 'free,family'):
         kw = dict(input_fp=str(indir), input_fmt='sam', nodes_fps=[nodes],
                   ranks=rank, **opts)
         if not dtok:
             os.environ['WOLTKA_NO_DTOK'] = '1'
+        tag = rank.replace(',', '_')
         try:
-            a, log_a = _run(tmp_path, 'w', False, **kw)
-            b, log_b = _run(tmp_path, 'g', True, **kw)
+            a, log_a = _run(tmp_path, 'w' + tag, False, **kw)
+            b, log_b = _run(tmp_path, 'g' + tag, True, **kw)
         finally:
             os.environ.pop('WOLTKA_NO_DTOK', None)
         assert list(a.values()) == list(b.values()) and log_a == log_b
@@ -298,6 +300,55 @@ def test_rank_option_stream_is_taken(ctx):
                 b = nat.canonical_counts(*c.counts_fetch())
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
                 assert a[0].size > 3
+
+
+def test_several_stream_jobs_are_taken(ctx):
+    """Job sets made of `free` and ranks under --uniq / --above / --major only
+    (mode 3: subject indices, rewritten per job at the flush) against the
+    general evaluator; reads and records are counted once."""
+    from woltka_amd import _native as nat
+    from woltka_amd import synth
+    rng = np.random.default_rng(9)
+    p = synth.as_sets(synth.lca_problem(rng, n_nodes=30000, n_subjects=2000,
+                                        n_reads=600_000, with_names=False,
+                                        offtree_frac=0.01))
+    h = p['hier']
+    feats, sidx = np.unique(p['subj'], return_inverse=True)
+    off = p['qoff'].astype(np.int64)
+    size = np.diff(off)
+    words = (sidx.astype(np.uint32) |
+             ((np.arange(sidx.size) - np.repeat(off[:-1], size)).astype(np.uint32) << np.uint32(23)) |
+             (np.repeat(size, size).astype(np.uint32) << np.uint32(27)))
+    half = off.size // 2
+    sets = [
+        [nat.Job(nat.MODE_RANK, s, nat.F_ABOVE, 0, 0.0) for s in range(3)],
+        [nat.Job(nat.MODE_RANK, 0, 0, 0, 0.8), nat.Job(nat.MODE_FREE, 0, nat.F_UNASSIGNED, 0, 0.0),
+         nat.Job(nat.MODE_RANK, 2, nat.F_UNIQ | nat.F_UNASSIGNED, 0, 0.0)],
+        [nat.Job(nat.MODE_FREE, 0, 0, 0, 0.0), nat.Job(nat.MODE_RANK, 1, nat.F_UNIQ, 0, 0.0)],
+    ]
+    for jobs in sets:
+        with nat.Context(0) as c:
+            c.set_tree(h.parent, h.last, h.rank_code)
+            for slot, rank in enumerate(('phylum', 'genus', 'species')):
+                c.build_rank_table(slot, h.rank_codes[rank])
+            c.counts_reserve(1 << 18)
+            seen = int(sidx[:int(off[half])].max()) + 1
+            c.set_subjects(feats[:seen].astype(np.int32))
+            assert c.words_begin(jobs, 4)
+            c.words_append(words[:int(off[half])], half)
+            c.set_subjects(feats.astype(np.int32))
+            assert c.words_begin(jobs, 4)
+            c.words_append(words[int(off[half]):], off.size - 1 - half)
+            a = nat.canonical_counts(*c.counts_fetch())
+            st = c.stats()
+            assert st['n_reads'] == off.size - 1 and st['n_records'] == words.size
+            c.counts_clear()
+            c.chunk_stage(sidx.astype(np.int32), p['qoff'], group=4,
+                          subj_is_set=True, indexed=True)
+            c.classify_staged(jobs)
+            b = nat.canonical_counts(*c.counts_fetch())
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            assert np.unique(nat.decode_keys(a[0])[0]).size == len(jobs)
 
 
 def test_free_rank_stream_is_taken(ctx):

@@ -390,17 +390,19 @@ class Engine:
                 len(self.jobs) > nat.MAX_JOBS or not self._tok_identity or \
                 os.environ.get('WOLTKA_NO_WORDS'):
             return False
-        if len(self.jobs) == 1 and self.jobs[0].mode == nat.MODE_FREE:
-            # `--rank free` alone: the free-rank stream (csrc/wk_free.hpp)
+        # jobs that look at whole reads — `--rank free`, a rank under --uniq /
+        # --above / --major above one half — all go to the per-read stream
+        # (csrc/wk_free.hpp), alone or several of them
+        def whole_reads(job):
+            if job.flags & nat.F_SIZED:
+                return False
+            if job.mode == nat.MODE_FREE:
+                return True
+            return job.mode == nat.MODE_RANK and (
+                job.major > 0.5 or (job.major <= 0 and bool(
+                    job.flags & (nat.F_UNIQ | nat.F_ABOVE))))
+        if all(map(whole_reads, self.jobs)):
             return self.use_tree
-        if len(self.jobs) == 1 and self.jobs[0].mode == nat.MODE_RANK and \
-                not self.jobs[0].flags & nat.F_SIZED:
-            # one rank under --uniq / --above / --major above one half: the
-            # same stream over the subjects' ancestors at the rank
-            job = self.jobs[0]
-            if job.major > 0.5 or (job.major <= 0 and job.flags & (
-                    nat.F_UNIQ | nat.F_ABOVE)):
-                return self.use_tree
         for job in self.jobs:
             if job.flags & (nat.F_UNIQ | nat.F_SIZED):
                 return False

@@ -61,6 +61,7 @@ struct FreeArgs {
     // a rank job under --uniq / --above / --major instead of the free-rank job:
     uint32_t by_rank, above;
     double major;  // > 0.5 (a value that reaches it is the only one that can), or 0
+    uint32_t count_stats;  // reads and records into stat_block (the first of several jobs over the same records)
     // reads per result id ([n_results]: 'Unassigned'), all zero between launches:
     // free_counts_kernel moves them to the count table and clears them
     uint32_t* dense;  // [n_results + 1]
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < lds_slots; i += blockDim.x)
         if (ccnt[i]) atomicAdd(&dense[ckeys[i]], ccnt[i]);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && a.count_stats) {
         a.stat_block[2 * blockIdx.x] += acc[0];
         a.stat_block[2 * blockIdx.x + 1] += acc[1];
     }
@@ -319,14 +320,14 @@ __global__ void __launch_bounds__(256) free_counts_kernel(uint32_t* __restrict__
     table_add(table, make_key(job, 0u, group, i == n_results ? (uint32_t)WK_FEATURE_UNASSIGNED : (uint32_t)result_node[i]), (unsigned long long)n * WK_WEIGHT_L);
 }
 
-// subject indices -> feature ids in place (chunks of the host tokenizer appended
-// to a free-rank accumulation)
-__global__ void __launch_bounds__(256) words_to_features_kernel(uint32_t* __restrict__ words, uint32_t n,
+// subject indices -> node ids (`src` may be `dst`: chunks appended to a
+// single-job accumulation are rewritten in place)
+__global__ void __launch_bounds__(256) words_to_features_kernel(const uint32_t* src, uint32_t* dst, uint32_t n,
                                                                 const int32_t* __restrict__ subj_feat, uint32_t n_subjects,
                                                                 uint32_t n_nodes, int* __restrict__ err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t w = words[i], s = w & kWordSubjMask;
+    const uint32_t w = src[i], s = w & kWordSubjMask;
     uint32_t f = kFreeMissing;
     if (s < n_subjects) {
         const uint32_t x = (uint32_t)subj_feat[s];
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(256) words_to_features_kernel(uint32_t* __rest
     } else if (w >> kWordSizeShift) {
         atomicOr(err, kErrFeatureRange);
     }
-    words[i] = (w & ~kWordSubjMask) | f;
+    dst[i] = (w & ~kWordSubjMask) | f;
 }
 
 }  // namespace wk

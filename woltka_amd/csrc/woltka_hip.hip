@@ -90,8 +90,20 @@ struct wk_ctx {
     // id, LCAs of rank-adjacent subjects as a sparse table; rebuilt when either changes
     std::vector<int32_t> parent_host, last_host, subj_feat_host;
     int tree_serial = 0, subj_serial = 0, free_tree = -1, free_subj = -1;
-    DevBuf f_rank, f_sparse, f_rblocks, f_dsparse, f_dparent, f_dself, f_rnode;  // (f_rblocks ...: the same over the distinct subject nodes, for the free-rank stream)
-    uint32_t f_dm = 0, f_results = 0;
+    DevBuf f_rank, f_sparse;
+    // tables of the per-read stream (wk_free.hpp) for one job: over the nodes its
+    // records can name — the subjects' nodes (kind 1, `--rank free`) or their
+    // ancestors at the job's rank (kind 2)
+    struct StreamTables {
+        DevBuf rblocks, dsparse, dparent, dself, rnode;
+        DevBuf subj_node;                    // kind 2: ancestor at the rank per subject (-1: none)
+        std::vector<int32_t> subj_node_host;
+        int node_slot = -1, node_tree = -1, node_rank = -1;  // what subj_node_host was made for
+        uint32_t dm = 0, results = 0;
+        int kind = -1, slot = -1, tree = -1, subj = -1, rank = -1;  // what the tables were made for
+    };
+    StreamTables st[WK_MAX_JOBS];
+    DevBuf w_tmp;  // several stream jobs: the records with the subject field rewritten for one job
     DevBuf f_dense;  // reads per result node of the free-rank stream
     int f_dense_tree = -1;
     uint32_t f_m = 0;
@@ -192,12 +204,8 @@ struct wk_ctx {
     };
     std::mutex reg_mu;
     std::vector<HostReg> regs;
-    int w_mode = 0;  // 0: subject indices for the weighted histogram; the stream of wk_free.hpp: 1: feature ids (one free-rank job), 2: ancestors at the job's rank (one rank job under --uniq / --above / --major)
-    DevBuf w_subj_t;                  // mode 2: ancestor at the rank per subject (-1: none)
-    std::vector<int32_t> w_subj_t_host;
-    int w_subj_t_slot = -1, w_subj_t_tree = -1, w_subj_t_rank = -1;  // what w_subj_t_host was made for
+    int w_mode = 0;  // 0: subject indices for the weighted histogram; the stream of wk_free.hpp: 1: feature ids (one free-rank job), 2: ancestors at the job's rank (one rank job under --uniq / --above / --major), 3: subject indices, rewritten per job when the sample is classified (several such jobs)
     int rank_serial = 0;              // bumped by wk_build_rank_table
-    int st_mode = -1, st_slot = -1, st_tree = -1, st_subj = -1, st_rank = -1;  // what the stream's tables (f_rblocks ...) were made for
     int free_per_cu = 2, free_threads = 1024, free_slots = 4096;  // launch shape of the free-rank stream (measurement knobs)  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
     int32_t max_gene_feature = 0;
     int use_range_log = 1;  // (0: the hashed miss log for the gene tally too; measurement)
@@ -346,12 +354,12 @@ __global__ void __launch_bounds__(256) table_compact_kernel(const unsigned long 
 // tree.find_rank (tree.py:467-510) for the subjects, on the host: ancestor (or
 // self) of each subject's node with the rank code of `slot`, -1 if none — what
 // rank_table_kernel holds for all nodes.  Kept up to date as subjects are added.
-static int ensure_subject_ancestors(wk_ctx* c, int slot) {
-    std::vector<int32_t>& t = c->w_subj_t_host;
-    if (c->w_subj_t_slot != slot || c->w_subj_t_tree != c->tree_serial || c->w_subj_t_rank != c->rank_serial) t.clear();
+static int ensure_subject_ancestors(wk_ctx* c, wk_ctx::StreamTables& T, int slot) {
+    std::vector<int32_t>& t = T.subj_node_host;
+    if (T.node_slot != slot || T.node_tree != c->tree_serial || T.node_rank != c->rank_serial) t.clear();
     if ((int32_t)t.size() > c->n_subjects) t.clear();
     const size_t have = t.size();
-    if (have == (size_t)c->n_subjects && c->w_subj_t_slot == slot) return WK_OK;
+    if (have == (size_t)c->n_subjects && T.node_slot == slot) return WK_OK;
     const int32_t code = c->rank_tab_code[slot];
     t.resize((size_t)c->n_subjects, -1);
     for (size_t s = have; s < t.size(); ++s) {
@@ -368,10 +376,10 @@ static int ensure_subject_ancestors(wk_ctx* c, int slot) {
             }
         t[s] = res;
     }
-    c->w_subj_t_slot = slot;
-    c->w_subj_t_tree = c->tree_serial;
-    c->w_subj_t_rank = c->rank_serial;
-    const int rc = upload(c, c->w_subj_t, t.data(), t.size() * 4);
+    T.node_slot = slot;
+    T.node_tree = c->tree_serial;
+    T.node_rank = c->rank_serial;
+    const int rc = upload(c, T.subj_node, t.data(), t.size() * 4);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return WK_OK;
@@ -380,16 +388,15 @@ static int ensure_subject_ancestors(wk_ctx* c, int slot) {
 // Tables of the per-read stream (wk_free.hpp) over the nodes its records can
 // name: the subjects' nodes (mode 1, `--rank free`) or their ancestors at the
 // job's rank (mode 2).
-static int ensure_stream_tables(wk_ctx* c, int mode, int slot) {
+static int ensure_stream_tables(wk_ctx* c, wk_ctx::StreamTables& T, int mode, int slot) {
     if (mode == 2) {
-        const int rc = ensure_subject_ancestors(c, slot);
+        const int rc = ensure_subject_ancestors(c, T, slot);
         if (rc) return rc;
     }
-    if (c->st_mode == mode && c->st_slot == slot && c->st_tree == c->tree_serial && c->st_subj == c->subj_serial &&
-        c->st_rank == c->rank_serial)
+    if (T.kind == mode && T.slot == slot && T.tree == c->tree_serial && T.subj == c->subj_serial && T.rank == c->rank_serial)
         return WK_OK;
     const int32_t n_nodes = c->n_nodes;
-    const std::vector<int32_t>& of = mode == 2 ? c->w_subj_t_host : c->subj_feat_host;
+    const std::vector<int32_t>& of = mode == 2 ? T.subj_node_host : c->subj_feat_host;
     std::vector<int32_t> dn;  // distinct nodes, ascending
     dn.reserve(of.size());
     for (int32_t v : of)
@@ -436,19 +443,19 @@ static int ensure_stream_tables(wk_ctx* c, int mode, int slot) {
         for (uint32_t i = 0; i + (1u << k) <= md - 1; ++i)
             dsparse[k * drow + i] = std::min(dsparse[(k - 1) * drow + i], dsparse[(k - 1) * drow + i + (1u << (k - 1))]);
     int rc;
-    if ((rc = upload(c, c->f_rblocks, blocks.data(), blocks.size() * sizeof(RankBlock)))) return rc;
-    if ((rc = upload(c, c->f_dsparse, dsparse.data(), dsparse.size() * 4))) return rc;
-    if ((rc = upload(c, c->f_dparent, dparent.data(), dparent.size() * 4))) return rc;
-    if ((rc = upload(c, c->f_dself, dself.data(), dself.size() * 4))) return rc;
-    if ((rc = upload(c, c->f_rnode, rnode.data(), rnode.size() * 4))) return rc;
+    if ((rc = upload(c, T.rblocks, blocks.data(), blocks.size() * sizeof(RankBlock)))) return rc;
+    if ((rc = upload(c, T.dsparse, dsparse.data(), dsparse.size() * 4))) return rc;
+    if ((rc = upload(c, T.dparent, dparent.data(), dparent.size() * 4))) return rc;
+    if ((rc = upload(c, T.dself, dself.data(), dself.size() * 4))) return rc;
+    if ((rc = upload(c, T.rnode, rnode.data(), rnode.size() * 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors are about to go out of scope
-    c->f_results = (uint32_t)rnode.size();
-    c->f_dm = (uint32_t)drow;
-    c->st_mode = mode;
-    c->st_slot = slot;
-    c->st_tree = c->tree_serial;
-    c->st_subj = c->subj_serial;
-    c->st_rank = c->rank_serial;
+    T.results = (uint32_t)rnode.size();
+    T.dm = (uint32_t)drow;
+    T.kind = mode;
+    T.slot = slot;
+    T.tree = c->tree_serial;
+    T.subj = c->subj_serial;
+    T.rank = c->rank_serial;
     return WK_OK;
 }
 
@@ -702,8 +709,10 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_rblocks, &c->f_dsparse, &c->f_dparent, &c->f_dself, &c->f_rnode, &c->f_dense, &c->w_subj_t, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_dense, &c->w_tmp, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
+    for (wk_ctx::StreamTables& T : c->st)
+        for (DevBuf* b : {&T.rblocks, &T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node}) b->release();
     c->c_words.release();
     for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
                       &c->d_state, &c->d_dict, &c->d_arena})
@@ -1664,27 +1673,36 @@ static int words_jobs_ok(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, Classify
     *ok = false;
     if (mode) *mode = 0;
     if (!c->use_weigh || c->n_subjects <= 0 || c->n_subjects > (int32_t)kWordSubjMask + 1) return WK_OK;
-    // one `--rank free` job: the free-rank stream over feature ids (wk_free.hpp)
-    if (n_jobs == 1 && jobs[0].mode == WK_MODE_FREE && !(jobs[0].flags & WK_F_SIZED)) {
-        if (c->n_nodes <= 0 || (uint32_t)c->n_nodes >= kFreeMissing) return WK_OK;
-        if (jobs[0].flags & WK_F_SUBOK)  // a subject that is no node is its own result under --subok: not a feature the stream can carry
-            for (int32_t f : c->subj_feat_host)
-                if (f >= c->n_nodes) return WK_OK;
-        if (mode) *mode = 1;
-        *ok = true;
-        return WK_OK;
-    }
-    // one rank job that looks at whole reads (--uniq, --above, --major above one half): the same stream over the
-    // subjects' ancestors at the rank
-    if (n_jobs == 1 && jobs[0].mode == WK_MODE_RANK && !(jobs[0].flags & WK_F_SIZED) &&
-        (jobs[0].major > 0.5 || (jobs[0].major <= 0.0 && (jobs[0].flags & (WK_F_UNIQ | WK_F_ABOVE))))) {
-        if (c->n_nodes <= 0 || (uint32_t)c->n_nodes >= kFreeMissing) return WK_OK;
-        const int slot = jobs[0].rank_slot;
-        if (slot < 0 || slot >= (int)(sizeof c->rank_tab / sizeof c->rank_tab[0]) || !c->rank_tab_valid[slot])
-            return fail(c, WK_E_STATE, "job 0: rank slot %d has not been built", slot);
-        if (mode) *mode = 2;
-        *ok = true;
-        return WK_OK;
+    // Jobs that look at whole reads — `--rank free` (classify.assign_free), a rank under --uniq, --above or --major above
+    // one half (classify.assign_rank) — go to the per-read stream over node ids (wk_free.hpp): one such job with the
+    // records rewritten as they are appended, several with the records rewritten per job when the sample is classified.
+    {
+        int n_stream = 0;
+        for (int j = 0; j < n_jobs; ++j) {
+            const wk_job& jb = jobs[j];
+            if (jb.flags & WK_F_SIZED) continue;
+            if (jb.mode == WK_MODE_FREE)
+                n_stream += 1;
+            else if (jb.mode == WK_MODE_RANK && (jb.major > 0.5 || (jb.major <= 0.0 && (jb.flags & (WK_F_UNIQ | WK_F_ABOVE)))))
+                n_stream += 1;
+        }
+        if (n_stream == n_jobs && n_jobs >= 1) {
+            if (c->n_nodes <= 0 || (uint32_t)c->n_nodes >= kFreeMissing) return WK_OK;
+            for (int j = 0; j < n_jobs; ++j) {
+                const wk_job& jb = jobs[j];
+                if (jb.mode == WK_MODE_FREE) {
+                    if (jb.flags & WK_F_SUBOK)  // a subject that is no node is its own result under --subok: not a feature the stream can carry
+                        for (int32_t f : c->subj_feat_host)
+                            if (f >= c->n_nodes) return WK_OK;
+                } else if (jb.rank_slot < 0 || jb.rank_slot >= (int)(sizeof c->rank_tab / sizeof c->rank_tab[0]) ||
+                           !c->rank_tab_valid[jb.rank_slot]) {
+                    return fail(c, WK_E_STATE, "job %d: rank slot %d has not been built", j, jb.rank_slot);
+                }
+            }
+            if (mode) *mode = n_jobs > 1 ? 3 : jobs[0].mode == WK_MODE_FREE ? 1 : 2;
+            *ok = true;
+            return WK_OK;
+        }
     }
     a = ClassifyArgs{};
     a.n_jobs = n_jobs;
@@ -1730,48 +1748,63 @@ int wk_words_flush(wk_ctx* c) {
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
     if (c->w_mode != 0) {
-        // ---- one free-rank job, or one rank job that looks at whole reads: the stream over node ids, then its dense
-        // counters into the count table
+        // ---- free-rank jobs and rank jobs that look at whole reads: per job, the stream over node ids, then its dense
+        // counters into the count table.  One job: the records hold its node ids since they were appended; several:
+        // they hold subject indices and are rewritten for one job at a time into a second buffer.
         const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->free_per_cu);
-        {
-            const int rcf = ensure_stream_tables(c, c->w_mode, c->w_mode == 2 ? c->w_jobs[0].rank_slot : -1);
-            if (rcf) return rcf;
-        }
-        FreeArgs fa{};
-        fa.rblocks = c->f_rblocks.as<RankBlock>();
-        fa.sparse = c->f_dsparse.as<int32_t>();
-        fa.parent_d = c->f_dparent.as<int32_t>();
-        fa.self_d = c->f_dself.as<int32_t>();
-        fa.sparse_m = c->f_dm;
-        fa.words = c->c_words.as<uint32_t>();
-        fa.n_records = (uint32_t)c->w_records;
-        fa.job = 0;
-        fa.group = (uint32_t)c->w_group;
-        fa.subok = (c->w_jobs[0].flags & WK_F_SUBOK) ? 1u : 0u;
-        fa.unassigned = (c->w_jobs[0].flags & WK_F_UNASSIGNED) ? 1u : 0u;
-        fa.by_rank = c->w_mode == 2 ? 1u : 0u;
-        fa.above = (c->w_jobs[0].flags & WK_F_ABOVE) ? 1u : 0u;
-        fa.major = c->w_mode == 2 ? c->w_jobs[0].major : 0.0;
         const CountTable table{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
-        // the dense counters of the results (zero between flushes: free_counts_kernel clears what it moves)
-        const size_t dense_bytes = ((size_t)c->f_results + 1) * 4;
-        if (c->f_dense.cap < dense_bytes || c->f_dense_tree != c->tree_serial) {  // (otherwise zero: more results never make the cleared range smaller)
-            HIP_TRY(c, c->f_dense.reserve(dense_bytes));
-            HIP_TRY(c, hipMemsetAsync(c->f_dense.p, 0, c->f_dense.cap, c->stream));
-            c->f_dense_tree = c->tree_serial;
+        if (c->w_mode == 3) HIP_TRY(c, c->w_tmp.reserve((size_t)c->w_records * 4 + 64));
+        for (size_t j = 0; j < c->w_jobs.size(); ++j) {
+            const wk_job& jb = c->w_jobs[j];
+            const int kind = jb.mode == WK_MODE_FREE ? 1 : 2;
+            wk_ctx::StreamTables& T = c->st[j];
+            {
+                const int rcf = ensure_stream_tables(c, T, kind, kind == 2 ? jb.rank_slot : -1);
+                if (rcf) return rcf;
+            }
+            FreeArgs fa{};
+            fa.words = c->c_words.as<uint32_t>();
+            if (c->w_mode == 3) {
+                hipLaunchKernelGGL(words_to_features_kernel, dim3((unsigned)((c->w_records + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->c_words.as<uint32_t>(), c->w_tmp.as<uint32_t>(), (uint32_t)c->w_records,
+                                   kind == 2 ? T.subj_node.as<int32_t>() : c->subj_feat.as<int32_t>(), (uint32_t)c->n_subjects,
+                                   (uint32_t)c->n_nodes, scalar_err(c));
+                fa.words = c->w_tmp.as<uint32_t>();
+            }
+            fa.rblocks = T.rblocks.as<RankBlock>();
+            fa.sparse = T.dsparse.as<int32_t>();
+            fa.parent_d = T.dparent.as<int32_t>();
+            fa.self_d = T.dself.as<int32_t>();
+            fa.sparse_m = T.dm;
+            fa.n_records = (uint32_t)c->w_records;
+            fa.job = (uint32_t)j;
+            fa.group = (uint32_t)c->w_group;
+            fa.subok = (jb.flags & WK_F_SUBOK) ? 1u : 0u;
+            fa.unassigned = (jb.flags & WK_F_UNASSIGNED) ? 1u : 0u;
+            fa.by_rank = kind == 2 ? 1u : 0u;
+            fa.above = (jb.flags & WK_F_ABOVE) ? 1u : 0u;
+            fa.major = kind == 2 ? jb.major : 0.0;
+            fa.count_stats = j == 0 ? 1u : 0u;  // (reads and records are counted once)
+            // the dense counters of the results (zero between launches: free_counts_kernel clears what it moves)
+            const size_t dense_bytes = ((size_t)T.results + 1) * 4;
+            if (c->f_dense.cap < dense_bytes || c->f_dense_tree != c->tree_serial) {  // (otherwise zero)
+                HIP_TRY(c, c->f_dense.reserve(dense_bytes));
+                HIP_TRY(c, hipMemsetAsync(c->f_dense.p, 0, c->f_dense.cap, c->stream));
+                c->f_dense_tree = c->tree_serial;
+            }
+            fa.dense = c->f_dense.as<uint32_t>();
+            fa.n_results = T.results;
+            fa.stat_block = c->stat_block.as<unsigned long long>();
+            KernelTimer* kt = ktimer_begin(c, "classify");
+            const size_t lds = (size_t)c->free_slots * 8 + (size_t)(c->free_threads / 64) * kFreeWaveLds;
+            hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, (uint32_t)c->free_slots);
+            ktimer_end(c, kt);
+            kt = ktimer_begin(c, "free_counts");
+            hipLaunchKernelGGL(free_counts_kernel, dim3((T.results + 256) / 256), dim3(256), 0, c->stream, fa.dense, fa.n_results,
+                               T.rnode.as<int32_t>(), fa.job, fa.group, table);
+            ktimer_end(c, kt);
+            HIP_TRY(c, hipGetLastError());
         }
-        fa.dense = c->f_dense.as<uint32_t>();
-        fa.n_results = c->f_results;
-        fa.stat_block = c->stat_block.as<unsigned long long>();
-        KernelTimer* kt = ktimer_begin(c, "classify");
-        const size_t lds = (size_t)c->free_slots * 8 + (size_t)(c->free_threads / 64) * kFreeWaveLds;
-        hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, (uint32_t)c->free_slots);
-        ktimer_end(c, kt);
-        kt = ktimer_begin(c, "free_counts");
-        hipLaunchKernelGGL(free_counts_kernel, dim3((c->f_results + 256) / 256), dim3(256), 0, c->stream, fa.dense, fa.n_results,
-                           c->f_rnode.as<int32_t>(), fa.job, fa.group, table);
-        ktimer_end(c, kt);
-        HIP_TRY(c, hipGetLastError());
         if (c->words_keep) return WK_OK;
         c->w_records = c->w_reads = 0;
         c->w_open = false;
@@ -1884,16 +1917,16 @@ int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group,
 
 // Free-rank accumulation: the subject fields of words [first, first + n) become feature ids.
 static int words_translate(wk_ctx* c, int64_t first, int64_t n) {
-    if (c->w_mode == 0 || n <= 0) return WK_OK;
+    if ((c->w_mode != 1 && c->w_mode != 2) || n <= 0) return WK_OK;  // (several stream jobs: rewritten per job at the flush)
     const int32_t* node_of = c->subj_feat.as<int32_t>();
     if (c->w_mode == 2) {  // (ancestors at the rank: -1 reads as "no node" like an id beyond the tree)
-        const int rc = ensure_subject_ancestors(c, c->w_jobs[0].rank_slot);
+        const int rc = ensure_subject_ancestors(c, c->st[0], c->w_jobs[0].rank_slot);
         if (rc) return rc;
-        node_of = c->w_subj_t.as<int32_t>();
+        node_of = c->st[0].subj_node.as<int32_t>();
     }
     hipLaunchKernelGGL(words_to_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                       c->c_words.as<uint32_t>() + first, (uint32_t)n, node_of, (uint32_t)c->n_subjects,
-                       (uint32_t)c->n_nodes, scalar_err(c));
+                       c->c_words.as<uint32_t>() + first, c->c_words.as<uint32_t>() + first, (uint32_t)n, node_of,
+                       (uint32_t)c->n_subjects, (uint32_t)c->n_nodes, scalar_err(c));
     HIP_TRY(c, hipGetLastError());
     return WK_OK;
 }
