@@ -11,6 +11,7 @@ Count keys carry a *group* = index of a (sample, stratum) pair, so one device
 table serves demultiplexed and stratified runs alike.
 """
 import os
+import time
 from fractions import Fraction
 from os.path import join
 
@@ -214,6 +215,16 @@ class StageRing:
                              for k, (dt, n) in self.layout.items()}
         return self._bufs[i]
 
+    def try_current(self):
+        """`current()` if a set is free right now, else None."""
+        import queue
+        if self._cur is None:
+            try:
+                self._cur = self._free.get_nowait()
+            except queue.Empty:
+                return None
+        return self.current()
+
     def take(self):
         i, self._cur = self._cur, None
         return i
@@ -358,6 +369,8 @@ class Engine:
         self._writer = None                 # MapWriter of the native read maps
         self._map_pool, self._map_seq, self._map_jobs = None, None, []   # their formatting threads
         self._subj_feat_arr = None
+        self._read_pool = None
+        self._dtok_lap = {}     # (WOLTKA_DTOK_TIMING: seconds inside _run_dtok)
         self.genes = None
         self.gene_feature = None
         # dense subject indices (order of first appearance in the alignments)
@@ -426,6 +439,9 @@ class Engine:
                 self._writer.close()
                 self._writer = None
         finally:
+            if self._read_pool is not None:
+                self._read_pool.shutdown(wait=True)
+                self._read_pool = None
             if self.tok is not None:
                 self.tok.close()
             if self._reader is not None:
@@ -926,6 +942,8 @@ class Engine:
         return self._subj_feat_arr
 
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
+    DTOK_READ_PIECE = int(os.environ.get('WOLTKA_READ_PIECE', 8 << 20))   # bytes per pread of the block reader's threads
+    DTOK_HEADROOM = 1 << 20     # room in front of a block's bytes for the run the block before left unfinished
     HOSTREG_PIECE = 256 << 20   # a file is pinned in place in pieces of this size (a multiple of the page size)
     HOSTREG_MIN = 64 << 20      # smaller files are read into pinned buffers
     HOSTREG_RATE = 40e9         # bytes/s of the first piece's pinning below which the file is read instead
@@ -947,55 +965,114 @@ class Engine:
         rd = self._reader
         block = self.DTOK_BLOCK
         if self._tring is None:
-            self._tring = StageRing(self.ctx, 5, {
-                'text': (np.uint8, block + (1 << 20))})
+            self._tring = StageRing(self.ctx, 8, {
+                'text': (np.uint8, block + self.DTOK_HEADROOM)})
         ring = self._tring
         free = queue.Queue()
 
         def blocks():
-            pos, carry, in_header, first = 0, b'', True, True
+            # A slot holds [headroom | file bytes]: the bytes of a block go to
+            # a fixed place, so the reads of the next blocks can be under way
+            # (8 MB pieces on a pool of threads: ~100 GB/s from the page cache
+            # with 16 of them, tools/ubench/pread_scaling.py; one 64 MB call at
+            # a time cut among the tokenizer's threads gave 15-40) while this
+            # one is cut; the unfinished last run of the block before (the
+            # carry) is copied in front of them.
+            from collections import deque
+            from concurrent.futures import ThreadPoolExecutor
+            H = self.DTOK_HEADROOM
+            PIECE = self.DTOK_READ_PIECE
+            if self._read_pool is None:
+                self._read_pool = ThreadPoolExecutor(
+                    max_workers=max(2, tokenizer_threads() // 2))
+            pool = self._read_pool
+            pending = deque()       # (slot, buf, futures, want, file position)
+            state = {'next': 0}
+
+            def issue(span, wait):
+                want = min(span, size - state['next'])
+                if want <= 0:
+                    return False
+                bufs = ring.current() if wait else ring.try_current()
+                if bufs is None:
+                    return False
+                buf, slot = bufs['text'], ring.take()
+                mv = memoryview(buf).cast('B')
+                p0 = state['next']
+                futs = [pool.submit(os.preadv, fd,
+                                    [mv[H + o:H + min(o + PIECE, want)]], p0 + o)
+                        for o in range(0, want, PIECE)]
+                pending.append((slot, buf, futs, want, p0))
+                state['next'] = p0 + want
+                return True
+
+            carry, in_header, first = b'', True, True
             # small blocks first while the dictionary is cold: a block's
             # unknown subjects are listed per record and interned on the host
             ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
             span = ramp or block
-            while pos < size or carry:
-                want = min(span, size - pos)
-                need = len(carry) + want
-                slot, buf = None, None
-                if need <= ring.layout['text'][1]:
-                    buf = ring.current()['text']
-                    slot = ring.take()
-                else:                       # (a run longer than a block)
-                    buf = np.empty(need, dtype=np.uint8)
-                view = memoryview(buf).cast('B')
-                view[:len(carry)] = carry
-                t0 = time.perf_counter()
-                got = rd.read_into(fd, pos, view[len(carry):need]) \
-                    if want else 0
-                lap['read'] += time.perf_counter() - t0
-                fill = len(carry) + got
-                pos += got
-                final = pos >= size or (want and not got)
-                t0 = time.perf_counter()
-                ok, begin, stop, hdr = nat.Tokenizer.sam_span(
-                    view[:fill], final, in_header)
-                lap['span'] += time.perf_counter() - t0
-                if not ok and not final:    # no complete run yet: read more
-                    carry = bytes(view[:fill])
-                    span *= 2
-                    if slot is not None:
+            try:
+                while True:
+                    if not pending and not issue(min(span, block), True):
+                        break
+                    while ramp is None and span <= block and len(pending) < 3 \
+                            and issue(block, False):
+                        pass
+                    slot, buf, futs, want, p0 = pending.popleft()
+                    t0 = time.perf_counter()
+                    got = sum(f.result() for f in futs)
+                    lap['read'] += time.perf_counter() - t0
+                    final = p0 + got >= size or got < want
+                    if len(carry) > H or span > block:
+                        # a run longer than the headroom / a block: the plain way
                         ring.release(slot)
-                    continue
-                if ramp is not None:
-                    ramp = min(block, ramp * 4)
-                    if ramp == block:
-                        tok.warm, ramp = True, None
-                span = ramp or block
-                carry = b'' if final else bytes(view[stop:fill])
-                yield slot, buf, fill, begin, stop, first, final, in_header, hdr
-                in_header, first = hdr, False
-                if final:
-                    return
+                        while pending:      # (read again from here)
+                            s2, _, f2, _, _ = pending.popleft()
+                            for f in f2:
+                                f.result()
+                            ring.release(s2)
+                        want = min(span, size - p0)
+                        whole = np.empty(len(carry) + want, dtype=np.uint8)
+                        view = memoryview(whole).cast('B')
+                        view[:len(carry)] = carry
+                        got = rd.read_into(fd, p0, view[len(carry):]) \
+                            if want else 0
+                        state['next'] = p0 + got
+                        final = p0 + got >= size or got < want
+                        slot, out = None, whole[:len(carry) + got]
+                    else:
+                        start = H - len(carry)
+                        if carry:
+                            memoryview(buf).cast('B')[start:H] = carry
+                        out = buf[start:H + got]
+                    fill = out.size
+                    t0 = time.perf_counter()
+                    ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                        out, final, in_header)
+                    lap['span'] += time.perf_counter() - t0
+                    if not ok and not final:    # no complete run yet: read more
+                        carry = out.tobytes()
+                        span *= 2
+                        if slot is not None:
+                            ring.release(slot)
+                        continue
+                    if ramp is not None:
+                        ramp = min(block, ramp * 4)
+                        if ramp == block:
+                            tok.warm, ramp = True, None
+                    span = ramp or block
+                    carry = b'' if final else out[stop:].tobytes()
+                    yield slot, out, fill, begin, stop, first, final, \
+                        in_header, hdr
+                    in_header, first = hdr, False
+                    if final:
+                        return
+            finally:
+                while pending:
+                    s2, _, f2, _, _ = pending.popleft()
+                    for f in f2:
+                        f.result()
+                    ring.release(s2)
 
         # The same blocks without a copy on the host: the file mapped read-only
         # and pinned in place piece by piece (wk_host_register), so that the
@@ -1180,6 +1257,10 @@ class Engine:
                   % (lap['blocks'], tot, lap['wait'], lap['copy'], lap['scan'],
                      lap['read'], lap['span'], lap['rest'],
                      lap.get('unreg', 0.0)), file=sys.stderr)
+            print('[dtok] per block on this thread:', {
+                k: round(v, 3) for k, v in self._dtok_lap.items()},
+                file=sys.stderr)
+            self._dtok_lap = {}
 
     def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False):
         """One block of the device route through the host tokenizer after
@@ -1260,9 +1341,17 @@ class Engine:
         group = self._group_array(1, sample, None)
         for rank in self.ranks:
             data[rank].setdefault(sample, {})
+        lap = self._dtok_lap
+        t0 = time.perf_counter()
         self._sync_subjects(data)
-        if self.ctx.words_begin(self.jobs, group):
+        t1 = time.perf_counter()
+        began = self.ctx.words_begin(self.jobs, group)
+        t2 = time.perf_counter()
+        lap['subjects'] = lap.get('subjects', 0.0) + t1 - t0
+        lap['begin'] = lap.get('begin', 0.0) + t2 - t1
+        if began:
             status, n_reads, _ = self.ctx.dtok_emit()
+            lap['emit'] = lap.get('emit', 0.0) + time.perf_counter() - t2
             if status == 0:
                 self._n_reads += n_reads
                 return n_reads

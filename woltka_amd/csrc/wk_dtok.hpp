@@ -467,17 +467,33 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
         word = (uint32_t)a.lsubj[i] | ((pos & 15u) << kWordSubjBits) | ((size & 31u) << kWordSizeShift);
     }
     if (big) atomicOr(&a.state->flags, kDtokBigRead);
-    // one reservation per wave
+    // one reservation per workgroup (a returning atomic on one word saturates
+    // near 90 per microsecond: one per wave — 24 k of them for a 64 MB block —
+    // was half of this kernel's time)
+    __shared__ uint32_t w_rec[kDtokThreads / kWave], w_reads[kDtokThreads / kWave];
+    __shared__ unsigned long long block_base;
+    const uint32_t wave = threadIdx.x / kWave;
     const unsigned long long mask = __ballot(rec);
     const unsigned long long reads = __ballot(rec && pos == 0u);
-    unsigned long long base = 0;
     if (lane == 0) {
-        if (mask) base = atomicAdd(&a.state->n_out, (unsigned long long)__popcll(mask));
-        if (reads) atomicAdd(&a.state->n_reads, (unsigned long long)__popcll(reads));
+        w_rec[wave] = (uint32_t)__popcll(mask);
+        w_reads[wave] = (uint32_t)__popcll(reads);
     }
-    base = __shfl(base, 0, kWave);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0, r = 0;
+        for (uint32_t w = 0; w < kDtokThreads / kWave; ++w) {
+            const uint32_t c = w_rec[w];
+            w_rec[w] = n;  // (exclusive prefix: the wave's place in the workgroup's range)
+            n += c;
+            r += w_reads[w];
+        }
+        block_base = n ? atomicAdd(&a.state->n_out, (unsigned long long)n) : 0ull;
+        if (r) atomicAdd(&a.state->n_reads, (unsigned long long)r);
+    }
+    __syncthreads();
     if (!rec) return;
-    const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned long long at = block_base + w_rec[wave] + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
     if (at < a.out_cap) a.out[at] = word;
 }
 

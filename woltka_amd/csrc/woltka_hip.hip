@@ -2127,8 +2127,9 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     c->copy_next ^= 1;
     const uint32_t n = (uint32_t)n64;
     HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
+    // (only the copy on this stream: the 64 zero bytes behind the text are a fill
+    // kernel, which wk_dtok_scan launches on its own stream behind the copy's event)
     HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, text + begin, n, c->copy_stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->copy_stream));
     c->copy_src[k] = text + begin;
     c->copy_n[k] = n;
@@ -2161,6 +2162,7 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
         if (c->copy_src[q] == src && c->copy_n[q] == n) k = q;
     if (k >= 0) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));
+        HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
     } else {
         k = c->copy_next;
         c->copy_next ^= 1;

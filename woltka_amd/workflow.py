@@ -85,13 +85,21 @@ def workflow(
     # (the run builds millions of small containers — table rows, profile
     # cells — and no reference cycles: the cyclic collector's passes over them
     # cost more than the classification; paused for the call)
+    # (and the helper threads — readers, formatters — hold the interpreter for
+    # moments only, but this thread asks for it back after every native call:
+    # with the default switch interval of 5 ms a hand-over cost ~0.2 ms, a
+    # dozen times per block of text)
     import gc
+    import sys
     gc_was_on = gc.isenabled()
+    switch = sys.getswitchinterval()
     gc.disable()
+    sys.setswitchinterval(min(switch, 1e-4))
     try:
         return _workflow(**{k: v for k, v in locals().items()
-                            if k not in ('gc', 'gc_was_on')})
+                            if k not in ('gc', 'gc_was_on', 'sys', 'switch')})
     finally:
+        sys.setswitchinterval(switch)
         if gc_was_on:
             gc.enable()
 
