@@ -79,6 +79,8 @@ int wk_coords_parse(const char* buf, int64_t len, wk_coords** out) {
     std::vector<Nucl> nucls;
     NameTable index;  // nucleotide name -> position in `nucls`
     NameTable used;   // gene ids seen (until the first repeat)
+    // (a gene line is >= ~12 bytes: room for all of them, no rehash on the way)
+    used.reserve((size_t)len / 12 + 16, (size_t)len / 2 + 16);
     int cur = -1;
     bool isdup = false;
     const char* p = buf;

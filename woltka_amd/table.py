@@ -35,6 +35,33 @@ def allkeys(dic):
     return set().union(*dic.values())
 
 
+class _NoMeta:
+    """`[{} for _ in features]` without the half million dicts: a sequence of
+    fresh empty metadata dicts of a given length."""
+
+    def __init__(self, n):
+        self._n = n
+
+    def __len__(self):
+        return self._n
+
+    def __bool__(self):
+        return self._n > 0
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [{} for _ in range(*i.indices(self._n))]
+        if not -self._n <= i < self._n:
+            raise IndexError(i)
+        return {}
+
+    def __iter__(self):
+        return ({} for _ in range(self._n))
+
+    def __eq__(self, other):
+        return list(self) == other
+
+
 def prep_table(profile, samples=None, tree=None, rankdic=None, namedic=None,
                name_as_id=False):
     """{sample: {feature: value}} -> (data, features, samples, metadata)."""
@@ -65,7 +92,7 @@ def prep_table(profile, samples=None, tree=None, rankdic=None, namedic=None,
                     if any(row)]
             features = [k for k, _ in kept]
             data = [row for _, row in kept]
-        return data, features, samples, [{} for _ in features]
+        return data, features, samples, _NoMeta(len(features))
     for key in keys:
         row = [profile[s][key] if key in profile[s] else 0 for s in samples]
         if not any(row):

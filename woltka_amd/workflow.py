@@ -432,7 +432,7 @@ def classify(
                 for (rank, sample, key), value in engine.replay_end().items():
                     data[rank][sample][key] = value
     finally:
-        engine.close()
+        engine.close_later()
     if cover is not None:
         click.echo('Calculating per sample coverage...', nl=False)
         write_coverage(cover.merged(), outcov_dir, outcov_fmt)
