@@ -604,6 +604,10 @@ int wk_coords_fetch(const wk_coords* c, int32_t* goff, int32_t* start0,
                     int32_t* end, int32_t* findex, char* genome_blob,
                     int64_t* genome_off, char* gene_blob, int64_t* gene_off);
 void wk_coords_free(wk_coords* c);
+/* The n strings blob[off[i], off[i + 1]) written to `out` one after the other,
+ * each followed by `sep` (off[n] - off[0] + n bytes): what a host layer splits
+ * into its own string objects in one call. */
+int wk_blob_join(const char* blob, const int64_t* off, int64_t n, char sep, char* out);
 
 /* ---- measurement ------------------------------------------------------- */
 /* HIP-event timing on the context's own stream (the stream every kernel of

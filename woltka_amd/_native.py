@@ -40,7 +40,7 @@ SYMBOLS = (
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
     'wk_set_uniform_group', 'wk_chunk_download', 'wk_ordinal_hit_offsets',
-    'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
+    'wk_blob_join', 'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
     'wk_words_begin', 'wk_words_append',
     'wk_words_wait', 'wk_words_flush', 'wk_words_pending',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
@@ -130,6 +130,8 @@ def load_library():
                                         i64p, i64p]),
         'wk_host_alloc': (C.c_int, [p, C.c_size_t, C.POINTER(C.c_void_p)]),
         'wk_host_free': (C.c_int, [p, C.c_void_p]),
+        'wk_blob_join': (C.c_int, [C.c_char_p, i64p, C.c_int64, C.c_char,
+                                   C.c_void_p]),
         'wk_host_register': (C.c_int, [p, C.c_void_p, C.c_size_t]),
         'wk_host_unregister': (C.c_int, [p, C.c_void_p]),
         'wk_words_begin': (C.c_int, [p, C.POINTER(Job), C.c_int32, C.c_int32,
@@ -981,7 +983,15 @@ def _blob(strings):
 
 def _split(raw, off):
     """list of str from a bytes blob and its offsets."""
-    o = off.tolist()
+    n = len(off) - 1
+    if n > 1000 and b'\n' not in raw:
+        # one decode + one split instead of a slice and a decode per string
+        off = _arr(off, np.int64)
+        out = np.empty(int(off[-1] - off[0]) + n, dtype=np.uint8)
+        if load_library().wk_blob_join(raw, _ptr(off, C.c_int64), n, b'\n',
+                                       C.c_void_p(out.ctypes.data)) == OK:
+            return out.tobytes().decode().split('\n')[:-1]
+    o = off.tolist() if hasattr(off, 'tolist') else list(off)
     return [raw[a:b].decode() for a, b in zip(o, o[1:])]
 
 

@@ -198,5 +198,18 @@ int wk_coords_fetch(const wk_coords* c, int32_t* goff, int32_t* start0, int32_t*
 
 void wk_coords_free(wk_coords* c) { delete c; }
 
+int wk_blob_join(const char* blob, const int64_t* off, int64_t n, char sep, char* out) {
+    if (n < 0 || !off || !out || (n > 0 && !blob && off[n] > off[0])) return WK_E_ARG;
+    char* w = out;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t len = off[i + 1] - off[i];
+        if (len < 0) return WK_E_ARG;
+        memcpy(w, blob + off[i], (size_t)len);
+        w += len;
+        *w++ = sep;
+    }
+    return WK_OK;
+}
+
 
 }  // extern "C"

@@ -73,8 +73,8 @@ class NativeGeneTable(GeneTable):
     @property
     def names(self):
         if self._names is None:
-            raw, o = self.name_blob, self.name_off.tolist()
-            self._names = [raw[a:b].decode() for a, b in zip(o, o[1:])]
+            from ._native import _split
+            self._names = _split(bytes(self.name_blob), self.name_off)
         return self._names
 
     @names.setter
