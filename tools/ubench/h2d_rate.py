@@ -61,3 +61,17 @@ for flags, label in ((0, 'default'), (0x40000000, 'non-coherent'), (0x80000000, 
             th.join()
         print(f'{label:15s} {"with 8 writer threads" if busy else "alone":22s}: {20 * n / t / 1e9:6.1f} GB/s, '
               f'{t / 20 * 1e3:.2f} ms per block, enqueue {t_call / 20 * 1e3:.3f} ms', flush=True)
+
+# source not aligned (a block begins where the last run of the block before was cut)
+pin = C.c_void_p()
+hip.hipHostMalloc(C.byref(pin), n + 4096, 0)
+for off in (0, 1, 4, 16, 64, 123, 256, 4096 - 7):
+    for size in (n, n - 13):
+        hip.hipMemcpyAsync(dev, C.c_void_p(pin.value + off), size, 1, stream)
+        hip.hipStreamSynchronize(stream)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hip.hipMemcpyAsync(dev, C.c_void_p(pin.value + off), size, 1, stream)
+            hip.hipStreamSynchronize(stream)
+        t = time.perf_counter() - t0
+        print(f'source offset {off:5d}, {size} bytes: {10 * size / t / 1e9:6.1f} GB/s', flush=True)

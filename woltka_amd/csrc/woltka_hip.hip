@@ -227,6 +227,9 @@ struct wk_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     const char* copy_src[2] = {nullptr, nullptr};
+    DevBuf d_tiles_k[2], d_tile_off_k[2];          // newlines per tile of a block copied ahead, counted behind its copy
+    unsigned long long* copy_newlines = nullptr;   // [2] pinned: their totals
+    bool copy_counted[2] = {false, false};
     uint32_t copy_n[2] = {0, 0};
     int copy_next = 0, dt_cur = 0;
     int use_subject_bins = 1;
@@ -714,6 +717,7 @@ void wk_destroy(wk_ctx* c) {
     for (wk_ctx::StreamTables& T : c->st)
         for (DevBuf* b : {&T.rblocks, &T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node}) b->release();
     c->c_words.release();
+    for (DevBuf* b : {&c->d_tiles_k[0], &c->d_tiles_k[1], &c->d_tile_off_k[0], &c->d_tile_off_k[1]}) b->release();
     for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
                       &c->d_state, &c->d_dict, &c->d_arena})
         b->release();
@@ -2130,6 +2134,27 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     // (only the copy on this stream: the 64 zero bytes behind the text are a fill
     // kernel, which wk_dtok_scan launches on its own stream behind the copy's event)
     HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, text + begin, n, c->copy_stream));
+    // ... and, behind the copy on its stream, the count of the block's newlines:
+    // wk_dtok_scan finds the number on the host instead of waiting for it
+    {
+        if (!c->copy_newlines) {
+            void* hp = nullptr;
+            HIP_TRY(c, hipHostMalloc(&hp, 64, hipHostMallocDefault));
+            c->host_blocks.push_back(hp);
+            c->copy_newlines = static_cast<unsigned long long*>(hp);
+        }
+        const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
+        HIP_TRY(c, c->d_tiles_k[k].reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, c->d_tile_off_k[k].reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 10 + k), 0, 8, c->copy_stream));
+        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->copy_stream, c->d_textbuf[k].as<unsigned char>(), n,
+                           c->d_tiles_k[k].as<unsigned long long>());
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->copy_stream, c->d_tiles_k[k].as<unsigned long long>(),
+                           c->d_tile_off_k[k].as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 10 + k));
+        HIP_TRY(c, hipMemcpyAsync(&c->copy_newlines[k], scalar_u64(c, 10 + k), 8, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(c, hipGetLastError());
+        c->copy_counted[k] = true;
+    }
     HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->copy_stream));
     c->copy_src[k] = text + begin;
     c->copy_n[k] = n;
@@ -2170,22 +2195,32 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
         HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
     }
+    const bool counted = c->copy_src[k] == src && c->copy_counted[k];
     c->copy_src[k] = nullptr;  // (the buffer's tag is used up)
+    c->copy_counted[k] = false;
     c->dt_cur = k;
     // line starts: newlines per tile -> offsets -> positions
     const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
-    HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
-    HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
     HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
-    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
     KernelTimer* kt = ktimer_begin(c, "dtok_lines");
-    hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
-                       c->d_tiles.as<unsigned long long>());
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
-                       c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
     unsigned long long n_newlines = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_newlines, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned long long* tile_off = nullptr;
+    if (counted) {  // (counted behind the copy: the number is on the host once the copy's event has passed)
+        HIP_TRY(c, hipEventSynchronize(c->copy_ev[k]));
+        n_newlines = c->copy_newlines[k];
+        tile_off = c->d_tile_off_k[k].as<unsigned long long>();
+    } else {
+        HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
+                           c->d_tiles.as<unsigned long long>());
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
+                           c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+        HIP_TRY(c, hipMemcpyAsync(&n_newlines, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        tile_off = c->d_tile_off.as<unsigned long long>();
+    }
     const bool open_end = src[n - 1] != '\n';  // a last line without newline
     const uint32_t lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
     HIP_TRY(c, c->d_lines.reserve(((size_t)lines + 2) * 4));
@@ -2202,7 +2237,7 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
     HIP_TRY(c, hipMemsetAsync(c->d_lines.p, 0, 4, c->stream));  // line 0 starts at 0
     hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
-                       c->d_tile_off.as<unsigned long long>(), c->d_lines.as<uint32_t>());
+                       tile_off, c->d_lines.as<uint32_t>());
     if (open_end) {
         const uint32_t end = n + 1;  // as if a newline followed the text
         HIP_TRY(c, hipMemcpyAsync(c->d_lines.as<uint32_t>() + lines, &end, 4, hipMemcpyHostToDevice, c->stream));
