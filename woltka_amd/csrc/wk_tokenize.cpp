@@ -116,6 +116,8 @@ struct Local {
     std::vector<int32_t> rend;   // per read: end offset into the records
     std::vector<uint64_t> qname; // per read: (offset << 24) | (len << 2) | mate
     std::vector<int32_t> group;  // per read: stratum id or -1 (want_groups)
+    std::string gkeys;             // ... their keys (read id + mate suffix), looked up together at the end of the range
+    std::vector<uint32_t> gkey_off;
     std::vector<int32_t> sample; // per read: sample id >= 0, or -(1 + local new-name id) (want_samples)
     NameTable fresh_samples;
     NameTable fresh;             // names not yet in the global table
@@ -138,6 +140,8 @@ struct Local {
         rend.clear();
         qname.clear();
         group.clear();
+        gkeys.clear();
+        gkey_off.clear();
         sample.clear();
         if (fresh.size()) fresh = NameTable();
         if (fresh_samples.size()) fresh_samples = NameTable();
@@ -447,6 +451,76 @@ class WorkPool {
     }
 };
 
+// One shard of the read id -> stratum table of a sample (tens of millions of
+// entries: every probe is a cache miss).  A slot carries 32 bits of the hash next
+// to the entry's index, an entry its key's place and its label: a hit costs the
+// slot, the entry and the key (three lines), a miss usually the slot alone.
+struct StrataShard {
+    struct Ent {
+        uint32_t off, len;
+        int32_t label;
+    };
+    std::vector<uint64_t> slot;  // (tag << 32) | (entry + 1); 0 = empty
+    std::vector<Ent> ent;
+    std::string arena;
+    size_t mask = 0;
+    StrataShard() { rehash(1 << 10); }
+    static uint32_t tag_of(uint64_t hv) { return (uint32_t)(hv >> 26); }
+    void rehash(size_t n) {
+        slot.assign(n, 0ull);
+        mask = n - 1;
+        for (size_t id = 0; id < ent.size(); ++id) {
+            const uint64_t hv = hash_bytes(arena.data() + ent[id].off, ent[id].len);
+            size_t h = hv & mask;
+            while (slot[h]) h = (h + 1) & mask;
+            slot[h] = ((uint64_t)tag_of(hv) << 32) | (uint64_t)(id + 1);
+        }
+    }
+    void reserve(size_t n, size_t bytes) {
+        size_t want = slot.size();
+        while (want < 2 * n + 2) want <<= 1;
+        if (want != slot.size()) rehash(want);
+        ent.reserve(n);
+        arena.reserve(bytes);
+    }
+    int32_t find_entry(const char* p, size_t n, uint64_t hv) const {
+        const uint32_t tag = tag_of(hv);
+        for (size_t h = hv & mask;; h = (h + 1) & mask) {
+            const uint64_t v = slot[h];
+            if (!v) return -1;
+            if ((uint32_t)(v >> 32) != tag) continue;
+            const Ent& e = ent[(uint32_t)v - 1u];
+            if (e.len == n && memcmp(arena.data() + e.off, p, n) == 0) return (int32_t)((uint32_t)v - 1u);
+        }
+    }
+    int32_t find(const char* p, size_t n, uint64_t hv) const {
+        const int32_t id = find_entry(p, n, hv);
+        return id < 0 ? -1 : ent[(size_t)id].label;
+    }
+    void put(const char* p, size_t n, uint64_t hv, int32_t label) {  // a repeated key keeps its last label, like dict()
+        const int32_t id = find_entry(p, n, hv);
+        if (id >= 0) {
+            ent[(size_t)id].label = label;
+            return;
+        }
+        if ((ent.size() + 1) * 2 > slot.size()) rehash(slot.size() * 2);
+        ent.push_back(Ent{(uint32_t)arena.size(), (uint32_t)n, label});
+        arena.append(p, n);
+        size_t h = hv & mask;
+        while (slot[h]) h = (h + 1) & mask;
+        slot[h] = ((uint64_t)tag_of(hv) << 32) | (uint64_t)ent.size();
+    }
+    void prefetch_slot(uint64_t hv) const { __builtin_prefetch(&slot[hv & mask]); }
+    void prefetch_entry(uint64_t hv) const {  // (the first slot of the probe sequence: where a key usually is)
+        const uint64_t v = slot[hv & mask];
+        if (v) __builtin_prefetch(&ent[(uint32_t)v - 1u]);
+    }
+    void prefetch_key(uint64_t hv) const {
+        const uint64_t v = slot[hv & mask];
+        if (v) __builtin_prefetch(arena.data() + ent[(uint32_t)v - 1u].off);
+    }
+};
+
 struct wk_tok {
     int n_threads = 1;
     NameTable names;     // global subject dictionary (sidx = id)
@@ -486,14 +560,11 @@ struct wk_tok {
     // (sharded by the top hash bits so that a map of tens of millions of reads is
     // built by all threads: each shard is owned by one thread while loading)
     static constexpr int kStrataShards = 64;
-    NameTable strata_keys[kStrataShards];
-    std::vector<int32_t> strata_of[kStrataShards];  // per key id of the shard
+    StrataShard strata[kStrataShards];
     NameTable strata_labels;
     int32_t strata_find(const char* p, size_t n) const {
         const uint64_t hv = hash_bytes(p, n);
-        const int sh = (int)(hv >> 58);
-        const int32_t id = strata_keys[sh].find(p, n, hv);
-        return id < 0 ? -1 : strata_of[sh][id];
+        return strata[hv >> 58].find(p, n, hv);
     }
     // demultiplexing (workflow.demultiplex, workflow.py:844-909): sample = text
     // before the first '_' of the read id, if anything follows it
@@ -546,6 +617,34 @@ inline bool same_name(const char* a, size_t an, const char* b, size_t bn) {
     return an == bn && memcmp(a, b, an) == 0;
 }
 
+// The strata of a range's reads, looked up together: the table of a sample does
+// not fit any cache, so the lookups run as a pipeline — hash and ask for the
+// slot's line, a few keys later for the entry's, then for the key's, and only
+// then compare — instead of one miss after the other per read.
+static void resolve_groups(const wk_tok* T, Local& out) {
+    const size_t n = out.group.size();
+    if (n == 0) return;
+    constexpr size_t D = 8, R = 32;  // keys between two steps; ring of hashes
+    uint64_t hv[R];
+    out.gkey_off.push_back((uint32_t)out.gkeys.size());
+    const char* keys = out.gkeys.data();
+    for (size_t i = 0; i < n + 3 * D; ++i) {
+        if (i < n) {
+            const uint64_t h = hash_bytes(keys + out.gkey_off[i], out.gkey_off[i + 1] - out.gkey_off[i]);
+            hv[i % R] = h;
+            T->strata[h >> 58].prefetch_slot(h);
+        }
+        if (i >= D && i - D < n) T->strata[hv[(i - D) % R] >> 58].prefetch_entry(hv[(i - D) % R]);
+        if (i >= 2 * D && i - 2 * D < n) T->strata[hv[(i - 2 * D) % R] >> 58].prefetch_key(hv[(i - 2 * D) % R]);
+        if (i >= 3 * D) {
+            const size_t j = i - 3 * D;
+            const uint64_t h = hv[j % R];
+            out.group[j] = T->strata[h >> 58].find(keys + out.gkey_off[j], out.gkey_off[j + 1] - out.gkey_off[j], h);
+        }
+    }
+    out.gkey_off.pop_back();
+}
+
 template <bool kExtra>
 void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, const char* e, int extra_bits, bool want_names,
                     bool want_groups, bool want_samples, Local& out) {
@@ -553,7 +652,6 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
     const bool filt = T->exclude.size() > 0;
     const bool track_pool = kExtra && filt && fmt == WK_FMT_SAM;
     static const char* const kSuffix[3] = {"", "/1", "/2"};
-    std::string keybuf;
     // room for the range's records up front (a trimmed SAM line is ~40 bytes)
     {
         const size_t guess = (size_t)(e - b) / 36 + 1024;
@@ -587,9 +685,10 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
             out.sample.push_back(id);
         }
         if (want_groups) {  // stratum of read id = QNAME + mate suffix
-            keybuf.assign(cur, cur_n);
-            keybuf.append(kSuffix[m]);
-            out.group.push_back(T->strata_find(keybuf.data(), keybuf.size()));
+            out.gkey_off.push_back((uint32_t)out.gkeys.size());
+            out.gkeys.append(cur, cur_n);
+            out.gkeys.append(kSuffix[m]);
+            out.group.push_back(-1);  // (resolve_groups, at the end of the range)
         }
     };
     auto flush = [&]() {
@@ -734,6 +833,7 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
         out.fin_qn = cur_n;
     }
     flush();
+    if (want_groups) resolve_groups(T, out);
 }
 
 // first mapped line at or after p whose QNAME differs from the previous mapped line's
@@ -1227,8 +1327,7 @@ int wk_tok_new_samples(wk_tok* t, char* blob, int64_t* off, int32_t* n_new) {
 int wk_tok_strata_clear(wk_tok* t) {
     if (!t) return WK_E_ARG;
     for (int i = 0; i < wk_tok::kStrataShards; ++i) {
-        t->strata_keys[i] = NameTable();
-        t->strata_of[i].clear();
+        t->strata[i] = StrataShard();
     }
     t->strata_labels = NameTable();
     return WK_OK;
@@ -1310,23 +1409,25 @@ int wk_tok_strata_load(wk_tok* t, const char* buf, int64_t len, int64_t* n_entri
     // phase 2: every shard takes its buckets in text order (a repeated read id
     // keeps its last label, like dict())
     run(S, [&](int sh) {
-        NameTable& keys = t->strata_keys[sh];
-        std::vector<int32_t>& of = t->strata_of[sh];
+        StrataShard& shard = t->strata[sh];
+        size_t more = 0, bytes = 0;
         for (int ti = 0; ti < T; ++ti)
             for (const Entry& en : bucket[(size_t)ti * S + sh]) {
-                const int32_t lab = remap[ti][en.label];
-                int32_t id = keys.find(en.key, en.kn, en.kh);
-                if (id < 0) {
-                    id = keys.add(en.key, en.kn, en.kh);
-                    of.push_back(lab);
-                } else {
-                    of[id] = lab;
-                }
+                more += 1;
+                bytes += en.kn;
             }
+        shard.reserve(shard.ent.size() + more, shard.arena.size() + bytes);
+        for (int ti = 0; ti < T; ++ti) {
+            const std::vector<Entry>& list = bucket[(size_t)ti * S + sh];
+            for (size_t q = 0; q < list.size(); ++q) {
+                if (q + 8 < list.size()) shard.prefetch_slot(list[q + 8].kh);
+                shard.put(list[q].key, list[q].kn, list[q].kh, remap[ti][list[q].label]);
+            }
+        }
     });
     if (n_entries) {
         int64_t n = 0;
-        for (int sh = 0; sh < S; ++sh) n += t->strata_keys[sh].size();
+        for (int sh = 0; sh < S; ++sh) n += (int64_t)t->strata[sh].ent.size();
         *n_entries = n;
     }
     if (n_labels) *n_labels = t->strata_labels.size();
