@@ -915,6 +915,9 @@ class Engine:
             def own(a):
                 if isinstance(a, _BySubject):
                     return a
+                if isinstance(a, memoryview) and \
+                        isinstance(a.obj, np.ndarray) and a.obj.flags.owndata:
+                    return a        # (a view of a block's own buffer keeps it alive)
                 return a if isinstance(a, np.ndarray) and a.flags.owndata \
                     and not isinstance(a, _Staged) else np.array(a)
             job = self._map_pool.submit(
