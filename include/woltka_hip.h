@@ -490,6 +490,13 @@ int wk_tok_strata_load(wk_tok* tok, const char* buf, int64_t len,
                        int64_t* n_entries, int32_t* n_labels);
 int wk_tok_strata_labels(wk_tok* tok, char* blob /* NULL: sizes only */,
                          int64_t* off /* [n_labels + 1] */);
+/* A tokenizer holds two such tables.  wk_tok_strata_select(tok, 1) makes
+ * clear / load / labels work on the one lookups do not use — the map of the next
+ * sample is read (by another thread) while the current sample is tokenised —,
+ * select(tok, 0) on the one in use again; wk_tok_strata_swap exchanges them (no
+ * tokenising call may be running). */
+int wk_tok_strata_select(wk_tok* tok, int other);
+int wk_tok_strata_swap(wk_tok* tok);
 /* Read-map text (file.write_readmap, file.py:469-500), multi-threaded.  One line
  * per assigned read: "read id <tab> name", or "read id <tab> name:n <tab> ..."
  * for a read split over several features; such reads (assign[r] ==

@@ -315,6 +315,42 @@ def test_large_strata_map_is_built_by_all_threads():
     assert want
 
 
+def test_second_strata_table_is_filled_aside_and_swapped_in():
+    """`load_strata(..., ahead=True)` fills the tokenizer's second table — from
+    another thread, while the first is being joined against — and
+    `strata_swap` puts it in place."""
+    import threading
+    n = 20000
+    sam = ''.join(f'read{i:07d}\t0\tG1\t1\t255\t10M\t*\t0\t0\t*\t*\n'
+                  for i in range(n)).encode()
+    map_a = ''.join(f'read{i:07d}\tA{i % 7}\n' for i in range(0, n, 2)).encode()
+    map_b = ''.join(f'read{i:07d}\tB{i % 5}\n' for i in range(0, n, 3)).encode()
+    tok = Tokenizer(4)
+    labels_a = tok.load_strata(io.BytesIO(map_a))
+    box = {}
+    th = threading.Thread(target=lambda: box.update(
+        labels=tok.load_strata(io.BytesIO(map_b), 50000, ahead=True)))
+    th.start()
+    for _ in range(5):      # the first table stays the one in use meanwhile
+        res = tok.parse(sam, first=True, final=True, want_groups=True)
+        got = [labels_a[g] if g >= 0 else None for g in res['group'].tolist()]
+        assert got == [f'A{i % 7}' if i % 2 == 0 else None for i in range(n)]
+    th.join()
+    labels_b = box['labels']
+    res = tok.parse(sam, first=True, final=True, want_groups=True)
+    assert [labels_a[g] if g >= 0 else None for g in res['group'].tolist()] == \
+        [f'A{i % 7}' if i % 2 == 0 else None for i in range(n)]
+    tok.strata_swap()
+    res = tok.parse(sam, first=True, final=True, want_groups=True)
+    assert [labels_b[g] if g >= 0 else None for g in res['group'].tolist()] == \
+        [f'B{i % 5}' if i % 3 == 0 else None for i in range(n)]
+    # a plain load after the swap replaces the table in use
+    labels_c = tok.load_strata(io.BytesIO(b'read0000001\tC\n'))
+    res = tok.parse(sam, first=True, final=True, want_groups=True)
+    assert [labels_c[g] for g in res['group'].tolist() if g >= 0] == ['C']
+    tok.close()
+
+
 def test_native_readmap_format_matches_python():
     from woltka_amd import _native as nat
     from woltka_amd.file import write_readmap

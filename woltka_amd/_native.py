@@ -53,7 +53,8 @@ SYMBOLS = (
     'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
-    'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_format_readmap',
+    'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_tok_strata_select',
+    'wk_tok_strata_swap', 'wk_format_readmap',
     'wk_tok_fetch_samples', 'wk_tok_new_samples', 'wk_preorder',
     'wk_hier_create', 'wk_hier_destroy', 'wk_hier_last_error',
     'wk_hier_add_text', 'wk_hier_update', 'wk_hier_finish', 'wk_hier_arrays',
@@ -185,6 +186,8 @@ def load_library():
         'wk_tok_new_samples': (C.c_int, [p, C.c_char_p, i64p, i32p]),
         'wk_tok_strata_load': (C.c_int, [p, C.c_void_p, C.c_int64, i64p, i32p]),
         'wk_tok_strata_labels': (C.c_int, [p, C.c_char_p, i64p]),
+        'wk_tok_strata_select': (C.c_int, [p, C.c_int]),
+        'wk_tok_strata_swap': (C.c_int, [p]),
         'wk_format_readmap': (C.c_int, [C.c_void_p, u64p, i32p, C.c_int64, i64p,
                                         i32p, i32p, C.c_char_p, i64p, C.c_int32,
                                         C.c_int, C.c_int, C.c_void_p, C.c_int64,
@@ -709,9 +712,23 @@ class Tokenizer:
         except Exception:
             pass
 
-    def load_strata(self, stream, block_bytes=1 << 27):
+    def strata_swap(self):
+        """The table `load_strata(..., ahead=True)` filled becomes the one the
+        parser joins against."""
+        self._check(self._lib.wk_tok_strata_swap(self._h))
+
+    def load_strata(self, stream, block_bytes=1 << 27, ahead=False):
         """Load a read-to-stratum map (binary stream) for the sample that is
-        about to be parsed; returns the label names (index = stratum id)."""
+        about to be parsed; returns the label names (index = stratum id).
+        ``ahead``: into the second table (while the first is in use, from
+        another thread); `strata_swap` then puts it in place."""
+        self._check(self._lib.wk_tok_strata_select(self._h, int(bool(ahead))))
+        try:
+            return self._load_strata(stream, block_bytes)
+        finally:
+            self._check(self._lib.wk_tok_strata_select(self._h, 0))
+
+    def _load_strata(self, stream, block_bytes):
         self._check(self._lib.wk_tok_strata_clear(self._h))
         n_ent, n_lab = C.c_int64(0), C.c_int32(0)
         carry = b''

@@ -370,6 +370,7 @@ class Engine:
         self._map_pool, self._map_seq, self._map_jobs = None, None, []   # their formatting threads
         self._subj_feat_arr = None
         self._read_pool = None
+        self._strata_ahead = None   # (thread, box) of a strata map being read ahead
         self._dtok_lap = {}     # (WOLTKA_DTOK_TIMING: seconds inside _run_dtok)
         self.genes = None
         self.gene_feature = None
@@ -448,6 +449,9 @@ class Engine:
                 self._writer.close()
                 self._writer = None
         finally:
+            if self._strata_ahead is not None:
+                self._strata_ahead[0].join()
+                self._strata_ahead = None
             if self._read_pool is not None:
                 self._read_pool.shutdown(wait=True)
                 self._read_pool = None
@@ -496,21 +500,49 @@ class Engine:
             self._reserve(4 * need)
 
     # ------------------------------------------------------------------
-    def load_strata(self, fp, zippers):
+    def load_strata(self, fp, zippers, then=None):
         """Read-to-stratum map of one sample into the native tokenizer;
-        returns the stratum labels (workflow.read_strata, workflow.py:912-938)."""
+        returns the stratum labels (workflow.read_strata, workflow.py:912-938).
+        ``then``: the map that will be asked for next — read on a thread into
+        the tokenizer's second table while this sample is tokenised."""
         from os.path import basename
-        from .file import readzip_bytes
         if self.tok is None:
             self.tok = nat.Tokenizer(tokenizer_threads(), self._exclude)
-        from . import pgzip
-        fh = pgzip.open_parallel(fp) if fp.endswith('.gz') else None
-        with (fh if fh is not None else readzip_bytes(fp, zippers)) as fh:
-            labels = self.tok.load_strata(fh)
+        labels = None
+        ahead, self._strata_ahead = self._strata_ahead, None
+        if ahead is not None:
+            thread, box = ahead
+            thread.join()
+            if box['fp'] == fp:
+                if 'err' in box:
+                    raise box['err']
+                self.tok.strata_swap()
+                labels = box['labels']
+        if labels is None:
+            labels = self._read_strata(fp, zippers, False)
+        if then is not None and then != fp:
+            import threading
+            box = {'fp': then}
+
+            def work():
+                try:
+                    box['labels'] = self._read_strata(then, zippers, True)
+                except Exception as e:      # raised when the map is asked for
+                    box['err'] = e
+            thread = threading.Thread(target=work, name='wk-strata')
+            self._strata_ahead = (thread, box)
+            thread.start()
         if not labels:
             raise ValueError('No stratification information is found in file: '
                              f'{basename(fp)}.')
         return labels
+
+    def _read_strata(self, fp, zippers, ahead):
+        from . import pgzip
+        from .file import readzip_bytes
+        fh = pgzip.open_parallel(fp) if fp.endswith('.gz') else None
+        with (fh if fh is not None else readzip_bytes(fp, zippers)) as fh:
+            return self.tok.load_strata(fh, ahead=ahead)
 
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,

@@ -560,11 +560,18 @@ struct wk_tok {
     // (sharded by the top hash bits so that a map of tens of millions of reads is
     // built by all threads: each shard is owned by one thread while loading)
     static constexpr int kStrataShards = 64;
-    StrataShard strata[kStrataShards];
-    NameTable strata_labels;
+    // (two of them: the table of the next sample can be built — wk_tok_strata_select
+    // — while the current one is in use, then swapped in)
+    struct StrataSet {
+        StrataShard shard[kStrataShards];
+        NameTable labels;
+    };
+    StrataSet strata_sets[2];
+    int strata_cur = 0, strata_target = 0;  // the set lookups use; the set clear / load / labels work on
+    const StrataShard* strata_shards() const { return strata_sets[strata_cur].shard; }
     int32_t strata_find(const char* p, size_t n) const {
         const uint64_t hv = hash_bytes(p, n);
-        return strata[hv >> 58].find(p, n, hv);
+        return strata_shards()[hv >> 58].find(p, n, hv);
     }
     // demultiplexing (workflow.demultiplex, workflow.py:844-909): sample = text
     // before the first '_' of the read id, if anything follows it
@@ -628,18 +635,19 @@ static void resolve_groups(const wk_tok* T, Local& out) {
     uint64_t hv[R];
     out.gkey_off.push_back((uint32_t)out.gkeys.size());
     const char* keys = out.gkeys.data();
+    const StrataShard* const shards = T->strata_shards();
     for (size_t i = 0; i < n + 3 * D; ++i) {
         if (i < n) {
             const uint64_t h = hash_bytes(keys + out.gkey_off[i], out.gkey_off[i + 1] - out.gkey_off[i]);
             hv[i % R] = h;
-            T->strata[h >> 58].prefetch_slot(h);
+            shards[h >> 58].prefetch_slot(h);
         }
-        if (i >= D && i - D < n) T->strata[hv[(i - D) % R] >> 58].prefetch_entry(hv[(i - D) % R]);
-        if (i >= 2 * D && i - 2 * D < n) T->strata[hv[(i - 2 * D) % R] >> 58].prefetch_key(hv[(i - 2 * D) % R]);
+        if (i >= D && i - D < n) shards[hv[(i - D) % R] >> 58].prefetch_entry(hv[(i - D) % R]);
+        if (i >= 2 * D && i - 2 * D < n) shards[hv[(i - 2 * D) % R] >> 58].prefetch_key(hv[(i - 2 * D) % R]);
         if (i >= 3 * D) {
             const size_t j = i - 3 * D;
             const uint64_t h = hv[j % R];
-            out.group[j] = T->strata[h >> 58].find(keys + out.gkey_off[j], out.gkey_off[j + 1] - out.gkey_off[j], h);
+            out.group[j] = shards[h >> 58].find(keys + out.gkey_off[j], out.gkey_off[j + 1] - out.gkey_off[j], h);
         }
     }
     out.gkey_off.pop_back();
@@ -1327,9 +1335,9 @@ int wk_tok_new_samples(wk_tok* t, char* blob, int64_t* off, int32_t* n_new) {
 int wk_tok_strata_clear(wk_tok* t) {
     if (!t) return WK_E_ARG;
     for (int i = 0; i < wk_tok::kStrataShards; ++i) {
-        t->strata[i] = StrataShard();
+        t->strata_sets[t->strata_target].shard[i] = StrataShard();
     }
-    t->strata_labels = NameTable();
+    t->strata_sets[t->strata_target].labels = NameTable();
     return WK_OK;
 }
 
@@ -1401,15 +1409,16 @@ int wk_tok_strata_load(wk_tok* t, const char* buf, int64_t len, int64_t* n_entri
         remap[ti].resize(f.size());
         for (int32_t k = 0; k < f.size(); ++k) {
             const char* p = f.arena.data() + f.off[k];
-            int32_t id = t->strata_labels.find(p, f.len[k], f.hash[k]);
-            if (id < 0) id = t->strata_labels.add(p, f.len[k], f.hash[k]);
+            NameTable& all = t->strata_sets[t->strata_target].labels;
+            int32_t id = all.find(p, f.len[k], f.hash[k]);
+            if (id < 0) id = all.add(p, f.len[k], f.hash[k]);
             remap[ti][k] = id;
         }
     }
     // phase 2: every shard takes its buckets in text order (a repeated read id
     // keeps its last label, like dict())
     run(S, [&](int sh) {
-        StrataShard& shard = t->strata[sh];
+        StrataShard& shard = t->strata_sets[t->strata_target].shard[sh];
         size_t more = 0, bytes = 0;
         for (int ti = 0; ti < T; ++ti)
             for (const Entry& en : bucket[(size_t)ti * S + sh]) {
@@ -1427,23 +1436,37 @@ int wk_tok_strata_load(wk_tok* t, const char* buf, int64_t len, int64_t* n_entri
     });
     if (n_entries) {
         int64_t n = 0;
-        for (int sh = 0; sh < S; ++sh) n += (int64_t)t->strata[sh].ent.size();
+        for (int sh = 0; sh < S; ++sh) n += (int64_t)t->strata_sets[t->strata_target].shard[sh].ent.size();
         *n_entries = n;
     }
-    if (n_labels) *n_labels = t->strata_labels.size();
+    if (n_labels) *n_labels = t->strata_sets[t->strata_target].labels.size();
     return WK_OK;
 }
 
 // Label names: blob (NULL = size query) and off[n_labels + 1]
 int wk_tok_strata_labels(wk_tok* t, char* blob, int64_t* off) {
     if (!t || !off) return WK_E_ARG;
+    const NameTable& labels = t->strata_sets[t->strata_target].labels;
     int64_t w = 0;
     off[0] = 0;
-    for (int32_t i = 0; i < t->strata_labels.size(); ++i) {
-        if (blob) memcpy(blob + w, t->strata_labels.arena.data() + t->strata_labels.off[i], t->strata_labels.len[i]);
-        w += t->strata_labels.len[i];
+    for (int32_t i = 0; i < labels.size(); ++i) {
+        if (blob) memcpy(blob + w, labels.arena.data() + labels.off[i], labels.len[i]);
+        w += labels.len[i];
         off[i + 1] = w;
     }
+    return WK_OK;
+}
+
+int wk_tok_strata_select(wk_tok* t, int other) {
+    if (!t) return WK_E_ARG;
+    t->strata_target = other ? t->strata_cur ^ 1 : t->strata_cur;
+    return WK_OK;
+}
+
+int wk_tok_strata_swap(wk_tok* t) {
+    if (!t) return WK_E_ARG;
+    t->strata_cur ^= 1;
+    t->strata_target = t->strata_cur;
     return WK_OK;
 }
 

@@ -298,8 +298,14 @@ def classify(
                         if native_strata:
                             sample = files[fp] if files else None
                             if sample != csample or labels is None:
-                                labels = engine.load_strata(stratmap[sample],
-                                                            zippers)
+                                # (the map of the sample after this one is
+                                # read meanwhile)
+                                later = [files[x] for x in files]
+                                later = [x for x in later[later.index(sample):]
+                                         if x != sample and x in stratmap]
+                                labels = engine.load_strata(
+                                    stratmap[sample], zippers,
+                                    then=stratmap[later[0]] if later else None)
                                 csample = sample
                         # read ids as Python strings only when the host logic
                         # needs them (demultiplexing, Python-side strata join);
