@@ -615,6 +615,12 @@ void wk_coords_free(wk_coords* c);
  * each followed by `sep` (off[n] - off[0] + n bytes): what a host layer splits
  * into its own string objects in one call. */
 int wk_blob_join(const char* blob, const int64_t* off, int64_t n, char sep, char* out);
+/* The rows of a one-sample TSV table (table.prep_table + table.write_tsv,
+ * woltka/table.py:29-66, 247-283): the n feature ids of `keys` (joined by '\n')
+ * in ascending order, each as "id \t value \n", rows of value 0 left out;
+ * `out` needs keys_len + 24 n bytes.  *n_rows = the features written. */
+int wk_table_body(const char* keys, int64_t keys_len, const int64_t* values, int64_t n, int threads,
+                  char* out, int64_t cap, int64_t* out_len, int64_t* n_rows);
 
 /* ---- measurement ------------------------------------------------------- */
 /* HIP-event timing on the context's own stream (the stream every kernel of

@@ -334,3 +334,42 @@ def test_index_bulk_forms_equal_the_single_ones():
     f, g = H.FeatureIndex(['p', 'q']), H.FeatureIndex(['p', 'q'])
     assert f.intern_many(['q', 'z', 'p', 'z', 'y']) == [g.intern(x) for x in ['q', 'z', 'p', 'z', 'y']]
     assert f.names_of([0, 3, 2]) == [g.names[i] for i in [0, 3, 2]]
+
+
+def test_one_sample_table_written_natively_equals_the_general_writer(tmp_path):
+    """`workflow._write_one_sample` (wk_table_body: sort + format natively)
+    against `prep_table` + `write_tsv` on profiles of one sample: ids that are
+    prefixes of each other, non-ASCII ids, zero cells (dropped), large and
+    negative values; refused inputs fall back."""
+    import random
+    from woltka_amd import table as T
+    rnd = random.Random(11)
+    alphabet = 'abcXYZ019_|.- éßλ中'
+    for trial in range(6):
+        n = rnd.choice([1024, 3000, 40000])
+        ids = set()
+        while len(ids) < n:
+            ids.add(''.join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 9))))
+        ids = list(ids)
+        rnd.shuffle(ids)
+        sample = {k: rnd.choice([0, 1, 7, rnd.randint(-5, 10 ** 15)]) for k in ids}
+        data = {'none': {'S1': sample}}
+        fast, slow = str(tmp_path / f'f{trial}.tsv'), str(tmp_path / f's{trial}.tsv')
+        rows = workflow._write_one_sample(data['none'], ['S1'], fast)
+        table = T.prep_table(data['none'], ['S1'])
+        T.write_table(table, slow, False)
+        assert rows == len(table[1])
+        assert open(fast, 'rb').read() == open(slow, 'rb').read()
+    # not of that kind: several samples, float cells, tuple ids, few features
+    assert workflow._write_one_sample({'a': sample, 'b': sample}, ['a', 'b'], fast) is None
+    assert workflow._write_one_sample({'a': {**sample, 'x': 0.5}}, ['a'], fast) is None
+    assert workflow._write_one_sample({'a': {('s', k): v for k, v in sample.items()}}, ['a'], fast) is None
+    assert workflow._write_one_sample({'a': {'k': 1}}, ['a'], fast) is None
+    big = dict(sample)
+    big['huge'] = 1 << 70
+    assert workflow._write_one_sample({'a': big}, ['a'], fast) is None
+    # compressed output goes through the same writer
+    gz = str(tmp_path / 'out.tsv.gz')
+    assert workflow._write_one_sample({'S1': sample}, ['S1'], gz) == len(table[1])
+    import gzip
+    assert gzip.open(gz, 'rb').read() == open(slow, 'rb').read()

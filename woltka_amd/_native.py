@@ -40,7 +40,7 @@ SYMBOLS = (
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
     'wk_set_uniform_group', 'wk_chunk_download', 'wk_ordinal_hit_offsets',
-    'wk_blob_join', 'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
+    'wk_blob_join', 'wk_table_body', 'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
     'wk_words_begin', 'wk_words_append',
     'wk_words_wait', 'wk_words_flush', 'wk_words_pending',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
@@ -133,6 +133,8 @@ def load_library():
         'wk_host_free': (C.c_int, [p, C.c_void_p]),
         'wk_blob_join': (C.c_int, [C.c_char_p, i64p, C.c_int64, C.c_char,
                                    C.c_void_p]),
+        'wk_table_body': (C.c_int, [C.c_char_p, C.c_int64, i64p, C.c_int64,
+                                    C.c_int, C.c_void_p, C.c_int64, i64p, i64p]),
         'wk_host_register': (C.c_int, [p, C.c_void_p, C.c_size_t]),
         'wk_host_unregister': (C.c_int, [p, C.c_void_p]),
         'wk_words_begin': (C.c_int, [p, C.POINTER(Job), C.c_int32, C.c_int32,
@@ -996,6 +998,23 @@ def _blob(strings):
     if enc:
         np.cumsum(np.fromiter(map(len, enc), np.int64, len(enc)), out=off[1:])
     return b''.join(enc), off
+
+
+def table_body(keys, values, n_threads=8):
+    """(bytes-like body, rows) of a one-sample TSV table: ``keys`` = the feature
+    ids joined by ``\\n`` (bytes), ``values`` their int64 values
+    (``wk_table_body``).  None when the native side refuses the input."""
+    values = _arr(values, np.int64)
+    n = values.size
+    out = np.empty(len(keys) + 24 * n + 8, dtype=np.uint8)
+    used, rows = np.zeros(1, np.int64), np.zeros(1, np.int64)
+    rc = load_library().wk_table_body(
+        keys, len(keys), _ptr(values, C.c_int64), n, int(n_threads),
+        C.c_void_p(out.ctypes.data), out.size, _ptr(used, C.c_int64),
+        _ptr(rows, C.c_int64))
+    if rc != OK:
+        return None
+    return memoryview(out)[:int(used[0])], int(rows[0])
 
 
 def _split(raw, off):

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/woltka_hip.h"
@@ -211,5 +212,82 @@ int wk_blob_join(const char* blob, const int64_t* off, int64_t n, char sep, char
     return WK_OK;
 }
 
+
+// The body of a one-sample TSV table (table.write_tsv after table.prep_table of
+// the reference, woltka/table.py:29-66, 247-283): the n keys of `keys` (joined by
+// '\n') in ascending order — byte order of UTF-8 = Python's order of str —, each
+// as "key \t value \n"; rows whose value is 0 are left out.
+int wk_table_body(const char* keys, int64_t keys_len, const int64_t* values, int64_t n, int threads, char* out, int64_t cap,
+                  int64_t* out_len, int64_t* n_rows) {
+    if (n < 0 || keys_len < 0 || !out_len || !n_rows || (n > 0 && (!keys || !values)) || (cap > 0 && !out)) return WK_E_ARG;
+    *out_len = *n_rows = 0;
+    if (n == 0) return WK_OK;
+    std::vector<uint32_t> off((size_t)n + 1);
+    {
+        int64_t k = 0;
+        off[0] = 0;
+        for (int64_t i = 0; i < keys_len; ++i)
+            if (keys[i] == '\n') {
+                if (++k >= n) return WK_E_ARG;  // more separators than keys
+                off[(size_t)k] = (uint32_t)(i + 1);
+            }
+        if (k != n - 1 || keys_len >= (1ll << 32)) return WK_E_ARG;
+        off[(size_t)n] = (uint32_t)(keys_len + 1);
+    }
+    auto less = [&](uint32_t a, uint32_t b) {
+        const uint32_t la = off[a + 1] - off[a] - 1, lb = off[b + 1] - off[b] - 1;
+        const int c = memcmp(keys + off[a], keys + off[b], std::min(la, lb));
+        return c < 0 || (c == 0 && la < lb);
+    };
+    std::vector<uint32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0u);
+    int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : 8, n >> 14));
+    if (T == 1) {
+        std::sort(order.begin(), order.end(), less);
+    } else {
+        std::vector<size_t> cut((size_t)T + 1);
+        for (int t = 0; t <= T; ++t) cut[(size_t)t] = (size_t)n * (size_t)t / (size_t)T;
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] { std::sort(order.begin() + (ptrdiff_t)cut[(size_t)t], order.begin() + (ptrdiff_t)cut[(size_t)t + 1], less); });
+        for (auto& x : th) x.join();
+        for (int step = 1; step < T; step *= 2) {  // pairwise merges, a thread each
+            std::vector<std::thread> mt;
+            for (int t = 0; t + step < T; t += 2 * step)
+                mt.emplace_back([&, t, step] {
+                    const size_t hi = cut[(size_t)std::min(T, t + 2 * step)];
+                    std::inplace_merge(order.begin() + (ptrdiff_t)cut[(size_t)t], order.begin() + (ptrdiff_t)cut[(size_t)(t + step)],
+                                       order.begin() + (ptrdiff_t)hi, less);
+                });
+            for (auto& x : mt) x.join();
+        }
+    }
+    char* w = out;
+    char* const end = out + cap;
+    int64_t rows = 0;
+    for (uint32_t i : order) {
+        const int64_t v = values[i];
+        if (v == 0) continue;
+        const uint32_t len = off[i + 1] - off[i] - 1;
+        if (w + len + 24 > end) return WK_E_CAPACITY;
+        memcpy(w, keys + off[i], len);
+        w += len;
+        *w++ = '\t';
+        char digits[24];
+        int d = 0;
+        uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+        do {
+            digits[d++] = (char)('0' + u % 10);
+            u /= 10;
+        } while (u);
+        if (v < 0) *w++ = '-';
+        while (d) *w++ = digits[--d];
+        *w++ = '\n';
+        rows += 1;
+    }
+    *out_len = (int64_t)(w - out);
+    *n_rows = rows;
+    return WK_OK;
+}
 
 }  // extern "C"

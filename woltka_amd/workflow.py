@@ -918,6 +918,41 @@ def round_profiles(data, digits=None):
                 del sample[feature]
 
 
+def _write_one_sample(profile, columns, path):
+    """A TSV table of one sample with plain feature ids and integer cells —
+    the usual output of a run on one file — sorted and formatted natively
+    (`wk_table_body`): what `prep_table` + `write_tsv` write, without a Python
+    object per row.  Returns the number of features, or None when the table is
+    not of that kind (the general writer then)."""
+    import locale
+    import numpy as np
+    from . import _native as nat
+    cols = [s for s in columns if s in profile]
+    if len(cols) != 1:
+        return None
+    sample = profile[cols[0]]
+    n = len(sample)
+    if n < 1024 or not set(map(type, sample)) <= {str} or \
+            not set(map(type, sample.values())) <= {int} or \
+            locale.getpreferredencoding(False).lower().replace('-', '') != 'utf8':
+        return None
+    try:
+        values = np.fromiter(sample.values(), np.int64, n)
+        keys = '\n'.join(sample).encode()
+        head = f'#FeatureID\t{cols[0]}\n'.encode()
+    except (OverflowError, UnicodeEncodeError):
+        return None
+    if keys.count(b'\n') != n - 1:      # (a feature id with a line break)
+        return None
+    res = nat.table_body(keys, values)
+    if res is None:
+        return None
+    with openzip(path, 'wb') as fh:
+        fh.write(head)
+        fh.write(res[0])
+    return res[1]
+
+
 def write_profiles(data, fp, is_biom=None, samples=None, tree=None,
                    rankdic=None, namedic=None, name_as_id=False,
                    add_rank=False, add_lineage=False):
@@ -941,6 +976,11 @@ def write_profiles(data, fp, is_biom=None, samples=None, tree=None,
     click.echo(f'Writing output profiles in {label} format...')
     columns = samples or sorted(allkeys(data))
     for rank, path in targets:
+        if not (biom or add_lineage or add_rank or namedic):
+            rows = _write_one_sample(data[rank], columns, path)
+            if rows is not None:
+                click.echo(f'  Rank: {rank}, samples: 1, features: {rows}.')
+                continue
         table = prep_table(data[rank], columns,
                            tree if add_lineage else None,
                            rankdic if add_rank else None, namedic,
