@@ -652,6 +652,7 @@ def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
     if coords_fp:
         click.echo('Reading gene coordinates...', nl=False)
         table = load_gene_coords_file(coords_fp, zippers)
+        table.names     # (as Python strings now, while the device context opens on its thread)
         click.echo(' Done.')
         click.echo(f'  Total number of host sequences: {len(table)}.')
         return OrdinalMapper(table, th=overlap and overlap / 100), chunk
