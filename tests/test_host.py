@@ -373,3 +373,50 @@ def test_one_sample_table_written_natively_equals_the_general_writer(tmp_path):
     assert workflow._write_one_sample({'S1': sample}, ['S1'], gz) == len(table[1])
     import gzip
     assert gzip.open(gz, 'rb').read() == open(slow, 'rb').read()
+
+
+def test_rounding_digits_zero_keeps_floats_at_any_size():
+    """``--digits 0`` is not ``digits=None``: round(x, 0) returns a float
+    (woltka/util.py:346-348), whatever the size of the sample."""
+    for n in (5, 300):
+        sample = {f'k{i}': i + 0.4 for i in range(1, n + 1)}
+        data = {'r': {'s': dict(sample)}}
+        workflow.round_profiles(data, 0)
+        got = data['r']['s']
+        assert got == {k: round(v, 0) for k, v in sample.items()}
+        assert all(type(x) is float for x in got.values())
+
+
+def test_hierarchy_and_coords_from_a_fifo(tmp_path):
+    """A FIFO / process substitution reports size 0 to fstat; it is streamed,
+    not mapped (and not read as an empty file)."""
+    import contextlib
+    import io
+    import threading
+    text = 'G1\tT1\nG2\tT1\nG3\tT2\n'
+    reg = tmp_path / 'reg.map'
+    reg.write_text(text)
+    fifo = str(tmp_path / 'fifo.map')
+    os.mkfifo(fifo)
+
+    def feed(payload):
+        with open(fifo, 'w') as f:
+            f.write(payload)
+    with contextlib.redirect_stdout(io.StringIO()):
+        exp = workflow.build_hierarchy(map_fps=[str(reg)])
+        th = threading.Thread(target=feed, args=(text,))
+        th.start()
+        got = workflow.build_hierarchy(map_fps=[fifo])
+        th.join()
+    assert dict(got[0]) == dict(exp[0]) and len(dict(got[0])) > 0
+    assert got[3] == exp[3]
+    coords = '>n1\ng1\t1\t10\ng2\t20\t5\n'
+    th = threading.Thread(target=feed, args=(coords,))
+    th.start()
+    from woltka_amd import ordinal
+    tab = ordinal.load_gene_coords_file(fifo)
+    th.join()
+    (tmp_path / 'c.txt').write_text(coords)
+    ref = ordinal.load_gene_coords_file(str(tmp_path / 'c.txt'))
+    assert list(tab.genomes) == list(ref.genomes)
+    assert np.array_equal(tab.start0, ref.start0)

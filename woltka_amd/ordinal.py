@@ -89,9 +89,17 @@ def load_gene_coords_file(fp, zippers=None):
     from . import _native
     from .file import readzip
     from .workflow import _file_bytes
+    import io
+    import os
     with _file_bytes(fp, zippers) as buf:
         res = _native.parse_gene_coords(buf)
+        # an input that can be read only once (FIFO, process substitution)
+        once = (bytes(buf) if res is None and not os.path.isfile(fp)
+                else None)
     if res is None:
+        if once is not None:
+            return load_gene_coords(io.TextIOWrapper(io.BytesIO(once)),
+                                    sort=True)
         with readzip(fp, zippers) as fh:
             return load_gene_coords(fh, sort=True)
     goff, start0, end, genomes, (blob, off), isdup, findex = res

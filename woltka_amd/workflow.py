@@ -726,7 +726,12 @@ def build_hierarchy(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
     if is_build:
         click.echo('Constructing classification system...')
 
+    streamed = {}   # bytes of inputs that can be read only once (FIFOs ...)
+
     def python_read(fp, reader):
+        if fp in streamed:
+            import io
+            return reader(io.TextIOWrapper(io.BytesIO(streamed.pop(fp))))
         with readzip(fp, zippers) as f:
             return reader(f)
 
@@ -734,7 +739,10 @@ def build_hierarchy(names_fps=[], nodes_fps=[], newick_fps=[], lineage_fps=[],
         """True when the native reader took the file."""
         try:
             with _file_bytes(fp, zippers) as buf:
+                if isinstance(buf, bytes) and not os.path.isfile(fp):
+                    streamed[fp] = buf
                 tax.add_text(kind, buf, rank)
+            streamed.pop(fp, None)
             return True
         except nat.HierarchyBuilder.Refused:
             return False
@@ -792,11 +800,21 @@ def _file_bytes(fp, zippers=None):
     from os.path import splitext
     from .file import ZIP_BY_EXT
     if ZIP_BY_EXT.get(splitext(fp)[1]) is None:
+        import stat
         with open(fp, 'rb') as f:
-            if os.fstat(f.fileno()).st_size == 0:
-                yield b''
+            st = os.fstat(f.fileno())
+            mm = None
+            # only a regular file with a size can be mapped; a FIFO, a process
+            # substitution, /dev/stdin or a procfs file reports size 0 and is
+            # streamed instead
+            if stat.S_ISREG(st.st_mode) and st.st_size > 0:
+                try:
+                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                except (OSError, ValueError):
+                    mm = None
+            if mm is None:
+                yield f.read()
                 return
-            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
             view = memoryview(mm)
             try:
                 yield view
@@ -902,11 +920,11 @@ def round_profiles(data, digits=None):
     other cells go through the rule."""
     for profile in data.values():
         for sample in profile.values():
-            if not digits and len(sample) > 256 and _round_bulk(sample):
+            if digits is None and len(sample) > 256 and _round_bulk(sample):
                 continue
             dead = []
             for feature, value in sample.items():
-                if type(value) is int and not digits:
+                if type(value) is int and digits is None:
                     if not value:
                         dead.append(feature)
                     continue
