@@ -599,6 +599,184 @@ def write_ordinal_inputs(tmp, prob, n_reads):
     return sam, coords, n_rec, size
 
 
+# --------------------------------------------------------------------------
+# BASELINE configs[4] ("config 5"): the two-pass stratified workflow
+# --------------------------------------------------------------------------
+TWOPASS_SEED = 1005
+
+
+def write_twopass_static(tmp, static):
+    """nodes.dmp, taxid.map (genome -> taxon), gene coordinates and the
+    gene -> function map of a `synth.twopass_static` problem."""
+    h = static['hier']
+    fps = {k: os.path.join(tmp, v) for k, v in (
+        ('nodes', 'nodes.dmp'), ('taxmap', 'taxid.map'),
+        ('coords', 'coords.txt'), ('funcmap', 'function.map'))}
+    write_nodes_dmp(fps['nodes'], h)
+    with open(fps['taxmap'], 'w') as f:
+        f.writelines(f'G{g:06d}\tT{t:07d}\n'
+                     for g, t in enumerate(static['host'].tolist()))
+    goff = static['genome_off'].tolist()
+    gs, ge = static['gstart'].tolist(), static['gend'].tolist()
+    gf = static['gene_feature'].tolist()
+    fn = static['function'].tolist()
+    with open(fps['coords'], 'w') as f:
+        for g in range(len(goff) - 1):
+            f.write(f'>G{g:06d}\n')
+            f.writelines(f'g{gf[j]}\t{gs[j] + 1}\t{ge[j]}\n'
+                         for j in range(goff[g], goff[g + 1]))
+    with open(fps['funcmap'], 'w') as f:
+        f.writelines(f'g{gf[j]}\tF{fn[j]:05d}\n' for j in range(len(gf))
+                     if fn[j] >= 0)
+    return fps
+
+
+def twopass_sample_file(args):
+    """(worker process) one sample of config 5 written as SAM text; the
+    shared inputs are regenerated from their seed.  Returns (records, bytes,
+    share of reads whose hits lie in one genus)."""
+    path, s, n_reads, static_kw = args
+    static = synth.twopass_static(np.random.default_rng(TWOPASS_SEED),
+                                  **static_kw)
+    prob = synth.twopass_sample(np.random.default_rng(TWOPASS_SEED + 1 + s),
+                                static, n_reads)
+    q = prob['qoff']
+    genus = static['genus'][prob['genome']]
+    one = float((np.minimum.reduceat(genus, q[:-1]) ==
+                 np.maximum.reduceat(genus, q[:-1])).mean())
+    del genus
+    read_of = prob['read_of']
+    flag = np.where(np.arange(read_of.size, dtype=np.int64) == q[read_of],
+                    0, 256).astype(np.int32)
+    size = write_sam(path, read_of.astype(np.int64), prob['genome'], b'R',
+                     b'G', 6, flag=flag, pos=prob['beg'] + 1)
+    return int(read_of.size), size, one
+
+
+def write_twopass_inputs(tmp, n_samples, n_reads, static_kw=None,
+                         workers=None):
+    """Config 5's input files under `tmp`: `aln/S01.sam` ... (one process per
+    sample, a few at a time) + the shared files.  Returns (paths, records,
+    bytes, mean share of reads with one genus)."""
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing as mp
+    static_kw = static_kw or {}
+    indir = os.path.join(tmp, 'aln')
+    os.makedirs(indir, exist_ok=True)
+    jobs = [(os.path.join(indir, f'S{s + 1:02d}.sam'), s, n_reads, static_kw)
+            for s in range(n_samples)]
+    workers = workers or max(1, min(n_samples, 8, (os.cpu_count() or 2) // 2))
+    if workers > 1 and n_reads >= 1_000_000:
+        with ProcessPoolExecutor(workers, mp.get_context('spawn')) as pool:
+            futs = [pool.submit(twopass_sample_file, j) for j in jobs]
+            static = synth.twopass_static(
+                np.random.default_rng(TWOPASS_SEED), **static_kw)
+            fps = write_twopass_static(tmp, static)
+            res = [f.result() for f in futs]
+    else:
+        static = synth.twopass_static(np.random.default_rng(TWOPASS_SEED),
+                                      **static_kw)
+        fps = write_twopass_static(tmp, static)
+        res = [twopass_sample_file(j) for j in jobs]
+    fps['aln'] = indir
+    return fps, sum(r[0] for r in res), sum(r[1] for r in res), \
+        sum(r[2] for r in res) / len(res)
+
+
+def twopass_calls(fps, tmp):
+    """The keyword arguments of the two `workflow.workflow` calls (README.md:
+    125-150 of the reference): pass 1 = taxonomy, `--rank genus --outmap`;
+    pass 2 = `--coords`, gene -> function map, `--stratify` by pass 1's maps."""
+    maps = os.path.join(tmp, 'maps')
+    kw1 = dict(input_fp=fps['aln'], output_fp=os.path.join(tmp, 'genus.tsv'),
+               input_fmt='sam', nodes_fps=[fps['nodes']],
+               map_fps=[fps['taxmap']], map_rank=None, ranks='genus',
+               outmap_dir=maps,
+               output_fmt=False)
+    kw2 = dict(input_fp=fps['aln'],
+               output_fp=os.path.join(tmp, 'genus_function.tsv'),
+               input_fmt='sam', coords_fp=fps['coords'], overlap=80,
+               map_fps=[fps['funcmap']], map_rank=None, ranks='function',
+               strata_dir=maps,
+               output_fmt=False)
+    return kw1, kw2
+
+
+def twopass_digests(tmp, kw1, kw2):
+    """sha256 of the two tables and of every read map's *text* (compressed
+    bytes depend on the compressor, the text does not)."""
+    import gzip
+    import hashlib
+    out = {}
+    for key, fp in (('table1', kw1['output_fp']), ('table2', kw2['output_fp'])):
+        with open(fp, 'rb') as f:
+            blob = f.read()
+        out[key] = {'sha256': hashlib.sha256(blob).hexdigest(),
+                    'rows': blob.count(b'\n') - 1}
+    maps = {}
+    for fn in sorted(os.listdir(kw1['outmap_dir'])):
+        h, lines = hashlib.sha256(), 0
+        with gzip.open(os.path.join(kw1['outmap_dir'], fn), 'rb') as f:
+            while True:
+                blob = f.read(1 << 24)
+                if not blob:
+                    break
+                h.update(blob)
+                lines += blob.count(b'\n')
+        maps[fn] = {'sha256': h.hexdigest(), 'lines': lines}
+    out['maps'] = maps
+    return out
+
+
+def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
+                static_kw=None, digest=False):
+    """BASELINE configs[4] on one GPU's share (8 samples x 20 M reads): both
+    `woltka classify` calls of the stratified recipe, each inside one clock
+    from file paths to written tables (+ gz read maps in pass 1)."""
+    import shutil
+    from woltka_amd import workflow
+    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
+        t0 = time.perf_counter()
+        fps, n_rec, n_bytes, one = write_twopass_inputs(
+            tmp, n_samples, n_reads, static_kw)
+        t_gen = time.perf_counter() - t0
+        kw1, kw2 = twopass_calls(fps, tmp)
+        best = {}
+        for rep in range(reps):
+            shutil.rmtree(kw1['outmap_dir'], ignore_errors=True)
+            for key, kw in (('pass1', kw1), ('pass2', kw2)):
+                ph = Phases()
+                try:
+                    t0 = time.perf_counter()
+                    quiet(workflow.workflow, device=device, **kw)
+                    dt = time.perf_counter() - t0
+                finally:
+                    ph.close()
+                if key not in best or dt < best[key][0]:
+                    best[key] = (dt, dict(ph.t))
+        map_bytes = sum(os.path.getsize(os.path.join(kw1['outmap_dir'], x))
+                        for x in os.listdir(kw1['outmap_dir']))
+        dig = twopass_digests(tmp, kw1, kw2) if digest else None
+    res = {'unit': 'records/s', 'samples': n_samples,
+           'reads_per_sample': n_reads, 'records': n_rec,
+           'text_bytes': n_bytes, 'reads_with_one_genus': round(one, 4),
+           'text_generated_s': round(t_gen, 1), 'map_bytes_gz': map_bytes,
+           'what': 'both calls of the stratified recipe, each '
+                   '`workflow.workflow` from file paths to written tables, SAM '
+                   'text in the page cache: pass 1 = 2M-node nodes.dmp + '
+                   'taxid.map, --rank genus --outmap (gz); pass 2 = --coords '
+                   '(5k genomes x 500k genes) --map function.map --rank '
+                   f'function --stratify <maps of pass 1>; best of {reps}'}
+    for key in ('pass1', 'pass2'):
+        dt, parts = best[key]
+        res[key] = {'value': round(n_rec / dt, 1), 'seconds': round(dt, 3),
+                    'phases_s': {k: round(v, 3)
+                                 for k, v in sorted(parts.items())}}
+    if dig is not None:
+        res['digests'] = dig
+    return res
+
+
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)

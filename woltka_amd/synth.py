@@ -250,3 +250,98 @@ def ordinal_problem(rng, n_genomes=5000, genes_per_genome=100,
                 beg=beg.astype(np.int32), end=(beg + 150).astype(np.int32),
                 length=np.full(read_of.size, 150, np.uint32),
                 hoff=hoff.astype(np.int32), n_reads=n_reads)
+
+
+def twopass_static(rng, n_nodes=2_000_000, n_genomes=5000,
+                   genes_per_genome=100, n_genera=250, n_functions=20_000,
+                   unmapped_genes=0.1):
+    """SURVEY §8d config 5, the inputs all samples share: the config-3
+    taxonomy with `n_genomes` genomes hung below species / strain nodes of
+    `n_genera` genera (a taxid.map: genome -> taxon), the config-4 gene model
+    on those genomes, and a gene -> function map that leaves a share of the
+    genes unmapped."""
+    parent, rank = taxonomy_arrays(rng, n_nodes)
+    h = hierarchy_from_arrays(parent, rank, RANK_CODES, with_names=False)
+    hp = h.parent.astype(np.int64)
+    rc = h.rank_code
+    # genus above every species / strain node (device ids, pre-order)
+    low = np.flatnonzero((rc == RANK_CODES['species']) |
+                         (rc == RANK_CODES['strain'])).astype(np.int64)
+    gen = low.copy()
+    for _ in range(64):
+        m = (rc[gen] != RANK_CODES['genus']) & (gen != 0)
+        if not m.any():
+            break
+        gen[m] = hp[gen[m]]
+    ok = rc[gen] == RANK_CODES['genus']
+    low, gen = low[ok], gen[ok]
+    genera = np.unique(gen)
+    genera = genera[rng.permutation(genera.size)[:n_genera]]
+    keep = np.isin(gen, genera)
+    low, gen = low[keep], gen[keep]
+    # genomes: a genus by popularity, then one of its species / strains
+    order = np.argsort(gen, kind='stable')
+    low, gen = low[order], gen[order]
+    first = np.searchsorted(gen, genera, side='left')
+    count = np.searchsorted(gen, genera, side='right') - first
+    pick = zipf_draw(rng, genera.size, n_genomes, s=0.5)
+    host = low[first[pick] + (rng.random(n_genomes) * count[pick]).astype(
+        np.int64)]
+    genes = ordinal_problem(rng, n_genomes, genes_per_genome, n_pairs=1)
+    ng = n_genomes * genes_per_genome
+    func = rng.integers(0, n_functions, ng).astype(np.int32)
+    func[rng.random(ng) < unmapped_genes] = -1
+    glen = genes['gend'].reshape(n_genomes, -1).max(axis=1).astype(
+        np.int64) + 500
+    return dict(hier=h, host=host, genus=genera[pick], genome_len=glen,
+                genome_off=genes['genome_off'], gstart=genes['gstart'],
+                gend=genes['gend'], gene_feature=genes['gene_feature'],
+                function=func, n_functions=n_functions)
+
+
+def twopass_sample(rng, static, n_reads, max_hits=16, up_p=0.25):
+    """One sample of config 5: reads with the config-3 hit model (one hit,
+    p = 0.5, else U{2..max_hits} hits on distinct genomes below an ancestor a
+    geometric number of levels above the anchor genome's taxon), every hit at
+    a uniform position of its genome, 150 bases long."""
+    h = static['hier']
+    hp = h.parent.astype(np.int64)
+    hl = h.last.astype(np.int64)
+    host = static['host']
+    by_host = np.argsort(host, kind='stable')       # genomes in taxon order
+    subjects = host[by_host]
+    n_gen = host.size
+    k = np.where(rng.random(n_reads) < 0.5, 1,
+                 rng.integers(2, max_hits + 1, n_reads)).astype(np.int64)
+    anchor = zipf_draw(rng, n_gen, n_reads)
+    anc = host[anchor].copy()
+    up = rng.geometric(up_p, n_reads) - 1
+    for step in range(1, int(up.max()) + 1):
+        m = up >= step
+        anc[m] = hp[anc[m]]
+    lo = np.searchsorted(subjects, anc, side='left')
+    hi = np.searchsorted(subjects, hl[anc], side='right')
+    short = np.flatnonzero((hi - lo < k) & (anc != 0))
+    while short.size:
+        anc[short] = hp[anc[short]]
+        lo[short] = np.searchsorted(subjects, anc[short], side='left')
+        hi[short] = np.searchsorted(subjects, hl[anc[short]], side='right')
+        short = short[(hi[short] - lo[short] < k[short]) & (anc[short] != 0)]
+    k = np.minimum(k, np.maximum(hi - lo, 1))
+    qoff = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(k, out=qoff[1:])
+    read_of = np.repeat(np.arange(n_reads, dtype=np.int32), k)
+    j = np.arange(read_of.size, dtype=np.int64) - qoff[read_of]
+    span = np.maximum(hi - lo, 1)[read_of]
+    start = (rng.random(n_reads) * (hi - lo)).astype(np.int64)[read_of]
+    pick = lo[read_of] + (start + (j * span) // k[read_of]) % span
+    del j, span, start
+    genome = by_host[np.minimum(pick, n_gen - 1)].astype(np.int32)
+    del pick
+    single = (k == 1)[read_of]
+    genome[single] = anchor[read_of[single]]
+    del single
+    beg = (rng.random(genome.size) *
+           (static['genome_len'][genome] - 400)).astype(np.int32)
+    return dict(genome=genome, beg=beg, qoff=qoff, read_of=read_of,
+                n_reads=n_reads)
