@@ -511,6 +511,18 @@ int wk_format_readmap(const char* text, const uint64_t* qname,
                       const int32_t* m_count, const char* names_blob,
                       const int64_t* names_off, int32_t n_names, int unassigned,
                       int n_threads, char* out, int64_t cap, int64_t* written);
+/* ---- gzip members of read-map text (host; csrc/wk_deflate.cpp) ------------- */
+/* file.openzip(..., 'at') of the read maps (file.py:30-59 via workflow.py:
+ * 1042-1046; gzip by default, cli.py:173-176): one standard gzip member per
+ * call, its total size in a 'WK' extra subfield so that the members of a map
+ * can be found and inflated in parallel (the stratified second pass,
+ * workflow.py:912-938).  wk_gz_member returns the member's size, -1 if `cap`
+ * is too small; wk_gz_bound(n) is always enough.  wk_crc32 continues `crc`
+ * (0 to start) over data[0, n), the gzip CRC-32. */
+int64_t wk_gz_bound(int64_t n);
+int64_t wk_gz_member(const char* data, int64_t n, char* out, int64_t cap);
+uint32_t wk_crc32(uint32_t crc, const char* data, int64_t n);
+
 /* Dictionary growth: total subjects, subjects not yet reported, their bytes. */
 int wk_tok_subjects(wk_tok* tok, int32_t* n_total, int32_t* n_new,
                     int64_t* new_bytes);

@@ -61,7 +61,8 @@ SYMBOLS = (
     'wk_hier_root', 'wk_hier_lookup', 'wk_hier_node_names', 'wk_hier_get',
     'wk_hier_size', 'wk_hier_keys', 'wk_hier_ranks',
     'wk_coords_parse', 'wk_coords_error', 'wk_coords_sizes',
-    'wk_coords_fetch', 'wk_coords_free')
+    'wk_coords_fetch', 'wk_coords_free',
+    'wk_gz_bound', 'wk_gz_member', 'wk_crc32')
 
 
 class Job(C.Structure):
@@ -219,6 +220,10 @@ def load_library():
         'wk_coords_fetch': (C.c_int, [p, i32p, i32p, i32p, i32p, C.c_void_p,
                                       i64p, C.c_void_p, i64p]),
         'wk_coords_free': (None, [p]),
+        'wk_gz_bound': (C.c_int64, [C.c_int64]),
+        'wk_gz_member': (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_int64]),
+        'wk_crc32': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_int64]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -953,6 +958,27 @@ class Tokenizer:
             o, ln, m = d >> 24, (d >> 2) & 0x3FFFFF, d & 3
             out.append(mv[o:o + ln].decode() + cls.MATE_SUFFIX[m])
         return out
+
+
+def gz_member(data):
+    """One gzip member (bytes) holding ``data`` (any buffer), deflated by
+    ``wk_gz_member`` (csrc/wk_deflate.cpp); the GIL is released meanwhile."""
+    lib = load_library()
+    raw = np.frombuffer(memoryview(data), dtype=np.uint8)
+    cap = lib.wk_gz_bound(raw.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib.wk_gz_member(C.c_void_p(raw.ctypes.data if raw.size else 0),
+                         raw.size, C.c_void_p(out.ctypes.data), cap)
+    if n < 0:
+        raise ValueError('wk_gz_member failed')
+    return out[:n].tobytes()
+
+
+def crc32(data, crc=0):
+    lib = load_library()
+    raw = np.frombuffer(memoryview(data), dtype=np.uint8)
+    return lib.wk_crc32(crc, C.c_void_p(raw.ctypes.data if raw.size else 0),
+                        raw.size)
 
 
 def format_readmap(buf, qname, assign, m_off, m_feat, m_count, names,

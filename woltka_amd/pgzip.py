@@ -17,8 +17,13 @@ _HEAD = b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x08\x00WK\x04\x00'    # + uin
 HEAD_LEN = len(_HEAD) + 4
 
 
-def member(data, level=4):
-    """One gzip member holding `data`, its total size in the 'WK' subfield."""
+def member(data, level=None):
+    """One gzip member holding `data`, its total size in the 'WK' subfield:
+    deflated natively (csrc/wk_deflate.cpp) unless a zlib `level` is asked
+    for."""
+    if level is None:
+        from . import _native
+        return _native.gz_member(data)
     c = zlib.compressobj(level, zlib.DEFLATED, -15)
     body = c.compress(data) + c.flush()
     size = HEAD_LEN + len(body) + 8
