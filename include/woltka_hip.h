@@ -308,6 +308,34 @@ int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
                  int64_t stop, int extra, int64_t* n_lines, int* status);
 int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
                  int* status);
+/* ---- read maps formatted on the device (csrc/wk_readmap.hpp) ----------------
+ * file.write_readmap (file.py:469-500) for blocks the device tokenised: the
+ * lines `query[/mate] <tab> taxon` / `query <tab> taxon:count <tab> ...`
+ * (sorted by descending count, then id string) are built on the device from the
+ * block's text and only the finished text is fetched.  Plain assigners over
+ * subjects that all have a taxon (the job sets wk_words_begin accepts for the
+ * weighted histogram).
+ *   wk_dtok_keep_reads   on: wk_dtok_emit keeps the block's per-read state for
+ *                        wk_dtok_readmap (and places the records in read order).
+ *   wk_readmap_tables    job j's tables over the current subject table:
+ *                        slot_of_subject[s] = compact index of the taxon of
+ *                        subject s at the job's rank (the subject's own
+ *                        feature for `--rank none`); slot_order[t] = rank of
+ *                        slot t's id string among the slots'; shown_off /
+ *                        shown = the text printed for slot t (the id, or its
+ *                        name under --name-as-id).  Sent again whenever the
+ *                        subject table grows.
+ *   wk_dtok_readmap      the text of the block emitted last at job j:
+ *                        *n_bytes = its size (0: no lines).
+ *   wk_dtok_readmap_fetch copies it to out[0, cap). */
+int wk_dtok_keep_reads(wk_ctx* ctx, int on);
+int wk_readmap_tables(wk_ctx* ctx, int32_t job, const int32_t* slot_of_subject,
+                      int32_t n_subjects, const int32_t* slot_order,
+                      const uint32_t* shown_off, const char* shown,
+                      int32_t n_slots);
+int wk_dtok_readmap(wk_ctx* ctx, int32_t job, int64_t* n_bytes);
+int wk_dtok_readmap_fetch(wk_ctx* ctx, char* out, int64_t cap);
+
 /* `extra` != 0 — the "ex" flavour (align.parse_sam_file_ex + ordinal_mapper,
  * align.py:350-406, ordinal.py:167-240): wk_dtok_scan also takes POS and CIGAR
  * (start, end, aligned length per line; text beyond [+-]digits and

@@ -51,6 +51,8 @@ SYMBOLS = (
     'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
     'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_set_header_state',
     'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
+    'wk_dtok_keep_reads', 'wk_readmap_tables', 'wk_dtok_readmap',
+    'wk_dtok_readmap_fetch',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_tok_strata_select',
@@ -181,6 +183,11 @@ def load_library():
         'wk_dtok_stage_hits': (C.c_int, [p, i32p, C.c_int32, C.c_double, i64p,
                                          i64p, C.POINTER(C.c_int)]),
         'wk_dtok_emit': (C.c_int, [p, i64p, i64p, C.POINTER(C.c_int)]),
+        'wk_dtok_keep_reads': (C.c_int, [p, C.c_int]),
+        'wk_readmap_tables': (C.c_int, [p, C.c_int32, i32p, C.c_int32, i32p,
+                                        u32p, C.c_char_p, C.c_int32]),
+        'wk_dtok_readmap': (C.c_int, [p, C.c_int32, i64p]),
+        'wk_dtok_readmap_fetch': (C.c_int, [p, C.c_void_p, C.c_int64]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
         'wk_tok_fetch_groups': (C.c_int, [p, i32p]),
@@ -541,6 +548,38 @@ class Context:
         self._check(self._lib.wk_dtok_emit(self._h, C.byref(a), C.byref(b),
                                            C.byref(st)))
         return st.value, a.value, b.value
+
+    def dtok_keep_reads(self, on):
+        """``wk_dtok_emit`` keeps the per-read state of its block for
+        ``dtok_readmap`` (read maps formatted on the device)."""
+        self._check(self._lib.wk_dtok_keep_reads(self._h, int(bool(on))))
+
+    def readmap_tables(self, job, slot_of_subject, slot_order, shown):
+        """Job ``job``'s read-map tables: the taxon slot of every subject,
+        the slots' order by id string, the text shown per slot (list of
+        bytes)."""
+        slot_of_subject = _arr(slot_of_subject, np.int32)
+        slot_order = _arr(slot_order, np.int32)
+        off = np.zeros(len(shown) + 1, dtype=np.uint32)
+        np.cumsum([len(x) for x in shown], out=off[1:])
+        self._check(self._lib.wk_readmap_tables(
+            self._h, int(job), _ptr(slot_of_subject, C.c_int32),
+            slot_of_subject.size, _ptr(slot_order, C.c_int32),
+            _ptr(off, C.c_uint32), b''.join(shown), len(shown)))
+
+    def dtok_readmap(self, job, out=None):
+        """Read-map text of the block emitted last at job ``job`` as a
+        uint8 array (``out``: a buffer to fetch it into when it is large
+        enough) and whether it lies in ``out``."""
+        n = C.c_int64(0)
+        self._check(self._lib.wk_dtok_readmap(self._h, int(job), C.byref(n)))
+        inside = out is not None and out.size >= n.value
+        if not inside:
+            out = np.empty(n.value, dtype=np.uint8)
+        if n.value:
+            self._check(self._lib.wk_dtok_readmap_fetch(
+                self._h, C.c_void_p(out.ctypes.data), out.size))
+        return out[:n.value], inside
 
     def ordinal_hit_offsets(self, n_hits):
         """Offsets of every hit's genes in the staged gene lists

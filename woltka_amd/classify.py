@@ -17,6 +17,8 @@ from os.path import join
 
 import numpy as np
 
+from functools import partial
+
 from . import _native as nat
 from .align import iter_align, pack_queries
 from .file import openzip, write_readmap
@@ -107,20 +109,29 @@ class MapWriter:
     while the device and the tokenizer work on the next chunk.  `flush` waits
     for everything."""
 
-    def __init__(self, threads=32, block=8 << 20, cap=1 << 30):
+    def __init__(self, threads=32, block=1 << 20, cap=1 << 30):
+        import threading
         from concurrent.futures import ThreadPoolExecutor
         self._pool = ThreadPoolExecutor(max_workers=threads)
-        self._pending = []          # [(path, [future | bytes])] in call order
+        self._pending = []          # [(path, [future | bytes], done)] in call order
         self._block = block
         self._held = []             # input bytes of the calls still pending
         self._cap = cap
+        self._lock = threading.Lock()       # the two lists
+        self._writing = threading.Lock()    # one drain at a time: the files' order
 
-    def append(self, path, data, kind):
-        if not kind or not data:
-            self._pending.append((path, [data]))
-            self._held.append(len(data))
-            self._drain(False)
-            return
+    def append(self, path, data, kind, done=None):
+        """``data``: bytes, or any buffer of bytes (a numpy uint8 array: its
+        pieces are compressed in place); ``done()`` is called once the call's
+        text has been written — the buffer may be reused from then on."""
+        if isinstance(data, np.ndarray):
+            data = memoryview(data).cast('B')
+        futs = []
+        if not kind or not len(data):
+            parts = [bytes(data) if done else data]
+            if done:
+                done()
+                done = None
         else:
             import bz2
             import lzma
@@ -129,32 +140,67 @@ class MapWriter:
                     'xz': lzma.compress}[kind]
             block = self._block
             cuts, pos = [0], 0
-            while len(data) - pos > block:
-                nl = data.rfind(b'\n', pos, pos + block) + 1
-                pos = nl if nl > pos else pos + block
-                cuts.append(pos)
+            if isinstance(data, memoryview):
+                raw = np.frombuffer(data, dtype=np.uint8)
+                while len(data) - pos > block:
+                    # the last newline of the next `block` bytes
+                    nl = np.flatnonzero(raw[pos:pos + block][::-1][:1 << 16]
+                                        == 10)
+                    pos = pos + block - int(nl[0]) if nl.size else pos + block
+                    cuts.append(pos)
+            else:
+                while len(data) - pos > block:
+                    nl = data.rfind(b'\n', pos, pos + block) + 1
+                    pos = nl if nl > pos else pos + block
+                    cuts.append(pos)
             cuts.append(len(data))
-            self._pending.append((path, [
-                self._pool.submit(pack, data[a:b])
-                for a, b in zip(cuts, cuts[1:])]))
-        self._held.append(len(data))
+            parts = futs = [self._pool.submit(pack, data[a:b])
+                            for a, b in zip(cuts, cuts[1:])]
+        with self._lock:
+            self._pending.append((path, parts, done))
+            self._held.append(len(data))
+        # members are written as soon as they and everything before them are
+        # ready (the last one to finish finds the others done)
+        for f in futs:
+            f.add_done_callback(self._kick)
+        self._kick()
         # text waiting to be compressed and written stays bounded: beyond the
         # cap the caller waits for the oldest members
-        self._drain(False)
-        while self._pending and sum(self._held) > self._cap:
+        while True:
+            with self._lock:
+                over = bool(self._pending) and sum(self._held) > self._cap
+            if not over:
+                break
             self._drain(True, one=True)
 
+    def _kick(self, _=None):
+        if self._writing.acquire(blocking=False):
+            try:
+                self._drain_locked(False, False)
+            finally:
+                self._writing.release()
+
     def _drain(self, wait, one=False):
-        while self._pending:
-            path, parts = self._pending[0]
-            if not wait and not all(isinstance(x, bytes) or x.done()
+        with self._writing:
+            self._drain_locked(wait, one)
+
+    def _drain_locked(self, wait, one):
+        while True:
+            with self._lock:
+                if not self._pending:
+                    return
+                path, parts, done = self._pending[0]
+            if not wait and not all(not hasattr(x, 'done') or x.done()
                                     for x in parts):
                 return
             with open(path, 'ab') as f:
                 for x in parts:
-                    f.write(x if isinstance(x, bytes) else x.result())
-            self._pending.pop(0)
-            self._held.pop(0)
+                    f.write(x.result() if hasattr(x, 'result') else x)
+            with self._lock:
+                self._pending.pop(0)
+                self._held.pop(0)
+            if done is not None:
+                done()
             if one:
                 return
 
@@ -395,6 +441,11 @@ class Engine:
         self._oring = None                          # coord-match staging
         self._tring, self._reader = None, None      # device tokenizer: text staging, reader threads
         self._deferred_from = None                  # see take_deferred
+        # read maps formatted on the device (csrc/wk_readmap.hpp)
+        self._dmaps = None          # (rank2dir, outzip, namedic) while a file is read that way
+        self._dmaps_n = -1          # subjects the device's read-map tables cover
+        self._dmaps_ok = False
+        self._mring = None          # pinned buffers the map text is fetched into
 
     def words_eligible(self):
         """Can chunks go to the device as packed words, accumulated per
@@ -424,6 +475,21 @@ class Engine:
                                               job.major > 0):
                 return False
             if job.mode not in (nat.MODE_NONE, nat.MODE_RANK):
+                return False
+        return True
+
+    def device_maps_eligible(self):
+        """Can the read maps be formatted on the device (wk_readmap.hpp)?  The
+        plain assigners, i.e. the job sets the weighted histogram takes."""
+        if self.sizes or self._replay is not None or \
+                len(self.jobs) > nat.MAX_JOBS or not self._tok_identity or \
+                os.environ.get('WOLTKA_NO_WORDS') or \
+                os.environ.get('WOLTKA_NO_DMAPS'):
+            return False
+        for job in self.jobs:
+            if job.flags & (nat.F_UNIQ | nat.F_SIZED | nat.F_ABOVE) or \
+                    job.major > 0 or \
+                    job.mode not in (nat.MODE_NONE, nat.MODE_RANK):
                 return False
         return True
 
@@ -547,7 +613,7 @@ class Engine:
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,
                       want_strings=True, want_samples=False, cover=None,
-                      fmt='sam', part=None, words=False):
+                      fmt='sam', part=None, words=False, dmaps=None):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed, strata ids, name descriptors, sample ids,
         ranges) where packed = (subj, qoff) of subject indices, or for
@@ -562,14 +628,21 @@ class Engine:
         device_ex = ordinal and cover is None and not want_names and \
             not want_groups and not want_samples and \
             len(self.jobs) <= nat.MAX_JOBS
-        if (words or device_ex) and fmt == 'sam' and not exclude and \
+        if (words or device_ex or dmaps) and fmt == 'sam' and not exclude and \
                 part is None and not os.environ.get('WOLTKA_NO_DTOK'):
             from .align import _parallel_reader
             reader = _parallel_reader(stream, tok, None)
             if reader is not None:
-                # the text goes to the GPU as it is: tokenised there
-                yield from self._device_chunks(reader, block_bytes,
-                                               ordinal=bool(ordinal))
+                # the text goes to the GPU as it is: tokenised there (with
+                # `dmaps` the read maps are formatted there too)
+                self._dmaps = dmaps if not (words or device_ex) else None
+                self.ctx.dtok_keep_reads(self._dmaps is not None)
+                try:
+                    yield from self._device_chunks(reader, block_bytes,
+                                                   ordinal=bool(ordinal))
+                finally:
+                    self._dmaps = None
+                    self.ctx.dtok_keep_reads(False)
                 return
         ring = None
         if words:
@@ -1249,7 +1322,8 @@ class Engine:
                     tok.set_header_state(hdr)
                 else:
                     yield from self._host_block(buf, fill, first, final,
-                                                hdr_in)
+                                                hdr_in,
+                                                names=self._dmaps is not None)
             finally:
                 if isinstance(slot, tuple):     # (mapped: copied up to here)
                     mapped['done'] = max(mapped['done'], slot[1])
@@ -1306,9 +1380,11 @@ class Engine:
                 file=sys.stderr)
             self._dtok_lap = {}
 
-    def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False):
+    def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False,
+                    names=False):
         """One block of the device route through the host tokenizer after
-        all (the general arrays)."""
+        all (the general arrays; ``names``: with the descriptors of the query
+        names, for the read maps)."""
         tok = self.tok
         tok.set_header_state(hdr_in)
         if ordinal:
@@ -1331,7 +1407,7 @@ class Engine:
                              res['off']), None, None, None, None
             return
         res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
-                        final=final, fmt='sam')
+                        final=final, fmt='sam', want_names=names)
         fresh = tok.new_subjects()
         if fresh:
             ids = np.fromiter(map(self.subjects.intern, fresh), np.int32,
@@ -1340,7 +1416,8 @@ class Engine:
         if res['off'].size > 1:
             subj = res['subj'] if self._tok_identity \
                 else self._tok_map[res['subj']]
-            yield None, (subj, res['off']), None, None, None, None
+            yield None, (subj, res['off']), None, \
+                ((buf[:fill], res['qname']) if names else None), None, None
 
     def _run_dhits(self, data, packed, sample):
         """A block the device has scanned for the coord-match: its hits are
@@ -1393,21 +1470,100 @@ class Engine:
         t2 = time.perf_counter()
         lap['subjects'] = lap.get('subjects', 0.0) + t1 - t0
         lap['begin'] = lap.get('begin', 0.0) + t2 - t1
+        dmaps = self._dmaps
+        if began and dmaps is not None:
+            began = self._sync_map_tables(dmaps[2])
         if began:
             status, n_reads, _ = self.ctx.dtok_emit()
-            lap['emit'] = lap.get('emit', 0.0) + time.perf_counter() - t2
+            t3 = time.perf_counter()
+            lap['emit'] = lap.get('emit', 0.0) + t3 - t2
             if status == 0:
                 self._n_reads += n_reads
+                if dmaps is not None and n_reads:
+                    self._device_maps(sample, *dmaps)
+                    lap['maps'] = lap.get('maps', 0.0) + \
+                        time.perf_counter() - t3
                 return n_reads
         n = 0
-        for _, (subj, qoff), *_ in self._host_block(buf, fill, first, final,
-                                                    hdr_in):
+        for _, (subj, qoff), _, names, *_ in self._host_block(
+                buf, fill, first, final, hdr_in, names=dmaps is not None):
             self._sync_subjects(data)
+            if dmaps is not None:
+                n += self.run_chunk(data, None, None, sample, None, None,
+                                    dmaps[0], dmaps[1], dmaps[2], False,
+                                    packed=(subj, qoff), names=names,
+                                    packed_is_set=True)
+                continue
             n += self.run_chunk(data, None, None, sample, None, None, None,
                                 None, None, False, packed=(subj, qoff),
                                 packed_is_set=True)
         self.tok.set_header_state(hdr)
         return n
+
+    def _sync_map_tables(self, namedic):
+        """The device's read-map tables (wk_readmap_tables) over the subject
+        table as it is now; False when some subject has no taxon at a rank
+        (the histogram refuses such a table too: the host route then)."""
+        n = len(self.subj_feature)
+        if n == self._dmaps_n:
+            return self._dmaps_ok
+        self._dmaps_n, self._dmaps_ok = n, False
+        feat = self._subject_features().astype(np.int64)
+        for j, mode in enumerate(self.modes):
+            if mode == nat.MODE_RANK:
+                anc = self._rank_table(self.slots[j])
+                inside = feat < self.hier.n_nodes
+                tax = np.where(inside, anc[np.where(inside, feat, 0)], -1)
+                if (tax < 0).any():
+                    return False
+            else:
+                tax = feat
+            used, slot = np.unique(tax, return_inverse=True)
+            ids = self.index.names_of(used.tolist())
+            order = np.empty(used.size, dtype=np.int32)
+            order[sorted(range(used.size), key=ids.__getitem__)] = \
+                np.arange(used.size, dtype=np.int32)
+            shown = [namedic.get(x, x) for x in ids] if namedic else ids
+            self.ctx.readmap_tables(j, slot.astype(np.int32), order,
+                                    [x.encode() for x in shown])
+        self._dmaps_ok = True
+        return True
+
+    MAP_TEXT_SLOT = 24 << 20    # bytes of a pinned buffer for a block's map text
+
+    def _device_maps(self, sample, rank2dir, outzip, namedic):
+        """The read maps of the block emitted last: text from the device
+        (wk_dtok_readmap), compressed and appended behind this thread's
+        back."""
+        if self._mring is None:
+            self._mring = StageRing(self.ctx, 6, {
+                'text': (np.uint8, self.MAP_TEXT_SLOT)})
+        if self._map_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._map_pool = ThreadPoolExecutor(max_workers=self.MAP_THREADS)
+            self._map_seq = ThreadPoolExecutor(max_workers=1)
+        if self._writer is None:
+            self._writer = MapWriter()
+        ring = self._mring
+        for j, rank in enumerate(self.ranks):
+            if rank not in rank2dir:
+                continue
+            bufs = ring.try_current()
+            while bufs is None:     # every buffer waits for its text to be written
+                self._maps_done()
+                self._writer._drain(True, one=True)
+                bufs = ring.try_current()
+            text, inside = self.ctx.dtok_readmap(j, out=bufs['text'])
+            done = None
+            if inside and text.size:
+                done = partial(ring.release, ring.take())
+            outfp = join(rank2dir[rank], f'{sample}.txt')
+            path = f'{outfp}.{outzip}' if outzip else outfp
+            # (through the sequencing thread: blocks the host formatted are
+            # appended from there too, in order)
+            self._maps_done(keep=4 * self.MAP_THREADS)
+            self._map_jobs.append(self._map_seq.submit(
+                self._writer.append, path, text, outzip, done))
 
     def _sync_subjects(self, data):
         """Subjects the tokenizer has met since the last call: their features

@@ -19,6 +19,7 @@
 #include "wk_dtok.hpp"
 #include "wk_free.hpp"
 #include "wk_ordinal.hpp"
+#include "wk_readmap.hpp"
 #include "wk_tok_internal.h"
 #include "wk_weigh.hpp"
 
@@ -232,6 +233,18 @@ struct wk_ctx {
     bool copy_counted[2] = {false, false};
     uint32_t copy_n[2] = {0, 0};
     int copy_next = 0, dt_cur = 0;
+    // read maps formatted on the device (wk_readmap.hpp): per job the taxon slot of every subject, the slots' order
+    // and shown text; per block the reads' leader lines, line lengths / offsets and the text itself
+    struct MapTables {
+        DevBuf slot_of_subject, slot_order, shown_off, shown;
+        int32_t n_subjects = 0, n_slots = 0;
+    };
+    MapTables rm[WK_MAX_JOBS];
+    DevBuf rm_line, rm_len, rm_text;
+    bool dt_keep_reads = false;   // wk_dtok_keep_reads: wk_dtok_emit places the records in read order and keeps the block
+    bool dt_emitted = false;      // the block scanned last was emitted with its reads kept
+    uint32_t dt_emit_reads = 0;
+    int64_t rm_bytes = 0;         // text of the last wk_dtok_readmap
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
 };
@@ -2300,7 +2313,9 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     unsigned long long totals = 0;
-    if (c->w_mode != 0) {
+    const bool ordered = c->w_mode != 0 || c->dt_keep_reads;
+    c->dt_emitted = false;
+    if (ordered) {
         // the per-read stream wants the records of a read next to each other, in
         // position order: placed by prefix sums instead of appended wave by wave
         const uint32_t n_tiles = grid.x;
@@ -2323,17 +2338,114 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     DtokState st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->w_mode != 0) {
+    if (ordered) {
         st.n_out = totals & 0xFFFFFFFFull;
         st.n_reads = totals >> 32;
     }
     if (st.flags) return WK_OK;  // a read of more than 16 subjects: nothing counts as appended
+    c->dt_emitted = c->dt_keep_reads;
+    c->dt_emit_reads = (uint32_t)st.n_reads;
     if ((rc = words_translate(c, c->w_records, (int64_t)st.n_out))) return rc;
     c->w_records += (int64_t)st.n_out;
     c->w_reads += (int64_t)st.n_reads;
     *n_reads = (int64_t)st.n_reads;
     *n_records = (int64_t)st.n_out;
     *status = 0;
+    return WK_OK;
+}
+
+// ---- read maps on the device (wk_readmap.hpp) -------------------------------------
+
+int wk_dtok_keep_reads(wk_ctx* c, int on) {
+    if (!c) return WK_E_ARG;
+    c->dt_keep_reads = on != 0;
+    if (!on) c->dt_emitted = false;
+    return WK_OK;
+}
+
+int wk_readmap_tables(wk_ctx* c, int32_t job, const int32_t* slot_of_subject, int32_t n_subjects, const int32_t* slot_order,
+                      const uint32_t* shown_off, const char* shown, int32_t n_slots) {
+    if (!c) return WK_E_ARG;
+    if (job < 0 || job >= WK_MAX_JOBS) return fail(c, WK_E_ARG, "job must be in [0, %d)", WK_MAX_JOBS);
+    if (n_subjects < 0 || n_slots < 0 || (n_subjects > 0 && !slot_of_subject) || (n_slots > 0 && (!slot_order || !shown_off)))
+        return fail(c, WK_E_ARG, "bad read-map tables");
+    for (int32_t s = 0; s < n_subjects; ++s)
+        if (slot_of_subject[s] < 0 || slot_of_subject[s] >= n_slots) return fail(c, WK_E_ARG, "subject %d has no taxon slot", s);
+    DeviceGuard guard(c->device);
+    wk_ctx::MapTables& T = c->rm[job];
+    static const uint32_t zero = 0;
+    int rc;
+    if ((rc = upload(c, T.slot_of_subject, slot_of_subject, (size_t)n_subjects * 4))) return rc;
+    if ((rc = upload(c, T.slot_order, slot_order, (size_t)n_slots * 4))) return rc;
+    if ((rc = upload(c, T.shown_off, n_slots > 0 ? shown_off : &zero, ((size_t)n_slots + 1) * 4))) return rc;
+    const size_t n_text = n_slots > 0 ? shown_off[n_slots] : 0;
+    if (n_text > 0 && !shown) return fail(c, WK_E_ARG, "bad read-map tables");
+    if ((rc = upload(c, T.shown, shown, n_text))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the caller's buffers are only valid during the call)
+    T.n_subjects = n_subjects;
+    T.n_slots = n_slots;
+    return WK_OK;
+}
+
+int wk_dtok_readmap(wk_ctx* c, int32_t job, int64_t* n_bytes) {
+    if (!c || !n_bytes) return WK_E_ARG;
+    *n_bytes = 0;
+    c->rm_bytes = 0;
+    if (job < 0 || job >= WK_MAX_JOBS) return fail(c, WK_E_ARG, "job must be in [0, %d)", WK_MAX_JOBS);
+    if (!c->dt_emitted) return fail(c, WK_E_STATE, "no block emitted with its reads kept (wk_dtok_keep_reads, wk_dtok_emit)");
+    const wk_ctx::MapTables& T = c->rm[job];
+    if (T.n_subjects < c->n_subjects) return fail(c, WK_E_STATE, "read-map tables of job %d cover %d of %d subjects", job, T.n_subjects, c->n_subjects);
+    const uint32_t n_reads = c->dt_emit_reads;
+    if (n_reads == 0 || c->dt_lines == 0) return WK_OK;
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, c->rm_line.reserve((size_t)n_reads * 4));
+    HIP_TRY(c, c->rm_len.reserve((size_t)n_reads * 8));
+    DtokArgs a = dtok_args(c);
+    ReadmapArgs m{};
+    m.slot_of_subject = T.slot_of_subject.as<int32_t>();
+    m.n_subjects = (uint32_t)T.n_subjects;
+    m.slot_order = T.slot_order.as<int32_t>();
+    m.shown_off = T.shown_off.as<uint32_t>();
+    m.shown = T.shown.as<unsigned char>();
+    m.read_line = c->rm_line.as<uint32_t>();
+    m.read_len = c->rm_len.as<unsigned long long>();
+    m.n_reads = n_reads;
+    const dim3 lgrid((c->dt_lines + kDtokThreads - 1) / kDtokThreads), rgrid((n_reads + kDtokThreads - 1) / kDtokThreads);
+    HIP_TRY(c, c->d_tiles.reserve((size_t)rgrid.x * 8));
+    HIP_TRY(c, c->d_tile_off.reserve((size_t)rgrid.x * 8));
+    HIP_TRY(c, hipMemsetAsync(c->rm_len.p, 0, (size_t)n_reads * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+    KernelTimer* kt = ktimer_begin(c, "readmap");
+    hipLaunchKernelGGL(readmap_len_kernel, lgrid, dim3(kDtokThreads), 0, c->stream, a, m);
+    hipLaunchKernelGGL(u64_tile_sum_kernel, rgrid, dim3(kDtokThreads), 0, c->stream, m.read_len, n_reads, c->d_tiles.as<unsigned long long>());
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
+                       c->d_tile_off.as<unsigned long long>(), (int64_t)rgrid.x, scalar_u64(c, 3));
+    hipLaunchKernelGGL(u64_tile_prefix_kernel, rgrid, dim3(kDtokThreads), 0, c->stream, m.read_len, n_reads, c->d_tile_off.as<unsigned long long>());
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (total >= (1ull << 40)) return fail(c, WK_E_RANGE, "read-map text of one block beyond 2^40 bytes");
+    if (total > 0) {
+        HIP_TRY(c, c->rm_text.reserve((size_t)total + 64));
+        m.out = c->rm_text.as<unsigned char>();
+        m.out_cap = total;
+        hipLaunchKernelGGL(readmap_write_kernel, rgrid, dim3(kDtokThreads), 0, c->stream, a, m);
+        HIP_TRY(c, hipGetLastError());
+    }
+    ktimer_end(c, kt);
+    c->rm_bytes = (int64_t)total;
+    *n_bytes = (int64_t)total;
+    return WK_OK;
+}
+
+int wk_dtok_readmap_fetch(wk_ctx* c, char* out, int64_t cap) {
+    if (!c) return WK_E_ARG;
+    if (c->rm_bytes == 0) return WK_OK;
+    if (!out || cap < c->rm_bytes) return fail(c, WK_E_CAPACITY, "need %lld bytes", (long long)c->rm_bytes);
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipMemcpyAsync(out, c->rm_text.p, (size_t)c->rm_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return WK_OK;
 }
 

@@ -322,11 +322,21 @@ def classify(
                                      want_names or native_strata or demux or
                                      trimsub or rank2dir is not None) and \
                             engine.words_eligible()
+                        # read maps of plain assigners, one sample per file:
+                        # the lines are formatted on the device next to the
+                        # tokenised text (csrc/wk_readmap.hpp)
+                        dmaps = None
+                        if rank2dir is not None and not (
+                                ordinal or cover is not None or demux or
+                                stratmap or trimsub or want_strings) and \
+                                engine.device_maps_eligible():
+                            dmaps = (rank2dir, outzip, namedic)
                         chunks = engine.native_chunks(
                             stream, head, exclude, NATIVE_BLOCK, ordinal,
                             want_names, trimsub, want_groups=native_strata,
                             want_strings=want_strings, want_samples=native_demux,
-                            cover=cover, fmt=fmt_, part=part, words=words)
+                            cover=cover, fmt=fmt_, part=part, words=words,
+                            dmaps=dmaps)
                         if ordinal and rank2dir is not None:
                             chunks = engine.regroup_hits(chunks, n)
                     else:
