@@ -308,6 +308,30 @@ int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
                  int64_t stop, int extra, int64_t* n_lines, int* status);
 int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
                  int* status);
+/* ---- strata map on the device (csrc/wk_strata.hpp) -------------------------
+ * workflow.read_strata + the lookups of classify.counter_strat (workflow.py:
+ * 912-938, file.py:368-385, classify.py:216-249) for samples the device
+ * tokenises: the text of the sample's read -> stratum map (lines `read <tab>
+ * label`; lines with another number of columns are ignored, the label is
+ * right-stripped, a repeated read keeps its last label) goes to the device as
+ * it is and is joined there, exactly (hashes find candidates, bytes decide).
+ *   wk_strata_load    builds the tables from text[0, n).  *status 1: something
+ *                     the kernels leave to the host's join (wk_tok_strata_*): a
+ *                     map of 4 GB or more, two ids or labels with equal 64-bit
+ *                     hashes, more than 65536 labels.
+ *   wk_strata_labels  the labels in order of first appearance: their slot,
+ *                     and where their text lies in the map's text.
+ *   wk_strata_groups  the (sample, stratum) group id of every label; from then
+ *                     on wk_dtok_stage_hits gives each read its group (-1: not
+ *                     in the map, not counted) until wk_strata_clear. */
+int wk_strata_load(wk_ctx* ctx, const char* text, int64_t n, int64_t* n_pairs,
+                   int32_t* n_labels, int* status);
+int wk_strata_labels(wk_ctx* ctx, int32_t* slot, int64_t* text_off,
+                     int32_t* text_len, int32_t cap, int32_t* n);
+int wk_strata_groups(wk_ctx* ctx, const int32_t* slot, const int32_t* group,
+                     int32_t n);
+int wk_strata_clear(wk_ctx* ctx);
+
 /* ---- read maps formatted on the device (csrc/wk_readmap.hpp) ----------------
  * file.write_readmap (file.py:469-500) for blocks the device tokenised: the
  * lines `query[/mate] <tab> taxon` / `query <tab> taxon:count <tab> ...`
@@ -550,6 +574,13 @@ int wk_format_readmap(const char* text, const uint64_t* qname,
 int64_t wk_gz_bound(int64_t n);
 int64_t wk_gz_member(const char* data, int64_t n, char* out, int64_t cap);
 uint32_t wk_crc32(uint32_t crc, const char* data, int64_t n);
+/* Inflate n members written by wk_gz_member, blob[lo[i], hi[i]) each, on
+ * n_threads threads straight into out[off[i], off[i+1]) (off = running sum of
+ * the members' ISIZE fields).  0, or -(1 + i) for the first member whose size /
+ * CRC-32 / stream is not what its trailer says. */
+int64_t wk_gz_inflate_members(const char* blob, const int64_t* lo,
+                              const int64_t* hi, int64_t n, char* out,
+                              const int64_t* off, int n_threads);
 
 /* Dictionary growth: total subjects, subjects not yet reported, their bytes. */
 int wk_tok_subjects(wk_tok* tok, int32_t* n_total, int32_t* n_new,

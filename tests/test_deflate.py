@@ -90,3 +90,28 @@ def test_hypothesis_roundtrip():
         d = b''.join(b * k for b, k in pieces)
         assert gzip.decompress(nat.gz_member(d)) == d
     check()
+
+
+def test_members_inflate_in_parallel_natively():
+    rnd = random.Random(5)
+    blobs = [b''.join(b'R%09d\tT%07d\n' % (rnd.randrange(10 ** 9), i % 977)
+                      for i in range(rnd.randint(0, 30000)))
+             for _ in range(23)]
+    chain = b''.join(pgzip.member(b) for b in blobs)
+    spans = pgzip.members_of(chain)
+    assert len(spans) == len(blobs)
+    text, inside = nat.gz_inflate_members(chain, spans, n_threads=4)
+    assert not inside and text.tobytes() == b''.join(blobs)
+    buf = np.empty(len(text) + 100, dtype=np.uint8)
+    text2, inside = nat.gz_inflate_members(chain, spans, out=buf, n_threads=3)
+    assert inside and text2.tobytes() == b''.join(blobs)
+    # zlib-written members of the same format inflate too
+    chain_z = b''.join(pgzip.member(b, level=4) for b in blobs)
+    text3, _ = nat.gz_inflate_members(chain_z, pgzip.members_of(chain_z))
+    assert text3.tobytes() == b''.join(blobs)
+    # a damaged member is reported, not returned
+    broken = bytearray(chain)
+    a, b = spans[7]
+    broken[(a + b) // 2] ^= 0x55
+    with pytest.raises(OSError):
+        nat.gz_inflate_members(bytes(broken), spans)

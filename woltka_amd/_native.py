@@ -52,7 +52,8 @@ SYMBOLS = (
     'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_set_header_state',
     'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
     'wk_dtok_keep_reads', 'wk_readmap_tables', 'wk_dtok_readmap',
-    'wk_dtok_readmap_fetch',
+    'wk_dtok_readmap_fetch', 'wk_strata_load', 'wk_strata_labels',
+    'wk_strata_groups', 'wk_strata_clear',
     'wk_tok_subjects',
     'wk_tok_new_subjects', 'wk_tok_fetch_groups', 'wk_tok_strata_clear',
     'wk_tok_strata_load', 'wk_tok_strata_labels', 'wk_tok_strata_select',
@@ -64,7 +65,7 @@ SYMBOLS = (
     'wk_hier_size', 'wk_hier_keys', 'wk_hier_ranks',
     'wk_coords_parse', 'wk_coords_error', 'wk_coords_sizes',
     'wk_coords_fetch', 'wk_coords_free',
-    'wk_gz_bound', 'wk_gz_member', 'wk_crc32')
+    'wk_gz_bound', 'wk_gz_member', 'wk_crc32', 'wk_gz_inflate_members')
 
 
 class Job(C.Structure):
@@ -188,6 +189,11 @@ def load_library():
                                         u32p, C.c_char_p, C.c_int32]),
         'wk_dtok_readmap': (C.c_int, [p, C.c_int32, i64p]),
         'wk_dtok_readmap_fetch': (C.c_int, [p, C.c_void_p, C.c_int64]),
+        'wk_strata_load': (C.c_int, [p, C.c_void_p, C.c_int64, i64p, i32p,
+                                     C.POINTER(C.c_int)]),
+        'wk_strata_labels': (C.c_int, [p, i32p, i64p, i32p, C.c_int32, i32p]),
+        'wk_strata_groups': (C.c_int, [p, i32p, i32p, C.c_int32]),
+        'wk_strata_clear': (C.c_int, [p]),
         'wk_tok_subjects': (C.c_int, [p, i32p, i32p, i64p]),
         'wk_tok_new_subjects': (C.c_int, [p, C.c_char_p, i32p]),
         'wk_tok_fetch_groups': (C.c_int, [p, i32p]),
@@ -231,6 +237,8 @@ def load_library():
         'wk_gz_member': (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_int64]),
         'wk_crc32': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_int64]),
+        'wk_gz_inflate_members': (C.c_int64, [C.c_void_p, i64p, i64p, C.c_int64,
+                                              C.c_void_p, i64p, C.c_int]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -580,6 +588,40 @@ class Context:
             self._check(self._lib.wk_dtok_readmap_fetch(
                 self._h, C.c_void_p(out.ctypes.data), out.size))
         return out[:n.value], inside
+
+    def strata_load(self, text):
+        """A sample's read -> stratum map (uint8 array of its text) as the
+        device's join table.  Returns None when the kernels leave the map to
+        the host's join, else (labels as bytes in order of first appearance,
+        their slots)."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        n_pairs, n_lab, st = C.c_int64(0), C.c_int32(0), C.c_int(1)
+        self._check(self._lib.wk_strata_load(
+            self._h, C.c_void_p(text.ctypes.data if text.size else 0),
+            text.size, C.byref(n_pairs), C.byref(n_lab), C.byref(st)))
+        if st.value != 0:
+            return None
+        cap = n_lab.value
+        slot = np.empty(cap, dtype=np.int32)
+        off = np.empty(cap, dtype=np.int64)
+        ln = np.empty(cap, dtype=np.int32)
+        n = C.c_int32(0)
+        self._check(self._lib.wk_strata_labels(
+            self._h, _ptr(slot, C.c_int32), _ptr(off, C.c_int64),
+            _ptr(ln, C.c_int32), cap, C.byref(n)))
+        labels = [text[o:o + k].tobytes()
+                  for o, k in zip(off[:n.value].tolist(), ln[:n.value].tolist())]
+        return labels, slot[:n.value]
+
+    def strata_groups(self, slots, groups):
+        slots = _arr(slots, np.int32)
+        groups = _arr(groups, np.int32)
+        self._check(self._lib.wk_strata_groups(
+            self._h, _ptr(slots, C.c_int32), _ptr(groups, C.c_int32),
+            slots.size))
+
+    def strata_clear(self):
+        self._check(self._lib.wk_strata_clear(self._h))
 
     def ordinal_hit_offsets(self, n_hits):
         """Offsets of every hit's genes in the staged gene lists
@@ -1011,6 +1053,33 @@ def gz_member(data):
     if n < 0:
         raise ValueError('wk_gz_member failed')
     return out[:n].tobytes()
+
+
+def gz_inflate_members(blob, spans, out=None, n_threads=0):
+    """The text of a chain of 'WK' gzip members (``pgzip.members_of``) as one
+    uint8 array, inflated on ``n_threads`` threads; ``out``: a buffer to
+    inflate into when it is large enough.  Returns (text, inside out?)."""
+    lib = load_library()
+    raw = np.frombuffer(memoryview(blob), dtype=np.uint8)
+    lo = np.asarray([a for a, _ in spans], dtype=np.int64)
+    hi = np.asarray([b for _, b in spans], dtype=np.int64)
+    isize = np.empty(lo.size, dtype=np.int64)
+    for i, b in enumerate(hi.tolist()):
+        isize[i] = int.from_bytes(raw[b - 4:b].tobytes(), 'little')
+    off = np.zeros(lo.size + 1, dtype=np.int64)
+    np.cumsum(isize, out=off[1:])
+    total = int(off[-1])
+    inside = out is not None and out.size >= total
+    if not inside:
+        out = np.empty(total, dtype=np.uint8)
+    rc = lib.wk_gz_inflate_members(
+        C.c_void_p(raw.ctypes.data if raw.size else 0), _ptr(lo, C.c_int64),
+        _ptr(hi, C.c_int64), lo.size, C.c_void_p(out.ctypes.data),
+        _ptr(off, C.c_int64), int(n_threads) or (os.cpu_count() or 1))
+    if rc != 0:
+        raise OSError(f'gzip member {-rc - 1} does not inflate to what its '
+                      'trailer says')
+    return out[:total], inside
 
 
 def crc32(data, crc=0):

@@ -446,6 +446,10 @@ class Engine:
         self._dmaps_n = -1          # subjects the device's read-map tables cover
         self._dmaps_ok = False
         self._mring = None          # pinned buffers the map text is fetched into
+        # strata map joined on the device (csrc/wk_strata.hpp)
+        self._dstrata = None        # {'fp', 'labels', 'slots', 'key'} while the device holds the sample's map
+        self._sbuf = [None, None]   # pinned buffers the map text is inflated into
+        self._sbuf_next = 0
 
     def words_eligible(self):
         """Can chunks go to the device as packed words, accumulated per
@@ -566,20 +570,151 @@ class Engine:
             self._reserve(4 * need)
 
     # ------------------------------------------------------------------
-    def load_strata(self, fp, zippers, then=None):
+    def _strata_text(self, fp, zippers, buf):
+        """The text of a read map as a uint8 array: a chain of 'WK' gzip
+        members (what `--outmap` of this package writes) is inflated on all
+        threads straight into ``buf`` (a pinned array, when it is large
+        enough); anything else is read the ordinary way."""
+        from . import pgzip
+        from .file import readzip_bytes
+        if fp.endswith('.gz'):
+            import mmap
+            with open(fp, 'rb') as f:
+                try:
+                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                except (OSError, ValueError):
+                    mm = None
+            if mm is not None:
+                spans = pgzip.members_of(mm)
+                if spans is not None:
+                    try:
+                        return nat.gz_inflate_members(
+                            mm, spans, out=buf,
+                            n_threads=tokenizer_threads())[0]
+                    finally:
+                        del spans
+                        mm.close()
+                mm.close()
+        with readzip_bytes(fp, zippers) as fh:
+            return np.frombuffer(fh.read(), dtype=np.uint8)
+
+    def _load_strata_device(self, fp, zippers, then):
+        """The sample's map as the device's join table; None when the kernels
+        leave it to the host's join."""
+        from os.path import basename
+        import threading
+        text = None
+        ahead, self._strata_ahead = self._strata_ahead, None
+        if ahead is not None:
+            thread, box = ahead
+            thread.join()
+            if box['fp'] == fp and 'text' in box:
+                text = box['text']
+        if text is None:
+            text = self._strata_text(fp, zippers, self._strata_buffer(fp))
+        if then is not None and then != fp:
+            box = {'fp': then}
+            buf = self._strata_buffer(then)
+
+            def work():
+                try:
+                    box['text'] = self._strata_text(then, zippers, buf)
+                except Exception:       # (read again, and raised, when asked for)
+                    pass
+            thread = threading.Thread(target=work, name='wk-strata')
+            self._strata_ahead = (thread, box)
+            thread.start()
+        got = self.ctx.strata_load(text)
+        if got is None:
+            self.ctx.strata_clear()
+            return None
+        labels, slots = got
+        if not labels:
+            raise ValueError('No stratification information is found in file: '
+                             f'{basename(fp)}.')
+        labels = [x.decode() for x in labels]
+        self._dstrata = {'fp': fp, 'zippers': zippers, 'labels': labels,
+                         'slots': slots, 'key': None, 'host': None}
+        return labels
+
+    def _strata_buffer(self, fp):
+        """One of two pinned buffers for a map's text (None when the map is
+        not a regular file or pinned memory is refused): sized for the largest
+        map seen so far, with room to spare."""
+        try:
+            size = os.path.getsize(fp)
+        except OSError:
+            return None
+        # (read-map text deflates 4-6x; a plain file needs its own size)
+        need = size * 8 if fp.endswith('.gz') else size
+        i = self._sbuf_next
+        self._sbuf_next ^= 1
+        buf = self._sbuf[i]
+        if buf is None or buf.size < need:
+            try:
+                buf = self.ctx.host_alloc(int(need * 1.25) + (1 << 20), np.uint8)
+            except Exception:
+                return self._sbuf[i]
+            self._sbuf[i] = buf
+        return buf
+
+    def _device_strata_groups(self, sample):
+        """The labels' (sample, stratum) group ids to the device — again after
+        every fold of the count table (the groups are numbered anew)."""
+        ds = self._dstrata
+        labels = ds['labels']
+        groups = self._strata_groups(sample, labels,
+                                     np.arange(len(labels), dtype=np.int32))
+        sig = (sample, self._epoch)
+        if ds['key'] != sig:
+            self.ctx.strata_groups(ds['slots'], groups)
+            ds['key'] = sig
+
+    def _host_strata_ids(self, ids):
+        """Stratum ids of the host tokenizer (blocks the device left to it)
+        in the numbering of the device's labels."""
+        ds = self._dstrata
+        if ds['host'] is None:
+            where = {lab: i for i, lab in enumerate(ds['labels'])}
+            ds['host'] = np.asarray([where.get(lab, -1)
+                                     for lab in ds['host_labels']],
+                                    dtype=np.int32)
+        remap = ds['host']
+        return np.where(ids >= 0, remap[np.maximum(ids, 0)], -1).astype(
+            np.int32)
+
+    def _host_strata_table(self):
+        """The host tokenizer's join table for the sample the device holds
+        (first block the device leaves to the host)."""
+        ds = self._dstrata
+        if 'host_labels' not in ds:
+            ds['host_labels'] = self._read_strata(ds['fp'], ds['zippers'],
+                                                  False)
+
+    def load_strata(self, fp, zippers, then=None, device=False):
         """Read-to-stratum map of one sample into the native tokenizer;
         returns the stratum labels (workflow.read_strata, workflow.py:912-938).
         ``then``: the map that will be asked for next — read on a thread into
-        the tokenizer's second table while this sample is tokenised."""
+        the tokenizer's second table while this sample is tokenised.
+        ``device``: the alignments of this sample will be tokenised on the
+        device: the join table is built there (csrc/wk_strata.hpp)."""
         from os.path import basename
         if self.tok is None:
             self.tok = nat.Tokenizer(tokenizer_threads(), self._exclude)
+        self._dstrata = None
+        if device and not os.environ.get('WOLTKA_NO_DSTRATA'):
+            labels = self._load_strata_device(fp, zippers, then)
+            if labels is not None:
+                return labels
+        else:
+            self.ctx.strata_clear()
         labels = None
         ahead, self._strata_ahead = self._strata_ahead, None
         if ahead is not None:
             thread, box = ahead
             thread.join()
-            if box['fp'] == fp:
+            if box['fp'] == fp and 'text' not in box and (
+                    'labels' in box or 'err' in box):
                 if 'err' in box:
                     raise box['err']
                 self.tok.strata_swap()
@@ -626,8 +761,8 @@ class Engine:
             self.tok = nat.Tokenizer(tokenizer_threads(), exclude)
         tok = self.tok
         device_ex = ordinal and cover is None and not want_names and \
-            not want_groups and not want_samples and \
-            len(self.jobs) <= nat.MAX_JOBS
+            (not want_groups or self._dstrata is not None) and \
+            not want_samples and len(self.jobs) <= nat.MAX_JOBS
         if (words or device_ex or dmaps) and fmt == 'sam' and not exclude and \
                 part is None and not os.environ.get('WOLTKA_NO_DTOK'):
             from .align import _parallel_reader
@@ -642,8 +777,13 @@ class Engine:
                                                    ordinal=bool(ordinal))
                 finally:
                     self._dmaps = None
-                    self.ctx.dtok_keep_reads(False)
+                    if getattr(self.ctx, '_h', None):   # (still open)
+                        self.ctx.dtok_keep_reads(False)
                 return
+        if want_groups and self._dstrata is not None:
+            # (the device holds the join table but this file is tokenised on
+            # the host after all)
+            self._host_strata_table()
         ring = None
         if words:
             if self._ring is None:
@@ -747,8 +887,10 @@ class Engine:
             ranges = None if cover is None else (
                 self._tok_cover[res['subj']], res['beg'], res['end'])
             if res['off'].size > 1:
-                yield reads, packed, res.get('group'), names, \
-                    res.get('sample'), ranges
+                group = res.get('group')
+                if group is not None and self._dstrata is not None:
+                    group = self._host_strata_ids(group)
+                yield reads, packed, group, names, res.get('sample'), ranges
             elif 'slot' in res:
                 ring.release(res['slot'])
 
@@ -1304,8 +1446,9 @@ class Engine:
                                 None, None, None, None
                         tok.set_header_state(hdr)
                     else:
-                        yield from self._host_block(buf, fill, first, final,
-                                                    hdr_in, True)
+                        yield from self._host_block(
+                            buf, fill, first, final, hdr_in, True,
+                            groups=self._dstrata is not None)
                     return
                 if fresh:
                     base = self._tok_map.size
@@ -1381,16 +1524,19 @@ class Engine:
             self._dtok_lap = {}
 
     def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False,
-                    names=False):
+                    names=False, groups=False):
         """One block of the device route through the host tokenizer after
         all (the general arrays; ``names``: with the descriptors of the query
         names, for the read maps)."""
         tok = self.tok
         tok.set_header_state(hdr_in)
         if ordinal:
+            if groups:      # (the join of this block on the host)
+                self._host_strata_table()
             tok.set_subject_map(self._tok_genome)
             res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
-                            final=final, extra=True, fmt='sam')
+                            final=final, extra=True, fmt='sam',
+                            want_groups=groups)
             fresh = tok.new_subjects()
             if fresh:       # (names met for the first time in this block:
                 gidx = self.genes.genome_index.get      # map them, once more)
@@ -1401,10 +1547,13 @@ class Engine:
                 tok.set_subject_map(self._tok_genome)
                 tok.set_header_state(hdr_in)
                 res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
-                                final=final, extra=True, fmt='sam')
+                                final=final, extra=True, fmt='sam',
+                                want_groups=groups)
             if res['off'].size > 1:
                 yield None, (res['subj'], res['beg'], res['end'], res['len'],
-                             res['off']), None, None, None, None
+                             res['off']), \
+                    (self._host_strata_ids(res['group']) if groups else None), \
+                    None, None, None
             return
         res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
                         final=final, fmt='sam', want_names=names)
@@ -1424,8 +1573,15 @@ class Engine:
         staged on the device (`wk_dtok_stage_hits`) and matched + counted like
         a chunk of `wk_ordinal_stage`."""
         buf, fill, first, final, hdr_in, hdr = packed[1]
-        self._ensure_table(data, 4 * (fill // 24 + 1), 1)
-        group = self._group_array(1, sample, None)
+        ds = self._dstrata
+        if ds is not None:
+            if len(self.groups) + len(ds['labels']) + 1 >= MAX_GROUPS // 2:
+                self.collect(data)
+            self._ensure_table(data, 4 * (fill // 24 + 1), len(ds['labels']))
+            self._device_strata_groups(sample)
+        else:
+            self._ensure_table(data, 4 * (fill // 24 + 1), 1)
+            group = self._group_array(1, sample, None)
         for rank in self.ranks:
             data[rank].setdefault(sample, {})
         if self._deferred_from is None:
@@ -1435,16 +1591,19 @@ class Engine:
         if status == 0:
             self._n_reads += n_reads
             if n_reads:
-                self.ctx.set_uniform_group(group)
+                if ds is None:
+                    self.ctx.set_uniform_group(group)
                 self.ctx.ordinal_count(self.jobs)
                 if self.sizes:
                     self._collect_log()
             return 0
         n = 0
-        for _, arrays, *_ in self._host_block(buf, fill, first, final, hdr_in,
-                                              True):
+        for _, arrays, ids, *_ in self._host_block(
+                buf, fill, first, final, hdr_in, True, groups=ds is not None):
             n += self.run_chunk(data, None, None, sample, None, None, None,
-                                None, None, True, packed=arrays)
+                                None, None, True, packed=arrays,
+                                strata_ids=ids,
+                                strata_labels=ds['labels'] if ds else None)
         self.tok.set_header_state(hdr)
         return n
 

@@ -18,6 +18,10 @@
 #include <vector>
 
 #include <immintrin.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <thread>
 
 #include "../../include/woltka_hip.h"
 
@@ -535,6 +539,59 @@ int64_t wk_gz_member(const char* data, int64_t n, char* out, int64_t cap) {
     std::memcpy(out + 20 + body, &crc, 4);
     std::memcpy(out + 24 + body, &isize, 4);
     return (int64_t)size;
+}
+
+// Inflate members written by wk_gz_member — blob[lo[i], hi[i]) each, found by
+// their 'WK' size fields — on `n_threads` threads straight into out[off[i],
+// off[i + 1]) (the caller sums the members' ISIZE fields): the stratified
+// second pass reads a sample's read map this way (workflow.read_strata,
+// workflow.py:912-938).  Returns 0, or -(1 + i) for the first member that is
+// not what its trailer says (size, CRC-32) or does not inflate.
+int64_t wk_gz_inflate_members(const char* blob, const int64_t* lo, const int64_t* hi, int64_t n, char* out, const int64_t* off,
+                              int n_threads) {
+    if (n < 0 || (n > 0 && (!blob || !lo || !hi || !out || !off))) return -1;
+    std::atomic<int64_t> next{0}, bad{n};
+    auto work = [&]() {
+        for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            const int64_t a = lo[i] + 20, b = hi[i] - 8, want = off[i + 1] - off[i];
+            bool ok = b >= a && want >= 0;
+            if (ok) {
+                z_stream z;
+                std::memset(&z, 0, sizeof z);
+                ok = inflateInit2(&z, -15) == Z_OK;
+                if (ok) {
+                    // (members are smaller than 4 GB: wk_gz_member refuses larger ones)
+                    z.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(blob + a));
+                    z.avail_in = (uInt)(b - a);
+                    z.next_out = reinterpret_cast<Bytef*>(out + off[i]);
+                    z.avail_out = (uInt)want;
+                    const int rc = inflate(&z, Z_FINISH);
+                    ok = rc == Z_STREAM_END && (int64_t)z.total_out == want;
+                    inflateEnd(&z);
+                }
+            }
+            if (ok) {
+                uint32_t crc, isize;
+                std::memcpy(&crc, blob + b, 4);
+                std::memcpy(&isize, blob + b + 4, 4);
+                ok = isize == (uint32_t)want && crc == wk_crc32(0, out + off[i], want);
+            }
+            if (!ok) {
+                int64_t cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {
+                }
+            }
+        }
+    };
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : 1, n));
+    if (T == 1) {
+        work();
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work);
+        for (auto& x : th) x.join();
+    }
+    return bad.load() < n ? -(1 + bad.load()) : 0;
 }
 
 }  // extern "C"

@@ -27,6 +27,7 @@
 // parse runs again.
 #pragma once
 #include "wk_device.hpp"
+#include "wk_strata.hpp"
 #include "wk_weigh.hpp"
 
 namespace wk {
@@ -88,6 +89,7 @@ struct DtokArgs {
     int32_t* o_end;
     uint32_t* o_len;
     int32_t* o_hoff;                // ... and the reads' offsets
+    int32_t* o_group;               // (with a strata map on the device) the reads' (sample, stratum) groups
 };
 
 constexpr uint32_t kDtokBadNumber = 32;  // POS / CIGAR text the kernels leave to the host's Python-exact parsers
@@ -358,7 +360,10 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_scan_lines_kernel(DtokArgs 
     }
 }
 
-__global__ void __launch_bounds__(kDtokThreads) dtok_place_kernel(DtokArgs a) {
+// kStrata: the read's group from the strata map on the device (wk_strata.hpp;
+// classify.counter_strat, classify.py:216-249: -1 = not in the map, skipped)
+template <bool kStrata>
+__global__ void __launch_bounds__(kDtokThreads) dtok_place_kernel(DtokArgs a, StrataArgs strata) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_lines || !(a.is_first[i] & 1u)) return;
     const uint32_t m = a.lmeta[i] >> 28;
@@ -389,7 +394,9 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_place_kernel(DtokArgs a) {
     a.o_len[at] = a.llen[i];
     if (a.is_first[i] & 2u) {  // the read's first hit: its offset
         for (uint32_t q = 0; q < m && q < 3u; ++q) groups_before += seen[q] ? 1u : 0u;
-        a.o_hoff[(uint32_t)(base >> 32) + groups_before] = (int32_t)at;
+        const uint32_t r = (uint32_t)(base >> 32) + groups_before;
+        a.o_hoff[r] = (int32_t)at;
+        if constexpr (kStrata) a.o_group[r] = strata_lookup(strata, a.text + a.line_start[i], a.lmeta[i] & 0x0FFFFFFFu, m);
     }
 }
 

@@ -241,6 +241,11 @@ struct wk_ctx {
     };
     MapTables rm[WK_MAX_JOBS];
     DevBuf rm_line, rm_len, rm_text;
+    // strata map of the current sample on the device (wk_strata.hpp)
+    DevBuf s_text, s_lines, s_tab, s_vlen, s_hash, s_label, s_slots, s_labels, s_label_text, s_label_group, s_state, s_tiles, s_tile_off;
+    uint32_t s_n = 0, s_n_lines = 0, s_mask = 0;
+    bool s_ready = false;   // wk_strata_load built the tables
+    bool s_use = false;     // wk_strata_groups gave the labels their groups: wk_dtok_stage_hits joins
     bool dt_keep_reads = false;   // wk_dtok_keep_reads: wk_dtok_emit places the records in read order and keeps the block
     bool dt_emitted = false;      // the block scanned last was emitted with its reads kept
     uint32_t dt_emit_reads = 0;
@@ -2354,6 +2359,155 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     return WK_OK;
 }
 
+// ---- strata map on the device (wk_strata.hpp) ---------------------------------------
+
+static StrataArgs strata_args(wk_ctx* c) {
+    StrataArgs s{};
+    s.text = c->s_text.as<unsigned char>();
+    s.n = c->s_n;
+    s.line_start = c->s_lines.as<uint32_t>();
+    s.n_lines = c->s_n_lines;
+    s.line_tab = c->s_tab.as<uint32_t>();
+    s.line_vlen = c->s_vlen.as<uint32_t>();
+    s.line_hash = c->s_hash.as<unsigned long long>();
+    s.line_label = c->s_label.as<uint32_t>();
+    s.slots = c->s_slots.as<StrataSlot>();
+    s.mask = c->s_mask;
+    s.labels = c->s_labels.as<LabelSlot>();
+    s.label_text = c->s_label_text.as<uint2>();
+    s.label_group = c->s_label_group.as<int32_t>();
+    s.state = c->s_state.as<uint32_t>();
+    return s;
+}
+
+int wk_strata_clear(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    c->s_ready = c->s_use = false;
+    return WK_OK;
+}
+
+int wk_strata_load(wk_ctx* c, const char* text, int64_t n64, int64_t* n_pairs, int32_t* n_labels, int* status) {
+    if (!c || n64 < 0 || (n64 > 0 && !text) || !n_pairs || !n_labels || !status) return WK_E_ARG;
+    *status = 1;
+    *n_pairs = 0;
+    *n_labels = 0;
+    c->s_ready = c->s_use = false;
+    if (n64 >= (1ll << 32) - 64) return WK_OK;  // (offsets are 32 bits: the host's join takes larger maps)
+    DeviceGuard guard(c->device);
+    const uint32_t n = (uint32_t)n64;
+    c->s_n = n;
+    c->s_n_lines = 0;
+    HIP_TRY(c, c->s_state.reserve(64));
+    HIP_TRY(c, hipMemsetAsync(c->s_state.p, 0, 64, c->stream));
+    HIP_TRY(c, c->s_labels.reserve((size_t)kStrataLabelSlots * sizeof(LabelSlot)));
+    HIP_TRY(c, c->s_label_text.reserve((size_t)kStrataLabelSlots * 8));
+    HIP_TRY(c, c->s_label_group.reserve((size_t)kStrataLabelSlots * 4));
+    HIP_TRY(c, hipMemsetAsync(c->s_labels.p, 0xFF, (size_t)kStrataLabelSlots * sizeof(LabelSlot), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->s_label_group.p, 0xFF, (size_t)kStrataLabelSlots * 4, c->stream));
+    if (n == 0) {
+        HIP_TRY(c, c->s_slots.reserve(1024 * sizeof(StrataSlot)));
+        HIP_TRY(c, hipMemsetAsync(c->s_slots.p, 0, 1024 * sizeof(StrataSlot), c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->s_mask = 1023;
+        c->s_ready = true;
+        *status = 0;
+        return WK_OK;
+    }
+    HIP_TRY(c, c->s_text.reserve((size_t)n + 64));
+    HIP_TRY(c, copy_text_async(c, c->s_text.p, text, n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->s_text.as<unsigned char>() + n, 0, 64, c->stream));
+    // line starts, like a block of alignment text
+    const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
+    HIP_TRY(c, c->s_tiles.reserve((size_t)n_tiles * 8));
+    HIP_TRY(c, c->s_tile_off.reserve((size_t)n_tiles * 8));
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+    hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->s_text.as<unsigned char>(), n,
+                       c->s_tiles.as<unsigned long long>());
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->s_tiles.as<unsigned long long>(),
+                       c->s_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+    unsigned long long n_newlines = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_newlines, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const bool open_end = text[n - 1] != '\n';
+    const uint32_t lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
+    HIP_TRY(c, c->s_lines.reserve(((size_t)lines + 2) * 4));
+    HIP_TRY(c, c->s_tab.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->s_vlen.reserve(((size_t)lines + 1) * 4));
+    HIP_TRY(c, c->s_hash.reserve(((size_t)lines + 1) * 8));
+    HIP_TRY(c, c->s_label.reserve(((size_t)lines + 1) * 4));
+    uint64_t slots = 1024;
+    while (slots < 2ull * lines) slots <<= 1;
+    HIP_TRY(c, c->s_slots.reserve((size_t)slots * sizeof(StrataSlot)));
+    HIP_TRY(c, hipMemsetAsync(c->s_slots.p, 0, (size_t)slots * sizeof(StrataSlot), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->s_lines.p, 0, 4, c->stream));
+    hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->s_text.as<unsigned char>(), n,
+                       c->s_tile_off.as<unsigned long long>(), c->s_lines.as<uint32_t>());
+    if (open_end) {
+        const uint32_t end = n + 1;
+        HIP_TRY(c, hipMemcpyAsync(c->s_lines.as<uint32_t>() + lines, &end, 4, hipMemcpyHostToDevice, c->stream));
+    }
+    c->s_n_lines = lines;
+    c->s_mask = (uint32_t)(slots - 1);
+    const StrataArgs s = strata_args(c);
+    const dim3 grid((lines + kStrataThreads - 1) / kStrataThreads);
+    KernelTimer* kt = ktimer_begin(c, "strata");
+    hipLaunchKernelGGL(strata_parse_kernel, grid, dim3(kStrataThreads), 0, c->stream, s);
+    hipLaunchKernelGGL(strata_verify_kernel, grid, dim3(kStrataThreads), 0, c->stream, s);
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t st[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(st, c->s_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (st[0]) return WK_OK;  // status 1: the host's join takes the sample
+    c->s_ready = true;
+    *n_pairs = st[1];
+    *n_labels = (int32_t)st[2];
+    *status = 0;
+    return WK_OK;
+}
+
+int wk_strata_labels(wk_ctx* c, int32_t* slot, int64_t* text_off, int32_t* text_len, int32_t cap, int32_t* n_out) {
+    if (!c || !n_out || cap < 0 || (cap > 0 && (!slot || !text_off || !text_len))) return WK_E_ARG;
+    *n_out = 0;
+    if (!c->s_ready) return fail(c, WK_E_STATE, "no strata map on the device (wk_strata_load)");
+    DeviceGuard guard(c->device);
+    std::vector<LabelSlot> tab(kStrataLabelSlots);
+    std::vector<uint2> txt(kStrataLabelSlots);
+    HIP_TRY(c, hipMemcpyAsync(tab.data(), c->s_labels.p, tab.size() * sizeof(LabelSlot), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(txt.data(), c->s_label_text.p, txt.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // in the order their first lines appear in the map
+    std::vector<std::pair<uint32_t, uint32_t>> order;  // (first line, slot)
+    for (uint32_t q = 0; q < kStrataLabelSlots; ++q)
+        if (tab[q].hash != kLabelEmpty) order.emplace_back(tab[q].rep, q);
+    std::sort(order.begin(), order.end());
+    if ((int64_t)order.size() > cap) return fail(c, WK_E_CAPACITY, "need room for %zu labels", order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        const uint32_t q = order[k].second;
+        slot[k] = (int32_t)q;
+        text_off[k] = txt[q].x;
+        text_len[k] = (int32_t)txt[q].y;
+    }
+    *n_out = (int32_t)order.size();
+    return WK_OK;
+}
+
+int wk_strata_groups(wk_ctx* c, const int32_t* slot, const int32_t* group, int32_t n) {
+    if (!c || n < 0 || (n > 0 && (!slot || !group))) return WK_E_ARG;
+    if (!c->s_ready) return fail(c, WK_E_STATE, "no strata map on the device (wk_strata_load)");
+    std::vector<int32_t> all(kStrataLabelSlots, -1);
+    for (int32_t k = 0; k < n; ++k) {
+        if (slot[k] < 0 || (uint32_t)slot[k] >= kStrataLabelSlots) return fail(c, WK_E_ARG, "label slot outside the table");
+        if (group[k] >= (1 << WK_KEY_GROUP_BITS)) return fail(c, WK_E_ARG, "group id outside [0, %d)", 1 << WK_KEY_GROUP_BITS);
+        all[slot[k]] = group[k];
+    }
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipMemcpyAsync(c->s_label_group.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->s_use = true;
+    return WK_OK;
+}
+
 // ---- read maps on the device (wk_readmap.hpp) -------------------------------------
 
 int wk_dtok_keep_reads(wk_ctx* c, int on) {
@@ -2489,7 +2643,13 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
                            c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
         hipLaunchKernelGGL(dtok_scan_lines_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tile_off.as<unsigned long long>());
-        hipLaunchKernelGGL(dtok_place_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        if (c->s_use) {
+            HIP_TRY(c, c->c_group.reserve(((size_t)lines + 1) * 4));
+            a.o_group = c->c_group.as<int32_t>();
+            hipLaunchKernelGGL(dtok_place_kernel<true>, grid, dim3(kDtokThreads), 0, c->stream, a, strata_args(c));
+        } else {
+            hipLaunchKernelGGL(dtok_place_kernel<false>, grid, dim3(kDtokThreads), 0, c->stream, a, StrataArgs{});
+        }
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
@@ -2502,7 +2662,7 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
     c->n_hits = hits;
     c->o_reads = reads;
     c->th = th;
-    c->has_group = false;
+    c->has_group = c->s_use && lines > 0;
     c->group_base = 0;
     c->rk_valid[0] = c->rk_valid[1] = false;
     c->ord_valid = true;

@@ -303,9 +303,20 @@ def classify(
                                 later = [files[x] for x in files]
                                 later = [x for x in later[later.index(sample):]
                                          if x != sample and x in stratmap]
+                                # coord-match on SAM text that the device
+                                # tokenises: the join runs there too
+                                from .file import ZIP_BY_EXT
+                                from os.path import splitext
+                                dstrata = bool(
+                                    ordinal and fmt_ == 'sam' and not exclude
+                                    and part is None and cover is None and
+                                    rank2dir is None and path != '-' and
+                                    ZIP_BY_EXT.get(splitext(path)[1]) is None
+                                    and not os.environ.get('WOLTKA_NO_DTOK'))
                                 labels = engine.load_strata(
                                     stratmap[sample], zippers,
-                                    then=stratmap[later[0]] if later else None)
+                                    then=stratmap[later[0]] if later else None,
+                                    device=dstrata)
                                 csample = sample
                         # read ids as Python strings only when the host logic
                         # needs them (demultiplexing, Python-side strata join);
@@ -387,7 +398,8 @@ def classify(
                         # stratum of every read; the strata map of a sample is read
                         # when the sample first shows up (workflow.py:327-330)
                         strata_of = None
-                        if stratmap and strata_ids is None:
+                        if stratmap and strata_ids is None and not (
+                                native and native_strata):
                             strata_of, csample, strata = strata_labels(
                                 sample_of, reads, stratmap, zippers, csample,
                                 strata)
