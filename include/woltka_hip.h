@@ -693,6 +693,19 @@ int wk_blob_join(const char* blob, const int64_t* off, int64_t n, char sep, char
 int wk_table_body(const char* keys, int64_t keys_len, const int64_t* values, int64_t n, int threads,
                   char* out, int64_t cap, int64_t* out_len, int64_t* n_rows);
 
+/* The rows of a TSV table with n_cols sample columns and, for stratified
+ * profiles, `stratum|feature` row names (same reference code): row r is named
+ * prefixes[prefix_of_row[r]] | names[name_of_row[r]] (no prefix when
+ * prefix_of_row is NULL, its entry negative or the prefix empty) and holds
+ * values[r * n_cols ..).  Sorted by (prefix, name) in byte order like
+ * `sorted(allkeys(profile))` over (stratum, feature) tuples; all-zero rows are
+ * left out.  prefixes / names: the strings joined by '\n'. */
+int wk_table_rows(const char* prefixes, int64_t prefixes_len, int32_t n_prefixes,
+                  const char* names, int64_t names_len, int32_t n_names,
+                  const int32_t* prefix_of_row, const int32_t* name_of_row,
+                  const int64_t* values, int64_t n_rows, int32_t n_cols,
+                  char* out, int64_t cap, int64_t* out_len, int64_t* rows_written);
+
 /* ---- measurement ------------------------------------------------------- */
 /* HIP-event timing on the context's own stream (the stream every kernel of
  * this library is launched on).  wk_timer_begin/end bracket a region;

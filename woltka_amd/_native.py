@@ -40,7 +40,7 @@ SYMBOLS = (
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
     'wk_set_uniform_group', 'wk_chunk_download', 'wk_ordinal_hit_offsets',
-    'wk_blob_join', 'wk_table_body', 'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
+    'wk_blob_join', 'wk_table_body', 'wk_table_rows', 'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
     'wk_words_begin', 'wk_words_append',
     'wk_words_wait', 'wk_words_flush', 'wk_words_pending',
     'wk_get_stats', 'wk_reset_stats', 'wk_timer_begin', 'wk_timer_end',
@@ -208,6 +208,10 @@ def load_library():
                                         i32p, i32p, C.c_char_p, i64p, C.c_int32,
                                         C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                         i64p]),
+        'wk_table_rows': (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.c_char_p,
+                                    C.c_int64, C.c_int32, i32p, i32p, i64p,
+                                    C.c_int64, C.c_int32, C.c_void_p,
+                                    C.c_int64, i64p, i64p]),
         'wk_hier_create': (C.c_int, [C.c_int, C.POINTER(p)]),
         'wk_hier_destroy': (None, [p]),
         'wk_hier_last_error': (C.c_char_p, [p]),
@@ -1146,6 +1150,45 @@ def table_body(keys, values, n_threads=8):
         keys, len(keys), _ptr(values, C.c_int64), n, int(n_threads),
         C.c_void_p(out.ctypes.data), out.size, _ptr(used, C.c_int64),
         _ptr(rows, C.c_int64))
+    if rc != OK:
+        return None
+    return memoryview(out)[:int(used[0])], int(rows[0])
+
+
+def table_rows(prefixes, names, prefix_of_row, name_of_row, values):
+    """(bytes-like body, rows) of a TSV table whose rows are named
+    ``prefix|name`` (``prefixes``: list of str or None) with ``values`` =
+    int64[n_rows, n_cols] (``wk_table_rows``: sorted, all-zero rows left out).
+    None when the native side refuses the input (a name with a line break)."""
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    n_rows, n_cols = values.shape
+    try:
+        pb = '\n'.join(prefixes).encode() if prefixes else b''
+        nb = '\n'.join(names).encode()
+    except UnicodeEncodeError:
+        return None
+    if (prefixes and pb.count(b'\n') != len(prefixes) - 1) or \
+            (names and nb.count(b'\n') != len(names) - 1):
+        return None
+    name_of_row = _arr(name_of_row, np.int32)
+    if prefixes:
+        prefix_of_row = _arr(prefix_of_row, np.int32)
+        plen = np.fromiter(map(len, prefixes), np.int64, len(prefixes))
+        per_row = int(np.where(prefix_of_row >= 0,
+                               plen[np.maximum(prefix_of_row, 0)], 0).sum())
+    else:
+        prefix_of_row, per_row = None, 0
+    nlen = np.fromiter(map(len, names), np.int64, len(names))
+    # (lengths in characters: a character takes up to four bytes)
+    cap = 4 * (per_row + int(nlen[name_of_row].sum())) + \
+        n_rows * (3 + 21 * n_cols) + 64
+    out = np.empty(cap, dtype=np.uint8)
+    used, rows = np.zeros(1, np.int64), np.zeros(1, np.int64)
+    rc = load_library().wk_table_rows(
+        pb, len(pb), len(prefixes) if prefixes else 0, nb, len(nb), len(names),
+        _ptr(prefix_of_row, C.c_int32), _ptr(name_of_row, C.c_int32),
+        _ptr(values, C.c_int64), n_rows, n_cols, C.c_void_p(out.ctypes.data),
+        out.size, _ptr(used, C.c_int64), _ptr(rows, C.c_int64))
     if rc != OK:
         return None
     return memoryview(out)[:int(used[0])], int(rows[0])

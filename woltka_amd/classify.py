@@ -409,6 +409,11 @@ class Engine:
         self._reserve(table_slots or max(1 << 20, 4 * len(self.index)))
         self._job_base = 0                  # first job of the batch in flight
         self._final = {}                    # (rank, sample) -> (units, big) of the last `finish`
+        # large folds of the count table stay arrays (cells.py): (job, sample
+        # index, stratum index, feature, units) per fold, until `finish`
+        self._stash, self._stash_big = [], []
+        self._lz_samples, self._lz_sample_ids = [], {}
+        self._lz_strata, self._lz_strata_ids = [], {}
         self._n_reads = 0                   # reads classified (bounds the mapper chunks)
         self._n_files = 0                   # alignment files begun (each restarts the mapper's chunks)
         self._replay = None
@@ -1924,6 +1929,8 @@ class Engine:
         for (rank, sample), (units, big) in self._final.items():
             if rank not in lists:
                 continue
+            if callable(units):     # (kept as arrays: cells.LazyCells.units)
+                units = units()
             keys = certify.uncertified(units, big, self._n_reads,
                                        nat.WEIGHT_L, digits, factor, chunk_n,
                                        n_files=max(1, self._n_files))
@@ -2366,6 +2373,8 @@ class Engine:
             data[rank].setdefault(sample, {})[key] = fsum(vals)
         self.sized = {}
 
+    LAZY_MIN = 4096     # cells of one fold from which they are kept as arrays
+
     def collect(self, data, keep_groups=False):
         """Fetch the device counts, fold them into ``data`` as exact
         ``Fraction``s (sum_k n_k / k, classify.py:167-170) and clear the
@@ -2395,7 +2404,38 @@ class Engine:
             np.add.at(tot, inv, units[~big])
             names = self.index.names
             names_of = self.index.names_of
-            if cells.size:
+            lazy = cells.size >= self.LAZY_MIN and \
+                not self.sizes and self._replay is None and \
+                not os.environ.get('WOLTKA_NO_LAZY')
+            if lazy:
+                # a large fold stays arrays: no Python object per cell
+                cj, _, cg, cf = nat.decode_keys(cells)
+                g2s = np.empty(len(self.groups), dtype=np.int32)
+                g2t = np.empty(len(self.groups), dtype=np.int32)
+                sid, tid = self._lz_sample_ids, self._lz_strata_ids
+                for g in np.unique(np.concatenate((cg, grp[big]))).tolist():
+                    sample, stratum = self.groups[g]
+                    if sample not in sid:
+                        sid[sample] = len(self._lz_samples)
+                        self._lz_samples.append(sample)
+                    g2s[g] = sid[sample]
+                    if stratum is None:
+                        g2t[g] = -1
+                    else:
+                        if stratum not in tid:
+                            tid[stratum] = len(self._lz_strata)
+                            self._lz_strata.append(stratum)
+                        g2t[g] = tid[stratum]
+                self._stash.append((
+                    (cj + self._job_base).astype(np.int32), g2s[cg], g2t[cg],
+                    cf.astype(np.int32), tot))
+                if big.any():   # (reads of more than 16 candidates: rationals)
+                    self._stash_big.append((
+                        (job[big] + self._job_base).astype(np.int32),
+                        g2s[grp[big]], g2t[grp[big]],
+                        feat[big].astype(np.int32), k[big].astype(np.int64),
+                        vals[big].astype(np.int64)))
+            elif cells.size:
                 run_of = cells >> np.uint64(nat.KEY_GROUP_SHIFT)    # (job, k=0, group)
                 cuts = np.flatnonzero(run_of[1:] != run_of[:-1]) + 1
                 lo = [0] + cuts.tolist()
@@ -2418,9 +2458,9 @@ class Engine:
                             dst[key] = get(key, 0) + u
                     else:
                         dst.update(zip(labels, tot[a:b].tolist()))
-            for j, kk, g, f, nn in zip(job[big].tolist(), k[big].tolist(),
-                                       grp[big].tolist(), feat[big].tolist(),
-                                       vals[big].tolist()):
+            for j, kk, g, f, nn in () if lazy else zip(
+                    job[big].tolist(), k[big].tolist(), grp[big].tolist(),
+                    feat[big].tolist(), vals[big].tolist()):
                 sample, stratum = self.groups[g]
                 name = 'Unassigned' if f == nat.FEATURE_UNASSIGNED \
                     else names[f]
@@ -2446,9 +2486,12 @@ class Engine:
             self._writer.flush()
         self._words_done()
         self.collect(data)
+        lazies = self._finish_stash(data, exact)
         # (kept for the certifier, `uncertified`)
         self._final = {k: (v, dict(self._big.get(k, {})))
                        for k, v in self._units.items()}
+        for k, (cells, big) in lazies.items():
+            self._final[k] = (cells.units, big)
         for k, v in self._big.items():
             self._final.setdefault(k, ({}, dict(v)))
         # units of 1/L (+ the k > 16 rationals) -> the caller's profile
@@ -2490,6 +2533,8 @@ class Engine:
             for key, v in extra.items():
                 dst[key] = dst.get(key, 0) + v
         self._units, self._big = {}, {}
+        for (rank, sample), (cells, _) in lazies.items():
+            data[rank][sample] = cells
         if self.sizes:
             self._finish_sized(data)
         if exact:
@@ -2498,11 +2543,104 @@ class Engine:
             exact_to_numbers(data)
 
 
+def _finish_stash(self, data, exact):
+    """The folds `collect` kept as arrays -> one `cells.CellStore` per rank
+    and a `cells.LazyCells` per (rank, sample): {(rank, sample): (cells,
+    {key: Fraction of the reads of more than 16 candidates})}.  A sample that
+    also has cells in dict form (small folds), or an exact merge over
+    processes, takes the dict route: its arrays are added to `_units` /
+    `_big`."""
+    from .cells import CellStore, LazyCells
+    stash, self._stash = self._stash, []
+    bigs, self._stash_big = self._stash_big, []
+    out = {}
+    if not stash:
+        return out
+    L = nat.WEIGHT_L
+    j = np.concatenate([x[0] for x in stash] + [x[0] for x in bigs])
+    sm = np.concatenate([x[1] for x in stash] +
+                        [x[1] for x in bigs]).astype(np.int64)
+    tt = np.concatenate([x[2] for x in stash] +
+                        [x[2] for x in bigs]).astype(np.int64)
+    ff = np.concatenate([x[3] for x in stash] +
+                        [x[3] for x in bigs]).astype(np.int64)
+    n_big = sum(x[0].size for x in bigs)
+    # (the rational parts come in as cells of 0 units: their keys exist)
+    uu = np.concatenate([x[4] for x in stash] +
+                        [np.zeros(n_big, dtype=np.int64)])
+    n_small = uu.size - n_big
+    bk = np.concatenate([x[4] for x in bigs]).tolist() if bigs else []
+    bn = np.concatenate([x[5] for x in bigs]).tolist() if bigs else []
+    n_t = len(self._lz_strata) + 1
+    allkey = (sm * n_t + (tt + 1)) * (nat.FEATURE_UNASSIGNED + 1) + ff
+    for job in np.unique(j).tolist():
+        rank = self.ranks[job]
+        m = np.flatnonzero(j == job)
+        key = allkey[m]
+        order = np.argsort(key, kind='stable')
+        key = key[order]
+        first = np.concatenate(([True], key[1:] != key[:-1]))
+        starts = np.flatnonzero(first)
+        units = np.add.reduceat(uu[m][order], starts)
+        pick = m[order[starts]]
+        s_, t_, f_ = sm[pick], tt[pick], ff[pick]
+        store = CellStore(self._lz_samples, self._lz_strata, self.index,
+                          nat.FEATURE_UNASSIGNED, s_.astype(np.int32),
+                          t_.astype(np.int32), f_.astype(np.int32), units, L)
+        # rational parts of this job: cell index -> Fraction
+        extra = {}
+        ukey = key[starts]
+        for q in np.flatnonzero(j[n_small:] == job).tolist():
+            i = int(np.searchsorted(ukey, allkey[n_small + q]))
+            extra[i] = extra.get(i, 0) + Fraction(bn[q], bk[q])
+        cuts = np.flatnonzero(s_[1:] != s_[:-1]) + 1
+        lo = [0] + cuts.tolist()
+        hi = cuts.tolist() + [s_.size]
+        at = sorted(extra)
+        for a, b in zip(lo, hi):
+            sample = self._lz_samples[int(s_[a])]
+            cells = LazyCells(store, np.arange(a, b, dtype=np.int64))
+            k = (rank, sample)
+            mine = [i for i in at if a <= i < b]
+            big = {}
+            if mine:
+                names = store.keys_of(np.asarray(mine, dtype=np.int64))
+                big = {name: extra[i] for name, i in zip(names, mine)}
+            ok = int(units[a:b].max()) < (1 << 53) and \
+                int(units[a:b].min()) >= 0
+            if exact or not ok or k in self._units or k in self._big or \
+                    data[rank].get(sample):
+                dst = self._units.setdefault(k, {})
+                for key_, u in cells.units().items():
+                    if u or key_ not in big:
+                        dst[key_] = dst.get(key_, 0) + u
+                if big:
+                    dstb = self._big.setdefault(k, {})
+                    for key_, v in big.items():
+                        dstb[key_] = dstb.get(key_, 0) + v
+                continue
+            for i in mine:      # the exact value of these few cells
+                v = Fraction(int(units[i]), L) + extra[i]
+                if v.denominator == 1:
+                    store.w[i], store.i[i] = True, v.numerator
+                else:
+                    store.w[i] = False
+                    store.x[i] = v.numerator / v.denominator
+            out[k] = (cells, big)
+    return out
+
+
+Engine._finish_stash = _finish_stash
+
+
 def exact_to_numbers(data):
     """``Fraction`` cells -> ``int`` when integral, else one correctly rounded
     ``float`` division."""
+    from .cells import LazyCells
     for profile in data.values():
         for sample in profile.values():
+            if type(sample) is LazyCells and sample.pending:
+                continue        # (arrays of ints and floats)
             for key, v in sample.items():
                 if type(v) is Fraction:
                     sample[key] = v.numerator if v.denominator == 1 \

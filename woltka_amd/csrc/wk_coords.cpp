@@ -290,4 +290,115 @@ int wk_table_body(const char* keys, int64_t keys_len, const int64_t* values, int
     return WK_OK;
 }
 
+
+}  // extern "C"
+
+namespace {
+
+// offsets of n strings joined by '\n' (none of them holds one); false if the blob is anything else
+bool split_lines(const char* blob, int64_t len, int64_t n, std::vector<uint32_t>& off) {
+    off.assign((size_t)n + 1, 0);
+    if (n == 0) return len == 0;
+    if (len >= (1ll << 32)) return false;
+    int64_t k = 0;
+    for (int64_t i = 0; i < len; ++i)
+        if (blob[i] == '\n') {
+            if (++k >= n) return false;
+            off[(size_t)k] = (uint32_t)(i + 1);
+        }
+    if (k != n - 1) return false;
+    off[(size_t)n] = (uint32_t)(len + 1);
+    return true;
+}
+
+// rank[i] = place of string i among the n strings in byte order (= Python's order of str for UTF-8)
+void rank_strings(const char* blob, const std::vector<uint32_t>& off, int64_t n, std::vector<uint32_t>& rank) {
+    std::vector<uint32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t la = off[a + 1] - off[a] - 1, lb = off[b + 1] - off[b] - 1;
+        const int c = memcmp(blob + off[a], blob + off[b], std::min(la, lb));
+        return c < 0 || (c == 0 && la < lb);
+    });
+    rank.assign((size_t)n, 0);
+    for (int64_t i = 0; i < n; ++i) rank[order[(size_t)i]] = (uint32_t)i;
+}
+
+inline char* put_i64(char* w, int64_t v) {
+    char digits[24];
+    int d = 0;
+    uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+    do {
+        digits[d++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    if (v < 0) *w++ = '-';
+    while (d) *w++ = digits[--d];
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+// The body of a TSV table with n_cols sample columns and (optionally) stratified
+// row names (table.prep_table + table.write_tsv, woltka/table.py:29-136, 247-283):
+// row r is named `prefix|name` — prefix_of_row[r] < 0 or an empty prefix: just
+// `name` — and holds values[r * n_cols .. + n_cols).  Rows come out sorted like
+// the reference's `sorted(allkeys(profile))` over (stratum, feature) tuples /
+// plain ids: by prefix, then by name, in byte order (rows without prefix as if
+// their prefix were the name's — the caller never mixes the two kinds); rows
+// that are all zero are left out.  `prefixes` / `names`: the strings joined by
+// '\n'.  `out` needs, per row, its two strings + 2 + 21 n_cols bytes.
+int wk_table_rows(const char* prefixes, int64_t prefixes_len, int32_t n_prefixes, const char* names, int64_t names_len,
+                  int32_t n_names, const int32_t* prefix_of_row, const int32_t* name_of_row, const int64_t* values, int64_t n_rows,
+                  int32_t n_cols, char* out, int64_t cap, int64_t* out_len, int64_t* rows_written) {
+    if (n_rows < 0 || n_cols < 0 || n_prefixes < 0 || n_names < 0 || !out_len || !rows_written ||
+        (n_rows > 0 && (!name_of_row || (n_cols > 0 && !values))) || (cap > 0 && !out))
+        return WK_E_ARG;
+    *out_len = *rows_written = 0;
+    std::vector<uint32_t> poff, noff, prank, nrank;
+    if (!split_lines(prefixes, prefixes_len, n_prefixes, poff) || !split_lines(names, names_len, n_names, noff)) return WK_E_ARG;
+    rank_strings(prefixes, poff, n_prefixes, prank);
+    rank_strings(names, noff, n_names, nrank);
+    std::vector<std::pair<uint64_t, uint32_t>> order((size_t)n_rows);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int32_t p = prefix_of_row ? prefix_of_row[r] : -1, m = name_of_row[r];
+        if (p >= n_prefixes || m < 0 || m >= n_names) return WK_E_ARG;
+        const uint64_t hi = p < 0 ? 0ull : 1ull + prank[(size_t)p];
+        order[(size_t)r] = {hi << 32 | nrank[(size_t)m], (uint32_t)r};
+    }
+    std::sort(order.begin(), order.end());
+    char* w = out;
+    char* const end = out + cap;
+    int64_t rows = 0;
+    for (const auto& kv : order) {
+        const uint32_t r = kv.second;
+        const int64_t* v = values + (size_t)r * (size_t)n_cols;
+        bool any = false;
+        for (int32_t c = 0; c < n_cols; ++c) any |= v[c] != 0;
+        if (!any) continue;
+        const int32_t p = prefix_of_row ? prefix_of_row[r] : -1, m = name_of_row[r];
+        const uint32_t pl = p < 0 ? 0u : poff[(size_t)p + 1] - poff[(size_t)p] - 1, nl = noff[(size_t)m + 1] - noff[(size_t)m] - 1;
+        if (w + pl + nl + 2 + (size_t)21 * (size_t)n_cols + 1 > end) return WK_E_CAPACITY;
+        if (pl) {
+            memcpy(w, prefixes + poff[(size_t)p], pl);
+            w += pl;
+            *w++ = '|';
+        }
+        memcpy(w, names + noff[(size_t)m], nl);
+        w += nl;
+        *w++ = '\t';  // (write_tsv joins the sample block as one field: the tab is there without samples too)
+        for (int32_t c = 0; c < n_cols; ++c) {
+            if (c) *w++ = '\t';
+            w = put_i64(w, v[c]);
+        }
+        *w++ = '\n';
+        rows += 1;
+    }
+    *out_len = (int64_t)(w - out);
+    *rows_written = rows;
+    return WK_OK;
+}
+
 }  // extern "C"

@@ -940,8 +940,12 @@ def round_profiles(data, digits=None):
     """Round cells, drop zeros (workflow.py:1106-1119, util.round_dict).  An
     ``int`` cell rounds to itself (``round(v * 2) / 2 == v``), so only the
     other cells go through the rule."""
+    from .cells import LazyCells
     for profile in data.values():
         for sample in profile.values():
+            if type(sample) is LazyCells and sample.pending and \
+                    digits is None and sample.round_bulk():
+                continue        # (rounded as arrays)
             if digits is None and len(sample) > 256 and _round_bulk(sample):
                 continue
             dead = []
@@ -1016,8 +1020,14 @@ def write_profiles(data, fp, is_biom=None, samples=None, tree=None,
     click.echo(f'Format of output feature table(s): {label}.')
     click.echo(f'Writing output profiles in {label} format...')
     columns = samples or sorted(allkeys(data))
+    from .cells import write_lazy_table
     for rank, path in targets:
         if not (biom or add_lineage or add_rank or namedic):
+            done = write_lazy_table(data[rank], columns, path, openzip)
+            if done is not None:
+                click.echo(f'  Rank: {rank}, samples: {done[0]}, features: '
+                           f'{done[1]}.')
+                continue
             rows = _write_one_sample(data[rank], columns, path)
             if rows is not None:
                 click.echo(f'  Rank: {rank}, samples: 1, features: {rows}.')
