@@ -728,8 +728,31 @@ def twopass_digests(tmp, kw1, kw2):
     return out
 
 
+def twopass_fixture_check(device, workdir=None):
+    """The two calls at the size the REAL reference was run at in the build
+    container (tests/golden/make_twopass_reference.py: 8 samples x 200 k
+    reads): True when both tables and every read map hash to the reference's
+    digests (tests/golden/vectors/ref_twopass.json), None when the digests are
+    not there."""
+    from woltka_amd import workflow
+    fp = os.path.join(ROOT, 'tests', 'golden', 'vectors', 'ref_twopass.json')
+    if not os.path.isfile(fp):
+        return None
+    with open(fp) as f:
+        gold = json.load(f)
+    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
+        fps, n_rec, n_bytes, _ = write_twopass_inputs(
+            tmp, gold['samples'], gold['reads_per_sample'])
+        kw1, kw2 = twopass_calls(fps, tmp)
+        quiet(workflow.workflow, device=device, **kw1)
+        quiet(workflow.workflow, device=device, **kw2)
+        got = twopass_digests(tmp, kw1, kw2)
+    return (n_rec, n_bytes) == (gold['records'], gold['text_bytes']) and \
+        got == gold['digests']
+
+
 def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
-                static_kw=None, digest=False):
+                static_kw=None, digest=False, check=False):
     """BASELINE configs[4] on one GPU's share (8 samples x 20 M reads): both
     `woltka classify` calls of the stratified recipe, each inside one clock
     from file paths to written tables (+ gz read maps in pass 1)."""
@@ -774,6 +797,9 @@ def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
                                  for k, v in sorted(parts.items())}}
     if dig is not None:
         res['digests'] = dig
+    if check:
+        res['equals_reference_at_fixture_size'] = twopass_fixture_check(
+            device, workdir)
     return res
 
 
@@ -1312,12 +1338,27 @@ def side_blocks(a, line, wl, ctx, dev):
             del prob
         except Exception as e:
             configs[key] = {'error': repr(e)}
+    if not a.no_e2e and a.workload == 'lca':
+        # BASELINE configs[4] on one GPU's share: 8 samples x 20 M reads, both
+        # calls of the stratified recipe (memory permitting: ~45 GB of text
+        # and maps at full size)
+        try:
+            frac = e2e_scale_for(1, a.e2e_frac, per_rank_bytes=45e9,
+                                 workdir=a.tmp)
+            e2e['twopass'] = e2e_twopass(
+                dev, 8, max(10_000, int(20_000_000 * frac * a.scale)),
+                workdir=a.tmp, reps=2, check=True)
+        except Exception as e:
+            e2e['twopass'] = {'error': repr(e)}
     line['configs'] = configs
     if e2e:
         line['e2e'] = e2e
         # the north star's end-to-end figures: whole `woltka classify` calls
         line['e2e_value'] = e2e.get('lca', {}).get('value')
         line['e2e_ordinal_value'] = e2e.get('ordinal', {}).get('value')
+        tp = e2e.get('twopass', {})
+        line['e2e_twopass_values'] = [tp.get('pass1', {}).get('value'),
+                                      tp.get('pass2', {}).get('value')]
     return line
 
 

@@ -37,3 +37,19 @@ def test_two_pass_recipe_equals_the_reference(tmp_path):
     assert got['table1'] == gold['digests']['table1']
     assert got['maps'] == gold['digests']['maps']
     assert got['table2'] == gold['digests']['table2']
+
+
+def test_bench_leg_takes_the_device_routes(tmp_path):
+    """bench.e2e_twopass at a small size: the in-bench fixture check agrees
+    with the reference's digests, and both passes ran on the device routes
+    (text tokenised, read maps formatted, strata joined there) — no block fell
+    back to the host tokenizer."""
+    import bench
+    from woltka_amd import classify
+    classify.ROUTES.clear()
+    res = bench.e2e_twopass(0, 2, 300_000, workdir=str(tmp_path), check=True)
+    assert res['equals_reference_at_fixture_size'] is True
+    assert res['pass1']['value'] > 0 and res['pass2']['value'] > 0
+    r = classify.ROUTES
+    assert r['dtok_maps'] > 0 and r['dhits_strata'] > 0 and r['dstrata'] >= 2
+    assert r['host_block'] == 0, dict(r)

@@ -25,6 +25,12 @@ from .file import openzip, write_readmap
 from .hierarchy import FeatureIndex, flatten_hierarchy
 from .ordinal import pack_hits
 
+# blocks / samples per route since the process started (diagnostics: which of
+# the routes below a run took; tests assert on them)
+from collections import Counter
+ROUTES = Counter()
+
+
 def cpu_budget():
     """CPUs this process may use: the hardware threads of its affinity mask,
     or — when the container's CPU bandwidth is capped (cgroup cpu.max /
@@ -638,6 +644,7 @@ class Engine:
             raise ValueError('No stratification information is found in file: '
                              f'{basename(fp)}.')
         labels = [x.decode() for x in labels]
+        ROUTES['dstrata'] += 1
         self._dstrata = {'fp': fp, 'zippers': zippers, 'labels': labels,
                          'slots': slots, 'key': None, 'host': None}
         return labels
@@ -1533,6 +1540,7 @@ class Engine:
         """One block of the device route through the host tokenizer after
         all (the general arrays; ``names``: with the descriptors of the query
         names, for the read maps)."""
+        ROUTES['host_block'] += 1
         tok = self.tok
         tok.set_header_state(hdr_in)
         if ordinal:
@@ -1594,6 +1602,7 @@ class Engine:
         status, n_reads, _ = self.ctx.dtok_stage_hits(self._tok_genome,
                                                       self._th)
         if status == 0:
+            ROUTES['dhits_strata' if ds is not None else 'dhits'] += 1
             self._n_reads += n_reads
             if n_reads:
                 if ds is None:
@@ -1642,6 +1651,7 @@ class Engine:
             t3 = time.perf_counter()
             lap['emit'] = lap.get('emit', 0.0) + t3 - t2
             if status == 0:
+                ROUTES['dtok_maps' if dmaps is not None else 'dtok'] += 1
                 self._n_reads += n_reads
                 if dmaps is not None and n_reads:
                     self._device_maps(sample, *dmaps)
