@@ -846,8 +846,66 @@ class Phases:
             setattr(owner, name, orig)
 
 
+def kernel_cells(wl):
+    """One pass of the kernel path over the workload's resident records ->
+    {table name: {feature name: exact value in units of 1 / L}}: what the
+    end-to-end leg's tables are compared with (`tables_vs_kernel_path`)."""
+    ctx = wl.ctx
+    ctx.counts_clear()
+    wl.step()
+    keys, vals = nat.canonical_counts(*ctx.counts_fetch())
+    ctx.counts_clear()
+    job, k, grp, feat = nat.decode_keys(keys)
+    out = {}
+    if wl.key == 'ordinal':
+        out['out.tsv'] = ('g%d', feat, vals.astype(np.int64))
+    else:
+        for j, rank in enumerate(wl.ranks):
+            m = job == j
+            out[f'{rank}.tsv'] = ('T%07d', feat[m], vals[m].astype(np.int64))
+    return out
+
+
+def tables_vs_kernel_path(tables, cells):
+    """Every cell of the written TSV tables against the kernel path's exact
+    counts of the same problem, rounded like util.round_dict: cells whose exact
+    value is not a half must be equal (a value of exactly m + 1/2 follows the
+    reference's float sum in the product — certify.py — and may land on either
+    side)."""
+    L = nat.WEIGHT_L
+    res = {'cells': 0, 'equal': 0, 'halves': 0, 'missing': 0}
+    for fp in tables:
+        fmt, feat, units = cells[os.path.basename(fp)]
+        want = {}
+        q, r = np.divmod(units, L)
+        up = 2 * r > L
+        half = 2 * r == L
+        val = q + up
+        for f, v, h in zip(feat.tolist(), val.tolist(), half.tolist()):
+            want[fmt % f] = (v, h)
+        got = {}
+        with open(fp) as fh:
+            next(fh)
+            for line in fh:
+                name, _, v = line.rstrip('\n').partition('\t')
+                got[name] = int(v)
+        for name, (v, h) in want.items():
+            if h:
+                res['halves'] += 1
+                ok = got.get(name, 0) in (v, v + 1)
+            elif v == 0:
+                ok = name not in got
+            else:
+                ok = got.get(name) == v
+            res['cells'] += 1
+            res['equal'] += bool(ok)
+        res['missing'] += len(set(got) - set(want))
+    res['ok'] = res['equal'] == res['cells'] and res['missing'] == 0
+    return res
+
+
 def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
-            sync=None):
+            sync=None, cells=None):
     """The whole `woltka classify` call — `workflow.workflow` from file paths
     (SAM text in the page cache, nodes.dmp / gene coordinates) to the written
     TSV tables — inside one clock: hierarchy / coordinate files read, device
@@ -911,8 +969,10 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
         dt, parts = best
         tables = [os.path.join(out, x) for x in sorted(os.listdir(out))] \
             if os.path.isdir(out) else [out]
-        cells = sum(sum(1 for ln in open(fp) if not ln.startswith('#'))
-                    for fp in tables)
+        rows = sum(sum(1 for ln in open(fp) if not ln.startswith('#'))
+                   for fp in tables)
+        same = tables_vs_kernel_path(tables, cells) \
+            if cells is not None and frac == 1.0 else None
     stream = dt - sum(parts.values())
     what = {'lca': '2M-node nodes.dmp, --rank phylum,genus,species, three '
                    'TSV tables',
@@ -924,7 +984,8 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
             'phases_s': {k: round(v, 3) for k, v in sorted(parts.items())},
             'streaming_s': round(stream, 3),
             'value_streaming': round(n_rec / max(stream, 1e-9), 1),
-            'text_generated_s': round(t_gen, 1), 'table_rows': cells,
+            'text_generated_s': round(t_gen, 1), 'table_rows': rows,
+            'tables_vs_kernel_path': same,
             'tokenizer_threads': __import__(
                 'woltka_amd.classify', fromlist=['x']).tokenizer_threads(),
             'what': (f'workflow.workflow (= `woltka classify`) from file paths '
@@ -1300,7 +1361,7 @@ def side_blocks(a, line, wl, ctx, dev):
             try:
                 e2e['lca'] = e2e_leg('lca', wl.prob, wl.reads, dev,
                                      frac=e2e_scale_for(1, a.e2e_frac, workdir=a.tmp),
-                                     workdir=a.tmp)
+                                     workdir=a.tmp, cells=kernel_cells(wl))
             except Exception as e:
                 e2e['lca'] = {'error': repr(e)}
     if not a.no_cpu:
@@ -1324,6 +1385,8 @@ def side_blocks(a, line, wl, ctx, dev):
             if key == 'ordinal' and not a.no_cpu:
                 configs[key]['cpu_baseline'] = cpu_baseline(w2, 8.0)
             prob, reads = (w2.prob, w2.reads) if key == 'ordinal' else (None, 0)
+            cells2 = kernel_cells(w2) if key == 'ordinal' and not a.no_e2e \
+                else None
             w2.close()
             c2.close()
             del w2
@@ -1332,7 +1395,7 @@ def side_blocks(a, line, wl, ctx, dev):
                     e2e['ordinal'] = e2e_leg(
                         'ordinal', prob, reads, dev,
                         frac=e2e_scale_for(1, a.e2e_frac, workdir=a.tmp),
-                        workdir=a.tmp)
+                        workdir=a.tmp, cells=cells2)
                 except Exception as e:
                     e2e['ordinal'] = {'error': repr(e)}
             del prob

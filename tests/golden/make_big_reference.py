@@ -9,6 +9,8 @@ the digests of the reference's tables are committed
 text on the device and compares the table bytes.
 
     python tests/golden/make_big_reference.py [scale]      # ~10-15 min, ~6 GB RAM
+    python tests/golden/make_big_reference.py free [scale]     # --rank free, ~10 M records
+    python tests/golden/make_big_reference.py coords [pairs]   # --coords, ~10.7 M records
 
 This is the full-size check of what certify.py certifies: phylum-level cells
 here sum millions of binary64 addends in the reference.
@@ -50,6 +52,28 @@ def build_input(tmp, scale):
     return sam, nodes, n_rec
 
 
+def build_free_input(tmp, scale):
+    """Config 3 at `scale` for the `--rank free` run (2 M reads, ~10 M
+    records at 0.04): (sam, nodes, records)."""
+    return build_input(tmp, scale)
+
+
+def build_coords_input(tmp, n_pairs):
+    """Config 4 with `n_pairs` read pairs: (alignment dir, coords path,
+    records) — shared with tests/test_gpu_big.py."""
+    import bench
+    from woltka_amd import synth
+    rng = np.random.default_rng(1004)
+    prob = synth.ordinal_problem(rng, n_pairs=n_pairs)
+    indir = os.path.join(tmp, 'aln')
+    os.makedirs(indir, exist_ok=True)
+    _, coords, n_rec, _ = bench.write_ordinal_inputs(indir, prob,
+                                                     prob['n_reads'])
+    dst = os.path.join(tmp, 'coords.txt')
+    os.replace(coords, dst)
+    return indir, dst, n_rec
+
+
 def digests(outdir):
     out = {}
     for fn in sorted(os.listdir(outdir)):
@@ -60,7 +84,65 @@ def digests(outdir):
     return out
 
 
+def run_free(scale=0.04):
+    """`--rank free` of the real reference on ~10 M records (tree.find_lca
+    over every multi-hit read)."""
+    from woltka.workflow import workflow
+    with tempfile.TemporaryDirectory() as tmp:
+        sam, nodes, n_rec = build_free_input(tmp, scale)
+        out = os.path.join(tmp, 'free.tsv')
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            workflow(input_fp=sam, output_fp=out, input_fmt='sam',
+                     nodes_fps=[nodes], ranks='free', output_fmt=False)
+        dt = time.time() - t0
+        with open(out, 'rb') as f:
+            blob = f.read()
+    res = {'seed': SEED, 'scale': scale, 'records': n_rec, 'ranks': 'free',
+           'reference_seconds': round(dt, 1),
+           'table': {'sha256': hashlib.sha256(blob).hexdigest(),
+                     'bytes': len(blob), 'rows': blob.count(b'\n') - 1}}
+    with open(os.path.join(HERE, 'vectors', 'ref_big_free.json'), 'w') as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+        f.write('\n')
+    print(json.dumps(res))
+
+
+def run_coords(n_pairs=5_000_000):
+    """`--coords` (ordinal.match_read_gene, no JIT) of the real reference on
+    config 4 with 5 M read pairs (~10.7 M records)."""
+    from woltka.workflow import workflow
+    with tempfile.TemporaryDirectory() as tmp:
+        indir, coords, n_rec = build_coords_input(tmp, n_pairs)
+        out = os.path.join(tmp, 'genes.tsv')
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            workflow(input_fp=indir, output_fp=out, input_fmt='sam',
+                     coords_fp=coords, overlap=80, output_fmt=False)
+        dt = time.time() - t0
+        with open(out, 'rb') as f:
+            blob = f.read()
+    res = {'seed': 1004, 'pairs': n_pairs, 'records': n_rec,
+           'reference_seconds': round(dt, 1),
+           'table': {'sha256': hashlib.sha256(blob).hexdigest(),
+                     'bytes': len(blob), 'rows': blob.count(b'\n') - 1}}
+    with open(os.path.join(HERE, 'vectors', 'ref_big_coords.json'), 'w') as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+        f.write('\n')
+    print(json.dumps(res))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] in ('free', 'coords'):
+        if not _refshim.install():
+            print('reference tree not present: nothing to do')
+            return
+        arg = sys.argv[2:3]
+        if sys.argv[1] == 'free':
+            run_free(*(float(x) for x in arg))
+        else:
+            run_coords(*(int(x) for x in arg))
+        return
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
     if not _refshim.install():
         print('reference tree not present: nothing to do')

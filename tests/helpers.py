@@ -135,3 +135,26 @@ class PackedCase:
         self.group = np.array(
             [gid[case['strata'][q]] if q in case['strata'] else -1
              for q in case['queries']], dtype=np.int32)
+
+
+def oracle_table(subj, qoff, specs, hier, group=None):
+    """(keys, counts) of the C oracle (oracle/oracle.c: classify.assign_* +
+    classify.counter restated) for jobs ``specs`` = [(mode, rank code, flags,
+    major fraction)] over feature-id records — one job at a time, so that the
+    contribution buffers stay small at 50 M reads."""
+    import c_oracle
+    keys, cnts = [], []
+    g = None if group is None else np.full(len(qoff) - 1, group, np.int32) \
+        if np.isscalar(group) else group
+    for j, (mode, code, flags, major) in enumerate(specs):
+        _, contrib = c_oracle.classify(
+            subj, qoff, [dict(mode=mode, rank_code=code, flags=flags,
+                              major=major)],
+            hier.parent, hier.rank_code, 0, g)
+        k, n = np.unique(contrib, return_counts=True)
+        del contrib
+        # (the oracle numbered its only job 0)
+        k = k | (np.uint64(j) << np.uint64(61))
+        keys.append(k)
+        cnts.append(n)
+    return np.concatenate(keys), np.concatenate(cnts)

@@ -69,6 +69,17 @@ def test_one_launch_over_250M_records():
         assert int(vals.max()) > 1 << 32        # (units of 1 / L: bins wrapped)
         st = c.stats()
         assert st['n_reads'] == n_reads and st['n_records'] == words.size
+        # the whole table against the C oracle (classify.assign_rank +
+        # classify.counter restated, classify.py:81-127, 144-171)
+        from helpers import assert_same_counts, oracle_table
+        # (one rank: the oracle lists a contribution per record, 250 M of them)
+        okeys, ocnt = oracle_table(
+            p['subj'], qoff, [(nat.MODE_RANK, h.rank_codes['genus'], 0, 0.0)],
+            h, group=0)
+        okeys |= np.uint64(1) << np.uint64(61)      # (job 1 of the launch)
+        one = job == 1
+        assert_same_counts(keys[one], vals[one], okeys, ocnt)
+        del okeys, ocnt
         # the first 1/16 both ways
         m = n_reads // 16
         e = int(qoff[m])
@@ -122,9 +133,13 @@ def test_per_read_stream_over_250M_records():
     per-read stream (csrc/wk_free.hpp) at the size `bench.py` times it: one
     launch over 250 M packed records.  At that size: a read adds L units or
     nothing (all of them with 'Unassigned' on), `--above` assigns at least the
-    reads `--major` assigns, which assigns at least those `--uniq` assigns; and
-    the first 1/8 of the reads give the same table through the general
-    evaluator (wk_chunk_stage + wk_classify_staged)."""
+    reads `--major` assigns, which assigns at least those `--uniq` assigns; the
+    first 1/8 of the reads give the same table through the general evaluator
+    (wk_chunk_stage + wk_classify_staged); and the WHOLE table of every mode
+    equals the C oracle's (oracle/oracle.c: classify.assign_free /
+    assign_rank / majority + classify.counter restated; classify.py:54-127,
+    144-171, 300-317) over all 50 M reads."""
+    from helpers import assert_same_counts, oracle_table
     rng = np.random.default_rng(1003)
     p = synth.as_sets(synth.lca_problem(rng, n_nodes=2_000_000,
                                         n_subjects=100_000,
@@ -168,6 +183,11 @@ def test_per_read_stream_over_250M_records():
             st = c.stats()
             assert st['n_reads'] == n_reads and st['n_records'] == words.size
             assert np.all(vals % L == 0)
+            code = h.rank_codes['genus'] if job.mode == nat.MODE_RANK else 0
+            okeys, ocnt = oracle_table(
+                p['subj'], qoff, [(job.mode, code, job.flags, job.major)], h,
+                group=0)
+            assert_same_counts(keys, vals, okeys, ocnt, name)
             assigned[name] = int(vals.astype(object).sum()) // L
             # the first 1/8 both ways
             c.counts_clear()

@@ -132,6 +132,13 @@ def test_words_api_conservation_and_wraps(ctx):
         assert c.words_pending() == (words.size, off.size - 1)
         k1, v1 = nat.canonical_counts(*c.counts_fetch())
         assert c.words_pending() == (0, 0)
+        # ... which is the C oracle's table (classify.py:32-51, 81-127, 144-171)
+        from helpers import assert_same_counts, oracle_table
+        assert_same_counts(k1, v1, *oracle_table(
+            p['subj'], p['qoff'],
+            [(nat.MODE_NONE, 0, 0, 0.0),
+             (nat.MODE_RANK, h.rank_codes['genus'], 0, 0.0),
+             (nat.MODE_RANK, h.rank_codes['phylum'], 0, 0.0)], h, group=3))
         job, k, grp, feat = nat.decode_keys(k1)
         assert (grp == 3).all()
         for j in range(3):      # every read adds L in total to every job
@@ -300,6 +307,12 @@ def test_rank_option_stream_is_taken(ctx):
                 b = nat.canonical_counts(*c.counts_fetch())
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
                 assert a[0].size > 3
+                # ... and against the C oracle directly (classify.py:81-127, 300-317)
+                from helpers import assert_same_counts, oracle_table
+                assert_same_counts(*a, *oracle_table(
+                    p['subj'], p['qoff'],
+                    [(nat.MODE_RANK, h.rank_codes[rank], flags, major)], h,
+                    group=2), (rank, flags, major))
 
 
 def test_several_stream_jobs_are_taken(ctx):
@@ -349,6 +362,12 @@ def test_several_stream_jobs_are_taken(ctx):
             b = nat.canonical_counts(*c.counts_fetch())
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
             assert np.unique(nat.decode_keys(a[0])[0]).size == len(jobs)
+            from helpers import assert_same_counts, oracle_table
+            codes = [h.rank_codes[r] for r in ('phylum', 'genus', 'species')]
+            assert_same_counts(*a, *oracle_table(
+                p['subj'], p['qoff'],
+                [(j.mode, codes[j.rank_slot] if j.mode == nat.MODE_RANK else 0,
+                  j.flags, j.major) for j in jobs], h, group=4))
 
 
 def test_free_rank_stream_is_taken(ctx):
@@ -389,3 +408,8 @@ def test_free_rank_stream_is_taken(ctx):
             b = nat.canonical_counts(*c.counts_fetch())
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
             assert a[0].size > 500
+            # ... and against the C oracle directly (classify.py:54-78, tree.py:513-566)
+            from helpers import assert_same_counts, oracle_table
+            assert_same_counts(*a, *oracle_table(
+                p['subj'], p['qoff'], [(nat.MODE_FREE, 0, flags, 0.0)], h,
+                group=2))
