@@ -52,20 +52,24 @@ PROFILES = os.path.join(ROOT, 'profiles')
 
 
 def measured_traffic(workload, scale):
-    """HBM bytes per launch of the dominant kernel from the committed
-    rocprofv3 PMC pass (FETCH_SIZE / WRITE_SIZE collected in separate passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); written
-    by tools/prof_bench.sh for the same command.  None when absent or measured
-    at another scale."""
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC pass
+    committed under profiles/ (FETCH_SIZE / WRITE_SIZE collected in separate
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
+    written by tools/prof_bench.sh for the same bench command — a PMC pass
+    cannot run inside the timed process).  Returns (bytes or None, provenance):
+    the file, the library build it was measured with, and whether that is the
+    build running now."""
     fp = os.path.join(PROFILES, f'traffic_{workload}.json')
     try:
         with open(fp) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
     if abs(t.get('scale', 1.0) - scale) > 1e-9:
-        return None
-    return t.get('hbm_bytes_per_launch')
+        return None, None
+    src = {'file': os.path.relpath(fp, ROOT), 'build_id': t.get('build_id'),
+           'same_build': t.get('build_id') == nat.build_id()}
+    return t.get('hbm_bytes_per_launch'), src
 
 
 # --------------------------------------------------------------------------
@@ -470,8 +474,22 @@ class OrdinalWorkload:
         return n, time.perf_counter() - t0
 
 
+def _option_workload(option):
+    """`--workload lca_above` etc. on their own (tools/prof_bench.sh): the
+    config-3 problem staged once, then the option's job over it."""
+    def make(ctx, seed, scale=1.0):
+        base = LcaWorkload(ctx, seed, scale)
+        wl = LcaOptionWorkload(ctx, option, base)
+        wl.seed = seed
+        return wl
+    return make
+
+
 WORKLOADS = {'flat': FlatWorkload, 'lca': LcaWorkload,
-             'lca_free': LcaFreeWorkload, 'ordinal': OrdinalWorkload}
+             'lca_free': LcaFreeWorkload, 'ordinal': OrdinalWorkload,
+             'lca_above': _option_workload('above'),
+             'lca_major': _option_workload('major'),
+             'lca_uniq': _option_workload('uniq')}
 
 
 # --------------------------------------------------------------------------
@@ -777,6 +795,13 @@ def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
                     ph.close()
                 if key not in best or dt < best[key][0]:
                     best[key] = (dt, dict(ph.t))
+        cold = {}
+        try:
+            shutil.rmtree(kw1['outmap_dir'], ignore_errors=True)
+            cold['pass1'] = cold_process_s(kw1, device)
+            cold['pass2'] = cold_process_s(kw2, device)
+        except Exception as e:
+            cold['error'] = repr(e)
         map_bytes = sum(os.path.getsize(os.path.join(kw1['outmap_dir'], x))
                         for x in os.listdir(kw1['outmap_dir']))
         dig = twopass_digests(tmp, kw1, kw2) if digest else None
@@ -793,6 +818,9 @@ def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
     for key in ('pass1', 'pass2'):
         dt, parts = best[key]
         res[key] = {'value': round(n_rec / dt, 1), 'seconds': round(dt, 3),
+                    'cold_process_s': cold.get(key, cold.get('error')),
+                    'value_cold_process': round(n_rec / cold[key], 1)
+                    if isinstance(cold.get(key), float) else None,
                     'phases_s': {k: round(v, 3)
                                  for k, v in sorted(parts.items())}}
     if dig is not None:
@@ -801,6 +829,41 @@ def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
         res['equals_reference_at_fixture_size'] = twopass_fixture_check(
             device, workdir)
     return res
+
+
+def cold_process_s(kw, device=0):
+    """Wall time of the same call as a process of its own — `python -m
+    woltka_amd.cli classify ...`, what a user types: interpreter start-up,
+    imports, hipInit, code-object load and the first touch of everything
+    included.  The inputs are in the page cache (the warm runs read them)."""
+    import subprocess
+    flag = {'input_fp': '--input', 'output_fp': '--output', 'input_fmt':
+            '--format', 'ranks': '--rank', 'coords_fp': '--coords', 'overlap':
+            '--overlap', 'strata_dir': '--stratify', 'outmap_dir': '--outmap'}
+    many = {'nodes_fps': '--nodes', 'map_fps': '--map'}
+    cmd = [sys.executable, '-m', 'woltka_amd.cli', 'classify', '--device',
+           str(device)]
+    for k, v in kw.items():
+        if k in flag:
+            cmd += [flag[k], str(v)]
+        elif k in many:
+            for x in v:
+                cmd += [many[k], x]
+        elif k == 'output_fmt' and v is False:
+            cmd.append('--to-tsv')
+        elif k == 'map_rank' and v is None:
+            pass
+        else:
+            raise KeyError(k)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep +
+               os.environ.get('PYTHONPATH', ''))
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.PIPE, text=True)
+    dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise RuntimeError('cold run failed: ' + p.stderr[-500:])
+    return round(dt, 3)
 
 
 def quiet(fn, *a, **k):
@@ -967,6 +1030,17 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
         finally:
             ph.close()
         dt, parts = best
+        cold = None
+        if sync is None:
+            try:
+                import shutil
+                if os.path.isdir(out):
+                    shutil.rmtree(out)
+                cold = cold_process_s(dict(input_fp=indir, output_fp=out,
+                                           input_fmt='sam', output_fmt=False,
+                                           **kw), device)
+            except Exception as e:
+                cold = repr(e)
         tables = [os.path.join(out, x) for x in sorted(os.listdir(out))] \
             if os.path.isdir(out) else [out]
         rows = sum(sum(1 for ln in open(fp) if not ln.startswith('#'))
@@ -981,6 +1055,9 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
     return {'value': round(n_rec / dt, 1), 'unit': 'records/s',
             'records': n_rec, 'reads': n_reads, 'frac_of_config': frac,
             'text_bytes': n_bytes, 'seconds': round(dt, 3),
+            'cold_process_s': cold,
+            'value_cold_process': round(n_rec / cold, 1)
+            if isinstance(cold, float) else None,
             'phases_s': {k: round(v, 3) for k, v in sorted(parts.items())},
             'streaming_s': round(stream, 3),
             'value_streaming': round(n_rec / max(stream, 1e-9), 1),
@@ -1224,22 +1301,44 @@ def config_block(wl, seconds, passes, steps, scale, key):
         alg = wl.launch_bytes
     achieved = alg / (kern_ms * 1e-3) / 1e9
     ms_pass = seconds * 1e3 / (steps * passes)
-    extra = {}
-    return {**extra, 'workload': wl.name, 'records': wl.records, 'reads': wl.reads,
-            'ms_per_pass': round(ms_pass, 4),
-            'value': round(wl.records / (ms_pass * 1e-3), 1),
-            'timed_region_s': round(seconds, 3),
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1),
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': measured_traffic(key, scale),
-                         'kernel': dominant,
-                         'kernel_symbol': getattr(wl, 'symbols', {}).get(
-                             dominant, f'wk::{dominant}_kernel'),
-                         'kernel_ms': round(kern_ms, 4),
-                         'algorithmic_bytes': alg,
-                         'kernels_ms': {f: round(v, 4)
-                                        for f, v in means.items()}}}
+    traffic, source = measured_traffic(key, scale)
+    # the whole step: every kernel of a pass against the configuration's
+    # algorithmic bytes — for a pass of several kernels this, not
+    # the dominant kernel's figure, is what the records/s follow
+    step_gbs = wl.alg_bytes / (ms_pass * 1e-3) / 1e9
+    overlapped = getattr(wl, 'n_chunks', 1)
+    block = {'workload': wl.name, 'records': wl.records, 'reads': wl.reads,
+             'ms_per_pass': round(ms_pass, 4),
+             'value': round(wl.records / (ms_pass * 1e-3), 1),
+             'timed_region_s': round(seconds, 3),
+             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1),
+                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                          'frac': round(achieved / HBM_PEAK_GBS, 4),
+                          'traffic': traffic, 'traffic_source': source,
+                          'kernel': dominant,
+                          'kernel_symbol': getattr(wl, 'symbols', {}).get(
+                              dominant, f'wk::{dominant}_kernel'),
+                          'kernel_ms': round(kern_ms, 4),
+                          'algorithmic_bytes': alg,
+                          'kernels_ms': {f: round(v, 4)
+                                         for f, v in means.items()},
+                          # the brackets are a chain of events over one pass:
+                          # their sum is the pass as the stream saw it
+                          'kernels_ms_sum': round(sum(means.values()), 4),
+                          'sum_over_ms_per_pass': round(
+                              sum(means.values()) * overlapped / ms_pass, 3)},
+             'roofline_step': {'bound': 'hbm',
+                               'algorithmic_bytes': wl.alg_bytes,
+                               'achieved': round(step_gbs, 1),
+                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': round(step_gbs / HBM_PEAK_GBS, 4)}}
+    if overlapped > 1:
+        block['roofline']['note'] = (
+            f'{overlapped} chunks on {overlapped} streams overlap in the timed '
+            'passes; the kernel brackets are those of one chunk launched '
+            'alone, rocprofv3 averages those of overlapping kernels: use '
+            'roofline_step')
+    return block
 
 
 def passes_for(wl, steps, target_s=1.25):
@@ -1337,6 +1436,10 @@ def side_blocks(a, line, wl, ctx, dev):
     """N = 1: the other configurations, the end-to-end legs and the CPU
     baseline, added to the headline's JSON line."""
     configs, e2e = {}, {}
+    # (one pass of the headline's kernel path, fetched: what the end-to-end
+    # leg's tables are compared with — before the blocks below stage other
+    # jobs over the same context)
+    cells = kernel_cells(wl) if a.workload == 'lca' and not a.no_e2e else None
     if a.workload == 'lca':
         try:
             free = LcaFreeWorkload(ctx, 0, a.scale, share=wl)
@@ -1361,7 +1464,7 @@ def side_blocks(a, line, wl, ctx, dev):
             try:
                 e2e['lca'] = e2e_leg('lca', wl.prob, wl.reads, dev,
                                      frac=e2e_scale_for(1, a.e2e_frac, workdir=a.tmp),
-                                     workdir=a.tmp, cells=kernel_cells(wl))
+                                     workdir=a.tmp, cells=cells)
             except Exception as e:
                 e2e['lca'] = {'error': repr(e)}
     if not a.no_cpu:

@@ -3,11 +3,11 @@
 # workload; results under gpurun_out/<tag>_<workload>/
 #   tools/prof_all.sh <tag> [workloads...]
 tag=${1:-r03prof}; shift
-wls=${*:-"lca lca_free ordinal flat"}
+wls=${*:-"lca lca_free lca_above lca_major lca_uniq ordinal flat"}
 for wl in $wls; do
   case $wl in
     lca) kern=weigh_bins ;;
-    lca_free) kern=free_stream ;;
+    lca_free|lca_above|lca_major|lca_uniq) kern=free_stream ;;
     ordinal) kern=match_hits ;;
     flat) kern=count_subjects ;;
   esac

@@ -65,8 +65,14 @@ struct DevBuf {
     }
 };
 
+// Kernel timing (wk_profile_kernels): the timed launches of one API call form a
+// chain of events — one at the call's start, one behind every timed family — and
+// a family's time runs from the event before it to its own.  The brackets of a
+// call therefore add up to the call's time on the stream (a pair of events of
+// its own around every small kernel read 30 us for 10 us kernels).
 struct KernelTimer {
-    hipEvent_t a = nullptr, b = nullptr;
+    hipEvent_t b = nullptr;     // behind the family's launches
+    hipEvent_t from = nullptr;  // the chain's event before them (not owned)
     bool valid = false;
 };
 
@@ -159,6 +165,9 @@ struct wk_ctx {
     bool timer_closed = false;
     bool profile = false;
     std::map<std::string, KernelTimer> ktimers;
+    hipEvent_t kt_step = nullptr;   // recorded where a timed API call starts
+    hipEvent_t kt_tail = nullptr;   // last event of the chain
+    int kt_depth = 0;
 
     int lds_slots = 8192;  // LDS front-cache slots per workgroup (16 B each = 128 KiB)
     int threads = 1024;    // workgroup size of the direct classify kernel
@@ -290,19 +299,42 @@ constexpr int kStatBlocks = 16384;  // >= the largest classify grid (256 CUs x 3
 unsigned long long* scalar_u64(wk_ctx* c, int idx) { return c->scalars.as<unsigned long long>() + idx; }
 int* scalar_err(wk_ctx* c) { return c->scalars.as<int>(); }
 
+// start of an API call that times its kernels: a fresh head of the chain
+void ktimer_step(wk_ctx* c) {
+    if (!c->profile) return;
+    if (!c->kt_step && hipEventCreate(&c->kt_step) != hipSuccess) {
+        c->kt_step = nullptr;
+        return;
+    }
+    (void)hipEventRecord(c->kt_step, c->stream);
+    c->kt_tail = c->kt_step;
+}
+// (API calls nest — wk_ordinal_count runs wk_classify_staged —: the outermost one heads the chain)
+struct KtScope {
+    wk_ctx* c;
+    explicit KtScope(wk_ctx* ctx) : c(ctx) {
+        if (c->kt_depth++ == 0) ktimer_step(c);
+    }
+    ~KtScope() { --c->kt_depth; }
+};
 KernelTimer* ktimer_begin(wk_ctx* c, const char* family) {
     if (!c->profile) return nullptr;
+    if (!c->kt_tail) ktimer_step(c);
+    if (!c->kt_tail) return nullptr;
     KernelTimer& t = c->ktimers[family];
-    if (!t.a) {
-        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return nullptr;
+    if (!t.b && hipEventCreate(&t.b) != hipSuccess) {
+        t.b = nullptr;
+        return nullptr;
     }
     t.valid = false;
-    (void)hipEventRecord(t.a, c->stream);
+    // (a family launched twice in a call: its second bracket would start at its own event, which is about to be recorded again)
+    t.from = c->kt_tail == t.b ? c->kt_step : c->kt_tail;
     return &t;
 }
 void ktimer_end(wk_ctx* c, KernelTimer* t) {
     if (!t) return;
     (void)hipEventRecord(t->b, c->stream);
+    c->kt_tail = t->b;
     t->valid = true;
 }
 
@@ -748,10 +780,9 @@ void wk_destroy(wk_ctx* c) {
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (DevBuf& b : c->rank_tab) b.release();
-    for (auto& kv : c->ktimers) {
-        if (kv.second.a) (void)hipEventDestroy(kv.second.a);
+    for (auto& kv : c->ktimers)
         if (kv.second.b) (void)hipEventDestroy(kv.second.b);
-    }
+    if (c->kt_step) (void)hipEventDestroy(c->kt_step);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1212,6 +1243,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
     if (!c->chunk_valid) return fail(c, WK_E_STATE, "no chunk staged");
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
 
     ClassifyArgs a{};
     a.subj = c->cur_subj;
@@ -1769,6 +1801,7 @@ int wk_words_flush(wk_ctx* c) {
     }
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     if (c->w_mode != 0) {
         // ---- free-rank jobs and rank jobs that look at whole reads: per job, the stream over node ids, then its dense
         // counters into the count table.  One job: the records hold its node ids since they were appended; several:
@@ -2189,6 +2222,7 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     const int64_t n64 = stop - begin;
     if (n64 >= (1ll << 31) - 64) return WK_OK;
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     const uint32_t n = (uint32_t)n64;
     c->dt_n = n;
     c->dt_lines = 0;
@@ -2307,6 +2341,7 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
         return WK_OK;
     }
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     int rc = words_roll(c, c->dt_lines);
     if (rc) return rc;
     if ((rc = words_room(c, c->dt_lines))) return rc;
@@ -2394,6 +2429,7 @@ int wk_strata_load(wk_ctx* c, const char* text, int64_t n64, int64_t* n_pairs, i
     c->s_ready = c->s_use = false;
     if (n64 >= (1ll << 32) - 64) return WK_OK;  // (offsets are 32 bits: the host's join takes larger maps)
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     const uint32_t n = (uint32_t)n64;
     c->s_n = n;
     c->s_n_lines = 0;
@@ -2552,6 +2588,7 @@ int wk_dtok_readmap(wk_ctx* c, int32_t job, int64_t* n_bytes) {
     const uint32_t n_reads = c->dt_emit_reads;
     if (n_reads == 0 || c->dt_lines == 0) return WK_OK;
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     HIP_TRY(c, c->rm_line.reserve((size_t)n_reads * 4));
     HIP_TRY(c, c->rm_len.reserve((size_t)n_reads * 8));
     DtokArgs a = dtok_args(c);
@@ -2614,6 +2651,7 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
     if (!(th > 0.0)) return fail(c, WK_E_ARG, "overlap threshold must be positive");
     c->dt_ready = false;
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     const uint32_t lines = c->dt_lines;
     int rc;
     if ((rc = upload(c, c->d_gmap, genome_of_subject, (size_t)std::max(n_subjects, 1) * 4))) return rc;
@@ -2812,6 +2850,7 @@ int wk_ordinal_match(wk_ctx* c) {
     if (!c->ord_valid) return fail(c, WK_E_STATE, "no ordinal chunk staged");
     if (!c->genes_set) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     int rc = reserve_match_buffers(c);
     if (rc) return rc;
     if (c->n_hits > 0) {
@@ -2857,6 +2896,7 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
         return wk_classify_staged(c, jobs, n_jobs, nullptr);
     }
     DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
     int rc = reserve_match_buffers(c);
     if (rc) return rc;
     // (without the per-hit counts: they are only needed for reads the tally
@@ -3030,7 +3070,7 @@ int wk_last_kernel_ms(wk_ctx* c, const char* family, double* ms) {
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipEventSynchronize(it->second.b));
     float f = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&f, it->second.a, it->second.b));
+    HIP_TRY(c, hipEventElapsedTime(&f, it->second.from, it->second.b));
     *ms = (double)f;
     return WK_OK;
 }
