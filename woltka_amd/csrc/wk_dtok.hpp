@@ -77,6 +77,7 @@ struct DtokArgs {
     DtokState* state;
     uint32_t* out;      // packed records
     uint32_t out_cap;
+    StreamSet streams;  // (weighted histogram: the records by slice of the subject table, wk_weigh.hpp)
     // "ex" flavour (coord-match): per line POS - 1, reference end, aligned length
     int32_t* lbeg;
     int32_t* lend;
@@ -474,11 +475,10 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
         word = (uint32_t)a.lsubj[i] | ((pos & 15u) << kWordSubjBits) | ((size & 31u) << kWordSizeShift);
     }
     if (big) atomicOr(&a.state->flags, kDtokBigRead);
-    // one reservation per workgroup (a returning atomic on one word saturates
-    // near 90 per microsecond: one per wave — 24 k of them for a 64 MB block —
-    // was half of this kernel's time)
+    // one reservation per workgroup and stream (a returning atomic on one word
+    // saturates near 90 per microsecond: one per wave — 24 k of them for a 64 MB
+    // block — was half of this kernel's time)
     __shared__ uint32_t w_rec[kDtokThreads / kWave], w_reads[kDtokThreads / kWave];
-    __shared__ unsigned long long block_base;
     const uint32_t wave = threadIdx.x / kWave;
     const unsigned long long mask = __ballot(rec);
     const unsigned long long reads = __ballot(rec && pos == 0u);
@@ -490,18 +490,13 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
     if (threadIdx.x == 0) {
         uint32_t n = 0, r = 0;
         for (uint32_t w = 0; w < kDtokThreads / kWave; ++w) {
-            const uint32_t c = w_rec[w];
-            w_rec[w] = n;  // (exclusive prefix: the wave's place in the workgroup's range)
-            n += c;
+            n += w_rec[w];
             r += w_reads[w];
         }
-        block_base = n ? atomicAdd(&a.state->n_out, (unsigned long long)n) : 0ull;
+        if (n) atomicAdd(&a.state->n_out, (unsigned long long)n);
         if (r) atomicAdd(&a.state->n_reads, (unsigned long long)r);
     }
-    __syncthreads();
-    if (!rec) return;
-    const unsigned long long at = block_base + w_rec[wave] + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-    if (at < a.out_cap) a.out[at] = word;
+    scatter_by_slice<kDtokThreads>(a.streams, rec, word);
 }
 
 // Plain flavour, ordered emission: the records of a read contiguous and in

@@ -169,6 +169,79 @@ struct BinsArgs {
 constexpr uint32_t kBinsTile = kWeighThreads * 4;  // records per workgroup and round
 constexpr uint32_t kBinsMaxLds = 160 * 1024 - 1024;
 
+// ---- records kept per slice of the subject table (round 4) -------------------------
+// A subject table beyond the LDS is cut into slices of kSliceBins subjects.  Round
+// 3's launch had a team of workgroups, one per slice, walk the same records: every
+// record crossed the memory system once per slice (1.57 GB measured for 1.0 GB of
+// records at three slices).  Now the records are kept apart from the start: whoever
+// appends them — dtok_emit_kernel on the device, words_partition_kernel behind a
+// copy from the host — writes a record to the stream of its subject's slice, and the
+// histogram reads every stream exactly once, with workgroups in proportion to the
+// streams' lengths (a Zipf sample has nine tenths of its records in slice 0).
+constexpr int kMaxStreams = 8;
+constexpr uint32_t kSliceBins = kBinsMaxLds / 4 - 96;
+
+struct StreamSet {
+    uint32_t* out[kMaxStreams];
+    unsigned long long* cursor;  // [kMaxStreams] records in each stream
+    uint32_t n_streams;
+    uint32_t cap;                // records a stream holds
+};
+
+// Every thread of the workgroup calls this: the records (`rec`, `word`) go to the
+// streams of their slices, one reservation per workgroup and slice.
+template <uint32_t kThreads>
+__device__ __forceinline__ void scatter_by_slice(const StreamSet& s, bool rec, uint32_t word) {
+    __shared__ uint32_t cnt[kThreads / kWave][kMaxStreams];
+    __shared__ unsigned long long base[kMaxStreams];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t sl = 0;
+    if (rec) {
+        sl = (word & ((1u << 23) - 1u)) / kSliceBins;
+        if (sl >= s.n_streams) sl = s.n_streams - 1u;  // (a subject beyond the table: the histogram reports it)
+    }
+    unsigned long long mine = 0;
+    for (uint32_t k = 0; k < s.n_streams; ++k) {
+        const unsigned long long m = __ballot(rec && sl == k);
+        if (lane == 0) cnt[wave][k] = (uint32_t)__popcll(m);
+        if (sl == k) mine = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < s.n_streams) {
+        const uint32_t k = threadIdx.x;
+        uint32_t n = 0;
+        for (uint32_t w = 0; w < kThreads / kWave; ++w) {
+            const uint32_t c = cnt[w][k];
+            cnt[w][k] = n;
+            n += c;
+        }
+        base[k] = n ? atomicAdd(&s.cursor[k], (unsigned long long)n) : 0ull;
+    }
+    __syncthreads();
+    if (rec) {
+        const unsigned long long at = base[sl] + cnt[wave][sl] + (unsigned long long)__popcll(mine & ((1ull << lane) - 1ull));
+        if (at < s.cap) s.out[sl][at] = word;
+    }
+}
+
+// records copied from the host -> the streams
+__global__ void __launch_bounds__(256) words_partition_kernel(const uint32_t* __restrict__ src, uint32_t n, StreamSet s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool rec = i < n;
+    scatter_by_slice<256>(s, rec, rec ? src[i] : 0u);
+}
+
+struct StreamBinsArgs {
+    const uint32_t* words[kMaxStreams];
+    uint32_t count[kMaxStreams];
+    uint32_t wg_first[kMaxStreams + 1];  // workgroups [wg_first[k], wg_first[k + 1]) walk stream k
+    uint32_t n_streams;
+    uint32_t n_subjects;
+    uint32_t* slab;  // [workgroups][kSliceBins]
+    uint32_t* hi;    // [n_subjects]
+    int* err;
+};
+
 template <int kRing = 4, bool kPacked = false>
 __global__ void __launch_bounds__(kWeighThreads) weigh_bins_kernel(BinsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -269,6 +342,77 @@ __global__ void __launch_bounds__(kWeighThreads) weigh_bins_kernel(BinsArgs a) {
     for (uint32_t i = threadIdx.x; i < a.bins; i += kWeighThreads) row[i] = bins[i];
 }
 
+// The histogram over the streams: a workgroup owns the bins of its stream's slice
+// and a share of that stream's tiles.  Same inner loop as weigh_bins_kernel (every
+// record of the stream lies in the slice; the idle bins take the lanes past its end).
+template <int kRing = 4>
+__global__ void __launch_bounds__(kWeighThreads) weigh_streams_kernel(StreamBinsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t lut[32];
+    uint32_t* bins = reinterpret_cast<uint32_t*>(smem);
+    uint32_t k = 0;
+    while (k + 1u < a.n_streams && blockIdx.x >= a.wg_first[k + 1]) ++k;
+    const uint32_t team = blockIdx.x - a.wg_first[k], n_teams = a.wg_first[k + 1] - a.wg_first[k];
+    const uint32_t lo = k * kSliceBins;
+    const uint32_t span = min(kSliceBins, a.n_subjects - min(lo, a.n_subjects));
+    const uint32_t n_records = a.count[k];
+
+    for (uint32_t i = threadIdx.x; i < kSliceBins + 64u; i += kWeighThreads) bins[i] = 0u;
+    if (threadIdx.x < 32u)
+        lut[threadIdx.x] = (threadIdx.x >= 1u && threadIdx.x <= (uint32_t)WK_WEIGHT_MAX_K) ? weight_of(threadIdx.x) : 0u;
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.words[k]), 0, (int)(n_records << 2), 0x00020000);
+    const uint32_t n_tiles = (n_records + kBinsTile - 1u) / kBinsTile;
+    v4i32 ring[kRing];
+    auto load = [&](uint32_t tile, v4i32& x) {
+        const uint32_t i = tile * kBinsTile + threadIdx.x * 4u;
+        x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(tile < n_tiles ? i << 2 : 0xFFFFFFF0u), 0, 0);
+    };
+    const uint32_t idle_addr = kSliceBins + (threadIdx.x & 63u);
+    bool outside = false;
+    auto add = [&](const v4i32& x) {
+        uint32_t c[4] = {(uint32_t)x.x, (uint32_t)x.y, (uint32_t)x.z, (uint32_t)x.w};
+        uint32_t w[4], at[4], old[4];
+        bool in[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w[j] = lut[c[j] >> kWordSizeShift];  // (past the end: 0, weight 0)
+            c[j] &= kWordSubjMask;
+            const uint32_t idx = c[j] - lo;
+            in[j] = idx < span;
+            outside |= (w[j] != 0u) & !in[j];
+            at[j] = in[j] ? idx : idle_addr;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) old[j] = atomicAdd(&bins[at[j]], w[j]);
+        bool wrapped = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wrapped |= in[j] & (old[j] + w[j] < old[j]);
+        if (wrapped) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (in[j] & (old[j] + w[j] < old[j])) atomicAdd(&a.hi[c[j]], 1u);
+        }
+    };
+    uint32_t tile = team;
+#pragma unroll
+    for (int u = 0; u < kRing - 1; ++u) load(tile + (uint32_t)u * n_teams, ring[u]);
+    while (tile < n_tiles) {
+#pragma unroll
+        for (int u = 0; u < kRing; ++u) {
+            load(tile + (uint32_t)(kRing - 1) * n_teams, ring[(u + kRing - 1) % kRing]);
+            add(ring[u]);
+            tile += n_teams;
+        }
+    }
+    if (outside) atomicOr(a.err, kErrFeatureRange);
+    __syncthreads();
+    uint32_t* row = a.slab + (size_t)blockIdx.x * kSliceBins;
+    for (uint32_t i = threadIdx.x; i < span; i += kWeighThreads) row[i] = bins[i];
+}
+
 // W[s] of every subject (column sums over the teams of its slice + the wraps)
 // -> for every job the key (job, k = 0, group, taxon of s) += W[s]: the
 // assigners of classify.py applied once per subject.  The adds go through an
@@ -284,21 +428,43 @@ struct WeighMergeArgs {
     int32_t col[WK_MAX_JOBS];
     uint32_t group;
     CountTable table;
+    uint32_t streams;                    // > 0: the slab of weigh_streams_kernel (rows of kSliceBins, per stream wg_first)
+    uint32_t wg_first[kMaxStreams + 1];
 };
 
+// 128 subjects per workgroup, eight threads each: a thread sums every eighth row of
+// its subject's column (a column of 230 rows read by one thread was latency, not
+// bandwidth: 0.084 ms for 42 MB), the eight partial sums meet in LDS.
+constexpr uint32_t kMergeSubjects = 128, kMergeParts = 8;
 __global__ void __launch_bounds__(1024) weigh_merge_kernel(WeighMergeArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long part[kMergeParts][kMergeSubjects];
     LdsCache cache{};
     cache.base = reinterpret_cast<unsigned long long*>(smem);
     cache.bmask = lds_slots / 4 - 1;
     lds_cache_init(cache);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sub = threadIdx.x & (kMergeSubjects - 1u), g = threadIdx.x / kMergeSubjects;
+    const uint32_t i = blockIdx.x * kMergeSubjects + sub;
+    unsigned long long w = 0;
     if (i < a.n_subjects) {
-        const uint32_t slice = i / a.bins, colm = i - slice * a.bins;
-        const uint32_t* p = a.slab + (size_t)slice * a.n_teams * a.bins + colm;
-        unsigned long long w = 0;
-#pragma unroll 8
-        for (uint32_t t = 0; t < a.n_teams; ++t) w += p[(size_t)t * a.bins];
+        if (a.streams) {
+            const uint32_t k = i / kSliceBins, colm = i - k * kSliceBins;
+            const uint32_t* p = a.slab + (size_t)a.wg_first[k] * kSliceBins + colm;
+            const uint32_t rows = a.wg_first[k + 1] - a.wg_first[k];
+#pragma unroll 4
+            for (uint32_t t = g; t < rows; t += kMergeParts) w += p[(size_t)t * kSliceBins];
+        } else {
+            const uint32_t slice = i / a.bins, colm = i - slice * a.bins;
+            const uint32_t* p = a.slab + (size_t)slice * a.n_teams * a.bins + colm;
+#pragma unroll 4
+            for (uint32_t t = g; t < a.n_teams; t += kMergeParts) w += p[(size_t)t * a.bins];
+        }
+    }
+    part[g][sub] = w;
+    __syncthreads();
+    if (g == 0 && i < a.n_subjects) {
+#pragma unroll
+        for (uint32_t q = 1; q < kMergeParts; ++q) w += part[q][sub];
         const uint32_t wraps = a.hi[i];
         if (wraps) {
             w += (unsigned long long)wraps << 32;

@@ -202,7 +202,14 @@ struct wk_ctx {
     bool rows_any_invalid = false;  // some subject lacks an ancestor at a rank column of the current rows
     // packed records of the native tokenizer accumulated over the chunks of one
     // sample (wk_words_*): one launch of the weighted histogram at the end
-    DevBuf c_words;
+    DevBuf c_words;   // (per-read stream, w_mode != 0: one buffer, reads contiguous)
+    // weighted histogram (w_mode 0): the records by slice of the subject table (wk_weigh.hpp), appended through device
+    // cursors; unsliced (more than kMaxStreams slices) = one stream for the team kernel
+    DevBuf w_stream[kMaxStreams], w_cursor, w_stage;
+    int w_streams = 0;              // streams the open accumulation writes to
+    bool w_sliced = false;
+    bool w_counts_known = false;    // w_count holds the cursors' values
+    unsigned long long w_count[kMaxStreams] = {};
     int64_t w_records = 0, w_reads = 0;  // accumulated so far
     std::vector<wk_job> w_jobs;          // the job set they will be classified under
     int32_t w_group = 0;
@@ -259,6 +266,7 @@ struct wk_ctx {
     bool dt_emitted = false;      // the block scanned last was emitted with its reads kept
     uint32_t dt_emit_reads = 0;
     int64_t rm_bytes = 0;         // text of the last wk_dtok_readmap
+    int use_streams = 1;   // (0: the records of all slices in one stream, round 3's team kernel; measurement)
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
 };
@@ -648,6 +656,17 @@ static int build_subject_rows(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, Cla
 
 extern "C" {
 
+static int streams_needed(const wk_ctx* c) { return std::max(1, (int)(((int64_t)c->n_subjects + kSliceBins - 1) / kSliceBins)); }
+
+// the accumulation is empty again
+static int words_reset(wk_ctx* c) {
+    c->w_records = c->w_reads = 0;
+    c->w_open = false;
+    c->w_counts_known = false;
+    if (c->w_cursor.p) HIP_TRY(c, hipMemsetAsync(c->w_cursor.p, 0, kMaxStreams * 8, c->stream));
+    return WK_OK;
+}
+
 int wk_words_flush(wk_ctx* c);
 int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group, int* ok);
 
@@ -737,6 +756,12 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_bins_kernel<8>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_streams_kernel<4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_streams_kernel<6>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_streams_kernel<8>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinsMaxLds)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&weigh_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_tiled_kernel),
@@ -767,6 +792,7 @@ void wk_destroy(wk_ctx* c) {
     for (wk_ctx::StreamTables& T : c->st)
         for (DevBuf* b : {&T.rblocks, &T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node}) b->release();
     c->c_words.release();
+    for (DevBuf& b : c->w_stream) b.release();
     for (DevBuf* b : {&c->d_tiles_k[0], &c->d_tiles_k[1], &c->d_tile_off_k[0], &c->d_tile_off_k[1]}) b->release();
     for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
                       &c->d_state, &c->d_dict, &c->d_arena})
@@ -889,6 +915,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_blocks_per_cu")) {
         if (value < 1 || value > 8) return fail(c, WK_E_ARG, "single_blocks_per_cu must be in [1, 8]");
         c->single_blocks_per_cu = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "streams")) {  // 0: the records of all slices in one stream (round 3's team kernel)
+        c->use_streams = value != 0;
         return WK_OK;
     }
     if (!strcmp(name, "weigh")) {  // 0 = off, 1 = auto (large multi-hit chunks), 2 = whenever the jobs allow it
@@ -1523,7 +1553,7 @@ int wk_classify_staged(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t* o
                 }
                 wm.group = (uint32_t)a.group_base;
                 wm.table = a.table;
-                hipLaunchKernelGGL(weigh_merge_kernel, dim3((ba.n_subjects + 1023u) / 1024u), dim3(1024), (size_t)4096 * 16,
+                hipLaunchKernelGGL(weigh_merge_kernel, dim3((ba.n_subjects + kMergeSubjects - 1u) / kMergeSubjects), dim3(1024), (size_t)4096 * 16,
                                    c->stream, wm, 4096u);
                 ktimer_end(c, kt);
                 kt = ktimer_begin(c, "leftover");
@@ -1794,11 +1824,7 @@ static bool same_jobs(const std::vector<wk_job>& have, const wk_job* jobs, int32
 
 int wk_words_flush(wk_ctx* c) {
     if (!c) return WK_E_ARG;
-    if (!c->w_open || c->w_records == 0) {
-        c->w_open = false;
-        c->w_records = c->w_reads = 0;
-        return WK_OK;
-    }
+    if (!c->w_open || c->w_records == 0) return words_reset(c);
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
     KtScope kt_scope(c);
@@ -1861,9 +1887,7 @@ int wk_words_flush(wk_ctx* c) {
             HIP_TRY(c, hipGetLastError());
         }
         if (c->words_keep) return WK_OK;
-        c->w_records = c->w_reads = 0;
-        c->w_open = false;
-        return WK_OK;
+        return words_reset(c);
     }
     ClassifyArgs a{};
     bool ok = false;
@@ -1877,49 +1901,117 @@ int wk_words_flush(wk_ctx* c) {
     (void)ok;
     const int32_t n_jobs = (int32_t)c->w_jobs.size();
     const uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
-    uint32_t w_xcd = 8;
-    if (cus % w_xcd) w_xcd = 1;
-    const int64_t cap = (int64_t)kBinsMaxLds / 4 - 96;
-    const uint32_t w_slices = (uint32_t)((c->n_subjects + cap - 1) / cap);
-    const uint32_t w_bins = ((uint32_t)c->n_subjects + w_slices - 1) / w_slices;
-    const uint32_t w_teams = (cus / w_xcd) / w_slices;
-    if (!w_teams) return fail(c, WK_E_RANGE, "subject table too large for the weighted histogram");
-    const uint32_t n_teams = w_xcd * w_teams;
-    HIP_TRY(c, c->w_slab.reserve((size_t)w_slices * n_teams * w_bins * 4));
+    // how many records every stream holds (known once per accumulation state)
+    if (!c->w_counts_known) {
+        HIP_TRY(c, hipMemcpyAsync(c->w_count, c->w_cursor.p, kMaxStreams * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->w_counts_known = true;
+    }
     if ((size_t)c->n_subjects > c->w_hi_clean) {
         HIP_TRY(c, c->w_hi.reserve((size_t)c->n_subjects * 4 + ((size_t)c->n_subjects * 4) / 2));
         HIP_TRY(c, hipMemsetAsync(c->w_hi.p, 0, c->w_hi.cap, c->stream));
         c->w_hi_clean = c->w_hi.cap / 4;
     }
-    BinsArgs ba{};
-    ba.subj = c->c_words.as<int32_t>();
-    ba.rk = nullptr;
-    ba.n_records = (uint32_t)c->w_records;
-    ba.n_subjects = (uint32_t)c->n_subjects;
-    ba.bins = w_bins;
-    ba.n_slices = w_slices;
-    ba.teams_per_xcd = w_teams;
-    ba.n_xcd = w_xcd;
-    ba.slab = c->w_slab.as<uint32_t>();
-    ba.hi = c->w_hi.as<uint32_t>();
-    ba.err = scalar_err(c);
-    const dim3 wgrid(cus);
-    const size_t wlds = ((size_t)w_bins + 96) * 4;
-    KernelTimer* kt = ktimer_begin(c, "classify");
-    if (c->bins_ring == 6)
-        hipLaunchKernelGGL((weigh_bins_kernel<6, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
-    else if (c->bins_ring == 8)
-        hipLaunchKernelGGL((weigh_bins_kernel<8, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
-    else
-        hipLaunchKernelGGL((weigh_bins_kernel<4, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
-    ktimer_end(c, kt);
-    kt = ktimer_begin(c, "weigh_merge");
     WeighMergeArgs wm{};
-    wm.slab = ba.slab;
-    wm.hi = ba.hi;
-    wm.n_subjects = ba.n_subjects;
-    wm.bins = w_bins;
-    wm.n_teams = n_teams;
+    KernelTimer* kt = nullptr;
+    if (c->w_sliced) {
+        // ---- a stream per slice of the subject table, each read once; workgroups in proportion to the streams' lengths
+        StreamBinsArgs sa{};
+        const int S = c->w_streams;
+        unsigned long long total = 0;
+        for (int k = 0; k < S; ++k) total += c->w_count[k];
+        uint32_t wg[kMaxStreams] = {}, used = 0;
+        for (int k = 0; k < S; ++k)
+            if (c->w_count[k]) {
+                wg[k] = (uint32_t)std::max<unsigned long long>(1, c->w_count[k] * cus / total);
+                used += wg[k];
+            }
+        while (used > cus) {  // (the minimum of one workgroup per stream pushed the sum over)
+            int big = 0;
+            for (int k = 1; k < S; ++k)
+                if (wg[k] > wg[big]) big = k;
+            --wg[big];
+            --used;
+        }
+        while (used < cus && total) {  // what the rounding left: to the stream with the most records per workgroup
+            int best = -1;
+            for (int k = 0; k < S; ++k)
+                if (wg[k] && (best < 0 || c->w_count[k] * wg[best] > c->w_count[best] * wg[k])) best = k;
+            ++wg[best];
+            ++used;
+        }
+        sa.n_streams = (uint32_t)S;
+        sa.n_subjects = (uint32_t)c->n_subjects;
+        uint32_t first = 0;
+        for (int k = 0; k < S; ++k) {
+            if (c->w_count[k] >= (1ull << 30)) return fail(c, WK_E_RANGE, "more than 2^30 records in one stream");
+            sa.words[k] = c->w_stream[k].as<uint32_t>();
+            sa.count[k] = (uint32_t)c->w_count[k];
+            sa.wg_first[k] = first;
+            first += wg[k];
+        }
+        for (int k = S; k <= kMaxStreams; ++k) sa.wg_first[k] = first;
+        const uint32_t n_wg = first;
+        HIP_TRY(c, c->w_slab.reserve((size_t)std::max(n_wg, 1u) * kSliceBins * 4));
+        sa.slab = c->w_slab.as<uint32_t>();
+        sa.hi = c->w_hi.as<uint32_t>();
+        sa.err = scalar_err(c);
+        kt = ktimer_begin(c, "classify");
+        if (n_wg) {
+            if (c->bins_ring == 6)
+                hipLaunchKernelGGL((weigh_streams_kernel<6>), dim3(n_wg), dim3(kWeighThreads), kBinsMaxLds, c->stream, sa);
+            else if (c->bins_ring == 8)
+                hipLaunchKernelGGL((weigh_streams_kernel<8>), dim3(n_wg), dim3(kWeighThreads), kBinsMaxLds, c->stream, sa);
+            else
+                hipLaunchKernelGGL((weigh_streams_kernel<4>), dim3(n_wg), dim3(kWeighThreads), kBinsMaxLds, c->stream, sa);
+        }
+        ktimer_end(c, kt);
+        wm.slab = sa.slab;
+        wm.hi = sa.hi;
+        wm.streams = (uint32_t)S;
+        for (int k = 0; k <= kMaxStreams; ++k) wm.wg_first[k] = sa.wg_first[k];
+        wm.bins = kSliceBins;
+        wm.n_teams = 0;
+    } else {
+        // ---- more slices than streams: one stream, a team of workgroups per tile (round 3's launch)
+        uint32_t w_xcd = 8;
+        if (cus % w_xcd) w_xcd = 1;
+        const int64_t cap = (int64_t)kBinsMaxLds / 4 - 96;
+        const uint32_t w_slices = (uint32_t)((c->n_subjects + cap - 1) / cap);
+        const uint32_t w_bins = ((uint32_t)c->n_subjects + w_slices - 1) / w_slices;
+        const uint32_t w_teams = (cus / w_xcd) / w_slices;
+        if (!w_teams) return fail(c, WK_E_RANGE, "subject table too large for the weighted histogram");
+        const uint32_t n_teams = w_xcd * w_teams;
+        HIP_TRY(c, c->w_slab.reserve((size_t)w_slices * n_teams * w_bins * 4));
+        BinsArgs ba{};
+        ba.subj = c->w_stream[0].as<int32_t>();
+        ba.rk = nullptr;
+        ba.n_records = (uint32_t)c->w_count[0];
+        ba.n_subjects = (uint32_t)c->n_subjects;
+        ba.bins = w_bins;
+        ba.n_slices = w_slices;
+        ba.teams_per_xcd = w_teams;
+        ba.n_xcd = w_xcd;
+        ba.slab = c->w_slab.as<uint32_t>();
+        ba.hi = c->w_hi.as<uint32_t>();
+        ba.err = scalar_err(c);
+        const dim3 wgrid(cus);
+        const size_t wlds = ((size_t)w_bins + 96) * 4;
+        kt = ktimer_begin(c, "classify");
+        if (c->bins_ring == 6)
+            hipLaunchKernelGGL((weigh_bins_kernel<6, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+        else if (c->bins_ring == 8)
+            hipLaunchKernelGGL((weigh_bins_kernel<8, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+        else
+            hipLaunchKernelGGL((weigh_bins_kernel<4, true>), wgrid, dim3(kWeighThreads), wlds, c->stream, ba);
+        ktimer_end(c, kt);
+        wm.slab = ba.slab;
+        wm.hi = ba.hi;
+        wm.bins = w_bins;
+        wm.n_teams = n_teams;
+    }
+    kt = ktimer_begin(c, "weigh_merge");
+    wm.n_subjects = (uint32_t)c->n_subjects;
     wm.rows = a.rows;
     wm.row_w = a.row_w;
     wm.n_jobs = n_jobs;
@@ -1929,15 +2021,13 @@ int wk_words_flush(wk_ctx* c) {
     }
     wm.group = (uint32_t)c->w_group;
     wm.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
-    hipLaunchKernelGGL(weigh_merge_kernel, dim3((ba.n_subjects + 1023u) / 1024u), dim3(1024), (size_t)4096 * 16, c->stream, wm, 4096u);
+    hipLaunchKernelGGL(weigh_merge_kernel, dim3((wm.n_subjects + kMergeSubjects - 1u) / kMergeSubjects), dim3(1024), (size_t)4096 * 16, c->stream, wm, 4096u);
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
     c->stat_extra_reads += c->w_reads;
     c->stat_extra_records += c->w_records;
     if (c->words_keep) return WK_OK;  // (bench: repeated passes over the resident batch)
-    c->w_records = c->w_reads = 0;
-    c->w_open = false;
-    return WK_OK;
+    return words_reset(c);
 }
 
 int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group, int* ok) {
@@ -1962,12 +2052,30 @@ int wk_words_begin(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, int32_t group,
         c->w_open = false;
         return WK_OK;
     }
+    if (!c->w_open || c->w_records == 0) {  // a fresh accumulation
+        if ((rc = words_reset(c))) return rc;
+        c->w_sliced = mode == 0 && c->use_streams && streams_needed(c) <= kMaxStreams;
+        c->w_streams = 0;
+    }
     c->w_jobs.assign(jobs, jobs + n_jobs);
     c->w_group = group;
     c->w_mode = mode;
     c->w_open = true;
     *ok = 1;
     return WK_OK;
+}
+
+static StreamSet stream_set(wk_ctx* c) {
+    StreamSet s{};
+    size_t cap = ~(size_t)0;
+    for (int k = 0; k < c->w_streams; ++k) {
+        s.out[k] = c->w_stream[k].as<uint32_t>();
+        cap = std::min(cap, c->w_stream[k].cap / 4);
+    }
+    s.cursor = c->w_cursor.as<unsigned long long>();
+    s.n_streams = (uint32_t)c->w_streams;
+    s.cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+    return s;
 }
 
 // Free-rank accumulation: the subject fields of words [first, first + n) become feature ids.
@@ -1988,6 +2096,28 @@ static int words_translate(wk_ctx* c, int64_t first, int64_t n) {
 
 // Room for n_more records behind the accumulated ones.
 static int words_room(wk_ctx* c, int64_t n_more) {
+    if (c->w_mode == 0) {
+        // every stream may take all of them (its cursor is only known to the device: at most w_records)
+        if (!c->w_cursor.p) {
+            HIP_TRY(c, c->w_cursor.reserve(kMaxStreams * 8));
+            HIP_TRY(c, hipMemsetAsync(c->w_cursor.p, 0, kMaxStreams * 8, c->stream));
+        }
+        const int want = c->w_sliced ? streams_needed(c) : 1;
+        c->w_streams = std::max(c->w_streams, want);
+        const size_t need = (size_t)(c->w_records + n_more) * 4 + 64;
+        for (int k = 0; k < c->w_streams; ++k) {
+            DevBuf& b = c->w_stream[k];
+            if (need <= b.cap) continue;
+            DevBuf bigger;
+            HIP_TRY(c, bigger.reserve(need * 2));
+            const size_t keep = std::min((size_t)c->w_records * 4, b.cap);
+            if (keep > 0) HIP_TRY(c, hipMemcpyAsync(bigger.p, b.p, keep, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            b.release();
+            b = bigger;
+        }
+        return WK_OK;
+    }
     const size_t need = (size_t)(c->w_records + n_more) * 4 + 64;
     if (need <= c->c_words.cap) return WK_OK;
     // grow: a new buffer (twice the need) takes over what is there
@@ -2003,7 +2133,8 @@ static int words_room(wk_ctx* c, int64_t n_more) {
 // The accumulated records would pass 2^30 (the histogram addresses bytes with
 // 32 bits): classify what is there and open the same job set again.
 static int words_roll(wk_ctx* c, int64_t n_more) {
-    if (c->w_records + n_more < (1ll << 30)) return WK_OK;
+    const bool outgrown = c->w_mode == 0 && c->w_sliced && streams_needed(c) > kMaxStreams;  // (continues unsliced)
+    if (c->w_records + n_more < (1ll << 30) && !outgrown) return WK_OK;
     const std::vector<wk_job> jobs = c->w_jobs;
     const int32_t group = c->w_group;
     int rc = wk_words_flush(c);
@@ -2029,12 +2160,22 @@ int wk_words_append(wk_ctx* c, const uint32_t* words, int64_t n_records, int64_t
         const int rcw = words_room(c, n_records);
         if (rcw) return rcw;
     }
-    if (n_records > 0)
+    if (n_records > 0 && c->w_mode == 0) {
+        HIP_TRY(c, c->w_stage.reserve((size_t)n_records * 4));
+        HIP_TRY(c, hipMemcpyAsync(c->w_stage.p, words, (size_t)n_records * 4, hipMemcpyHostToDevice, c->stream));
+    } else if (n_records > 0) {
         HIP_TRY(c, hipMemcpyAsync(c->c_words.as<uint32_t>() + c->w_records, words, (size_t)n_records * 4, hipMemcpyHostToDevice, c->stream));
+    }
     if (slot >= 0) {
         if (!c->slot_ev[slot]) HIP_TRY(c, hipEventCreateWithFlags(&c->slot_ev[slot], hipEventDisableTiming));
         HIP_TRY(c, hipEventRecord(c->slot_ev[slot], c->stream));
         c->slot_busy[slot] = true;
+    }
+    if (n_records > 0 && c->w_mode == 0) {  // ... to the streams of their slices
+        hipLaunchKernelGGL(words_partition_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, c->stream,
+                           c->w_stage.as<uint32_t>(), (uint32_t)n_records, stream_set(c));
+        HIP_TRY(c, hipGetLastError());
+        c->w_counts_known = false;
     }
     {
         const int rct = words_translate(c, c->w_records, n_records);
@@ -2346,8 +2487,16 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     if (rc) return rc;
     if ((rc = words_room(c, c->dt_lines))) return rc;
     DtokArgs a = dtok_args(c);
-    a.out = c->c_words.as<uint32_t>() + c->w_records;
-    a.out_cap = c->dt_lines;
+    if (c->w_mode == 0) {
+        a.streams = stream_set(c);
+        c->w_counts_known = false;
+        // (a block the kernels give up on must leave the streams as they were)
+        HIP_TRY(c, c->w_stage.reserve(kMaxStreams * 8));
+        HIP_TRY(c, hipMemcpyAsync(c->w_stage.p, c->w_cursor.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        a.out = c->c_words.as<uint32_t>() + c->w_records;
+        a.out_cap = c->dt_lines;
+    }
     const dim3 grid((c->dt_lines + kDtokThreads - 1) / kDtokThreads);
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
@@ -2368,7 +2517,10 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
                            c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
         hipLaunchKernelGGL(dtok_scan_lines_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tile_off.as<unsigned long long>());
-        hipLaunchKernelGGL(dtok_place_words_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        if (c->w_mode == 0)  // (read maps wanted, records for the histogram: by slice, in no particular order)
+            hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(dtok_place_words_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
         HIP_TRY(c, hipMemcpyAsync(&totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
     } else {
         hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
@@ -2382,7 +2534,13 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
         st.n_out = totals & 0xFFFFFFFFull;
         st.n_reads = totals >> 32;
     }
-    if (st.flags) return WK_OK;  // a read of more than 16 subjects: nothing counts as appended
+    if (st.flags) {  // a read of more than 16 subjects: nothing counts as appended
+        if (c->w_mode == 0) {
+            HIP_TRY(c, hipMemcpyAsync(c->w_cursor.p, c->w_stage.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        return WK_OK;
+    }
     c->dt_emitted = c->dt_keep_reads;
     c->dt_emit_reads = (uint32_t)st.n_reads;
     if ((rc = words_translate(c, c->w_records, (int64_t)st.n_out))) return rc;
