@@ -54,8 +54,14 @@ def build_input(tmp, scale):
 
 def build_free_input(tmp, scale):
     """Config 3 at `scale` for the `--rank free` run (2 M reads, ~10 M
-    records at 0.04): (sam, nodes, records)."""
-    return build_input(tmp, scale)
+    records at 0.04): (alignment directory, nodes, records).  A directory —
+    one sample per file — not a single file, which `woltka classify` takes
+    for a multiplexed one (workflow.py:393-399)."""
+    indir = os.path.join(tmp, 'aln')
+    os.makedirs(indir, exist_ok=True)
+    sam, nodes, n_rec = build_input(indir, scale)
+    os.replace(nodes, os.path.join(tmp, 'nodes.dmp'))
+    return indir, os.path.join(tmp, 'nodes.dmp'), n_rec
 
 
 def build_coords_input(tmp, n_pairs):

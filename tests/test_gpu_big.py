@@ -76,7 +76,8 @@ def test_free_rank_at_10M_records_equals_the_reference(tmp_path):
         workflow(input_fp=sam, output_fp=out, input_fmt='sam',
                  nodes_fps=[nodes], ranks='free', output_fmt=False)
     assert _sha(out) == gold['table']
-    assert classify.ROUTES['dtok'] > 0 and classify.ROUTES['host_block'] == 0
+    assert classify.ROUTES['dtok'] > 0 and classify.ROUTES['host_block'] == 0, \
+        dict(classify.ROUTES)
 
 
 @pytest.mark.skipif(not os.path.isfile(GOLD_COORDS),
@@ -99,4 +100,5 @@ def test_coord_match_at_10M_records_equals_the_reference(tmp_path):
         workflow(input_fp=indir, output_fp=out, input_fmt='sam',
                  coords_fp=coords, overlap=80, output_fmt=False)
     assert _sha(out) == gold['table']
-    assert classify.ROUTES['dhits'] > 0 and classify.ROUTES['host_block'] == 0
+    assert classify.ROUTES['dhits'] > 0 and classify.ROUTES['host_block'] == 0, \
+        dict(classify.ROUTES)

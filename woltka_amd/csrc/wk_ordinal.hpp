@@ -354,7 +354,7 @@ struct TallyArgs {
 constexpr uint32_t kTallyThreads = 512;
 constexpr uint32_t kTallyQueue = 3072;  // reads with several hits wait here until a full workgroup's worth is queued
 
-// kRange (one job; gene ids below 2^28, at most 4096 per partition): the genes of
+// kRange (one job; gene ids below 2^28, at most 16384 per partition): the genes of
 // a chunk are ~10^5..10^6 keys, so an LDS hash cache in front of the log holds
 // next to none of them and its probes are most of this kernel's time.  Every
 // {gene, n} goes to the log instead, as one 4-byte entry, into the partition its
@@ -525,21 +525,25 @@ __global__ void __launch_bounds__(kTallyThreads) ordinal_tally_kernel(TallyArgs 
 // partition p — the genes g with g mod n_parts = p — from every stream in a dense
 // LDS array of weights indexed by g / n_parts, and puts the genes that were hit
 // into the count table.
+// (kRangeMergeSplit workgroups per partition, each with every kRangeMergeSplit-th stream: the count table adds theirs up)
+constexpr uint32_t kRangeMergeSplit = 8;
 __global__ void __launch_bounds__(1024) range_merge_kernel(const uint32_t* __restrict__ plog32, const uint32_t* __restrict__ plog_cnt,
                                                            uint32_t n_rows, uint32_t plog_cap, uint32_t span, uint32_t job,
                                                            uint32_t group, CountTable table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* const sum = reinterpret_cast<unsigned long long*>(smem);
     const uint32_t part = blockIdx.x, n_parts = gridDim.x, shift = 31u - (uint32_t)__clz((int)n_parts);
+    const uint32_t piece = blockIdx.y, pieces = gridDim.y;
     for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) sum[i] = 0ull;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
     // one stream per wave at a time; a stream is short (~n_hits / (rows x parts)
     // entries), so the next one's length is fetched while this one is added up,
     // and its entries are loaded four to a lane before the first is used
-    uint32_t n = wave < n_rows ? plog_cnt[(size_t)wave * n_parts + part] : 0u;
-    for (uint32_t row = wave; row < n_rows; row += n_waves) {
-        const uint32_t next = row + n_waves;
+    const uint32_t row0 = piece * n_waves + wave, stride = pieces * n_waves;
+    uint32_t n = row0 < n_rows ? plog_cnt[(size_t)row0 * n_parts + part] : 0u;
+    for (uint32_t row = row0; row < n_rows; row += stride) {
+        const uint32_t next = row + stride;
         const uint32_t n_next = next < n_rows ? plog_cnt[(size_t)next * n_parts + part] : 0u;
         const uint32_t* src = plog32 + ((size_t)row * n_parts + part) * plog_cap;
         for (uint32_t i = lane; i < n; i += 256) {

@@ -266,6 +266,7 @@ struct wk_ctx {
     bool dt_emitted = false;      // the block scanned last was emitted with its reads kept
     uint32_t dt_emit_reads = 0;
     int64_t rm_bytes = 0;         // text of the last wk_dtok_readmap
+    int range_parts_opt = 0;   // partitions of the dense gene log (0: as few as the merge's LDS array allows; measurement)
     int use_streams = 1;   // (0: the records of all slices in one stream, round 3's team kernel; measurement)
     int use_subject_bins = 1;
     int use_hot_bins = 1;  // hot-subject bins for subject tables beyond the LDS  // count-first mode of the split for small subject tables
@@ -770,6 +771,8 @@ int wk_create(int device, wk_ctx** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&match_hits_kernel<true, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&range_merge_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&partition_merge_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess) {
         int rc = fail(nullptr, WK_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
@@ -915,6 +918,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_blocks_per_cu")) {
         if (value < 1 || value > 8) return fail(c, WK_E_ARG, "single_blocks_per_cu must be in [1, 8]");
         c->single_blocks_per_cu = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "range_parts")) {  // partitions of the dense gene log (a power of two; 0 = auto)
+        c->range_parts_opt = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "streams")) {  // 0: the records of all slices in one stream (round 3's team kernel)
@@ -2900,6 +2907,19 @@ int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const
 }
 
 // Launch of match_hits_kernel: per-genome words in LDS when they fit.
+// The dense log of the gene tally (wk_ordinal.hpp): genes go to the partition their low bits name, a partition is summed in
+// an LDS array of 64-bit weights indexed by the high bits.  As few partitions as that array allows: every (workgroup,
+// partition) stream has a line open in L2, and 768 x 256 of them (25 MB) did not stay there — the scattered 4-byte stores
+// went out as partial lines, 1.08 GB written for 0.34 GB of entries (profiles/r03_ordinal_pmc_summary.txt).
+static bool range_log_shape(const wk_ctx* c, uint32_t* parts, uint32_t* span) {
+    constexpr uint32_t kSpanMax = 16384;  // 128 KiB of LDS
+    uint32_t p = c->range_parts_opt > 0 ? (uint32_t)c->range_parts_opt : 16u;
+    while (p < kLogPartsMax && (uint32_t)(c->max_gene_feature / (int32_t)p) + 1u > kSpanMax) p <<= 1;
+    *parts = p;
+    *span = (uint32_t)(c->max_gene_feature / (int32_t)p) + 1u;
+    return *span <= kSpanMax && c->max_gene_feature < (1 << 28);
+}
+
 static int launch_match_hits(wk_ctx* c, bool counts) {
     MatchArgs a{};
     a.genome = c->o_genome.as<int32_t>();
@@ -3073,9 +3093,8 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     t.group = c->group_base;
     t.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
     // one job over gene ids with at most 4096 per partition: the dense log (wk_ordinal.hpp)
-    const uint32_t range_parts = ((int64_t)c->max_gene_feature >> 8) < 4096 ? 256u : kLogPartsMax;
-    const uint32_t range_span = (uint32_t)(c->max_gene_feature / (int32_t)range_parts) + 1u;
-    const bool by_range = c->use_range_log && n_jobs == 1 && range_span <= 4096u && c->max_gene_feature < (1 << 28);
+    uint32_t range_parts = 0, range_span = 0;
+    const bool by_range = range_log_shape(c, &range_parts, &range_span) && c->use_range_log && n_jobs == 1;
     // distinct keys: the genes (256 merge tables of 8192 slots hold ~1.3 M at a comfortable load)
     if (by_range)
         t.log_parts = range_parts;
@@ -3104,7 +3123,7 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
         hipLaunchKernelGGL(ordinal_tally_kernel<true>, dim3(blocks), dim3(kTallyThreads), tally_lds, c->stream, t, 0u);
         ktimer_end(c, kt);
         kt = ktimer_begin(c, "partition_merge");
-        hipLaunchKernelGGL(range_merge_kernel, dim3(t.log_parts), dim3(1024), (size_t)8 * range_span, c->stream, t.plog32,
+        hipLaunchKernelGGL(range_merge_kernel, dim3(t.log_parts, kRangeMergeSplit), dim3(1024), (size_t)8 * range_span, c->stream, t.plog32,
                            t.plog_cnt, (uint32_t)blocks, t.plog_cap, range_span, 0u, (uint32_t)t.group, t.table);
         ktimer_end(c, kt);
     } else {
