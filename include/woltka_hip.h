@@ -306,6 +306,12 @@ int wk_words_pending(wk_ctx* ctx, int64_t* n_records, int64_t* n_reads);
 int wk_dtok_copy(wk_ctx* ctx, const char* text, int64_t begin, int64_t stop);
 int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
                  int64_t stop, int extra, int64_t* n_lines, int* status);
+/* The format of the blocks wk_dtok_scan is given from now on: WK_FMT_SAM
+ * (default), or — plain flavour only — WK_FMT_MAP (align.parse_map_file,
+ * align.py:621-674) / WK_FMT_B6O (align.parse_b6o_file, align.py:753-803):
+ * rows `query <tab> subject ...`, grouped into runs of equal queries the same
+ * way; lines that are not rows of the format are ignored. */
+int wk_dtok_format(wk_ctx* ctx, int fmt);
 int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
                  int* status);
 /* ---- strata map on the device (csrc/wk_strata.hpp) -------------------------
@@ -498,6 +504,10 @@ int wk_tok_sam_span(const char* buf, int64_t len, int final_block, int in_header
                     int64_t* begin, int64_t* stop, int* in_header_after);
 /* The header state wk_tok_text continues from, for callers that had the device
  * tokenizer (wk_dtok_*) take the blocks before. */
+/* The same for any of the formats (WK_FMT_*; header lines exist in SAM only). */
+int wk_tok_span(int fmt, int extra, const char* buf, int64_t len, int final_block,
+                int in_header, int64_t* begin, int64_t* stop,
+                int* in_header_after);
 int wk_tok_set_header_state(wk_tok* tok, int in_header);
 /* *got bytes of [offset, offset + len) of the open file `fd` into dst, read by
  * all tokenizer threads (pread on slices); short only at the end of the file. */

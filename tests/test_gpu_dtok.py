@@ -310,3 +310,76 @@ def test_device_ex_malformed_numbers_raise_like_the_host(tmp_path, bad):
         except Exception as e:      # noqa: BLE001
             errs.append((type(e), str(e)))
     assert errs[0] == errs[1] and errs[0] is not None
+
+
+def _random_rows(rng, fmt, n_queries, subjects):
+    """Simple-map or BLAST-tabular text with what the reference's parsers have
+    to deal with (align.py:621-674, 753-803): lines that are not rows (no tab /
+    fewer than three fields: ignored without ending a run), subjects with
+    trailing blanks (map: stripped), repeated subjects, extra columns."""
+    lines = []
+    for q in range(n_queries):
+        name = f'A00123:45:HXX:{q % 4}:{q}' if q % 3 else f'r{q}'
+        k = rng.choice([1, 1, 1, 2, 3, 5, 9, 16])
+        for _ in range(k):
+            s = rng.choice(subjects)
+            if fmt == 'map':
+                tail = rng.choice(['', '', '', ' ', '\r', ' \t', '\textra\tcols'])
+                lines.append(f'{name}\t{s}{tail}')
+            else:
+                a, b = sorted((rng.randrange(1, 5000), rng.randrange(1, 5000)))
+                lines.append(f'{name}\t{s}\t{rng.randrange(80, 100)}.5\t'
+                             f'{b - a + 1}\t0\t0\t1\t{b - a + 1}\t{a}\t{b}\t'
+                             f'1e-{rng.randrange(5, 50)}\t{rng.randrange(50, 300)}')
+            if rng.random() < 0.03:
+                # (two fields are a row of a map, not of a BLAST table)
+                lines.append(rng.choice(['', 'no tab here', f'{name}'] + (
+                    [f'{name}\tonly_two_fields'] if fmt == 'b6o' else [])))
+    return '\n'.join(lines) + '\n'
+
+
+@pytest.mark.parametrize('fmt', ['map', 'b6o'])
+@pytest.mark.parametrize('block', [1 << 26, 1 << 15])
+@pytest.mark.parametrize('maps', [False, True])
+def test_map_and_b6o_rows_on_the_device(tmp_path, monkeypatch, fmt, block,
+                                        maps):
+    """Simple maps and BLAST tabular text through the device tokenizer (and,
+    with --outmap, the read maps formatted there) against the host tokenizer:
+    same log, same tables, same read maps — and the device route was taken."""
+    import gzip
+    from woltka_amd import classify
+    monkeypatch.setattr(classify.Engine, 'DTOK_BLOCK', block)
+    rng = random.Random(hash((fmt, block)) & 0xFFFF)
+    subjects = [f'G{i:04d}' for i in range(300)]
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    for s in ('S1', 'S2'):
+        (indir / f'{s}.{fmt}').write_text(_random_rows(rng, fmt, 4000, subjects))
+    mp = tmp_path / 'genus.map'
+    mp.write_text(''.join(f'{s}\tT{i % 37}\n' for i, s in enumerate(subjects)))
+    res = []
+    for host in (False, True):
+        kw = dict(input_fp=str(indir), input_fmt=fmt, map_fps=[str(mp)],
+                  map_rank=None, ranks='none,genus')
+        if maps:
+            kw['outmap_dir'] = str(tmp_path / f'maps_{host}')
+        classify.ROUTES.clear()
+        tables, log = _run(tmp_path, f'{fmt}{host}', host, **kw)
+        routes = dict(classify.ROUTES)
+        got = {}
+        if maps:
+            for root, _, files in os.walk(kw['outmap_dir']):
+                for fn in files:
+                    with gzip.open(os.path.join(root, fn), 'rb') as f:
+                        got[os.path.relpath(os.path.join(root, fn),
+                                            kw['outmap_dir'])] = f.read()
+            assert len(got) == 4
+        res.append((tables, log.replace(f'maps_{host}', 'maps'), got))
+        if not host:
+            assert routes.get('dtok_maps' if maps else 'dtok', 0) > 0, routes
+        else:
+            assert not routes.get('dtok') and not routes.get('dtok_maps')
+    assert res[0][1] == res[1][1]
+    assert res[0][0] == res[1][0]
+    assert res[0][2] == res[1][2]
+    assert all(len(v) > 50 for v in res[0][0].values())

@@ -49,7 +49,8 @@ SYMBOLS = (
     'wk_tok_set_exclude', 'wk_tok_sam_tail', 'wk_tok_sam', 'wk_tok_text',
     'wk_tok_boundary',
     'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
-    'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_set_header_state',
+    'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
+    'wk_dtok_format',
     'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
     'wk_dtok_keep_reads', 'wk_readmap_tables', 'wk_dtok_readmap',
     'wk_dtok_readmap_fetch', 'wk_strata_load', 'wk_strata_labels',
@@ -177,6 +178,10 @@ def load_library():
                                   i64p]),
         'wk_tok_sam_span': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       i64p, i64p, C.POINTER(C.c_int)]),
+        'wk_tok_span': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                  C.c_int, C.c_int, i64p, i64p,
+                                  C.POINTER(C.c_int)]),
+        'wk_dtok_format': (C.c_int, [p, C.c_int]),
         'wk_tok_set_header_state': (C.c_int, [p, C.c_int]),
         'wk_dtok_copy': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64]),
         'wk_dtok_scan': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
@@ -551,6 +556,11 @@ class Context:
                                            C.byref(n), C.byref(st)))
         return st.value, n.value
 
+    def dtok_format(self, fmt):
+        """Format of the blocks ``dtok_scan`` is given from now on: 'sam',
+        'map' or 'b6o' (the plain flavour only for the latter two)."""
+        self._check(self._lib.wk_dtok_format(self._h, Tokenizer.FORMATS[fmt]))
+
     def dtok_emit(self):
         """Group the scanned block's lines into reads and append their
         records to the accumulated packed records.  Returns (status, reads,
@@ -887,16 +897,17 @@ class Tokenizer:
         return out.value
 
     @staticmethod
-    def sam_span(buf, final, in_header):
-        """(ok, begin, stop, in_header_after) of a block of SAM text: the part
-        that can be tokenised now (``wk_tok_sam_span``)."""
+    def sam_span(buf, final, in_header, fmt='sam'):
+        """(ok, begin, stop, in_header_after) of a block of alignment text (SAM
+        unless ``fmt`` says otherwise): the part that can be tokenised now
+        (``wk_tok_span``)."""
         raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
         b, s, h = C.c_int64(0), C.c_int64(0), C.c_int(0)
         addr = C.c_void_p(raw.ctypes.data) if raw.size \
             else C.cast(C.c_char_p(b''), C.c_void_p)
-        rc = load_library().wk_tok_sam_span(addr, raw.size, int(bool(final)),
-                                            int(bool(in_header)), C.byref(b),
-                                            C.byref(s), C.byref(h))
+        rc = load_library().wk_tok_span(
+            Tokenizer.FORMATS[fmt], 0, addr, raw.size, int(bool(final)),
+            int(bool(in_header)), C.byref(b), C.byref(s), C.byref(h))
         return rc == OK, b.value, s.value, bool(h.value)
 
     def set_header_state(self, in_header):

@@ -454,6 +454,7 @@ class Engine:
         self._deferred_from = None                  # see take_deferred
         # read maps formatted on the device (csrc/wk_readmap.hpp)
         self._dmaps = None          # (rank2dir, outzip, namedic) while a file is read that way
+        self._dfmt = 'sam'          # format of the file the device tokenises
         self._dmaps_n = -1          # subjects the device's read-map tables cover
         self._dmaps_ok = False
         self._mring = None          # pinned buffers the map text is fetched into
@@ -775,8 +776,12 @@ class Engine:
         device_ex = ordinal and cover is None and not want_names and \
             (not want_groups or self._dstrata is not None) and \
             not want_samples and len(self.jobs) <= nat.MAX_JOBS
-        if (words or device_ex or dmaps) and fmt == 'sam' and not exclude and \
-                part is None and not os.environ.get('WOLTKA_NO_DTOK'):
+        # (the device tokenises SAM in both flavours, simple maps and BLAST
+        # tabular text in the plain one: align.py:621-674, 753-803)
+        if (words or device_ex or dmaps) and (
+                fmt == 'sam' or (fmt in ('map', 'b6o') and not ordinal)) and \
+                not exclude and part is None and \
+                not os.environ.get('WOLTKA_NO_DTOK'):
             from .align import _parallel_reader
             reader = _parallel_reader(stream, tok, None)
             if reader is not None:
@@ -784,6 +789,8 @@ class Engine:
                 # `dmaps` the read maps are formatted there too)
                 self._dmaps = dmaps if not (words or device_ex) else None
                 self.ctx.dtok_keep_reads(self._dmaps is not None)
+                self._dfmt = fmt
+                self.ctx.dtok_format(fmt)
                 try:
                     yield from self._device_chunks(reader, block_bytes,
                                                    ordinal=bool(ordinal))
@@ -1319,7 +1326,7 @@ class Engine:
                     fill = out.size
                     t0 = time.perf_counter()
                     ok, begin, stop, hdr = nat.Tokenizer.sam_span(
-                        out, final, in_header)
+                        out, final, in_header, self._dfmt)
                     lap['span'] += time.perf_counter() - t0
                     if not ok and not final:    # no complete run yet: read more
                         carry = out.tobytes()
@@ -1378,7 +1385,8 @@ class Engine:
                 view = arr[pos:end]
                 t0 = time.perf_counter()
                 ok, begin, stop, hdr = nat.Tokenizer.sam_span(view, final,
-                                                              in_header)
+                                                              in_header,
+                                                              self._dfmt)
                 lap['span'] += time.perf_counter() - t0
                 if not ok and not final:    # no complete run yet: look further
                     span *= 2
@@ -1569,7 +1577,7 @@ class Engine:
                     None, None, None
             return
         res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
-                        final=final, fmt='sam', want_names=names)
+                        final=final, fmt=self._dfmt, want_names=names)
         fresh = tok.new_subjects()
         if fresh:
             ids = np.fromiter(map(self.subjects.intern, fresh), np.int32,

@@ -63,6 +63,7 @@ struct DictSlot {
 struct DtokArgs {
     const unsigned char* text;  // [n] + 64 readable bytes behind
     uint32_t n;
+    uint32_t fmt;  // 0 SAM, 1 simple map, 2 BLAST tabular (WK_FMT_*; plain flavour only for 1 and 2)
     const uint32_t* line_start;  // [n_lines + 1], line_start[n_lines] = n (+1 if the last line has no newline)
     uint32_t n_lines;
     int32_t* lsubj;    // [n_lines]
@@ -174,8 +175,43 @@ __device__ __forceinline__ unsigned long long dtok_hash(const unsigned char* p, 
     return h ^ (h >> 32);
 }
 
+// the subject text[rb, rb + rn) in the dictionary: its id, or kLineUnknown (and the name listed for the host)
+__device__ __forceinline__ int32_t dtok_subject(const DtokArgs& a, uint32_t rb, uint32_t rn) {
+    const unsigned long long hv = dtok_hash(a.text + rb, rn);
+    uint32_t h = (uint32_t)hv & a.dict_mask;
+    int32_t id = kLineUnknown;
+    for (;;) {
+        const DictSlot s = a.dict[h];
+        if (s.id < 0) break;
+        if (s.hash == hv) {
+            const unsigned char* nm = a.arena + s.off;
+            const uint32_t ln = (uint32_t)nm[0] | ((uint32_t)nm[1] << 8) | ((uint32_t)nm[2] << 16) | ((uint32_t)nm[3] << 24);
+            bool same = ln == rn;
+            for (uint32_t k = 0; same && k < rn; ++k) same = nm[4 + k] == a.text[rb + k];
+            if (same) {
+                id = s.id;
+                break;
+            }
+        }
+        h = (h + 1u) & a.dict_mask;
+    }
+    if (id == kLineUnknown) {
+        const uint32_t at = atomicAdd(&a.state->n_unknown, 1u);
+        if (at < a.unknown_cap)
+            a.unknown[at] = make_uint2(rb, rn);
+        else
+            atomicOr(&a.state->flags, kDtokUnknownFull);
+    }
+    return id;
+}
+
 // a thread per line: QNAME / FLAG / RNAME, mate, subject id; kEx: also POS and
-// CIGAR -> start, end, aligned length (align.py:376-398, 572-583)
+// CIGAR -> start, end, aligned length (align.py:376-398, 572-583).  The simple
+// map (align.parse_map_file, align.py:621-674: query <tab> subject, the subject
+// right-stripped, lines without a tab ignored) and BLAST tabular rows
+// (align.parse_b6o_file, align.py:753-803: `qseqid, sseqid, _ = line.split('\t',
+// 2)`, lines of fewer fields ignored) are split here too; an ignored line does not
+// end a run of equal queries, like an unmapped SAM record.
 template <bool kEx>
 __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,6 +220,45 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
     uint32_t hi = a.line_start[i + 1];  // behind the line's newline (or n + 1 for a last line without one)
     hi = hi > lo ? hi - 1u : lo;        // the newline itself / the end of the text
     if (hi > a.n) hi = a.n;
+    if constexpr (!kEx) {
+        if (a.fmt != 0u) {
+            uint32_t t0 = hi, t1 = hi;
+            for (uint32_t p = lo; p < hi; ++p)
+                if (a.text[p] == '\t') {
+                    if (t0 == hi) {
+                        t0 = p;
+                    } else {
+                        t1 = p;
+                        break;
+                    }
+                }
+            const uint32_t qn = t0 - lo;
+            if (t0 == hi || (a.fmt == 2u && t1 == hi)) {  // not a row of the format
+                a.lsubj[i] = kLineUnmapped;
+                a.lmeta[i] = 0;
+                return;
+            }
+            if (qn >= (1u << 28)) {
+                a.lsubj[i] = kLineBad;
+                a.lmeta[i] = 0;
+                atomicOr(&a.state->flags, kDtokLongName);
+                return;
+            }
+            const uint32_t rb = t0 + 1u;
+            uint32_t re = t1;
+            if (a.fmt == 1u)  // subject.rstrip()
+                while (re > rb) {
+                    const unsigned char ch = a.text[re - 1u];
+                    if (ch == ' ' || ch == '\r' || ch == '\n' || ch == '\t' || ch == '\v' || ch == '\f')
+                        --re;
+                    else
+                        break;
+                }
+            a.lmeta[i] = qn;
+            a.lsubj[i] = dtok_subject(a, rb, re - rb);
+            return;
+        }
+    }
     // the first three (six) tabs
     constexpr int kTabs = kEx ? 6 : 3;
     uint32_t tab[kTabs];
@@ -219,33 +294,7 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
     const uint32_t mate = (flag >> 6) & 3u;
     if (mate == 3u) atomicOr(&a.state->flags, kDtokBothMates);
     a.lmeta[i] = qn | (mate << 28);
-    // dictionary
-    const unsigned long long hv = dtok_hash(a.text + rb, rn);
-    uint32_t h = (uint32_t)hv & a.dict_mask;
-    int32_t id = kLineUnknown;
-    for (;;) {
-        const DictSlot s = a.dict[h];
-        if (s.id < 0) break;
-        if (s.hash == hv) {
-            const unsigned char* nm = a.arena + s.off;
-            const uint32_t ln = (uint32_t)nm[0] | ((uint32_t)nm[1] << 8) | ((uint32_t)nm[2] << 16) | ((uint32_t)nm[3] << 24);
-            bool same = ln == rn;
-            for (uint32_t k = 0; same && k < rn; ++k) same = nm[4 + k] == a.text[rb + k];
-            if (same) {
-                id = s.id;
-                break;
-            }
-        }
-        h = (h + 1u) & a.dict_mask;
-    }
-    a.lsubj[i] = id;
-    if (id == kLineUnknown) {
-        const uint32_t at = atomicAdd(&a.state->n_unknown, 1u);
-        if (at < a.unknown_cap)
-            a.unknown[at] = make_uint2(rb, rn);
-        else
-            atomicOr(&a.state->flags, kDtokUnknownFull);
-    }
+    a.lsubj[i] = dtok_subject(a, rb, rn);
     if constexpr (kEx) {
         // POS: [+-]digits (anything else int() may or may not accept: the host decides)
         uint32_t p = tab[2] + 1u;

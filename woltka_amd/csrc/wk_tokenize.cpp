@@ -1688,6 +1688,21 @@ int wk_tok_sam_span(const char* buf, int64_t len, int final_block, int in_header
     return ok ? WK_OK : WK_E_STATE;
 }
 
+// The same for any format the device tokenizer takes (WK_FMT_*): no header lines
+// outside SAM.
+int wk_tok_span(int fmt, int extra, const char* buf, int64_t len, int final_block, int in_header, int64_t* begin, int64_t* stop,
+                int* in_header_after) {
+    if (!buf || len < 0 || !begin || !stop || !in_header_after || fmt < WK_FMT_SAM || fmt > WK_FMT_PAF) return WK_E_ARG;
+    bool hdr = fmt == WK_FMT_SAM && in_header != 0;
+    const char* b = buf;
+    const char* s = buf + len;
+    const bool ok = block_span(fmt, extra != 0, buf, len, final_block != 0, hdr, b, s);
+    *begin = b - buf;
+    *stop = ok ? s - buf : b - buf;
+    *in_header_after = hdr ? 1 : 0;
+    return ok ? WK_OK : WK_E_STATE;
+}
+
 // The header state wk_tok_text continues from (blocks the device tokenizer took
 // are not seen by it).
 int wk_tok_set_header_state(wk_tok* t, int in_header) {

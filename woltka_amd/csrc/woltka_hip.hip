@@ -235,6 +235,7 @@ struct wk_ctx {
     DevBuf d_textbuf[2], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
+    int dt_fmt = 0;   // WK_FMT_* of the blocks (wk_dtok_format)
     uint32_t dt_n = 0, dt_lines = 0, dt_dict_mask = 0;
     int32_t dt_dict_names = -1;  // names of the tokenizer the mirror holds
     const wk_tok* dt_dict_tok = nullptr;
@@ -2249,6 +2250,7 @@ static DtokArgs dtok_args(wk_ctx* c) {
     DtokArgs a{};
     a.text = c->d_textbuf[c->dt_cur].as<unsigned char>();
     a.n = c->dt_n;
+    a.fmt = (uint32_t)c->dt_fmt;
     a.line_start = c->d_lines.as<uint32_t>();
     a.n_lines = c->dt_lines;
     a.lsubj = c->d_lsubj.as<int32_t>();
@@ -2360,6 +2362,13 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     return WK_OK;
 }
 
+int wk_dtok_format(wk_ctx* c, int fmt) {
+    if (!c) return WK_E_ARG;
+    if (fmt != WK_FMT_SAM && fmt != WK_FMT_MAP && fmt != WK_FMT_B6O) return fail(c, WK_E_ARG, "the device tokenizer takes SAM, simple maps and BLAST tabular text");
+    c->dt_fmt = fmt;
+    return WK_OK;
+}
+
 int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int extra, int64_t* n_lines, int* status) {
     if (!c || !tok || !text || begin < 0 || stop < begin || !n_lines || !status) return WK_E_ARG;
     *status = 1;
@@ -2367,6 +2376,7 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     c->dt_ready = false;
     c->dt_extra = extra != 0;
     if (!wkx_tok_device_ok(tok)) return WK_OK;  // an exclusion set: the host tokenizer's business
+    if (extra && c->dt_fmt != WK_FMT_SAM) return WK_OK;  // (the "ex" flavour of the other formats: the host's)
     const int64_t n64 = stop - begin;
     if (n64 >= (1ll << 31) - 64) return WK_OK;
     DeviceGuard guard(c->device);
