@@ -123,6 +123,10 @@ const char* wk_build_id(void);
 /* Number of HIP devices visible to this process (0 when there is none). */
 int wk_device_count(void);
 /* Create a context on HIP device `device`.  Fails (WK_E_HIP) without a GPU. */
+/* PCI address of a device ("0000:c1:00.0") — with it a host layer finds the
+ * NUMA node the GPU hangs off (/sys/bus/pci/devices/<address>/numa_node) and
+ * keeps the process that feeds it on that node. */
+int wk_device_pci_bus_id(int device, char* buf, size_t cap);
 int wk_create(int device, wk_ctx** out);
 void wk_destroy(wk_ctx* ctx);
 const char* wk_last_error(const wk_ctx* ctx); /* ctx may be NULL */

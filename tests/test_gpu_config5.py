@@ -4,9 +4,10 @@ paired multi-hit SAM with coordinates, pass 1 = taxonomy tree + `--rank genus
 --outmap`, pass 2 = `--coords` + gene -> function maps + `--stratify` by the
 read maps of pass 1; one case with a file per sample, one multiplexed.  Tables
 and read maps must equal the reference's byte for byte — in one process, and
-with the samples sharded over two shares the way `bench.py --gpus N` /
-`torch.distributed.run` shard them over GPUs (here both shares run on the one
-device of the test box and are merged on the host)."""
+with the samples sharded over two shares the way `woltka classify --gpus N`
+shards them over GPUs (here both shares run on the one device of the test box
+and are merged on the host) — in one process, and in two started by the
+command itself."""
 import contextlib
 import gzip
 import io
@@ -35,7 +36,7 @@ def real(v, tmp, files):
     return v
 
 
-def two_passes(case, tmp):
+def two_passes(case, tmp, **more):
     files = case['files']
     for rel, text in files.items():
         fp = os.path.join(str(tmp), rel)
@@ -48,6 +49,8 @@ def two_passes(case, tmp):
     a2 = {k: real(v, tmp, files) for k, v in case['pass2'].items()}
     a2.update(output_fp=os.path.join(str(tmp), 'out2'),
               strata_dir=os.path.join(str(tmp), 'maps'))
+    a1.update(more)
+    a2.update(more)
     with contextlib.redirect_stdout(io.StringIO()):
         wf.workflow(**a1)
         wf.workflow(**a2)
@@ -76,6 +79,7 @@ def test_config5_two_shares(i, tmp_path, monkeypatch):
     """The multi-GPU path of workflow.workflow (samples -> shares -> exact
     per-share profiles -> host merge) with world = 2, both shares on this
     device one after the other."""
+    import types
     world = 2
 
     def sharded(classify_fn, files, rank, world_, gather=None, split=True):
@@ -85,12 +89,23 @@ def test_config5_two_shares(i, tmp_path, monkeypatch):
             parts.append(classify_fn(share) if share else {})
         return shard.merge_profiles(parts)
 
-    monkeypatch.setattr(wf, 'env_rank', lambda: (0, 0, world))
     monkeypatch.setattr(wf, 'classify_sharded', sharded)
-    import torch.distributed as dist
-    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    comm = types.SimpleNamespace(rank=0, local=0, world=world, kind='test',
+                                 gather=None)
     case = CASES[i]
-    t1, t2, maps = two_passes(case, tmp_path)
+    t1, t2, maps = two_passes(case, tmp_path, comm=comm)
+    assert t1 == case['expect']['table1']
+    assert maps == case['expect']['maps']
+    assert t2 == case['expect']['table2']
+
+
+@pytest.mark.parametrize('i', range(len(CASES)))
+def test_config5_two_processes_started_by_the_command(i, tmp_path):
+    """`woltka classify --gpus 2` for real: this process is rank 0, a second
+    one is started (shard.LocalWorld — multiprocessing, no torch), both on the
+    test box's one device; tables and read maps equal the reference's."""
+    case = CASES[i]
+    t1, t2, maps = two_passes(case, tmp_path, gpus=2)
     assert t1 == case['expect']['table1']
     assert maps == case['expect']['maps']
     assert t2 == case['expect']['table2']

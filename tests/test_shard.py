@@ -3,6 +3,7 @@ bundled bowtie2 samples (with the CPU oracle standing in for the device) and
 the gathered, merged profile equals the single-process one and the reference's
 golden table."""
 import io
+from fractions import Fraction
 import lzma
 import os
 
@@ -156,3 +157,102 @@ def test_byte_ranges_never_split_a_read(tmp_path, fmt):
     for n in (2, 5):
         cat = [r for i in range(n) for r in reads((i, n))]
         assert cat == whole
+
+
+def _mux_text(n_reads, samples):
+    """Multiplexed SAM: reads named <sample>_<i>, 1-3 hits each."""
+    import random
+    rnd = random.Random(9)
+    lines = ['@HD\tVN:1.0\n']
+    for i in range(n_reads):
+        s = samples[i * len(samples) // n_reads]
+        for _ in range(rnd.randint(1, 3)):
+            lines.append(f'{s}_{i}\t0\tG{rnd.randrange(30):03d}\t1\t42\t50M\t*\t0'
+                         f'\t0\t*\t*\n')
+    return ''.join(lines)
+
+
+def _count_share(share):
+    """Test-only stand-in for workflow.classify on a share that may hold
+    `FilePart` byte ranges of a multiplexed file: reads through the native
+    (host) tokenizer, `--rank none` counts by the Python oracle."""
+    import woltka_oracle as orc
+    from woltka_amd import align
+    from woltka_amd._native import Tokenizer
+    data = {'none': {}}
+    for fp, sample in share.items():
+        part = (fp.part, fp.parts) if isinstance(fp, shard.FilePart) else None
+        tok = Tokenizer(2)
+        names, pairs = [], []
+        with open(shard.file_path(fp), 'rb') as f:
+            for buf, res in align.native_sam_blocks(f, tok, 1 << 14, fmt='sam',
+                                                    want_names=True, part=part):
+                names.extend(tok.new_subjects())
+                q = Tokenizer.query_names(buf, res['qname'])
+                off = res['off'].tolist()
+                pairs.extend((q[i], {names[s] for s in
+                                     res['subj'][off[i]:off[i + 1]]})
+                             for i in range(len(q)))
+        tok.close()
+        per = {}
+        for q, subs in pairs:
+            s = q.split('_')[0] if sample is None else sample
+            per.setdefault(s, ([], []))
+            per[s][0].append(q)
+            per[s][1].append(subs)
+        for s, (qs, ss) in per.items():
+            _, counts = orc.classify_chunk(qs, ss, 'none')
+            cur = data['none'].setdefault(s, {})
+            for k, v in counts.items():
+                cur[k] = cur.get(k, 0) + Fraction(v).limit_denominator(720720)
+    return data
+
+
+def _local_entry(comm=None, files=None, out=None):
+    """What every rank of the `LocalWorld` test runs."""
+    data = shard.classify_sharded(_count_share, files, comm.rank, comm.world,
+                                  gather=comm.gather)
+    assert (data is None) == (comm.rank != 0)
+    if out is not None and data is not None:
+        out.update(data)
+
+
+@pytest.mark.timeout(300)
+def test_local_world_of_four_with_uneven_files_and_a_cut_file(tmp_path):
+    """`woltka classify --gpus 4` without a GPU: shard.start_local_world
+    (multiprocessing, no torch) over three sample files of very different sizes
+    and one large multiplexed file that is cut into byte ranges — rank 0
+    gathers what the four ranks counted, and it is what one process counts."""
+    files = {}
+    for name, n in (('A', 300), ('B', 4000), ('C', 40)):
+        fp = tmp_path / f'{name}.sam'
+        fp.write_text(_mux_text(n, [name]).replace(f'{name}_', 'r'))
+        files[str(fp)] = name
+    mux = tmp_path / 'mux.sam'
+    mux.write_text(_mux_text(60000, ['X', 'Y', 'Z']))
+    files[str(mux)] = None          # (demultiplexed by the stand-in)
+    shares = shard.partition_files(files, 4)
+    parts = [fp for sh in shares for fp in sh if isinstance(fp, shard.FilePart)]
+    assert len(parts) >= 2 and all(p.path == str(mux) for p in parts)
+    assert all(len(sh) > 0 for sh in shares)
+    comm, procs = shard.start_local_world(4, _local_entry, {'files': files})
+    out = {}
+    _local_entry(comm=comm, files=files, out=out)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    single = _count_share(files)
+    assert out == single
+    assert set(out['none']) == {'A', 'B', 'C', 'X', 'Y', 'Z'}
+
+
+def _failing_entry(comm=None):
+    raise ValueError('boom')
+
+
+def test_a_failing_rank_is_reported():
+    comm, procs = shard.start_local_world(2, _failing_entry, {})
+    with pytest.raises(RuntimeError, match='rank 1 failed: ValueError: boom'):
+        comm.gather({})
+    for p in procs:
+        p.join(60)

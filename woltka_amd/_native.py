@@ -30,7 +30,8 @@ MAX_RANK_SLOTS = MAX_JOBS * 4
 
 # every symbol the header declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    'wk_abi_version', 'wk_build_id', 'wk_device_count', 'wk_create', 'wk_destroy',
+    'wk_abi_version', 'wk_build_id', 'wk_device_count', 'wk_device_pci_bus_id',
+    'wk_create', 'wk_destroy',
     'wk_last_error',
     'wk_device_name', 'wk_sync', 'wk_set_option', 'wk_set_tree',
     'wk_build_rank_table', 'wk_get_rank_table', 'wk_set_genes',
@@ -103,6 +104,7 @@ def load_library():
         'wk_abi_version': (C.c_int, []),
         'wk_build_id': (C.c_char_p, []),
         'wk_device_count': (C.c_int, []),
+        'wk_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         'wk_create': (C.c_int, [C.c_int, C.POINTER(p)]),
         'wk_destroy': (None, [p]),
         'wk_last_error': (C.c_char_p, [p]),
@@ -266,6 +268,14 @@ def _arr(a, dtype):
 
 def _ptr(a, ctype):
     return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+def device_pci_bus_id(device):
+    """PCI address of HIP device ``device`` (e.g. '0000:c1:00.0')."""
+    buf = C.create_string_buffer(64)
+    if load_library().wk_device_pci_bus_id(int(device), buf, 64) != OK:
+        raise RuntimeError('no such HIP device')
+    return buf.value.decode()
 
 
 def decode_keys(keys):

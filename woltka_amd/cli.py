@@ -2,8 +2,9 @@
 
 Option-for-option counterpart of the reference's ``classify`` command
 (woltka/cli.py:41-199): same flags, destinations, types, defaults and help
-texts, so that ``--help`` and every existing invocation look the same.  One
-extra option, ``--device``, selects the GPU.
+texts, so that ``--help`` and every existing invocation look the same.  Two
+extra options: ``--device`` selects the GPU, ``--gpus N`` shards the samples
+over N GPUs of the node (one process each, started by this one).
 
 The options are kept as one table (flags, keyword arguments of
 ``click.option``) and attached in a loop.
@@ -79,6 +80,7 @@ OPTIONS = [
     (('--no-exe',), dict(_flag, help='Disable calling external programs for decompression.')),
     # this build only
     (('--device',), dict(type=click.INT, default=0, show_default=True, help='HIP device (GPU) to run the classification kernels on.')),
+    (('--gpus',), dict(type=click.IntRange(1, 64), default=1, show_default=True, help='Number of GPUs of this node to shard the samples over (one process per GPU).')),
 ]
 
 

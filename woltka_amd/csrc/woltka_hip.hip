@@ -688,6 +688,16 @@ int wk_device_count(void) {
 
 const char* wk_last_error(const wk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
+int wk_device_pci_bus_id(int device, char* buf, size_t cap) {
+    if (!buf || cap < 16) return fail(nullptr, WK_E_ARG, "bad arguments");
+    const hipError_t e = hipDeviceGetPCIBusId(buf, (int)cap, device);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, WK_E_HIP, "hipDeviceGetPCIBusId(%d) failed: %s", device, hipGetErrorString(e));
+    }
+    return WK_OK;
+}
+
 int wk_create(int device, wk_ctx** out) {
     if (!out) return fail(nullptr, WK_E_ARG, "out is NULL");
     *out = nullptr;

@@ -3,12 +3,17 @@
 The reference has no parallelism; its documented scale-out is "run separate
 jobs per sample subset and merge" (doc/perform.md:70-98), which works because
 ``data[rank][sample]`` depends only on that sample's records
-(woltka/workflow.py:1058).  Here one process drives one GPU
-(``torch.distributed`` launch: RANK / LOCAL_RANK / WORLD_SIZE), every process
+(woltka/workflow.py:1058).  Here one process drives one GPU, every process
 classifies its share of the alignment files with its own device context, and
 the per-process profiles — disjoint sample sets, a few KB each — are gathered
-on rank 0 through the host (gloo).  There is no device-side collective: xGMI /
-RCCL are not involved in the data path.
+on rank 0 through the host.  There is no device-side collective: xGMI / RCCL
+are not involved in the data path.
+
+Two ways to get the processes: `woltka classify --gpus N` starts them itself
+(``LocalWorld``: multiprocessing, pipes to rank 0, every rank's threads pinned
+to the NUMA node of its GPU — no PyTorch anywhere), or a launcher that sets
+RANK / LOCAL_RANK / WORLD_SIZE (``torch.distributed.run``) does, and the
+profiles are gathered with gloo (``TorchWorld``).
 """
 import os
 from os.path import isfile, splitext
@@ -113,7 +118,8 @@ def env_rank():
 
 def classify_sharded(classify_fn, files, rank, world, gather=None, split=True):
     """Run ``classify_fn(share)`` on this process's share of ``files`` and
-    merge all shares' results on every process.
+    merge all shares' results where they are gathered (every rank under
+    ``TorchWorld``, rank 0 under ``LocalWorld``; ``None`` elsewhere).
 
     ``classify_fn`` maps a files list/dict to a ``data`` dict (normally a
     ``functools.partial`` of ``workflow.classify`` bound to this process's
@@ -131,4 +137,112 @@ def classify_sharded(classify_fn, files, rank, world, gather=None, split=True):
             out = [None] * world
             dist.all_gather_object(out, obj)
             return out
-    return merge_profiles(gather(mine))
+    parts = gather(mine)
+    return None if parts is None else merge_profiles(parts)
+
+
+class LocalWorld:
+    """The ranks `woltka classify --gpus N` started itself: this process is
+    rank ``rank`` of ``world``; rank 0 holds a pipe to every other rank, the
+    others one to rank 0.  ``gather(obj)`` returns every rank's object on rank
+    0 (in rank order) and ``None`` elsewhere."""
+    kind = 'local'
+
+    def __init__(self, rank, world, conns):
+        self.rank, self.local, self.world = rank, rank, world
+        self._conns = conns
+
+    def gather(self, obj):
+        if self.rank != 0:
+            self._conns.send(('ok', obj))
+            return None
+        out = [obj]
+        for r, conn in enumerate(self._conns, 1):
+            try:
+                status, payload = conn.recv()
+            except EOFError:
+                status, payload = 'error', 'the process died'
+            if status != 'ok':
+                raise RuntimeError(f'rank {r} failed: {payload}')
+            out.append(payload)
+        return out
+
+
+class TorchWorld:
+    """Ranks started by ``torch.distributed.run`` (or any launcher that sets
+    RANK / LOCAL_RANK / WORLD_SIZE): profiles gathered with gloo on every
+    rank."""
+    kind = 'torch'
+
+    def __init__(self):
+        self.rank, self.local, self.world = env_rank()
+
+    def gather(self, obj):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group('gloo')
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+
+
+def _local_rank_main(entry, kwargs, rank, world, conn):
+    """(child process) run ``entry(**kwargs, comm=LocalWorld(...))`` with the
+    console silenced; what it raises goes to rank 0."""
+    import contextlib
+    import io
+    try:
+        os.environ['LOCAL_WORLD_SIZE'] = str(world)
+        with contextlib.redirect_stdout(io.StringIO()):
+            entry(comm=LocalWorld(rank, world, conn), **kwargs)
+    except BaseException as e:      # noqa: BLE001 - reported by rank 0
+        try:
+            conn.send(('error', f'{type(e).__name__}: {e}'))
+        except Exception:
+            pass
+    finally:
+        conn.close()
+
+
+def start_local_world(world, entry, kwargs):
+    """Start ranks 1 .. world - 1 (``multiprocessing``, spawn) running
+    ``entry(**kwargs, comm=...)``; returns (comm of rank 0, processes).
+    ``entry`` must be importable by name (a module-level function)."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    conns, procs = [], []
+    for rank in range(1, world):
+        parent, child = ctx.Pipe()
+        p = ctx.Process(target=_local_rank_main,
+                        args=(entry, kwargs, rank, world, child))
+        p.start()
+        child.close()
+        conns.append(parent)
+        procs.append(p)
+    return LocalWorld(0, world, conns), procs
+
+
+def pin_near_gpu(device):
+    """This process (its present and future threads) onto the CPUs of the NUMA
+    node its GPU hangs off — the text it reads is copied to pinned memory and
+    from there to the device: both ends on one node.  Best effort: returns the
+    CPU list, or None when the topology cannot be read."""
+    try:
+        from . import _native as nat
+        bdf = nat.device_pci_bus_id(device)
+        with open(f'/sys/bus/pci/devices/{bdf.lower()}/numa_node') as f:
+            node = int(f.read())
+        if node < 0:
+            return None
+        with open(f'/sys/devices/system/node/node{node}/cpulist') as f:
+            cpus = set()
+            for part in f.read().strip().split(','):
+                a, _, b = part.partition('-')
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return sorted(cpus)
+    except (OSError, ValueError, RuntimeError, AttributeError):
+        pass
+    return None

@@ -79,7 +79,8 @@ def workflow(
         add_lineage: bool = False, outmap_dir: str = None,
         outmap_zip: str = 'gz', outcov_dir: str = None,
         outcov_fmt: str = None, chunk: int = None, cache: int = 1024,
-        no_exe: bool = False, device: int = 0) -> dict:
+        no_exe: bool = False, device: int = 0, gpus: int = 1,
+        comm: object = None) -> dict:
     """Main classification workflow (command-line arguments in, profile out);
     same steps in the same order as the reference (workflow.py:109-159)."""
     # (the run builds millions of small containers — table rows, profile
@@ -110,15 +111,65 @@ def _workflow(input_fp, output_fp, input_fmt, input_ext, samples, demux,
               above, subok, coords_fp, overlap, strata_dir, sizes, frac, scale,
               digits, output_fmt, unassigned, name_as_id, add_rank,
               add_lineage, outmap_dir, outmap_zip, outcov_dir, outcov_fmt,
-              chunk, cache, no_exe, device):
+              chunk, cache, no_exe, device, gpus=1, comm=None):
+    # `--gpus N`: this process becomes rank 0 of N and starts the others
+    # (shard.LocalWorld: multiprocessing, no PyTorch); a launcher that set
+    # WORLD_SIZE (torch.distributed.run) is honoured as before
+    procs = []
+    if comm is None and env_rank()[2] > 1:
+        from .shard import TorchWorld
+        comm = TorchWorld()
+    elif comm is None and gpus and gpus > 1:
+        from .shard import start_local_world
+        kw = {k: v for k, v in locals().items()
+              if k not in ('comm', 'procs', 'gpus', 'TorchWorld',
+                           'start_local_world')}
+        comm, procs = start_local_world(gpus, _rank_entry, kw)
+    try:
+        return _workflow_ranked(
+            input_fp, output_fp, input_fmt, input_ext, samples, demux,
+            exclude, trimsub, nodes_fps, newick_fps, lineage_fps,
+            columns_fps, map_fps, map_rank, names_fps, ranks, uniq, major,
+            above, subok, coords_fp, overlap, strata_dir, sizes, frac, scale,
+            digits, output_fmt, unassigned, name_as_id, add_rank,
+            add_lineage, outmap_dir, outmap_zip, outcov_dir, outcov_fmt,
+            chunk, cache, no_exe, device, comm)
+    finally:
+        for p in procs:
+            p.join()
+
+
+def _rank_entry(comm=None, **kw):
+    """A rank `woltka classify --gpus N` started (shard.start_local_world)."""
+    return _workflow(gpus=1, comm=comm, **kw)
+
+
+def _workflow_ranked(input_fp, output_fp, input_fmt, input_ext, samples, demux,
+                     exclude, trimsub, nodes_fps, newick_fps, lineage_fps,
+                     columns_fps, map_fps, map_rank, names_fps, ranks, uniq,
+                     major, above, subok, coords_fp, overlap, strata_dir,
+                     sizes, frac, scale, digits, output_fmt, unassigned,
+                     name_as_id, add_rank, add_lineage, outmap_dir,
+                     outmap_zip, outcov_dir, outcov_fmt, chunk, cache, no_exe,
+                     device, comm):
     zippers = None if no_exe else {}
     samples, files, demux = parse_samples(input_fp, input_ext, samples, demux)
     exclude = parse_exclude(exclude)
     stratmap = parse_strata(strata_dir, samples)
     # (the device context comes up while the inputs below are read)
     from . import classify as _classify
-    if env_rank()[2] == 1:
+    restore = None
+    if comm is None:
         _classify.open_context_ahead(device)
+    elif comm.kind == 'local':
+        # the ranks share this node's CPUs (classify.tokenizer_threads) and
+        # each keeps to the NUMA node of its GPU
+        from . import _native as nat
+        from .shard import pin_near_gpu
+        restore = (os.environ.get('LOCAL_WORLD_SIZE'),
+                   os.sched_getaffinity(0))
+        os.environ['LOCAL_WORLD_SIZE'] = str(comm.world)
+        pin_near_gpu(comm.local % max(nat.device_count(), 1))
     try:
         return _workflow_with_context(
             samples, files, demux, exclude, stratmap, zippers, output_fp,
@@ -127,9 +178,18 @@ def _workflow(input_fp, output_fp, input_fmt, input_ext, samples, demux,
             above, subok, coords_fp, overlap, sizes, frac, scale, digits,
             output_fmt, unassigned, name_as_id, add_rank, add_lineage,
             outmap_dir, outmap_zip, outcov_dir, outcov_fmt, chunk, cache,
-            device)
+            device, comm)
     finally:
         _classify.drop_context_ahead()
+        if restore is not None:
+            if restore[0] is None:
+                os.environ.pop('LOCAL_WORLD_SIZE', None)
+            else:
+                os.environ['LOCAL_WORLD_SIZE'] = restore[0]
+            try:
+                os.sched_setaffinity(0, restore[1])
+            except OSError:
+                pass
 
 
 def _workflow_with_context(
@@ -138,7 +198,7 @@ def _workflow_with_context(
         map_fps, map_rank, names_fps, ranks, uniq, major, above, subok,
         coords_fp, overlap, sizes, frac, scale, digits, output_fmt,
         unassigned, name_as_id, add_rank, add_lineage, outmap_dir, outmap_zip,
-        outcov_dir, outcov_fmt, chunk, cache, device):
+        outcov_dir, outcov_fmt, chunk, cache, device, comm=None):
     tree, rankdic, namedic, root = build_hierarchy(
         names_fps, nodes_fps, newick_fps, lineage_fps, columns_fps, map_fps,
         map_rank, zippers)
@@ -156,25 +216,25 @@ def _workflow_with_context(
             exact=exact,
             rounding=(digits, scale_factor(scale) if scale else None, frac))
 
-    # one process per GPU under the torch.distributed launcher: alignment
-    # files (samples) shard across processes, profiles merge on the host
-    rank_, local, world = env_rank()
-    if world > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group('gloo')
+    # one process per GPU (`--gpus N`, or a launcher's RANK / WORLD_SIZE):
+    # alignment files (samples) shard across processes, profiles merge on the
+    # host
+    if comm is not None and comm.world > 1:
         from . import _native as nat
-        dev = local % max(nat.device_count(), 1)    # narrowed visibility: 0
+        dev = comm.local % max(nat.device_count(), 1)   # narrowed visibility: 0
         # one large plain file may be cut into byte ranges, unless per-sample
         # side files (read maps, coverage) are written; cells of a sample
         # that several processes saw are added as exact rationals
         data = classify_sharded(lambda share: run(share, dev, exact=True),
-                                files, rank_, world,
+                                files, comm.rank, comm.world,
+                                gather=comm.gather,
                                 split=not (outmap_dir or outcov_dir))
+        if data is None:        # (gathered on rank 0 only)
+            return None
         exact_to_numbers(data)
         for r in ranks:
             data.setdefault(r, {})
-        if rank_ != 0:
+        if comm.rank != 0:
             return data
     else:
         data = run(files, device)
