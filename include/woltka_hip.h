@@ -421,6 +421,14 @@ int wk_ordinal_match(wk_ctx* ctx);
  * staged classify chunk is not valid afterwards. */
 int wk_ordinal_count(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs);
 
+/* With wk_set_option("gene_index_pairs", 1) before wk_set_genes the gene lists
+ * of wk_ordinal_match are kept by gene table index as well (and translated to
+ * features for the classification): out[i] = index of the i-th (hit, gene)
+ * match, in the order of wk_chunk_download's features — what tells genes apart
+ * that share a feature (`--trim-sub` next to `--coords`, workflow.py:318-319)
+ * when a read map has to list the queries in the reference's order
+ * (ordinal.py:290-335). */
+int wk_ordinal_pair_genes(wk_ctx* ctx, int32_t* out, int64_t cap);
 /* The chunk staged last (wk_chunk_stage / wk_ordinal_stage) has no per-read
  * groups: every read belongs to group `group` (what WK_GROUP_UNIFORM says for
  * wk_chunk_stage). */

@@ -95,15 +95,9 @@ def test_random_cli_case(tmp_path, i):
                 rel = os.path.relpath(join(root, fn), args['outmap_dir'])
                 with gzip.open(join(root, fn), 'rt') as f:
                     maps[rel] = f.read()
-        if 'coords_fp' in case['kwargs'] and case['kwargs'].get('trimsub'):
-            # --coords --trim-sub: genes that share a trimmed id are one
-            # feature on the device, and the order in which the reference's
-            # matcher met the queries cannot be told from features alone
-            # (DESIGN §7): same lines, input order
-            assert {k: sorted(v.splitlines()) for k, v in maps.items()} == \
-                {k: sorted(v.splitlines()) for k, v in expect['maps'].items()}
-        else:
-            assert maps == expect['maps']
+        # (also under --coords --trim-sub, where genes share a trimmed id: the
+        # gene lists then carry the genes themselves, wk_ordinal_pair_genes)
+        assert maps == expect['maps']
     if case.get('want_cov'):
         got_cov = {fn: open(join(args['outcov_dir'], fn)).read()
                    for fn in sorted(os.listdir(args['outcov_dir']))}

@@ -41,6 +41,7 @@ SYMBOLS = (
     'wk_chunk_stage', 'wk_classify_staged', 'wk_classify_chunk',
     'wk_ordinal_stage', 'wk_ordinal_match', 'wk_ordinal_count',
     'wk_set_uniform_group', 'wk_chunk_download', 'wk_ordinal_hit_offsets',
+    'wk_ordinal_pair_genes',
     'wk_blob_join', 'wk_table_body', 'wk_table_rows', 'wk_host_alloc', 'wk_host_free', 'wk_host_register', 'wk_host_unregister',
     'wk_words_begin', 'wk_words_append',
     'wk_words_wait', 'wk_words_flush', 'wk_words_pending',
@@ -219,6 +220,7 @@ def load_library():
                                     C.c_int64, C.c_int32, i32p, i32p, i64p,
                                     C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_int64, i64p, i64p]),
+        'wk_ordinal_pair_genes': (C.c_int, [p, i32p, C.c_int64]),
         'wk_hier_create': (C.c_int, [C.c_int, C.POINTER(p)]),
         'wk_hier_destroy': (None, [p]),
         'wk_hier_last_error': (C.c_char_p, [p]),
@@ -652,6 +654,14 @@ class Context:
         (``chunk_download``): int32[n_hits + 1]."""
         out = np.empty(n_hits + 1, dtype=np.int32)
         self._check(self._lib.wk_ordinal_hit_offsets(
+            self._h, _ptr(out, C.c_int32), out.size))
+        return out
+
+    def ordinal_pair_genes(self, n_pairs):
+        """Gene table index of every (hit, gene) match of the staged gene
+        lists (option ``gene_index_pairs``): int32[n_pairs]."""
+        out = np.empty(n_pairs, dtype=np.int32)
+        self._check(self._lib.wk_ordinal_pair_genes(
             self._h, _ptr(out, C.c_int32), out.size))
         return out
 

@@ -431,6 +431,7 @@ class Engine:
         self._dtok_lap = {}     # (WOLTKA_DTOK_TIMING: seconds inside _run_dtok)
         self.genes = None
         self.gene_feature = None
+        self._pairs_by_index = False
         # dense subject indices (order of first appearance in the alignments)
         # -> feature ids, mirrored on the device by wk_set_subjects
         self.subjects = FeatureIndex()
@@ -914,7 +915,7 @@ class Engine:
                 ring.release(res['slot'])
 
     # ------------------------------------------------------------------
-    def set_genes(self, table, prefix, trimsub=None):
+    def set_genes(self, table, prefix, trimsub=None, read_maps=False):
         """Upload the gene tables; gene names join the feature index (genes
         that are nodes of the hierarchy keep their node id).  ``trimsub``
         (``--trim-sub`` next to ``--coords``: workflow.strip_suffix runs on the
@@ -928,6 +929,13 @@ class Engine:
                                        dtype=np.int32)
         self.genes = table
         self._gene_of_feature = None        # see _gene_indices
+        # genes that share a (trimmed) id are one feature; a read map lists
+        # the queries in the order the reference's matcher met them
+        # (`_mapper_order`), which needs the genes themselves: the device
+        # then keeps the gene lists by table index too
+        self._pairs_by_index = bool(read_maps) and \
+            np.unique(self.gene_feature).size != self.gene_feature.size
+        self.ctx.set_option('gene_index_pairs', int(self._pairs_by_index))
         self.ctx.set_genes(table.goff, table.start0, table.end,
                            self.gene_feature)
         if not self._table_fixed and 4 * len(self.index) > self.slots_reserved:
@@ -2226,7 +2234,10 @@ class Engine:
         first match.  Returns read indices, or None when the genes cannot be
         told apart (--trim-sub)."""
         genome, beg, end, _, hoff = packed
-        gi = self._gene_indices(pairs)
+        if self._pairs_by_index:
+            gi = self.ctx.ordinal_pair_genes(pairs.size).astype(np.int64)
+        else:
+            gi = self._gene_indices(pairs)
         if gi is None:
             return None
         n_hits = genome.size

@@ -304,6 +304,15 @@ __global__ void __launch_bounds__(kMatchThreads) match_write_kernel(MatchArgs a,
     }
 }
 
+// out[i] = table[idx[i]] (gene table indices -> their features)
+__global__ void __launch_bounds__(256) gather_i32_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ table,
+                                                         int64_t n, int64_t n_table, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t j = idx[i];
+    out[i] = (j >= 0 && j < n_table) ? table[j] : -1;
+}
+
 // Per-read gene offsets: the hits of a read are contiguous, so the genes of a
 // read are the concatenation of its hits' genes (union taken later by the
 // classify kernel's duplicate removal; ordinal.py:331-332 builds a set).

@@ -131,6 +131,9 @@ struct wk_ctx {
     // genes
     DevBuf gene4, g_grid, g_first, g_goff, g_shift;  // gene tables (wk_set_genes; wk_ordinal.hpp)
     bool genes_set = false;
+    bool genes_by_index = false;   // gene lists carry gene table indices (wk_ordinal_pair_genes), translated to features for the classification
+    int gene_index_opt = 0;        // asked for by the next wk_set_genes (option "gene_index_pairs")
+    DevBuf g_feature, o_pairs_feat;
     int grid_density = 2;  // grid cells per gene (rounded up to a power of two per genome)
     int32_t n_genomes = 0, n_genes = 0;
 
@@ -931,6 +934,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         c->single_blocks_per_cu = (int)value;
         return WK_OK;
     }
+    if (!strcmp(name, "gene_index_pairs")) {  // the next wk_set_genes: gene lists by gene table index (wk_ordinal_pair_genes)
+        c->gene_index_opt = value != 0;
+        return WK_OK;
+    }
     if (!strcmp(name, "range_parts")) {  // partitions of the dense gene log (a power of two; 0 = auto)
         c->range_parts_opt = (int)value;
         return WK_OK;
@@ -1062,7 +1069,7 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
             packed[4 * (size_t)i] = start0[i];
             packed[4 * (size_t)i + 1] = end[i];
             packed[4 * (size_t)i + 2] = m;
-            packed[4 * (size_t)i + 3] = gene_feature[i];
+            packed[4 * (size_t)i + 3] = c->gene_index_opt ? i : gene_feature[i];
             m = end[i] > m ? end[i] : m;
         }
     }
@@ -1100,6 +1107,8 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
     if ((rc = upload(c, c->g_first, first.data(), first.size() * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->g_goff, goff.data(), goff.size() * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->g_shift, shift.data(), shift.size()))) return rc;
+    if ((rc = upload(c, c->g_feature, gene_feature, (size_t)n_genes * 4))) return rc;
+    c->genes_by_index = c->gene_index_opt != 0;
     c->genes_set = true;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_genomes = n_genomes;
@@ -3024,6 +3033,16 @@ static int materialise_gene_lists(wk_ctx* c) {
     c->stat_pairs += (int64_t)total;
     // the per-read gene lists become the current classify chunk
     c->cur_subj = c->o_pairs.as<int32_t>();
+    if (c->genes_by_index) {  // (the lists name genes by table index: their features for the classification)
+        HIP_TRY(c, c->o_pairs_feat.reserve((size_t)(total ? total : 1) * 4));
+        if (total > 0) {
+            hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                               c->o_pairs.as<int32_t>(), c->g_feature.as<int32_t>(), (int64_t)total, (int64_t)c->n_genes,
+                               c->o_pairs_feat.as<int32_t>());
+            HIP_TRY(c, hipGetLastError());
+        }
+        c->cur_subj = c->o_pairs_feat.as<int32_t>();
+    }
     c->cur_qoff = c->o_qoff.as<int32_t>();
     c->n_reads = c->o_reads;
     c->n_records = (int64_t)total;
@@ -3061,12 +3080,24 @@ int wk_ordinal_match(wk_ctx* c) {
 
 int wk_ordinal_hit_offsets(wk_ctx* c, int32_t* poff, int64_t cap) {
     if (!c || !poff) return WK_E_ARG;
-    if (!c->chunk_valid || c->cur_subj != c->o_pairs.as<int32_t>()) return fail(c, WK_E_STATE, "no gene lists staged (wk_ordinal_match)");
+    if (!c->chunk_valid || (c->cur_subj != c->o_pairs.as<int32_t>() && c->cur_subj != c->o_pairs_feat.as<int32_t>()))
+        return fail(c, WK_E_STATE, "no gene lists staged (wk_ordinal_match)");
     if (cap < c->n_hits + 1) return fail(c, WK_E_CAPACITY, "need %lld offsets", (long long)c->n_hits + 1);
     DeviceGuard guard(c->device);
     if (c->n_hits) HIP_TRY(c, hipMemcpyAsync(poff, c->o_poff.p, (size_t)c->n_hits * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     poff[c->n_hits] = (int32_t)c->n_records;
+    return WK_OK;
+}
+
+int wk_ordinal_pair_genes(wk_ctx* c, int32_t* out, int64_t cap) {
+    if (!c || (cap > 0 && !out)) return WK_E_ARG;
+    if (!c->genes_by_index) return fail(c, WK_E_STATE, "the gene lists carry features (option gene_index_pairs before wk_set_genes)");
+    if (!c->chunk_valid || c->cur_subj != c->o_pairs_feat.as<int32_t>()) return fail(c, WK_E_STATE, "no gene lists staged (wk_ordinal_match)");
+    if (cap < c->n_records) return fail(c, WK_E_CAPACITY, "need %lld entries", (long long)c->n_records);
+    DeviceGuard guard(c->device);
+    if (c->n_records) HIP_TRY(c, hipMemcpyAsync(out, c->o_pairs.p, (size_t)c->n_records * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return WK_OK;
 }
 
@@ -3085,7 +3116,7 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     if (n_jobs < 1 || n_jobs > WK_MAX_JOBS || !jobs) return fail(c, WK_E_ARG, "n_jobs must be in [1, %d]", WK_MAX_JOBS);
     // the genes themselves are counted (rank none, one group, no size
     // normalisation): tallied per read straight from the matches
-    bool tally = c->use_tally && !c->has_group && c->slots > 0 && c->n_hits > 0 && c->o_reads > 0;
+    bool tally = c->use_tally && !c->has_group && !c->genes_by_index && c->slots > 0 && c->n_hits > 0 && c->o_reads > 0;
     for (int j = 0; j < n_jobs && tally; ++j)
         tally = jobs[j].mode == WK_MODE_NONE && !(jobs[j].flags & (WK_F_UNIQ | WK_F_SIZED));
     if (!tally) {

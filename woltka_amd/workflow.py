@@ -279,7 +279,8 @@ def classify(
                     sizes=sizes)
     ordinal = isinstance(mapper, OrdinalMapper)
     if ordinal:
-        engine.set_genes(mapper.table, mapper.prefix, trimsub)
+        engine.set_genes(mapper.table, mapper.prefix, trimsub,
+                         read_maps=rank2dir is not None)
     n = chunk or DEVICE_CHUNK
     csample, strata = False, None
     try:
