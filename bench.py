@@ -229,7 +229,7 @@ class LcaWorkload:
             # whole sample (wk_words_flush).  "words_keep": the records stay
             # for the next timed pass.
             words = packed_words(sidx, p['qoff'])
-            ctx.set_option('words_keep', 1)
+            ctx.tune('words_keep', 1)
             if not ctx.words_begin(self.jobs, 0):
                 raise RuntimeError('the job set does not take packed records')
             step = 6_000_000
@@ -310,9 +310,9 @@ class LcaFreeWorkload(LcaWorkload):
         sidx = subject_indices(self.prob)[1]
         words = packed_words(sidx, self.prob['qoff'])
         del sidx
-        ctx.set_option('words_keep', 0)
+        ctx.tune('words_keep', 0)
         ctx.counts_clear()
-        ctx.set_option('words_keep', 1)
+        ctx.tune('words_keep', 1)
         if not ctx.words_begin(self.jobs, 0):
             raise RuntimeError('the free-rank stream refused the job')
         step = 6_000_000
@@ -350,9 +350,9 @@ class LcaOptionWorkload(LcaWorkload):
         sidx = subject_indices(self.prob)[1]
         words = packed_words(sidx, self.prob['qoff'])
         del sidx
-        ctx.set_option('words_keep', 0)
+        ctx.tune('words_keep', 0)
         ctx.counts_clear()
-        ctx.set_option('words_keep', 1)
+        ctx.tune('words_keep', 1)
         if not ctx.words_begin(self.jobs, 0):
             raise RuntimeError('the per-read stream refused the job')
         step = 6_000_000
@@ -1363,7 +1363,7 @@ def run_rank(a, rank, world, local, sync):
     ctx = nat.Context(dev)
     for kv in a.opt:
         name, _, value = kv.partition('=')
-        ctx.set_option(name, int(value))
+        ctx.tune(name, int(value))
     # one sample set per GPU: different seed per rank, same shape (weak scaling)
     wl = WORKLOADS[a.workload](ctx, seed=1002 + rank, scale=a.scale)
     wl.sync()
@@ -1616,7 +1616,7 @@ def parse_args(argv=None):
                     help='passes over the staged batch per step (default: '
                          'sized for a timed region of about one second)')
     ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE',
-                    help='wk_set_option knob (measurement; results never '
+                    help='wk_tune knob (measurement; results never '
                          'depend on them)')
     ap.add_argument('--no-cpu', action='store_true',
                     help='skip the CPU baseline leg')

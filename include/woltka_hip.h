@@ -122,17 +122,27 @@ int wk_abi_version(void);
 const char* wk_build_id(void);
 /* Number of HIP devices visible to this process (0 when there is none). */
 int wk_device_count(void);
-/* Create a context on HIP device `device`.  Fails (WK_E_HIP) without a GPU. */
 /* PCI address of a device ("0000:c1:00.0") — with it a host layer finds the
  * NUMA node the GPU hangs off (/sys/bus/pci/devices/<address>/numa_node) and
  * keeps the process that feeds it on that node. */
 int wk_device_pci_bus_id(int device, char* buf, size_t cap);
+/* Create a context on HIP device `device`.  Fails (WK_E_HIP) without a GPU. */
 int wk_create(int device, wk_ctx** out);
 void wk_destroy(wk_ctx* ctx);
 const char* wk_last_error(const wk_ctx* ctx); /* ctx may be NULL */
 int wk_device_name(const wk_ctx* ctx, char* buf, size_t cap);
 int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
-/* Tuning knobs: "lds_slots" (LDS front-cache slots per workgroup, power of two
+/* Product options.  "gene_index_pairs" (0/1; takes effect at the next
+ * wk_set_genes): the gene lists of wk_ordinal_match are kept by gene table index
+ * as well (wk_ordinal_pair_genes).  Unknown names are an error. */
+int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
+
+/* ---- measurement only ---------------------------------------------------
+ * Launch shapes, ablation switches and what a benchmark needs to time repeated
+ * passes over one resident batch.  Not part of the drop-in surface: nothing in
+ * the host layer (woltka_amd/) calls it; bench.py (--opt NAME=VALUE), tools/
+ * and the tests that hold one route against another do.  Results never depend
+ * on a knob.  The knobs: "lds_slots" (LDS front-cache slots per workgroup, power of two
  * in [64, 8192]), "use_lds" (0/1), "tiled" (0/1: LDS-staged classify kernel),
  * "dense" (0/1: dense LDS bins for small id spaces), "plog" (0 off / 1 auto / 2
  * always: partitioned miss log), "plog_max_bytes", "log_parts" (0 auto, or a
@@ -159,8 +169,10 @@ int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
  * repeated passes over one resident batch), "free_sparse" (0/1: `--rank free` on
  * chunks of subject indices looks the LCA up in a sparse table over the
  * subjects instead of walking up the tree).
- * Results never depend on them. */
-int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
+ * "streams" (0: the packed records of all slices of the subject table in one
+ * stream, round 3's team kernel), "range_parts" (partitions of the dense gene
+ * log; 0 = as few as the merge's LDS array allows). */
+int wk_tune(wk_ctx* ctx, const char* name, int64_t value);
 
 /* ---- static state ------------------------------------------------------ */
 /* Flattened hierarchy (replaces the `tree`/`rankdic` dicts produced by

@@ -8,7 +8,7 @@ checked at that size:
     over the table = (reads with a gene) x L, and that number of reads equals
     the statistics' `n_reads`;
   * the first 1/16 of the reads give the same table (a) through the gene-list
-    route (match_write + the generic evaluator, wk_set_option("tally", 0)) and
+    route (match_write + the generic evaluator, wk_tune("tally", 0)) and
     (b) from the C oracle's end-point sweep (oracle/oracle.c: ordinal.
     match_read_gene, ordinal.py:476-582) + rank-none counter.
 """
@@ -53,12 +53,12 @@ def test_one_count_over_107M_hits():
         tables = []
         for tally in (1, 0):
             c.counts_clear()
-            c.set_option('tally', tally)
+            c.tune('tally', tally)
             c.ordinal_stage(*part, 0.8)
             c.set_uniform_group(0)
             c.ordinal_count(jobs)
             tables.append(nat.canonical_counts(*c.counts_fetch()))
-        c.set_option('tally', 1)
+        c.tune('tally', 1)
         assert np.array_equal(tables[0][0], tables[1][0])
         assert np.array_equal(tables[0][1], tables[1][1])
     ph, pg = c_oracle.ordinal_match(p['genome_off'], p['gstart'], p['gend'],

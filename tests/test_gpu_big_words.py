@@ -88,7 +88,7 @@ def test_one_launch_over_250M_records():
         c.words_append(words[:e], m)
         a = nat.canonical_counts(*c.counts_fetch())
         c.counts_clear()
-        c.set_option('weigh', 0)
+        c.tune('weigh', 0)
         c.chunk_stage(sidx[:e], qoff[:m + 1], group=0, subj_is_set=True,
                       indexed=True)
         c.classify_staged(jobs)
@@ -108,7 +108,7 @@ def test_above_major_uniq_at_50M_records(flags, major):
     tables = []
     for split in (1, 0):
         with nat.Context(0) as c:
-            c.set_option('split', split)
+            c.tune('split', split)
             c.set_tree(h.parent, h.last, h.rank_code)
             jobs = []
             for slot, rank in enumerate(('phylum', 'genus')):

@@ -3,7 +3,7 @@
 subjects of the tree, the LCA of a read is the smaller of two entries of a
 sparse table over the LCAs of rank-adjacent subjects) against the C oracle
 (find_lca by lineages, oracle/oracle.c) and against the walk
-(wk_set_option("free_sparse", 0)): bit-exact count tables, statistics and
+(wk_tune("free_sparse", 0)): bit-exact count tables, statistics and
 per-read assignments.  Covers --subok / --unassigned, free next to given
 ranks (with and without room for the extra row column), subjects outside the
 tree, reads whose LCA is the root, several subjects with one feature, a change
@@ -49,7 +49,7 @@ def _run(ctx, prob, specs, group=None, seed=1, is_set=True, dup_subjects=0):
     okeys, ocnt = np.unique(contrib, return_counts=True)
     try:
         for sparse in (1, 0):
-            ctx.set_option('free_sparse', sparse)
+            ctx.tune('free_sparse', sparse)
             ctx.counts_clear()
             ctx.reset_stats()
             assign = ctx.classify_chunk(jobs, subj, prob['qoff'], group=group,
@@ -61,7 +61,7 @@ def _run(ctx, prob, specs, group=None, seed=1, is_set=True, dup_subjects=0):
             st = ctx.stats()
             assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
     finally:
-        ctx.set_option('free_sparse', 1)
+        ctx.tune('free_sparse', 1)
 
 
 def _free(flags=0):

@@ -4,7 +4,7 @@ genes tallied per read straight from the matches, wk_ordinal.hpp) against
   * the C oracle (ordinal.match_read_gene's end-point sweep + the rank-none
     counter, oracle/oracle.c), and
   * the long way through gene lists and the generic evaluator
-    (wk_set_option("tally", 0)): whole count table and statistics equal.
+    (wk_tune("tally", 0)): whole count table and statistics equal.
 
 Inputs cover what the tally hands back to the generic evaluator (hits with
 more than two genes, reads with more than 8 distinct genes or more than 16
@@ -104,14 +104,14 @@ def oracle_counts(p, th, n_jobs=1, group=0):
 def test_tally_vs_oracle_and_gene_lists(ctx, th, density, in_lds):
     rng = np.random.default_rng(1000 + int(th * 10) + density)
     p = piled_problem(rng)
-    ctx.set_option('grid_density', density)
-    ctx.set_option('match_lds', in_lds)
+    ctx.tune('grid_density', density)
+    ctx.tune('match_lds', in_lds)
     ctx.set_genes(p['genome_off'], p['gstart'], p['gend'], p['gene_feature'])
     ctx.counts_reserve(1 << 18)
     jobs = [nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)]
     res = []
     for tally in (1, 0):
-        ctx.set_option('tally', tally)
+        ctx.tune('tally', tally)
         ctx.counts_clear()
         ctx.reset_stats()
         ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
@@ -140,7 +140,7 @@ def test_tally_two_jobs_and_plain_reads(ctx):
             nat.Job(nat.MODE_NONE, 0, nat.F_UNASSIGNED, 0, 0.0)]
     res = []
     for tally in (1, 0):
-        ctx.set_option('tally', tally)
+        ctx.tune('tally', tally)
         ctx.counts_clear()
         ctx.reset_stats()
         ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],

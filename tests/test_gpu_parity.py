@@ -162,7 +162,7 @@ def test_golden_ordinal(ctx):
 
 def _device_vs_oracle(ctx, prob, specs, lds=True):
     h = prob['hier']
-    ctx.set_option('use_lds', int(lds))
+    ctx.tune('use_lds', int(lds))
     if h is not None:
         ctx.set_tree(h.parent, h.last, h.rank_code)
     jobs = device_jobs(ctx, specs)
@@ -220,18 +220,18 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
                  dict(dense=1, plog=1, split=0, subject_bins=1, log_parts=0,
                       plog_max_bytes=4 << 30, count_kernel=1)):
         for k, v in opts.items():
-            ctx.set_option(k, v)
+            ctx.tune(k, v)
         ctx.counts_clear()
         ctx.classify_staged(jobs)
         keys3, vals3 = ctx.counts_fetch()
         assert_same_counts(keys3, vals3, okeys, ocnt, opts)
-    ctx.set_option('dense', 1)
-    ctx.set_option('plog', 1)
-    ctx.set_option('plog_max_bytes', 4 << 30)
-    ctx.set_option('log_parts', 0)
-    ctx.set_option('count_kernel', 1)
+    ctx.tune('dense', 1)
+    ctx.tune('plog', 1)
+    ctx.tune('plog_max_bytes', 4 << 30)
+    ctx.tune('log_parts', 0)
+    ctx.tune('count_kernel', 1)
     # per-read assignments and statistics through the forced split
-    ctx.set_option('split', 2)
+    ctx.tune('split', 2)
     ctx.counts_clear()
     ctx.reset_stats()
     assign4 = ctx.classify_staged(jobs, want_assign=True)
@@ -241,8 +241,8 @@ def _device_vs_oracle(ctx, prob, specs, lds=True):
     st = ctx.stats()
     assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
     assert st['n_records'] == prob['subj'].size
-    ctx.set_option('split', 1)
-    ctx.set_option('use_lds', 1)
+    ctx.tune('split', 1)
+    ctx.tune('use_lds', 1)
 
 
 ALL_SPECS = [
@@ -279,11 +279,11 @@ def test_tiny_lds_cache_overflows_to_hbm(ctx):
     rng = np.random.default_rng(7)
     prob = synth.lca_problem(rng, n_nodes=20000, n_subjects=4000,
                              n_reads=100000, dup_frac=0.05, offtree_frac=0.0)
-    ctx.set_option('lds_slots', 64)
+    ctx.tune('lds_slots', 64)
     try:
         _device_vs_oracle(ctx, prob, ALL_SPECS + _rank_specs(prob['hier']))
     finally:
-        ctx.set_option('lds_slots', 8192)
+        ctx.tune('lds_slots', 8192)
 
 
 def test_tiled_kernel_vs_oracle(ctx):
@@ -292,13 +292,13 @@ def test_tiled_kernel_vs_oracle(ctx):
     prob = synth.lca_problem(rng, n_nodes=30000, n_subjects=3000,
                              n_reads=200000, dup_frac=0.1, offtree_frac=0.02,
                              with_group=True, max_hits=40)
-    ctx.set_option('tiled', 1)
-    ctx.set_option('lds_slots', 2048)
+    ctx.tune('tiled', 1)
+    ctx.tune('lds_slots', 2048)
     try:
         _device_vs_oracle(ctx, prob, ALL_SPECS + _rank_specs(prob['hier']))
     finally:
-        ctx.set_option('tiled', 0)
-        ctx.set_option('lds_slots', 8192)
+        ctx.tune('tiled', 0)
+        ctx.tune('lds_slots', 8192)
 
 
 def test_flat_histogram_vs_oracle(ctx):
@@ -465,12 +465,12 @@ def test_full_size_mixed_chunk_through_the_split(ctx):
     okeys, ocnt = np.unique(contrib, return_counts=True)
     assert_same_counts(keys, vals, okeys, ocnt)
     # the single-pass kernel gives the same table
-    ctx.set_option('split', 0)
+    ctx.tune('split', 0)
     try:
         ctx.classify_staged(jobs)
         keys2, vals2 = ctx.counts_fetch()
     finally:
-        ctx.set_option('split', 1)
+        ctx.tune('split', 1)
     assert_same_counts(keys2, vals2, okeys, 2 * ocnt)
 
 
@@ -483,11 +483,11 @@ def test_hot_subject_bins_vs_oracle(ctx):
                              n_reads=400000, dup_frac=0.0, offtree_frac=0.0)
     specs = ALL_SPECS[:2] + _rank_specs(prob['hier'])[:3]
     _device_vs_oracle(ctx, prob, specs)
-    ctx.set_option('hot_bins', 0)
+    ctx.tune('hot_bins', 0)
     try:
         _device_vs_oracle(ctx, prob, specs)
     finally:
-        ctx.set_option('hot_bins', 1)
+        ctx.tune('hot_bins', 1)
 
 
 def _as_sets(prob, rng, big_reads=0):

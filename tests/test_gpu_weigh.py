@@ -36,7 +36,7 @@ def _run(ctx, prob, specs, group=None, order=None, weigh=2):
     _, contrib = c_oracle.classify(prob['subj'], prob['qoff'], ojobs,
                                    h.parent, h.rank_code, 0, ogroup)
     okeys, ocnt = np.unique(contrib, return_counts=True)
-    ctx.set_option('weigh', weigh)
+    ctx.tune('weigh', weigh)
     try:
         for rep in range(2):        # twice: the wrap counters must come back clean
             ctx.counts_clear()
@@ -49,7 +49,7 @@ def _run(ctx, prob, specs, group=None, order=None, weigh=2):
             assert st['n_reads'] == int((np.diff(prob['qoff']) > 0).sum())
             assert st['n_records'] == prob['subj'].size
     finally:
-        ctx.set_option('weigh', 1)
+        ctx.tune('weigh', 1)
 
 
 def _plain_specs(h, unassigned=False):
@@ -121,14 +121,14 @@ def test_weigh_index_outside_table_is_reported(ctx):
     ctx.counts_reserve(1 << 16)
     sidx = sidx.astype(np.int32)
     sidx[12345] = feats.size + 3
-    ctx.set_option('weigh', 2)
+    ctx.tune('weigh', 2)
     try:
         ctx.classify_chunk(jobs, sidx, prob['qoff'], subj_is_set=True,
                            indexed=True)
         with pytest.raises(ValueError):
             ctx.counts_fetch()
     finally:
-        ctx.set_option('weigh', 1)
+        ctx.tune('weigh', 1)
         ctx.counts_clear()
 
 
@@ -147,7 +147,7 @@ def test_weigh_auto_equals_generic(ctx):
     ctx.counts_reserve(1 << 20)
     tables = []
     for w in (1, 0):
-        ctx.set_option('weigh', w)
+        ctx.tune('weigh', w)
         ctx.counts_clear()
         ctx.profile_kernels(True)
         ctx.classify_chunk(jobs, sidx.astype(np.int32), prob['qoff'],
@@ -156,7 +156,7 @@ def test_weigh_auto_equals_generic(ctx):
             assert ctx.last_kernel_ms('weigh_merge') > 0   # the path was taken
         ctx.profile_kernels(False)
         tables.append(ctx.counts_fetch())
-    ctx.set_option('weigh', 1)
+    ctx.tune('weigh', 1)
     assert_same_counts(*tables[0], *tables[1])
 
 

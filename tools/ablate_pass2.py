@@ -10,7 +10,7 @@ from woltka_amd import _native as nat  # noqa: E402
 ctx = nat.Context(0)
 wl = bench.WORKLOADS['flat'](ctx, 1002, 1.0)
 for abl in (0, 32, 64, 96, 128, 192):
-    ctx.set_option('ablate', abl)
+    ctx.tune('ablate', abl)
     for _ in range(3):
         wl.step()
     ctx.sync()

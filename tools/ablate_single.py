@@ -10,9 +10,9 @@ from woltka_amd import _native as nat  # noqa: E402
 
 ctx = nat.Context(0)
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'flat'](ctx, 1002, 1.0)
-ctx.set_option('split', 2)
+ctx.tune('split', 2)
 for abl in (0, 1, 2, 3, 8, 10):
-    ctx.set_option('ablate', abl)
+    ctx.tune('ablate', abl)
     for _ in range(3):
         wl.step()
     ctx.sync()

@@ -12,10 +12,10 @@ ctx = nat.Context(0)
 wl = bench.WORKLOADS[sys.argv[1]](ctx, 1002, float(sys.argv[2]))
 for o in sys.argv[3:]:
     k, v = o.split('=')
-    ctx.set_option(k, int(v))
+    ctx.tune(k, int(v))
 fams = ('classify', 'leftover', 'partition_merge', 'dense_merge', 'match_count', 'match_write')
 for abl in (0, 1, 16, 17, 8):
-    ctx.set_option('ablate', abl)
+    ctx.tune('ablate', abl)
     for _ in range(2):
         wl.step()
     ctx.sync()

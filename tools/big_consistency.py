@@ -18,7 +18,7 @@ wl = bench.WORKLOADS['lca'](ctx, 1003, scale)
 print(f'{wl.records} records, {wl.reads} reads staged in {time.time() - t0:.0f} s', flush=True)
 tables = []
 for split in (1, 0):
-    ctx.set_option('split', split)
+    ctx.tune('split', split)
     ctx.counts_clear()
     ctx.reset_stats()
     t0 = time.time()

@@ -15,9 +15,9 @@ free = bench.LcaFreeWorkload(ctx, 0, 1.0, share=wl)
 shapes = [  # (threads, cache slots, workgroups per CU)
     (1024, 8192, 1), (1024, 4096, 2), (1024, 2048, 2), (512, 4096, 3), (512, 2048, 4), (256, 1024, 6)]
 for threads, slots, per_cu in shapes:
-    ctx.set_option('free_per_cu', per_cu)
-    ctx.set_option('free_threads', threads)
-    ctx.set_option('free_slots', slots)
+    ctx.tune('free_per_cu', per_cu)
+    ctx.tune('free_threads', threads)
+    ctx.tune('free_slots', slots)
     for _ in range(3):
         free.step()
     free.sync()

@@ -11,7 +11,7 @@ ctx = nat.Context(0)
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'flat'](ctx, 1002, float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
 for o in sys.argv[3:]:
     k, v = o.split('=')
-    ctx.set_option(k, int(v))
+    ctx.tune(k, int(v))
 for _ in range(5):
     wl.step()
 ctx.sync()

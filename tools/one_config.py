@@ -17,7 +17,7 @@ ctx = nat.Context(0)
 wl = bench.WORKLOADS[a.workload](ctx, 1002, a.scale)
 for o in a.opt:
     k, v = o.split('=')
-    ctx.set_option(k, int(v))
+    ctx.tune(k, int(v))
 for _ in range(a.steps):
     wl.step()
 ctx.sync()

@@ -12,7 +12,7 @@ from woltka_amd import _native as nat  # noqa: E402
 ctx = nat.Context(0)
 wl = bench.OrdinalWorkload(ctx, 1002, float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
 for flag in (1, 0, 1):
-    ctx.set_option('range_log', flag)
+    ctx.tune('range_log', flag)
     for _ in range(3):
         wl.step()
     wl.sync()

@@ -12,7 +12,7 @@ for scale in (0.1, 0.25, 0.5, 1.0, 2.0, 4.0):
     ctx = nat.Context(0)
     wl = bench.WORKLOADS[wlname](ctx, 1002, scale)
     for k, v in opts:
-        ctx.set_option(k, int(v))
+        ctx.tune(k, int(v))
     for _ in range(3):
         wl.step()
     ctx.sync()

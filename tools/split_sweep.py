@@ -22,9 +22,9 @@ configs = [dict(split=0), dict(split=2, single_blocks_per_cu=1),
            dict(split=2, single_blocks_per_cu=4, threads=256),
            dict(split=2, single_blocks_per_cu=8, threads=256)]
 for cfg in configs:
-    ctx.set_option('threads', 1024)
+    ctx.tune('threads', 1024)
     for k, v in cfg.items():
-        ctx.set_option(k, v)
+        ctx.tune(k, v)
     for _ in range(3):
         wl.step()
     ctx.sync()

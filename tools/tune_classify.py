@@ -25,8 +25,8 @@ def main():
     ctx = nat.Context(0)
     wl = bench.WORKLOADS[a.workload](ctx, 1002, a.scale)
     ctx.profile_kernels(True)
-    ctx.set_option('ablate', a.ablate)
-    ctx.set_option('dense', a.dense)
+    ctx.tune('ablate', a.ablate)
+    ctx.tune('dense', a.dense)
     print(f'workload {wl.name}: {wl.records} records, {wl.alg_bytes / 1e6:.1f} MB algorithmic')
     cfgs = []
     for tiled in ((1, 0) if a.tiled < 0 else (a.tiled,)):
@@ -37,10 +37,10 @@ def main():
                 cfgs.append((tiled, slots, threads, bpc))
     for tiled, slots, threads, bpc in cfgs:
             if True:
-                ctx.set_option('tiled', tiled)
-                ctx.set_option('lds_slots', slots)
-                ctx.set_option('threads', threads)
-                ctx.set_option('blocks_per_cu', bpc)
+                ctx.tune('tiled', tiled)
+                ctx.tune('lds_slots', slots)
+                ctx.tune('threads', threads)
+                ctx.tune('blocks_per_cu', bpc)
                 ctx.counts_clear()
                 ts = []
                 for _ in range(a.reps):

@@ -13,9 +13,9 @@ wl = bench.WORKLOADS[wlname](ctx, 1002, 1.0)
 for threads, per_cu, slots in ((1024, 1, 8192), (1024, 1, 4096), (512, 2, 4096),
                                (512, 2, 2048), (512, 1, 8192), (256, 4, 2048),
                                (256, 4, 1024), (768, 1, 8192)):
-    ctx.set_option('threads', threads)
-    ctx.set_option('blocks_per_cu', per_cu)
-    ctx.set_option('lds_slots', slots)
+    ctx.tune('threads', threads)
+    ctx.tune('blocks_per_cu', per_cu)
+    ctx.tune('lds_slots', slots)
     for _ in range(2):
         wl.step()
     ctx.sync()

@@ -18,7 +18,7 @@ base = None
 for spec in sets:
     opts = dict(kv.split('=') for kv in spec.split(','))
     for k, v in opts.items():
-        ctx.set_option(k, int(v))
+        ctx.tune(k, int(v))
     for _ in range(3):
         wl.step()
     ctx.sync()

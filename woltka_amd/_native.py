@@ -33,7 +33,7 @@ SYMBOLS = (
     'wk_abi_version', 'wk_build_id', 'wk_device_count', 'wk_device_pci_bus_id',
     'wk_create', 'wk_destroy',
     'wk_last_error',
-    'wk_device_name', 'wk_sync', 'wk_set_option', 'wk_set_tree',
+    'wk_device_name', 'wk_sync', 'wk_set_option', 'wk_tune', 'wk_set_tree',
     'wk_build_rank_table', 'wk_get_rank_table', 'wk_set_genes',
     'wk_set_subjects',
     'wk_counts_reserve', 'wk_counts_clear', 'wk_counts_fetch',
@@ -112,6 +112,7 @@ def load_library():
         'wk_device_name': (C.c_int, [p, C.c_char_p, C.c_size_t]),
         'wk_sync': (C.c_int, [p]),
         'wk_set_option': (C.c_int, [p, C.c_char_p, C.c_int64]),
+        'wk_tune': (C.c_int, [p, C.c_char_p, C.c_int64]),
         'wk_set_tree': (C.c_int, [p, i32p, i32p, i32p, C.c_int32]),
         'wk_build_rank_table': (C.c_int, [p, C.c_int32, C.c_int32]),
         'wk_get_rank_table': (C.c_int, [p, C.c_int32, i32p]),
@@ -348,6 +349,11 @@ class Context:
                                             int(value)))
 
     # -- static state -----------------------------------------------------
+    def tune(self, name, value):
+        """A measurement knob (``wk_tune``: launch shapes, ablation switches;
+        bench.py, tools/ and tests only — results never depend on them)."""
+        self._check(self._lib.wk_tune(self._h, name.encode(), int(value)))
+
     def set_tree(self, parent, last, rank_code):
         parent, last, rank_code = (_arr(parent, np.int32),
                                    _arr(last, np.int32),

@@ -847,6 +847,17 @@ int wk_sync(wk_ctx* c) {
 
 int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return WK_E_ARG;
+    if (!strcmp(name, "gene_index_pairs")) {  // the next wk_set_genes: gene lists by gene table index (wk_ordinal_pair_genes)
+        c->gene_index_opt = value != 0;
+        return WK_OK;
+    }
+    return fail(c, WK_E_ARG, "unknown option '%s' (launch shapes and ablation switches: wk_tune)", name);
+}
+
+// Launch shapes, ablation switches and what bench.py needs to time repeated passes:
+// measurement only — nothing in woltka_amd/ calls it, results never depend on it.
+int wk_tune(wk_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return WK_E_ARG;
     if (!strcmp(name, "lds_slots")) {
         if (value < 64 || value > 8192 || (value & (value - 1))) return fail(c, WK_E_ARG, "lds_slots must be a power of two in [64, 8192]");
         c->lds_slots = (int)value;
@@ -934,10 +945,6 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         c->single_blocks_per_cu = (int)value;
         return WK_OK;
     }
-    if (!strcmp(name, "gene_index_pairs")) {  // the next wk_set_genes: gene lists by gene table index (wk_ordinal_pair_genes)
-        c->gene_index_opt = value != 0;
-        return WK_OK;
-    }
     if (!strcmp(name, "range_parts")) {  // partitions of the dense gene log (a power of two; 0 = auto)
         c->range_parts_opt = (int)value;
         return WK_OK;
@@ -986,7 +993,7 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
         c->use_lds = value ? 1 : 0;
         return WK_OK;
     }
-    return fail(c, WK_E_ARG, "unknown option '%s'", name);
+    return fail(c, WK_E_ARG, "unknown tuning knob '%s'", name);
 }
 
 // ---- static state ----------------------------------------------------------
