@@ -1,0 +1,683 @@
+"""Alignment text tokenised on the device (csrc/wk_dtok.hpp): blocks read
+into pinned memory, scanned, and appended as packed records (`_run_dtok`) or
+staged as coord-match hits (`_run_dhits`); read maps formatted there
+(csrc/wk_readmap.hpp) and the strata map joined there (csrc/wk_strata.hpp).
+Blocks the kernels leave alone go through the host tokenizer (`_host_block`)."""
+import os
+import time
+from functools import partial
+from os.path import join
+
+import numpy as np
+
+from .. import _native as nat
+from ..hostio import (MAX_GROUPS, ROUTES, MapWriter, StageRing, _prefetch,
+                      tokenizer_threads)
+
+
+class DeviceTextRoute:
+    """(mixin of classify.Engine)"""
+
+    # ------------------------------------------------------------------
+    def _strata_text(self, fp, zippers, buf):
+        """The text of a read map as a uint8 array: a chain of 'WK' gzip
+        members (what `--outmap` of this package writes) is inflated on all
+        threads straight into ``buf`` (a pinned array, when it is large
+        enough); anything else is read the ordinary way."""
+        from .. import pgzip
+        from ..file import readzip_bytes
+        if fp.endswith('.gz'):
+            import mmap
+            with open(fp, 'rb') as f:
+                try:
+                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                except (OSError, ValueError):
+                    mm = None
+            if mm is not None:
+                spans = pgzip.members_of(mm)
+                if spans is not None:
+                    try:
+                        return nat.gz_inflate_members(
+                            mm, spans, out=buf,
+                            n_threads=tokenizer_threads())[0]
+                    finally:
+                        del spans
+                        mm.close()
+                mm.close()
+        with readzip_bytes(fp, zippers) as fh:
+            return np.frombuffer(fh.read(), dtype=np.uint8)
+
+    def _load_strata_device(self, fp, zippers, then):
+        """The sample's map as the device's join table; None when the kernels
+        leave it to the host's join."""
+        from os.path import basename
+        import threading
+        text = None
+        ahead, self._strata_ahead = self._strata_ahead, None
+        if ahead is not None:
+            thread, box = ahead
+            thread.join()
+            if box['fp'] == fp and 'text' in box:
+                text = box['text']
+        if text is None:
+            text = self._strata_text(fp, zippers, self._strata_buffer(fp))
+        if then is not None and then != fp:
+            box = {'fp': then}
+            buf = self._strata_buffer(then)
+
+            def work():
+                try:
+                    box['text'] = self._strata_text(then, zippers, buf)
+                except Exception:       # (read again, and raised, when asked for)
+                    pass
+            thread = threading.Thread(target=work, name='wk-strata')
+            self._strata_ahead = (thread, box)
+            thread.start()
+        got = self.ctx.strata_load(text)
+        if got is None:
+            self.ctx.strata_clear()
+            return None
+        labels, slots = got
+        if not labels:
+            raise ValueError('No stratification information is found in file: '
+                             f'{basename(fp)}.')
+        labels = [x.decode() for x in labels]
+        ROUTES['dstrata'] += 1
+        self._dstrata = {'fp': fp, 'zippers': zippers, 'labels': labels,
+                         'slots': slots, 'key': None, 'host': None}
+        return labels
+
+    def _strata_buffer(self, fp):
+        """One of two pinned buffers for a map's text (None when the map is
+        not a regular file or pinned memory is refused): sized for the largest
+        map seen so far, with room to spare."""
+        try:
+            size = os.path.getsize(fp)
+        except OSError:
+            return None
+        # (read-map text deflates 4-6x; a plain file needs its own size)
+        need = size * 8 if fp.endswith('.gz') else size
+        i = self._sbuf_next
+        self._sbuf_next ^= 1
+        buf = self._sbuf[i]
+        if buf is None or buf.size < need:
+            try:
+                buf = self.ctx.host_alloc(int(need * 1.25) + (1 << 20), np.uint8)
+            except Exception:
+                return self._sbuf[i]
+            self._sbuf[i] = buf
+        return buf
+
+    def _device_strata_groups(self, sample):
+        """The labels' (sample, stratum) group ids to the device — again after
+        every fold of the count table (the groups are numbered anew)."""
+        ds = self._dstrata
+        labels = ds['labels']
+        groups = self._strata_groups(sample, labels,
+                                     np.arange(len(labels), dtype=np.int32))
+        sig = (sample, self._epoch)
+        if ds['key'] != sig:
+            self.ctx.strata_groups(ds['slots'], groups)
+            ds['key'] = sig
+
+    def _host_strata_ids(self, ids):
+        """Stratum ids of the host tokenizer (blocks the device left to it)
+        in the numbering of the device's labels."""
+        ds = self._dstrata
+        if ds['host'] is None:
+            where = {lab: i for i, lab in enumerate(ds['labels'])}
+            ds['host'] = np.asarray([where.get(lab, -1)
+                                     for lab in ds['host_labels']],
+                                    dtype=np.int32)
+        remap = ds['host']
+        return np.where(ids >= 0, remap[np.maximum(ids, 0)], -1).astype(
+            np.int32)
+
+    def _host_strata_table(self):
+        """The host tokenizer's join table for the sample the device holds
+        (first block the device leaves to the host)."""
+        ds = self._dstrata
+        if 'host_labels' not in ds:
+            ds['host_labels'] = self._read_strata(ds['fp'], ds['zippers'],
+                                                  False)
+
+    DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
+    DTOK_READ_PIECE = int(os.environ.get('WOLTKA_READ_PIECE', 8 << 20))   # bytes per pread of the block reader's threads
+    DTOK_HEADROOM = 1 << 20     # room in front of a block's bytes for the run the block before left unfinished
+    HOSTREG_PIECE = 256 << 20   # a file is pinned in place in pieces of this size (a multiple of the page size)
+    HOSTREG_MIN = 64 << 20      # smaller files are read into pinned buffers
+    HOSTREG_RATE = 40e9         # bytes/s of the first piece's pinning below which the file is read instead
+
+    def _device_chunks(self, reader, host_block, ordinal=False):
+        """A SAM file through the tokenizer on the device (csrc/wk_dtok.hpp):
+        a helper thread reads blocks into pinned buffers (pread by its own
+        threads) and cuts them where the last run of equal query ids starts;
+        this thread has the device copy, parse and — in `_run_dtok`, once the
+        subjects the block brought are registered — group and append them.
+        Blocks the kernels leave to the host tokenizer (malformed lines, both
+        mate bits, reads of more than 16 subjects) are tokenised on the host
+        as before.  Yields what `native_chunks` yields."""
+        import queue
+        fd, size = reader
+        tok = self.tok
+        if self._reader is None:
+            self._reader = nat.Tokenizer(max(2, tokenizer_threads() // 2))
+        rd = self._reader
+        block = self.DTOK_BLOCK
+        if self._tring is None:
+            self._tring = StageRing(self.ctx, 8, {
+                'text': (np.uint8, block + self.DTOK_HEADROOM)})
+        ring = self._tring
+        free = queue.Queue()
+
+        def blocks():
+            # A slot holds [headroom | file bytes]: the bytes of a block go to
+            # a fixed place, so the reads of the next blocks can be under way
+            # (8 MB pieces on a pool of threads: ~100 GB/s from the page cache
+            # with 16 of them, tools/ubench/pread_scaling.py; one 64 MB call at
+            # a time cut among the tokenizer's threads gave 15-40) while this
+            # one is cut; the unfinished last run of the block before (the
+            # carry) is copied in front of them.
+            from collections import deque
+            from concurrent.futures import ThreadPoolExecutor
+            H = self.DTOK_HEADROOM
+            PIECE = self.DTOK_READ_PIECE
+            if self._read_pool is None:
+                self._read_pool = ThreadPoolExecutor(
+                    max_workers=max(2, tokenizer_threads() // 2))
+            pool = self._read_pool
+            pending = deque()       # (slot, buf, futures, want, file position)
+            state = {'next': 0}
+
+            def issue(span, wait):
+                want = min(span, size - state['next'])
+                if want <= 0:
+                    return False
+                bufs = ring.current() if wait else ring.try_current()
+                if bufs is None:
+                    return False
+                buf, slot = bufs['text'], ring.take()
+                mv = memoryview(buf).cast('B')
+                p0 = state['next']
+                futs = [pool.submit(os.preadv, fd,
+                                    [mv[H + o:H + min(o + PIECE, want)]], p0 + o)
+                        for o in range(0, want, PIECE)]
+                pending.append((slot, buf, futs, want, p0))
+                state['next'] = p0 + want
+                return True
+
+            carry, in_header, first = b'', True, True
+            # small blocks first while the dictionary is cold: a block's
+            # unknown subjects are listed per record and interned on the host
+            ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
+            span = ramp or block
+            try:
+                while True:
+                    if not pending and not issue(min(span, block), True):
+                        break
+                    while ramp is None and span <= block and len(pending) < 3 \
+                            and issue(block, False):
+                        pass
+                    slot, buf, futs, want, p0 = pending.popleft()
+                    t0 = time.perf_counter()
+                    got = sum(f.result() for f in futs)
+                    lap['read'] += time.perf_counter() - t0
+                    final = p0 + got >= size or got < want
+                    if len(carry) > H or span > block:
+                        # a run longer than the headroom / a block: the plain way
+                        ring.release(slot)
+                        while pending:      # (read again from here)
+                            s2, _, f2, _, _ = pending.popleft()
+                            for f in f2:
+                                f.result()
+                            ring.release(s2)
+                        want = min(span, size - p0)
+                        whole = np.empty(len(carry) + want, dtype=np.uint8)
+                        view = memoryview(whole).cast('B')
+                        view[:len(carry)] = carry
+                        got = rd.read_into(fd, p0, view[len(carry):]) \
+                            if want else 0
+                        state['next'] = p0 + got
+                        final = p0 + got >= size or got < want
+                        slot, out = None, whole[:len(carry) + got]
+                    else:
+                        start = H - len(carry)
+                        if carry:
+                            memoryview(buf).cast('B')[start:H] = carry
+                        out = buf[start:H + got]
+                    fill = out.size
+                    t0 = time.perf_counter()
+                    ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                        out, final, in_header, self._dfmt)
+                    lap['span'] += time.perf_counter() - t0
+                    if not ok and not final:    # no complete run yet: read more
+                        carry = out.tobytes()
+                        span *= 2
+                        if slot is not None:
+                            ring.release(slot)
+                        continue
+                    if ramp is not None:
+                        ramp = min(block, ramp * 4)
+                        if ramp == block:
+                            tok.warm, ramp = True, None
+                    span = ramp or block
+                    carry = b'' if final else out[stop:].tobytes()
+                    yield slot, out, fill, begin, stop, first, final, \
+                        in_header, hdr
+                    in_header, first = hdr, False
+                    if final:
+                        return
+            finally:
+                while pending:
+                    s2, _, f2, _, _ = pending.popleft()
+                    for f in f2:
+                        f.result()
+                    ring.release(s2)
+
+        # The same blocks without a copy on the host: the file mapped read-only
+        # and pinned in place piece by piece (wk_host_register), so that the
+        # device copies the text straight from the page cache.  The host then
+        # only looks at a block's ends (header lines, the last run) and at the
+        # names of subjects it has not met.
+        PIECE = self.HOSTREG_PIECE
+        mapped = {'reg': [], 'base': 0, 'done': 0}
+
+        def pieces_until(upto):
+            reg, base = mapped['reg'], mapped['base']
+            for i in range(min(len(reg), -(-upto // PIECE))):
+                if reg[i] == 0:
+                    t0 = time.perf_counter()
+                    ok = self.ctx.host_register(
+                        base + i * PIECE, min(PIECE, size - i * PIECE))
+                    lap['read'] += time.perf_counter() - t0
+                    reg[i] = 1 if ok else -1
+            done = mapped['done']               # text the device has copied
+            for i in range(min(len(reg), done // PIECE)):
+                if reg[i] == 1:
+                    self.ctx.host_unregister(base + i * PIECE)
+                    reg[i] = 2
+
+        def blocks_mapped(arr):
+            pos, in_header, first = 0, True, True
+            ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
+            span = ramp or block
+            while pos < size:
+                end = min(size, pos + span)
+                final = end >= size
+                view = arr[pos:end]
+                t0 = time.perf_counter()
+                ok, begin, stop, hdr = nat.Tokenizer.sam_span(view, final,
+                                                              in_header,
+                                                              self._dfmt)
+                lap['span'] += time.perf_counter() - t0
+                if not ok and not final:    # no complete run yet: look further
+                    span *= 2
+                    continue
+                if ramp is not None:
+                    ramp = min(block, ramp * 4)
+                    if ramp == block:
+                        tok.warm, ramp = True, None
+                span = ramp or block
+                pieces_until(pos + stop)
+                yield ('map', pos + stop), view, end - pos, begin, stop, \
+                    first, final, in_header, hdr
+                in_header, first = hdr, False
+                if final:
+                    return
+                pos += stop
+
+        def open_mapped():
+            """The file as a pinned read-only array, or None (small file, no
+            mapping, the runtime refuses: the pread route then)."""
+            if size < self.HOSTREG_MIN or os.environ.get('WOLTKA_NO_HOSTREG'):
+                return None
+            import mmap
+            try:
+                mm = mmap.mmap(fd, size, flags=mmap.MAP_SHARED,
+                               prot=mmap.PROT_READ)
+            except (OSError, ValueError):
+                return None
+            arr = np.frombuffer(mm, dtype=np.uint8)
+            mapped['base'] = arr.ctypes.data
+            mapped['reg'] = [0] * (-(-size // PIECE))
+            mapped['done'] = 0
+            t0 = time.perf_counter()
+            pieces_until(1)
+            rate = min(PIECE, size) / max(time.perf_counter() - t0, 1e-9)
+            if mapped['reg'][0] != 1:
+                mapped['reg'] = []
+                return None
+            # pinning the pages of a tmpfs file runs at ~20 GB/s, on one thread
+            # whatever the number of threads that ask (the cache of a disk
+            # file: ~160 GB/s), and unmapping it costs as much again: such a
+            # file is read into pinned buffers faster, with 2 and with 16
+            # threads (measured with 1-8 processes per box,
+            # tools/e2e_mapped_vs_pread.py, tools/ubench/host_register*.py)
+            if rate < self.HOSTREG_RATE and \
+                    not os.environ.get('WOLTKA_HOSTREG'):
+                self.ctx.host_unregister(mapped['base'])
+                mapped['reg'] = []
+                return None
+            return arr
+
+        import time
+        lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0, 'read': 0.0,
+               'span': 0.0, 'blocks': 0}
+        timing = bool(os.environ.get('WOLTKA_DTOK_TIMING'))
+
+        def one(item):
+            slot, buf, fill, begin, stop, first, final, hdr_in, hdr = item
+            try:
+                t0 = time.perf_counter()
+                status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop,
+                                                     extra=ordinal)
+                lap['scan'] += time.perf_counter() - t0
+                lap['blocks'] += 1
+                fresh = tok.new_subjects()
+                if ordinal:
+                    if fresh:       # genome indices of the gene tables
+                        gidx = self.genes.genome_index.get
+                        self._tok_genome = np.concatenate([
+                            self._tok_genome,
+                            np.fromiter((gidx(x, -1) for x in fresh),
+                                        np.int32, len(fresh))])
+                    if status == 0:
+                        if n_lines:
+                            yield None, ('dhits', (buf, fill, first, final,
+                                                   hdr_in, hdr)), \
+                                None, None, None, None
+                        tok.set_header_state(hdr)
+                    else:
+                        yield from self._host_block(
+                            buf, fill, first, final, hdr_in, True,
+                            groups=self._dstrata is not None)
+                    return
+                if fresh:
+                    base = self._tok_map.size
+                    ids = np.fromiter(map(self.subjects.intern, fresh),
+                                      np.int32, len(fresh))
+                    if self._tok_identity and not np.array_equal(
+                            ids, np.arange(base, base + ids.size)):
+                        self._tok_identity = False
+                    self._tok_map = np.concatenate([self._tok_map, ids])
+                if status == 0 and self._tok_identity:
+                    if n_lines:
+                        yield None, ('dtok', (buf, fill, first, final, hdr_in,
+                                              hdr)), None, None, None, None
+                    tok.set_header_state(hdr)
+                else:
+                    yield from self._host_block(buf, fill, first, final,
+                                                hdr_in,
+                                                names=self._dmaps is not None)
+            finally:
+                if isinstance(slot, tuple):     # (mapped: copied up to here)
+                    mapped['done'] = max(mapped['done'], slot[1])
+                elif slot is not None:
+                    ring.release(slot)
+
+        # the copy of a block's text to the device starts one block ahead:
+        # it overlaps the kernels of the block before
+        prev = None
+        t_all = time.perf_counter()
+        whole = open_mapped()
+        it = _prefetch(blocks() if whole is None else blocks_mapped(whole))
+        try:
+            while True:
+                t0 = time.perf_counter()
+                item = next(it, None)
+                lap['wait'] += time.perf_counter() - t0
+                if item is None:
+                    break
+                if item[0] is not None:         # (pinned: an asynchronous copy)
+                    t0 = time.perf_counter()
+                    self.ctx.dtok_copy(item[1], item[3], item[4])
+                    lap['copy'] += time.perf_counter() - t0
+                if prev is not None:
+                    yield from one(prev)
+                prev = item
+            if prev is not None:
+                yield from one(prev)
+        finally:
+            if whole is not None:
+                # (every copy has been waited for by the kernels of its block;
+                # a consumer that stopped early may have left one in flight)
+                t0 = time.perf_counter()
+                self.ctx.sync()
+                lap['rest'] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                for i, state in enumerate(mapped['reg']):
+                    if state == 1:
+                        self.ctx.host_unregister(mapped['base'] + i * PIECE)
+                mapped['reg'] = []
+                del whole
+                lap['unreg'] = time.perf_counter() - t0
+        if timing:
+            import sys
+            tot = time.perf_counter() - t_all
+            print('[dtok] %d blocks, %.3f s: waiting for text %.3f, copy calls '
+                  '%.3f, scan calls %.3f; reader: pread / register %.3f, span '
+                  '%.3f; last sync %.3f, unregister %.3f'
+                  % (lap['blocks'], tot, lap['wait'], lap['copy'], lap['scan'],
+                     lap['read'], lap['span'], lap['rest'],
+                     lap.get('unreg', 0.0)), file=sys.stderr)
+            print('[dtok] per block on this thread:', {
+                k: round(v, 3) for k, v in self._dtok_lap.items()},
+                file=sys.stderr)
+            self._dtok_lap = {}
+
+    def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False,
+                    names=False, groups=False):
+        """One block of the device route through the host tokenizer after
+        all (the general arrays; ``names``: with the descriptors of the query
+        names, for the read maps)."""
+        ROUTES['host_block'] += 1
+        tok = self.tok
+        tok.set_header_state(hdr_in)
+        if ordinal:
+            if groups:      # (the join of this block on the host)
+                self._host_strata_table()
+            tok.set_subject_map(self._tok_genome)
+            res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
+                            final=final, extra=True, fmt='sam',
+                            want_groups=groups)
+            fresh = tok.new_subjects()
+            if fresh:       # (names met for the first time in this block:
+                gidx = self.genes.genome_index.get      # map them, once more)
+                self._tok_genome = np.concatenate([
+                    self._tok_genome,
+                    np.fromiter((gidx(x, -1) for x in fresh), np.int32,
+                                len(fresh))])
+                tok.set_subject_map(self._tok_genome)
+                tok.set_header_state(hdr_in)
+                res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
+                                final=final, extra=True, fmt='sam',
+                                want_groups=groups)
+            if res['off'].size > 1:
+                yield None, (res['subj'], res['beg'], res['end'], res['len'],
+                             res['off']), \
+                    (self._host_strata_ids(res['group']) if groups else None), \
+                    None, None, None
+            return
+        res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
+                        final=final, fmt=self._dfmt, want_names=names)
+        fresh = tok.new_subjects()
+        if fresh:
+            ids = np.fromiter(map(self.subjects.intern, fresh), np.int32,
+                              len(fresh))
+            self._tok_map = np.concatenate([self._tok_map, ids])
+        if res['off'].size > 1:
+            subj = res['subj'] if self._tok_identity \
+                else self._tok_map[res['subj']]
+            yield None, (subj, res['off']), None, \
+                ((buf[:fill], res['qname']) if names else None), None, None
+
+    def _run_dhits(self, data, packed, sample):
+        """A block the device has scanned for the coord-match: its hits are
+        staged on the device (`wk_dtok_stage_hits`) and matched + counted like
+        a chunk of `wk_ordinal_stage`."""
+        buf, fill, first, final, hdr_in, hdr = packed[1]
+        ds = self._dstrata
+        if ds is not None:
+            if len(self.groups) + len(ds['labels']) + 1 >= MAX_GROUPS // 2:
+                self.collect(data)
+            self._ensure_table(data, 4 * (fill // 24 + 1), len(ds['labels']))
+            self._device_strata_groups(sample)
+        else:
+            self._ensure_table(data, 4 * (fill // 24 + 1), 1)
+            group = self._group_array(1, sample, None)
+        for rank in self.ranks:
+            data[rank].setdefault(sample, {})
+        if self._deferred_from is None:
+            self._deferred_from = self.ctx.stats()['n_reads']
+        status, n_reads, _ = self.ctx.dtok_stage_hits(self._tok_genome,
+                                                      self._th)
+        if status == 0:
+            ROUTES['dhits_strata' if ds is not None else 'dhits'] += 1
+            self._n_reads += n_reads
+            if n_reads:
+                if ds is None:
+                    self.ctx.set_uniform_group(group)
+                self.ctx.ordinal_count(self.jobs)
+                if self.sizes:
+                    self._collect_log()
+            return 0
+        n = 0
+        for _, arrays, ids, *_ in self._host_block(
+                buf, fill, first, final, hdr_in, True, groups=ds is not None):
+            n += self.run_chunk(data, None, None, sample, None, None, None,
+                                None, None, True, packed=arrays,
+                                strata_ids=ids,
+                                strata_labels=ds['labels'] if ds else None)
+        self.tok.set_header_state(hdr)
+        return n
+
+    def _run_dtok(self, data, packed, sample):
+        """A block the device has scanned: register the subjects it brought,
+        have the job set accepted for them, then group and append its records
+        (`wk_dtok_emit`).  If the weighted histogram cannot take the block —
+        a subject without an ancestor at a requested rank, a read of more than
+        16 subjects — the host tokenizer parses it for the general route."""
+        buf, fill, first, final, hdr_in, hdr = packed[1]
+        if (sample, None) not in self.group_ids:
+            if len(self.groups) + 1 >= MAX_GROUPS // 2:
+                self.collect(data)
+            self._ensure_table(data, max(len(self.subjects), 1 << 16) + 1, 1)
+        group = self._group_array(1, sample, None)
+        for rank in self.ranks:
+            data[rank].setdefault(sample, {})
+        lap = self._dtok_lap
+        t0 = time.perf_counter()
+        self._sync_subjects(data)
+        t1 = time.perf_counter()
+        began = self.ctx.words_begin(self.jobs, group)
+        t2 = time.perf_counter()
+        lap['subjects'] = lap.get('subjects', 0.0) + t1 - t0
+        lap['begin'] = lap.get('begin', 0.0) + t2 - t1
+        dmaps = self._dmaps
+        if began and dmaps is not None:
+            began = self._sync_map_tables(dmaps[2])
+        if began:
+            status, n_reads, _ = self.ctx.dtok_emit()
+            t3 = time.perf_counter()
+            lap['emit'] = lap.get('emit', 0.0) + t3 - t2
+            if status == 0:
+                ROUTES['dtok_maps' if dmaps is not None else 'dtok'] += 1
+                self._n_reads += n_reads
+                if dmaps is not None and n_reads:
+                    self._device_maps(sample, *dmaps)
+                    lap['maps'] = lap.get('maps', 0.0) + \
+                        time.perf_counter() - t3
+                return n_reads
+        n = 0
+        for _, (subj, qoff), _, names, *_ in self._host_block(
+                buf, fill, first, final, hdr_in, names=dmaps is not None):
+            self._sync_subjects(data)
+            if dmaps is not None:
+                n += self.run_chunk(data, None, None, sample, None, None,
+                                    dmaps[0], dmaps[1], dmaps[2], False,
+                                    packed=(subj, qoff), names=names,
+                                    packed_is_set=True)
+                continue
+            n += self.run_chunk(data, None, None, sample, None, None, None,
+                                None, None, False, packed=(subj, qoff),
+                                packed_is_set=True)
+        self.tok.set_header_state(hdr)
+        return n
+
+    def _sync_map_tables(self, namedic):
+        """The device's read-map tables (wk_readmap_tables) over the subject
+        table as it is now; False when some subject has no taxon at a rank
+        (the histogram refuses such a table too: the host route then)."""
+        n = len(self.subj_feature)
+        if n == self._dmaps_n:
+            return self._dmaps_ok
+        self._dmaps_n, self._dmaps_ok = n, False
+        feat = self._subject_features().astype(np.int64)
+        for j, mode in enumerate(self.modes):
+            if mode == nat.MODE_RANK:
+                anc = self._rank_table(self.slots[j])
+                inside = feat < self.hier.n_nodes
+                tax = np.where(inside, anc[np.where(inside, feat, 0)], -1)
+                if (tax < 0).any():
+                    return False
+            else:
+                tax = feat
+            used, slot = np.unique(tax, return_inverse=True)
+            ids = self.index.names_of(used.tolist())
+            order = np.empty(used.size, dtype=np.int32)
+            order[sorted(range(used.size), key=ids.__getitem__)] = \
+                np.arange(used.size, dtype=np.int32)
+            shown = [namedic.get(x, x) for x in ids] if namedic else ids
+            self.ctx.readmap_tables(j, slot.astype(np.int32), order,
+                                    [x.encode() for x in shown])
+        self._dmaps_ok = True
+        return True
+
+    MAP_TEXT_SLOT = 24 << 20    # bytes of a pinned buffer for a block's map text
+
+    def _device_maps(self, sample, rank2dir, outzip, namedic):
+        """The read maps of the block emitted last: text from the device
+        (wk_dtok_readmap), compressed and appended behind this thread's
+        back."""
+        if self._mring is None:
+            self._mring = StageRing(self.ctx, 6, {
+                'text': (np.uint8, self.MAP_TEXT_SLOT)})
+        if self._map_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._map_pool = ThreadPoolExecutor(max_workers=self.MAP_THREADS)
+            self._map_seq = ThreadPoolExecutor(max_workers=1)
+        if self._writer is None:
+            self._writer = MapWriter()
+        ring = self._mring
+        for j, rank in enumerate(self.ranks):
+            if rank not in rank2dir:
+                continue
+            bufs = ring.try_current()
+            while bufs is None:     # every buffer waits for its text to be written
+                self._maps_done()
+                self._writer._drain(True, one=True)
+                bufs = ring.try_current()
+            text, inside = self.ctx.dtok_readmap(j, out=bufs['text'])
+            done = None
+            if inside and text.size:
+                done = partial(ring.release, ring.take())
+            outfp = join(rank2dir[rank], f'{sample}.txt')
+            path = f'{outfp}.{outzip}' if outzip else outfp
+            # (through the sequencing thread: blocks the host formatted are
+            # appended from there too, in order)
+            self._maps_done(keep=4 * self.MAP_THREADS)
+            self._map_jobs.append(self._map_seq.submit(
+                self._writer.append, path, text, outzip, done))
+
+    def _sync_subjects(self, data):
+        """Subjects the tokenizer has met since the last call: their features
+        to the device (and room for their keys)."""
+        known = len(self.subj_feature)
+        if len(self.subjects) > known:
+            self.subj_feature.extend(self.index.intern_many(
+                self.subjects.names[known:]))
+            self.ctx.set_subjects(self.subj_feature)
+            if 4 * len(self.subjects) * len(self.jobs) > self.slots_reserved \
+                    and not self._table_fixed:
+                self.collect(data, keep_groups=True)
+                self._reserve(8 * len(self.subjects) * len(self.jobs))
