@@ -330,6 +330,16 @@ int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
 int wk_dtok_format(wk_ctx* ctx, int fmt);
 int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
                  int* status);
+/* wk_dtok_scan and wk_dtok_emit of the plain flavour with one wait instead of
+ * two: while the words of this sample are open (wk_words_begin accepted the
+ * jobs) the emission is queued right behind the parse — the usual block
+ * brings no subject the dictionary does not know — and discarded again if the
+ * parse says otherwise.  *emitted = 1: the block's records are appended
+ * (*n_reads, *n_records as wk_dtok_emit reports them); 0: the call did what
+ * wk_dtok_scan does (*status as there) and wk_dtok_emit is still to come. */
+int wk_dtok_scan_emit(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
+                      int64_t stop, int64_t* n_lines, int* status, int* emitted,
+                      int64_t* n_reads, int64_t* n_records);
 /* ---- strata map on the device (csrc/wk_strata.hpp) -------------------------
  * workflow.read_strata + the lookups of classify.counter_strat (workflow.py:
  * 912-938, file.py:368-385, classify.py:216-249) for samples the device

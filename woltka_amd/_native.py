@@ -54,7 +54,8 @@ SYMBOLS = (
     'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
     'wk_dtok_format',
     'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
-    'wk_dtok_keep_reads', 'wk_readmap_tables', 'wk_dtok_readmap',
+    'wk_dtok_scan_emit', 'wk_dtok_keep_reads', 'wk_readmap_tables',
+    'wk_dtok_readmap',
     'wk_dtok_readmap_fetch', 'wk_strata_load', 'wk_strata_labels',
     'wk_strata_groups', 'wk_strata_clear',
     'wk_tok_subjects',
@@ -193,6 +194,9 @@ def load_library():
         'wk_dtok_stage_hits': (C.c_int, [p, i32p, C.c_int32, C.c_double, i64p,
                                          i64p, C.POINTER(C.c_int)]),
         'wk_dtok_emit': (C.c_int, [p, i64p, i64p, C.POINTER(C.c_int)]),
+        'wk_dtok_scan_emit': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
+                                        i64p, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), i64p, i64p]),
         'wk_dtok_keep_reads': (C.c_int, [p, C.c_int]),
         'wk_readmap_tables': (C.c_int, [p, C.c_int32, i32p, C.c_int32, i32p,
                                         u32p, C.c_char_p, C.c_int32]),
@@ -573,6 +577,21 @@ class Context:
                                            int(stop), int(bool(extra)),
                                            C.byref(n), C.byref(st)))
         return st.value, n.value
+
+    def dtok_scan_emit(self, tok, buf, begin, stop):
+        """``dtok_scan`` + ``dtok_emit`` of the plain flavour with one wait
+        (``wk_dtok_scan_emit``).  Returns (status, n_lines, n_reads or None):
+        ``n_reads`` is a number when the block's records have been appended,
+        ``None`` when only the scan was done."""
+        raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+        n, st, em = C.c_int64(0), C.c_int(1), C.c_int(0)
+        a, b = C.c_int64(0), C.c_int64(0)
+        addr = C.c_void_p(raw.ctypes.data) if raw.size \
+            else C.cast(C.c_char_p(b''), C.c_void_p)
+        self._check(self._lib.wk_dtok_scan_emit(
+            self._h, tok._h, addr, int(begin), int(stop), C.byref(n),
+            C.byref(st), C.byref(em), C.byref(a), C.byref(b)))
+        return st.value, n.value, (a.value if em.value else None)
 
     def dtok_format(self, fmt):
         """Format of the blocks ``dtok_scan`` is given from now on: 'sam',

@@ -737,6 +737,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
     def begin_file(self):
         """A new alignment file starts: the reference's mapper chunks count
         queries per file (align.plain_mapper, align.py:84-115)."""
+        self._spec = False
         if self._replay is not None:
             self._replay_close()
             self._replay['pos'] = 0

@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -171,6 +173,7 @@ struct wk_ctx {
     hipEvent_t kt_step = nullptr;   // recorded where a timed API call starts
     hipEvent_t kt_tail = nullptr;   // last event of the chain
     int kt_depth = 0;
+    double lap_s[4] = {0, 0, 0, 0};   // (wk_tune "lap_print") seconds inside wk_dtok_copy / scan / waits of scan / emit
 
     int lds_slots = 8192;  // LDS front-cache slots per workgroup (16 B each = 128 KiB)
     int threads = 1024;    // workgroup size of the direct classify kernel
@@ -208,7 +211,7 @@ struct wk_ctx {
     DevBuf c_words;   // (per-read stream, w_mode != 0: one buffer, reads contiguous)
     // weighted histogram (w_mode 0): the records by slice of the subject table (wk_weigh.hpp), appended through device
     // cursors; unsliced (more than kMaxStreams slices) = one stream for the team kernel
-    DevBuf w_stream[kMaxStreams], w_cursor, w_stage;
+    DevBuf w_stream[kMaxStreams], w_cursor, w_stage, w_backup;
     int w_streams = 0;              // streams the open accumulation writes to
     bool w_sliced = false;
     bool w_counts_known = false;    // w_count holds the cursors' values
@@ -235,7 +238,8 @@ struct wk_ctx {
     bool slot_busy[kStageSlots] = {};
     std::vector<void*> host_blocks;      // wk_host_alloc
     // device tokenizer (wk_dtok.hpp): the block scanned last and the dictionary mirror
-    DevBuf d_textbuf[2], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
+    static constexpr int kTextBufs = 3;   // the block being scanned + two copied ahead
+    DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
     int dt_fmt = 0;   // WK_FMT_* of the blocks (wk_dtok_format)
@@ -246,12 +250,12 @@ struct wk_ctx {
     // the text of a block is copied on a stream of its own into one of two
     // buffers while the kernels work on the other (wk_dtok_copy)
     hipStream_t copy_stream = nullptr;
-    hipEvent_t copy_ev[2] = {nullptr, nullptr};
-    const char* copy_src[2] = {nullptr, nullptr};
-    DevBuf d_tiles_k[2], d_tile_off_k[2];          // newlines per tile of a block copied ahead, counted behind its copy
-    unsigned long long* copy_newlines = nullptr;   // [2] pinned: their totals
-    bool copy_counted[2] = {false, false};
-    uint32_t copy_n[2] = {0, 0};
+    hipEvent_t copy_ev[kTextBufs] = {};
+    const char* copy_src[kTextBufs] = {};
+    DevBuf d_tiles_k[kTextBufs], d_tile_off_k[kTextBufs];          // newlines per tile of a block copied ahead, counted behind its copy
+    unsigned long long* copy_newlines = nullptr;   // [kTextBufs] pinned: their totals
+    bool copy_counted[kTextBufs] = {};
+    uint32_t copy_n[kTextBufs] = {};
     int copy_next = 0, dt_cur = 0;
     // read maps formatted on the device (wk_readmap.hpp): per job the taxon slot of every subject, the slots' order
     // and shown text; per block the reads' leader lines, line lengths / offsets and the text itself
@@ -311,6 +315,13 @@ constexpr int kStatBlocks = 16384;  // >= the largest classify grid (256 CUs x 3
 
 unsigned long long* scalar_u64(wk_ctx* c, int idx) { return c->scalars.as<unsigned long long>() + idx; }
 int* scalar_err(wk_ctx* c) { return c->scalars.as<int>(); }
+
+struct Lap {
+    double* acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Lap(double* a) : acc(a) {}
+    ~Lap() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // start of an API call that times its kernels: a fresh head of the chain
 void ktimer_step(wk_ctx* c) {
@@ -810,8 +821,12 @@ void wk_destroy(wk_ctx* c) {
         for (DevBuf* b : {&T.rblocks, &T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node}) b->release();
     c->c_words.release();
     for (DevBuf& b : c->w_stream) b.release();
-    for (DevBuf* b : {&c->d_tiles_k[0], &c->d_tiles_k[1], &c->d_tile_off_k[0], &c->d_tile_off_k[1]}) b->release();
-    for (DevBuf* b : {&c->d_textbuf[0], &c->d_textbuf[1], &c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
+    for (int q = 0; q < wk_ctx::kTextBufs; ++q) {
+        c->d_tiles_k[q].release();
+        c->d_tile_off_k[q].release();
+        c->d_textbuf[q].release();
+    }
+    for (DevBuf* b : {&c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
                       &c->d_state, &c->d_dict, &c->d_arena})
         b->release();
     for (void* hp : c->host_blocks) (void)hipHostFree(hp);
@@ -943,6 +958,12 @@ int wk_tune(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_blocks_per_cu")) {
         if (value < 1 || value > 8) return fail(c, WK_E_ARG, "single_blocks_per_cu must be in [1, 8]");
         c->single_blocks_per_cu = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "lap_print")) {
+        fprintf(stderr, "[wk] seconds inside wk_dtok_copy %.3f, wk_dtok_scan(_emit) %.3f of which waiting for the stream %.3f, for the copy %.3f\n", c->lap_s[0],
+                c->lap_s[1], c->lap_s[2], c->lap_s[3]);
+        c->lap_s[0] = c->lap_s[1] = c->lap_s[2] = c->lap_s[3] = 0;
         return WK_OK;
     }
     if (!strcmp(name, "range_parts")) {  // partitions of the dense gene log (a power of two; 0 = auto)
@@ -2347,6 +2368,7 @@ int wk_host_unregister(wk_ctx* c, const void* p) {
 
 int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     if (!c || !text || begin < 0 || stop < begin) return WK_E_ARG;
+    Lap lap(&c->lap_s[0]);
     const int64_t n64 = stop - begin;
     if (n64 == 0 || n64 >= (1ll << 31) - 64) return WK_OK;
     DeviceGuard guard(c->device);
@@ -2355,12 +2377,13 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
         for (hipEvent_t& ev : c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const int k = c->copy_next;
-    c->copy_next ^= 1;
+    if (c->copy_src[k]) return fail(c, WK_E_STATE, "more than %d blocks copied ahead of the scan", wk_ctx::kTextBufs - 1);
+    c->copy_next = (c->copy_next + 1) % wk_ctx::kTextBufs;
     const uint32_t n = (uint32_t)n64;
     HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
     // (only the copy on this stream: the 64 zero bytes behind the text are a fill
     // kernel, which wk_dtok_scan launches on its own stream behind the copy's event)
-    HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, text + begin, n, c->copy_stream));
+    HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, text + begin, (size_t)n, c->copy_stream));
     // ... and, behind the copy on its stream, the count of the block's newlines:
     // wk_dtok_scan finds the number on the host instead of waiting for it
     {
@@ -2395,8 +2418,18 @@ int wk_dtok_format(wk_ctx* c, int fmt) {
     return WK_OK;
 }
 
-int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int extra, int64_t* n_lines, int* status) {
+static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* totals);
+static int dtok_emit_finish(wk_ctx* c, bool keep, bool ordered, DtokState st, unsigned long long totals, int64_t* n_reads,
+                            int64_t* n_records);
+
+// `emit` (may be null): with the words of this sample open (wk_words_begin), the emission is queued right behind the
+// parse — the usual block brings no subject the dictionary does not know — and the host waits once for both; *emit = 1
+// when the block's records have been appended that way (then emitted[0..1] = reads, records).
+static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int extra, int64_t* n_lines, int* status,
+                          int* emit, int64_t* emitted) {
     if (!c || !tok || !text || begin < 0 || stop < begin || !n_lines || !status) return WK_E_ARG;
+    if (emit) *emit = 0;
+    Lap lap(&c->lap_s[1]);
     *status = 1;
     *n_lines = 0;
     c->dt_ready = false;
@@ -2419,14 +2452,16 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     // the block's text: copied ahead by wk_dtok_copy (then the kernels only wait
     // for that copy), or copied now
     int k = -1;
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < wk_ctx::kTextBufs; ++q)
         if (c->copy_src[q] == src && c->copy_n[q] == n) k = q;
     if (k >= 0) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));
         HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
     } else {
-        k = c->copy_next;
-        c->copy_next ^= 1;
+        k = c->copy_next;  // (a buffer no block copied ahead is waiting in)
+        for (int q = 0; q < wk_ctx::kTextBufs && c->copy_src[k]; ++q) k = (k + 1) % wk_ctx::kTextBufs;
+        if (c->copy_src[k]) return fail(c, WK_E_STATE, "every text buffer holds a block copied ahead");
+        if (k == c->copy_next) c->copy_next = (c->copy_next + 1) % wk_ctx::kTextBufs;
         HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
         HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
@@ -2442,7 +2477,10 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     unsigned long long n_newlines = 0;
     const unsigned long long* tile_off = nullptr;
     if (counted) {  // (counted behind the copy: the number is on the host once the copy's event has passed)
-        HIP_TRY(c, hipEventSynchronize(c->copy_ev[k]));
+        {
+            Lap wait(&c->lap_s[3]);
+            HIP_TRY(c, hipEventSynchronize(c->copy_ev[k]));
+        }
         n_newlines = c->copy_newlines[k];
         tile_off = c->d_tile_off_k[k].as<unsigned long long>();
     } else {
@@ -2494,9 +2532,30 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
             hipLaunchKernelGGL(dtok_parse_kernel<false>, dim3((lines + kDtokThreads - 1) / kDtokThreads), dim3(kDtokThreads), 0, c->stream, a);
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
+        const bool speculate = emit && round == 0 && !extra && c->w_open && lines > 0;
+        bool ordered = false;
+        unsigned long long totals = 0;
+        if (speculate && (rc = dtok_emit_launch(c, &ordered, &totals))) return rc;
         DtokState st{};
         HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        {
+            Lap wait(&c->lap_s[2]);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (speculate) {
+            const bool keep = st.flags == 0 && st.n_unknown == 0;
+            int64_t nr = 0, nrec = 0;
+            if ((rc = dtok_emit_finish(c, keep, ordered, st, totals, &nr, &nrec))) return rc;
+            if (keep) {
+                *status = 0;
+                *n_lines = lines;
+                *emit = 1;
+                emitted[0] = nr;
+                emitted[1] = nrec;
+                c->dt_ready = false;  // (nothing left for wk_dtok_emit)
+                return WK_OK;
+            }
+        }
         if (st.flags) return WK_OK;  // status 1: the host tokenizer takes the block
         if (st.n_unknown == 0) {
             *status = 0;
@@ -2513,19 +2572,24 @@ int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_
     return fail(c, WK_E_STATE, "device tokenizer: subjects still unknown after interning them");
 }
 
-int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
-    if (!c || !n_reads || !n_records || !status) return WK_E_ARG;
-    *status = 1;
-    *n_reads = *n_records = 0;
-    if (!c->dt_ready || c->dt_extra) return fail(c, WK_E_STATE, "no block scanned for the plain flavour (wk_dtok_scan)");
-    if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
-    c->dt_ready = false;
-    if (c->dt_lines == 0) {
-        *status = 0;
-        return WK_OK;
-    }
-    DeviceGuard guard(c->device);
-    KtScope kt_scope(c);
+int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int extra, int64_t* n_lines, int* status) {
+    return dtok_scan_impl(c, tok, text, begin, stop, extra, n_lines, status, nullptr, nullptr);
+}
+
+int wk_dtok_scan_emit(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int64_t* n_lines, int* status, int* emitted,
+                      int64_t* n_reads, int64_t* n_records) {
+    if (!emitted || !n_reads || !n_records) return WK_E_ARG;
+    int64_t out[2] = {0, 0};
+    const int rc = dtok_scan_impl(c, tok, text, begin, stop, 0, n_lines, status, emitted, out);
+    *n_reads = out[0];
+    *n_records = out[1];
+    return rc;
+}
+
+// The emission of a scanned block in two halves, so that wk_dtok_scan_emit can queue it behind the parse without
+// waiting in between: `launch` queues the kernels (and, where the records are placed by prefix sums, the copy of their
+// totals), `finish` — once the stream has been waited for — accepts or discards what they wrote.
+static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* totals) {
     int rc = words_roll(c, c->dt_lines);
     if (rc) return rc;
     if ((rc = words_room(c, c->dt_lines))) return rc;
@@ -2534,8 +2598,8 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
         a.streams = stream_set(c);
         c->w_counts_known = false;
         // (a block the kernels give up on must leave the streams as they were)
-        HIP_TRY(c, c->w_stage.reserve(kMaxStreams * 8));
-        HIP_TRY(c, hipMemcpyAsync(c->w_stage.p, c->w_cursor.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, c->w_backup.reserve(kMaxStreams * 8));
+        HIP_TRY(c, hipMemcpyAsync(c->w_backup.p, c->w_cursor.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
     } else {
         a.out = c->c_words.as<uint32_t>() + c->w_records;
         a.out_cap = c->dt_lines;
@@ -2544,8 +2608,8 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
-    unsigned long long totals = 0;
     const bool ordered = c->w_mode != 0 || c->dt_keep_reads;
+    *ordered_out = ordered;
     c->dt_emitted = false;
     if (ordered) {
         // the per-read stream wants the records of a read next to each other, in
@@ -2564,34 +2628,63 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
             hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
         else
             hipLaunchKernelGGL(dtok_place_words_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
-        HIP_TRY(c, hipMemcpyAsync(&totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
     } else {
         hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     }
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
-    DtokState st{};
-    HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return WK_OK;
+}
+
+// (the stream has been waited for) `keep` false: the streams' cursors go back to where they were
+static int dtok_emit_finish(wk_ctx* c, bool keep, bool ordered, DtokState st, unsigned long long totals, int64_t* n_reads,
+                            int64_t* n_records) {
     if (ordered) {
         st.n_out = totals & 0xFFFFFFFFull;
         st.n_reads = totals >> 32;
     }
-    if (st.flags) {  // a read of more than 16 subjects: nothing counts as appended
+    if (!keep) {
         if (c->w_mode == 0) {
-            HIP_TRY(c, hipMemcpyAsync(c->w_cursor.p, c->w_stage.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->w_cursor.p, c->w_backup.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
         return WK_OK;
     }
     c->dt_emitted = c->dt_keep_reads;
     c->dt_emit_reads = (uint32_t)st.n_reads;
-    if ((rc = words_translate(c, c->w_records, (int64_t)st.n_out))) return rc;
+    const int rc = words_translate(c, c->w_records, (int64_t)st.n_out);
+    if (rc) return rc;
     c->w_records += (int64_t)st.n_out;
     c->w_reads += (int64_t)st.n_reads;
     *n_reads = (int64_t)st.n_reads;
     *n_records = (int64_t)st.n_out;
-    *status = 0;
+    return WK_OK;
+}
+
+int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
+    if (!c || !n_reads || !n_records || !status) return WK_E_ARG;
+    *status = 1;
+    *n_reads = *n_records = 0;
+    if (!c->dt_ready || c->dt_extra) return fail(c, WK_E_STATE, "no block scanned for the plain flavour (wk_dtok_scan)");
+    if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
+    c->dt_ready = false;
+    if (c->dt_lines == 0) {
+        *status = 0;
+        return WK_OK;
+    }
+    DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
+    bool ordered = false;
+    unsigned long long totals = 0;
+    int rc = dtok_emit_launch(c, &ordered, &totals);
+    if (rc) return rc;
+    DtokState st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // (a read of more than 16 subjects: nothing counts as appended)
+    if ((rc = dtok_emit_finish(c, st.flags == 0, ordered, st, totals, n_reads, n_records))) return rc;
+    if (st.flags == 0) *status = 0;
     return WK_OK;
 }
 

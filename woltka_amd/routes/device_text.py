@@ -143,6 +143,7 @@ class DeviceTextRoute:
 
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
     DTOK_READ_PIECE = int(os.environ.get('WOLTKA_READ_PIECE', 8 << 20))   # bytes per pread of the block reader's threads
+    DTOK_AHEAD = 2              # blocks copied to the device ahead of the one being scanned (wk_ctx::kTextBufs - 1)
     DTOK_HEADROOM = 1 << 20     # room in front of a block's bytes for the run the block before left unfinished
     HOSTREG_PIECE = 256 << 20   # a file is pinned in place in pieces of this size (a multiple of the page size)
     HOSTREG_MIN = 64 << 20      # smaller files are read into pinned buffers
@@ -369,8 +370,15 @@ class DeviceTextRoute:
             slot, buf, fill, begin, stop, first, final, hdr_in, hdr = item
             try:
                 t0 = time.perf_counter()
-                status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop,
-                                                     extra=ordinal)
+                done = None
+                if self._spec and not ordinal:
+                    # (the sample's words are open and the block before went
+                    # through: scan and emission with one wait)
+                    status, n_lines, done = self.ctx.dtok_scan_emit(
+                        tok, buf, begin, stop)
+                else:
+                    status, n_lines = self.ctx.dtok_scan(tok, buf, begin, stop,
+                                                         extra=ordinal)
                 lap['scan'] += time.perf_counter() - t0
                 lap['blocks'] += 1
                 fresh = tok.new_subjects()
@@ -403,9 +411,11 @@ class DeviceTextRoute:
                 if status == 0 and self._tok_identity:
                     if n_lines:
                         yield None, ('dtok', (buf, fill, first, final, hdr_in,
-                                              hdr)), None, None, None, None
+                                              hdr, done)), None, None, None, \
+                            None
                     tok.set_header_state(hdr)
                 else:
+                    self._spec = False
                     yield from self._host_block(buf, fill, first, final,
                                                 hdr_in,
                                                 names=self._dmaps is not None)
@@ -415,9 +425,11 @@ class DeviceTextRoute:
                 elif slot is not None:
                     ring.release(slot)
 
-        # the copy of a block's text to the device starts one block ahead:
-        # it overlaps the kernels of the block before
-        prev = None
+        # the copy of a block's text to the device starts two blocks ahead
+        # (three text buffers on the device): the link is never left waiting
+        # for this thread, and a block's copy is long done when its turn comes
+        from collections import deque
+        ahead = deque()
         t_all = time.perf_counter()
         whole = open_mapped()
         it = _prefetch(blocks() if whole is None else blocks_mapped(whole))
@@ -432,11 +444,11 @@ class DeviceTextRoute:
                     t0 = time.perf_counter()
                     self.ctx.dtok_copy(item[1], item[3], item[4])
                     lap['copy'] += time.perf_counter() - t0
-                if prev is not None:
-                    yield from one(prev)
-                prev = item
-            if prev is not None:
-                yield from one(prev)
+                ahead.append(item)
+                if len(ahead) > self.DTOK_AHEAD:
+                    yield from one(ahead.popleft())
+            while ahead:
+                yield from one(ahead.popleft())
         finally:
             if whole is not None:
                 # (every copy has been waited for by the kernels of its block;
@@ -453,6 +465,7 @@ class DeviceTextRoute:
                 lap['unreg'] = time.perf_counter() - t0
         if timing:
             import sys
+            self.ctx.tune('lap_print', 1)
             tot = time.perf_counter() - t_all
             print('[dtok] %d blocks, %.3f s: waiting for text %.3f, copy calls '
                   '%.3f, scan calls %.3f; reader: pread / register %.3f, span '
@@ -557,7 +570,15 @@ class DeviceTextRoute:
         (`wk_dtok_emit`).  If the weighted histogram cannot take the block —
         a subject without an ancestor at a requested rank, a read of more than
         16 subjects — the host tokenizer parses it for the general route."""
-        buf, fill, first, final, hdr_in, hdr = packed[1]
+        buf, fill, first, final, hdr_in, hdr, done = packed[1]
+        if done is not None:
+            # (scanned and appended in one call, `wk_dtok_scan_emit`)
+            dmaps = self._dmaps
+            ROUTES['dtok_maps' if dmaps is not None else 'dtok'] += 1
+            self._n_reads += done
+            if dmaps is not None and done:
+                self._device_maps(sample, *dmaps)
+            return done
         if (sample, None) not in self.group_ids:
             if len(self.groups) + 1 >= MAX_GROUPS // 2:
                 self.collect(data)
@@ -587,7 +608,11 @@ class DeviceTextRoute:
                     self._device_maps(sample, *dmaps)
                     lap['maps'] = lap.get('maps', 0.0) + \
                         time.perf_counter() - t3
+                # (from here on the blocks of this file are scanned and
+                # emitted with one wait, until one is refused)
+                self._spec = not os.environ.get('WOLTKA_NO_SPEC')
                 return n_reads
+        self._spec = False
         n = 0
         for _, (subj, qoff), _, names, *_ in self._host_block(
                 buf, fill, first, final, hdr_in, names=dmaps is not None):
