@@ -286,8 +286,9 @@ class LcaFreeWorkload(LcaWorkload):
     multi-hit read (one pass, one job)."""
     key = 'lca_free'
     packed = False
-    families = ('classify', 'free_counts')
+    families = ('classify', 'free_log', 'free_counts')
     symbols = {'classify': 'wk::free_stream_kernel',
+               'free_log': 'wk::free_log_kernel',
                'free_counts': 'wk::free_counts_kernel'}
     ranks = ('free',)
 
@@ -329,8 +330,9 @@ class LcaOptionWorkload(LcaWorkload):
     per-read stream over the packed records (csrc/wk_free.hpp, the records
     carry the subjects' ancestors at the rank), one launch per sample."""
     dominant = 'classify'
-    families = ('classify', 'free_counts')
+    families = ('classify', 'free_log', 'free_counts')
     symbols = {'classify': 'wk::free_stream_kernel',
+               'free_log': 'wk::free_log_kernel',
                'free_counts': 'wk::free_counts_kernel'}
 
     def __init__(self, ctx, option, share):

@@ -67,12 +67,24 @@ struct FreeArgs {
     uint32_t* dense;  // [n_results + 1]
     uint32_t n_results;
     unsigned long long* stat_block;
+    // results the workgroup's cache had no room for, as a list per wave: log[wave * log_cap ...], log_cnt[wave] of them
+    uint32_t* log;
+    uint32_t* log_cnt;
+    uint32_t log_cap;
 };
 
-constexpr uint32_t kFreeQueue = 128;    // per-wave queue of reads to evaluate: < 64 left over + <= 64 new
+constexpr uint32_t kFreeMiss = 128;     // per-wave ring of results on their way to the log: < 64 left over + <= 64 new
+constexpr uint32_t kFreeQueue = 256;    // per-wave queue of reads to evaluate: < 64 left over + <= 128 new
 constexpr uint32_t kFreeBlock = 256;    // records a wave loads at a time
 constexpr uint32_t kFreeAdvance = 240;  // ... of which it owns the last 240
-constexpr uint32_t kFreeWaveLds = kFreeQueue * 8 + kFreeBlock * 4 + kFreeBlock * 2;  // queue, staged block, list of read ends
+// LDS of a wave: its queue, its ring of uncached results and, under --major, the staged block
+__host__ __device__ constexpr uint32_t free_wave_lds(bool major) { return kFreeQueue * 8 + kFreeMiss * 4 + (major ? kFreeBlock * 4 : 0u); }
+
+__device__ __forceinline__ uint32_t rank_in(const uint4 b, uint32_t node) {
+    const unsigned long long bits = ((unsigned long long)b.y << 32) | b.x;
+    const uint32_t bit = node & 63u;
+    return b.z + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull));
+}
 
 __device__ __forceinline__ uint32_t rank_of(const RankBlock* __restrict__ blocks, uint32_t node) {
     const uint4 b = *reinterpret_cast<const uint4*>(blocks + (node >> 6));
@@ -84,16 +96,17 @@ __device__ __forceinline__ uint32_t rank_of(const RankBlock* __restrict__ blocks
 // A wave takes blocks of 256 records — one 16-byte load per lane, the next
 // block's issued before this one is looked at — of which it owns the last 240
 // (a read of <= 16 records lies inside the block that owns its last record), and
-// works on a block in three steps, each with the lanes on the unit that costs
-// least there (the stream is bound by vector instructions, ~1 per record now; a
-// version with one record per lane and a segmented min/max across lanes spent 8
-// cycles per record and SIMD):
-//   1. a lane looks at its own four records and marks the last records of reads;
-//      four ballots turn the marks into a list of read ends (LDS, 16-bit);
-//   2. a lane takes a read end off the list and walks back over that read's
-//      records in the staged block for the smallest and the largest id — no
-//      work shared between lanes, so none repeated — and queues what the read
-//      needs: {smallest, largest, what to do};
+// works on a block in three steps (the stream is bound by vector instructions,
+// not by its bytes):
+//   1. a lane looks at its own four records: ids, places in their reads; the
+//      smallest and largest id of the lane's last run of records of one read, and
+//      — four shuffles — what the one to four lanes before it hold of the read its
+//      first record continues (a read of <= 16 records began at most four lanes
+//      back).  Round 3 listed the read ends in LDS and had a lane walk back over
+//      each read's records there: 0.21 ms of config 3's 0.95;
+//   2. along its four records a lane keeps the running minimum and maximum and, at
+//      a record that ends a read, queues what the read needs: {smallest, largest,
+//      what to do};
 //   3. 64 queued reads at a time: the table gathers and the counting, every lane
 //      busy, as in a kernel with one read per lane but without that kernel's
 //      gathers of the reads' records.
@@ -101,11 +114,14 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long acc[2];
     // The counting: results are node ids and the job is one, so a slot of the
-    // workgroup's LDS cache is {node, reads} in 8 bytes, and what the cache cannot
-    // hold goes to a dense array of counters in HBM by a fire-and-forget atomic —
-    // no log of misses to merge afterwards.  (Tried and not faster: one array per
-    // XCD, picked by HW_REG_XCC_ID, with atomics of workgroup scope; counters
-    // indexed by node id, 8 MB, were as fast as these ~1 MB.)
+    // workgroup's LDS cache is {node, reads} in 8 bytes.  What the cache cannot
+    // hold went to a dense array of counters in HBM by a fire-and-forget atomic
+    // in round 3: 17.5 M atomics at config 3, 0.56 GB of write traffic and 0.4 of
+    // the kernel's 0.95 ms.  Now such a result is appended to a list of the
+    // wave's own — 64 at a time, one 256-byte store — and free_log_kernel counts
+    // the lists in LDS afterwards, a slice of the result ids per workgroup.
+    // (Tried and not faster than the atomics: one array per XCD, picked by
+    // HW_REG_XCC_ID, with atomics of workgroup scope.)
     uint32_t* const dense = a.dense;
     uint32_t* const ckeys = reinterpret_cast<uint32_t*>(smem);
     uint32_t* const ccnt = ckeys + lds_slots;
@@ -116,188 +132,234 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
     }
     if (threadIdx.x < 2) acc[threadIdx.x] = 0ull;
     __syncthreads();
-    auto count = [&](uint32_t node) {
-        uint32_t h = (node * 0x9E3779B1u) >> cshift;
-#pragma unroll
-        for (int probe = 0; probe < 2; ++probe) {
-            uint32_t k = ckeys[h];
-            if (k == 0xFFFFFFFFu) {
-                k = atomicCAS(&ckeys[h], 0xFFFFFFFFu, node);
-                if (k == 0xFFFFFFFFu) k = node;
-            }
-            if (k == node) {
-                atomicAdd(&ccnt[h], 1u);
-                return;
-            }
-            h = (h + 1u) & (lds_slots - 1u);
-        }
-        atomicAdd(&dense[node], 1u);
-    };
     // (plain LDS pointers: a volatile one turns the accesses into flat ones, each with a wait)
-    unsigned char* const mine = smem + (size_t)lds_slots * 8 + (size_t)(threadIdx.x >> 6) * kFreeWaveLds;
-    unsigned long long* const queue = reinterpret_cast<unsigned long long*>(mine);
-    uint32_t* const stage = reinterpret_cast<uint32_t*>(mine + kFreeQueue * 8);
-    unsigned short* const ends = reinterpret_cast<unsigned short*>(mine + kFreeQueue * 8 + kFreeBlock * 4);
+    unsigned char* const mine = smem + (size_t)lds_slots * 8 + (size_t)(threadIdx.x >> 6) * free_wave_lds(a.major > 0.0);
+    uint2* const queue = reinterpret_cast<uint2*>(mine);
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(mine + kFreeQueue * 8);
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(mine + kFreeQueue * 8 + kFreeMiss * 4);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    // entry kinds (bits 62-63): 0 = the result id itself, 1 = parent of a node, 2 = LCA of two, 3 = the node
-    constexpr unsigned long long kParent = 1ull << 62, kLca = 2ull << 62, kSelf = 3ull << 62;
-    auto evaluate = [&](uint32_t head, uint32_t n) {
-        const bool on = lane < n;
-        const unsigned long long e = on ? queue[(head + lane) & (kFreeQueue - 1)] : 0ull;
-        const uint32_t kind = (uint32_t)(e >> 62), lo = (uint32_t)e & kWordSubjMask, hi = (uint32_t)(e >> 32) & kWordSubjMask;
-        int32_t res = kind == 0u && on ? (int32_t)(uint32_t)e : -1;
-        if (kind != 0u) {
-            const uint32_t p = rank_of(a.rblocks, lo);
-            if (kind == 1u) {
-                res = a.parent_d[p];
-            } else if (kind == 3u) {
-                res = a.self_d[p];
-                if (res == 0 && hi != 0u) res = -1;  // (several records, all the root: None)
-            } else {
-                const uint32_t q = rank_of(a.rblocks, hi);
-                const uint32_t k = 31u - (uint32_t)__clz((int)(q - p));  // q > p: distinct nodes
-                const int32_t* row = a.sparse + (size_t)k * a.sparse_m;
-                const int32_t x = row[p], y = row[q - (1u << k)];
-                const int32_t anc = x < y ? x : y;
-                res = anc == 0 ? -1 : anc;
-            }
-            if (res < 0 && a.unassigned) res = (int32_t)a.n_results;
-        }
-        if (res >= 0) count((uint32_t)res);
-    };
-    // the queue, the list and the staged block are the wave's own: its LDS accesses
+    // the queue, the rings and the staged block are the wave's own: its LDS accesses
     // complete in order, the fences keep the compiler from moving them across
     auto settle = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-
+    uint32_t* const my_log = a.log + (size_t)wave0 * a.log_cap;
+    uint32_t ring_head = 0, ring_tail = 0, logged = 0;  // (wave-uniform)
+    // every lane calls; `have`: this lane has a result
+    auto count = [&](bool have, uint32_t node) {
+        bool miss = have;
+        if (have) {
+            uint32_t h = (node * 0x9E3779B1u) >> cshift;
+#pragma unroll
+            for (int probe = 0; probe < 2; ++probe) {
+                uint32_t k = ckeys[h];
+                if (k == 0xFFFFFFFFu) {
+                    k = atomicCAS(&ckeys[h], 0xFFFFFFFFu, node);
+                    if (k == 0xFFFFFFFFu) k = node;
+                }
+                if (k == node) {
+                    atomicAdd(&ccnt[h], 1u);
+                    miss = false;
+                    break;
+                }
+                h = (h + 1u) & (lds_slots - 1u);
+            }
+        }
+        const unsigned long long mm = __ballot(miss);
+        if (mm == 0ull) return;
+        if (miss) ring[(ring_tail + (uint32_t)__popcll(mm & below)) & (kFreeMiss - 1)] = node;
+        ring_tail += (uint32_t)__popcll(mm);
+        if (ring_tail - ring_head >= (uint32_t)kWave) {
+            settle();
+            my_log[logged + lane] = ring[(ring_head + lane) & (kFreeMiss - 1)];
+            ring_head += kWave;
+            logged += kWave;
+        }
+    };
+    // 64 queued reads, one per lane.  (Two per lane, with the gathers of both in
+    // flight together, needed more registers than the 64 that eight waves per SIMD
+    // leave and was slower, 0.75 against 0.65 ms at config 3; one round of gathers
+    // whatever the read needs — the node's rank block twice, two table entries —
+    // instead of the branches below: 0.70 ms.)
+    auto evaluate = [&](uint32_t head, uint32_t n) {
+        const bool on = lane < n;
+        const uint2 e = on ? queue[(head + lane) & (kFreeQueue - 1)] : make_uint2(0u, 0u);
+        const uint32_t mn = e.x & kWordSubjMask, mx = e.y & kWordSubjMask;
+        // (a missing subject carries the largest value of the field: it is the maximum)
+        // what to do: 0 = nothing to look up, 1 = parent of node lo, 2 = LCA of lo and hi, 3 = the node lo
+        uint32_t kind = 0, lo = mn, hi = mx;
+        if (a.by_rank) {
+            uint32_t to = kFreeMissing;  // where the read goes without a look at the tree
+            bool lca = false;
+            if (mn == mx) {
+                to = mn;
+            } else if (a.major > 0.0) {
+                // the only value that can reach a threshold above one half:
+                // Boyer-Moore's candidate, then its votes
+                const uint32_t at = e.x >> kWordSubjBits, size = on ? e.y >> kWordSizeShift : 0u;
+                uint32_t cand = 0, lead = 0, votes = 0;
+                for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
+                    if (i < size) {
+                        const uint32_t g = stage[at - i] & kWordSubjMask;
+                        if (lead == 0u) cand = g;
+                        lead += (g == cand) ? 1u : (uint32_t)-1;
+                    }
+                for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
+                    if (i < size) votes += ((stage[at - i] & kWordSubjMask) == cand) ? 1u : 0u;
+                if ((double)votes >= (double)size * a.major) to = cand;
+            } else if (a.above) {
+                lca = mx != kFreeMissing;
+            }
+            kind = lca ? 2u : (to != kFreeMissing ? 3u : 0u);
+            lo = lca ? mn : to;
+            hi = lca ? mx : 0u;
+        } else if (mx == kFreeMissing) {
+            kind = 0u;
+        } else if (e.y >> kWordSizeShift == 1u) {
+            kind = a.subok ? 3u : 1u;
+            hi = 0u;
+        } else if (mn != mx) {
+            kind = 2u;
+        } else {  // the same node several times (cannot happen with sets): itself, None if the root
+            kind = 3u;
+            hi = 1u;
+        }
+        int32_t res = -1;
+        if (on && kind != 0u) {
+            // (both rank blocks in one round of loads: the smallest node's again where there is no largest)
+            const uint32_t other = kind == 2u ? hi : lo;
+            const uint4 b_lo = *reinterpret_cast<const uint4*>(a.rblocks + (lo >> 6));
+            const uint4 b_hi = *reinterpret_cast<const uint4*>(a.rblocks + (other >> 6));
+            const uint32_t p = rank_in(b_lo, lo);
+            if (kind == 1u) {
+                res = a.parent_d[p];
+            } else if (kind == 3u) {
+                res = a.self_d[p];
+                if (res == 0 && hi != 0u) res = -1;  // (several records, all the root: None)
+            } else {
+                const uint32_t q = rank_in(b_hi, other);
+                const uint32_t k = 31u - (uint32_t)__clz((int)(q - p));  // q > p: distinct nodes
+                const int32_t* row = a.sparse + (size_t)k * a.sparse_m;
+                const int32_t x = row[p], y = row[q - (1u << k)];
+                const int32_t anc = x < y ? x : y;
+                res = anc == 0 ? -1 : anc;
+            }
+        }
+        if (on && res < 0 && a.unassigned) res = (int32_t)a.n_results;
+        count(res >= 0, (uint32_t)res);
+    };
     // block b looks at records [240 b - 16, 240 b + 240) and owns the last 240
     const uint32_t n_blocks = (a.n_records + kFreeAdvance - 1) / kFreeAdvance;
+    // (one load whatever the place, so that the compiler can count the loads in
+    // flight and wait for this block's only, not for the next one's too: the
+    // records before the stream's start and behind its end are masked afterwards —
+    // the buffer has 64 bytes of room behind the last record)
     auto load_block = [&](uint32_t b) -> uint4 {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (b >= n_blocks) return v;
         const int64_t r0 = (int64_t)b * kFreeAdvance - 16 + 4 * (int64_t)lane;
-        if (r0 >= 0 && r0 + 4 <= (int64_t)a.n_records) {
-            v = *reinterpret_cast<const uint4*>(a.words + r0);
-        } else {  // the stream's two ends
-            if (r0 >= 0 && r0 < (int64_t)a.n_records) v.x = a.words[r0];
-            if (r0 + 1 >= 0 && r0 + 1 < (int64_t)a.n_records) v.y = a.words[r0 + 1];
-            if (r0 + 2 >= 0 && r0 + 2 < (int64_t)a.n_records) v.z = a.words[r0 + 2];
-            if (r0 + 3 >= 0 && r0 + 3 < (int64_t)a.n_records) v.w = a.words[r0 + 3];
-        }
+        const bool inside = r0 >= 0 && r0 < (int64_t)a.n_records;
+        uint4 v = *reinterpret_cast<const uint4*>(a.words + (inside ? r0 : 0));
+        const uint32_t left = inside ? (uint32_t)((int64_t)a.n_records - r0) : 0u;
+        v.x = left > 0u ? v.x : 0u;
+        v.y = left > 1u ? v.y : 0u;
+        v.z = left > 2u ? v.z : 0u;
+        v.w = left > 3u ? v.w : 0u;
         return v;
     };
-    unsigned long long my_reads = 0, my_records = 0;
-    uint32_t head = 0, tail = 0;  // (wave-uniform)
+    uint32_t my_records = 0;      // (wave-uniform, as are these: a wave's share of < 2^32 records)
+    uint32_t head = 0, tail = 0;  // (tail: the reads met so far)
+    uint32_t at23[4];             // a record's place in the staged block, for --major
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) at23[j] = a.major > 0.0 ? (4u * lane + j) << kWordSubjBits : 0u;
     uint4 cur = load_block(wave0);
     for (uint32_t b = wave0; b < n_blocks; b += waves) {
         const uint4 nxt = load_block(b + waves);
-        *reinterpret_cast<uint4*>(stage + 4 * lane) = cur;
-        // 1. the read ends among this lane's four records (lanes 0-3 hold the 16
-        // records before the owned range)
+        // 1. a lane's own four records: ids, places in their reads
         const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
-        uint32_t n_ends = 0;
+        uint32_t f[4], pos[4], size[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t size = w4[j] >> kWordSizeShift, pos = (w4[j] >> kWordSubjBits) & 15u;
-            const bool mine_j = size != 0u && lane >= 4u;
-            const bool last = mine_j && pos + 1u == size;
-            my_records += mine_j ? 1ull : 0ull;
-            my_reads += last ? 1ull : 0ull;
-            const unsigned long long mask = __ballot(last);
-            if (last) ends[n_ends + (uint32_t)__popcll(mask & below)] = (unsigned short)(4u * lane + (uint32_t)j);
-            n_ends += (uint32_t)__popcll(mask);
+            f[j] = w4[j] & kWordSubjMask;
+            pos[j] = (w4[j] >> kWordSubjBits) & 15u;
+            size[j] = w4[j] >> kWordSizeShift;
         }
-        settle();
-        // 2. one read per lane
-        for (uint32_t base = 0; base < n_ends; base += kWave) {
-            const bool on = base + lane < n_ends;
-            const uint32_t at = on ? (uint32_t)ends[base + lane] : 0u;
-            const uint32_t word = on ? stage[at] : 0u;
-            const uint32_t size = word >> kWordSizeShift;
-            uint32_t mn = word & kWordSubjMask, mx = mn;
-            // (four records a step, so that their LDS reads are in flight together;
-            // steps beyond the read's first record look at that one again)
-            const uint32_t first = at + 1u - (size ? size : 1u);
-            for (uint32_t i = 1; __ballot(i < size) != 0ull; i += 4) {
-                uint32_t v[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const uint32_t k = at - i - j;
-                    v[j] = stage[(int32_t)k > (int32_t)first ? k : first];
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const uint32_t f = v[j] & kWordSubjMask;
-                    mn = f < mn ? f : mn;
-                    mx = f > mx ? f : mx;
-                }
-            }
-            // (a missing subject carries the largest value of the field: it is the maximum)
-            unsigned long long e = 0;
-            bool put = on;
-            if (a.by_rank) {
-                uint32_t to = kFreeMissing;  // where the read goes without a look at the tree
-                bool lca = false;
-                if (mn == mx) {
-                    to = mn;
-                } else if (a.major > 0.0) {
-                    // the only value that can reach a threshold above one half:
-                    // Boyer-Moore's candidate, then its votes
-                    uint32_t cand = 0, lead = 0, votes = 0;
-                    for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
-                        if (i < size) {
-                            const uint32_t f = stage[at - i] & kWordSubjMask;
-                            if (lead == 0u) cand = f;
-                            lead += (f == cand) ? 1u : (uint32_t)-1;
-                        }
-                    for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
-                        if (i < size) votes += ((stage[at - i] & kWordSubjMask) == cand) ? 1u : 0u;
-                    if ((double)votes >= (double)size * a.major) to = cand;
-                } else if (a.above) {
-                    lca = mx != kFreeMissing;
-                }
-                if (lca)
-                    e = kLca | ((unsigned long long)mx << 32) | mn;
-                else if (to != kFreeMissing)
-                    e = kSelf | to;
-                else
-                    e = (unsigned long long)a.n_results, put = on && a.unassigned != 0u;
-            } else if (mx == kFreeMissing) {
-                e = (unsigned long long)a.n_results, put = on && a.unassigned != 0u;
-            } else if (size == 1u) {
-                e = (a.subok ? kSelf : kParent) | mn;
-            } else if (mn != mx) {
-                e = kLca | ((unsigned long long)mx << 32) | mn;
-            } else {  // the same node several times (cannot happen with sets): itself, None if the root
-                e = kSelf | (1ull << 32) | mn;
-            }
-            const unsigned long long mask = __ballot(put);
-            if (put) queue[(tail + (uint32_t)__popcll(mask & below)) & (kFreeQueue - 1)] = e;
-            tail += (uint32_t)__popcll(mask);
+        if (a.major > 0.0) {  // (the vote count walks a read's records)
+            *reinterpret_cast<uint4*>(stage + 4 * lane) = cur;
             settle();
-            // 3. (< 64 left over + <= 64 new fit the queue)
-            if (tail - head >= (uint32_t)kWave) {
-                evaluate(head, kWave);
-                head += kWave;
+        }
+        // the smallest and the largest id of the lane's last run of records of one
+        // read (from the last record that begins a read; all four if none does) ...
+        uint32_t tmn = f[3], tmx = f[3];
+        bool open = pos[3] != 0u;
+#pragma unroll
+        for (int j = 2; j >= 0; --j) {
+            tmn = open && f[j] < tmn ? f[j] : tmn;
+            tmx = open && f[j] > tmx ? f[j] : tmx;
+            open = open && pos[j] != 0u;
+        }
+        // ... of the d lanes before this one make what the read of the lane's first
+        // record brings along: it began 1 .. 15 records back, in lane - d, and holds
+        // every record of the lanes between
+        const uint32_t d = (pos[0] + 3u) >> 2;
+        uint32_t rmn = 0xFFFFFFFFu, rmx = 0u;
+#pragma unroll
+        for (uint32_t k = 1; k <= 4u; ++k) {
+            const uint32_t smn = (uint32_t)__shfl_up((int)tmn, k), smx = (uint32_t)__shfl_up((int)tmx, k);
+            rmn = d >= k && smn < rmn ? smn : rmn;
+            rmx = d >= k && smx > rmx ? smx : rmx;
+        }
+        // 2. the running minimum and maximum along the four records; a record that
+        // ends a read is queued: {smallest id | place in the staged block << 23,
+        // largest id | the record's place and size fields}
+        uint2 ent[4];
+        unsigned long long ends[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool begins = pos[j] == 0u;
+            rmn = begins || f[j] < rmn ? f[j] : rmn;
+            rmx = begins || f[j] > rmx ? f[j] : rmx;
+            // (a record past the stream's end has size 0, and the 16 records before the owned ones are lanes 0-3's)
+            ends[j] = __ballot(lane >= 4u && pos[j] + 1u == size[j]);
+            ent[j] = make_uint2(rmn | at23[j], (w4[j] & ~kWordSubjMask) | rmx);
+        }
+        my_records += min((uint32_t)kFreeAdvance, a.n_records - b * kFreeAdvance);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // (two records' worth at a time: < 64 left over + <= 128 new fit the queue)
+#pragma unroll
+            for (int j = 2 * h; j < 2 * h + 2; ++j) {
+                const uint32_t at = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(ends[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends[j], 0u));
+                if ((ends[j] >> lane) & 1ull) queue[at & (kFreeQueue - 1)] = ent[j];
+                tail += (uint32_t)__popcll(ends[j]);
+            }
+            settle();
+            // 3.
+            while (tail - head >= (uint32_t)kWave) {
+                evaluate(head, (uint32_t)kWave);
+                head += (uint32_t)kWave;
                 settle();
             }
+        }
+        if (a.major > 0.0 && tail != head) {  // (the votes are counted in this block's records)
+            evaluate(head, tail - head);
+            head = tail;
+            settle();
         }
         cur = nxt;
     }
     settle();
     if (tail != head) evaluate(head, tail - head);
-    my_reads = wave_sum(my_reads);
-    my_records = wave_sum(my_records);
+    settle();
+    if (lane < ring_tail - ring_head) my_log[logged + lane] = ring[(ring_head + lane) & (kFreeMiss - 1)];
+    if (lane == 0) a.log_cnt[wave0] = logged + (ring_tail - ring_head);
     if (lane == 0) {
-        atomicAdd(&acc[0], my_reads);
-        atomicAdd(&acc[1], my_records);
+        atomicAdd(&acc[0], (unsigned long long)tail);
+        atomicAdd(&acc[1], (unsigned long long)my_records);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < lds_slots; i += blockDim.x)
@@ -308,16 +370,98 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
     }
 }
 
-// the dense counters -> the count table (weight L per read), cleared on the way
+// The lists of results the caches had no room for, counted: a workgroup takes a
+// slice of kLogBins result ids (32-bit counters in LDS) and one of kLogParts
+// shares of the waves' lists, and leaves its counters as they are in `partial`
+// — no atomics on the way out; free_counts_kernel adds the shares up.  The
+// workgroups of one share sit on one XCD (blockIdx % 8), so the share's lists
+// come from HBM once and from that XCD's L2 for the other slices.
+constexpr uint32_t kLogBins = 36864;  // 144 KB
+constexpr uint32_t kLogParts = 32;    // (a multiple of 8)
+constexpr uint32_t kLogThreads = 1024;
+
+struct FreeLogArgs {
+    const uint32_t* log;
+    const uint32_t* log_cnt;
+    uint32_t log_cap, n_waves;
+    uint32_t n_slices;
+    uint32_t* partial;    // [kLogParts][n_slices][kLogBins]
+    uint32_t* part_used;  // [kLogParts][n_slices] 1: the share met results of the slice
+};
+
+__global__ void __launch_bounds__(kLogThreads) free_log_kernel(FreeLogArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t bins[];
+    __shared__ uint32_t any;
+    const uint32_t r = blockIdx.x >> 3, slice = r % a.n_slices, part = (r / a.n_slices) * 8u + (blockIdx.x & 7u);
+    const uint32_t w_lo = (uint32_t)((unsigned long long)part * a.n_waves / kLogParts);
+    const uint32_t w_hi = (uint32_t)((unsigned long long)(part + 1u) * a.n_waves / kLogParts);
+    const uint32_t slot = part * a.n_slices + slice;
+    // (nothing listed in this share — every result found room in the caches, as under --uniq at a high rank: done)
+    uint32_t listed = 0;
+    for (uint32_t w = w_lo + threadIdx.x; w < w_hi; w += kLogThreads) listed |= a.log_cnt[w];
+    if (!__syncthreads_or((int)listed)) {
+        if (threadIdx.x == 0) a.part_used[slot] = 0u;
+        return;
+    }
+    if (threadIdx.x == 0) any = 0u;
+    for (uint32_t i = threadIdx.x; i < kLogBins; i += kLogThreads) bins[i] = 0u;
+    __syncthreads();
+    const uint32_t base = slice * kLogBins;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    bool met = false;
+    // (a wave takes a list at a time, eight 16-byte loads in flight per lane: with one, the kernel waited for memory
+    // 0.17 ms at config 3's 17.5 M entries)
+    constexpr uint32_t kDeep = 8;
+    for (uint32_t w = w_lo + wv; w < w_hi; w += kLogThreads / kWave) {
+        const uint32_t cnt = a.log_cnt[w];
+        const uint32_t* src = a.log + (size_t)w * a.log_cap;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 4u * kWave * kDeep) {
+            uint4 v[kDeep];
+#pragma unroll
+            for (uint32_t k = 0; k < kDeep; ++k) {
+                const uint32_t i = i0 + 4u * kWave * k + 4u * lane;
+                // (a list's room is a multiple of 64 entries, and the lists are one allocation: a load that
+                // starts inside the list stays inside the allocation)
+                v[k] = i < cnt ? *reinterpret_cast<const uint4*>(src + i) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kDeep; ++k) {
+                const uint32_t i = i0 + 4u * kWave * k + 4u * lane;
+                const uint32_t id[4] = {v[k].x - base, v[k].y - base, v[k].z - base, v[k].w - base};
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j)
+                    if (i + j < cnt && id[j] < kLogBins) {
+                        atomicAdd(&bins[id[j]], 1u);
+                        met = true;
+                    }
+            }
+        }
+    }
+    if (met) any = 1u;
+    __syncthreads();
+    if (threadIdx.x == 0) a.part_used[slot] = any;
+    if (!any) return;
+    uint32_t* out = a.partial + (size_t)slot * kLogBins;
+    for (uint32_t i = threadIdx.x; i < kLogBins; i += kLogThreads) out[i] = bins[i];
+}
+
+// the dense counters + the shares of free_log_kernel -> the count table (weight L
+// per read); the dense counters are cleared on the way
 __global__ void __launch_bounds__(256) free_counts_kernel(uint32_t* __restrict__ dense, uint32_t n_results,
                                                           const int32_t* __restrict__ result_node, uint32_t job, uint32_t group,
-                                                          CountTable table) {
+                                                          const uint32_t* __restrict__ partial, const uint32_t* __restrict__ part_used,
+                                                          uint32_t n_slices, CountTable table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_results) return;
-    const uint32_t n = dense[i];
+    unsigned long long n = dense[i];
+    if (n) dense[i] = 0u;
+    const uint32_t slice = i / kLogBins, bin = i - slice * kLogBins;
+    for (uint32_t part = 0; part < kLogParts; ++part) {
+        const uint32_t slot = part * n_slices + slice;
+        if (part_used[slot]) n += partial[(size_t)slot * kLogBins + bin];
+    }
     if (!n) return;
-    dense[i] = 0u;
-    table_add(table, make_key(job, 0u, group, i == n_results ? (uint32_t)WK_FEATURE_UNASSIGNED : (uint32_t)result_node[i]), (unsigned long long)n * WK_WEIGHT_L);
+    table_add(table, make_key(job, 0u, group, i == n_results ? (uint32_t)WK_FEATURE_UNASSIGNED : (uint32_t)result_node[i]), n * WK_WEIGHT_L);
 }
 
 // subject indices -> node ids (`src` may be `dst`: chunks appended to a

@@ -114,6 +114,7 @@ struct wk_ctx {
     StreamTables st[WK_MAX_JOBS];
     DevBuf w_tmp;  // several stream jobs: the records with the subject field rewritten for one job
     DevBuf f_dense;  // reads per result node of the free-rank stream
+    DevBuf f_log, f_log_cnt, f_partial, f_part_used;  // results the stream's LDS caches had no room for, per wave; their counts per share (free_log_kernel)
     int f_dense_tree = -1;
     uint32_t f_m = 0;
     int use_free_sparse = 1;
@@ -740,6 +741,8 @@ int wk_create(int device, wk_ctx** out) {
     // (160 KiB per CU minus the kernels' few bytes of static LDS)
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_log_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLogBins * 4))) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&classify_kernel<true, false, 1>),
@@ -815,7 +818,7 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_dense, &c->w_tmp, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_dense, &c->f_log, &c->f_log_cnt, &c->f_partial, &c->f_part_used, &c->w_tmp, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (wk_ctx::StreamTables& T : c->st)
         for (DevBuf* b : {&T.rblocks, &T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node}) b->release();
@@ -1931,13 +1934,38 @@ int wk_words_flush(wk_ctx* c) {
             fa.dense = c->f_dense.as<uint32_t>();
             fa.n_results = T.results;
             fa.stat_block = c->stat_block.as<unsigned long long>();
+            // (two workgroups of 1024 threads share a CU's 160 KB: under --major the staged blocks take the room of half the cache)
+            const bool major = fa.major > 0.0;
+            const uint32_t slots = major ? (uint32_t)std::min(c->free_slots, 2048) : (uint32_t)c->free_slots;
+            const size_t lds = (size_t)slots * 8 + (size_t)(c->free_threads / 64) * free_wave_lds(major);
+            // a wave's list of uncached results: room for every read it can meet (240 per block of records)
+            const uint32_t n_waves = (uint32_t)blocks * (uint32_t)(c->free_threads / 64);
+            const uint32_t n_blocks = (fa.n_records + kFreeAdvance - 1) / kFreeAdvance;
+            fa.log_cap = ((n_blocks + n_waves - 1) / n_waves * kFreeAdvance + 63u) / 64u * 64u;
+            const uint32_t n_slices = (T.results + 1 + kLogBins - 1) / kLogBins;
+            HIP_TRY(c, c->f_log.reserve((size_t)n_waves * fa.log_cap * 4));
+            HIP_TRY(c, c->f_log_cnt.reserve((size_t)n_waves * 4));
+            HIP_TRY(c, c->f_partial.reserve((size_t)kLogParts * n_slices * kLogBins * 4));
+            HIP_TRY(c, c->f_part_used.reserve((size_t)kLogParts * n_slices * 4));
+            fa.log = c->f_log.as<uint32_t>();
+            fa.log_cnt = c->f_log_cnt.as<uint32_t>();
             KernelTimer* kt = ktimer_begin(c, "classify");
-            const size_t lds = (size_t)c->free_slots * 8 + (size_t)(c->free_threads / 64) * kFreeWaveLds;
-            hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, (uint32_t)c->free_slots);
+            hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
+            ktimer_end(c, kt);
+            FreeLogArgs la{};
+            la.log = fa.log;
+            la.log_cnt = fa.log_cnt;
+            la.log_cap = fa.log_cap;
+            la.n_waves = n_waves;
+            la.n_slices = n_slices;
+            la.partial = c->f_partial.as<uint32_t>();
+            la.part_used = c->f_part_used.as<uint32_t>();
+            kt = ktimer_begin(c, "free_log");
+            hipLaunchKernelGGL(free_log_kernel, dim3(kLogParts * n_slices), dim3(kLogThreads), (size_t)kLogBins * 4, c->stream, la);
             ktimer_end(c, kt);
             kt = ktimer_begin(c, "free_counts");
             hipLaunchKernelGGL(free_counts_kernel, dim3((T.results + 256) / 256), dim3(256), 0, c->stream, fa.dense, fa.n_results,
-                               T.rnode.as<int32_t>(), fa.job, fa.group, table);
+                               T.rnode.as<int32_t>(), fa.job, fa.group, la.partial, la.part_used, n_slices, table);
             ktimer_end(c, kt);
             HIP_TRY(c, hipGetLastError());
         }
