@@ -522,6 +522,8 @@ SAM_OK = 'q1\t0\tG1\t10\t1\t10M\t*\t0\t0\t*\t*\n'
 @pytest.mark.parametrize('bad,extra', [
     ('\n', False),                                          # blank line in the body
     ('\n', True),
+    ('q2\t\tG1\t7\t1\t10M\t*\t0\t0\t*\t*\n', False),        # int('') as the FLAG
+    ('q2\t\tG1\t7\t1\t10M\t*\t0\t0\t*\t*\n', True),
     ('q2\t0\tG1\tx7\t1\t10M\t*\t0\t0\t*\t*\n', True),       # int(pos)
     ('q2\t0\tG1\t7\t1\tM\t*\t0\t0\t*\t*\n', True),          # int('') in the CIGAR
     ('q2\t0\tG1\t7\t1\t5Z3M\t*\t0\t0\t*\t*\n', True),       # int('Z3')

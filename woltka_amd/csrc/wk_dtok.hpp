@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
         return;
     }
     uint32_t flag = 0;
-    bool digits = true;
+    bool digits = tab[1] > tab[0] + 1u;  // (an empty FLAG: int('') raises, align.py:322)
     for (uint32_t p = tab[0] + 1u; p < tab[1]; ++p) {
         const uint32_t d = (uint32_t)a.text[p] - (uint32_t)'0';
         digits &= d <= 9u;

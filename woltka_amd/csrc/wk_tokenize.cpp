@@ -193,6 +193,7 @@ inline Line parse_line(const char* p, const char* e, bool extra) {
     L.q = p;
     L.qn = t1 - p;
     int f = 0;
+    if (t2 == t1 + 1) return L;  // (an empty FLAG: int('') raises)
     for (const char* c = t1 + 1; c < t2; ++c) {
         if (*c < '0' || *c > '9') return L;
         f = f * 10 + (*c - '0');

@@ -50,6 +50,15 @@ class FeatureIndex:
         """Ids of ``names`` (list of int), allocating new ones in order."""
         found = list(map(self.ids.get, names))
         if None in found:
+            if found.count(None) == len(found):
+                # all new (a block's unknown subjects): one update of the
+                # dict — unless a name comes twice
+                base = len(self.names)
+                ids = dict(zip(names, range(base, base + len(names))))
+                if len(ids) == len(names):
+                    self.ids.update(ids)
+                    self.names.extend(names)
+                    return list(range(base, base + len(names)))
             intern = self.intern
             found = [intern(x) if i is None else i
                      for x, i in zip(names, found)]

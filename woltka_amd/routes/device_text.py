@@ -402,8 +402,8 @@ class DeviceTextRoute:
                     return
                 if fresh:
                     base = self._tok_map.size
-                    ids = np.fromiter(map(self.subjects.intern, fresh),
-                                      np.int32, len(fresh))
+                    ids = np.asarray(self.subjects.intern_many(fresh),
+                                     dtype=np.int32)
                     if self._tok_identity and not np.array_equal(
                             ids, np.arange(base, base + ids.size)):
                         self._tok_identity = False
@@ -515,8 +515,7 @@ class DeviceTextRoute:
                         final=final, fmt=self._dfmt, want_names=names)
         fresh = tok.new_subjects()
         if fresh:
-            ids = np.fromiter(map(self.subjects.intern, fresh), np.int32,
-                              len(fresh))
+            ids = np.asarray(self.subjects.intern_many(fresh), dtype=np.int32)
             self._tok_map = np.concatenate([self._tok_map, ids])
         if res['off'].size > 1:
             subj = res['subj'] if self._tok_identity \
