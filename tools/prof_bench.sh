@@ -15,7 +15,10 @@ echo "kernel-trace rc=$?"
 f=$(find "$OUT/kt" -name "*kernel_stats.csv" 2>/dev/null | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv" && cut -c1-150 "$OUT/kernel_stats.csv" | head -8
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU"; do
+# (PMC_SETS=traffic: the two passes the traffic figure needs, nothing else)
+sets=("FETCH_SIZE" "WRITE_SIZE")
+[ "${PMC_SETS:-all}" = all ] && sets+=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU")
+for set in "${sets[@]}"; do
   i=$((i+1))
   timeout 900 rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -- $CMD > "$OUT/pmc$i.log" 2>&1
   echo "pmc$i rc=$?"

@@ -6,13 +6,17 @@
 // --subok), a read with several to their lowest common ancestor (tree.find_lca,
 // tree.py:513-566), nowhere if that is the root or a subject is not in the tree.
 //
-// The records arrive as packed words (wk_weigh.hpp) whose subject field holds
-// the subject's *feature id* here — the pre-order id of its node, or
-// kFreeMissing for a name that is not a node (the tokenizer on the device
-// writes them that way, host-tokenised chunks are translated when they are
-// appended).  Pre-order ids turn find_lca into "lowest ancestor of the smallest
-// id whose subtree holds the largest" (DESIGN §2), so a read needs the minimum
-// and the maximum of its records' ids and nothing else.  The position and size
+// The records arrive as packed words (wk_weigh.hpp) whose subject field holds,
+// here, the *rank of the subject's node among the distinct subject nodes in
+// pre-order* — or kFreeMissing for a name that is not a node (the field is
+// rewritten when a chunk is appended, words_to_ranks_kernel; when a later chunk
+// brings new subjects the ranks of the records accumulated so far are renumbered,
+// ranks_renumber_kernel).  Pre-order ids turn find_lca into "lowest ancestor of
+// the smallest id whose subtree holds the largest" (DESIGN §2), ranks keep the
+// order of the ids, so a read needs the minimum and the maximum of its records'
+// ranks and nothing else — and the tables of the look-ups are indexed by rank
+// (round 3's records carried node ids: two gathers of rank blocks per read, two
+// of the three cache lines a read's look-ups moved).  The position and size
 // in every word make the stream self-describing: the last record of a read
 // says where the read began — no offsets, no per-read gathers of candidate
 // rows (round 2's evaluator: 225 M 16-byte row gathers, 1.5 ms).
@@ -34,24 +38,15 @@ namespace wk {
 constexpr uint32_t kFreeMissing = kWordSubjMask;  // feature field of a subject that is not in the tree
 constexpr uint32_t kFreeThreads = 1024;
 
-// rank of a subject's node among the distinct subject nodes in pre-order: a bit
-// per node and a running count per 64 of them (16 B per 64 nodes: 512 KB for a
-// 2 M-node tree, where a plain rank per node is 8 MB and does not stay in an
-// XCD's L2)
-struct RankBlock {
-    unsigned long long bits;
-    uint32_t before, pad;
-};
-
 struct FreeArgs {
     const uint32_t* words;  // [n_records] feature | position << 23 | size << 27
     uint32_t n_records;
     // the lowest common ancestor without a walk over the distinct
-    // subject nodes d_0 < d_1 < ... in pre-order: sparse[k][i] = the smallest among
-    // LCA(d_j, d_j+1), j in [i, i + 2^k); parent_d[i] = parent of d_i, self_d[i] =
-    // d_i — all three as *result ids*: the possible results (subject nodes and
-    // their ancestors) numbered in pre-order, the root 0
-    const RankBlock* rblocks;  // [n_nodes / 64 + 1]
+    // subject nodes d_0 < d_1 < ... in pre-order, which the records name by their
+    // index: sparse[k][i] = the smallest among LCA(d_j, d_j+1), j in [i, i + 2^k);
+    // parent_d[i] = parent of d_i, self_d[i] = d_i — all three as *result ids*: the
+    // possible results (subject nodes and their ancestors) numbered in pre-order,
+    // the root 0
     const int32_t* sparse;     // [levels][sparse_m]
     const int32_t* parent_d;   // [sparse_m]
     const int32_t* self_d;     // [sparse_m]
@@ -79,19 +74,6 @@ constexpr uint32_t kFreeBlock = 256;    // records a wave loads at a time
 constexpr uint32_t kFreeAdvance = 240;  // ... of which it owns the last 240
 // LDS of a wave: its queue, its ring of uncached results and, under --major, the staged block
 __host__ __device__ constexpr uint32_t free_wave_lds(bool major) { return kFreeQueue * 8 + kFreeMiss * 4 + (major ? kFreeBlock * 4 : 0u); }
-
-__device__ __forceinline__ uint32_t rank_in(const uint4 b, uint32_t node) {
-    const unsigned long long bits = ((unsigned long long)b.y << 32) | b.x;
-    const uint32_t bit = node & 63u;
-    return b.z + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull));
-}
-
-__device__ __forceinline__ uint32_t rank_of(const RankBlock* __restrict__ blocks, uint32_t node) {
-    const uint4 b = *reinterpret_cast<const uint4*>(blocks + (node >> 6));
-    const unsigned long long bits = ((unsigned long long)b.y << 32) | b.x;
-    const uint32_t bit = node & 63u;
-    return b.z + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull));
-}
 
 // A wave takes blocks of 256 records — one 16-byte load per lane, the next
 // block's issued before this one is looked at — of which it owns the last 240
@@ -232,18 +214,14 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
         }
         int32_t res = -1;
         if (on && kind != 0u) {
-            // (both rank blocks in one round of loads: the smallest node's again where there is no largest)
-            const uint32_t other = kind == 2u ? hi : lo;
-            const uint4 b_lo = *reinterpret_cast<const uint4*>(a.rblocks + (lo >> 6));
-            const uint4 b_hi = *reinterpret_cast<const uint4*>(a.rblocks + (other >> 6));
-            const uint32_t p = rank_in(b_lo, lo);
+            const uint32_t p = lo;
             if (kind == 1u) {
                 res = a.parent_d[p];
             } else if (kind == 3u) {
                 res = a.self_d[p];
                 if (res == 0 && hi != 0u) res = -1;  // (several records, all the root: None)
             } else {
-                const uint32_t q = rank_in(b_hi, other);
+                const uint32_t q = hi;
                 const uint32_t k = 31u - (uint32_t)__clz((int)(q - p));  // q > p: distinct nodes
                 const int32_t* row = a.sparse + (size_t)k * a.sparse_m;
                 const int32_t x = row[p], y = row[q - (1u << k)];
@@ -464,22 +442,32 @@ __global__ void __launch_bounds__(256) free_counts_kernel(uint32_t* __restrict__
     table_add(table, make_key(job, 0u, group, i == n_results ? (uint32_t)WK_FEATURE_UNASSIGNED : (uint32_t)result_node[i]), n * WK_WEIGHT_L);
 }
 
-// subject indices -> node ids (`src` may be `dst`: chunks appended to a
-// single-job accumulation are rewritten in place)
-__global__ void __launch_bounds__(256) words_to_features_kernel(const uint32_t* src, uint32_t* dst, uint32_t n,
-                                                                const int32_t* __restrict__ subj_feat, uint32_t n_subjects,
-                                                                uint32_t n_nodes, int* __restrict__ err) {
+// subject indices -> ranks of their nodes (`src` may be `dst`: chunks appended to
+// a single-job accumulation are rewritten in place); rank_of_subject[s] < 0: the
+// subject has no node
+__global__ void __launch_bounds__(256) words_to_ranks_kernel(const uint32_t* src, uint32_t* dst, uint32_t n,
+                                                             const int32_t* __restrict__ rank_of_subject, uint32_t n_subjects,
+                                                             int* __restrict__ err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t w = src[i], s = w & kWordSubjMask;
     uint32_t f = kFreeMissing;
     if (s < n_subjects) {
-        const uint32_t x = (uint32_t)subj_feat[s];
-        f = x < n_nodes ? x : kFreeMissing;
+        const int32_t x = rank_of_subject[s];
+        f = x >= 0 ? (uint32_t)x : kFreeMissing;
     } else if (w >> kWordSizeShift) {
         atomicOr(err, kErrFeatureRange);
     }
     dst[i] = (w & ~kWordSubjMask) | f;
+}
+
+// the subject set has grown: ranks of the records accumulated so far -> ranks among the larger set
+__global__ void __launch_bounds__(256) ranks_renumber_kernel(uint32_t* words, uint32_t n, const int32_t* __restrict__ new_of_old,
+                                                             uint32_t n_old) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = words[i], r = w & kWordSubjMask;
+    if (r < n_old) words[i] = (w & ~kWordSubjMask) | (uint32_t)new_of_old[r];
 }
 
 }  // namespace wk

@@ -104,7 +104,12 @@ struct wk_ctx {
     // records can name — the subjects' nodes (kind 1, `--rank free`) or their
     // ancestors at the job's rank (kind 2)
     struct StreamTables {
-        DevBuf rblocks, dsparse, dparent, dself, rnode;
+        DevBuf dsparse, dparent, dself, rnode;
+        // the distinct nodes the stream's records can name, ascending — a record names one by its index — and per
+        // subject that index (-1: the subject has no node); what they were made for
+        std::vector<int32_t> dn_host;
+        DevBuf subj_rank;
+        int rk_kind = -1, rk_slot = -1, rk_tree = -1, rk_subj = -1, rk_rank = -1;
         DevBuf subj_node;                    // kind 2: ancestor at the rank per subject (-1: none)
         std::vector<int32_t> subj_node_host;
         int node_slot = -1, node_tree = -1, node_rank = -1;  // what subj_node_host was made for
@@ -113,6 +118,7 @@ struct wk_ctx {
     };
     StreamTables st[WK_MAX_JOBS];
     DevBuf w_tmp;  // several stream jobs: the records with the subject field rewritten for one job
+    DevBuf w_renum;  // old rank -> new rank when the subject table grows under accumulated records
     DevBuf f_dense;  // reads per result node of the free-rank stream
     DevBuf f_log, f_log_cnt, f_partial, f_part_used;  // results the stream's LDS caches had no room for, per wave; their counts per share (free_log_kernel)
     int f_dense_tree = -1;
@@ -463,15 +469,17 @@ static int ensure_subject_ancestors(wk_ctx* c, wk_ctx::StreamTables& T, int slot
     return WK_OK;
 }
 
-// Tables of the per-read stream (wk_free.hpp) over the nodes its records can
-// name: the subjects' nodes (mode 1, `--rank free`) or their ancestors at the
-// job's rank (mode 2).
-static int ensure_stream_tables(wk_ctx* c, wk_ctx::StreamTables& T, int mode, int slot) {
+// The nodes the records of the per-read stream (wk_free.hpp) can name — the
+// subjects' nodes (mode 1, `--rank free`) or their ancestors at the job's rank
+// (mode 2) — and every subject's place among them.  `before` (optional) receives
+// the list as it was when a list for the same job over the same tree is replaced
+// (the subject table has grown): records written under it are renumbered.
+static int ensure_rank_table(wk_ctx* c, wk_ctx::StreamTables& T, int mode, int slot, std::vector<int32_t>* before) {
     if (mode == 2) {
         const int rc = ensure_subject_ancestors(c, T, slot);
         if (rc) return rc;
     }
-    if (T.kind == mode && T.slot == slot && T.tree == c->tree_serial && T.subj == c->subj_serial && T.rank == c->rank_serial)
+    if (T.rk_kind == mode && T.rk_slot == slot && T.rk_tree == c->tree_serial && T.rk_subj == c->subj_serial && T.rk_rank == c->rank_serial)
         return WK_OK;
     const int32_t n_nodes = c->n_nodes;
     const std::vector<int32_t>& of = mode == 2 ? T.subj_node_host : c->subj_feat_host;
@@ -481,11 +489,37 @@ static int ensure_stream_tables(wk_ctx* c, wk_ctx::StreamTables& T, int mode, in
         if (v >= 0 && v < n_nodes) dn.push_back(v);
     std::sort(dn.begin(), dn.end());
     dn.erase(std::unique(dn.begin(), dn.end()), dn.end());
-    // rank blocks, the parents, the table of neighbours' LCAs
+    std::vector<int32_t> rank_of(of.size(), -1);
+    for (size_t s = 0; s < of.size(); ++s)
+        if (of[s] >= 0 && of[s] < n_nodes) rank_of[s] = (int32_t)(std::lower_bound(dn.begin(), dn.end(), of[s]) - dn.begin());
+    const int rc = upload(c, T.subj_rank, rank_of.data(), rank_of.size() * 4);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the vector is about to go out of scope)
+    const bool same_job = T.rk_kind == mode && T.rk_slot == slot && T.rk_tree == c->tree_serial && T.rk_rank == c->rank_serial;
+    if (before) {
+        before->clear();
+        if (same_job) before->swap(T.dn_host);
+    }
+    T.dn_host.swap(dn);
+    T.rk_kind = mode;
+    T.rk_slot = slot;
+    T.rk_tree = c->tree_serial;
+    T.rk_subj = c->subj_serial;
+    T.rk_rank = c->rank_serial;
+    return WK_OK;
+}
+
+// Tables of the per-read stream over those nodes: the parents, the table of neighbours' LCAs.
+static int ensure_stream_tables(wk_ctx* c, wk_ctx::StreamTables& T, int mode, int slot) {
+    {
+        const int rc = ensure_rank_table(c, T, mode, slot, nullptr);
+        if (rc) return rc;
+    }
+    if (T.kind == mode && T.slot == slot && T.tree == c->tree_serial && T.subj == c->subj_serial && T.rank == c->rank_serial)
+        return WK_OK;
+    const int32_t n_nodes = c->n_nodes;
+    const std::vector<int32_t>& dn = T.dn_host;
     const uint32_t md = (uint32_t)dn.size();
-    std::vector<RankBlock> blocks((size_t)n_nodes / 64 + 1, RankBlock{0ull, 0u, 0u});
-    for (int32_t v : dn) blocks[(size_t)v >> 6].bits |= 1ull << (v & 63);
-    for (size_t b = 1; b < blocks.size(); ++b) blocks[b].before = blocks[b - 1].before + (uint32_t)__builtin_popcountll(blocks[b - 1].bits);
     uint32_t dlevels = 1;
     while (md > 1 && (2u << (dlevels - 1)) <= md - 1) dlevels += 1;
     const size_t drow = std::max<uint32_t>(md, 1u);
@@ -521,7 +555,6 @@ static int ensure_stream_tables(wk_ctx* c, wk_ctx::StreamTables& T, int mode, in
         for (uint32_t i = 0; i + (1u << k) <= md - 1; ++i)
             dsparse[k * drow + i] = std::min(dsparse[(k - 1) * drow + i], dsparse[(k - 1) * drow + i + (1u << (k - 1))]);
     int rc;
-    if ((rc = upload(c, T.rblocks, blocks.data(), blocks.size() * sizeof(RankBlock)))) return rc;
     if ((rc = upload(c, T.dsparse, dsparse.data(), dsparse.size() * 4))) return rc;
     if ((rc = upload(c, T.dparent, dparent.data(), dparent.size() * 4))) return rc;
     if ((rc = upload(c, T.dself, dself.data(), dself.size() * 4))) return rc;
@@ -673,6 +706,7 @@ static int build_subject_rows(wk_ctx* c, const wk_job* jobs, int32_t n_jobs, Cla
 
 extern "C" {
 
+static int refresh_word_ranks(wk_ctx* c, int64_t count);
 static int streams_needed(const wk_ctx* c) { return std::max(1, (int)(((int64_t)c->n_subjects + kSliceBins - 1) / kSliceBins)); }
 
 // the accumulation is empty again
@@ -818,10 +852,10 @@ void wk_destroy(wk_ctx* c) {
     DevBuf* bufs[] = {&c->nodes, &c->rank_code, &c->gene4, &c->g_grid, &c->g_first, &c->g_goff, &c->g_shift,
                       &c->tkeys, &c->tvals, &c->c_subj, &c->c_qoff, &c->c_group, &c->o_genome, &c->o_beg,
                       &c->o_end, &c->o_len, &c->o_hoff, &c->o_cnt, &c->o_ub, &c->o_first2, &c->o_poff, &c->o_pairs, &c->o_qoff,
-                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_dense, &c->f_log, &c->f_log_cnt, &c->f_partial, &c->f_part_used, &c->w_tmp, &c->assign_out, &c->fetch_k, &c->fetch_v};
+                      &c->o_tile_sum, &c->o_tile_off, &c->scalars, &c->stat_block, &c->log, &c->subj_feat, &c->subj_rows, &c->dense_slab, &c->plog, &c->plog_cnt, &c->left_mask, &c->left_list, &c->first_slab, &c->w_slab, &c->w_hi, &c->w_invalid, &c->c_rk[0], &c->c_rk[1], &c->rk_left[0], &c->rk_left[1], &c->rk_totals, &c->f_rank, &c->f_sparse, &c->f_dense, &c->w_renum, &c->f_log, &c->f_log_cnt, &c->f_partial, &c->f_part_used, &c->w_tmp, &c->assign_out, &c->fetch_k, &c->fetch_v};
     for (DevBuf* b : bufs) b->release();
     for (wk_ctx::StreamTables& T : c->st)
-        for (DevBuf* b : {&T.rblocks, &T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node}) b->release();
+        for (DevBuf* b : {&T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node, &T.subj_rank}) b->release();
     c->c_words.release();
     for (DevBuf& b : c->w_stream) b.release();
     for (int q = 0; q < wk_ctx::kTextBufs; ++q) {
@@ -1893,6 +1927,10 @@ int wk_words_flush(wk_ctx* c) {
         const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->free_per_cu);
         const CountTable table{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
         if (c->w_mode == 3) HIP_TRY(c, c->w_tmp.reserve((size_t)c->w_records * 4 + 64));
+        if (c->w_mode != 3) {  // (subjects registered since the last chunk was appended)
+            const int rcr = refresh_word_ranks(c, c->w_records);
+            if (rcr) return rcr;
+        }
         for (size_t j = 0; j < c->w_jobs.size(); ++j) {
             const wk_job& jb = c->w_jobs[j];
             const int kind = jb.mode == WK_MODE_FREE ? 1 : 2;
@@ -1904,13 +1942,11 @@ int wk_words_flush(wk_ctx* c) {
             FreeArgs fa{};
             fa.words = c->c_words.as<uint32_t>();
             if (c->w_mode == 3) {
-                hipLaunchKernelGGL(words_to_features_kernel, dim3((unsigned)((c->w_records + 255) / 256)), dim3(256), 0, c->stream,
-                                   c->c_words.as<uint32_t>(), c->w_tmp.as<uint32_t>(), (uint32_t)c->w_records,
-                                   kind == 2 ? T.subj_node.as<int32_t>() : c->subj_feat.as<int32_t>(), (uint32_t)c->n_subjects,
-                                   (uint32_t)c->n_nodes, scalar_err(c));
+                hipLaunchKernelGGL(words_to_ranks_kernel, dim3((unsigned)((c->w_records + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->c_words.as<uint32_t>(), c->w_tmp.as<uint32_t>(), (uint32_t)c->w_records, T.subj_rank.as<int32_t>(),
+                                   (uint32_t)c->n_subjects, scalar_err(c));
                 fa.words = c->w_tmp.as<uint32_t>();
             }
-            fa.rblocks = T.rblocks.as<RankBlock>();
             fa.sparse = T.dsparse.as<int32_t>();
             fa.parent_d = T.dparent.as<int32_t>();
             fa.self_d = T.dself.as<int32_t>();
@@ -2161,18 +2197,37 @@ static StreamSet stream_set(wk_ctx* c) {
     return s;
 }
 
-// Free-rank accumulation: the subject fields of words [first, first + n) become feature ids.
+// Single-job accumulation of the per-read stream: the first `count` records name their nodes by rank among the
+// subjects' nodes.  When the subject table has grown since they were written, they are renumbered.
+static int refresh_word_ranks(wk_ctx* c, int64_t count) {
+    wk_ctx::StreamTables& T = c->st[0];
+    std::vector<int32_t> before;
+    const int rc = ensure_rank_table(c, T, c->w_mode, c->w_mode == 2 ? c->w_jobs[0].rank_slot : -1, &before);
+    if (rc) return rc;
+    if (count <= 0 || before.empty() || before == T.dn_host) return WK_OK;
+    std::vector<int32_t> new_of_old(before.size());
+    for (size_t i = 0; i < before.size(); ++i) {
+        const auto it = std::lower_bound(T.dn_host.begin(), T.dn_host.end(), before[i]);
+        if (it == T.dn_host.end() || *it != before[i]) return fail(c, WK_E_STATE, "a subject changed its node under accumulated records");
+        new_of_old[i] = (int32_t)(it - T.dn_host.begin());
+    }
+    const int rcu = upload(c, c->w_renum, new_of_old.data(), new_of_old.size() * 4);
+    if (rcu) return rcu;
+    hipLaunchKernelGGL(ranks_renumber_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->c_words.as<uint32_t>(),
+                       (uint32_t)count, c->w_renum.as<int32_t>(), (uint32_t)before.size());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the vector is about to go out of scope)
+    return WK_OK;
+}
+
+// ... and the subject fields of words [first, first + n), subject indices as the tokenizers write them, become such ranks.
 static int words_translate(wk_ctx* c, int64_t first, int64_t n) {
     if ((c->w_mode != 1 && c->w_mode != 2) || n <= 0) return WK_OK;  // (several stream jobs: rewritten per job at the flush)
-    const int32_t* node_of = c->subj_feat.as<int32_t>();
-    if (c->w_mode == 2) {  // (ancestors at the rank: -1 reads as "no node" like an id beyond the tree)
-        const int rc = ensure_subject_ancestors(c, c->st[0], c->w_jobs[0].rank_slot);
-        if (rc) return rc;
-        node_of = c->st[0].subj_node.as<int32_t>();
-    }
-    hipLaunchKernelGGL(words_to_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                       c->c_words.as<uint32_t>() + first, c->c_words.as<uint32_t>() + first, (uint32_t)n, node_of,
-                       (uint32_t)c->n_subjects, (uint32_t)c->n_nodes, scalar_err(c));
+    const int rc = refresh_word_ranks(c, first);
+    if (rc) return rc;
+    hipLaunchKernelGGL(words_to_ranks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       c->c_words.as<uint32_t>() + first, c->c_words.as<uint32_t>() + first, (uint32_t)n,
+                       c->st[0].subj_rank.as<int32_t>(), (uint32_t)c->n_subjects, scalar_err(c));
     HIP_TRY(c, hipGetLastError());
     return WK_OK;
 }
