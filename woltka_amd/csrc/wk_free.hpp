@@ -349,30 +349,30 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
 }
 
 // The lists of results the caches had no room for, counted: a workgroup takes a
-// slice of kLogBins result ids (32-bit counters in LDS) and one of kLogParts
+// slice of kLogBins result ids (32-bit counters in LDS) and one of n_parts
 // shares of the waves' lists, and leaves its counters as they are in `partial`
 // — no atomics on the way out; free_counts_kernel adds the shares up.  The
 // workgroups of one share sit on one XCD (blockIdx % 8), so the share's lists
 // come from HBM once and from that XCD's L2 for the other slices.
 constexpr uint32_t kLogBins = 36864;  // 144 KB
-constexpr uint32_t kLogParts = 32;    // (a multiple of 8)
+constexpr uint32_t kListSharesMax = 32;  // shares of the lists: a multiple of 8, as many as fill the CUs once (one workgroup per CU: the bins)
 constexpr uint32_t kLogThreads = 1024;
 
 struct FreeLogArgs {
     const uint32_t* log;
     const uint32_t* log_cnt;
     uint32_t log_cap, n_waves;
-    uint32_t n_slices;
-    uint32_t* partial;    // [kLogParts][n_slices][kLogBins]
-    uint32_t* part_used;  // [kLogParts][n_slices] 1: the share met results of the slice
+    uint32_t n_slices, n_parts;
+    uint32_t* partial;    // [n_parts][n_slices][kLogBins]
+    uint32_t* part_used;  // [n_parts][n_slices] 1: the share met results of the slice
 };
 
 __global__ void __launch_bounds__(kLogThreads) free_log_kernel(FreeLogArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t bins[];
     __shared__ uint32_t any;
     const uint32_t r = blockIdx.x >> 3, slice = r % a.n_slices, part = (r / a.n_slices) * 8u + (blockIdx.x & 7u);
-    const uint32_t w_lo = (uint32_t)((unsigned long long)part * a.n_waves / kLogParts);
-    const uint32_t w_hi = (uint32_t)((unsigned long long)(part + 1u) * a.n_waves / kLogParts);
+    const uint32_t w_lo = (uint32_t)((unsigned long long)part * a.n_waves / a.n_parts);
+    const uint32_t w_hi = (uint32_t)((unsigned long long)(part + 1u) * a.n_waves / a.n_parts);
     const uint32_t slot = part * a.n_slices + slice;
     // (nothing listed in this share — every result found room in the caches, as under --uniq at a high rank: done)
     uint32_t listed = 0;
@@ -428,13 +428,13 @@ __global__ void __launch_bounds__(kLogThreads) free_log_kernel(FreeLogArgs a) {
 __global__ void __launch_bounds__(256) free_counts_kernel(uint32_t* __restrict__ dense, uint32_t n_results,
                                                           const int32_t* __restrict__ result_node, uint32_t job, uint32_t group,
                                                           const uint32_t* __restrict__ partial, const uint32_t* __restrict__ part_used,
-                                                          uint32_t n_slices, CountTable table) {
+                                                          uint32_t n_slices, uint32_t n_parts, CountTable table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_results) return;
     unsigned long long n = dense[i];
     if (n) dense[i] = 0u;
     const uint32_t slice = i / kLogBins, bin = i - slice * kLogBins;
-    for (uint32_t part = 0; part < kLogParts; ++part) {
+    for (uint32_t part = 0; part < n_parts; ++part) {
         const uint32_t slot = part * n_slices + slice;
         if (part_used[slot]) n += partial[(size_t)slot * kLogBins + bin];
     }

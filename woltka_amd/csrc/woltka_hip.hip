@@ -1981,8 +1981,10 @@ int wk_words_flush(wk_ctx* c) {
             const uint32_t n_slices = (T.results + 1 + kLogBins - 1) / kLogBins;
             HIP_TRY(c, c->f_log.reserve((size_t)n_waves * fa.log_cap * 4));
             HIP_TRY(c, c->f_log_cnt.reserve((size_t)n_waves * 4));
-            HIP_TRY(c, c->f_partial.reserve((size_t)kLogParts * n_slices * kLogBins * 4));
-            HIP_TRY(c, c->f_part_used.reserve((size_t)kLogParts * n_slices * 4));
+            // (shares x slices = workgroups of free_log_kernel, one per CU: as many as run at once)
+            const uint32_t n_parts = std::max(8u, std::min(kListSharesMax, ((uint32_t)c->prop.multiProcessorCount / n_slices) & ~7u));
+            HIP_TRY(c, c->f_partial.reserve((size_t)n_parts * n_slices * kLogBins * 4));
+            HIP_TRY(c, c->f_part_used.reserve((size_t)n_parts * n_slices * 4));
             fa.log = c->f_log.as<uint32_t>();
             fa.log_cnt = c->f_log_cnt.as<uint32_t>();
             KernelTimer* kt = ktimer_begin(c, "classify");
@@ -1994,14 +1996,15 @@ int wk_words_flush(wk_ctx* c) {
             la.log_cap = fa.log_cap;
             la.n_waves = n_waves;
             la.n_slices = n_slices;
+            la.n_parts = n_parts;
             la.partial = c->f_partial.as<uint32_t>();
             la.part_used = c->f_part_used.as<uint32_t>();
             kt = ktimer_begin(c, "free_log");
-            hipLaunchKernelGGL(free_log_kernel, dim3(kLogParts * n_slices), dim3(kLogThreads), (size_t)kLogBins * 4, c->stream, la);
+            hipLaunchKernelGGL(free_log_kernel, dim3(n_parts * n_slices), dim3(kLogThreads), (size_t)kLogBins * 4, c->stream, la);
             ktimer_end(c, kt);
             kt = ktimer_begin(c, "free_counts");
             hipLaunchKernelGGL(free_counts_kernel, dim3((T.results + 256) / 256), dim3(256), 0, c->stream, fa.dense, fa.n_results,
-                               T.rnode.as<int32_t>(), fa.job, fa.group, la.partial, la.part_used, n_slices, table);
+                               T.rnode.as<int32_t>(), fa.job, fa.group, la.partial, la.part_used, n_slices, n_parts, table);
             ktimer_end(c, kt);
             HIP_TRY(c, hipGetLastError());
         }
