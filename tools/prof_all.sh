@@ -11,6 +11,9 @@ for wl in $wls; do
     ordinal) kern=match_hits ;;
     flat) kern=count_subjects ;;
   esac
-  echo "== $wl ($kern)"
-  bash tools/prof_bench.sh ${tag}_$wl $wl 1.0 $kern 2>&1 | tail -12
+  # (FULL="lca ordinal": every PMC set for these, the two traffic passes only for the others)
+  sets=all
+  if [ -n "${FULL:-}" ]; then case " $FULL " in *" $wl "*) sets=all ;; *) sets=traffic ;; esac; fi
+  echo "== $wl ($kern, PMC sets: $sets)"
+  PMC_SETS=$sets bash tools/prof_bench.sh ${tag}_$wl $wl 1.0 $kern 2>&1 | tail -12
 done

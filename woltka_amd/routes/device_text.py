@@ -381,7 +381,12 @@ class DeviceTextRoute:
                                                          extra=ordinal)
                 lap['scan'] += time.perf_counter() - t0
                 lap['blocks'] += 1
+                t1 = time.perf_counter()
                 fresh = tok.new_subjects()
+                if timing and lap['blocks'] <= 16:
+                    lap.setdefault('first', []).append(
+                        (stop - begin, round((t1 - t0) * 1e3, 2), len(fresh),
+                         round((time.perf_counter() - t1) * 1e3, 2)))
                 if ordinal:
                     if fresh:       # genome indices of the gene tables
                         gidx = self.genes.genome_index.get
@@ -473,6 +478,8 @@ class DeviceTextRoute:
                   % (lap['blocks'], tot, lap['wait'], lap['copy'], lap['scan'],
                      lap['read'], lap['span'], lap['rest'],
                      lap.get('unreg', 0.0)), file=sys.stderr)
+            print('[dtok] first blocks (bytes, scan ms, new subjects, names ms):',
+                  lap.get('first'), file=sys.stderr)
             print('[dtok] per block on this thread:', {
                 k: round(v, 3) for k, v in self._dtok_lap.items()},
                 file=sys.stderr)
