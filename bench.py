@@ -190,7 +190,7 @@ class LcaWorkload:
     key = 'lca'
     dominant = 'classify'
     families = ('classify', 'weigh_merge', 'leftover', 'partition_merge')
-    symbols = {'classify': 'wk::weigh_bins_kernel<4, true>',
+    symbols = {'classify': 'wk::weigh_streams_kernel<4>',
                'weigh_merge': 'wk::weigh_merge_kernel',
                'leftover': 'wk::classify_kernel<true, true, 0>',
                'partition_merge': 'wk::partition_merge_kernel'}

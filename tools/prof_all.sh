@@ -6,7 +6,7 @@ tag=${1:-r03prof}; shift
 wls=${*:-"lca lca_free lca_above lca_major lca_uniq ordinal flat"}
 for wl in $wls; do
   case $wl in
-    lca) kern=weigh_bins ;;
+    lca) kern=weigh_streams ;;
     lca_free|lca_above|lca_major|lca_uniq) kern=free_stream ;;
     ordinal) kern=match_hits ;;
     flat) kern=count_subjects ;;
