@@ -95,8 +95,11 @@ class DeviceTextRoute:
             size = os.path.getsize(fp)
         except OSError:
             return None
-        # (read-map text deflates 4-6x; a plain file needs its own size)
-        need = size * 8 if fp.endswith('.gz') else size
+        # (a plain file needs its own size, a chain of 'WK' members what its
+        # members say they hold; any other gzip file: text deflates 4-6x)
+        need = size
+        if fp.endswith('.gz'):
+            need = self._inflated_size(fp) or size * 8
         i = self._sbuf_next
         self._sbuf_next ^= 1
         buf = self._sbuf[i]
@@ -107,6 +110,27 @@ class DeviceTextRoute:
                 return self._sbuf[i]
             self._sbuf[i] = buf
         return buf
+
+    @staticmethod
+    def _inflated_size(fp):
+        """Bytes a chain of 'WK' gzip members inflates to (the ISIZE fields of
+        its members, RFC 1952), or None for any other file."""
+        import mmap
+        import struct
+        from .. import pgzip
+        try:
+            with open(fp, 'rb') as f:
+                mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        except (OSError, ValueError):
+            return None
+        try:
+            spans = pgzip.members_of(mm)
+            if spans is None:
+                return None
+            return sum(struct.unpack_from('<I', mm, b - 4)[0]
+                       for _, b in spans)
+        finally:
+            mm.close()
 
     def _device_strata_groups(self, sample):
         """The labels' (sample, stratum) group ids to the device — again after

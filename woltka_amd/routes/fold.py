@@ -331,8 +331,10 @@ class Folding:
         uu = np.concatenate([x[4] for x in stash] +
                             [np.zeros(n_big, dtype=np.int64)])
         n_small = uu.size - n_big
-        bk = np.concatenate([x[4] for x in bigs]).tolist() if bigs else []
-        bn = np.concatenate([x[5] for x in bigs]).tolist() if bigs else []
+        bk = np.concatenate([x[4] for x in bigs]).astype(np.int64) if bigs \
+            else np.zeros(0, dtype=np.int64)
+        bn = np.concatenate([x[5] for x in bigs]).astype(np.int64) if bigs \
+            else np.zeros(0, dtype=np.int64)
         n_t = len(self._lz_strata) + 1
         allkey = (sm * n_t + (tt + 1)) * (nat.FEATURE_UNASSIGNED + 1) + ff
         for job in np.unique(j).tolist():
@@ -352,9 +354,18 @@ class Folding:
             # rational parts of this job: cell index -> Fraction
             extra = {}
             ukey = key[starts]
-            for q in np.flatnonzero(j[n_small:] == job).tolist():
-                i = int(np.searchsorted(ukey, allkey[n_small + q]))
-                extra[i] = extra.get(i, 0) + Fraction(bn[q], bk[q])
+            qs = np.flatnonzero(j[n_small:] == job)
+            if qs.size:
+                # (n / k per part; parts of one cell with one k are added as
+                # integers first: k <= 4095)
+                at_cell = np.searchsorted(ukey, allkey[n_small + qs])
+                both, inv = np.unique(at_cell.astype(np.int64) * 4096 + bk[qs],
+                                      return_inverse=True)
+                tot = np.zeros(both.size, dtype=np.int64)
+                np.add.at(tot, inv, bn[qs])
+                for c, t in zip(both.tolist(), tot.tolist()):
+                    i, k = divmod(c, 4096)
+                    extra[i] = extra.get(i, 0) + Fraction(t, k)
             cuts = np.flatnonzero(s_[1:] != s_[:-1]) + 1
             lo = [0] + cuts.tolist()
             hi = cuts.tolist() + [s_.size]
