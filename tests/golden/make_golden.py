@@ -799,8 +799,19 @@ def gen_cli_coords_maps():
                    name='cli_coords_maps.json')
 
 
+def gen_cli_coords_zero():
+    """`--coords --outmap` with hits of aligned length 0 (CIGAR `*` or all
+    soft clip, a 0 in the length column): ordinal_mapper counts them when it
+    decides whether the next query still fits the chunk (`idx + len(records)
+    > n`, ordinal.py:222) and drops them afterwards (ordinal.py:231), so
+    they move chunk boundaries -- and with them the order of the read map's
+    lines -- without ever being matched."""
+    gen_cli_coords(seed=89, n_cases=20, with_maps=True, zero_len=True,
+                   name='cli_coords_zero.json')
+
+
 def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
-                   name='cli_coords.json', with_maps=False):
+                   name='cli_coords.json', with_maps=False, zero_len=False):
     """Coord-match (`--coords`) on random small inputs: reads placed over /
     next to genes of the bundled coordinates file, three formats with
     coordinates, random overlap thresholds, optional gene-length normalisation
@@ -831,16 +842,28 @@ def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
             for qi in range(rng.randint(15, 60) * (4 if with_maps else 1)):
                 q = f'r{qi:04d}'
                 paired = fmt == 'sam' and rng.random() < 0.5
-                for h in range(rng.choice([1, 1, 2, 3])):
+                # (zero_len: a fifth of the queries have nothing but empty
+                # hits, some of them many)
+                hollow = zero_len and rng.random() < 0.2
+                n_hits = rng.choice([1, 1, 2, 3])
+                if hollow and rng.random() < 0.3:
+                    n_hits = rng.randint(4, 12)
+                for h in range(n_hits):
                     s = rng.choice(subjects)
                     gs, ge = rng.choice(genes[s])
                     ln = rng.choice([75, 100, 150])
                     pos = max(1, gs + rng.randint(-ln, ge - gs))
+                    empty = hollow or (zero_len and rng.random() < 0.25)
                     if fmt == 'sam':
                         flag = rng.choice([99, 147]) if paired else \
                             rng.choice([0, 16, 256])
                         cig = rng.choice([f'{ln}M', f'{ln - 10}M2D10M',
                                           f'5S{ln - 5}M'])
+                        if empty:
+                            cig = rng.choice(['*', f'{ln}S', '20H'])
+                    elif empty:
+                        ln = 0
+                    if fmt == 'sam':
                         lines.append(f'{q}\t{flag}\t{s}\t{pos}\t255\t{cig}\t='
                                      f'\t0\t0\t*\t*\n')
                     elif fmt == 'b6o':
@@ -894,7 +917,8 @@ def gen_cli_coords(seed=53, n_cases=18, with_exclude=False,
         if rng.random() < 0.3:
             kw['chunk'] = rng.choice([5, 40])
         if with_maps:
-            kw['chunk'] = rng.choice([None, 7, 30, 90, 400])
+            kw['chunk'] = rng.choice([7, 13, 30, 90] if zero_len
+                                     else [None, 7, 30, 90, 400])
             if kw['chunk'] is None:
                 del kw['chunk']
             kw.pop('sizes', None)
@@ -1649,6 +1673,7 @@ def main():
     gen_cli_coords()
     gen_cli_coords_excl()
     gen_cli_coords_maps()
+    gen_cli_coords_zero()
     gen_cli_strata()
     gen_cli_config5()
     gen_cli_medium()

@@ -5,7 +5,9 @@ wrote (table text per rank, decompressed read maps) or raised.  The GPU path
 must write the same bytes / raise the same error.  18 more cases
 (gen_cli_coords) go through `--coords`: reads placed over / next to genes of
 the bundled coordinates, three formats, overlap 50 / 80 / 100, gene-length
-normalisation (`--sizes .`) and gene -> function maps."""
+normalisation (`--sizes .`) and gene -> function maps; 16 with `--outmap` and
+small chunks, 20 more of those with hits of aligned length 0 (which count
+towards the reference's chunk boundaries and nothing else, ordinal.py:222,231)."""
 import contextlib
 import gzip
 import io
@@ -22,7 +24,8 @@ _BIG = 'big_' if os.environ.get('WOLTKA_BIG_SWEEP') else ''    # one-off sweeps
 CASES = load_vectors(_BIG + 'cli_random.json') + \
     load_vectors(_BIG + 'cli_coords.json') + \
     ([] if _BIG else load_vectors('cli_coords_excl.json')) + \
-    ([] if _BIG else load_vectors('cli_coords_maps.json'))
+    ([] if _BIG else load_vectors('cli_coords_maps.json')) + \
+    ([] if _BIG else load_vectors('cli_coords_zero.json'))
 TAX = join(DATA, 'taxonomy')
 FUN = join(DATA, 'function')
 

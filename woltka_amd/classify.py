@@ -291,14 +291,17 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
     def native_chunks(self, stream, head, exclude, block_bytes, ordinal,
                       want_names, trimsub=None, want_groups=False,
                       want_strings=True, want_samples=False, cover=None,
-                      fmt='sam', part=None, words=False, dmaps=None):
+                      fmt='sam', part=None, words=False, dmaps=None,
+                      keep_empty=False):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed, strata ids, name descriptors, sample ids,
         ranges) where packed = (subj, qoff) of subject indices, or for
         coord-match (genome, beg, end, length, hoff).  With ``cover`` (a
         ``ranges.Coverage``) the "ex" columns are produced for plain
         classification too and ``ranges`` = (coverage subject id, beg, end) per
-        record."""
+        record.  ``keep_empty``: hits of aligned length 0 stay in the arrays
+        (`regroup_hits` counts them where ordinal.py:222 does, then drops
+        them)."""
         from .align import native_sam_blocks
         if self.tok is None:
             self.tok = nat.Tokenizer(tokenizer_threads(), exclude)
@@ -375,7 +378,8 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
             if not ordinal:
                 tok.set_subject_map(None)
             for buf, res in native_sam_blocks(stream, tok, block_bytes,
-                                              extra=3 if cover is not None
+                                              extra=3 if (cover is not None
+                                                          or keep_empty)
                                               else int(ordinal),
                                               want_names=want_names,
                                               head=head,

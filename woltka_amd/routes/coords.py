@@ -62,20 +62,43 @@ class CoordMatchRoute:
 
     def regroup_hits(self, chunks, n):
         """Chunks of the native tokenizer's coord-match arrays cut again
-        where ordinal.ordinal_mapper cuts (ordinal.py:219-237: a chunk takes
-        queries while its hits stay <= ``n``): the order in which a read map
+        where ordinal.ordinal_mapper cuts (ordinal.py:219-237): a chunk is
+        flushed before the query whose records -- those of aligned length 0
+        included, `idx + len(records) > n` -- would not fit next to the
+        *kept* hits cached so far; only hits with a length are cached
+        (ordinal.py:231).  The chunks come in with the zero-length hits still
+        there (``native_chunks(keep_empty=True)``) and leave without them,
+        queries left with no hit dropped.  The order in which a read map
         lists the queries is decided chunk by chunk (`_mapper_order`).  Only
         read-map runs need it; the counts do not depend on chunking."""
         held = None             # (reads, arrays..., per-read arrays) not yet emitted
 
-        def cut(reads, packed, strata, names, samples, ranges, lo, hi):
+        def take(v, keep):
+            return None if v is None else v[keep]
+
+        def cut(reads, packed, strata, names, samples, ranges, lo, hi,
+                slim=True):
             genome, beg, end, length, hoff = packed
             a, b = int(hoff[lo]), int(hoff[hi])
-            return (reads[lo:hi],
-                    (genome[a:b], beg[a:b], end[a:b], length[a:b],
-                     (hoff[lo:hi + 1] - hoff[lo]).astype(np.int32)),
-                    None if strata is None else strata[lo:hi], None,
-                    None if samples is None else samples[lo:hi], None)
+            hoff = (hoff[lo:hi + 1] - hoff[lo]).astype(np.int64)
+            genome, beg, end, length = (genome[a:b], beg[a:b], end[a:b],
+                                        length[a:b])
+            reads = reads[lo:hi]
+            strata = None if strata is None else strata[lo:hi]
+            samples = None if samples is None else samples[lo:hi]
+            if slim and length.size and not length.all():
+                good = length != 0
+                kept = np.concatenate(([0], np.cumsum(good)))[hoff]
+                genome, beg, end, length = (genome[good], beg[good],
+                                            end[good], length[good])
+                alive = kept[1:] > kept[:-1]
+                if not alive.all():
+                    reads = [r for r, ok in zip(reads, alive) if ok]
+                    strata, samples = take(strata, alive), take(samples, alive)
+                    kept = np.concatenate((kept[:1], kept[1:][alive]))
+                hoff = kept
+            return (reads, (genome, beg, end, length, hoff.astype(np.int32)),
+                    strata, None, samples, None)
 
         def join(x, y):
             if x is None:
@@ -92,18 +115,30 @@ class CoordMatchRoute:
             reads, packed = item[0], item[1]
             hoff = packed[4].astype(np.int64)
             lo, n_reads = 0, len(reads)
+            # kept hits before each query, records (kept or not) of each
+            before = np.concatenate(([0], np.cumsum(packed[3] != 0)))[hoff]
+            raw = np.diff(hoff)
+            reach = before[:-1] + raw       # what the flush test looks at
+            widest = int(raw.max()) if raw.size else 0
             while lo < n_reads:
-                # the longest run of queries from `lo` with at most n hits (a
-                # query of more hits than that is a chunk of its own)
-                hi = int(np.searchsorted(hoff, hoff[lo] + n, side='right')) - 1
-                hi = max(hi, lo + 1)
+                # the chunk opens with query `lo` whatever its size; it is
+                # flushed before the first later query j with
+                # kept(lo..j-1) + records(j) > n
+                limit = int(before[lo]) + n
+                j0 = max(lo + 1, int(np.searchsorted(
+                    before, limit - widest, side='right')) - 1)
+                j1 = min(n_reads, int(np.searchsorted(
+                    before, limit, side='right')) + 1)
+                over = np.flatnonzero(reach[j0:j1] > limit)
+                hi = j0 + int(over[0]) if over.size else n_reads
                 if hi >= n_reads and not final:
                     break       # may continue in the next block
-                hi = min(hi, n_reads)
-                yield cut(*item, lo, hi)
+                out = cut(*item, lo, hi)
+                if out[0]:
+                    yield out
                 lo = hi
             return_rest[0] = None if lo >= n_reads else \
-                cut(*item, lo, n_reads)
+                cut(*item, lo, n_reads, slim=False)
 
         return_rest = [None]
         for item in chunks:

@@ -408,7 +408,8 @@ def classify(
                             want_names, trimsub, want_groups=native_strata,
                             want_strings=want_strings, want_samples=native_demux,
                             cover=cover, fmt=fmt_, part=part, words=words,
-                            dmaps=dmaps)
+                            dmaps=dmaps,
+                            keep_empty=bool(ordinal and rank2dir is not None))
                         if ordinal and rank2dir is not None:
                             chunks = engine.regroup_hits(chunks, n)
                     else:
