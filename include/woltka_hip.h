@@ -323,10 +323,14 @@ int wk_dtok_copy(wk_ctx* ctx, const char* text, int64_t begin, int64_t stop);
 int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
                  int64_t stop, int extra, int64_t* n_lines, int* status);
 /* The format of the blocks wk_dtok_scan is given from now on: WK_FMT_SAM
- * (default), or — plain flavour only — WK_FMT_MAP (align.parse_map_file,
- * align.py:621-674) / WK_FMT_B6O (align.parse_b6o_file, align.py:753-803):
- * rows `query <tab> subject ...`, grouped into runs of equal queries the same
- * way; lines that are not rows of the format are ignored. */
+ * (default), WK_FMT_B6O (align.parse_b6o_file / _ex, align.py:753-856),
+ * WK_FMT_PAF (align.parse_paf_file / _ex, align.py:984-1095) or -- plain
+ * flavour only, it has no other -- WK_FMT_MAP (align.parse_map_file,
+ * align.py:621-674): rows `query <tab> subject ...` (PAF: the subject is the
+ * 6th field), grouped into runs of equal queries the same way; lines that are
+ * not rows of the format are ignored.  With `extra` a BLAST / PAF row also
+ * gives start, end and aligned length; number text beyond sign-and-digits
+ * sends the block to the host tokenizer (status 1), as POS / CIGAR do. */
 int wk_dtok_format(wk_ctx* ctx, int fmt);
 int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
                  int* status);

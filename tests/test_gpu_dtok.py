@@ -326,6 +326,14 @@ def _random_rows(rng, fmt, n_queries, subjects):
             if fmt == 'map':
                 tail = rng.choice(['', '', '', ' ', '\r', ' \t', '\textra\tcols'])
                 lines.append(f'{name}\t{s}{tail}')
+            elif fmt == 'paf':
+                a = rng.randrange(0, 5000)
+                ln = rng.randrange(50, 150)
+                more = rng.choice(['', '', '\ttp:A:P\tcm:i:12', '\t'])
+                lines.append(f'{name}\t{ln}\t0\t{ln}\t{rng.choice("+-")}\t{s}\t'
+                             f'9999999\t{a}\t{a + ln}\t{ln}\t{ln}\t60{more}'
+                             if rng.random() < 0.9 else
+                             f'{name}\t\t\t\t\t{s}\t')  # (seven fields: a row)
             else:
                 a, b = sorted((rng.randrange(1, 5000), rng.randrange(1, 5000)))
                 lines.append(f'{name}\t{s}\t{rng.randrange(80, 100)}.5\t'
@@ -333,17 +341,20 @@ def _random_rows(rng, fmt, n_queries, subjects):
                              f'1e-{rng.randrange(5, 50)}\t{rng.randrange(50, 300)}')
             if rng.random() < 0.03:
                 # (two fields are a row of a map, not of a BLAST table)
+                # (and six fields are not a row of a PAF file: align.py:1021-1024)
                 lines.append(rng.choice(['', 'no tab here', f'{name}'] + (
-                    [f'{name}\tonly_two_fields'] if fmt == 'b6o' else [])))
+                    [f'{name}\tonly_two_fields'] if fmt != 'map' else []) + (
+                    [f'{name}\t100\t0\t100\t+\t{subjects[0]}'] if fmt == 'paf'
+                    else [])))
     return '\n'.join(lines) + '\n'
 
 
-@pytest.mark.parametrize('fmt', ['map', 'b6o'])
+@pytest.mark.parametrize('fmt', ['map', 'b6o', 'paf'])
 @pytest.mark.parametrize('block', [1 << 26, 1 << 15])
 @pytest.mark.parametrize('maps', [False, True])
 def test_map_and_b6o_rows_on_the_device(tmp_path, monkeypatch, fmt, block,
                                         maps):
-    """Simple maps and BLAST tabular text through the device tokenizer (and,
+    """Simple maps, BLAST tabular text and PAF through the device tokenizer (and,
     with --outmap, the read maps formatted there) against the host tokenizer:
     same log, same tables, same read maps — and the device route was taken."""
     import gzip
@@ -383,3 +394,117 @@ def test_map_and_b6o_rows_on_the_device(tmp_path, monkeypatch, fmt, block,
     assert res[0][0] == res[1][0]
     assert res[0][2] == res[1][2]
     assert all(len(v) > 50 for v in res[0][0].values())
+
+
+def _random_coords_rows(rng, fmt, n_queries, odd=False):
+    """A gene coordinates file and BLAST tabular / PAF rows with coordinates on
+    its genomes (align.py:807-856, 1046-1095): genomes without genes, reversed
+    subject coordinates (b6o), hits of length 0, lines that are not rows (too
+    few fields); `odd`: number text int() / float() accept that the kernels do
+    not read themselves ('+12', ' 7', '1_0', 'nan') -- those blocks go back to
+    the host tokenizer."""
+    coords, _ = _random_coords_sam(rng, 0)
+    lens = {}
+    for part in coords.split('>')[1:]:
+        rows = part.strip().split('\n')
+        lens[rows[0]] = max(max(int(r.split('\t')[1]), int(r.split('\t')[2]))
+                            for r in rows[1:]) + 200
+    lines = []
+    for q in range(n_queries):
+        name = f'read{q}'
+        for _ in range(rng.choice([1, 1, 1, 2, 3, 6])):
+            g = rng.choice(list(lens) + ['Gnone'])
+            ln = rng.choice([0, 30, 75, 100, 150, 150])
+            a = rng.randrange(1, lens.get(g, 500))
+            sc = rng.choice(['200', '57.5', '1e-5', '3.2E+01', '.5', '7.'])
+            num = str(ln)
+            # (in the first quarter of the file, so that later blocks stay
+            # on the device)
+            odd_here = odd and q < n_queries // 4
+            if odd_here and rng.random() < 0.02:
+                num = rng.choice([f'+{ln}', f' {ln}', f'{ln} ', '1_0'])
+            if odd_here and rng.random() < 0.02:
+                sc = rng.choice(['nan', 'inf', ' 12.5', '-INF'])
+            if fmt == 'b6o':
+                x, y = a, a + max(ln, 1) - 1
+                if rng.random() < 0.5:
+                    x, y = y, x
+                lines.append(f'{name}\t{g}\t98.5\t{num}\t0\t0\t1\t{ln}\t{x}\t{y}'
+                             f'\t1e-9\t{sc}')
+            else:
+                mapq = rng.choice(['60', '0', '255'])
+                if odd_here and rng.random() < 0.02:
+                    mapq = rng.choice(['6_0', 'x', '+60', ''])   # (x, '': skipped)
+                lines.append(f'{name}\t{ln}\t0\t{ln}\t+\t{g}\t9999999\t{a - 1}\t'
+                             f'{a - 1 + ln}\t{ln}\t{num}\t{mapq}' +
+                             rng.choice(['', '', '\ttp:A:P']))
+            if rng.random() < 0.03:
+                lines.append(rng.choice(['', 'no tab', f'{name}\t{g}\t1\t2',
+                                         f'{name}\t5\t0\t5\t+\t{g}\t9\t1\t6\t5']))
+    return coords, '\n'.join(lines) + '\n'
+
+
+@pytest.mark.parametrize('fmt', ['b6o', 'paf'])
+@pytest.mark.parametrize('block', [1 << 26, 1 << 15])
+@pytest.mark.parametrize('odd', [False, True])
+def test_b6o_and_paf_coord_match_on_the_device(tmp_path, monkeypatch, fmt,
+                                               block, odd):
+    """--coords on BLAST tabular text and PAF through the "ex" flavour of the
+    device tokenizer vs the host tokenizer: same tables, same log -- and the
+    hits were staged on the device."""
+    from woltka_amd import classify as C
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    rng = random.Random(hash((fmt, block, odd)) & 0xFFFF)
+    coords, text = _random_coords_rows(rng, fmt, 4000, odd)
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    (indir / f'S1.{fmt}').write_text(text)
+    (indir / f'S2.{fmt}').write_text(
+        text[:len(text) // 3].rsplit('\n', 1)[0] + '\n')
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    kw = dict(input_fp=str(indir), input_fmt=fmt, coords_fp=str(cfp),
+              overlap=rng.choice([50, 80]))
+    C.ROUTES.clear()
+    a, log_a = _run(tmp_path, 'd', False, **kw)
+    routes = dict(C.ROUTES)
+    if not odd:
+        assert routes.get('dhits', 0) > 0 and not routes.get('host_block'), \
+            routes
+    elif block < 1 << 20:
+        assert routes.get('dhits', 0) > 0 and routes.get('host_block', 0) > 0, \
+            routes
+    b, log_b = _run(tmp_path, 'h', True, **kw)
+    assert a == b and log_a == log_b
+    assert len(a['table']) > 500
+
+
+@pytest.mark.parametrize('fmt,bad', [
+    ('b6o', 'readX\tG001\t98.5\tabc\t0\t0\t1\t100\t5\t104\t1e-9\t200'),
+    ('b6o', 'readX\tG001\t98.5\t100\t0\t0\t1\t100\t5\t104\t1e-9\tscore'),
+    ('b6o', 'readX\tG001\t98.5\t100\t0\t0\t1\t100\tfive\t104\t1e-9\t200'),
+    ('b6o', 'readX\tG001\t98.5\tabc\t0'),
+])
+def test_b6o_numbers_that_raise_do_so_on_both_routes(tmp_path, fmt, bad):
+    """int() / float() of a BLAST row's fields raise ValueError in
+    parse_b6o_file_ex (align.py:832-835; a short line too, when its fourth
+    field is no number): the device route leaves the block to the host
+    tokenizer, which raises the same way."""
+    rng = random.Random(4)
+    coords, text = _random_coords_rows(rng, fmt, 300)
+    lines = text.split('\n')
+    lines.insert(len(lines) // 2, bad)
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    (indir / f'S1.{fmt}').write_text('\n'.join(lines))
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    kw = dict(input_fp=str(indir), input_fmt=fmt, coords_fp=str(cfp))
+    errs = []
+    for host in (False, True):
+        try:
+            _run(tmp_path, f'e{host}', host, **kw)
+            errs.append(None)
+        except Exception as e:      # noqa: BLE001
+            errs.append((type(e), str(e)))
+    assert errs[0] == errs[1] and errs[0] is not None

@@ -565,6 +565,30 @@ def test_b6o_ex_needs_a_float_score():
         run_native(''.join(bad).encode(), 1, 1 << 16, extra=True, fmt='b6o')
 
 
+def test_number_text_as_the_reference_reads_it():
+    """What the reference gave on these rows when this test was written
+    (parse_b6o_file_ex / parse_paf_file_ex, align.py:832-835, 1067): int()
+    takes single underscores between digits; a short BLAST row whose fourth
+    field is no number raises (int(x[3]) is evaluated before x[11] is missed),
+    one whose fourth field is a number is skipped."""
+    rows = ['r1\tG1\t98.5\t1_0\t0\t0\t1\t100\t5\t104\t1e-9\t200\n',
+            'r2\tG1\t98.5\t100\t0\n']
+    got, _ = run_native(''.join(rows).encode(), 1, 1 << 16, extra=True,
+                        fmt='b6o')
+    assert got == [('r1', [('G1', None, 10, 4, 104)])]
+    assert list(align.parse_align(rows, 'b6o', None, True)) == \
+        [('r1', [('G1', 200.0, 10, 4, 104)])]
+    short = [rows[0], 'r2\tG1\t98.5\tabc\t0\n']
+    with pytest.raises(ValueError):
+        list(align.parse_align(short, 'b6o', None, True))
+    with pytest.raises(ValueError):
+        run_native(''.join(short).encode(), 1, 1 << 16, extra=True, fmt='b6o')
+    paf = ['q\t10\t0\t10\t+\tG\t99\t1\t1_1\t10\t1_0\t6_0\n']
+    got, _ = run_native(''.join(paf).encode(), 1, 1 << 16, extra=True,
+                        fmt='paf')
+    assert got == [('q', [('G', None, 10, 1, 11)])]
+
+
 @pytest.mark.parametrize('threads,block', [(1, 1 << 20), (4, 3000), (7, 700)])
 def test_packed_words_equal_the_plain_arrays(threads, block):
     """wk_tok_fetch_packed: subject | position << 23 | size << 27 per record,

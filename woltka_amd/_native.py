@@ -595,7 +595,7 @@ class Context:
 
     def dtok_format(self, fmt):
         """Format of the blocks ``dtok_scan`` is given from now on: 'sam',
-        'map' or 'b6o' (the plain flavour only for the latter two)."""
+        'b6o', 'paf' or 'map' (the last in the plain flavour only)."""
         self._check(self._lib.wk_dtok_format(self._h, Tokenizer.FORMATS[fmt]))
 
     def dtok_emit(self):

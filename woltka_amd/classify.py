@@ -309,10 +309,12 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         device_ex = ordinal and cover is None and not want_names and \
             (not want_groups or self._dstrata is not None) and \
             not want_samples and len(self.jobs) <= nat.MAX_JOBS
-        # (the device tokenises SAM in both flavours, simple maps and BLAST
-        # tabular text in the plain one: align.py:621-674, 753-803)
+        # (the device tokenises SAM, BLAST tabular text and PAF in both
+        # flavours, simple maps in the plain one -- they have no other:
+        # align.py:258-547, 621-674, 753-981, 984-1213)
         if (words or device_ex or dmaps) and (
-                fmt == 'sam' or (fmt in ('map', 'b6o') and not ordinal)) and \
+                fmt in ('sam', 'b6o', 'paf') or (fmt == 'map' and
+                                                 not ordinal)) and \
                 not exclude and part is None and \
                 not os.environ.get('WOLTKA_NO_DTOK'):
             from .align import _parallel_reader

@@ -63,7 +63,7 @@ struct DictSlot {
 struct DtokArgs {
     const unsigned char* text;  // [n] + 64 readable bytes behind
     uint32_t n;
-    uint32_t fmt;  // 0 SAM, 1 simple map, 2 BLAST tabular (WK_FMT_*; plain flavour only for 1 and 2)
+    uint32_t fmt;  // 0 SAM, 1 simple map, 2 BLAST tabular, 3 PAF (WK_FMT_*; the simple map in the plain flavour only)
     const uint32_t* line_start;  // [n_lines + 1], line_start[n_lines] = n (+1 if the last line has no newline)
     uint32_t n_lines;
     int32_t* lsubj;    // [n_lines]
@@ -205,13 +205,115 @@ __device__ __forceinline__ int32_t dtok_subject(const DtokArgs& a, uint32_t rb, 
     return id;
 }
 
+// ---- "ex" rows of BLAST tabular text and PAF (coord-match) ---------------------------
+// int() / float() of a field as far as the kernels go: blanks around, a sign, decimal
+// digits (a float: digits with a point and an exponent).  Anything else Python may or
+// may not accept (underscores, "nan", other white space ...): false, and the block goes to
+// the host's parsers.
+__device__ __forceinline__ bool dtok_blank(unsigned char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); }
+
+__device__ inline bool dtok_int_field(const unsigned char* __restrict__ t, uint32_t b, uint32_t e, long long& v) {
+    while (b < e && dtok_blank(t[b])) ++b;
+    while (e > b && dtok_blank(t[e - 1u])) --e;
+    bool neg = false;
+    if (b < e && (t[b] == '-' || t[b] == '+')) neg = t[b++] == '-';
+    if (b >= e || e - b > 10u) return false;
+    long long x = 0;
+    for (; b < e; ++b) {
+        const uint32_t d = (uint32_t)t[b] - (uint32_t)'0';
+        if (d > 9u) return false;
+        x = x * 10 + (long long)d;
+    }
+    v = neg ? -x : x;
+    return true;
+}
+
+__device__ inline bool dtok_float_field(const unsigned char* __restrict__ t, uint32_t b, uint32_t e) {
+    while (b < e && dtok_blank(t[b])) ++b;
+    while (e > b && dtok_blank(t[e - 1u])) --e;
+    if (b < e && (t[b] == '-' || t[b] == '+')) ++b;
+    uint32_t digits = 0;
+    while (b < e && (uint32_t)t[b] - (uint32_t)'0' <= 9u) ++b, ++digits;
+    if (b < e && t[b] == '.') {
+        ++b;
+        while (b < e && (uint32_t)t[b] - (uint32_t)'0' <= 9u) ++b, ++digits;
+    }
+    if (digits == 0u) return false;
+    if (b < e && (t[b] == 'e' || t[b] == 'E')) {
+        ++b;
+        if (b < e && (t[b] == '-' || t[b] == '+')) ++b;
+        uint32_t ed = 0;
+        while (b < e && (uint32_t)t[b] - (uint32_t)'0' <= 9u) ++b, ++ed;
+        if (ed == 0u) return false;
+    }
+    return b == e;
+}
+
+// One line of BLAST tabular text (align.parse_b6o_file_ex, align.py:807-856: `x =
+// line.split('\t')`; qseqid, sseqid, length, score = x[0], x[1], int(x[3]), float(x[11]);
+// start, end = sorted(int(x[8]), int(x[9])); a line of fewer than twelve fields is
+// skipped -- unless x[3] is there and no number: int() raises before x[11] is missed) or
+// of PAF (align.parse_paf_file_ex, align.py:1046-1095: (x[5], int(x[11]), int(x[10]),
+// int(x[7]), int(x[8])), a line that fails either way skipped).  Start as the staged hits
+// hold it (0-based), end, aligned length.
+__device__ inline void dtok_row_ex(const DtokArgs& a, uint32_t i, uint32_t lo, uint32_t hi) {
+    uint32_t f[13];
+    uint32_t nf = 1;
+    f[0] = lo;
+    for (uint32_t p = lo; p < hi && nf < 13u; ++p)
+        if (a.text[p] == '\t') f[nf++] = p + 1u;
+    auto fe = [&](uint32_t k) { return k + 1u < nf ? f[k + 1u] - 1u : hi; };
+    const bool b6o = a.fmt == 2u;
+    auto bad = [&] {
+        a.lsubj[i] = kLineBad;
+        a.lmeta[i] = 0;
+        atomicOr(&a.state->flags, kDtokBadNumber);
+    };
+    long long n = 0, x = 0, y = 0, sc = 0;
+    if (nf < 12u) {
+        if (b6o && nf >= 4u && !dtok_int_field(a.text, f[3], fe(3), n)) return bad();  // (the host knows whether int() raises)
+        a.lsubj[i] = kLineUnmapped;
+        a.lmeta[i] = 0;
+        return;
+    }
+    const uint32_t qn = fe(0) - lo;
+    if (qn >= (1u << 28)) {
+        a.lsubj[i] = kLineBad;
+        a.lmeta[i] = 0;
+        atomicOr(&a.state->flags, kDtokLongName);
+        return;
+    }
+    bool ok;
+    if (b6o)
+        ok = dtok_int_field(a.text, f[3], fe(3), n) && dtok_float_field(a.text, f[11], fe(11)) &&
+             dtok_int_field(a.text, f[8], fe(8), x) && dtok_int_field(a.text, f[9], fe(9), y);
+    else
+        ok = dtok_int_field(a.text, f[11], fe(11), sc) && dtok_int_field(a.text, f[10], fe(10), n) &&
+             dtok_int_field(a.text, f[7], fe(7), x) && dtok_int_field(a.text, f[8], fe(8), y);
+    long long beg = x, end = y;
+    if (b6o) {
+        beg = (x < y ? x : y) - 1;
+        end = x < y ? y : x;
+    }
+    ok = ok && n >= 0 && n <= 2147483647ll && beg >= -2147483647ll && beg <= 2147483647ll && end >= -2147483647ll && end <= 2147483647ll;
+    if (!ok) return bad();
+    const uint32_t sub = b6o ? 1u : 5u;
+    a.lmeta[i] = qn;
+    a.lsubj[i] = dtok_subject(a, f[sub], fe(sub) - f[sub]);
+    a.lbeg[i] = (int32_t)beg;
+    a.lend[i] = (int32_t)end;
+    a.llen[i] = (uint32_t)n;
+}
+
 // a thread per line: QNAME / FLAG / RNAME, mate, subject id; kEx: also POS and
 // CIGAR -> start, end, aligned length (align.py:376-398, 572-583).  The simple
 // map (align.parse_map_file, align.py:621-674: query <tab> subject, the subject
 // right-stripped, lines without a tab ignored) and BLAST tabular rows
 // (align.parse_b6o_file, align.py:753-803: `qseqid, sseqid, _ = line.split('\t',
-// 2)`, lines of fewer fields ignored) are split here too; an ignored line does not
-// end a run of equal queries, like an unmapped SAM record.
+// 2)`, lines of fewer fields ignored) are split here too, and so are PAF rows
+// (align.parse_paf_file, align.py:984-1045: `qname, _, _, _, _, tname, _ =
+// line.split('\t', 6)`, lines of fewer than seven fields ignored); an ignored line
+// does not end a run of equal queries, like an unmapped SAM record.
 template <bool kEx>
 __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,20 +322,27 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
     uint32_t hi = a.line_start[i + 1];  // behind the line's newline (or n + 1 for a last line without one)
     hi = hi > lo ? hi - 1u : lo;        // the newline itself / the end of the text
     if (hi > a.n) hi = a.n;
+    if constexpr (kEx) {
+        if (a.fmt != 0u) return dtok_row_ex(a, i, lo, hi);
+    }
     if constexpr (!kEx) {
         if (a.fmt != 0u) {
-            uint32_t t0 = hi, t1 = hi;
+            // the query ends at the first tab; the subject is the field behind tab
+            // number `sub` (the 2nd field, PAF: the 6th) and ends at the next tab
+            const uint32_t sub = a.fmt == 3u ? 4u : 0u;
+            uint32_t t0 = hi, ts = hi, t1 = hi, seen = 0;
             for (uint32_t p = lo; p < hi; ++p)
                 if (a.text[p] == '\t') {
-                    if (t0 == hi) {
-                        t0 = p;
-                    } else {
+                    if (seen == 0u) t0 = p;
+                    if (seen == sub) ts = p;
+                    if (seen == sub + 1u) {
                         t1 = p;
                         break;
                     }
+                    ++seen;
                 }
             const uint32_t qn = t0 - lo;
-            if (t0 == hi || (a.fmt == 2u && t1 == hi)) {  // not a row of the format
+            if (t0 == hi || (a.fmt >= 2u && t1 == hi)) {  // not a row of the format
                 a.lsubj[i] = kLineUnmapped;
                 a.lmeta[i] = 0;
                 return;
@@ -244,7 +353,7 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
                 atomicOr(&a.state->flags, kDtokLongName);
                 return;
             }
-            const uint32_t rb = t0 + 1u;
+            const uint32_t rb = ts + 1u;
             uint32_t re = t1;
             if (a.fmt == 1u)  // subject.rstrip()
                 while (re > rb) {

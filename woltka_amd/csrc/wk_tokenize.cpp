@@ -228,7 +228,9 @@ inline bool parse_int(const char* p, const char* e, long& v) {
     if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
     if (p >= e) return false;
     long x = 0;
-    for (; p < e; ++p) {
+    for (const char* b = p; p < e; ++p) {
+        // (int() takes single underscores between digits)
+        if (*p == '_' && p > b && p[-1] != '_' && p + 1 < e && p[1] >= '0' && p[1] <= '9') continue;
         if (*p < '0' || *p > '9') return false;
         x = x * 10 + (*p - '0');
     }
@@ -273,7 +275,13 @@ inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
         L.ok = true;
         return L;
     }
-    if (nf < want) return L;
+    if (nf < want) {
+        // (parse_b6o_file_ex evaluates int(x[3]) before it misses x[11], align.py:832: a
+        // short line whose fourth field is no number raises instead of being skipped)
+        long n3;
+        if (extra && fmt == WK_FMT_B6O && nf >= 4 && !parse_int(fb(3), fe(3), n3)) L.bad_number = true;
+        return L;
+    }
     const int sub = fmt == WK_FMT_B6O ? 1 : 5;
     L.q = fb(0);
     L.qn = fe(0) - fb(0);

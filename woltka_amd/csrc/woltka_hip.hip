@@ -2499,7 +2499,8 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
 
 int wk_dtok_format(wk_ctx* c, int fmt) {
     if (!c) return WK_E_ARG;
-    if (fmt != WK_FMT_SAM && fmt != WK_FMT_MAP && fmt != WK_FMT_B6O) return fail(c, WK_E_ARG, "the device tokenizer takes SAM, simple maps and BLAST tabular text");
+    if (fmt != WK_FMT_SAM && fmt != WK_FMT_MAP && fmt != WK_FMT_B6O && fmt != WK_FMT_PAF)
+        return fail(c, WK_E_ARG, "the device tokenizer takes SAM, simple maps, BLAST tabular text and PAF");
     c->dt_fmt = fmt;
     return WK_OK;
 }
@@ -2521,7 +2522,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     c->dt_ready = false;
     c->dt_extra = extra != 0;
     if (!wkx_tok_device_ok(tok)) return WK_OK;  // an exclusion set: the host tokenizer's business
-    if (extra && c->dt_fmt != WK_FMT_SAM) return WK_OK;  // (the "ex" flavour of the other formats: the host's)
+    if (extra && c->dt_fmt == WK_FMT_MAP) return WK_OK;  // (a simple map has no "ex" flavour, align.py:236)
     const int64_t n64 = stop - begin;
     if (n64 >= (1ll << 31) - 64) return WK_OK;
     DeviceGuard guard(c->device);

@@ -522,7 +522,7 @@ class DeviceTextRoute:
                 self._host_strata_table()
             tok.set_subject_map(self._tok_genome)
             res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
-                            final=final, extra=True, fmt='sam',
+                            final=final, extra=True, fmt=self._dfmt,
                             want_groups=groups)
             fresh = tok.new_subjects()
             if fresh:       # (names met for the first time in this block:
@@ -534,7 +534,7 @@ class DeviceTextRoute:
                 tok.set_subject_map(self._tok_genome)
                 tok.set_header_state(hdr_in)
                 res = tok.parse(memoryview(buf).cast('B')[:fill], first=first,
-                                final=final, extra=True, fmt='sam',
+                                final=final, extra=True, fmt=self._dfmt,
                                 want_groups=groups)
             if res['off'].size > 1:
                 yield None, (res['subj'], res['beg'], res['end'], res['len'],
