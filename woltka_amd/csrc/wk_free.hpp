@@ -72,8 +72,8 @@ constexpr uint32_t kFreeMiss = 128;     // per-wave ring of results on their way
 constexpr uint32_t kFreeQueue = 256;    // per-wave queue of reads to evaluate: < 64 left over + <= 128 new
 constexpr uint32_t kFreeBlock = 256;    // records a wave loads at a time
 constexpr uint32_t kFreeAdvance = 240;  // ... of which it owns the last 240
-// LDS of a wave: its queue, its ring of uncached results and, under --major, the staged block
-__host__ __device__ constexpr uint32_t free_wave_lds(bool major) { return kFreeQueue * 8 + kFreeMiss * 4 + (major ? kFreeBlock * 4 : 0u); }
+// LDS of a wave: its queue and its ring of uncached results
+__host__ __device__ constexpr uint32_t free_wave_lds() { return kFreeQueue * 8 + kFreeMiss * 4; }
 
 // A wave takes blocks of 256 records — one 16-byte load per lane, the next
 // block's issued before this one is looked at — of which it owns the last 240
@@ -92,9 +92,13 @@ __host__ __device__ constexpr uint32_t free_wave_lds(bool major) { return kFreeQ
 //   3. 64 queued reads at a time: the table gathers and the counting, every lane
 //      busy, as in a kernel with one read per lane but without that kernel's
 //      gathers of the reads' records.
+// kMajor: the instance for a rank job under --major (the vote along the records;
+// the look-up is the value's own node or nothing).
+template <bool kMajor>
 __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) free_stream_kernel(FreeArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long acc[2];
+    __shared__ uint32_t need[32];  // --major: the votes a read of so many records asks for
     // The counting: results are node ids and the job is one, so a slot of the
     // workgroup's LDS cache is {node, reads} in 8 bytes.  What the cache cannot
     // hold went to a dense array of counters in HBM by a fire-and-forget atomic
@@ -113,12 +117,18 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
         ccnt[i] = 0u;
     }
     if (threadIdx.x < 2) acc[threadIdx.x] = 0ull;
+    if (kMajor && threadIdx.x < 32u) {  // (the size field has five bits)
+        // the smallest v with `v >= size * th` as classify.majority compares them
+        // (classify.py:300-317, in fp64), none: a number no read reaches
+        uint32_t v = 0;
+        while (v <= 17u && !((double)v >= (double)threadIdx.x * a.major)) ++v;
+        need[threadIdx.x] = v <= 17u ? v : 0xFFFFFFFFu;
+    }
     __syncthreads();
     // (plain LDS pointers: a volatile one turns the accesses into flat ones, each with a wait)
-    unsigned char* const mine = smem + (size_t)lds_slots * 8 + (size_t)(threadIdx.x >> 6) * free_wave_lds(a.major > 0.0);
+    unsigned char* const mine = smem + (size_t)lds_slots * 8 + (size_t)(threadIdx.x >> 6) * free_wave_lds();
     uint2* const queue = reinterpret_cast<uint2*>(mine);
     uint32_t* const ring = reinterpret_cast<uint32_t*>(mine + kFreeQueue * 8);
-    uint32_t* const stage = reinterpret_cast<uint32_t*>(mine + kFreeQueue * 8 + kFreeMiss * 4);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -176,25 +186,14 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
         // (a missing subject carries the largest value of the field: it is the maximum)
         // what to do: 0 = nothing to look up, 1 = parent of node lo, 2 = LCA of lo and hi, 3 = the node lo
         uint32_t kind = 0, lo = mn, hi = mx;
-        if (a.by_rank) {
+        if constexpr (kMajor) {  // (the block loop has voted: both are where the read goes)
+            kind = mn != kFreeMissing ? 3u : 0u;
+            hi = 0u;
+        } else if (a.by_rank) {
             uint32_t to = kFreeMissing;  // where the read goes without a look at the tree
             bool lca = false;
             if (mn == mx) {
                 to = mn;
-            } else if (a.major > 0.0) {
-                // the only value that can reach a threshold above one half:
-                // Boyer-Moore's candidate, then its votes
-                const uint32_t at = e.x >> kWordSubjBits, size = on ? e.y >> kWordSizeShift : 0u;
-                uint32_t cand = 0, lead = 0, votes = 0;
-                for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
-                    if (i < size) {
-                        const uint32_t g = stage[at - i] & kWordSubjMask;
-                        if (lead == 0u) cand = g;
-                        lead += (g == cand) ? 1u : (uint32_t)-1;
-                    }
-                for (uint32_t i = 0; __ballot(i < size) != 0ull; ++i)
-                    if (i < size) votes += ((stage[at - i] & kWordSubjMask) == cand) ? 1u : 0u;
-                if ((double)votes >= (double)size * a.major) to = cand;
             } else if (a.above) {
                 lca = mx != kFreeMissing;
             }
@@ -251,9 +250,6 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
     };
     uint32_t my_records = 0;      // (wave-uniform, as are these: a wave's share of < 2^32 records)
     uint32_t head = 0, tail = 0;  // (tail: the reads met so far)
-    uint32_t at23[4];             // a record's place in the staged block, for --major
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; ++j) at23[j] = a.major > 0.0 ? (4u * lane + j) << kWordSubjBits : 0u;
     uint4 cur = load_block(wave0);
     for (uint32_t b = wave0; b < n_blocks; b += waves) {
         const uint4 nxt = load_block(b + waves);
@@ -265,10 +261,6 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
             f[j] = w4[j] & kWordSubjMask;
             pos[j] = (w4[j] >> kWordSubjBits) & 15u;
             size[j] = w4[j] >> kWordSizeShift;
-        }
-        if (a.major > 0.0) {  // (the vote count walks a read's records)
-            *reinterpret_cast<uint4*>(stage + 4 * lane) = cur;
-            settle();
         }
         // the smallest and the largest id of the lane's last run of records of one
         // read (from the last record that begins a read; all four if none does) ...
@@ -292,7 +284,7 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
             rmx = d >= k && smx > rmx ? smx : rmx;
         }
         // 2. the running minimum and maximum along the four records; a record that
-        // ends a read is queued: {smallest id | place in the staged block << 23,
+        // ends a read is queued: {smallest id,
         // largest id | the record's place and size fields}
         uint2 ent[4];
         unsigned long long ends[4];
@@ -303,7 +295,88 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
             rmx = begins || f[j] > rmx ? f[j] : rmx;
             // (a record past the stream's end has size 0, and the 16 records before the owned ones are lanes 0-3's)
             ends[j] = __ballot(lane >= 4u && pos[j] + 1u == size[j]);
-            ent[j] = make_uint2(rmn | at23[j], (w4[j] & ~kWordSubjMask) | rmx);
+            ent[j] = make_uint2(rmn, (w4[j] & ~kWordSubjMask) | rmx);
+        }
+        if constexpr (kMajor) {
+            // --major (classify.majority, classify.py:300-317; one vote per record): the
+            // only value that can reach a threshold above one half is the one a
+            // Boyer-Moore count leaves, and such counts merge -- (value, lead) of two
+            // parts of a read: equal values add their leads, different ones cancel --
+            // so the candidate comes along the records the way the minimum and the
+            // maximum do: the lane's last run, the d lanes before, the four records.
+            // (Rounds 3-4 staged the block in LDS and had the lane of a read's end walk
+            // its records twice, a record at a time: 0.43 of the stream's 0.85 ms at
+            // config 3, whatever the unrolling.)
+            auto step = [](uint32_t& c, uint32_t& l, uint32_t x) {
+                const bool same = x == c;
+                c = !same && l == 0u ? x : c;
+                l = same || l == 0u ? l + 1u : l - 1u;
+            };
+            uint32_t tc = f[3], tl = 1u;
+            bool run = pos[3] != 0u;
+#pragma unroll
+            for (int j = 2; j >= 0; --j) {
+                uint32_t c2 = tc, l2 = tl;
+                step(c2, l2, f[j]);
+                tc = run ? c2 : tc;
+                tl = run ? l2 : tl;
+                run = run && pos[j] != 0u;
+            }
+            uint32_t rc = 0u, rl = 0u;
+#pragma unroll
+            for (uint32_t k = 1; k <= 4u; ++k) {
+                const uint32_t sc = (uint32_t)__shfl_up((int)tc, k), sl = (uint32_t)__shfl_up((int)tl, k);
+                const bool same = sc == rc, more = rl >= sl;
+                const uint32_t nl = same ? rl + sl : (more ? rl - sl : sl - rl);
+                const uint32_t nc = same || more ? rc : sc;
+                rc = d >= k ? nc : rc;
+                rl = d >= k ? nl : rl;
+            }
+            uint32_t cand[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t c2 = rc, l2 = rl;
+                step(c2, l2, f[j]);
+                rc = pos[j] == 0u ? f[j] : c2;
+                rl = pos[j] == 0u ? 1u : l2;
+                cand[j] = rc;
+            }
+            // its votes.  The read of a lane's first record ends in this lane at record
+            // j0 (if it does): the lanes before, whose last runs are its other records,
+            // fetch its candidate from here -- a read that goes on behind a lane's last
+            // record ends 1 - 4 lanes further -- count it in their runs, and this lane
+            // adds up what the d lanes before counted
+            const uint32_t j0 = size[0] - 1u - pos[0];  // (a masked record: size 0, no lane asks)
+            const uint32_t headc = j0 == 0u ? cand[0] : (j0 == 1u ? cand[1] : (j0 == 2u ? cand[2] : cand[3]));
+            const uint32_t ahead = (size[3] - pos[3] + 2u) >> 2;  // lanes until the read of the last record ends: ceil(records left / 4)
+            uint32_t hc = 0u;
+#pragma unroll
+            for (uint32_t k = 1; k <= 4u; ++k) {
+                const uint32_t v = (uint32_t)__shfl_down((int)headc, k);
+                hc = ahead == k ? v : hc;
+            }
+            uint32_t tv = f[3] == hc ? 1u : 0u;
+            run = pos[3] != 0u;
+#pragma unroll
+            for (int j = 2; j >= 0; --j) {
+                tv += run && f[j] == hc ? 1u : 0u;
+                run = run && pos[j] != 0u;
+            }
+            uint32_t before = 0u;
+#pragma unroll
+            for (uint32_t k = 1; k <= 4u; ++k) {
+                const uint32_t v = (uint32_t)__shfl_up((int)tv, k);
+                before += d >= k ? v : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t votes = pos[j] > (uint32_t)j ? before : 0u;
+#pragma unroll
+                for (int i = 0; i <= j; ++i) votes += (uint32_t)(j - i) <= pos[j] && f[i] == cand[j] ? 1u : 0u;
+                const uint32_t mn = ent[j].x, mx = ent[j].y & kWordSubjMask;
+                const uint32_t to = mn == mx ? mn : (votes >= need[size[j]] ? cand[j] : kFreeMissing);
+                ent[j] = make_uint2(to, (w4[j] & ~kWordSubjMask) | to);
+            }
         }
         my_records += min((uint32_t)kFreeAdvance, a.n_records - b * kFreeAdvance);
 #pragma unroll
@@ -322,11 +395,6 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
                 head += (uint32_t)kWave;
                 settle();
             }
-        }
-        if (a.major > 0.0 && tail != head) {  // (the votes are counted in this block's records)
-            evaluate(head, tail - head);
-            head = tail;
-            settle();
         }
         cur = nxt;
     }

@@ -773,7 +773,9 @@ int wk_create(int device, wk_ctx** out) {
     }
     // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
     // (160 KiB per CU minus the kernels' few bytes of static LDS)
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel),
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_log_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLogBins * 4))) != hipSuccess ||
@@ -1970,10 +1972,8 @@ int wk_words_flush(wk_ctx* c) {
             fa.dense = c->f_dense.as<uint32_t>();
             fa.n_results = T.results;
             fa.stat_block = c->stat_block.as<unsigned long long>();
-            // (two workgroups of 1024 threads share a CU's 160 KB: under --major the staged blocks take the room of half the cache)
-            const bool major = fa.major > 0.0;
-            const uint32_t slots = major ? (uint32_t)std::min(c->free_slots, 2048) : (uint32_t)c->free_slots;
-            const size_t lds = (size_t)slots * 8 + (size_t)(c->free_threads / 64) * free_wave_lds(major);
+            const uint32_t slots = (uint32_t)c->free_slots;
+            const size_t lds = (size_t)slots * 8 + (size_t)(c->free_threads / 64) * free_wave_lds();
             // a wave's list of uncached results: room for every read it can meet (240 per block of records)
             const uint32_t n_waves = (uint32_t)blocks * (uint32_t)(c->free_threads / 64);
             const uint32_t n_blocks = (fa.n_records + kFreeAdvance - 1) / kFreeAdvance;
@@ -1988,7 +1988,10 @@ int wk_words_flush(wk_ctx* c) {
             fa.log = c->f_log.as<uint32_t>();
             fa.log_cnt = c->f_log_cnt.as<uint32_t>();
             KernelTimer* kt = ktimer_begin(c, "classify");
-            hipLaunchKernelGGL(free_stream_kernel, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
+            if (fa.major > 0.0)
+                hipLaunchKernelGGL(free_stream_kernel<true>, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
+            else
+                hipLaunchKernelGGL(free_stream_kernel<false>, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
             ktimer_end(c, kt);
             FreeLogArgs la{};
             la.log = fa.log;
