@@ -287,7 +287,7 @@ class LcaFreeWorkload(LcaWorkload):
     key = 'lca_free'
     packed = False
     families = ('classify', 'free_log', 'free_counts')
-    symbols = {'classify': 'wk::free_stream_kernel',
+    symbols = {'classify': 'wk::free_stream_kernel<false>',
                'free_log': 'wk::free_log_kernel',
                'free_counts': 'wk::free_counts_kernel'}
     ranks = ('free',)
@@ -331,11 +331,14 @@ class LcaOptionWorkload(LcaWorkload):
     carry the subjects' ancestors at the rank), one launch per sample."""
     dominant = 'classify'
     families = ('classify', 'free_log', 'free_counts')
-    symbols = {'classify': 'wk::free_stream_kernel',
+    symbols = {'classify': 'wk::free_stream_kernel<false>',
                'free_log': 'wk::free_log_kernel',
                'free_counts': 'wk::free_counts_kernel'}
 
     def __init__(self, ctx, option, share):
+        if option == 'major':       # (the instance that votes)
+            self.symbols = dict(self.symbols,
+                                classify='wk::free_stream_kernel<true>')
         self.ctx, self.prob = ctx, share.prob
         self.records, self.reads = share.records, share.reads
         self.key = f'lca_{option}'
