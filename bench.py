@@ -383,6 +383,24 @@ class OrdinalWorkload:
         self.name = (f'synthetic paired SAM {n_pairs / 1e6:g}M pairs, 5k genomes '
                      'x 500k genes, overlap 80, rank none')
         self.prob = p = synth.ordinal_problem(rng, n_pairs=n_pairs)
+        if os.environ.get('WOLTKA_BENCH_SORT_HITS'):
+            # measurement only (what binning the hits by genome at
+            # staging would buy): the reads of one hit ordered by genome, the
+            # others behind them as they came; the counts do not depend on it
+            nh = np.diff(p['hoff'])
+            key = np.where(nh == 1, p['genome'][p['hoff'][:-1].clip(
+                max=p['genome'].size - 1)], np.int32(1 << 30))
+            order = np.argsort(key, kind='stable')
+            nh2 = nh[order]
+            hoff2 = np.zeros(nh2.size + 1, p['hoff'].dtype)
+            np.cumsum(nh2, out=hoff2[1:])
+            src = np.repeat(p['hoff'][:-1][order] - hoff2[:-1], nh2) + \
+                np.arange(int(hoff2[-1]), dtype=np.int64)
+            for k in ('genome', 'beg', 'end', 'length'):
+                p[k] = np.ascontiguousarray(p[k][src])
+            p['hoff'] = hoff2
+            self.name += ' [hits ordered by genome: measurement]'
+            del nh, key, order, nh2, src
         ctx.set_genes(p['genome_off'], p['gstart'], p['gend'],
                       p['gene_feature'])
         ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'],
