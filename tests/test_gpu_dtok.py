@@ -508,3 +508,35 @@ def test_b6o_numbers_that_raise_do_so_on_both_routes(tmp_path, fmt, bad):
         except Exception as e:      # noqa: BLE001
             errs.append((type(e), str(e)))
     assert errs[0] == errs[1] and errs[0] is not None
+
+
+@pytest.mark.parametrize('fmt', ['b6o', 'paf'])
+def test_b6o_and_paf_stratified_coord_match_on_the_device(tmp_path, fmt):
+    """--coords --stratify on BLAST tabular text / PAF: the hits staged and the
+    strata map joined on the device (the reads are named by the first field,
+    no mate suffix) vs the host tokenizer and its join."""
+    from woltka_amd import classify as C
+    rng = random.Random(17 + len(fmt))
+    coords, text = _random_coords_rows(rng, fmt, 5000)
+    indir, sdir = tmp_path / 'in', tmp_path / 'strata'
+    indir.mkdir()
+    sdir.mkdir()
+    for s, part in (('S1', text), ('S2', text[:len(text) // 2].rsplit(
+            '\n', 1)[0] + '\n')):
+        (indir / f'{s}.{fmt}').write_text(part)
+        reads = sorted({ln.split('\t')[0] for ln in part.split('\n') if ln})
+        (sdir / f'{s}.txt').write_text(''.join(
+            f'{q}\tT{rng.randrange(25)}\n' for q in reads
+            if rng.random() < 0.9))
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    kw = dict(input_fp=str(indir), input_fmt=fmt, coords_fp=str(cfp),
+              strata_dir=str(sdir))
+    C.ROUTES.clear()
+    a, log_a = _run(tmp_path, 'd', False, **kw)
+    routes = dict(C.ROUTES)
+    assert routes.get('dhits_strata', 0) > 0 and routes.get('dstrata', 0) >= 2 \
+        and not routes.get('host_block'), routes
+    b, log_b = _run(tmp_path, 'h', True, **kw)
+    assert a == b and log_a == log_b
+    assert len(a['table']) > 2000

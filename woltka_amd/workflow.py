@@ -364,12 +364,14 @@ def classify(
                                 later = [files[x] for x in files]
                                 later = [x for x in later[later.index(sample):]
                                          if x != sample and x in stratmap]
-                                # coord-match on SAM text that the device
-                                # tokenises: the join runs there too
+                                # coord-match on text that the device tokenises
+                                # (SAM, BLAST tabular, PAF): the join runs
+                                # there too
                                 from .file import ZIP_BY_EXT
                                 from os.path import splitext
                                 dstrata = bool(
-                                    ordinal and fmt_ == 'sam' and not exclude
+                                    ordinal and fmt_ in ('sam', 'b6o', 'paf')
+                                    and not exclude
                                     and part is None and cover is None and
                                     rank2dir is None and path != '-' and
                                     ZIP_BY_EXT.get(splitext(path)[1]) is None
