@@ -145,14 +145,22 @@ def test_native_arrays_equal_python_flattening(tmp_path, threads):
 
 
 def test_cycle_and_empty():
+    # a cycle beside the rooted part: fill_root lets it stand (tree.py:329-353);
+    # its nodes stay in the dict views and leave the numbered tree
     tax = H.NativeTaxonomy(2)
-    tax.add_text(nat.HIER_NODES, b'r\tr\na\tb\nb\ta\n')
-    with pytest.raises(ValueError, match='cannot reach the root'):
-        tax.finish()
+    tax.add_text(nat.HIER_NODES, b'r\tr\na\tb\nb\ta\nc\tr\n')
+    tax.finish()
+    assert dict(tax.tree) == {'r': 'r', 'a': 'b', 'b': 'a', 'c': 'r'}
+    assert tax.root == 'r' and tax.n_nodes == 2
+    h = tax.hierarchy()
+    assert [h.index.get(x) for x in 'rcab'] == [0, 1, -1, -1]
+    # nothing but a cycle: fill_root returns None (tree.py:358-360), the dicts stand
     tax = H.NativeTaxonomy(2)
     tax.add_text(nat.HIER_NODES, b'a\tb\nb\ta\n')
-    with pytest.raises(ValueError, match='exactly one root'):
-        tax.finish()
+    tax.finish()
+    assert dict(tax.tree) == {'a': 'b', 'b': 'a'} and tax.root is None
+    assert tax.n_nodes == 0 and tax.hierarchy().index.get('a') == -1
+    assert H.flatten_hierarchy({'a': 'b', 'b': 'a'}).n_nodes == 0
     tax = H.NativeTaxonomy(2).finish()
     assert tax.n_nodes == 0 and tax.root is None and not tax.tree
     assert dict(tax.tree) == {} and len(tax.rankdic) == 0
@@ -178,3 +186,42 @@ def test_bundled_taxonomy_through_native_ingest():
     assert dict(tree) == t2 and dict(rankdic) == r2 and dict(namedic) == n2
     assert root == root2
     assert T.lineage_str('1117', tree, namedic) == T.lineage_str('1117', t2, n2)
+
+
+CYCLIC_NODES = (b'1\t1\tno rank\n2\t1\tphylum\n3\t2\tgenus\n4\t3\tspecies\n'
+                b'10\t11\tgenus\n11\t10\tphylum\n20\t21\tspecies\n21\t22\tgenus\n'
+                b'22\t23\tphylum\n23\t21\tno rank\n5\t2\tgenus\n')
+
+
+def test_cycles_beside_the_rooted_part_like_the_reference(tmp_path):
+    """workflow.build_hierarchy of the reference on this file (run in the
+    build container when the test was written) returns the dicts below, root
+    '1': fill_root does not mind the two cycles (tree.py:329-353).  Same here;
+    the device tree holds the five nodes that reach the root, the others are
+    names outside it -- for both ingest routes."""
+    from woltka_amd.workflow import build_hierarchy
+    from woltka_amd.hierarchy import flatten_hierarchy
+    fp = tmp_path / 'nodes.tsv'
+    fp.write_bytes(CYCLIC_NODES)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tree, rankdic, namedic, root = build_hierarchy(nodes_fps=[str(fp)])
+    ref_tree = {'1': '1', '2': '1', '3': '2', '4': '3', '10': '11', '11': '10',
+                '20': '21', '21': '22', '22': '23', '23': '21', '5': '2'}
+    ref_ranks = {'1': 'no rank', '2': 'phylum', '3': 'genus', '4': 'species',
+                 '10': 'genus', '11': 'phylum', '20': 'species', '21': 'genus',
+                 '22': 'phylum', '23': 'no rank', '5': 'genus'}
+    assert dict(tree) == ref_tree and dict(rankdic) == ref_ranks and root == '1'
+    assert len(tree) == 11 and '10' in tree and tree['23'] == '21'
+    for h in (tree.native.hierarchy(),
+              flatten_hierarchy(ref_tree, ref_ranks, '1')):
+        assert h.n_nodes == 5
+        ids = [h.index.get(x) for x in ('1', '2', '3', '4', '5')]
+        assert sorted(ids) == [0, 1, 2, 3, 4] and ids[0] == 0
+        assert [h.index.get(x) for x in ('10', '11', '20', '21', '22', '23')] \
+            == [-1] * 6
+        names = h.index.names_of(list(range(5)))
+        assert [names[p] for p in h.parent.tolist()] == \
+            [ref_tree[x] for x in names]
+        inv = {v: k for k, v in h.rank_codes.items()}
+        assert [inv[c] for c in h.rank_code.tolist()] == \
+            [ref_ranks[x] for x in names]

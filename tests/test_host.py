@@ -272,8 +272,10 @@ def test_hierarchy_flattening_properties():
         desc = [u for u in range(n) if _is_desc(h, u, v)]
         assert desc == list(range(v, h.last[v] + 1))
     assert h.rank_code[h.index.ids['a']] == h.rank_codes['phylum']
-    with pytest.raises(ValueError, match='cannot reach the root'):
-        flatten_hierarchy({'r': 'r', 'x': 'y', 'y': 'x'})
+    # (a cycle beside the rooted part leaves the numbered tree, tree.py:329-353)
+    hc = flatten_hierarchy({'r': 'r', 'x': 'y', 'y': 'x', 'c': 'r'})
+    assert hc.n_nodes == 2 and hc.index.get('x') == -1 and \
+        hc.index.names_of([0, 1]) == ['r', 'c']
     with pytest.raises(ValueError, match='exactly one root'):
         flatten_hierarchy({'r': 'r', 's': 's'})
     with pytest.raises(ValueError, match='fill_root'):

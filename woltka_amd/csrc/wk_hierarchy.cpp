@@ -613,7 +613,14 @@ int wk_hier_finish(wk_hier* h, int64_t* n_nodes, int32_t* n_ranks) {
         for (int32_t c : h->shard[s].rank)
             if (c > 0) h->rank_used[(size_t)c - 1] += 1;
     if (n == 0) return WK_OK;
-    if (!h->has_root) return hfail(h, WK_E_STATE, "Hierarchy must have exactly one root.");
+    if (!h->has_root) {
+        // no node without a parent among the keys, none that is its own: every walk of fill_root ends in a cycle, it
+        // adds nothing and returns None (tree.py:358-360) — build_hierarchy goes on with that.  The dict views hold the
+        // nodes, the numbered tree is empty: every subject is a name outside it.
+        h->n_nodes = 0;
+        if (n_nodes) *n_nodes = 0;
+        return WK_OK;
+    }
     if (n > (int64_t)WK_MAX_FEATURE) return hfail(h, WK_E_RANGE, "too many hierarchy nodes");
     // node numbers in input order: shard-major, order of first appearance inside a shard
     std::vector<int64_t> base(kShards + 1, 0);
@@ -640,10 +647,60 @@ int wk_hier_finish(wk_hier* h, int64_t* n_nodes, int32_t* n_ranks) {
         }
     });
     lap("fill_root+number");
-    const int64_t root = h->shard[ref_shard(h->root_ref)].dense[ref_local(h->root_ref)];
+    int64_t root = h->shard[ref_shard(h->root_ref)].dense[ref_local(h->root_ref)];
     std::vector<int64_t> pre((size_t)n), size((size_t)n), depth((size_t)n);
     int64_t bad = -1;
-    const int rc = wk_preorder(par.data(), n, root, pre.data(), size.data(), depth.data(), &bad);
+    int rc = wk_preorder(par.data(), n, root, pre.data(), size.data(), depth.data(), &bad);
+    if (rc == WK_E_STATE) {
+        // A cycle beside the rooted part.  tree.fill_root lets it stand (its walk stops at a node it has tested,
+        // tree.py:329-353) and the reference only fails — by never returning — once a read walks into it
+        // (tree.py:418-429).  Here the nodes that cannot reach the root stay in the dict views and leave the numbered
+        // tree: a subject among them is a name outside the tree (it assigns nothing), everything else is classified
+        // as the reference does.  (state: 1 reaches the root, 2 does not, 3 on the walk in progress)
+        std::vector<uint8_t> st((size_t)n, 0);
+        st[(size_t)root] = 1;
+        std::vector<int64_t> walk;
+        for (int64_t d = 0; d < n; ++d) {
+            if (st[(size_t)d]) continue;
+            walk.clear();
+            int64_t cur = d;
+            while (st[(size_t)cur] == 0) {
+                st[(size_t)cur] = 3;
+                walk.push_back(cur);
+                cur = par[(size_t)cur];
+            }
+            const uint8_t res = st[(size_t)cur] == 1 ? 1 : 2;
+            for (int64_t v : walk) st[(size_t)v] = res;
+        }
+        std::vector<int64_t> newid((size_t)n, -1);
+        int64_t m = 0;
+        for (int64_t d = 0; d < n; ++d)
+            if (st[(size_t)d] == 1) newid[(size_t)d] = m++;
+        std::vector<int64_t> par2((size_t)m);
+        std::vector<uint32_t> ref2((size_t)m);
+        std::vector<int32_t> code2((size_t)m);
+        for (int64_t d = 0; d < n; ++d) {
+            const int64_t v = newid[(size_t)d];
+            if (v < 0) continue;
+            par2[(size_t)v] = newid[(size_t)par[(size_t)d]];  // (the parent of a node that reaches the root does too)
+            ref2[(size_t)v] = ref_of_dense[(size_t)d];
+            code2[(size_t)v] = code_of_dense[(size_t)d];
+        }
+        for (int s = 0; s < kShards; ++s)
+            for (int64_t& d : h->shard[s].dense)
+                if (d >= 0) d = newid[(size_t)d];
+        par.swap(par2);
+        ref_of_dense.swap(ref2);
+        code_of_dense.swap(code2);
+        root = newid[(size_t)root];
+        n = m;
+        h->n_nodes = n;
+        if (n_nodes) *n_nodes = n;
+        pre.resize((size_t)n);
+        size.resize((size_t)n);
+        depth.resize((size_t)n);
+        rc = wk_preorder(par.data(), n, root, pre.data(), size.data(), depth.data(), &bad);
+    }
     lap("preorder");
     if (rc == WK_E_STATE) {
         uint32_t ln = 0;

@@ -355,10 +355,11 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
     Raises
     ------
     ValueError
-        A parent is missing, there is no unique root, or some node cannot
-        reach the root (a cycle).  The reference would loop forever when a
-        query walks into a cycle (woltka/tree.py:418-429); here it is rejected
-        up front.
+        A parent is missing or there is no unique root.  Nodes that cannot
+        reach the root (a cycle beside the rooted part) are left out of the
+        numbered tree: the reference would loop forever when a query walks
+        into them (woltka/tree.py:418-429), here such a subject is a name
+        outside the tree.
     """
     names = list(tree)
     n = len(names)
@@ -374,12 +375,35 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
     except KeyError as e:
         raise ValueError(f'Parent {e} is not part of the hierarchy; call '
                          'fill_root first.')
+    if root is None and not (par == np.arange(n, dtype=np.int64)).any():
+        # nothing but cycles: fill_root adds no root and returns None
+        # (tree.py:358-360); the numbered tree is empty, every subject a name
+        # outside it
+        return Hierarchy(FeatureIndex(), np.empty(0, np.int32),
+                         np.empty(0, np.int32), np.empty(0, np.int32), {},
+                         np.empty(0, np.int32))
     try:
         pre, size, depth, r = preorder_numbering(
             par, None if root is None else tmp[root])
-    except _Unreachable as e:
-        raise ValueError(f'Node "{names[e.node]}" cannot reach the root '
-                         '(cyclic hierarchy).')
+    except _Unreachable:
+        # a cycle beside the rooted part: fill_root lets it stand
+        # (tree.py:329-353) and the reference only fails -- by never
+        # returning -- once a read walks into it (tree.py:418-429).  The
+        # nodes that cannot reach the root stay in the caller's dicts and
+        # leave the numbered tree (csrc/wk_hierarchy.cpp does the same): a
+        # subject among them is a name outside the tree
+        r = int(np.flatnonzero(par == np.arange(n, dtype=np.int64))[0])
+        top = par.copy()
+        for _ in range(max(1, int(n).bit_length())):    # 2^k steps >= n
+            top = top[top]
+        keep = np.flatnonzero(top == r)
+        newid = np.full(n, -1, dtype=np.int64)
+        newid[keep] = np.arange(keep.size, dtype=np.int64)
+        par = newid[par[keep]]
+        names = [names[i] for i in keep.tolist()]
+        n = len(names)
+        tmp = dict(zip(names, range(n)))
+        pre, size, depth, r = preorder_numbering(par, int(newid[r]))
     ids = np.arange(n, dtype=np.int64)
     inv = np.empty(n, dtype=np.int64)
     inv[pre] = ids
