@@ -57,8 +57,9 @@ def measured_traffic(workload, scale):
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
     written by tools/prof_bench.sh for the same bench command — a PMC pass
     cannot run inside the timed process).  Returns (bytes or None, provenance):
-    the file, the library build it was measured with, and whether that is the
-    build running now."""
+    the file, the library build it was measured with, whether that is the
+    build running now and -- where the file says -- whether the device sources
+    (csrc/*.hip, *.hpp) are the ones it was measured with."""
     fp = os.path.join(PROFILES, f'traffic_{workload}.json')
     try:
         with open(fp) as f:
@@ -69,6 +70,14 @@ def measured_traffic(workload, scale):
         return None, None
     src = {'file': os.path.relpath(fp, ROOT), 'build_id': t.get('build_id'),
            'same_build': t.get('build_id') == nat.build_id()}
+    if t.get('device_digest'):
+        # (the build id covers the host C++ too; the kernels a profile is
+        # about are the device sources, __graft_entry__.device_digest)
+        try:
+            import __graft_entry__ as ge
+            src['same_device_code'] = t['device_digest'] == ge.device_digest()
+        except Exception:       # noqa: BLE001 (provenance only)
+            pass
     return t.get('hbm_bytes_per_launch'), src
 
 

@@ -41,7 +41,9 @@ if vals['FETCH_SIZE'] and vals['WRITE_SIZE']:
     # reports half of the bytes of a coalesced streaming read -> doubled
     sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.getcwd()))
     from woltka_amd import _native as nat
+    import __graft_entry__ as ge
     t = {'workload': wl, 'scale': scale, 'kernel': kern, 'launches': len(vals['FETCH_SIZE']), 'build_id': nat.build_id(),
+         'device_digest': ge.device_digest(),
          'FETCH_SIZE_KiB_mean': fetch_kb, 'WRITE_SIZE_KiB_mean': write_kb,
          'hbm_bytes_per_launch': int(2 * fetch_kb * 1024 + write_kb * 1024),
          'note': 'FETCH_SIZE doubled (gfx950 correction); separate PMC passes'}
