@@ -11,6 +11,8 @@ from woltka_amd._native import Tokenizer
 
 
 def run_native(text, threads, block, excl=None, extra=False, fmt='sam'):
+    """``extra=3``: the "ex" flavour with the hits of aligned length 0 kept
+    (what `--outcov` and `--coords --outmap` read)."""
     tok = Tokenizer(threads, exclude=excl)
     names = []
     reads = []
@@ -563,6 +565,39 @@ def test_b6o_ex_needs_a_float_score():
         list(align.parse_align(bad, 'b6o', None, True))
     with pytest.raises(ValueError):
         run_native(''.join(bad).encode(), 1, 1 << 16, extra=True, fmt='b6o')
+
+
+@pytest.mark.parametrize('fmt', ['sam', 'b6o', 'paf'])
+@pytest.mark.parametrize('threads,block', [(1, 1 << 20), (3, 900)])
+def test_empty_hits_kept_on_request(fmt, threads, block):
+    """`--coords --outmap` counts a query's records of aligned length 0 towards
+    the chunk boundary (ordinal.py:222) before it drops them (ordinal.py:231):
+    with the keep flag the tokenizer hands over every record the reference's
+    "ex" parsers yield, queries with nothing but empty hits included; without
+    it such hits and queries are gone."""
+    rows = []
+    for q in range(300):
+        for h in range(1 + q % 3):
+            ln = 0 if (q + h) % 4 == 0 or q % 7 == 0 else 100
+            pos = 10 + 13 * q + h
+            if fmt == 'sam':
+                rows.append(f'q{q}\t0\tG{q % 9}\t{pos}\t1\t'
+                            f'{"*" if ln == 0 else "100M"}\t*\t0\t0\t*\t*\n')
+            elif fmt == 'b6o':
+                rows.append(f'q{q}\tG{q % 9}\t99\t{ln}\t0\t0\t1\t100\t{pos}\t'
+                            f'{pos + 99}\t1e-9\t200\n')
+            else:
+                rows.append(f'q{q}\t100\t0\t100\t+\tG{q % 9}\t9999\t{pos}\t'
+                            f'{pos + 100}\t90\t{ln}\t60\n')
+    exp = [(q, [(r[0], None, r[2], r[3], r[4]) for r in recs])
+           for q, recs in align.parse_align(rows, fmt, None, True)]
+    assert any(not any(r[2] for r in recs) for _, recs in exp)
+    text = ''.join(rows).encode()
+    got, _ = run_native(text, threads, block, extra=3, fmt=fmt)
+    assert got == exp
+    got, _ = run_native(text, threads, block, extra=True, fmt=fmt)
+    assert got == [(q, kept) for q, kept in
+                   ((q, [r for r in recs if r[2]]) for q, recs in exp) if kept]
 
 
 def test_number_text_as_the_reference_reads_it():
