@@ -600,6 +600,31 @@ def test_empty_hits_kept_on_request(fmt, threads, block):
                    ((q, [r for r in recs if r[2]]) for q, recs in exp) if kept]
 
 
+def test_b6o_score_is_what_float_takes():
+    """`float(x[11])` (align.py:832): the host tokenizer accepts a score exactly
+    when Python's float() does -- underscores between digits, inf / nan in any
+    case; no hex floats, no `nan(...)`, which strtod would take."""
+    row = 'q1\tG1\t99.0\t100\t0\t0\t1\t100\t5\t104\t1e-9\t{}\n'
+    for sc in ['200', '2.5', '.5', '5.', '1e3', '1E-3', '0x1p3', '0x10', '1e',
+               'e3', 'infinity', 'nan', 'NAN(1)', '1_0.5', '1__0.5', '_1.5',
+               '1_.5', '1._5', '1.5_', '1e1_0', '1e_1', ' 7.5 ', '1.5\r',
+               '+.5e+1', '--1', '1d5', '1.e3', 'Infinity', 'iNf', '-nan', '1e+',
+               '.', '+.', '1.0f', '', ' ', '1 2', 'infinit', '1e5.0', '1.2.3',
+               '00.5', '-0', '1E+05']:
+        try:
+            float(sc)
+            takes = True
+        except ValueError:
+            takes = False
+        try:
+            got, _ = run_native(row.format(sc).encode(), 1, 1 << 16,
+                                extra=True, fmt='b6o')
+            ours = got == [('q1', [('G1', None, 100, 4, 104)])]
+        except ValueError:
+            ours = False
+        assert ours == takes, sc
+
+
 def test_number_text_as_the_reference_reads_it():
     """What the reference gave on these rows when this test was written
     (parse_b6o_file_ex / parse_paf_file_ex, align.py:832-835, 1067): int()

@@ -238,6 +238,51 @@ inline bool parse_int(const char* p, const char* e, long& v) {
     return true;
 }
 
+// Would Python's float() take the text?  (ASCII forms: blanks around, a sign, then
+// "inf" / "infinity" / "nan" in any case, or digits with single underscores between
+// them, a point, an exponent.  strtod takes more -- hex floats, "nan(...)" -- and
+// knows no underscores.)
+inline bool py_float_ok(const char* p, const char* e) {
+    auto blank = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
+    while (p < e && blank(*p)) ++p;
+    while (e > p && blank(e[-1])) --e;
+    if (p < e && (*p == '-' || *p == '+')) ++p;
+    auto word = [&](const char* w) {
+        size_t n = strlen(w);
+        if ((size_t)(e - p) != n) return false;
+        for (size_t i = 0; i < n; ++i)
+            if ((p[i] | 0x20) != w[i]) return false;
+        return true;
+    };
+    if (word("inf") || word("infinity") || word("nan")) return true;
+    auto digits = [&]() {  // digit (["_"] digit)*: how many digits
+        int n = 0;
+        while (p < e) {
+            if (*p >= '0' && *p <= '9') {
+                ++n;
+                ++p;
+            } else if (*p == '_' && n > 0 && p + 1 < e && p[1] >= '0' && p[1] <= '9') {
+                ++p;
+            } else {
+                break;
+            }
+        }
+        return n;
+    };
+    int n = digits();
+    if (p < e && *p == '.') {
+        ++p;
+        n += digits();
+    }
+    if (n == 0) return false;
+    if (p < e && (*p == 'e' || *p == 'E')) {
+        ++p;
+        if (p < e && (*p == '-' || *p == '+')) ++p;
+        if (digits() == 0) return false;
+    }
+    return p == e;
+}
+
 // Row extractors of the simple formats (align.py: parse_map_file :621,
 // parse_b6o_file :753 / _ex :807, parse_paf_file :984 / _ex :1046): a line
 // that does not qualify is skipped (ok = false), like the reference's
@@ -300,25 +345,9 @@ inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
             L.bad_number = true;
             return L;
         }
-        {   // score = float(x[11]) must parse as well (align.py:832)
-            const char* sb = fb(11);
-            const char* se = fe(11);
-            while (sb < se && (*sb == ' ' || (*sb >= '\t' && *sb <= '\r'))) ++sb;
-            while (se > sb && (se[-1] == ' ' || (se[-1] >= '\t' && se[-1] <= '\r'))) --se;
-            char tmp[64];
-            const size_t sn = (size_t)(se - sb);
-            char* endp = nullptr;
-            bool okf = sn > 0 && sn < sizeof tmp;
-            if (okf) {
-                memcpy(tmp, sb, sn);
-                tmp[sn] = 0;
-                (void)strtod(tmp, &endp);
-                okf = endp == tmp + sn;
-            }
-            if (!okf) {
-                L.bad_number = true;
-                return L;
-            }
+        if (!py_float_ok(fb(11), fe(11))) {  // score = float(x[11]) must parse as well (align.py:832)
+            L.bad_number = true;
+            return L;
         }
         L.len = (uint32_t)n;
         L.beg = (int32_t)((a < b ? a : b) - 1);
