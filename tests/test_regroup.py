@@ -74,3 +74,30 @@ def test_regroup_cuts_where_the_reference_flushes(seed):
         got.append([(q, list(map(int, genome[a:b])))
                     for q, a, b in zip(reads, hoff[:-1], hoff[1:])])
     assert got == mapper_chunks(queries, n)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_python_parser_route_cuts_the_same_way(seed, monkeypatch):
+    """`ordinal_chunks` (the route of the Python parsers) applies the same
+    test: the hits cached so far leave out those of aligned length 0."""
+    from woltka_amd.routes import coords
+    rng = random.Random(100 + seed)
+    n = rng.choice([1, 3, 7, 20])
+    queries, h = [], 0
+    for qi in range(rng.randint(1, 200)):
+        lens = []
+        for _ in range(rng.choice([1, 1, 2, 3, rng.randint(1, 9)])):
+            lens.append((h, rng.choice([0, 0, 50, 100])))
+            h += 1
+        queries.append((f'q{qi}', lens))
+    # records as the "ex" parsers yield them: (subject, score, length, beg, end)
+    parsed = [(q, [('G', None, ln, hh, hh + 1) for hh, ln in lens])
+              for q, lens in queries]
+    monkeypatch.setattr(coords, 'iter_align', lambda *a: iter(parsed))
+
+    class Route(coords.CoordMatchRoute):
+        def _stage_hits(self, pairs):
+            return [(q, [r[3] for r in recs if r[2]]) for q, recs in pairs]
+    got = [[x for x in chunk if x[1]]
+           for chunk in Route().ordinal_chunks(None, 'sam', None, n, 0.8)]
+    assert [c for c in got if c] == mapper_chunks(queries, n)

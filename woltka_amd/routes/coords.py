@@ -48,11 +48,14 @@ class CoordMatchRoute:
         pending, nhits = [], 0
         self._th = th
         for query, records in iter_align(fh, fmt, excl, True):
+            # (`idx + len(records) > n`, ordinal.py:222: every record of the
+            # next query against the hits cached so far -- which leave out
+            # those of aligned length 0, ordinal.py:231)
             if pending and nhits + len(records) > n:
                 yield self._stage_hits(pending)
                 pending, nhits = [], 0
             pending.append((query, records))
-            nhits += len(records)
+            nhits += sum(1 for r in records if r[2])
         yield self._stage_hits(pending)
 
     def _stage_hits(self, pairs):
