@@ -172,7 +172,7 @@ struct Line {
     // map / b6o / paf rows of the "ex" flavour carry their numbers directly
     int32_t beg, end;
     uint32_t len;
-    bool bad_number;  // a field Python's int() would refuse (the reference raises)
+    bool bad_number;  // a field Python's int() would refuse (the reference raises; SAM: the FLAG, once the line is kept)
     // the line itself (without its newline) and the hash of its subject name
     const char* line;
     const char* le;
@@ -180,6 +180,36 @@ struct Line {
 };
 
 constexpr size_t kScanSlack = 64;  // bytes the vector scanner wants ahead of a line start
+
+inline bool is_unmapped(const Line& L) { return L.rn == 1 && L.r[0] == '*'; }
+
+// decimal integer like Python's int() on a clean field: optional sign, digits
+inline bool parse_int(const char* p, const char* e, long& v) {
+    auto blank = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
+    while (p < e && blank(*p)) ++p;  // int() ignores surrounding whitespace
+    while (e > p && blank(e[-1])) --e;
+    bool neg = false;
+    if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
+    if (p >= e) return false;
+    if (e - p > 18 + (e - p) / 2) return false;  // (beyond 18 digits and their underscores: no number an alignment file holds)
+    long x = 0;
+    for (const char* b = p; p < e; ++p) {
+        // (int() takes single underscores between digits)
+        if (*p == '_' && p > b && p[-1] != '_' && p + 1 < e && p[1] >= '0' && p[1] <= '9') continue;
+        if (*p < '0' || *p > '9') return false;
+        x = x * 10 + (*p - '0');
+    }
+    v = neg ? -x : x;
+    return true;
+}
+
+// FLAG as int() reads it (align.py:322): the value's low bits (the mate bits are all that is looked at)
+inline bool parse_flag(const char* b, const char* e, int& flag) {
+    long v;
+    if (!parse_int(b, e, v)) return false;
+    flag = (int)(v & 0x7FFFFFFFl);
+    return true;
+}
 
 // split the first 3 (or 6) tab-separated fields of [p, e)
 inline Line parse_line(const char* p, const char* e, bool extra) {
@@ -192,15 +222,13 @@ inline Line parse_line(const char* p, const char* e, bool extra) {
     if (!t3) return L;
     L.q = p;
     L.qn = t1 - p;
-    int f = 0;
-    if (t2 == t1 + 1) return L;  // (an empty FLAG: int('') raises)
-    for (const char* c = t1 + 1; c < t2; ++c) {
-        if (*c < '0' || *c > '9') return L;
-        f = f * 10 + (*c - '0');
-    }
-    L.flag = f;
     L.r = t2 + 1;
     L.rn = t3 - t2 - 1;
+    int f = 0;
+    // (an unmapped record is skipped before its FLAG is looked at, align.py:318-322;
+    // an empty FLAG, or text int() refuses, raises)
+    if (!is_unmapped(L) && !parse_flag(t1 + 1, t2, f)) L.bad_number = true;  // (raises where the FLAG is converted)
+    L.flag = f;
     if (extra) {
         const char* t4 = (const char*)memchr(t3 + 1, '\t', e - t3 - 1);
         if (!t4) return L;
@@ -217,26 +245,7 @@ inline Line parse_line(const char* p, const char* e, bool extra) {
     return L;
 }
 
-inline bool is_unmapped(const Line& L) { return L.rn == 1 && L.r[0] == '*'; }
 
-// decimal integer like Python's int() on a clean field: optional sign, digits
-inline bool parse_int(const char* p, const char* e, long& v) {
-    auto blank = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
-    while (p < e && blank(*p)) ++p;  // int() ignores surrounding whitespace
-    while (e > p && blank(e[-1])) --e;
-    bool neg = false;
-    if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
-    if (p >= e) return false;
-    long x = 0;
-    for (const char* b = p; p < e; ++p) {
-        // (int() takes single underscores between digits)
-        if (*p == '_' && p > b && p[-1] != '_' && p + 1 < e && p[1] >= '0' && p[1] <= '9') continue;
-        if (*p < '0' || *p > '9') return false;
-        x = x * 10 + (*p - '0');
-    }
-    v = neg ? -x : x;
-    return true;
-}
 
 // Would Python's float() take the text?  (ASCII forms: blanks around, a sign, then
 // "inf" / "infinity" / "nan" in any case, or digits with single underscores between
@@ -370,29 +379,20 @@ inline bool is_row(int fmt, const Line& L) { return L.ok && !(fmt == WK_FMT_SAM 
 
 // align.cigar_to_lens (align.py:550-583).  false where the reference raises:
 // int() of the characters collected since the last operation runs only for
-// M = X D N, and refuses an empty string or anything but digits.
+// M = X D N, and refuses an empty string or anything int() does.
 inline bool cigar_lens(const char* c, size_t n, uint32_t& aligned, uint32_t& span) {
-    uint64_t a = 0, x = 0, num = 0;
-    bool digits = false, clean = true;  // the pending number: has digits / digits only
+    int64_t a = 0, x = 0;
+    size_t s = 0;  // start of the text collected since the last operation
     for (size_t i = 0; i < n; ++i) {
         const char ch = c[i];
-        if (ch >= '0' && ch <= '9') {
-            num = num * 10 + (ch - '0');
-            digits = true;
-        } else if (ch == 'M' || ch == '=' || ch == 'X' || ch == 'D' || ch == 'N') {
-            if (!digits || !clean) return false;
-            if (ch == 'D' || ch == 'N')
-                x += num;
-            else
-                a += num;
-            num = 0;
-            digits = false;
+        const bool lens = ch == 'M' || ch == '=' || ch == 'X', skip = ch == 'D' || ch == 'N';
+        if (lens || skip) {
+            long v;
+            if (!parse_int(c + s, c + i, v)) return false;  // int(n), with what int() takes (sign, blanks, underscores)
+            (skip ? x : a) += v;
+            s = i + 1;
         } else if (ch == 'I' || ch == 'H' || ch == 'P' || ch == 'S') {
-            num = 0;
-            digits = false;
-            clean = true;
-        } else {
-            clean = false;  // joins the pending text: int() fails at the next M = X D N
+            s = i + 1;
         }
     }
     aligned = (uint32_t)a;
@@ -824,6 +824,13 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
                 keep = false;
                 continue;
             }
+            if (fmt == WK_FMT_SAM && L.bad_number) {
+                // int(flag) of a line that is kept (the filtering parsers never convert
+                // the FLAG of a line they drop, align.py:438-470, 511-540)
+                out.error = 2;
+                out.error_at = (size_t)(line - base);
+                return;
+            }
             if (track_pool) {
                 if (run_start) {  // `pool = ([], [], [])` (align.py:526)
                     out.pool_lines.clear();
@@ -832,7 +839,9 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
                 out.pool_lines.emplace_back(line, le);
             }
             const int mate = fmt == WK_FMT_SAM ? (L.flag >> 6) & 3 : 0;
-            if (mate == 3) {
+            // (both mate bits index a 3-tuple with 3, align.py:339 -- in the "ex" parser
+            // after int(pos) and cigar_to_lens have had their say, align.py:382-391)
+            if (mate == 3 && !(kExtra && fmt == WK_FMT_SAM)) {
                 out.error = 1;
                 out.error_at = (size_t)(line - base);
                 return;
@@ -856,6 +865,11 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
                 uint32_t aligned = 0, span = 0;
                 if (!parse_int(L.pos, L.pos_end, pos) || !cigar_lens(L.cigar, L.cn, aligned, span)) {
                     out.error = 2;
+                    out.error_at = (size_t)(line - base);
+                    return;
+                }
+                if (mate == 3) {
+                    out.error = 1;
                     out.error_at = (size_t)(line - base);
                     return;
                 }
