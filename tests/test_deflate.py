@@ -115,3 +115,18 @@ def test_members_inflate_in_parallel_natively():
     broken[(a + b) // 2] ^= 0x55
     with pytest.raises(OSError):
         nat.gz_inflate_members(bytes(broken), spans)
+
+
+def test_incompressible_pieces_fit_the_bound():
+    """a 1 MiB piece of high-entropy bytes (MapWriter's piece size)
+    closes a stored block every 32 k tokens — the bound counts those blocks."""
+    import os
+    for n in (1 << 20, (1 << 20) + 1, 3 << 20, 32768, 32769, 65535 * 3):
+        d = os.urandom(n)
+        m = pgzip.member(d)
+        assert gzip.decompress(m) == d
+        assert len(m) <= nat.load_library().wk_gz_bound(n)
+    # mostly literal text with rare matches: dynamic blocks near the raw size
+    rng = np.random.default_rng(9)
+    d = bytes(rng.integers(32, 127, 2 << 20, dtype=np.uint8))
+    assert gzip.decompress(pgzip.member(d)) == d

@@ -256,3 +256,43 @@ def test_a_failing_rank_is_reported():
         comm.gather({})
     for p in procs:
         p.join(60)
+
+
+def _mixed_entry(comm=None):
+    """Rank 1 fails, the others send an object far above a pipe's buffer."""
+    if comm.rank == 1:
+        raise ValueError('boom')
+    comm.gather({'x': b'\0' * (1 << 20)})
+
+
+@pytest.mark.timeout(120)
+def test_a_failing_rank_does_not_leave_the_others_blocked():
+    """rank 1 raises while rank 2 is sending 1 MB.  Rank 0 hears
+    every rank before it raises, and `stop_local_world` returns with all ranks
+    ended."""
+    import time
+    comm, procs = shard.start_local_world(3, _mixed_entry, {})
+    with pytest.raises(RuntimeError, match='rank 1 failed: ValueError: boom'):
+        comm.gather({})
+    t0 = time.time()
+    shard.stop_local_world(comm, procs, failed=True)
+    assert time.time() - t0 < 30
+    assert not any(p.is_alive() for p in procs)
+
+
+def _slow_sender(comm=None):
+    import time
+    time.sleep(1.0)
+    comm.gather({'x': b'\0' * (4 << 20)})
+
+
+@pytest.mark.timeout(120)
+def test_rank_zero_failing_before_the_gather_ends_the_ranks():
+    """Rank 0 raises before it ever gathers: the ranks blocked in send() (no
+    reader) are ended by `stop_local_world`, the join is bounded."""
+    import time
+    comm, procs = shard.start_local_world(3, _slow_sender, {})
+    t0 = time.time()
+    shard.stop_local_world(comm, procs, failed=True, grace=3.0)
+    assert time.time() - t0 < 30
+    assert not any(p.is_alive() for p in procs)

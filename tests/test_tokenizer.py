@@ -741,3 +741,76 @@ def test_packed_words_equal_the_plain_arrays(threads, block):
                     sink=lambda *a: {'packed': np.zeros(1 << 16, np.uint32)})
     assert 'words' not in res and int(np.diff(res['off']).max()) == 17
     tok.close()
+
+
+def test_long_number_text_is_exact_or_a_loud_error():
+    """digit strings of 19-36 characters used to overflow a signed
+    long.  Now: a zero-padded number is its value (int() takes any padding),
+    the mate bits of a FLAG are exact whatever its length (`int(flag) >> 6 &
+    3` is all the reference looks at), and a coordinate wider than the 32 bits
+    it is held in raises instead of wrapping."""
+    pad = '0' * 40
+    sam = (f'r1\t{pad}99\tG1\t{pad}100\t0\t{pad}10M\t*\t0\t0\t*\t*\n'
+           f'r1\t{pad}147\tG2\t5\t0\t1_0M2D\t*\t0\t0\t*\t*\n')
+    got, _ = run_native(sam.encode(), 1, 1 << 16, extra=True)
+    exp = list(align.parse_align(sam.splitlines(True), 'sam', None, True))
+    assert [(q, [(s, None, ln, b, e) for s, _, ln, b, e in recs])
+            for q, recs in exp] == got
+    # a FLAG of 30 digits: its bits 6 and 7 as Python computes them
+    for flag in (10 ** 29 + 64, 10 ** 29 + 128, 3 * 10 ** 25, -(10 ** 22) - 64):
+        line = f'q\t{flag}\tG1\t1\t0\t5M\t*\t0\t0\t*\t*\n'
+        mate = flag >> 6 & 3
+        if mate == 3:
+            with pytest.raises(IndexError):
+                run_native(line.encode(), 1, 1 << 16)
+            continue
+        got, _ = run_native(line.encode(), 1, 1 << 16)
+        assert got == [('q' + ('', '/1', '/2')[mate], {'G1'})]
+        assert got == list(align.parse_align([line], 'sam'))
+    # coordinates beyond 32 bits: never a wrapped value
+    for pos, cigar in (('12345678901234567890', '5M'), ('1', '99999999999M'),
+                       ('2147483647', '5M'), ('1', '1M12345678901234567890123D')):
+        line = f'q\t0\tG1\t{pos}\t0\t{cigar}\t*\t0\t0\t*\t*\n'
+        with pytest.raises(ValueError, match='32 bits'):
+            run_native(line.encode(), 1, 1 << 16, extra=True)
+    b6 = 'r\tG\t9\t10\t0\t0\t1\t10\t99999999999999999999\t5\t1e-9\t20\n'
+    with pytest.raises(ValueError):
+        run_native(b6.encode(), 1, 1 << 16, extra=True, fmt='b6o')
+
+
+def test_strata_labels_are_stripped_like_str_rstrip():
+    """`value.rstrip()` (file.py:384) strips every character
+    str.isspace() knows -- \\x1c-\\x1f, U+0085, NBSP, the Unicode spaces -- and
+    the map is read with universal newlines (a lone \\r ends a line)."""
+    from woltka_amd.file import read_map_uniq
+    tails = ['', ' ', '\x1c', '\x1f \x1d', '\x85', '\xa0', ' ',
+             ' ', ' ', ' ', ' ', ' ', ' ',
+             '　 \xa0\x1e', '​', '\xe9', ' x']
+    assert all(t == '' or t.isspace() for t in tails[:14])
+    rows = [f'q{i}\tL{i % 3}{t}\n' for i, t in enumerate(tails)]
+    rows += ['qa\tA\rqb\tB\r\nqc\tC \r', 'qd\tD\n']
+    data = ''.join(rows).encode()
+    fh = io.TextIOWrapper(io.BytesIO(data), encoding='utf-8', newline=None)
+    exp = dict(read_map_uniq(fh))
+    assert exp['qa'] == 'A' and exp['qc'] == 'C' and exp['q15'] == 'L0\xe9'
+    sam = ''.join(f'{q}\t0\tG1\t1\t0\t5M\t*\t0\t0\t*\t*\n' for q in exp)
+    for threads in (1, 3):
+        tok = Tokenizer(threads)
+        labels = tok.load_strata(io.BytesIO(data), 1 << 20)
+        got = {}
+        for buf, res in align.native_sam_blocks(io.BytesIO(sam.encode()), tok,
+                                                1 << 20, want_groups=True,
+                                                want_names=True):
+            for q, g in zip(Tokenizer.query_names(buf, res['qname']),
+                            res['group'].tolist()):
+                got[q] = labels[g] if g >= 0 else None
+        tok.close()
+        assert got == exp
+
+
+def test_simple_map_subjects_are_stripped_like_str_rstrip():
+    rows = ['r1\tG1\x1c\n', 'r1\tG1 \xa0\n', 'r2\tG2　\tx\n',
+            'r3\tG3\xe9\n']
+    got, _ = run_native(''.join(rows).encode(), 1, 1 << 16, fmt='map')
+    assert got == list(align.parse_align(rows, 'map'))
+    assert got == [('r1', {'G1'}), ('r2', {'G2'}), ('r3', {'G3\xe9'})]

@@ -517,7 +517,11 @@ uint32_t wk_crc32(uint32_t crc, const char* data, int64_t n) {
 
 int64_t wk_gz_bound(int64_t n) {
     if (n < 0) return -1;
-    return n + 5 * (n / 65535 + 1) + 64;
+    // A block is closed every kMaxTokens tokens (>= kMaxTokens bytes of input
+    // each but the last) and costs at most its bytes + 5 per stored piece of
+    // 65535 + the alignment of its first and last byte; head and trailer: 28.
+    const int64_t blocks = n / kMaxTokens + 1;
+    return n + 5 * (n / 65535 + blocks) + 2 * blocks + 64;
 }
 
 // One gzip member holding data[0, n): header with the 'WK' extra subfield (the

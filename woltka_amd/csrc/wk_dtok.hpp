@@ -363,6 +363,19 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
                     else
                         break;
                 }
+            if (a.fmt == 1u && re > rb) {
+                // a byte str.rstrip() may have an opinion on (\x1c-\x1f, the UTF-8
+                // spaces), or a \r inside the row: the host reads the block like Python
+                const unsigned char ch = a.text[re - 1u];
+                bool odd = ch >= 0x80 || (ch >= 0x1c && ch <= 0x1f);
+                for (uint32_t p = lo; p < re && !odd; ++p) odd = a.text[p] == '\r';
+                if (odd) {
+                    a.lsubj[i] = kLineBad;
+                    a.lmeta[i] = 0;
+                    atomicOr(&a.state->flags, kDtokShortLine);
+                    return;
+                }
+            }
             a.lmeta[i] = qn;
             a.lsubj[i] = dtok_subject(a, rb, re - rb);
             return;

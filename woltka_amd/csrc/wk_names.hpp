@@ -24,6 +24,36 @@ inline uint64_t hash_bytes(const char* p, size_t n) {
     return h ^ (h >> 32);
 }
 
+// End of [b, e) after Python's str.rstrip() on the UTF-8 text: every character
+// str.isspace() knows -- \t \n \v \f \r, \x1c-\x1f, space, U+0085, U+00A0,
+// U+1680, U+2000-200A, U+2028, U+2029, U+202F, U+205F, U+3000.
+inline const char* py_rstrip(const char* b, const char* e) {
+    for (;;) {
+        if (e <= b) return e;
+        const unsigned char c = (unsigned char)e[-1];
+        if (c == ' ' || (c >= '\t' && c <= '\r') || (c >= 0x1c && c <= 0x1f)) {
+            --e;
+            continue;
+        }
+        if (c < 0x80) return e;
+        if (e - b >= 2 && (unsigned char)e[-2] == 0xC2 && (c == 0x85 || c == 0xA0)) {
+            e -= 2;
+            continue;
+        }
+        if (e - b >= 3) {
+            const unsigned char a0 = (unsigned char)e[-3], a1 = (unsigned char)e[-2];
+            const bool sp = (a0 == 0xE1 && a1 == 0x9A && c == 0x80) ||
+                            (a0 == 0xE2 && a1 == 0x80 && ((c >= 0x80 && c <= 0x8A) || c == 0xA8 || c == 0xA9 || c == 0xAF)) ||
+                            (a0 == 0xE2 && a1 == 0x81 && c == 0x9F) || (a0 == 0xE3 && a1 == 0x80 && c == 0x80);
+            if (sp) {
+                e -= 3;
+                continue;
+            }
+        }
+        return e;
+    }
+}
+
 // string -> id table; names live in an arena (stable across calls), ids are
 // dense in order of insertion
 struct NameTable {

@@ -29,6 +29,8 @@ constexpr unsigned long long kLabelEmpty = ~0ull;
 
 constexpr uint32_t kStrataCollision = 1;   // different keys / labels, equal hashes
 constexpr uint32_t kStrataLabelsFull = 2;  // more distinct labels than half the label table
+constexpr uint32_t kStrataOddBytes = 4;    // a \r inside a line, or a label ending in a byte str.rstrip() may have an opinion on
+                                           // (\x1c-\x1f, UTF-8 spaces): the host's join reads such text like Python
 
 struct StrataSlot {
     unsigned long long hash;  // 0: empty
@@ -99,6 +101,7 @@ __global__ void __launch_bounds__(kStrataThreads) strata_parse_kernel(StrataArgs
             tab = p;
             break;
         }
+        if (b == '\r') atomicOr(&s.state[0], kStrataOddBytes);  // (universal newlines: the line ends here)
         kh.put(b);
     }
     bool pair = tab < hi;
@@ -115,8 +118,15 @@ __global__ void __launch_bounds__(kStrataThreads) strata_parse_kernel(StrataArgs
         else
             break;
     }
+    if (ve > tab + 1u) {
+        const unsigned char b = s.text[ve - 1u];
+        if (b >= 0x80 || (b >= 0x1c && b <= 0x1f)) atomicOr(&s.state[0], kStrataOddBytes);
+    }
     NameHash lh;
-    for (uint32_t p = tab + 1u; p < ve; ++p) lh.put(s.text[p]);
+    for (uint32_t p = tab + 1u; p < ve; ++p) {
+        if (s.text[p] == '\r') atomicOr(&s.state[0], kStrataOddBytes);
+        lh.put(s.text[p]);
+    }
     unsigned long long hk = kh.done(), hl = lh.done();
     if (hk == 0ull) hk = 1ull;
     if (hl == kLabelEmpty) hl = kLabelEmpty - 1ull;

@@ -183,7 +183,15 @@ constexpr size_t kScanSlack = 64;  // bytes the vector scanner wants ahead of a 
 
 inline bool is_unmapped(const Line& L) { return L.rn == 1 && L.r[0] == '*'; }
 
-// decimal integer like Python's int() on a clean field: optional sign, digits
+// decimal integer like Python's int() on a clean field: optional sign, digits,
+// single underscores between digits, blanks around.  Python's integers have no
+// width: a value of more than 18 significant digits SATURATES here at +-kHuge
+// (every caller tests the range its field has, so the text is a loud error and
+// never a wrapped number), `wrap` = keep the low 64 bits instead (what
+// `int(flag) >> 6 & 3` looks at, exact for any length).  More than 4300 digits:
+// int() itself refuses (sys.get_int_max_str_digits()).
+constexpr long kHuge = 1l << 62;
+template <bool wrap = false>
 inline bool parse_int(const char* p, const char* e, long& v) {
     auto blank = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
     while (p < e && blank(*p)) ++p;  // int() ignores surrounding whitespace
@@ -191,22 +199,37 @@ inline bool parse_int(const char* p, const char* e, long& v) {
     bool neg = false;
     if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
     if (p >= e) return false;
-    if (e - p > 18 + (e - p) / 2) return false;  // (beyond 18 digits and their underscores: no number an alignment file holds)
-    long x = 0;
+    unsigned long x = 0;
+    bool huge = false;
+    long digits = 0;
     for (const char* b = p; p < e; ++p) {
         // (int() takes single underscores between digits)
         if (*p == '_' && p > b && p[-1] != '_' && p + 1 < e && p[1] >= '0' && p[1] <= '9') continue;
         if (*p < '0' || *p > '9') return false;
-        x = x * 10 + (*p - '0');
+        ++digits;
+        const unsigned long d = (unsigned long)(*p - '0');
+        if (wrap) {
+            x = x * 10ul + d;
+        } else if (x > ((unsigned long)kHuge - 9ul) / 10ul) {
+            huge = true;
+        } else {
+            x = x * 10ul + d;
+        }
     }
-    v = neg ? -x : x;
+    if (digits > 4300) return false;
+    if (wrap)
+        v = (long)(neg ? 0ul - x : x);
+    else
+        v = huge ? (neg ? -kHuge : kHuge) : (neg ? -(long)x : (long)x);
     return true;
 }
+
+inline bool fits_i32(long v) { return v >= INT32_MIN && v <= INT32_MAX; }
 
 // FLAG as int() reads it (align.py:322): the value's low bits (the mate bits are all that is looked at)
 inline bool parse_flag(const char* b, const char* e, int& flag) {
     long v;
-    if (!parse_int(b, e, v)) return false;
+    if (!parse_int<true>(b, e, v)) return false;
     flag = (int)(v & 0x7FFFFFFFl);
     return true;
 }
@@ -320,10 +343,7 @@ inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
         L.q = fb(0);
         L.qn = fe(0) - fb(0);
         const char* rb = fb(1);
-        const char* re = fe(1);
-        while (re > rb && (re[-1] == ' ' || re[-1] == '\r' || re[-1] == '\n' || re[-1] == '\t' || re[-1] == '\v' ||
-                           re[-1] == '\f'))
-            --re;  // str.rstrip()
+        const char* re = wkh::py_rstrip(rb, fe(1));  // subject.rstrip() (align.py:653)
         L.r = rb;
         L.rn = re - rb;
         L.ok = true;
@@ -358,6 +378,11 @@ inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
             L.bad_number = true;
             return L;
         }
+        // (coordinates are held in 32 bits: anything wider is a loud error)
+        if (!fits_i32(a) || !fits_i32(b) || !fits_i32((a < b ? a : b) - 1) || n > (long)UINT32_MAX || n < -(long)UINT32_MAX) {
+            L.bad_number = true;
+            return L;
+        }
         L.len = (uint32_t)n;
         L.beg = (int32_t)((a < b ? a : b) - 1);
         L.end = (int32_t)(a < b ? b : a);
@@ -367,6 +392,10 @@ inline Line parse_row(int fmt, const char* p, const char* e, bool extra) {
         if (!parse_int(fb(10), fe(10), n) || !parse_int(fb(7), fe(7), a) || !parse_int(fb(8), fe(8), b) ||
             !parse_int(fb(11), fe(11), sc))
             return L;  // ValueError is caught there: the row is skipped
+        if (!fits_i32(a) || !fits_i32(b) || n > (long)UINT32_MAX || n < -(long)UINT32_MAX) {
+            L.bad_number = true;  // (numbers, but wider than the 32 bits they are held in)
+            return L;
+        }
         L.len = (uint32_t)n;
         L.beg = (int32_t)a;
         L.end = (int32_t)b;
@@ -380,7 +409,8 @@ inline bool is_row(int fmt, const Line& L) { return L.ok && !(fmt == WK_FMT_SAM 
 // align.cigar_to_lens (align.py:550-583).  false where the reference raises:
 // int() of the characters collected since the last operation runs only for
 // M = X D N, and refuses an empty string or anything int() does.
-inline bool cigar_lens(const char* c, size_t n, uint32_t& aligned, uint32_t& span) {
+inline bool cigar_lens(const char* c, size_t n, int64_t& aligned, int64_t& span) {
+    constexpr int64_t kWide = 1ll << 40;  // sums saturate here: far beyond the 32 bits the caller accepts
     int64_t a = 0, x = 0;
     size_t s = 0;  // start of the text collected since the last operation
     for (size_t i = 0; i < n; ++i) {
@@ -389,14 +419,15 @@ inline bool cigar_lens(const char* c, size_t n, uint32_t& aligned, uint32_t& spa
         if (lens || skip) {
             long v;
             if (!parse_int(c + s, c + i, v)) return false;  // int(n), with what int() takes (sign, blanks, underscores)
-            (skip ? x : a) += v;
+            int64_t& acc = skip ? x : a;
+            acc = std::max<int64_t>(-kWide, std::min<int64_t>(kWide, acc + std::max<long>(-kWide, std::min<long>(kWide, v))));
             s = i + 1;
         } else if (ch == 'I' || ch == 'H' || ch == 'P' || ch == 'S') {
             s = i + 1;
         }
     }
-    aligned = (uint32_t)a;
-    span = (uint32_t)(a + x);
+    aligned = a;
+    span = a + x;
     return true;
 }
 
@@ -862,7 +893,7 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
                 // int(pos) and cigar_to_lens raise on text that is not a number
                 // (align.py:382-385); a negative POS is a number
                 long pos = 0;
-                uint32_t aligned = 0, span = 0;
+                int64_t aligned = 0, span = 0;
                 if (!parse_int(L.pos, L.pos_end, pos) || !cigar_lens(L.cigar, L.cn, aligned, span)) {
                     out.error = 2;
                     out.error_at = (size_t)(line - base);
@@ -873,10 +904,18 @@ void tokenize_range(const wk_tok* T, int fmt, const char* base, const char* b, c
                     out.error_at = (size_t)(line - base);
                     return;
                 }
+                // numbers, but wider than the 32 bits coordinates are held in
+                // (a stated limit, DESIGN: a loud error, never a wrapped value)
+                if (!fits_i32(pos - 1) || aligned < -(int64_t)UINT32_MAX || aligned > (int64_t)UINT32_MAX || span < INT32_MIN ||
+                    span > INT32_MAX || !fits_i32(pos - 1 + span)) {
+                    out.error = 3;
+                    out.error_at = (size_t)(line - base);
+                    return;
+                }
                 if (aligned == 0 && !keep_empty) continue;  // ordinal.py:231 (range.py keeps them)
                 rc.beg = (int32_t)(pos - 1);
                 rc.end = (int32_t)(pos - 1 + span);
-                rc.len = aligned;
+                rc.len = (uint32_t)aligned;
             } else {
                 if (L.len == 0 && !keep_empty) continue;
                 rc.beg = L.beg;
@@ -1144,7 +1183,10 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
     for (int i = 0; i < T; ++i)
         if (loc[i].error) {
             char msg[160];
-            snprintf(msg, sizeof msg, loc[i].error == 1 ? "SAM flag with both mate bits set at byte %zu" : "malformed alignment line at byte %zu",
+            snprintf(msg, sizeof msg,
+                     loc[i].error == 1   ? "SAM flag with both mate bits set at byte %zu"
+                     : loc[i].error == 3 ? "coordinate wider than 32 bits at byte %zu"
+                                         : "malformed alignment line at byte %zu",
                      loc[i].error_at);
             t->err = msg;
             t->n_loc = 0;
@@ -1425,11 +1467,14 @@ int wk_tok_strata_load(wk_tok* t, const char* buf, int64_t len, int64_t* n_entri
         while (p < stop) {
             const char* nl = (const char*)memchr(p, '\n', stop - p);
             const char* le = nl ? nl + 1 : stop;  // line including its newline
+            // (the reference reads text with universal newlines: a \r without a
+            // \n behind it ends a line as well)
+            if (const char* cr = (const char*)memchr(p, '\r', le - p))
+                if (cr + 1 < le && cr[1] != '\n') le = cr + 1;
             const char* tab = (const char*)memchr(p, '\t', le - p);
             if (tab && !memchr(tab + 1, '\t', le - tab - 1)) {
                 const char* vb = tab + 1;
-                const char* ve = le;
-                while (ve > vb && (ve[-1] == '\n' || ve[-1] == '\r' || ve[-1] == ' ' || ve[-1] == '\v' || ve[-1] == '\f')) --ve;
+                const char* ve = wkh::py_rstrip(vb, le);  // value.rstrip() (file.py:384)
                 const size_t kn = (size_t)(tab - p);
                 const uint64_t kh = hash_bytes(p, kn);
                 const uint64_t lh = hash_bytes(vb, (size_t)(ve - vb));

@@ -392,7 +392,17 @@ def flatten_hierarchy(tree, rankdic=None, root=None):
         # nodes that cannot reach the root stay in the caller's dicts and
         # leave the numbered tree (csrc/wk_hierarchy.cpp does the same): a
         # subject among them is a name outside the tree
-        r = int(np.flatnonzero(par == np.arange(n, dtype=np.int64))[0])
+        # (the caller's root when one was given; else the self-parented node,
+        # which must be the only one -- several crowns without a stated root
+        # are `fill_root`'s business, not a cycle's)
+        if root is not None:
+            r = tmp[root]
+        else:
+            selfs = np.flatnonzero(par == np.arange(n, dtype=np.int64))
+            if selfs.size != 1:
+                raise ValueError('The hierarchy has no unique root; call '
+                                 'fill_root first.')
+            r = int(selfs[0])
         top = par.copy()
         for _ in range(max(1, int(n).bit_length())):    # 2^k steps >= n
             top = top[top]

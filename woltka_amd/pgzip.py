@@ -23,7 +23,10 @@ def member(data, level=None):
     for."""
     if level is None:
         from . import _native
-        return _native.gz_member(data)
+        try:
+            return _native.gz_member(data)
+        except ValueError:      # (never seen since the bound counts blocks)
+            level = 6
     c = zlib.compressobj(level, zlib.DEFLATED, -15)
     body = c.compress(data) + c.flush()
     size = HEAD_LEN + len(body) + 8

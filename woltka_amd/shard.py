@@ -156,16 +156,38 @@ class LocalWorld:
         if self.rank != 0:
             self._conns.send(('ok', obj))
             return None
-        out = [obj]
-        for r, conn in enumerate(self._conns, 1):
-            try:
-                status, payload = conn.recv()
-            except EOFError:
-                status, payload = 'error', 'the process died'
-            if status != 'ok':
-                raise RuntimeError(f'rank {r} failed: {payload}')
-            out.append(payload)
+        # every rank is heard before anything is raised: a rank blocked in
+        # send() (an object larger than the pipe's buffer) is drained even
+        # when another one failed, so that it can end
+        from multiprocessing.connection import wait
+        out = [obj] + [None] * len(self._conns)
+        failed = []
+        pending = {conn: r for r, conn in enumerate(self._conns, 1)}
+        while pending:
+            for conn in wait(list(pending)):
+                r = pending.pop(conn)
+                try:
+                    status, payload = conn.recv()
+                except (EOFError, OSError):
+                    status, payload = 'error', 'the process died'
+                if status == 'ok':
+                    out[r] = payload
+                else:
+                    failed.append((r, payload))
+        if failed:
+            r, payload = min(failed)
+            raise RuntimeError(f'rank {r} failed: {payload}')
         return out
+
+    def close(self):
+        """(rank 0) drop the pipes: a rank still sending gets a broken pipe
+        instead of waiting for a reader that will not come."""
+        if self.rank == 0:
+            for conn in self._conns:
+                try:
+                    conn.close()
+                except OSError:
+                    pass
 
 
 class TorchWorld:
@@ -220,6 +242,32 @@ def start_local_world(world, entry, kwargs):
         conns.append(parent)
         procs.append(p)
     return LocalWorld(0, world, conns), procs
+
+
+def stop_local_world(comm, procs, failed=False, grace=None):
+    """End the ranks ``start_local_world`` started.  After a clean run they
+    have sent their share and are joined; after a failure (of rank 0 itself,
+    or reported by ``gather``) the pipes are closed, the ranks get ``grace``
+    seconds to end by themselves and are terminated, then killed, after it:
+    the caller's exception is never held back by a join that cannot return."""
+    if not procs:
+        return
+    if grace is None:
+        grace = 5.0 if failed else None
+    if failed and isinstance(comm, LocalWorld):
+        comm.close()
+    for p in procs:
+        p.join(grace)
+    for stop in ('terminate', 'kill'):
+        alive = [p for p in procs if p.is_alive()]
+        if not alive:
+            break
+        for p in alive:
+            getattr(p, stop)()
+        for p in alive:
+            p.join(2.0)
+    if isinstance(comm, LocalWorld):
+        comm.close()
 
 
 def pin_near_gpu(device):

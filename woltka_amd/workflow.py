@@ -125,8 +125,9 @@ def _workflow(input_fp, output_fp, input_fmt, input_ext, samples, demux,
               if k not in ('comm', 'procs', 'gpus', 'TorchWorld',
                            'start_local_world')}
         comm, procs = start_local_world(gpus, _rank_entry, kw)
+    failed = True
     try:
-        return _workflow_ranked(
+        out = _workflow_ranked(
             input_fp, output_fp, input_fmt, input_ext, samples, demux,
             exclude, trimsub, nodes_fps, newick_fps, lineage_fps,
             columns_fps, map_fps, map_rank, names_fps, ranks, uniq, major,
@@ -134,9 +135,13 @@ def _workflow(input_fp, output_fp, input_fmt, input_ext, samples, demux,
             digits, output_fmt, unassigned, name_as_id, add_rank,
             add_lineage, outmap_dir, outmap_zip, outcov_dir, outcov_fmt,
             chunk, cache, no_exe, device, comm)
+        failed = False
+        return out
     finally:
-        for p in procs:
-            p.join()
+        if procs:
+            # (a failed run must not wait on ranks blocked in send())
+            from .shard import stop_local_world
+            stop_local_world(comm, procs, failed=failed)
 
 
 def _rank_entry(comm=None, **kw):
