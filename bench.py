@@ -544,7 +544,7 @@ def _synth_lib():
             lib.wk_synth_sam.restype = C.c_int64
             lib.wk_synth_sam.argtypes = [C.c_char_p, C.c_int64, i64p, C.c_char,
                                          i32p, i32p, C.c_char, C.c_int, i32p,
-                                         i32p, C.c_int]
+                                         i32p, C.c_int, C.c_int]
             _SYNTH = lib
         except OSError:
             _SYNTH = False
@@ -552,7 +552,7 @@ def _synth_lib():
 
 
 def write_sam(path, read_id, subject, qprefix=b'R', sprefix=b'T', swidth=7,
-              flag=None, pos=None, alen=None, block=4_000_000):
+              flag=None, pos=None, alen=None, block=4_000_000, seqqual=0):
     """SAM text, one line per alignment record (trimmed as doc/perform.md:
     122-128 recommends: SEQ / QUAL '*'):
     ``<q><read id:09d> flag <s><subject:0{swidth}d> pos 42 <len>M * 0 0 * *``;
@@ -576,11 +576,11 @@ def write_sam(path, read_id, subject, qprefix=b'R', sprefix=b'T', swidth=7,
             qprefix, ptr(keep[0], C.c_int32),
             subject.ctypes.data_as(C.POINTER(C.c_int32)), sprefix, swidth,
             ptr(keep[1], C.c_int32), ptr(keep[2], C.c_int32),
-            min(os.cpu_count() or 1, 64))
+            min(os.cpu_count() or 1, 64), int(seqqual))
         if size < 0:
             raise OSError(f'writing {path} failed')
         return int(size)
-    if flag is not None or pos is not None or alen is not None:
+    if flag is not None or pos is not None or alen is not None or seqqual:
         raise RuntimeError('tools/native/libwk_synth.so is missing (run '
                            '__graft_entry__.build()): the numpy writer knows '
                            'fixed-width lines only')
@@ -603,14 +603,16 @@ def write_sam(path, read_id, subject, qprefix=b'R', sprefix=b'T', swidth=7,
     return size + 23
 
 
-def write_sam_lca(path, prob, n_reads):
-    """SAM text of the first `n_reads` reads of a packed config-3 problem.
-    Returns (records, bytes)."""
+def write_sam_lca(path, prob, n_reads, first=0, seqqual=0):
+    """SAM text of reads [first, n_reads) of a packed config-3 problem.
+    `seqqual`: bases of SEQ / QUAL per line instead of '*' (what an aligner
+    writes unless told otherwise).  Returns (records, bytes)."""
     qoff = prob['qoff']
-    n_rec = int(qoff[n_reads])
-    read_of = np.repeat(np.arange(n_reads, dtype=np.int64),
-                        np.diff(qoff[:n_reads + 1]))
-    return n_rec, write_sam(path, read_of, prob['subj'][:n_rec])
+    lo, hi = int(qoff[first]), int(qoff[n_reads])
+    read_of = np.repeat(np.arange(first, n_reads, dtype=np.int64),
+                        np.diff(qoff[first:n_reads + 1]))
+    return hi - lo, write_sam(path, read_of, prob['subj'][lo:hi],
+                              seqqual=seqqual)
 
 
 def write_nodes_dmp(path, hier):
@@ -861,6 +863,128 @@ def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
         res['equals_reference_at_fixture_size'] = twopass_fixture_check(
             device, workdir)
     return res
+
+
+def lca_problem(seed=1002, scale=1.0):
+    """The packed configs[2] problem of `seed` (what LcaWorkload stages)."""
+    n_reads = int(50_000_000 * scale)
+    return synth.as_sets(synth.lca_problem(
+        np.random.default_rng(seed), n_nodes=2_000_000, n_subjects=100_000,
+        n_reads=n_reads, with_names=False))
+
+
+def e2e_inputs(kind, d, reads=0, prob=None):
+    """Write the input files of one end-to-end leg under directory `d` and
+    `<d>/<kind>.meta.json` = {kwargs of workflow.workflow, records, reads,
+    text_bytes}; returns that dict.  `reads` = 0: the configuration's size.
+    (tools/e2e_once.py --prepare, the profilers' entry; `e2e_leg` below.)"""
+    sub = os.path.join(d, kind)
+    os.makedirs(sub, exist_ok=True)
+    indir = os.path.join(sub, 'in')
+    os.makedirs(indir, exist_ok=True)
+    meta = {'kind': kind}
+    if kind in ('lca', 'lca_seqqual', 'lca_gz', 'lca_gz8'):
+        if prob is None:
+            prob = lca_problem(1002, (reads or 50_000_000) / 50_000_000)
+        n_reads = min(reads or 50_000_000, int(prob['qoff'].size - 1))
+        nodes = os.path.join(sub, 'nodes.dmp')
+        write_nodes_dmp(nodes, prob['hier'])
+        kw = dict(input_fp=indir, output_fp=os.path.join(sub, 'out'),
+                  input_fmt='sam', output_fmt=False, nodes_fps=[nodes],
+                  ranks='phylum,genus,species')
+        if kind == 'lca':
+            n_rec, n_bytes = write_sam_lca(os.path.join(indir, 'S1.sam'),
+                                           prob, n_reads)
+        elif kind == 'lca_seqqual':
+            n_rec, n_bytes = write_sam_lca(os.path.join(indir, 'S1.sam'),
+                                           prob, n_reads, seqqual=150)
+        else:
+            parts = 8 if kind == 'lca_gz8' else 1
+            n_rec = n_bytes = 0
+            meta['gz_bytes'] = 0
+            cuts = [n_reads * i // parts for i in range(parts + 1)]
+            for i in range(parts):
+                fp = os.path.join(indir, f'S{i + 1}.sam')
+                r, b = write_sam_lca(fp, prob, cuts[i + 1], first=cuts[i])
+                n_rec, n_bytes = n_rec + r, n_bytes + b
+                meta['gz_bytes'] += gzip_file(fp)
+        meta.update(records=n_rec, reads=n_reads, text_bytes=n_bytes)
+    elif kind == 'flat':
+        n_reads = reads or 10_000_000
+        p = synth.flat_problem(np.random.default_rng(1002), n_reads=n_reads,
+                               with_names=False)
+        h = p['hier']
+        # subjects G%09d drawn Zipf; the flat map subject -> genus
+        # (`--map flat2genus.map --rank genus`: SURVEY 8d config 2)
+        n_rec = int(p['subj'].size)
+        n_bytes = write_sam(os.path.join(indir, 'S1.sam'),
+                            np.arange(n_rec, dtype=np.int64), p['subj'],
+                            b'R', b'G', 9)
+        mp = os.path.join(sub, 'flat2genus.map')
+        par = h.parent
+        with open(mp, 'w') as f:
+            f.writelines(f'G{v:09d}\tT{int(par[v]):07d}\n'
+                         for v in np.unique(p['subj']).tolist())
+        kw = dict(input_fp=indir, output_fp=os.path.join(sub, 'out.tsv'),
+                  input_fmt='sam', output_fmt=False, map_fps=[mp],
+                  map_rank=None, ranks='genus')
+        meta.update(records=n_rec, reads=n_reads, text_bytes=n_bytes)
+    elif kind == 'ordinal':
+        n_reads = reads or 100_000_000
+        if prob is None:
+            prob = synth.ordinal_problem(np.random.default_rng(1002),
+                                         n_pairs=n_reads // 2)
+        n_reads = min(n_reads, int(prob['n_reads']))
+        _, coords, n_rec, n_bytes = write_ordinal_inputs(indir, prob, n_reads)
+        os.replace(coords, os.path.join(sub, 'coords.txt'))
+        kw = dict(input_fp=indir, output_fp=os.path.join(sub, 'out.tsv'),
+                  input_fmt='sam', output_fmt=False,
+                  coords_fp=os.path.join(sub, 'coords.txt'), overlap=80)
+        meta.update(records=n_rec, reads=n_reads, text_bytes=n_bytes)
+    elif kind in ('twopass1', 'twopass2'):
+        # (both calls share their inputs: <d>/twopass)
+        sub = os.path.join(d, 'twopass')
+        os.makedirs(sub, exist_ok=True)
+        n_reads = reads or 20_000_000
+        mfp = os.path.join(sub, 'inputs.json')
+        if os.path.isfile(mfp):
+            with open(mfp) as f:
+                got = json.load(f)
+        else:
+            fps, n_rec, n_bytes, one = write_twopass_inputs(sub, 8, n_reads)
+            got = {'fps': fps, 'records': n_rec, 'text_bytes': n_bytes,
+                   'reads': 8 * n_reads}
+            with open(mfp, 'w') as f:
+                json.dump(got, f)
+        kw1, kw2 = twopass_calls(got['fps'], sub)
+        if kind == 'twopass2' and not os.path.isdir(kw1['outmap_dir']):
+            from woltka_amd import workflow
+            quiet(workflow.workflow, **kw1)     # pass 1's maps
+        kw = kw1 if kind == 'twopass1' else kw2
+        meta.update(records=got['records'], reads=got['reads'],
+                    text_bytes=got['text_bytes'])
+    else:
+        raise ValueError(kind)
+    meta['kwargs'] = kw
+    with open(os.path.join(d, f'{kind}.meta.json'), 'w') as f:
+        json.dump(meta, f)
+    return meta
+
+
+def gzip_file(fp, level=6):
+    """`fp` -> `fp`.gz (one member, zlib at `level`: what `gzip` / bowtie2's
+    pipe writes), the plain file removed.  Returns the compressed size."""
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)
+    with open(fp, 'rb') as src, open(fp + '.gz', 'wb') as dst:
+        while True:
+            blob = src.read(1 << 24)
+            if not blob:
+                break
+            dst.write(c.compress(blob))
+        dst.write(c.flush())
+    os.remove(fp)
+    return os.path.getsize(fp + '.gz')
 
 
 def cold_process_s(kw, device=0):

@@ -630,6 +630,22 @@ int64_t wk_gz_inflate_members(const char* blob, const int64_t* lo,
                               const int64_t* hi, int64_t n, char* out,
                               const int64_t* off, int n_threads);
 
+/* ---- gzip input, inflated natively (host; csrc/wk_inflate.cpp) ------------ */
+/* file.readzip's decompressor (woltka/file.py:62-129: `gzip -cdfq` as a child,
+ * or the gzip module) for alignment files: a regular `.gz` file is mapped and
+ * inflated by this library's own table-driven decoder on up to n_threads
+ * threads -- one stream cut into chunks that find a block start each and are
+ * decoded with an unknown window, resolved in order; members that state their
+ * size (BGZF 'BC', this library's 'WK') one task each.  CRC-32 and ISIZE of
+ * every member are verified.  wk_gunzip_open: NULL on failure (`err` says why);
+ * wk_gunzip_read: the next bytes of text into dst[0, cap) (cap >= 65536),
+ * their number, 0 at the end, -1 on damaged data (wk_gunzip_error). */
+typedef struct wk_gunzip wk_gunzip;
+wk_gunzip* wk_gunzip_open(const char* path, int n_threads, char* err, size_t err_cap);
+int64_t wk_gunzip_read(wk_gunzip* h, char* dst, int64_t cap);
+const char* wk_gunzip_error(wk_gunzip* h);
+void wk_gunzip_close(wk_gunzip* h);
+
 /* Dictionary growth: total subjects, subjects not yet reported, their bytes. */
 int wk_tok_subjects(wk_tok* tok, int32_t* n_total, int32_t* n_new,
                     int64_t* new_bytes);

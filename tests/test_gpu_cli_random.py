@@ -51,10 +51,48 @@ def _label(i):
     return f'{i}-' + '-'.join(map(str, bits))
 
 
+def expects_device_text(case, args):
+    """Must this reference case be tokenised on the device?  The stated limits
+    of the device text route (DESIGN: routes), nothing more: plain text files
+    in a directory (a single file is demultiplexed), no `--exclude`, no
+    `--demux`, no `--trim-sub`, no coverage, no `--sizes`; plain
+    classification with job sets the packed words take (plain ranks, or
+    whole-read jobs only) with or without read maps; `--coords` without read
+    maps.  Returns the ROUTES keys of which one must have counted."""
+    kw = case['kwargs']
+    files = [f for f in case['files'] if f.startswith('aln/')]
+    if not files or kw['input_fp'] != 'aln':
+        return None
+    if any(os.path.splitext(f)[1] in ('.gz', '.bz2', '.xz') for f in files):
+        return None
+    if any(kw.get(k) for k in ('exclude', 'demux', 'trimsub', 'sizes',
+                               'strata_dir', 'samples')):
+        return None
+    if case.get('want_cov') or 'error' in case['expect']:
+        return None
+    if kw.get('coords_fp'):
+        return None if case['want_maps'] else ('dhits', 'dhits_strata')
+    ranks = (kw.get('ranks') or 'none').split(',')
+    whole = [r == 'free' or bool(kw.get('uniq') or kw.get('above') or
+                                 (kw.get('major') or 0) > 50)
+             for r in ranks]
+    if kw.get('uniq') and not all(whole):
+        return None             # (--uniq at --rank none: the general route)
+    if any(whole) and not all(whole):
+        return None             # mixed job sets: the general evaluator
+    if kw.get('major') and not all(whole):
+        return None
+    if case['want_maps'] and any(whole):
+        return None             # device read maps: the plain assigners
+    return ('dtok_maps',) if case['want_maps'] else ('dtok',)
+
+
 @pytest.mark.parametrize('i', range(len(CASES)), ids=_label)
 def test_random_cli_case(tmp_path, i):
     from woltka_amd.workflow import workflow
+    from woltka_amd.classify import ROUTES
     case = CASES[i]
+    routes_before = dict(ROUTES)
     for rel, text in case['files'].items():
         write_case_file(tmp_path / rel, text)
 
@@ -91,6 +129,14 @@ def test_random_cli_case(tmp_path, i):
         got = {fn: (tmp_path / 'out' / fn).read_text()
                for fn in sorted(os.listdir(tmp_path / 'out'))}
     assert got == expect['tables']
+    # the route: an uncompressed SAM / BLAST / PAF / map case
+    # within the stated limits went through the tokenizer on the device
+    want = expects_device_text(case, args)
+    took = {k: ROUTES[k] - routes_before.get(k, 0) for k in ROUTES
+            if ROUTES[k] != routes_before.get(k, 0)}
+    if want is not None and any(x.strip() for f, x in case['files'].items()
+                                if f.startswith('aln/')):
+        assert any(took.get(k) for k in want), (want, took)
     if case['want_maps']:
         maps = {}
         for root, _, fns in os.walk(args['outmap_dir']):

@@ -540,3 +540,48 @@ def test_b6o_and_paf_stratified_coord_match_on_the_device(tmp_path, fmt):
     b, log_b = _run(tmp_path, 'h', True, **kw)
     assert a == b and log_a == log_b
     assert len(a['table']) > 2000
+
+
+def test_text_str_rstrip_has_an_opinion_on_goes_to_the_host(tmp_path):
+    """a simple map whose subjects end in \\x1c / NBSP / U+3000, and
+    a strata map whose labels do (or that holds a lone \\r): the device hands
+    the block / the map to the host, which strips like `str.rstrip()` -- the
+    tables are those of the Python parsers (`--no-exe`-less host route with
+    WOLTKA_NO_DTOK)."""
+    from woltka_amd import classify as C
+    tails = ['', ' ', '\x1c', '\xa0', '　', '\x1f \x85']
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    rows = [f'r{q}\tG{q % 7}{tails[q % len(tails)]}\n' for q in range(600)]
+    (indir / 'S1.map').write_text(''.join(rows))
+    kw = dict(input_fp=str(indir), input_fmt='map')
+    C.ROUTES.clear()
+    a, _ = _run(tmp_path, 'd', False, **kw)
+    assert C.ROUTES.get('host_block', 0) > 0
+    b, _ = _run(tmp_path, 'h', True, **kw)
+    assert a == b
+    want = {f'G{i}' for i in range(7)}
+    got = {ln.split(b'\t')[0].decode() for ln in a['table'].split(b'\n')[1:]
+           if ln}
+    assert got == want
+    # strata labels
+    rng = random.Random(4)
+    coords, text = _random_coords_rows(rng, 'b6o', 1500)
+    ind2, sdir = tmp_path / 'in2', tmp_path / 'strata'
+    ind2.mkdir()
+    sdir.mkdir()
+    (ind2 / 'S1.b6o').write_text(text)
+    reads = sorted({ln.split('\t')[0] for ln in text.split('\n') if ln})
+    (sdir / 'S1.txt').write_text(''.join(
+        f'{q}\tT{i % 5}{tails[i % len(tails)]}\n' for i, q in enumerate(reads)))
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    kw = dict(input_fp=str(ind2), input_fmt='b6o', coords_fp=str(cfp),
+              strata_dir=str(sdir))
+    C.ROUTES.clear()
+    a, _ = _run(tmp_path, 'sd', False, **kw)
+    assert not C.ROUTES.get('dstrata'), dict(C.ROUTES)
+    b, _ = _run(tmp_path, 'sh', True, **kw)
+    assert a == b
+    strata = {ln.split(b'|')[0] for ln in a['table'].split(b'\n')[1:] if ln}
+    assert strata == {b'T%d' % i for i in range(5)}

@@ -26,6 +26,7 @@ typedef struct {
     const int32_t* alen;
     char qprefix, sprefix;
     int swidth;
+    int seqqual; /* bases of SEQ / QUAL per line; 0: '*' */
     int status;
 } Job;
 
@@ -51,7 +52,8 @@ static char* put_uint(char* p, uint32_t v) { return put_fixed(p, v, udigits(v));
 static int64_t line_len(const Job* j, int64_t i) {
     /* q + 9 + \t + flag + \t + s + swidth + \t + pos + \t42\t + len + "M\t*\t0\t0\t*\t*\n" */
     return 1 + 9 + 1 + udigits(j->flag ? (uint32_t)j->flag[i] : 0u) + 1 + 1 + j->swidth + 1 +
-           udigits(j->pos ? (uint32_t)j->pos[i] : 1u) + 4 + udigits(j->alen ? (uint32_t)j->alen[i] : 150u) + 12;
+           udigits(j->pos ? (uint32_t)j->pos[i] : 1u) + 4 + udigits(j->alen ? (uint32_t)j->alen[i] : 150u) + 12 +
+           (j->seqqual ? 2 * (j->seqqual - 1) : 0);
 }
 
 static void* size_job(void* arg) {
@@ -65,8 +67,9 @@ static void* size_job(void* arg) {
 static void* write_job(void* arg) {
     Job* j = (Job*)arg;
     static const char tail[] = "M\t*\t0\t0\t*\t*\n";
+    static const char tail_sq[] = "M\t*\t0\t0\t";
     const size_t cap = 8u << 20;
-    char* buf = (char*)malloc(cap + 256);
+    char* buf = (char*)malloc(cap + 256 + 2 * (size_t)j->seqqual);
     int fd = open(j->path, O_WRONLY);
     if (!buf || fd < 0) {
         j->status = -1;
@@ -89,8 +92,28 @@ static void* write_job(void* arg) {
         memcpy(p, "\t42\t", 4);
         p += 4;
         p = put_uint(p, j->alen ? (uint32_t)j->alen[i] : 150u);
-        memcpy(p, tail, 12);
-        p += 12;
+        if (!j->seqqual) {
+            memcpy(p, tail, 12);
+            p += 12;
+        } else { /* SEQ and QUAL of `seqqual` characters, varying with the record */
+            memcpy(p, tail_sq, 8);
+            p += 8;
+            uint64_t x = (uint64_t)i * 0x9E3779B97F4A7C15ull + 12345u;
+            for (int k = 0; k < j->seqqual; ++k) {
+                x ^= x << 13;
+                x ^= x >> 7;
+                x ^= x << 17;
+                *p++ = "ACGT"[x & 3];
+            }
+            *p++ = '\t';
+            for (int k = 0; k < j->seqqual; ++k) {
+                x ^= x << 13;
+                x ^= x >> 7;
+                x ^= x << 17;
+                *p++ = (char)('#' + (x & 31) + (x >> 60));
+            }
+            *p++ = '\n';
+        }
         if ((size_t)(p - buf) >= cap || i + 1 == j->hi) {
             size_t left = (size_t)(p - buf);
             const char* q = buf;
@@ -116,9 +139,9 @@ static void* write_job(void* arg) {
 /* Returns the file size, or -1. */
 int64_t wk_synth_sam(const char* path, int64_t n_rec, const int64_t* read_id, char qprefix, const int32_t* flag,
                      const int32_t* subject, char sprefix, int swidth, const int32_t* pos, const int32_t* alen,
-                     int n_threads) {
+                     int n_threads, int seqqual) {
     static const char head[] = "@HD\tVN:1.0\tSO:unsorted\n";
-    if (!path || n_rec < 0 || !read_id || !subject || swidth < 1 || swidth > 12) return -1;
+    if (!path || n_rec < 0 || !read_id || !subject || swidth < 1 || swidth > 12 || seqqual < 0 || seqqual > 100000) return -1;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     if ((int64_t)n_threads > n_rec / 65536 + 1) n_threads = (int)(n_rec / 65536 + 1);
@@ -138,6 +161,7 @@ int64_t wk_synth_sam(const char* path, int64_t n_rec, const int64_t* read_id, ch
         j->qprefix = qprefix;
         j->sprefix = sprefix;
         j->swidth = swidth;
+        j->seqqual = seqqual;
     }
     for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, size_job, &jobs[t]);
     for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);

@@ -69,7 +69,8 @@ SYMBOLS = (
     'wk_hier_size', 'wk_hier_keys', 'wk_hier_ranks',
     'wk_coords_parse', 'wk_coords_error', 'wk_coords_sizes',
     'wk_coords_fetch', 'wk_coords_free',
-    'wk_gz_bound', 'wk_gz_member', 'wk_crc32', 'wk_gz_inflate_members')
+    'wk_gz_bound', 'wk_gz_member', 'wk_crc32', 'wk_gz_inflate_members',
+    'wk_gunzip_open', 'wk_gunzip_read', 'wk_gunzip_error', 'wk_gunzip_close')
 
 
 class Job(C.Structure):
@@ -257,6 +258,10 @@ def load_library():
         'wk_crc32': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_int64]),
         'wk_gz_inflate_members': (C.c_int64, [C.c_void_p, i64p, i64p, C.c_int64,
                                               C.c_void_p, i64p, C.c_int]),
+        'wk_gunzip_open': (p, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
+        'wk_gunzip_read': (C.c_int64, [p, C.c_void_p, C.c_int64]),
+        'wk_gunzip_error': (C.c_char_p, [p]),
+        'wk_gunzip_close': (None, [p]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -1113,6 +1118,49 @@ def gz_member(data):
     if n < 0:
         raise ValueError('wk_gz_member failed')
     return out[:n].tobytes()
+
+
+class Gunzip:
+    """A regular gzip file inflated by ``wk_gunzip_*`` (csrc/wk_inflate.cpp):
+    ``readinto(buffer)`` fills a writable buffer of at least 64 KB with the
+    next bytes of text on ``threads`` threads (the GIL is released) and
+    returns their number, 0 at the end.  ``OSError`` where the gzip module
+    raises one (damaged data, CRC); ``ValueError`` when the file is not what
+    this reader takes (the caller then opens it the ordinary way)."""
+
+    def __init__(self, path, threads=1):
+        self._lib = load_library()
+        err = C.create_string_buffer(200)
+        self._h = self._lib.wk_gunzip_open(os.fsencode(path), int(threads),
+                                           err, len(err))
+        if not self._h:
+            raise ValueError(err.value.decode() or 'wk_gunzip_open failed')
+
+    def readinto(self, out):
+        arr = np.frombuffer(out, dtype=np.uint8) \
+            if not isinstance(out, np.ndarray) else out
+        n = self._lib.wk_gunzip_read(self._h, C.c_void_p(arr.ctypes.data),
+                                     arr.size)
+        if n < 0:
+            raise OSError(self._lib.wk_gunzip_error(self._h).decode())
+        return n
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.wk_gunzip_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def gz_inflate_members(blob, spans, out=None, n_threads=0):

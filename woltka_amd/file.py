@@ -46,11 +46,133 @@ def readzip(fp, zippers=None):
     return ZIP_MODULES[kind].open(fp, 'rt')
 
 
-def readzip_bytes(fp, zippers=None):
-    """Like ``readzip`` but a *binary* stream (input of the native tokenizer)."""
+class GunzipStream(io.RawIOBase):
+    """Binary stream over a regular gzip file inflated by this package's own
+    decoder on several threads (``_native.Gunzip``, csrc/wk_inflate.cpp: one
+    stream cut into chunks that are decoded with unknown windows and resolved
+    in order; BGZF / 'WK' members one task each; CRC-32 and ISIZE verified).
+    ``readinto`` of a large buffer (>= 64 KB) fills it directly by all threads
+    -- how the device text route reads its blocks; smaller reads, ``read`` and
+    ``readline`` are served from an internal buffer."""
+    CHUNK = 16 << 20
+
+    def __init__(self, fp, threads=1):
+        from . import _native
+        super().__init__()
+        self._gz = _native.Gunzip(fp, threads)
+        self._buf = memoryview(b'')
+        self._eof = False
+        self.threads = threads
+
+    def _more(self):
+        if self._eof:
+            return False
+        import numpy as np
+        raw = np.empty(self.CHUNK, dtype=np.uint8)
+        n = self._gz.readinto(raw)
+        if n == 0:
+            self._eof = True
+            return False
+        self._buf = memoryview(raw)[:n]
+        return True
+
+    def readinto(self, out):
+        mv = memoryview(out).cast('B')
+        if len(self._buf):
+            n = min(len(mv), len(self._buf))
+            mv[:n] = self._buf[:n]
+            self._buf = self._buf[n:]
+            return n
+        if self._eof:
+            return 0
+        if len(mv) >= (1 << 16):
+            n = self._gz.readinto(mv)
+            if n == 0:
+                self._eof = True
+            return n
+        if not self._more():
+            return 0
+        return self.readinto(out)
+
+    def read(self, n=-1):
+        parts, got = [], 0
+        while n < 0 or got < n:
+            if not len(self._buf) and not self._more():
+                break
+            k = len(self._buf) if n < 0 else min(n - got, len(self._buf))
+            parts.append(bytes(self._buf[:k]))
+            self._buf = self._buf[k:]
+            got += k
+        return b''.join(parts)
+
+    def readline(self, size=-1):
+        parts = []
+        while True:
+            if not len(self._buf) and not self._more():
+                break
+            # (a line is short: look at a window, not at all 16 MB, per call)
+            head = bytes(self._buf[:4096])
+            i = head.find(b'\n')
+            if i < 0 and len(self._buf) > 4096:
+                head = bytes(self._buf)
+                i = head.find(b'\n')
+            if i >= 0:
+                parts.append(head[:i + 1])
+                self._buf = self._buf[i + 1:]
+                break
+            parts.append(head)
+            self._buf = memoryview(b'')
+        return b''.join(parts)
+
+    def readable(self):
+        return True
+
+    def close(self):
+        if not self.closed:
+            self._gz.close()
+            self._buf = memoryview(b'')
+            super().close()
+
+
+def gunzip_threads(n_files=1):
+    """Threads of one file's inflater when `n_files` compressed files are
+    inflated at once: this process's tokenizer threads shared among them
+    (WOLTKA_GUNZIP_THREADS overrides; 0 = the ordinary decompressors)."""
+    import os
+    forced = os.environ.get('WOLTKA_GUNZIP_THREADS')
+    if forced is not None and forced != '':
+        return max(0, int(forced))
+    from .hostio import tokenizer_threads
+    return max(1, tokenizer_threads() // max(1, n_files))
+
+
+def open_gunzip(fp, threads=None):
+    """``GunzipStream`` over ``fp`` or None: not a regular gzip file (a
+    `.gz` name on plain text, a pipe), the native library missing, or
+    switched off."""
+    import os
+    if threads is None:
+        threads = gunzip_threads()
+    if not threads or fp == '-' or not isfile(fp):
+        return None
+    try:
+        return GunzipStream(fp, threads)
+    except (ValueError, OSError, RuntimeError):
+        return None
+
+
+def readzip_bytes(fp, zippers=None, threads=None):
+    """Like ``readzip`` but a *binary* stream (input of the native tokenizer).
+    A regular gzip file is inflated by this package's own parallel decoder
+    (``GunzipStream``) with or without ``--no-exe``; everything else as
+    ``readzip`` does (file.py:62-129)."""
     kind = ZIP_BY_EXT.get(splitext(fp)[1])
     if kind is None:
         return open(fp, 'rb')
+    if kind == 'gzip':
+        stream = open_gunzip(fp, threads)
+        if stream is not None:
+            return stream
     if zippers is None:
         return ZIP_MODULES[kind].open(fp, 'rb')
     if kind not in zippers:
@@ -173,8 +295,22 @@ class FilesAhead:
             self._next += 1
             if fp != '-' and splitext(fp)[1] in ZIP_BY_EXT and \
                     fp not in self._open:
+                if ZIP_BY_EXT[splitext(fp)[1]] == 'gzip':
+                    # (the native inflater runs ahead by itself, on its share
+                    # of the threads: no reader thread, and the blocks go
+                    # straight into the consumer's buffers)
+                    stream = open_gunzip(fp, self._gz_threads())
+                    if stream is not None:
+                        self._open[fp] = stream
+                        continue
                 self._open[fp] = AheadStream(
-                    lambda fp=fp: readzip_bytes(fp, self._zippers))
+                    lambda fp=fp: readzip_bytes(fp, self._zippers, 0))
+
+    def _gz_threads(self):
+        """Threads per gzip file: as many files as are in flight share them."""
+        n = sum(1 for fp in self._paths
+                if fp != '-' and splitext(fp)[1] in ZIP_BY_EXT)
+        return gunzip_threads(min(n, self._depth + 1))
 
     def open(self, i):
         """Binary stream of the i-th path."""
@@ -182,7 +318,7 @@ class FilesAhead:
         fp = self._paths[i]
         stream = self._open.pop(fp, None)
         return stream if stream is not None else readzip_bytes(
-            fp, self._zippers)
+            fp, self._zippers, self._gz_threads())
 
     def close(self):
         for s in self._open.values():
