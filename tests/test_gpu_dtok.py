@@ -585,3 +585,47 @@ def test_text_str_rstrip_has_an_opinion_on_goes_to_the_host(tmp_path):
     assert a == b
     strata = {ln.split(b'|')[0] for ln in a['table'].split(b'\n')[1:] if ln}
     assert strata == {b'T%d' % i for i in range(5)}
+
+
+@pytest.mark.parametrize('ordinal', [False, True])
+@pytest.mark.parametrize('block', [1 << 26, 1 << 16])
+def test_gzip_files_take_the_device_route(tmp_path, monkeypatch, ordinal,
+                                          block):
+    """`.sam.gz` inflated natively (csrc/wk_inflate.cpp) feeds the device
+    tokenizer block by block: same tables as the plain files, the device
+    route taken, with the format given or told from the first line; BGZF
+    chains and several members alike."""
+    import gzip
+    from woltka_amd import classify as C
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    rng = random.Random(21 + ordinal)
+    if ordinal:
+        coords, text = _random_coords_sam(rng, 6000)
+        (tmp_path / 'coords.txt').write_text(coords)
+        extra = dict(coords_fp=str(tmp_path / 'coords.txt'))
+    else:
+        subjects = [f'G{i:04d}' for i in range(200)]
+        text = _random_sam(rng, 6000, subjects, True, True, True)
+        extra = {}
+    plain, zipped = tmp_path / 'plain', tmp_path / 'zipped'
+    plain.mkdir()
+    zipped.mkdir()
+    half = text.index('\n', len(text) // 2) + 1
+    (plain / 'S1.sam').write_text(text)
+    (plain / 'S2.sam').write_text(text[:half])
+    (zipped / 'S1.sam.gz').write_bytes(gzip.compress(text.encode(), 6))
+    (zipped / 'S2.sam.gz').write_bytes(
+        gzip.compress(text[:half // 2].encode(), 1) +
+        gzip.compress(text[half // 2:half].encode(), 9))
+    want, _ = _run(tmp_path, 'p', False, input_fp=str(plain), input_fmt='sam',
+                   **extra)
+    for fmt in ('sam', None):
+        C.ROUTES.clear()
+        got, _ = _run(tmp_path, f'z{fmt}', False, input_fp=str(zipped),
+                      input_fmt=fmt, **extra)
+        assert C.ROUTES.get('dhits' if ordinal else 'dtok', 0) > 0, \
+            dict(C.ROUTES)
+        assert got == want
+    host, _ = _run(tmp_path, 'zh', True, input_fp=str(zipped),
+                   input_fmt='sam', **extra)
+    assert host == want

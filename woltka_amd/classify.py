@@ -318,7 +318,16 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
                 not exclude and part is None and \
                 not os.environ.get('WOLTKA_NO_DTOK'):
             from .align import _parallel_reader
+            from .file import GunzipStream
             reader = _parallel_reader(stream, tok, None)
+            if reader is None and isinstance(stream, GunzipStream):
+                # a gzip file inflated by this package's own decoder: its
+                # blocks go from the inflater's threads straight into the
+                # pinned buffers the device copies from (a line read to
+                # tell the format goes back in front)
+                stream.unread(head)
+                head = b''
+                reader = stream
             if reader is not None:
                 # the text goes to the GPU as it is: tokenised there (with
                 # `dmaps` the read maps are formatted there too)

@@ -124,6 +124,11 @@ class GunzipStream(io.RawIOBase):
             self._buf = memoryview(b'')
         return b''.join(parts)
 
+    def unread(self, data):
+        """Put bytes that were read (a sniffed first line) back in front."""
+        if data:
+            self._buf = memoryview(bytes(data) + bytes(self._buf))
+
     def readable(self):
         return True
 

@@ -183,7 +183,11 @@ class DeviceTextRoute:
         mate bits, reads of more than 16 subjects) are tokenised on the host
         as before.  Yields what `native_chunks` yields."""
         import queue
-        fd, size = reader
+        source = None               # a stream (inflated text) instead of a file
+        if isinstance(reader, tuple):
+            fd, size = reader
+        else:
+            source, fd, size = reader, -1, 0
         tok = self.tok
         if self._reader is None:
             self._reader = nat.Tokenizer(max(2, tokenizer_threads() // 2))
@@ -298,6 +302,118 @@ class DeviceTextRoute:
                     for f in f2:
                         f.result()
                     ring.release(s2)
+
+        def blocks_stream():
+            # The same cut for text that arrives in order from a stream (a gzip
+            # file inflated natively: file.GunzipStream fills a slot with all
+            # its threads, and decodes ahead by itself): one slot is read ahead
+            # on a helper thread while the block before is cut and scanned.
+            from collections import deque
+            from concurrent.futures import ThreadPoolExecutor
+            H = self.DTOK_HEADROOM
+            pool = ThreadPoolExecutor(max_workers=1)
+            pending = deque()
+            state = {'eof': False}
+
+            def fill(mv, want):
+                got = 0
+                while got < want:
+                    k = source.readinto(mv[H + got:H + want])
+                    if not k:
+                        break
+                    got += k
+                return got
+
+            def issue(want, wait):
+                if state['eof']:
+                    return False
+                bufs = ring.current() if wait else ring.try_current()
+                if bufs is None:
+                    return False
+                buf, slot = bufs['text'], ring.take()
+                mv = memoryview(buf).cast('B')
+                pending.append((slot, buf, pool.submit(fill, mv, want), want))
+                return True
+
+            def rest_of(parts, more):
+                """(slow path) everything at hand + `more` bytes of the stream
+                as one array."""
+                while pending:
+                    s2, b2, f2, w2 = pending.popleft()
+                    g2 = f2.result()
+                    parts.append(b2[H:H + g2].tobytes())
+                    ring.release(s2)
+                    if g2 < w2:
+                        state['eof'] = True
+                if more > 0 and not state['eof']:
+                    extra = source.read(more)
+                    parts.append(extra)
+                    if len(extra) < more:
+                        state['eof'] = True
+                return np.frombuffer(b''.join(parts), dtype=np.uint8)
+
+            carry, in_header, first = b'', True, True
+            ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
+            span = ramp or block
+            try:
+                while True:
+                    if not pending and not issue(min(span, block), True):
+                        if not carry:
+                            break
+                        slot, out, final = None, np.frombuffer(
+                            carry, dtype=np.uint8), True
+                    else:
+                        if ramp is None and len(pending) < 2:
+                            issue(block, False)
+                        slot, buf, fut, want = pending.popleft()
+                        t0 = time.perf_counter()
+                        got = fut.result()
+                        lap['read'] += time.perf_counter() - t0
+                        if got < want:
+                            state['eof'] = True
+                        final = state['eof'] and not pending
+                        if len(carry) > H or span > block:
+                            parts = [carry, buf[H:H + got].tobytes()]
+                            ring.release(slot)
+                            slot = None
+                            out = rest_of(parts, span - got)
+                            final = state['eof']
+                        else:
+                            start = H - len(carry)
+                            if carry:
+                                memoryview(buf).cast('B')[start:H] = carry
+                            out = buf[start:H + got]
+                    fill_n = out.size
+                    t0 = time.perf_counter()
+                    ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                        out, final, in_header, self._dfmt)
+                    lap['span'] += time.perf_counter() - t0
+                    if not ok and not final:    # no complete run yet: read more
+                        carry = out.tobytes()
+                        span *= 2
+                        if slot is not None:
+                            ring.release(slot)
+                        continue
+                    if ramp is not None:
+                        ramp = min(block, ramp * 4)
+                        if ramp == block:
+                            tok.warm, ramp = True, None
+                    span = ramp or block
+                    carry = b'' if final else out[stop:].tobytes()
+                    yield slot, out, fill_n, begin, stop, first, final, \
+                        in_header, hdr
+                    in_header, first = hdr, False
+                    if final:
+                        return
+            finally:
+                while pending:
+                    s2, _, f2, _ = pending.popleft()
+                    try:
+                        f2.result()
+                    except Exception:   # noqa: BLE001 - already on its way out
+                        pass
+                    ring.release(s2)
+                pool.shutdown(wait=True)
 
         # The same blocks without a copy on the host: the file mapped read-only
         # and pinned in place piece by piece (wk_host_register), so that the
@@ -460,8 +576,9 @@ class DeviceTextRoute:
         from collections import deque
         ahead = deque()
         t_all = time.perf_counter()
-        whole = open_mapped()
-        it = _prefetch(blocks() if whole is None else blocks_mapped(whole))
+        whole = open_mapped() if source is None else None
+        it = _prefetch(blocks_stream() if source is not None else
+                       blocks() if whole is None else blocks_mapped(whole))
         try:
             while True:
                 t0 = time.perf_counter()

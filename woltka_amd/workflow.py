@@ -372,14 +372,15 @@ def classify(
                                 # coord-match on text that the device tokenises
                                 # (SAM, BLAST tabular, PAF): the join runs
                                 # there too
-                                from .file import ZIP_BY_EXT
+                                from .file import ZIP_BY_EXT, GunzipStream
                                 from os.path import splitext
                                 dstrata = bool(
                                     ordinal and fmt_ in ('sam', 'b6o', 'paf')
                                     and not exclude
                                     and part is None and cover is None and
                                     rank2dir is None and path != '-' and
-                                    ZIP_BY_EXT.get(splitext(path)[1]) is None
+                                    (ZIP_BY_EXT.get(splitext(path)[1]) is None
+                                     or isinstance(stream, GunzipStream))
                                     and not os.environ.get('WOLTKA_NO_DTOK'))
                                 labels = engine.load_strata(
                                     stratmap[sample], zippers,
