@@ -9,11 +9,30 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    with open(os.path.join(ROOT, 'include', 'woltka_hip.h')) as f:
+def declared_in(header):
+    with open(os.path.join(ROOT, 'include', header)) as f:
         text = f.read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(wk_[a-z_0-9]+)\s*\(', text)))
+
+
+def declared_symbols():
+    """The product header and the measurement header together: what the
+    library exports."""
+    return sorted(set(declared_in('woltka_hip.h')) |
+                  set(declared_in('woltka_hip_measure.h')))
+
+
+def test_measurement_entry_points_live_in_their_own_header():
+    """knobs, timers and the benchmark's resident-text passes are
+    not part of the drop-in surface."""
+    product = set(declared_in('woltka_hip.h'))
+    measure = set(declared_in('woltka_hip_measure.h'))
+    assert not product & measure
+    for name in ('wk_tune', 'wk_timer_begin', 'wk_timer_end', 'wk_timer_ms',
+                 'wk_profile_kernels', 'wk_last_kernel_ms'):
+        assert name in measure and name not in product
+    assert 'wk_create' in product and 'wk_classify_chunk' in product
 
 
 def test_header_and_binding_agree():

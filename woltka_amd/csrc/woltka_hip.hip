@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/woltka_hip.h"
+#include "../../include/woltka_hip_measure.h"
 #include "wk_classify.hpp"
 #include "wk_device.hpp"
 #include "wk_dtok.hpp"
