@@ -206,18 +206,16 @@ class LcaWorkload:
     ranks = ('phylum', 'genus', 'species')
     packed = True
 
-    def __init__(self, ctx, seed, scale=1.0):
+    def __init__(self, ctx, seed, scale=1.0, prob=None):
         self.ctx = ctx
-        rng = np.random.default_rng(seed)
         n_reads = int(50_000_000 * scale)
         self.name = (f'synthetic SAM {n_reads / 1e6:g}M reads x <=16 hits, '
                      '2M-node taxonomy, ranks phylum,genus,species; one '
                      'sample, records packed by the tokenizer, appended in '
-                     'chunks of 6M reads, one classify launch per sample')
+                     'chunks of 6M reads (sliced by subject there: outside '
+                     'this pass), one classify launch per sample')
         # (reads are sets of subjects, as the plain parsers produce them)
-        self.prob = p = synth.as_sets(synth.lca_problem(
-            rng, n_nodes=2_000_000, n_subjects=100_000, n_reads=n_reads,
-            with_names=False))
+        self.prob = p = prob if prob is not None else lca_problem(seed, scale)
         h = p['hier']
         ctx.set_tree(h.parent, h.last, h.rank_code)
         self.jobs = []
@@ -517,7 +515,174 @@ def _option_workload(option):
     return make
 
 
+class TextLcaWorkload:
+    """configs[2] as the product runs it: the SAM TEXT of the sample resident
+    in HBM, block by block through the tokenizer on the device (newlines ->
+    lines -> QNAME / FLAG / RNAME -> subject ids -> runs of equal QNAME ->
+    reads -> one packed word per record, by slice of the subject table) and,
+    at the end of the sample, the weighted histogram over the words.  A step =
+    one pass over the whole sample's text = every kernel `woltka classify`
+    launches for it, in the order and with the waits of the product's loop
+    (`Engine._device_chunks` / `_run_dtok`: `wk_dtok_scan_emit` per block of
+    64 MB, `wk_words_flush` per sample); only the host link is left out -- the
+    blocks were uploaded before the clock starts (`wk_text_upload`)."""
+    key = 'lca_text'
+    dominant = 'dtok_emit'
+    families = ('dtok_lines', 'dtok_parse', 'dtok_emit')
+    symbols = {'dtok_lines': 'wk::dtok_count_kernel + wk::tile_scan_kernel + '
+                             'wk::dtok_lines_kernel',
+               'dtok_parse': 'wk::dtok_parse_kernel<false>',
+               'dtok_emit': 'wk::dtok_runs_kernel + wk::dtok_first_kernel + '
+                            'wk::dtok_emit_kernel',
+               'classify': 'wk::weigh_streams_kernel<4>'}
+    ranks = ('phylum', 'genus', 'species')
+    BLOCK = 1 << 26
+
+    def __init__(self, ctx, seed, scale=1.0, workdir=None, prob=None):
+        import mmap
+        self.ctx = ctx
+        n_reads = int(50_000_000 * scale)
+        self.prob = p = prob if prob is not None else lca_problem(seed, scale)
+        h = p['hier']
+        self.reads = min(n_reads, int(p['qoff'].size - 1))
+        self._tmp = tempfile.TemporaryDirectory(dir=workdir)
+        fp = os.path.join(self._tmp.name, 'S1.sam')
+        self.records, self.text_bytes = write_sam_lca(fp, p, self.reads)
+        self.name = (f'synthetic SAM text of {self.reads / 1e6:g}M reads x <=16 '
+                     f'hits ({self.text_bytes / 1e9:.2f} GB) resident in HBM, '
+                     '2M-node taxonomy, ranks phylum,genus,species: device '
+                     'tokenizer per 64 MB block + one weighted histogram per '
+                     'sample (the kernels of `woltka classify`, host link '
+                     'left out)')
+        self._f = open(fp, 'rb')
+        self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        text = np.frombuffer(self._mm, dtype=np.uint8)
+        ctx.set_tree(h.parent, h.last, h.rank_code)
+        self.jobs = []
+        for slot, rank in enumerate(self.ranks):
+            ctx.build_rank_table(slot, h.rank_codes[rank])
+            self.jobs.append(nat.Job(nat.MODE_RANK, slot, 0, 0, 0.0))
+        ctx.counts_reserve(1 << 24)
+        ctx.dtok_format('sam')
+        self.tok = nat.Tokenizer(2)
+        # the blocks as the product's reader cuts them (device_text.
+        # blocks_mapped): 64 MB, ending where the last run of equal QNAMEs
+        # starts
+        self.blocks, pos, in_header = [], 0, True
+        size = text.size
+        while pos < size:
+            span = self.BLOCK
+            while True:
+                end = min(size, pos + span)
+                view = text[pos:end]
+                ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                    view, end >= size, in_header, 'sam')
+                if ok or end >= size:
+                    break
+                span *= 2
+            self.blocks.append((view, begin, stop, hdr))
+            in_header = hdr
+            if end >= size:
+                break
+            pos += stop
+        # first pass, the two-call way (like a file's first blocks): the
+        # subjects are interned, their features go to the device, the job set
+        # is accepted; the blocks stay on the device
+        feats, began = [], False
+        for view, begin, stop, hdr in self.blocks:
+            ctx.text_upload(view, begin, stop)
+            status, n_lines = ctx.dtok_scan(self.tok, view, begin, stop)
+            if status != 0:
+                raise RuntimeError('the device tokenizer refused a block of '
+                                   'the synthetic text')
+            fresh = self.tok.new_subjects()
+            if fresh:
+                feats.extend(int(x[1:]) for x in fresh)     # 'T0001234'
+                ctx.set_subjects(np.asarray(feats, dtype=np.int32))
+                began = False
+            if not began:
+                if not ctx.words_begin(self.jobs, 0):
+                    raise RuntimeError('the job set does not take packed '
+                                       'records')
+                began = True
+            st, n_reads_b, _ = ctx.dtok_emit()
+            if st != 0:
+                raise RuntimeError('the emission of a block was refused')
+            self.tok.set_header_state(hdr)
+        ctx.words_flush()
+        self.n_subjects = len(feats)
+        # the cells of this pass (compared with the packed-words route)
+        keys, vals = ctx.counts_fetch()
+        o = np.argsort(keys, kind='stable')
+        self.first_pass = (keys[o], vals[o])
+        ctx.counts_clear()
+        # text in + one 4-byte word per record out + the pass over the words
+        # (SURVEY 8d's 4 B/record + tables): DESIGN "bytes per record"
+        self.block_bytes = [int(stop - begin) for _, begin, stop, _ in
+                            self.blocks]
+        self.alg_bytes = self.text_bytes + 4 * self.records + (
+            4 * self.records + 8 * h.n_nodes + 3 * 4 * h.n_nodes)
+        self._probe = max(range(len(self.blocks)),
+                          key=lambda i: self.block_bytes[i])
+        rec_per_byte = self.records / max(self.text_bytes, 1)
+        self.launch_bytes = int(self.block_bytes[self._probe] *
+                                (1 + 4 * rec_per_byte))
+
+    def step(self):
+        ctx, tok = self.ctx, self.tok
+        if not ctx.words_begin(self.jobs, 0):
+            raise RuntimeError('words_begin refused')
+        reads = 0
+        for view, begin, stop, hdr in self.blocks:
+            status, _, done = ctx.dtok_scan_emit(tok, view, begin, stop)
+            if status != 0 or done is None:
+                raise RuntimeError('a resident block was refused')
+            reads += done
+            tok.set_header_state(hdr)
+        ctx.words_flush()
+        if reads != self.reads:
+            raise RuntimeError(f'{reads} reads emitted, {self.reads} expected')
+
+    def profile_step(self):
+        """One block (the largest) scanned + emitted, then flushed: the
+        brackets of the three tokenizer families are those of one block."""
+        ctx = self.ctx
+        view, begin, stop, hdr = self.blocks[self._probe]
+        ctx.words_begin(self.jobs, 0)
+        ctx.dtok_scan_emit(self.tok, view, begin, stop)
+        ctx.words_flush()
+
+    def family_bytes(self, family):
+        return self.launch_bytes
+
+    def sync(self):
+        self.ctx.sync()
+
+    def close(self):
+        try:
+            self.ctx.text_clear()
+            self.tok.close()
+        finally:
+            self.blocks = []
+            self._mm.close()
+            self._f.close()
+            self._tmp.cleanup()
+
+    def check(self):
+        keys, vals = self.ctx.counts_fetch()
+        return int(keys.size)
+
+    def cells_equal(self, other_keys, other_vals):
+        """Do the cells of the first pass equal those of another route over
+        the same records (exact integers)?"""
+        o = np.argsort(other_keys, kind='stable')
+        k, v = self.first_pass
+        return bool(np.array_equal(k, other_keys[o]) and
+                    np.array_equal(v, other_vals[o]))
+
+
 WORKLOADS = {'flat': FlatWorkload, 'lca': LcaWorkload,
+             'lca_text': TextLcaWorkload,
              'lca_free': LcaFreeWorkload, 'ordinal': OrdinalWorkload,
              'lca_above': _option_workload('above'),
              'lca_major': _option_workload('major'),
@@ -857,6 +1022,8 @@ def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
                     if isinstance(cold.get(key), float) else None,
                     'phases_s': {k: round(v, 3)
                                  for k, v in sorted(parts.items())}}
+    for key in ('pass1', 'pass2'):
+        e2e_roofline(res[key], device, n_bytes)
     if dig is not None:
         res['digests'] = dig
     if check:
@@ -971,18 +1138,44 @@ def e2e_inputs(kind, d, reads=0, prob=None):
     return meta
 
 
-def gzip_file(fp, level=6):
-    """`fp` -> `fp`.gz (one member, zlib at `level`: what `gzip` / bowtie2's
-    pipe writes), the plain file removed.  Returns the compressed size."""
+def gzip_file(fp, level=6, piece=16 << 20):
+    """`fp` -> `fp`.gz: ONE gzip member holding one deflate stream, as `gzip`
+    writes it, made by all CPUs the way pigz does -- pieces of 16 MB deflated
+    at `level` with the 32 KB before them as dictionary and ended by a sync
+    flush, laid end to end; the plain file is removed.  Returns the
+    compressed size."""
+    import mmap
+    import struct
     import zlib
-    c = zlib.compressobj(level, zlib.DEFLATED, 31)
+    from concurrent.futures import ThreadPoolExecutor
+    from woltka_amd.hostio import cpu_budget
+    size = os.path.getsize(fp)
     with open(fp, 'rb') as src, open(fp + '.gz', 'wb') as dst:
-        while True:
-            blob = src.read(1 << 24)
-            if not blob:
-                break
-            dst.write(c.compress(blob))
-        dst.write(c.flush())
+        dst.write(b'\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03')
+        crc = 0
+        if size:
+            mm = mmap.mmap(src.fileno(), 0, access=mmap.ACCESS_READ)
+            view = memoryview(mm)
+            cuts = list(range(0, size, piece)) + [size]
+
+            def work(i):
+                lo, hi = cuts[i], cuts[i + 1]
+                kw = {'zdict': bytes(view[max(0, lo - 32768):lo])} if lo else {}
+                c = zlib.compressobj(level, zlib.DEFLATED, -15, **kw)
+                body = c.compress(view[lo:hi])
+                body += c.flush(zlib.Z_FINISH if hi == size
+                                else zlib.Z_SYNC_FLUSH)
+                return body
+            with ThreadPoolExecutor(max(1, min(cpu_budget(), 32))) as pool:
+                for body in pool.map(work, range(len(cuts) - 1)):
+                    dst.write(body)
+            for lo in range(0, size, 1 << 28):
+                crc = nat.crc32(view[lo:lo + (1 << 28)], crc)
+            view.release()
+            mm.close()
+        else:
+            dst.write(b'\x03\x00')
+        dst.write(struct.pack('<II', crc, size & 0xFFFFFFFF))
     os.remove(fp)
     return os.path.getsize(fp + '.gz')
 
@@ -1203,6 +1396,12 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
                    for fp in tables)
         same = tables_vs_kernel_path(tables, cells) \
             if cells is not None and frac == 1.0 else None
+        import hashlib
+        digest = {}
+        for fp in tables:
+            with open(fp, 'rb') as f:
+                digest[os.path.basename(fp)] = hashlib.sha256(
+                    f.read()).hexdigest()[:16]
     stream = dt - sum(parts.values())
     what = {'lca': '2M-node nodes.dmp, --rank phylum,genus,species, three '
                    'TSV tables',
@@ -1219,12 +1418,93 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
             'value_streaming': round(n_rec / max(stream, 1e-9), 1),
             'text_generated_s': round(t_gen, 1), 'table_rows': rows,
             'tables_vs_kernel_path': same,
+            'tables_sha256_16': digest,
             'tokenizer_threads': __import__(
                 'woltka_amd.classify', fromlist=['x']).tokenizer_threads(),
             'what': (f'workflow.workflow (= `woltka classify`) from file paths '
                      f'to written tables, SAM text in the page cache: {what}; '
                      'everything inside `seconds` (best of '
                      f'{reps} runs)')}
+
+
+H2D = {}
+
+
+def h2d_peak(device):
+    """Pinned host -> device copy rate of this box (bytes/s), measured once
+    per process the way the text route copies (wk_h2d_rate: 64 MB pieces back
+    to back on a stream of their own)."""
+    if device not in H2D:
+        with nat.Context(device) as c:
+            H2D[device] = max(c.h2d_rate(64 << 20, 48) for _ in range(2))
+    return H2D[device]
+
+
+def e2e_roofline(leg, device, text_bytes=None):
+    """What bounds a whole `woltka classify` call on the text route is the
+    host link: every byte of (inflated) text crosses it once.  achieved = text
+    bytes / the call's wall time, peak = the copy rate measured on this box in
+    this run."""
+    try:
+        peak = h2d_peak(device)
+        nbytes = text_bytes if text_bytes is not None else leg['text_bytes']
+        got = nbytes / leg['seconds']
+        leg['roofline'] = {'bound': 'h2d', 'bytes': nbytes,
+                           'achieved': round(got / 1e9, 2),
+                           'peak': round(peak / 1e9, 2), 'unit': 'GB/s',
+                           'frac': round(got / peak, 4),
+                           'peak_source': 'wk_h2d_rate: pinned 64 MB copies '
+                                          'back to back, this box, this run',
+                           'floor_s': round(nbytes / peak, 3)}
+    except Exception as e:      # noqa: BLE001 - a side figure
+        leg['roofline'] = {'error': repr(e)}
+    return leg
+
+
+def e2e_kind(kind, device, workdir=None, reads=0, reps=3, prob=None):
+    """One more end-to-end leg over inputs `e2e_inputs` knows (lca_gz,
+    lca_gz8, lca_seqqual, flat): the whole `workflow.workflow` call inside one
+    clock, best of `reps`."""
+    from woltka_amd import workflow
+    import shutil
+    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
+        t0 = time.perf_counter()
+        meta = e2e_inputs(kind, tmp, reads, prob=prob)
+        t_gen = time.perf_counter() - t0
+        kw = meta['kwargs']
+        ph = Phases()
+        try:
+            best = None
+            for _ in range(reps):
+                ph.t = {}
+                out = kw['output_fp']
+                if os.path.isdir(out):
+                    shutil.rmtree(out)
+                t0 = time.perf_counter()
+                quiet(workflow.workflow, device=device, **kw)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, dict(ph.t))
+        finally:
+            ph.close()
+        out = kw['output_fp']
+        tables = [os.path.join(out, x) for x in sorted(os.listdir(out))] \
+            if os.path.isdir(out) else [out]
+        digest = {}
+        import hashlib
+        for fp in tables:
+            with open(fp, 'rb') as f:
+                digest[os.path.basename(fp)] = hashlib.sha256(
+                    f.read()).hexdigest()[:16]
+    dt, parts = best
+    leg = {'value': round(meta['records'] / dt, 1), 'unit': 'records/s',
+           'records': meta['records'], 'reads': meta['reads'],
+           'text_bytes': meta['text_bytes'], 'seconds': round(dt, 3),
+           'phases_s': {k: round(v, 3) for k, v in sorted(parts.items())},
+           'text_generated_s': round(t_gen, 1), 'tables_sha256_16': digest}
+    if 'gz_bytes' in meta:
+        leg['gz_bytes'] = meta['gz_bytes']
+    return e2e_roofline(leg, device)
 
 
 # --------------------------------------------------------------------------
@@ -1357,6 +1637,10 @@ class NoSync:
     def allmax(self, x):
         return x
 
+    def gather(self, x):
+        """Every rank's number, in rank order, on every rank."""
+        return [x]
+
     def close(self):
         pass
 
@@ -1379,6 +1663,13 @@ class TorchSync(NoSync):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t[0])
 
+    def gather(self, x):
+        import torch
+        out = [torch.zeros(1, dtype=torch.float64)
+               for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(out, torch.tensor([x], dtype=torch.float64))
+        return [float(t[0]) for t in out]
+
     def close(self):
         self.dist.destroy_process_group()
 
@@ -1399,6 +1690,45 @@ class MpSync(NoSync):
         m = max(self.shared[:])
         self.bar.wait()
         return m
+
+    def gather(self, x):
+        self.shared[self.rank] = x
+        self.bar.wait()
+        out = list(self.shared[:])
+        self.bar.wait()
+        return out
+
+
+def pci_number(bus_id):
+    """'0000:05:00.0' -> an integer (domain, bus, device, function), 0 when
+    the text is anything else."""
+    import re
+    m = re.fullmatch(r'([0-9a-fA-F]+):([0-9a-fA-F]+):([0-9a-fA-F]+)\.([0-7])',
+                     bus_id.strip())
+    if not m:
+        return 0
+    d, b, v, f = (int(x, 16) for x in m.groups())
+    return (d << 16) | (b << 8) | (v << 3) | f
+
+
+def pci_text(num):
+    num = int(num)
+    return '%04x:%02x:%02x.%d' % (num >> 16, (num >> 8) & 0xFF,
+                                  (num >> 3) & 0x1F, num & 7)
+
+
+def rank_devices(dev, sync):
+    """The PCI addresses of every rank's device (rank order) and the number of
+    distinct devices among them: what `n_gpus` may claim."""
+    try:
+        mine = pci_number(nat.device_pci_bus_id(dev))
+    except Exception:       # noqa: BLE001 - reported as unknown
+        mine = 0
+    nums = sync.gather(float(mine))
+    names = [pci_text(x) if x else 'unknown' for x in nums]
+    known = [x for x in nums if x]
+    distinct = len(set(known)) + (len(nums) - len(known))
+    return names, distinct
 
 
 def timed_steps(wl, steps, warmup, passes, sync):
@@ -1515,13 +1845,33 @@ def passes_for(wl, steps, target_s=1.25):
 def run_rank(a, rank, world, local, sync):
     # one process per GPU; a launcher that narrows the visible devices to one
     # per process leaves a single device 0
-    dev = local % max(nat.device_count(), 1)
+    n_dev = max(nat.device_count(), 1)
+    if world > n_dev and not a.oversubscribe:      # (every rank: none is left waiting)
+        # (a SCALE line must not be able to claim GPUs that are not there:
+        # ranks stacked on one device only on request)
+        raise SystemExit(f'bench: {world} ranks but {n_dev} visible device(s) '
+                         f'(rank {rank}); pass --oversubscribe to stack ranks '
+                         'on a device')
+    dev = local % n_dev
     ctx = nat.Context(dev)
+    devices, n_distinct = rank_devices(dev, sync)
     for kv in a.opt:
         name, _, value = kv.partition('=')
         ctx.tune(name, int(value))
     # one sample set per GPU: different seed per rank, same shape (weak scaling)
-    wl = WORKLOADS[a.workload](ctx, seed=1002 + rank, scale=a.scale)
+    if a.workload == 'lca_text':
+        # (every rank holds its sample's text in the work directory and the
+        # packed problem in memory: a host that cannot hold `world` of them
+        # gets a smaller sample, the same on every rank, and the line says so)
+        fit = e2e_scale_for(world, a.scale, per_rank_bytes=30e9,
+                            workdir=a.tmp) if world > 1 else a.scale
+        if world > 1:
+            fit = -sync.allmax(-fit)
+        a.scale = fit
+        wl = TextLcaWorkload(ctx, seed=1002 + rank, scale=a.scale,
+                             workdir=a.tmp)
+    else:
+        wl = WORKLOADS[a.workload](ctx, seed=1002 + rank, scale=a.scale)
     wl.sync()
     passes = a.passes or passes_for(wl, a.steps)
     if world > 1:                   # every rank the same number of passes
@@ -1529,7 +1879,8 @@ def run_rank(a, rank, world, local, sync):
     elapsed = timed_steps(wl, a.steps, a.warmup, passes, sync)
     checksum = wl.check()
     if rank != 0:
-        if not (a.headline_only or a.no_e2e) and a.workload == 'lca':
+        if not (a.headline_only or a.no_e2e) and a.workload in ('lca',
+                                                                 'lca_text'):
             e2e_ranks(a, None, wl, dev, world, sync)
         wl.close()
         ctx.close()
@@ -1541,21 +1892,27 @@ def run_rank(a, rank, world, local, sync):
         'metric': 'alignment records/sec classified',
         'value': round(value, 1),
         'unit': 'records/s',
-        'n_gpus': world,
+        # (distinct devices among the ranks: ranks stacked on one device --
+        # `--oversubscribe` -- do not count as GPUs)
+        'n_gpus': n_distinct,
+        'ranks': world,
+        'rank_devices': devices,
+        'oversubscribed': n_distinct < world,
         'steps': a.steps,
         'warmup': a.warmup,
         'ms_per_step': round(ms_per_step, 4),
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'int32',
+        'dtype': 'u8' if a.workload == 'lca_text' else 'int32',
         'data': 'synthetic',
         'config': {'workload': wl.name, 'records_per_gpu': wl.records,
                    'reads_per_gpu': wl.reads, 'scale': a.scale,
                    'passes_per_step': passes,
                    'ms_per_pass': block['ms_per_pass'],
                    'timed_region_s': round(elapsed, 3),
-                   'sharding': f'samples x {world} GPUs, no collective'},
+                   'sharding': f'samples x {world} ranks on {n_distinct} '
+                               'GPU(s), no collective'},
         'roofline': block['roofline'],
         'device': ctx.device_name,
         'checksum': checksum,
@@ -1565,7 +1922,7 @@ def run_rank(a, rank, world, local, sync):
         ctx.close()
         return line
     if world > 1:
-        if not a.no_e2e and a.workload == 'lca':
+        if not a.no_e2e and a.workload in ('lca', 'lca_text'):
             e2e_ranks(a, line, wl, dev, world, sync)
         wl.close()
         ctx.close()
@@ -1592,11 +1949,42 @@ def side_blocks(a, line, wl, ctx, dev):
     """N = 1: the other configurations, the end-to-end legs and the CPU
     baseline, added to the headline's JSON line."""
     configs, e2e = {}, {}
+    if a.workload == 'lca_text':
+        # the same records as packed words (the host-tokenizer route's hand-
+        # over, and what the per-read blocks below classify): the weighted
+        # histogram alone over resident, sliced records -- round 4's headline
+        prob, first_pass = wl.prob, wl.first_pass
+        text_cells_equal = None
+        wl.close()
+        wl = LcaWorkload(ctx, 1002, a.scale, prob=prob)
+        wl.sync()
+        try:
+            ctx.counts_clear()
+            wl.step()
+            k2, v2 = ctx.counts_fetch()
+            o = np.argsort(k2, kind='stable')
+            text_cells_equal = bool(np.array_equal(first_pass[0], k2[o]) and
+                                    np.array_equal(first_pass[1], v2[o]))
+            ctx.counts_clear()
+            p2 = passes_for(wl, a.steps, 0.5)
+            t = timed_steps(wl, a.steps, 1, p2, NoSync())
+            configs['lca'] = config_block(wl, t, p2, a.steps, a.scale, 'lca')
+            configs['lca']['note'] = (
+                'the histogram over records that are resident and sliced by '
+                'subject already; the slicing happens where the records are '
+                'made (dtok_emit on the device-text route = the headline; '
+                'words_partition_kernel at wk_words_append on the host-words '
+                'route) and is not inside this pass')
+        except Exception as e:
+            configs['lca'] = {'error': repr(e)}
+        line['cells_equal_words_route'] = text_cells_equal
+        del first_pass
     # (one pass of the headline's kernel path, fetched: what the end-to-end
     # leg's tables are compared with — before the blocks below stage other
     # jobs over the same context)
-    cells = kernel_cells(wl) if a.workload == 'lca' and not a.no_e2e else None
-    if a.workload == 'lca':
+    cells = kernel_cells(wl) if a.workload in ('lca', 'lca_text') and \
+        not a.no_e2e else None
+    if a.workload in ('lca', 'lca_text'):
         try:
             free = LcaFreeWorkload(ctx, 0, a.scale, share=wl)
             p2 = passes_for(free, a.steps, 0.5)
@@ -1623,6 +2011,32 @@ def side_blocks(a, line, wl, ctx, dev):
                                      workdir=a.tmp, cells=cells)
             except Exception as e:
                 e2e['lca'] = {'error': repr(e)}
+            if 'error' not in e2e['lca']:
+                e2e_roofline(e2e['lca'], dev)
+            # the same records as the inputs people have: one / eight gzip
+            # files (inflated natively, csrc/wk_inflate.cpp), and SAM lines
+            # that carry 150 bases of SEQ and QUAL
+            for kind, kw in (('lca_gz', {}), ('lca_gz8', {}),
+                             ('lca_seqqual', {'reps': 2})):
+                try:
+                    frac = e2e_scale_for(
+                        1, a.e2e_frac, workdir=a.tmp,
+                        per_rank_bytes=95e9 if kind == 'lca_seqqual' else 14e9)
+                    n = max(1000, int(wl.reads * frac))
+                    if kind == 'lca_seqqual':
+                        # (350 B per line: a fifth of the reads is 17 GB of text)
+                        n = min(n, max(1000, wl.reads // 5))
+                    e2e[kind] = e2e_kind(kind, dev, a.tmp, reads=n,
+                                         prob=wl.prob, **kw)
+                    e2e[kind]['frac_of_config'] = frac
+                    if kind.startswith('lca_gz') and \
+                            'error' not in e2e['lca'] and frac == 1.0:
+                        e2e[kind]['tables_equal_plain_run'] = (
+                            e2e[kind]['tables_sha256_16'] ==
+                            e2e['lca'].get('tables_sha256_16')) \
+                            if kind == 'lca_gz' else None
+                except Exception as e:
+                    e2e[kind] = {'error': repr(e)}
     if not a.no_cpu:
         try:
             line['cpu_baseline'] = cpu_baseline(wl, workdir=a.tmp)
@@ -1657,10 +2071,12 @@ def side_blocks(a, line, wl, ctx, dev):
                         workdir=a.tmp, cells=cells2)
                 except Exception as e:
                     e2e['ordinal'] = {'error': repr(e)}
+                if 'error' not in e2e['ordinal']:
+                    e2e_roofline(e2e['ordinal'], dev)
             del prob
         except Exception as e:
             configs[key] = {'error': repr(e)}
-    if not a.no_e2e and a.workload == 'lca':
+    if not a.no_e2e and a.workload in ('lca', 'lca_text'):
         # BASELINE configs[4] on one GPU's share: 8 samples x 20 M reads, both
         # calls of the stratified recipe (memory permitting: ~45 GB of text
         # and maps at full size)
@@ -1672,6 +2088,13 @@ def side_blocks(a, line, wl, ctx, dev):
                 workdir=a.tmp, reps=2, check=True)
         except Exception as e:
             e2e['twopass'] = {'error': repr(e)}
+    if not a.no_e2e and a.workload in ('lca', 'lca_text'):
+        # BASELINE configs[1] end to end: 10 M reads x 1 hit, flat map
+        try:
+            e2e['flat'] = e2e_kind('flat', dev, a.tmp,
+                                   reads=max(1000, int(10_000_000 * a.scale)))
+        except Exception as e:
+            e2e['flat'] = {'error': repr(e)}
     line['configs'] = configs
     if e2e:
         line['e2e'] = e2e
@@ -1734,6 +2157,10 @@ def spawn_local(a):
     import multiprocessing as mp
     mpc = mp.get_context('spawn')
     world = a.gpus
+    n_dev = max(nat.device_count(), 1)
+    if world > n_dev and not a.oversubscribe:
+        raise SystemExit(f'bench: --gpus {world} but {n_dev} visible device(s); '
+                         'pass --oversubscribe to stack ranks on a device')
     bar = mpc.Barrier(world)
     shared = mpc.Array('d', world)
     procs, conns = [], []
@@ -1765,7 +2192,8 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='lca')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS),
+                    default='lca_text')
     ap.add_argument('--scale', type=float, default=1.0,
                     help='fraction of the named workload size (default: full)')
     ap.add_argument('--passes', type=int, default=0,
@@ -1774,6 +2202,10 @@ def parse_args(argv=None):
     ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE',
                     help='wk_tune knob (measurement; results never '
                          'depend on them)')
+    ap.add_argument('--oversubscribe', action='store_true',
+                    help='let --gpus N exceed the visible devices (ranks are '
+                         'stacked; the line then reports n_gpus = distinct '
+                         'devices and oversubscribed = true)')
     ap.add_argument('--no-cpu', action='store_true',
                     help='skip the CPU baseline leg')
     ap.add_argument('--no-e2e', action='store_true',

@@ -65,6 +65,18 @@ int wk_timer_ms(wk_ctx* ctx, double* ms);
 int wk_profile_kernels(wk_ctx* ctx, int enable);
 int wk_last_kernel_ms(wk_ctx* ctx, const char* family, double* ms);
 
+/* Resident text: text[begin, stop) -- a block as the host cuts it for
+ * wk_dtok_scan -- is copied to the device and stays there; a later scan of the
+ * same bytes copies nothing.  bench.py times the device side of the text route
+ * this way (every kernel a block goes through, inputs in HBM when the clock
+ * starts).  wk_text_clear frees the blocks. */
+int wk_text_upload(wk_ctx* ctx, const char* text, int64_t begin, int64_t stop);
+int wk_text_clear(wk_ctx* ctx);
+/* The rate (bytes/s) of `reps` pinned host -> device copies of `bytes` each,
+ * back to back on a stream of their own: the bound of the end-to-end text
+ * route on this box (bench.py's e2e rooflines are quoted against it). */
+int wk_h2d_rate(wk_ctx* ctx, int64_t bytes, int reps, double* bytes_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,7 +70,8 @@ SYMBOLS = (
     'wk_coords_parse', 'wk_coords_error', 'wk_coords_sizes',
     'wk_coords_fetch', 'wk_coords_free',
     'wk_gz_bound', 'wk_gz_member', 'wk_crc32', 'wk_gz_inflate_members',
-    'wk_gunzip_open', 'wk_gunzip_read', 'wk_gunzip_error', 'wk_gunzip_close')
+    'wk_gunzip_open', 'wk_gunzip_read', 'wk_gunzip_error', 'wk_gunzip_close',
+    'wk_text_upload', 'wk_text_clear', 'wk_h2d_rate')
 
 
 class Job(C.Structure):
@@ -262,6 +263,10 @@ def load_library():
         'wk_gunzip_read': (C.c_int64, [p, C.c_void_p, C.c_int64]),
         'wk_gunzip_error': (C.c_char_p, [p]),
         'wk_gunzip_close': (None, [p]),
+        'wk_text_upload': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64]),
+        'wk_text_clear': (C.c_int, [p]),
+        'wk_h2d_rate': (C.c_int, [p, C.c_int64, C.c_int,
+                                  C.POINTER(C.c_double)]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)
@@ -597,6 +602,25 @@ class Context:
             self._h, tok._h, addr, int(begin), int(stop), C.byref(n),
             C.byref(st), C.byref(em), C.byref(a), C.byref(b)))
         return st.value, n.value, (a.value if em.value else None)
+
+    def text_upload(self, buf, begin, stop):
+        """(measurement) ``buf[begin:stop]`` -- a block as the host cuts it --
+        to the device, to stay: a later scan of the same bytes copies
+        nothing (``wk_text_upload``)."""
+        raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+        self._check(self._lib.wk_text_upload(
+            self._h, C.c_void_p(raw.ctypes.data), int(begin), int(stop)))
+
+    def text_clear(self):
+        self._check(self._lib.wk_text_clear(self._h))
+
+    def h2d_rate(self, nbytes=64 << 20, reps=32):
+        """(measurement) bytes/s of pinned host -> device copies of
+        ``nbytes`` each on this box (``wk_h2d_rate``)."""
+        out = C.c_double(0.0)
+        self._check(self._lib.wk_h2d_rate(self._h, int(nbytes), int(reps),
+                                          C.byref(out)))
+        return out.value
 
     def dtok_format(self, fmt):
         """Format of the blocks ``dtok_scan`` is given from now on: 'sam',

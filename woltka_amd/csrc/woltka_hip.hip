@@ -250,6 +250,17 @@ struct wk_ctx {
     DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
+    // measurement (woltka_hip_measure.h): blocks of text that are resident on the device already
+    // (wk_text_upload) -- the scan of such a block copies nothing
+    struct ResidentText {
+        const char* host;
+        uint32_t n;
+        unsigned char* dev;
+        unsigned long long* tile_off;  // the block's newline offsets per tile, counted at upload
+        unsigned long long n_newlines;
+    };
+    std::vector<ResidentText> resident;
+    const unsigned char* dt_text = nullptr;  // the text of the block scanned last
     int dt_fmt = 0;   // WK_FMT_* of the blocks (wk_dtok_format)
     uint32_t dt_n = 0, dt_lines = 0, dt_dict_mask = 0;
     int32_t dt_dict_names = -1;  // names of the tokenizer the mirror holds
@@ -869,6 +880,11 @@ void wk_destroy(wk_ctx* c) {
     for (DevBuf* b : {&c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
                       &c->d_state, &c->d_dict, &c->d_arena})
         b->release();
+    for (wk_ctx::ResidentText& r : c->resident) {
+        (void)hipFree(r.dev);
+        (void)hipFree(r.tile_off);
+    }
+    c->resident.clear();
     for (void* hp : c->host_blocks) (void)hipHostFree(hp);
     for (const wk_ctx::HostReg& r : c->regs) (void)hipHostUnregister(const_cast<char*>(r.p));
     c->regs.clear();
@@ -2385,7 +2401,7 @@ static int dtok_mirror_dict(wk_ctx* c, const wk_tok* tok) {
 
 static DtokArgs dtok_args(wk_ctx* c) {
     DtokArgs a{};
-    a.text = c->d_textbuf[c->dt_cur].as<unsigned char>();
+    a.text = c->dt_text;
     a.n = c->dt_n;
     a.fmt = (uint32_t)c->dt_fmt;
     a.line_start = c->d_lines.as<uint32_t>();
@@ -2501,6 +2517,90 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     return WK_OK;
 }
 
+// (measurement) text[begin, stop) to the device, to stay: a later wk_dtok_scan / wk_dtok_scan_emit of the same
+// bytes finds them there and copies nothing.
+int wk_text_upload(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
+    if (!c || !text || begin < 0 || stop <= begin || stop - begin >= (1ll << 31) - 64) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    const uint32_t n = (uint32_t)(stop - begin);
+    const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
+    wk_ctx::ResidentText r{};
+    r.host = text + begin;
+    r.n = n;
+    void *dev = nullptr, *tiles = nullptr, *off = nullptr;
+    HIP_TRY(c, hipMalloc(&dev, (size_t)n + 64));
+    HIP_TRY(c, hipMalloc(&tiles, (size_t)n_tiles * 8));
+    HIP_TRY(c, hipMalloc(&off, (size_t)n_tiles * 8));
+    HIP_TRY(c, hipMemcpyAsync(dev, r.host, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync((char*)dev + n, 0, 64, c->stream));
+    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+    hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, (const unsigned char*)dev, n,
+                       (unsigned long long*)tiles);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)tiles, (unsigned long long*)off,
+                       (int64_t)n_tiles, scalar_u64(c, 3));
+    HIP_TRY(c, hipMemcpyAsync(&r.n_newlines, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(tiles);
+    r.dev = (unsigned char*)dev;
+    r.tile_off = (unsigned long long*)off;
+    c->resident.push_back(r);
+    return WK_OK;
+}
+
+// (measurement) the rate of pinned host -> device copies of `bytes` each on this box, the way the text
+// route makes them (hipMemcpyAsync from pinned memory on a stream of their own): bytes per second over
+// `reps` copies back to back, timed with events.
+int wk_h2d_rate(wk_ctx* c, int64_t bytes, int reps, double* bytes_per_s) {
+    if (!c || bytes <= 0 || reps <= 0 || !bytes_per_s) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    void *h[2] = {nullptr, nullptr}, *d[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            if (h[i]) (void)hipHostFree(h[i]);
+            if (d[i]) (void)hipFree(d[i]);
+        }
+        if (st) (void)hipStreamDestroy(st);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc(&h[i], (size_t)bytes, hipHostMallocDefault);
+        if (e == hipSuccess) std::memset(h[i], 0x41 + i, (size_t)bytes);
+        if (e == hipSuccess) e = hipMalloc(&d[i], (size_t)bytes);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMemcpyAsync(d[i], h[i], (size_t)bytes, hipMemcpyHostToDevice, st);  // warm
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (int i = 0; i < reps && e == hipSuccess; ++i) e = hipMemcpyAsync(d[i & 1], h[i & 1], (size_t)bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    cleanup();
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, WK_E_HIP, "wk_h2d_rate: %s", hipGetErrorString(e));
+    }
+    *bytes_per_s = ms > 0.f ? (double)bytes * reps / (ms * 1e-3) : 0.0;
+    return WK_OK;
+}
+
+int wk_text_clear(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    for (wk_ctx::ResidentText& r : c->resident) {
+        (void)hipFree(r.dev);
+        (void)hipFree(r.tile_off);
+    }
+    c->resident.clear();
+    return WK_OK;
+}
+
 int wk_dtok_format(wk_ctx* c, int fmt) {
     if (!c) return WK_E_ARG;
     if (fmt != WK_FMT_SAM && fmt != WK_FMT_MAP && fmt != WK_FMT_B6O && fmt != WK_FMT_PAF)
@@ -2543,9 +2643,18 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     // the block's text: copied ahead by wk_dtok_copy (then the kernels only wait
     // for that copy), or copied now
     int k = -1;
-    for (int q = 0; q < wk_ctx::kTextBufs; ++q)
+    const unsigned char* resident = nullptr;
+    const wk_ctx::ResidentText* res = nullptr;
+    for (const wk_ctx::ResidentText& r : c->resident)
+        if (r.host == src && r.n == n) {
+            resident = r.dev;
+            res = &r;
+        }
+    for (int q = 0; q < wk_ctx::kTextBufs && !resident; ++q)
         if (c->copy_src[q] == src && c->copy_n[q] == n) k = q;
-    if (k >= 0) {
+    if (resident) {
+        // (measurement: the block is on the device already, 64 zero bytes behind it)
+    } else if (k >= 0) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));
         HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
     } else {
@@ -2557,17 +2666,31 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
     }
-    const bool counted = c->copy_src[k] == src && c->copy_counted[k];
-    c->copy_src[k] = nullptr;  // (the buffer's tag is used up)
-    c->copy_counted[k] = false;
-    c->dt_cur = k;
+    const bool counted = !resident && c->copy_src[k] == src && c->copy_counted[k];
+    if (!resident) {
+        c->copy_src[k] = nullptr;  // (the buffer's tag is used up)
+        c->copy_counted[k] = false;
+        c->dt_cur = k;
+    }
+    c->dt_text = resident ? resident : c->d_textbuf[k].as<unsigned char>();
     // line starts: newlines per tile -> offsets -> positions
     const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
     HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
     KernelTimer* kt = ktimer_begin(c, "dtok_lines");
     unsigned long long n_newlines = 0;
     const unsigned long long* tile_off = nullptr;
-    if (counted) {  // (counted behind the copy: the number is on the host once the copy's event has passed)
+    if (res) {
+        // (the product counts a block's newlines behind its copy and never waits for them; here the
+        // same two kernels run in front of the scan, their result was taken at upload)
+        HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
+        HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
+        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
+                           c->d_tiles.as<unsigned long long>());
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
+                           c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+        n_newlines = res->n_newlines;
+        tile_off = res->tile_off;
+    } else if (counted) {  // (counted behind the copy: the number is on the host once the copy's event has passed)
         {
             Lap wait(&c->lap_s[3]);
             HIP_TRY(c, hipEventSynchronize(c->copy_ev[k]));
@@ -2578,7 +2701,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
         HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
-        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
+        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
                            c->d_tiles.as<unsigned long long>());
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
                            c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
@@ -2601,7 +2724,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     }
     if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
     HIP_TRY(c, hipMemsetAsync(c->d_lines.p, 0, 4, c->stream));  // line 0 starts at 0
-    hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->d_textbuf[k].as<unsigned char>(), n,
+    hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
                        tile_off, c->d_lines.as<uint32_t>());
     if (open_end) {
         const uint32_t end = n + 1;  // as if a newline followed the text
