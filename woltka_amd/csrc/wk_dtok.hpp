@@ -79,6 +79,7 @@ struct DtokArgs {
     uint32_t* out;      // packed records
     uint32_t out_cap;
     StreamSet streams;  // (weighted histogram: the records by slice of the subject table, wk_weigh.hpp)
+    unsigned long long* cursor_backup;  // [kMaxStreams] the streams' cursors before this block's emission (or null)
     // "ex" flavour (coord-match): per line POS - 1, reference end, aligned length
     int32_t* lbeg;
     int32_t* lend;
@@ -110,6 +111,9 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_count_kernel(const unsigned
                                                                  unsigned long long* __restrict__ tile_count) {
     __shared__ uint32_t wsum[kDtokThreads / kWave];
     const uint32_t tile = blockIdx.x;
+    // (the 64 bytes behind the text are zeroed here, by the last tile: no fill launch per block.  The
+    // kernels that look behind `n` -- vector loads of a line's tail -- run behind this one on the stream)
+    if (tile == gridDim.x - 1u && threadIdx.x < 64u) const_cast<unsigned char*>(text)[n + threadIdx.x] = 0;
     const uint32_t p = tile * kDtokTile + threadIdx.x * 16u;
     uint32_t c = 0;
     if (p + 16u <= n) {
@@ -131,30 +135,54 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_count_kernel(const unsigned
 // written by the host side); tile_off = exclusive scan of tile_count
 __global__ void __launch_bounds__(kDtokThreads) dtok_lines_kernel(const unsigned char* __restrict__ text, uint32_t n,
                                                                  const unsigned long long* __restrict__ tile_off,
-                                                                 uint32_t* __restrict__ line_start) {
-    __shared__ uint32_t scan[kDtokThreads];
+                                                                 uint32_t* __restrict__ line_start, DtokState* state = nullptr) {
+    __shared__ uint32_t wtot[kDtokThreads / kWave];
     const uint32_t tile = blockIdx.x;
+    if (tile == 0u && threadIdx.x == 0u) {
+        line_start[0] = 0u;  // line 0 starts at 0
+        if (state) *state = DtokState{0u, 0u, 0ull, 0ull};  // (the block's scalars, for the first parse)
+    }
     const uint32_t p = tile * kDtokTile + threadIdx.x * 16u;
-    unsigned char b[16];
-    uint32_t c = 0;
+    // (16 aligned bytes in one load: the text has 64 zero bytes behind it, so a load that starts inside it never
+    // leaves the buffer, and what lies behind `n` is no newline)
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (p < n) v = *reinterpret_cast<const uint4*>(text + p);
+    auto marks = [](uint32_t w) {  // 0x80 in every byte that is '\n'
+        const uint32_t x = w ^ 0x0A0A0A0Au;
+        return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+    };
+    uint32_t z[4] = {marks(v.x), marks(v.y), marks(v.z), marks(v.w)};
+    if (p + 16u > n) {  // the block's last bytes: nothing behind n counts (the pad is zero, but be exact)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        b[i] = (p + (uint32_t)i < n) ? text[p + (uint32_t)i] : (unsigned char)0;
-        c += b[i] == '\n';
+        for (uint32_t w = 0; w < 4; ++w)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (p + 4u * w + k >= n) z[w] &= ~(0x80u << (8u * k));
     }
-    scan[threadIdx.x] = c;
+    const uint32_t c = (uint32_t)(__popc(z[0]) + __popc(z[1]) + __popc(z[2]) + __popc(z[3]));
+    // inclusive scan: shuffles inside the wave, the waves' totals through LDS (one barrier)
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t inc = c;
+#pragma unroll
+    for (uint32_t d = 1; d < kWave; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, kWave);
+        if (lane >= d) inc += up;
+    }
+    if (lane == kWave - 1) wtot[wave] = inc;
     __syncthreads();
-    // inclusive scan over the workgroup (Hillis-Steele: 8 steps of 256 threads)
-    for (uint32_t d = 1; d < kDtokThreads; d <<= 1) {
-        const uint32_t v = threadIdx.x >= d ? scan[threadIdx.x - d] : 0u;
-        __syncthreads();
-        scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t at = (uint32_t)tile_off[tile] + scan[threadIdx.x] - c + 1u;  // (+1: line 0 starts at 0)
+    uint32_t before = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (b[i] == '\n') line_start[at++] = p + (uint32_t)i + 1u;
+    for (uint32_t w = 0; w < kDtokThreads / kWave; ++w) before += w < wave ? wtot[w] : 0u;
+    uint32_t at = (uint32_t)tile_off[tile] + before + inc - c + 1u;  // (+1: line 0 starts at 0)
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        uint32_t m = z[w];
+        while (m) {
+            const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;  // 7, 15, 23 or 31
+            line_start[at++] = p + 4u * w + (bit >> 3) + 1u;
+            m &= m - 1u;
+        }
+    }
 }
 
 // the host's hash of a name (wkh::hash_bytes), byte for byte
@@ -314,8 +342,36 @@ __device__ inline void dtok_row_ex(const DtokArgs& a, uint32_t i, uint32_t lo, u
 // (align.parse_paf_file, align.py:984-1045: `qname, _, _, _, _, tname, _ =
 // line.split('\t', 6)`, lines of fewer than seven fields ignored); an ignored line
 // does not end a run of equal queries, like an unmapped SAM record.
+// The text of a workgroup's lines staged in LDS: the 256 lines of a workgroup are one contiguous piece
+// of text (10 KB of trimmed SAM), loaded with coalesced 16-byte loads; the threads then walk their lines
+// byte by byte in LDS instead of issuing a global load per byte and lane (64 lanes x 42-byte stride: one
+// cache line per lane and instruction).  Returns the pointer to index with ABSOLUTE text positions
+// (the stage shifted back by the piece's start), or the global text when the piece does not fit.
+constexpr uint32_t kDtokStage = 24 * 1024;
+__device__ __forceinline__ const unsigned char* dtok_stage_lines(const DtokArgs& a, unsigned char* stage, uint32_t first_line, uint32_t end_line,
+                                                                 uint32_t* lo_out) {
+    // (uniform over the workgroup: every thread calls this, there is a barrier inside)
+    const uint32_t lo = a.line_start[first_line] & ~15u;
+    uint32_t hi = a.line_start[end_line];
+    hi = hi > a.n ? a.n : hi;
+    *lo_out = lo;
+    if (hi <= lo || hi - lo > kDtokStage - 16u) return nullptr;
+    for (uint32_t off = threadIdx.x * 16u; off < hi - lo; off += kDtokThreads * 16u)
+        *reinterpret_cast<uint4*>(stage + off) = *reinterpret_cast<const uint4*>(a.text + lo + off);  // (16 bytes may pass `hi`: the text's pad)
+    __syncthreads();
+    return stage - lo;
+}
+
 template <bool kEx>
 __global__ void __launch_bounds__(kDtokThreads) dtok_parse_kernel(DtokArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kDtokStage];
+    {
+        const uint32_t i0 = blockIdx.x * blockDim.x;
+        const uint32_t i1 = min(i0 + blockDim.x, a.n_lines);
+        uint32_t lo0;
+        const unsigned char* staged = i0 < i1 ? dtok_stage_lines(a, stage, i0, i1, &lo0) : nullptr;
+        if (staged) a.text = staged;  // (positions stay absolute: the unknown subjects' offsets, the lines' ends)
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_lines) return;
     const uint32_t lo = a.line_start[i];
@@ -576,6 +632,19 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_place_kernel(DtokArgs a, St
 // with the previous *mapped* line: unmapped records do not split a run.)
 __global__ void __launch_bounds__(kDtokThreads) dtok_runs_kernel(DtokArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (a block the kernels give up on must leave the streams as they were: their cursors are put aside
+    // here, in front of the emission on the same stream)
+    if (a.cursor_backup && blockIdx.x == 0u && threadIdx.x < (uint32_t)kMaxStreams) a.cursor_backup[threadIdx.x] = a.streams.cursor[threadIdx.x];
+    // the workgroup's lines and the line before them staged in LDS (dtok_stage_lines): the QNAMEs compared are
+    // those of neighbouring lines
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kDtokStage];
+    const unsigned char* staged = nullptr;
+    uint32_t lo0 = 0;
+    {
+        const uint32_t i0 = blockIdx.x * blockDim.x;
+        const uint32_t i1 = min(i0 + blockDim.x, a.n_lines);
+        if (i0 < i1) staged = dtok_stage_lines(a, stage, i0 > 0u ? i0 - 1u : 0u, i1, &lo0);
+    }
     if (i >= a.n_lines) return;
     unsigned char start = 0;
     if (a.lsubj[i] >= 0) {
@@ -586,8 +655,9 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_runs_kernel(DtokArgs a) {
         } else {
             const uint32_t qn = a.lmeta[i] & 0x0FFFFFFFu, pn = a.lmeta[j] & 0x0FFFFFFFu;
             bool same = qn == pn;
-            const unsigned char* x = a.text + a.line_start[i];
-            const unsigned char* y = a.text + a.line_start[j];
+            const uint32_t ls = a.line_start[i], ps = a.line_start[j];
+            const unsigned char* x = (staged ? staged : a.text) + ls;
+            const unsigned char* y = (staged && ps >= lo0 ? staged : a.text) + ps;  // (a line further back: from the text itself)
             for (uint32_t k = 0; same && k < qn; ++k) same = x[k] == y[k];
             start = same ? 0 : 1;
         }
@@ -625,49 +695,58 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_first_kernel(DtokArgs a) {
 // them — and go out as packed words, appended in no particular order (the
 // histogram does not care).
 __global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // kScatterItems lines per thread (a workgroup: kScatterItems x 256 consecutive lines, lane-interleaved):
+    // their records leave with one reservation per stream (scatter_by_slice_n)
+    const uint32_t first_line = blockIdx.x * (kDtokThreads * kScatterItems) + threadIdx.x;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    bool rec = false, big = false;
-    uint32_t word = 0, pos = 0;
-    if (i < a.n_lines && a.is_first[i]) {
-        rec = true;
-        const uint32_t m = a.lmeta[i] >> 28;
-        if (!a.is_start[i]) {
-            uint32_t j = i;
-            do {
-                --j;
-                pos += (a.is_first[j] && (a.lmeta[j] >> 28) == m) ? 1u : 0u;
-            } while (!a.is_start[j]);
+    bool rec[kScatterItems];
+    uint32_t word[kScatterItems];
+    bool big = false;
+    uint32_t n_rec = 0, n_reads = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kScatterItems; ++r) {
+        const uint32_t i = first_line + r * kDtokThreads;
+        rec[r] = false;
+        word[r] = 0;
+        uint32_t pos = 0;
+        if (i < a.n_lines && a.is_first[i]) {
+            rec[r] = true;
+            const uint32_t m = a.lmeta[i] >> 28;
+            if (!a.is_start[i]) {
+                uint32_t j = i;
+                do {
+                    --j;
+                    pos += (a.is_first[j] && (a.lmeta[j] >> 28) == m) ? 1u : 0u;
+                } while (!a.is_start[j]);
+            }
+            uint32_t size = pos + 1u;
+            for (uint32_t j = i + 1u; j < a.n_lines && !a.is_start[j]; ++j)
+                size += (a.is_first[j] && (a.lmeta[j] >> 28) == m) ? 1u : 0u;
+            big |= size > (uint32_t)WK_WEIGHT_MAX_K;
+            word[r] = (uint32_t)a.lsubj[i] | ((pos & 15u) << kWordSubjBits) | ((size & 31u) << kWordSizeShift);
         }
-        uint32_t size = pos + 1u;
-        for (uint32_t j = i + 1u; j < a.n_lines && !a.is_start[j]; ++j)
-            size += (a.is_first[j] && (a.lmeta[j] >> 28) == m) ? 1u : 0u;
-        big = size > (uint32_t)WK_WEIGHT_MAX_K;
-        word = (uint32_t)a.lsubj[i] | ((pos & 15u) << kWordSubjBits) | ((size & 31u) << kWordSizeShift);
+        n_rec += (uint32_t)__popcll(__ballot(rec[r]));
+        n_reads += (uint32_t)__popcll(__ballot(rec[r] && pos == 0u));
     }
     if (big) atomicOr(&a.state->flags, kDtokBigRead);
-    // one reservation per workgroup and stream (a returning atomic on one word
-    // saturates near 90 per microsecond: one per wave — 24 k of them for a 64 MB
-    // block — was half of this kernel's time)
+    // the block's totals: one pair of adds per workgroup
     __shared__ uint32_t w_rec[kDtokThreads / kWave], w_reads[kDtokThreads / kWave];
     const uint32_t wave = threadIdx.x / kWave;
-    const unsigned long long mask = __ballot(rec);
-    const unsigned long long reads = __ballot(rec && pos == 0u);
     if (lane == 0) {
-        w_rec[wave] = (uint32_t)__popcll(mask);
-        w_reads[wave] = (uint32_t)__popcll(reads);
+        w_rec[wave] = n_rec;
+        w_reads[wave] = n_reads;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t n = 0, r = 0;
+        uint32_t n = 0, q = 0;
         for (uint32_t w = 0; w < kDtokThreads / kWave; ++w) {
             n += w_rec[w];
-            r += w_reads[w];
+            q += w_reads[w];
         }
         if (n) atomicAdd(&a.state->n_out, (unsigned long long)n);
-        if (r) atomicAdd(&a.state->n_reads, (unsigned long long)r);
+        if (q) atomicAdd(&a.state->n_reads, (unsigned long long)q);
     }
-    scatter_by_slice<kDtokThreads>(a.streams, rec, word);
+    scatter_by_slice_n<kDtokThreads, kScatterItems>(a.streams, rec, word);
 }
 
 // Plain flavour, ordered emission: the records of a read contiguous and in

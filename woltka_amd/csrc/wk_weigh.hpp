@@ -224,11 +224,65 @@ __device__ __forceinline__ void scatter_by_slice(const StreamSet& s, bool rec, u
     }
 }
 
-// records copied from the host -> the streams
+// The same for kItems records per thread: ONE reservation per workgroup and slice for all of them.  (A
+// returning atomic on one word completes about 90 times per microsecond; with a reservation per 256
+// records the cursors of the streams were the whole cost of appending records: 160 us of a 64 MB
+// block's emission, 1.3 ms per 28 M host words -- profiles/r05a_e2e_lca, r04_lca_kernel_stats.)
+constexpr uint32_t kScatterItems = 8;
+template <uint32_t kThreads, uint32_t kItems>
+__device__ __forceinline__ void scatter_by_slice_n(const StreamSet& s, const bool (&rec)[kItems], const uint32_t (&word)[kItems]) {
+    __shared__ uint32_t cnt[kItems][kThreads / kWave][kMaxStreams];
+    __shared__ unsigned long long base[kMaxStreams];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t sl[kItems];
+    unsigned long long mine[kItems];
+#pragma unroll
+    for (uint32_t r = 0; r < kItems; ++r) {
+        sl[r] = 0;
+        if (rec[r]) {
+            sl[r] = (word[r] & ((1u << 23) - 1u)) / kSliceBins;
+            if (sl[r] >= s.n_streams) sl[r] = s.n_streams - 1u;  // (a subject beyond the table: the histogram reports it)
+        }
+        mine[r] = 0;
+        for (uint32_t k = 0; k < s.n_streams; ++k) {
+            const unsigned long long m = __ballot(rec[r] && sl[r] == k);
+            if (lane == 0) cnt[r][wave][k] = (uint32_t)__popcll(m);
+            if (sl[r] == k) mine[r] = m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < s.n_streams) {
+        const uint32_t k = threadIdx.x;
+        uint32_t n = 0;
+        for (uint32_t r = 0; r < kItems; ++r)
+            for (uint32_t w = 0; w < kThreads / kWave; ++w) {
+                const uint32_t c = cnt[r][w][k];
+                cnt[r][w][k] = n;
+                n += c;
+            }
+        base[k] = n ? atomicAdd(&s.cursor[k], (unsigned long long)n) : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < kItems; ++r)
+        if (rec[r]) {
+            const unsigned long long at = base[sl[r]] + cnt[r][wave][sl[r]] + (unsigned long long)__popcll(mine[r] & ((1ull << lane) - 1ull));
+            if (at < s.cap) s.out[sl[r]][at] = word[r];
+        }
+}
+
+// records copied from the host -> the streams (kScatterItems x 256 per workgroup)
 __global__ void __launch_bounds__(256) words_partition_kernel(const uint32_t* __restrict__ src, uint32_t n, StreamSet s) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool rec = i < n;
-    scatter_by_slice<256>(s, rec, rec ? src[i] : 0u);
+    const uint32_t first = blockIdx.x * (256u * kScatterItems) + threadIdx.x;
+    bool rec[kScatterItems];
+    uint32_t word[kScatterItems];
+#pragma unroll
+    for (uint32_t r = 0; r < kScatterItems; ++r) {
+        const uint32_t i = first + r * 256u;
+        rec[r] = i < n;
+        word[r] = rec[r] ? src[i] : 0u;
+    }
+    scatter_by_slice_n<256, kScatterItems>(s, rec, word);
 }
 
 struct StreamBinsArgs {

@@ -2333,7 +2333,7 @@ int wk_words_append(wk_ctx* c, const uint32_t* words, int64_t n_records, int64_t
         c->slot_busy[slot] = true;
     }
     if (n_records > 0 && c->w_mode == 0) {  // ... to the streams of their slices
-        hipLaunchKernelGGL(words_partition_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(words_partition_kernel, dim3((unsigned)((n_records + 256 * kScatterItems - 1) / (256 * kScatterItems))), dim3(256), 0, c->stream,
                            c->w_stage.as<uint32_t>(), (uint32_t)n_records, stream_set(c));
         HIP_TRY(c, hipGetLastError());
         c->w_counts_known = false;
@@ -2502,7 +2502,6 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
         const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
         HIP_TRY(c, c->d_tiles_k[k].reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off_k[k].reserve((size_t)n_tiles * 8));
-        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 10 + k), 0, 8, c->copy_stream));
         hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->copy_stream, c->d_textbuf[k].as<unsigned char>(), n,
                            c->d_tiles_k[k].as<unsigned long long>());
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->copy_stream, c->d_tiles_k[k].as<unsigned long long>(),
@@ -2532,8 +2531,7 @@ int wk_text_upload(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     HIP_TRY(c, hipMalloc(&tiles, (size_t)n_tiles * 8));
     HIP_TRY(c, hipMalloc(&off, (size_t)n_tiles * 8));
     HIP_TRY(c, hipMemcpyAsync(dev, r.host, n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync((char*)dev + n, 0, 64, c->stream));
-    HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
+    // (the pad behind the text: dtok_count_kernel's last tile; the total: tile_scan_kernel stores it)
     hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, (const unsigned char*)dev, n,
                        (unsigned long long*)tiles);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)tiles, (unsigned long long*)off,
@@ -2655,16 +2653,14 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     if (resident) {
         // (measurement: the block is on the device already, 64 zero bytes behind it)
     } else if (k >= 0) {
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));
-        HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));  // (the pad: zeroed by the count behind the copy)
     } else {
         k = c->copy_next;  // (a buffer no block copied ahead is waiting in)
         for (int q = 0; q < wk_ctx::kTextBufs && c->copy_src[k]; ++q) k = (k + 1) % wk_ctx::kTextBufs;
         if (c->copy_src[k]) return fail(c, WK_E_STATE, "every text buffer holds a block copied ahead");
         if (k == c->copy_next) c->copy_next = (c->copy_next + 1) % wk_ctx::kTextBufs;
         HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
-        HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_textbuf[k].as<unsigned char>() + n, 0, 64, c->stream));
+        HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));  // (the pad: zeroed by the count below)
     }
     const bool counted = !resident && c->copy_src[k] == src && c->copy_counted[k];
     if (!resident) {
@@ -2700,7 +2696,6 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     } else {
         HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
-        HIP_TRY(c, hipMemsetAsync(scalar_u64(c, 3), 0, 8, c->stream));
         hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
                            c->d_tiles.as<unsigned long long>());
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
@@ -2723,9 +2718,9 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         HIP_TRY(c, c->d_lscan.reserve(((size_t)lines + 1) * 8));
     }
     if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
-    HIP_TRY(c, hipMemsetAsync(c->d_lines.p, 0, 4, c->stream));  // line 0 starts at 0
+    // (line 0 and the block's scalars are written by the lines kernel itself)
     hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
-                       tile_off, c->d_lines.as<uint32_t>());
+                       tile_off, c->d_lines.as<uint32_t>(), c->d_state.as<DtokState>());
     if (open_end) {
         const uint32_t end = n + 1;  // as if a newline followed the text
         HIP_TRY(c, hipMemcpyAsync(c->d_lines.as<uint32_t>() + lines, &end, 4, hipMemcpyHostToDevice, c->stream));
@@ -2737,7 +2732,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     for (int round = 0; round < 3; ++round) {
         int rc = dtok_mirror_dict(c, tok);
         if (rc) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->d_state.p, 0, sizeof(DtokState), c->stream));
+        if (round > 0) HIP_TRY(c, hipMemsetAsync(c->d_state.p, 0, sizeof(DtokState), c->stream));  // (round 0: by dtok_lines_kernel)
         const DtokArgs a = dtok_args(c);
         kt = ktimer_begin(c, "dtok_parse");
         if (extra)
@@ -2813,12 +2808,13 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
         c->w_counts_known = false;
         // (a block the kernels give up on must leave the streams as they were)
         HIP_TRY(c, c->w_backup.reserve(kMaxStreams * 8));
-        HIP_TRY(c, hipMemcpyAsync(c->w_backup.p, c->w_cursor.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
+        a.cursor_backup = c->w_backup.as<unsigned long long>();  // (copied by dtok_runs_kernel)
     } else {
         a.out = c->c_words.as<uint32_t>() + c->w_records;
         a.out_cap = c->dt_lines;
     }
     const dim3 grid((c->dt_lines + kDtokThreads - 1) / kDtokThreads);
+    const dim3 emit_grid((c->dt_lines + kDtokThreads * kScatterItems - 1) / (kDtokThreads * kScatterItems));
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
@@ -2839,12 +2835,12 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
                            c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
         hipLaunchKernelGGL(dtok_scan_lines_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tile_off.as<unsigned long long>());
         if (c->w_mode == 0)  // (read maps wanted, records for the histogram: by slice, in no particular order)
-            hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+            hipLaunchKernelGGL(dtok_emit_kernel, emit_grid, dim3(kDtokThreads), 0, c->stream, a);
         else
             hipLaunchKernelGGL(dtok_place_words_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
         HIP_TRY(c, hipMemcpyAsync(totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
     } else {
-        hipLaunchKernelGGL(dtok_emit_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        hipLaunchKernelGGL(dtok_emit_kernel, emit_grid, dim3(kDtokThreads), 0, c->stream, a);
     }
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
