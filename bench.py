@@ -422,9 +422,28 @@ class OrdinalWorkload:
         self.alg_bytes = 20 * self.records + 16 * p['gstart'].size + \
             int(6.4 * self.records)
         self.launch_bytes = self.alg_bytes
-        # match_hits -> ordinal_tally -> range_merge (wk_ordinal_count; the
-        # gene-list kernels only run for reads the tally leaves over)
-        self.families = ('match_count', 'classify', 'partition_merge')
+        # stripe_match over the reads of one hit, sorted by genome stripe when
+        # the chunk is staged (stripe_sort: once per staged chunk -- timed
+        # here, reported beside the pass and inside `roofline_step_with_sort`)
+        # + match_hits -> ordinal_tally -> range_merge over the reads of
+        # several hits (wk_ordinal_count)
+        self.families = ('stripe_match', 'match_count', 'classify',
+                         'partition_merge')
+        self.dominant = 'stripe_match'
+        self.symbols = dict(self.symbols,
+                            stripe_match='wk::stripe_match_kernel',
+                            stripe_sort='wk::stripe_count_kernel + '
+                                        'stripe_rows + stripe_scatter')
+        ctx.profile_kernels(True)
+        ctx.ordinal_count(self.jobs)        # (the chunk is sorted here)
+        try:
+            self.sort_ms = ctx.last_kernel_ms('stripe_sort')
+        except RuntimeError:                # (stripes switched off)
+            self.sort_ms = None
+            self.families = ('match_count', 'classify', 'partition_merge')
+            self.dominant = 'match_count'
+        ctx.profile_kernels(False)
+        ctx.counts_clear()
         self._steps = 0
 
     def family_bytes(self, family):
@@ -432,6 +451,11 @@ class OrdinalWorkload:
         p = self.prob
         pairs = int(self.ctx.stats()['n_pairs']) // max(1, self._steps)
         tables = 16 * p['gstart'].size
+        if family == 'stripe_match':
+            # the sorted hits of the one-hit reads (16 B each) in, the gene
+            # records once; the bins leave as ~one add per gene
+            one = int(np.count_nonzero(np.diff(p['hoff']) == 1))
+            return 16 * one + tables + 8 * p['gstart'].size
         if family == 'match_count':     # hits in, first two matches out (+ grid)
             return 16 * self.records + tables + 8 * self.records + \
                 8 * p['gstart'].size
@@ -1818,6 +1842,18 @@ def config_block(wl, seconds, passes, steps, scale, key):
                                'achieved': round(step_gbs, 1),
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': round(step_gbs / HBM_PEAK_GBS, 4)}}
+    if getattr(wl, 'sort_ms', None) is not None:
+        # (coord-match: the counting sort of the hits by genome stripe runs
+        # once per staged chunk, in front of the first pass; the product
+        # counts every chunk once, so its step is sort + pass)
+        with_sort = ms_pass + wl.sort_ms
+        block['sort_ms'] = round(wl.sort_ms, 4)
+        block['ms_per_pass_with_sort'] = round(with_sort, 4)
+        gbs = wl.alg_bytes / (with_sort * 1e-3) / 1e9
+        block['roofline_step_with_sort'] = {
+            'bound': 'hbm', 'algorithmic_bytes': wl.alg_bytes,
+            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 4)}
     if overlapped > 1:
         block['roofline']['note'] = (
             f'{overlapped} chunks on {overlapped} streams overlap in the timed '

@@ -1,0 +1,380 @@
+// wk_stripe.hpp — coord-match with the hits binned by genome stripe and the genes in LDS.
+//
+// ordinal.flush_chunk (woltka/ordinal.py:243-335) buckets a chunk's reads by genome and sweeps each
+// genome's merged queue of gene and read end points (match_read_gene, ordinal.py:476-582).  The first
+// three rounds kept the hits in input order and gathered 16-byte gene and grid records from HBM per
+// hit (wk_ordinal.hpp: match_hits -> first2[] -> ordinal_tally -> log -> range_merge): 2.3x the
+// algorithmic bytes through the fabric and a chain of dependent gathers per hit.  Here:
+//
+//   stripe_count / row scan / stripe_scatter   the reads of ONE hit (93 % of config 4) are counting-
+//       sorted by genome STRIPE -- consecutive genomes whose genes (<= kStripeGenes) fit the LDS --
+//       as 16-byte records; the other reads (several hits: their genes are a union over hits) are
+//       compacted, in order, into arrays of their own and go through wk_ordinal.hpp's kernels;
+//   stripe_match   a workgroup takes a piece of one stripe's hits, loads the stripe's gene records
+//       into LDS once, finds every hit's genes there (binary search over the genome's starts, walk
+//       back while an earlier gene still reaches the hit: the predicate of wk_ordinal.hpp) and adds
+//       1/n to the genes' bins in LDS; the bins go to the count table when the piece is done.
+//       No first2[], no log, no merge pass; a hit is read once (16 bytes).
+//   stripe_overflow   hits with more than two genes (nested genes) are listed and counted by a
+//       workgroup each, exactly (distinct features, any number up to the count key's 4095).
+//
+// All of it counts what classify.assign_none + counter count for `--coords` at rank none
+// (classify.py:32-51, 144-171): a read with n distinct genes adds 1/n to each.
+#pragma once
+#include "wk_ordinal.hpp"
+
+namespace wk {
+
+constexpr uint32_t kStripeGenes = 3072;      // gene records of a stripe (48 KB of LDS) and as many 64-bit bins (24 KB)
+constexpr uint32_t kStripeMax = 1024;        // stripes a chunk can be sorted into (per-tile counters in LDS)
+constexpr uint32_t kStripeTileThreads = 256;
+constexpr uint32_t kStripeTileItems = 8;
+constexpr uint32_t kStripeTileReads = kStripeTileThreads * kStripeTileItems;  // reads per workgroup of the count / scatter passes
+constexpr uint32_t kStripeMatchThreads = 512;
+constexpr uint32_t kStripePiece = 32768;     // hits per workgroup of stripe_match
+constexpr uint32_t kStripeStatBlocks = 4096; // (a part of the context's kStatBlocks pairs of statistics counters)
+
+struct StripeSortArgs {
+    const int32_t* genome;
+    const int32_t* beg;
+    const int32_t* end;
+    const uint32_t* len;
+    const int32_t* hoff;  // [n_reads + 1]
+    int64_t n_reads;
+    const int32_t* stripe_of;  // [n_genomes] stripe of a genome, -1: none (too many genes for the LDS)
+    int32_t n_genomes;
+    uint32_t n_stripes;
+    uint32_t n_tiles;
+    // rows 0 .. n_stripes - 1: reads of one hit per stripe; row n_stripes: the other reads; row n_stripes + 1: their hits
+    uint32_t* cnt;             // [n_stripes + 2][n_tiles]: counts, then (after the scan) exclusive offsets inside the row
+    const unsigned long long* row_base;  // [n_stripes + 2] exclusive offsets of the rows 0 .. n_stripes - 1 among the binned hits
+    int4* binned;              // [single hits] {genome, beg, end, len}
+    int32_t* r_genome;         // the other reads, compacted in order: hits ...
+    int32_t* r_beg;
+    int32_t* r_end;
+    uint32_t* r_len;
+    int32_t* r_hoff;           // ... and offsets [n_rest_reads + 1]
+};
+
+// the class of a read: its stripe (one hit on a genome of a stripe), n_stripes (anything else that has hits
+// worth matching), 0xFFFFFFFF (nothing to match: no hits, or one hit of length 0 / on an unknown genome)
+__device__ __forceinline__ uint32_t stripe_class(const StripeSortArgs& a, int64_t r, int32_t* h0_out, int32_t* nh_out) {
+    const int32_t h0 = a.hoff[r], nh = a.hoff[r + 1] - h0;
+    *h0_out = h0;
+    *nh_out = nh;
+    if (nh <= 0) return 0xFFFFFFFFu;
+    if (nh > 1) return a.n_stripes;
+    const int32_t g = a.genome[h0];
+    if (g < 0 || g >= a.n_genomes || a.len[h0] == 0u) return 0xFFFFFFFFu;  // ordinal.py:231, 294-297: matches nothing
+    const int32_t s = a.stripe_of[g];
+    return s < 0 ? a.n_stripes : (uint32_t)s;
+}
+
+// pass 1: per tile of reads, how many go where
+__global__ void __launch_bounds__(kStripeTileThreads) stripe_count_kernel(StripeSortArgs a) {
+    __shared__ uint32_t cnt[kStripeMax + 2];
+    for (uint32_t i = threadIdx.x; i < a.n_stripes + 2u; i += blockDim.x) cnt[i] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kStripeTileReads;
+#pragma unroll
+    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
+        const int64_t r = base + it * kStripeTileThreads + threadIdx.x;
+        if (r < a.n_reads) {
+            int32_t h0, nh;
+            const uint32_t cls = stripe_class(a, r, &h0, &nh);
+            if (cls != 0xFFFFFFFFu) {
+                atomicAdd(&cnt[cls], 1u);
+                if (cls == a.n_stripes) atomicAdd(&cnt[a.n_stripes + 1u], (uint32_t)nh);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_stripes + 2u; i += blockDim.x) a.cnt[(size_t)i * a.n_tiles + blockIdx.x] = cnt[i];
+}
+
+// pass 2: every row scanned over the tiles (a workgroup per row), the row's total to `tot`
+__global__ void __launch_bounds__(1024) stripe_rows_kernel(uint32_t* __restrict__ cnt, uint32_t n_tiles, unsigned long long* __restrict__ tot) {
+    constexpr uint32_t kPer = 8;
+    __shared__ unsigned long long wave_tot[16];
+    uint32_t* row = cnt + (size_t)blockIdx.x * n_tiles;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    unsigned long long carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += blockDim.x * kPer) {
+        const uint32_t first = base + threadIdx.x * kPer;
+        uint32_t v[kPer];
+        unsigned long long mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            v[k] = first + k < n_tiles ? row[first + k] : 0u;
+            mine += v[k];
+        }
+        unsigned long long inc = mine;
+#pragma unroll
+        for (uint32_t d = 1; d < kWave; d <<= 1) {
+            const unsigned long long up = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += up;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        unsigned long long before = 0, round_total = 0;
+        for (uint32_t q = 0; q < n_waves; ++q) {
+            const unsigned long long t = wave_tot[q];
+            before += q < wave ? t : 0ull;
+            round_total += t;
+        }
+        unsigned long long run = carry + before + inc - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            if (first + k < n_tiles) row[first + k] = (uint32_t)run;  // (< 2^31 hits per chunk)
+            run += v[k];
+        }
+        carry += round_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+
+// exclusive offsets of the stripes' rows among the binned hits (n <= kStripeMax + 2 values)
+__global__ void __launch_bounds__(64) stripe_bases_kernel(const unsigned long long* __restrict__ tot, unsigned long long* __restrict__ base, uint32_t n_stripes) {
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (uint32_t s = 0; s < n_stripes; ++s) {
+            base[s] = run;
+            run += tot[s];
+        }
+        base[n_stripes] = run;  // all single hits
+        base[n_stripes + 1] = 0;
+    }
+}
+
+// pass 3: the hits to their places
+__global__ void __launch_bounds__(kStripeTileThreads) stripe_scatter_kernel(StripeSortArgs a) {
+    __shared__ uint32_t cur[kStripeMax];  // next place of a stripe's hits of this tile, inside the row
+    __shared__ unsigned long long wtot[kStripeTileThreads / kWave];
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < a.n_stripes; i += blockDim.x) cur[i] = a.cnt[(size_t)i * a.n_tiles + tile];
+    __syncthreads();
+    const int64_t base = (int64_t)tile * kStripeTileReads;
+    // the other reads keep their order: thread t owns the reads base + t * items .. (consecutive), an
+    // exclusive scan of (reads | hits << 32) over the threads places them
+    int32_t h0[kStripeTileItems], nh[kStripeTileItems];
+    uint32_t cls[kStripeTileItems];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
+        const int64_t r = base + (int64_t)threadIdx.x * kStripeTileItems + it;
+        cls[it] = 0xFFFFFFFFu;
+        h0[it] = nh[it] = 0;
+        if (r < a.n_reads) cls[it] = stripe_class(a, r, &h0[it], &nh[it]);
+        if (cls[it] == a.n_stripes) mine += 1ull | ((unsigned long long)(uint32_t)nh[it] << 32);
+    }
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    unsigned long long inc = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < kWave; d <<= 1) {
+        const unsigned long long up = __shfl_up(inc, d, kWave);
+        if (lane >= d) inc += up;
+    }
+    if (lane == kWave - 1) wtot[wave] = inc;
+    __syncthreads();
+    unsigned long long before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kStripeTileThreads / kWave; ++w) before += w < wave ? wtot[w] : 0ull;
+    unsigned long long run = before + inc - mine;
+    uint32_t rr = a.cnt[(size_t)a.n_stripes * a.n_tiles + tile] + (uint32_t)(run & 0xFFFFFFFFull);
+    uint32_t rh = a.cnt[(size_t)(a.n_stripes + 1u) * a.n_tiles + tile] + (uint32_t)(run >> 32);
+#pragma unroll
+    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
+        if (cls[it] == 0xFFFFFFFFu) continue;
+        if (cls[it] == a.n_stripes) {
+            a.r_hoff[rr++] = (int32_t)rh;
+            for (int32_t k = 0; k < nh[it]; ++k) {
+                const int32_t h = h0[it] + k;
+                a.r_genome[rh] = a.genome[h];
+                a.r_beg[rh] = a.beg[h];
+                a.r_end[rh] = a.end[h];
+                a.r_len[rh] = a.len[h];
+                ++rh;
+            }
+        } else {
+            const uint32_t at = atomicAdd(&cur[cls[it]], 1u);
+            const int32_t h = h0[it];
+            a.binned[a.row_base[cls[it]] + at] = make_int4(a.genome[h], a.beg[h], a.end[h], (int32_t)a.len[h]);
+        }
+    }
+}
+
+struct StripeUnit {  // a piece of one stripe's hits
+    uint32_t stripe;
+    uint32_t first, count;  // among the binned hits
+    uint32_t pad;
+};
+
+struct StripeMatchArgs {
+    const int4* binned;
+    const StripeUnit* units;
+    const int4* gene4;         // wk_set_genes: {start0, end, largest end before the gene in its genome, feature}
+    const int32_t* gene_off;   // [n_genomes + 1] genes of a genome
+    const int2* stripe_genes;  // [n_stripes] {first gene, number of genes}
+    double th;
+    int32_t n_jobs;
+    int32_t job_index[WK_MAX_JOBS];
+    int32_t group;
+    CountTable table;
+    uint32_t* overflow;        // hits (indices among the binned) with more than two genes
+    uint32_t overflow_cap;
+    unsigned long long* stat;  // [0] reads with a gene, [1] read-gene matches, [2] overflow hits
+    unsigned long long* stat_block;  // the context's (reads, records) counters, kStripeStatBlocks pairs
+};
+
+__global__ void __launch_bounds__(kStripeMatchThreads) stripe_match_kernel(StripeMatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int4* const genes = reinterpret_cast<int4*>(smem);
+    unsigned long long* const bins = reinterpret_cast<unsigned long long*>(smem + (size_t)kStripeGenes * 16);
+    __shared__ unsigned long long acc[2];
+    const StripeUnit u = a.units[blockIdx.x];
+    const int2 sg = a.stripe_genes[u.stripe];
+    const int32_t g_lo = sg.x, n_g = sg.y;
+    for (int32_t i = threadIdx.x; i < n_g; i += blockDim.x) {
+        genes[i] = a.gene4[g_lo + i];
+        bins[i] = 0ull;
+    }
+    if (threadIdx.x < 2) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long my_reads = 0, my_pairs = 0;
+    for (uint32_t k = threadIdx.x; k < u.count; k += blockDim.x) {
+        const int4 hit = a.binned[u.first + k];
+        const int64_t rs = hit.y, re = hit.z;
+        const int64_t rel = effective_len((uint32_t)hit.w, a.th);
+        // genes of the hit's genome, as indices into the stripe's records
+        const int32_t lo = a.gene_off[hit.x] - g_lo, hi = a.gene_off[hit.x + 1] - g_lo;
+        // the last gene that starts at or before re - rel (later ones cannot overlap by rel)
+        const int64_t t = re - rel;
+        int32_t l = lo, h = hi;  // first gene with start > t
+        while (l < h) {
+            const int32_t m = (l + h) >> 1;
+            if ((int64_t)genes[m].x <= t)
+                l = m + 1;
+            else
+                h = m;
+        }
+        int32_t n = 0, fx = -1, fy = -1, ix = -1, iy = -1;
+        const int64_t min_end = rs + rel;
+        for (int32_t j = l - 1; j >= lo; --j) {
+            const int4 g = genes[j];
+            const int64_t gs = g.x, ge = g.y;
+            const int64_t ov = (ge < re ? ge : re) - (gs > rs ? gs : rs);
+            if (ov >= rel) {
+                if (n == 0) {
+                    fx = g.w;
+                    ix = j;
+                } else if (n == 1) {
+                    fy = g.w;
+                    iy = j;
+                }
+                n += 1;
+            }
+            if ((int64_t)g.z < min_end) break;  // nothing before j reaches the hit
+        }
+        if (n == 0) continue;
+        if (n > 2) {  // (nested genes: counted exactly by stripe_overflow_kernel)
+            const uint32_t at = (uint32_t)atomicAdd(&a.stat[2], 1ull);
+            if (at < a.overflow_cap) a.overflow[at] = u.first + k;
+            continue;
+        }
+        my_reads += 1;
+        my_pairs += (unsigned long long)n;
+        const bool two = n == 2 && fy != fx;  // (two rows of one gene id are one gene: ordinal.py:331-332 builds a set)
+        const unsigned long long w = (unsigned long long)weight_of(two ? 2u : 1u);
+        atomicAdd(&bins[ix], w);
+        if (two) atomicAdd(&bins[iy], w);
+    }
+    my_reads = wave_sum(my_reads);
+    my_pairs = wave_sum(my_pairs);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicAdd(&acc[0], my_reads);
+        atomicAdd(&acc[1], my_pairs);
+    }
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < n_g; i += blockDim.x) {
+        const unsigned long long w = bins[i];
+        if (!w) continue;
+        const uint32_t feature = (uint32_t)genes[i].w;
+        for (int32_t jb = 0; jb < a.n_jobs; ++jb) table_add(a.table, make_key((uint32_t)a.job_index[jb], 0u, (uint32_t)a.group, feature), w);
+    }
+    if (threadIdx.x == 0) {
+        if (acc[0]) atomicAdd(&a.stat[0], acc[0]);
+        if (acc[1]) atomicAdd(&a.stat[1], acc[1]);
+        // (what wk_get_stats adds up: reads classified, records = matches)
+        const uint32_t sb = blockIdx.x % kStripeStatBlocks;
+        if (acc[0]) atomicAdd(&a.stat_block[2 * sb], acc[0]);
+        if (acc[1]) atomicAdd(&a.stat_block[2 * sb + 1], acc[1]);
+    }
+}
+
+// A hit with more than two genes: a wave collects them all, keeps the distinct features and adds 1/n to each
+// (n <= 16: in units of 1/L like everything else; beyond: under the key's k, which classify.counter's
+// 1/len(remaining) is).  More than kOverflowMax genes: the error flag (the limit of the count key).
+constexpr uint32_t kOverflowMax = 4095;
+__global__ void __launch_bounds__(64) stripe_overflow_kernel(StripeMatchArgs a, uint32_t n_over) {
+    __shared__ int32_t feat[kOverflowMax + 1];
+    __shared__ uint32_t n_feat;
+    const uint32_t o = blockIdx.x;
+    if (o >= n_over) return;
+    const int4 hit = a.binned[a.overflow[o]];
+    const int64_t rs = hit.y, re = hit.z, rel = effective_len((uint32_t)hit.w, a.th);
+    if (threadIdx.x == 0) {
+        // (one lane walks: these hits are a handful per million)
+        uint32_t n = 0, total = 0;
+        bool too_many = false;
+        const int32_t lo = a.gene_off[hit.x], hi = a.gene_off[hit.x + 1];
+        const int64_t t = re - rel, min_end = rs + rel;
+        int32_t l = lo, h = hi;
+        while (l < h) {
+            const int32_t m = (l + h) >> 1;
+            if ((int64_t)a.gene4[m].x <= t)
+                l = m + 1;
+            else
+                h = m;
+        }
+        for (int32_t j = l - 1; j >= lo; --j) {
+            const int4 g = a.gene4[j];
+            const int64_t gs = g.x, ge = g.y;
+            const int64_t ov = (ge < re ? ge : re) - (gs > rs ? gs : rs);
+            if (ov >= rel) {
+                total += 1;
+                bool dup = false;
+                for (uint32_t z = 0; z < n && !dup; ++z) dup = feat[z] == g.w;
+                if (!dup) {
+                    if (n < kOverflowMax)
+                        feat[n++] = g.w;
+                    else
+                        too_many = true;
+                }
+            }
+            if ((int64_t)g.z < min_end) break;
+        }
+        if (too_many) {
+            atomicOr(a.table.err, kErrKRange);  // (more distinct genes in a read than the count key's k can say)
+            n = 0;
+        }
+        n_feat = n;
+        if (n) {
+            atomicAdd(&a.stat[0], 1ull);
+            atomicAdd(&a.stat[1], (unsigned long long)total);
+            atomicAdd(&a.stat_block[0], 1ull);
+            atomicAdd(&a.stat_block[1], (unsigned long long)total);
+        }
+    }
+    __syncthreads();
+    const uint32_t n = n_feat;
+    for (uint32_t z = threadIdx.x; z < n; z += blockDim.x)
+        for (int32_t jb = 0; jb < a.n_jobs; ++jb) {
+            if (n <= (uint32_t)WK_WEIGHT_MAX_K)
+                table_add(a.table, make_key((uint32_t)a.job_index[jb], 0u, (uint32_t)a.group, (uint32_t)feat[z]), (unsigned long long)weight_of(n));
+            else
+                table_add(a.table, make_key((uint32_t)a.job_index[jb], n, (uint32_t)a.group, (uint32_t)feat[z]), 1ull);
+        }
+}
+
+}  // namespace wk

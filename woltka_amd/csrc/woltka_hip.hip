@@ -22,6 +22,7 @@
 #include "wk_dtok.hpp"
 #include "wk_free.hpp"
 #include "wk_ordinal.hpp"
+#include "wk_stripe.hpp"
 #include "wk_readmap.hpp"
 #include "wk_tok_internal.h"
 #include "wk_weigh.hpp"
@@ -164,6 +165,15 @@ struct wk_ctx {
     int64_t n_hits = 0, o_reads = 0;
     double th = 0.8;
     bool ord_valid = false;
+    // hits binned by genome stripe (wk_stripe.hpp): the stripes of the gene tables, the sorted chunk
+    DevBuf g_gene_off, g_stripe_of, g_stripe_genes;
+    std::vector<int2> stripe_genes_host;
+    int use_stripes = 1;       // (0: the gather kernels of wk_ordinal.hpp for every read; measurement)
+    DevBuf sb_cnt, sb_tot, sb_base, sb_binned, sb_units, sb_over, sb_stat;
+    DevBuf r_genome, r_beg, r_end, r_len, r_hoff;
+    bool sb_valid = false;     // the staged chunk has been sorted
+    int64_t sb_single = 0, sb_rest_reads = 0, sb_rest_hits = 0;
+    uint32_t sb_n_units = 0;
 
     // misc device scalars: [0]=err(int) [3]=total pairs [4]=compact counter [5]=log cursor
     DevBuf scalars;
@@ -246,7 +256,7 @@ struct wk_ctx {
     bool slot_busy[kStageSlots] = {};
     std::vector<void*> host_blocks;      // wk_host_alloc
     // device tokenizer (wk_dtok.hpp): the block scanned last and the dictionary mirror
-    static constexpr int kTextBufs = 3;   // the block being scanned + two copied ahead
+    static constexpr int kTextBufs = 4;   // the block being scanned + three copied ahead
     DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
@@ -276,6 +286,13 @@ struct wk_ctx {
     bool copy_counted[kTextBufs] = {};
     uint32_t copy_n[kTextBufs] = {};
     int copy_next = 0, dt_cur = 0;
+    // A text buffer is free, holds a block copied ahead (tagged by copy_src / copy_n), or is the one the
+    // kernels of the block scanned last read (until the next scan begins).  wk_dtok_copy may be called
+    // from another thread than the scans (the host layer's reader thread issues the copies as soon as a
+    // block is cut): the states and tags are guarded by copy_mu.
+    enum : unsigned char { kBufFree = 0, kBufCopied = 1, kBufScanning = 2 };
+    unsigned char buf_state[kTextBufs] = {};
+    std::mutex copy_mu;
     // read maps formatted on the device (wk_readmap.hpp): per job the taxon slot of every subject, the slots' order
     // and shown text; per block the reads' leader lines, line lengths / offsets and the text itself
     struct MapTables {
@@ -963,6 +980,11 @@ int wk_tune(wk_ctx* c, const char* name, int64_t value) {
         c->tally_slots = (int)value;
         return WK_OK;
     }
+    if (!strcmp(name, "stripes")) {
+        if (value != 0 && value != 1) return fail(c, WK_E_ARG, "stripes must be 0 or 1");
+        c->use_stripes = (int)value;
+        return WK_OK;
+    }
     if (!strcmp(name, "tally")) {
         c->use_tally = (int)value;
         return WK_OK;
@@ -1192,8 +1214,36 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
     if ((rc = upload(c, c->g_goff, goff.data(), goff.size() * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->g_shift, shift.data(), shift.size()))) return rc;
     if ((rc = upload(c, c->g_feature, gene_feature, (size_t)n_genes * 4))) return rc;
+    // genome stripes for the sorted coord-match (wk_stripe.hpp): consecutive genomes while their genes fit
+    // the LDS; a genome with more genes than that has no stripe (its hits keep the gather kernels)
+    {
+        std::vector<int32_t> stripe_of((size_t)std::max(n_genomes, 1), -1);
+        c->stripe_genes_host.clear();
+        int32_t g = 0;
+        while (g < n_genomes) {
+            const int32_t n_g = genome_off[g + 1] - genome_off[g];
+            if ((uint32_t)n_g > kStripeGenes) {
+                ++g;
+                continue;
+            }
+            const int32_t first_gene = genome_off[g];
+            int32_t count = 0;
+            const int32_t sid = (int32_t)c->stripe_genes_host.size();
+            while (g < n_genomes && (uint32_t)(count + genome_off[g + 1] - genome_off[g]) <= kStripeGenes) {
+                count += genome_off[g + 1] - genome_off[g];
+                stripe_of[g] = sid;
+                ++g;
+            }
+            c->stripe_genes_host.push_back(make_int2(first_gene, count));
+        }
+        if (c->stripe_genes_host.empty()) c->stripe_genes_host.push_back(make_int2(0, 0));
+        if ((rc = upload(c, c->g_stripe_of, stripe_of.data(), stripe_of.size() * 4))) return rc;
+        if ((rc = upload(c, c->g_stripe_genes, c->stripe_genes_host.data(), c->stripe_genes_host.size() * sizeof(int2)))) return rc;
+        if ((rc = upload(c, c->g_gene_off, genome_off, ((size_t)n_genomes + 1) * 4))) return rc;
+    }
     c->genes_by_index = c->gene_index_opt != 0;
     c->genes_set = true;
+    c->sb_valid = false;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_genomes = n_genomes;
     c->n_genes = n_genes;
@@ -2482,9 +2532,20 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (hipEvent_t& ev : c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    const int k = c->copy_next;
-    if (c->copy_src[k]) return fail(c, WK_E_STATE, "more than %d blocks copied ahead of the scan", wk_ctx::kTextBufs - 1);
-    c->copy_next = (c->copy_next + 1) % wk_ctx::kTextBufs;
+    int k = -1;
+    {
+        std::lock_guard<std::mutex> lock(c->copy_mu);
+        for (int q = 0; q < wk_ctx::kTextBufs && k < 0; ++q) {
+            const int cand = (c->copy_next + q) % wk_ctx::kTextBufs;
+            if (c->buf_state[cand] == wk_ctx::kBufFree) k = cand;
+        }
+        if (k >= 0) {
+            c->buf_state[k] = wk_ctx::kBufCopied;
+            c->copy_src[k] = nullptr;  // (tagged below, once the copy is queued)
+            c->copy_next = (k + 1) % wk_ctx::kTextBufs;
+        }
+    }
+    if (k < 0) return fail(c, WK_E_STATE, "more than %d blocks copied ahead of the scan", wk_ctx::kTextBufs - 1);
     const uint32_t n = (uint32_t)n64;
     HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
     // (only the copy on this stream: the 64 zero bytes behind the text are a fill
@@ -2511,8 +2572,11 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
         c->copy_counted[k] = true;
     }
     HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->copy_stream));
-    c->copy_src[k] = text + begin;
-    c->copy_n[k] = n;
+    {
+        std::lock_guard<std::mutex> lock(c->copy_mu);
+        c->copy_n[k] = n;
+        c->copy_src[k] = text + begin;
+    }
     return WK_OK;
 }
 
@@ -2648,26 +2712,43 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             resident = r.dev;
             res = &r;
         }
-    for (int q = 0; q < wk_ctx::kTextBufs && !resident; ++q)
-        if (c->copy_src[q] == src && c->copy_n[q] == n) k = q;
+    bool counted = false;
+    {
+        std::lock_guard<std::mutex> lock(c->copy_mu);
+        // (the buffer of the block scanned before is free from here on: its kernels have been waited for)
+        for (int q = 0; q < wk_ctx::kTextBufs; ++q)
+            if (c->buf_state[q] == wk_ctx::kBufScanning) c->buf_state[q] = wk_ctx::kBufFree;
+        for (int q = 0; q < wk_ctx::kTextBufs && !resident; ++q)
+            if (c->buf_state[q] == wk_ctx::kBufCopied && c->copy_src[q] == src && c->copy_n[q] == n) k = q;
+        if (!resident && k < 0) {  // not copied ahead: a free buffer, copied into below
+            for (int q = 0; q < wk_ctx::kTextBufs && k < 0; ++q) {
+                const int cand = (c->copy_next + q) % wk_ctx::kTextBufs;
+                if (c->buf_state[cand] == wk_ctx::kBufFree) k = cand;
+            }
+            if (k < 0) return fail(c, WK_E_STATE, "every text buffer holds a block copied ahead");
+            c->copy_counted[k] = false;
+            c->copy_src[k] = nullptr;
+            k = -1 - k;  // (marks "copy now")
+        } else if (!resident) {
+            counted = c->copy_counted[k];
+        }
+        if (!resident) {
+            const int kk = k >= 0 ? k : -1 - k;
+            c->buf_state[kk] = wk_ctx::kBufScanning;
+            c->copy_src[kk] = nullptr;  // (the buffer's tag is used up)
+            c->copy_counted[kk] = false;
+        }
+    }
     if (resident) {
         // (measurement: the block is on the device already, 64 zero bytes behind it)
     } else if (k >= 0) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));  // (the pad: zeroed by the count behind the copy)
     } else {
-        k = c->copy_next;  // (a buffer no block copied ahead is waiting in)
-        for (int q = 0; q < wk_ctx::kTextBufs && c->copy_src[k]; ++q) k = (k + 1) % wk_ctx::kTextBufs;
-        if (c->copy_src[k]) return fail(c, WK_E_STATE, "every text buffer holds a block copied ahead");
-        if (k == c->copy_next) c->copy_next = (c->copy_next + 1) % wk_ctx::kTextBufs;
+        k = -1 - k;
         HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
         HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));  // (the pad: zeroed by the count below)
     }
-    const bool counted = !resident && c->copy_src[k] == src && c->copy_counted[k];
-    if (!resident) {
-        c->copy_src[k] = nullptr;  // (the buffer's tag is used up)
-        c->copy_counted[k] = false;
-        c->dt_cur = k;
-    }
+    if (!resident) c->dt_cur = k;
     c->dt_text = resident ? resident : c->d_textbuf[k].as<unsigned char>();
     // line starts: newlines per tile -> offsets -> positions
     const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
@@ -3208,6 +3289,7 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
     c->group_base = 0;
     c->rk_valid[0] = c->rk_valid[1] = false;
     c->ord_valid = true;
+    c->sb_valid = false;
     c->chunk_valid = false;
     *n_reads = reads;
     *n_hits = hits;
@@ -3241,6 +3323,7 @@ int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const
     c->group_base = 0;
     c->rk_valid[0] = c->rk_valid[1] = false;
     c->ord_valid = true;
+    c->sb_valid = false;
     c->chunk_valid = false;
     return WK_OK;
 }
@@ -3419,23 +3502,9 @@ int wk_set_uniform_group(wk_ctx* c, int32_t group) {
     return WK_OK;
 }
 
-int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
-    if (!c) return WK_E_ARG;
-    if (!c->ord_valid) return fail(c, WK_E_STATE, "no ordinal chunk staged");
-    if (!c->genes_set) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
-    if (n_jobs < 1 || n_jobs > WK_MAX_JOBS || !jobs) return fail(c, WK_E_ARG, "n_jobs must be in [1, %d]", WK_MAX_JOBS);
-    // the genes themselves are counted (rank none, one group, no size
-    // normalisation): tallied per read straight from the matches
-    bool tally = c->use_tally && !c->has_group && !c->genes_by_index && c->slots > 0 && c->n_hits > 0 && c->o_reads > 0;
-    for (int j = 0; j < n_jobs && tally; ++j)
-        tally = jobs[j].mode == WK_MODE_NONE && !(jobs[j].flags & (WK_F_UNIQ | WK_F_SIZED));
-    if (!tally) {
-        int rc = wk_ordinal_match(c);
-        if (rc) return rc;
-        return wk_classify_staged(c, jobs, n_jobs, nullptr);
-    }
-    DeviceGuard guard(c->device);
-    KtScope kt_scope(c);
+// The genes of the staged chunk's reads counted straight from the matches (rank none, one group): the
+// gather kernels of wk_ordinal.hpp over c->o_* (match_hits -> first2 -> ordinal_tally -> log -> merge).
+static int tally_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     int rc = reserve_match_buffers(c);
     if (rc) return rc;
     // (without the per-hit counts: they are only needed for reads the tally
@@ -3515,6 +3584,162 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     rc = wk_classify_staged(c, jobs, n_jobs, nullptr);
     c->listed_only = false;
     return rc;
+}
+
+
+// ---- the sorted coord-match (wk_stripe.hpp) ------------------------------------------------------
+static StripeSortArgs stripe_sort_args(wk_ctx* c, uint32_t n_tiles) {
+    StripeSortArgs a{};
+    a.genome = c->o_genome.as<int32_t>();
+    a.beg = c->o_beg.as<int32_t>();
+    a.end = c->o_end.as<int32_t>();
+    a.len = c->o_len.as<uint32_t>();
+    a.hoff = c->o_hoff.as<int32_t>();
+    a.n_reads = c->o_reads;
+    a.stripe_of = c->g_stripe_of.as<int32_t>();
+    a.n_genomes = c->n_genomes;
+    a.n_stripes = (uint32_t)c->stripe_genes_host.size();
+    a.n_tiles = n_tiles;
+    a.cnt = c->sb_cnt.as<uint32_t>();
+    a.row_base = c->sb_base.as<unsigned long long>();
+    a.binned = c->sb_binned.as<int4>();
+    a.r_genome = c->r_genome.as<int32_t>();
+    a.r_beg = c->r_beg.as<int32_t>();
+    a.r_end = c->r_end.as<int32_t>();
+    a.r_len = c->r_len.as<uint32_t>();
+    a.r_hoff = c->r_hoff.as<int32_t>();
+    return a;
+}
+
+// The staged chunk sorted: reads of one hit by genome stripe, the others compacted (once per staged chunk).
+static int stripe_sort(wk_ctx* c) {
+    if (c->sb_valid) return WK_OK;
+    const uint32_t n_stripes = (uint32_t)c->stripe_genes_host.size();
+    const uint32_t n_tiles = (uint32_t)((c->o_reads + kStripeTileReads - 1) / kStripeTileReads);
+    const size_t rows = (size_t)n_stripes + 2;
+    HIP_TRY(c, c->sb_cnt.reserve(rows * n_tiles * 4));
+    HIP_TRY(c, c->sb_tot.reserve(rows * 8));
+    HIP_TRY(c, c->sb_base.reserve(rows * 8));
+    // (every read could have one hit, or none: both outputs sized for the chunk)
+    HIP_TRY(c, c->sb_binned.reserve((size_t)std::max<int64_t>(c->o_reads, 1) * 16));
+    HIP_TRY(c, c->r_genome.reserve((size_t)std::max<int64_t>(c->n_hits, 1) * 4));
+    HIP_TRY(c, c->r_beg.reserve((size_t)std::max<int64_t>(c->n_hits, 1) * 4));
+    HIP_TRY(c, c->r_end.reserve((size_t)std::max<int64_t>(c->n_hits, 1) * 4));
+    HIP_TRY(c, c->r_len.reserve((size_t)std::max<int64_t>(c->n_hits, 1) * 4));
+    HIP_TRY(c, c->r_hoff.reserve(((size_t)c->o_reads + 1) * 4));
+    const StripeSortArgs a = stripe_sort_args(c, n_tiles);
+    KernelTimer* kt = ktimer_begin(c, "stripe_sort");
+    hipLaunchKernelGGL(stripe_count_kernel, dim3(n_tiles), dim3(kStripeTileThreads), 0, c->stream, a);
+    hipLaunchKernelGGL(stripe_rows_kernel, dim3((unsigned)rows), dim3(1024), 0, c->stream, c->sb_cnt.as<uint32_t>(), n_tiles,
+                       c->sb_tot.as<unsigned long long>());
+    hipLaunchKernelGGL(stripe_bases_kernel, dim3(1), dim3(64), 0, c->stream, c->sb_tot.as<unsigned long long>(),
+                       c->sb_base.as<unsigned long long>(), n_stripes);
+    hipLaunchKernelGGL(stripe_scatter_kernel, dim3(n_tiles), dim3(kStripeTileThreads), 0, c->stream, a);
+    ktimer_end(c, kt);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<unsigned long long> tot(rows);
+    HIP_TRY(c, hipMemcpyAsync(tot.data(), c->sb_tot.p, rows * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the pieces of the stripes' hits, one workgroup each
+    std::vector<StripeUnit> units;
+    unsigned long long first = 0;
+    for (uint32_t s = 0; s < n_stripes; ++s) {
+        for (unsigned long long at = 0; at < tot[s]; at += kStripePiece)
+            units.push_back(StripeUnit{s, (uint32_t)(first + at), (uint32_t)std::min<unsigned long long>(kStripePiece, tot[s] - at), 0u});
+        first += tot[s];
+    }
+    c->sb_single = (int64_t)first;
+    c->sb_rest_reads = (int64_t)tot[n_stripes];
+    c->sb_rest_hits = (int64_t)tot[n_stripes + 1];
+    c->sb_n_units = (uint32_t)units.size();
+    if (!units.empty()) {
+        int rc = upload(c, c->sb_units, units.data(), units.size() * sizeof(StripeUnit));
+        if (rc) return rc;
+    }
+    const int32_t end = (int32_t)c->sb_rest_hits;  // r_hoff's last entry
+    HIP_TRY(c, hipMemcpyAsync(c->r_hoff.as<int32_t>() + c->sb_rest_reads, &end, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sb_valid = true;
+    return WK_OK;
+}
+
+static int stripe_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
+    int rc = stripe_sort(c);
+    if (rc) return rc;
+    HIP_TRY(c, c->sb_stat.reserve(64));
+    HIP_TRY(c, hipMemsetAsync(c->sb_stat.p, 0, 64, c->stream));
+    StripeMatchArgs m{};
+    m.binned = c->sb_binned.as<int4>();
+    m.units = c->sb_units.as<StripeUnit>();
+    m.gene4 = c->gene4.as<int4>();
+    m.gene_off = c->g_gene_off.as<int32_t>();
+    m.stripe_genes = c->g_stripe_genes.as<int2>();
+    m.th = c->th;
+    m.n_jobs = n_jobs;
+    for (int j = 0; j < n_jobs; ++j) m.job_index[j] = j;
+    m.group = c->group_base;
+    m.table = CountTable{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
+    const uint32_t over_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->sb_single, 1), 1 << 24);
+    HIP_TRY(c, c->sb_over.reserve((size_t)over_cap * 4));
+    m.overflow = c->sb_over.as<uint32_t>();
+    m.overflow_cap = over_cap;
+    m.stat = c->sb_stat.as<unsigned long long>();
+    m.stat_block = c->stat_block.as<unsigned long long>();
+    if (c->sb_n_units) {
+        KernelTimer* kt = ktimer_begin(c, "stripe_match");
+        hipLaunchKernelGGL(stripe_match_kernel, dim3(c->sb_n_units), dim3(kStripeMatchThreads), (size_t)kStripeGenes * 24, c->stream, m);
+        ktimer_end(c, kt);
+        HIP_TRY(c, hipGetLastError());
+    }
+    unsigned long long stat[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(stat, c->sb_stat.p, 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (stat[2] > over_cap) return fail(c, WK_E_CAPACITY, "more than %u hits with three or more genes in one chunk", over_cap);
+    if (stat[2]) {
+        hipLaunchKernelGGL(stripe_overflow_kernel, dim3((unsigned)stat[2]), dim3(64), 0, c->stream, m, (uint32_t)stat[2]);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(stat, c->sb_stat.p, 24, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->stat_pairs += (int64_t)stat[1];
+    c->chunk_valid = false;
+    if (c->sb_rest_reads == 0) return WK_OK;
+    // the reads of several hits (and hits on genomes without a stripe): the gather kernels, over their own arrays
+    auto swap_rest = [&]() {
+        std::swap(c->o_genome, c->r_genome);
+        std::swap(c->o_beg, c->r_beg);
+        std::swap(c->o_end, c->r_end);
+        std::swap(c->o_len, c->r_len);
+        std::swap(c->o_hoff, c->r_hoff);
+        std::swap(c->n_hits, c->sb_rest_hits);
+        std::swap(c->o_reads, c->sb_rest_reads);
+    };
+    swap_rest();
+    rc = tally_count(c, jobs, n_jobs);
+    swap_rest();
+    return rc;
+}
+
+int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
+    if (!c) return WK_E_ARG;
+    if (!c->ord_valid) return fail(c, WK_E_STATE, "no ordinal chunk staged");
+    if (!c->genes_set) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
+    if (n_jobs < 1 || n_jobs > WK_MAX_JOBS || !jobs) return fail(c, WK_E_ARG, "n_jobs must be in [1, %d]", WK_MAX_JOBS);
+    // the genes themselves are counted (rank none, one group, no size
+    // normalisation): tallied per read straight from the matches
+    bool tally = c->use_tally && !c->has_group && !c->genes_by_index && c->slots > 0 && c->n_hits > 0 && c->o_reads > 0;
+    for (int j = 0; j < n_jobs && tally; ++j)
+        tally = jobs[j].mode == WK_MODE_NONE && !(jobs[j].flags & (WK_F_UNIQ | WK_F_SIZED));
+    if (!tally) {
+        int rc = wk_ordinal_match(c);
+        if (rc) return rc;
+        return wk_classify_staged(c, jobs, n_jobs, nullptr);
+    }
+    DeviceGuard guard(c->device);
+    KtScope kt_scope(c);
+    const size_t n_stripes = c->stripe_genes_host.size();
+    if (c->use_stripes && n_stripes >= 1 && n_stripes <= kStripeMax && c->stripe_genes_host[0].y > 0) return stripe_count(c, jobs, n_jobs);
+    return tally_count(c, jobs, n_jobs);
 }
 
 int wk_chunk_download(wk_ctx* c, int32_t* subj, int64_t subj_cap, int32_t* qoff, int64_t qoff_cap, int64_t* n_records,

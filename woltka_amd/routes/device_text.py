@@ -167,7 +167,7 @@ class DeviceTextRoute:
 
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
     DTOK_READ_PIECE = int(os.environ.get('WOLTKA_READ_PIECE', 8 << 20))   # bytes per pread of the block reader's threads
-    DTOK_AHEAD = 2              # blocks copied to the device ahead of the one being scanned (wk_ctx::kTextBufs - 1)
+    DTOK_AHEAD = 3              # blocks copied to the device ahead of the one being scanned (wk_ctx::kTextBufs - 1)
     DTOK_HEADROOM = 1 << 20     # room in front of a block's bytes for the run the block before left unfinished
     HOSTREG_PIECE = 256 << 20   # a file is pinned in place in pieces of this size (a multiple of the page size)
     HOSTREG_MIN = 64 << 20      # smaller files are read into pinned buffers
@@ -570,15 +570,34 @@ class DeviceTextRoute:
                 elif slot is not None:
                     ring.release(slot)
 
-        # the copy of a block's text to the device starts two blocks ahead
-        # (three text buffers on the device): the link is never left waiting
-        # for this thread, and a block's copy is long done when its turn comes
-        from collections import deque
-        ahead = deque()
+        # The copy of a block's text to the device is issued by the reader
+        # thread itself, as soon as the block is cut (`wk_dtok_copy` may be
+        # called beside the scans): the link never waits for this thread --
+        # issuing a copy between two scans left it idle for a third of a
+        # block's time.  Up to DTOK_AHEAD blocks are on their way or waiting on
+        # the device (wk_ctx::kTextBufs - 1); a block's buffer there is free
+        # again when the loop comes back for the next one.
+        import threading
+        free_bufs = threading.Semaphore(self.DTOK_AHEAD)
+        stop = threading.Event()
+
+        def copied(gen):
+            for item in gen:
+                if item[0] is not None:         # (pinned: an asynchronous copy)
+                    while not free_bufs.acquire(timeout=0.05):
+                        if stop.is_set():
+                            return
+                    t0 = time.perf_counter()
+                    self.ctx.dtok_copy(item[1], item[3], item[4])
+                    lap['copy'] += time.perf_counter() - t0
+                yield item
+
         t_all = time.perf_counter()
         whole = open_mapped() if source is None else None
-        it = _prefetch(blocks_stream() if source is not None else
-                       blocks() if whole is None else blocks_mapped(whole))
+        it = _prefetch(copied(blocks_stream() if source is not None else
+                              blocks() if whole is None
+                              else blocks_mapped(whole)),
+                       depth=self.DTOK_AHEAD)
         try:
             while True:
                 t0 = time.perf_counter()
@@ -586,16 +605,11 @@ class DeviceTextRoute:
                 lap['wait'] += time.perf_counter() - t0
                 if item is None:
                     break
-                if item[0] is not None:         # (pinned: an asynchronous copy)
-                    t0 = time.perf_counter()
-                    self.ctx.dtok_copy(item[1], item[3], item[4])
-                    lap['copy'] += time.perf_counter() - t0
-                ahead.append(item)
-                if len(ahead) > self.DTOK_AHEAD:
-                    yield from one(ahead.popleft())
-            while ahead:
-                yield from one(ahead.popleft())
+                yield from one(item)
+                if item[0] is not None:
+                    free_bufs.release()
         finally:
+            stop.set()
             if whole is not None:
                 # (every copy has been waited for by the kernels of its block;
                 # a consumer that stopped early may have left one in flight)
