@@ -248,7 +248,7 @@ class LcaWorkload:
         del sidx
         # 4 B/record + 4 B/read + parent/last 8 B + 3 rank tables
         # (kept as the roofline's numerator so that rounds compare; the packed
-        # route itself streams 4 B/record and reads no offsets: DESIGN §3.0)
+        # route itself streams 4 B/record and reads no offsets: DESIGN_HISTORY §3.0)
         self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
                           8 * h.n_nodes + 3 * 4 * h.n_nodes)
         self.launch_bytes = self.alg_bytes
@@ -391,7 +391,7 @@ class OrdinalWorkload:
                      'x 500k genes, overlap 80, rank none')
         self.prob = p = synth.ordinal_problem(rng, n_pairs=n_pairs)
         if os.environ.get('WOLTKA_BENCH_SORT_HITS'):
-            # measurement only (what binning the hits by genome at
+            # measurement only (DESIGN_HISTORY §7, what binning the hits by genome at
             # staging would buy): the reads of one hit ordered by genome, the
             # others behind them as they came; the counts do not depend on it
             nh = np.diff(p['hoff'])
@@ -1947,6 +1947,9 @@ def run_rank(a, rank, world, local, sync):
                    'passes_per_step': passes,
                    'ms_per_pass': block['ms_per_pass'],
                    'timed_region_s': round(elapsed, 3),
+                   **({'sort_ms': block['sort_ms'],
+                       'ms_per_pass_with_sort': block['ms_per_pass_with_sort']}
+                      if 'sort_ms' in block else {}),
                    'sharding': f'samples x {world} ranks on {n_distinct} '
                                'GPU(s), no collective'},
         'roofline': block['roofline'],

@@ -8,7 +8,7 @@
 //   classify.counter / counter_strat (woltka/classify.py:144-171, 216-249)
 //   workflow.assign_readmap's Unassigned substitution (woltka/workflow.py:1038-1039)
 //
-// Kernels, in the order a chunk meets them:
+// Kernels, in the order a chunk meets them (DESIGN_HISTORY.md §3.1):
 //   count_subjects_kernel    pass 1 of the two-class split when the subject table
 //                            fits the LDS bins: histogram of the subject indices of
 //                            the reads with exactly one candidate + one "left for

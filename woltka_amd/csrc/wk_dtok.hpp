@@ -359,7 +359,10 @@ __device__ __forceinline__ const unsigned char* dtok_stage_lines(const DtokArgs&
     for (uint32_t off = threadIdx.x * 16u; off < hi - lo; off += kDtokThreads * 16u)
         *reinterpret_cast<uint4*>(stage + off) = *reinterpret_cast<const uint4*>(a.text + lo + off);  // (16 bytes may pass `hi`: the text's pad)
     __syncthreads();
-    return stage - lo;
+    // (as a flat address: the subtraction must not happen in the 32-bit LDS address space, where it wraps --
+    // the cast to a generic pointer comes first, the arithmetic is done on the 64-bit integer)
+    const unsigned char* flat = stage;
+    return reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(flat) - (uintptr_t)lo);
 }
 
 template <bool kEx>

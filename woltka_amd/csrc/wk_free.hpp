@@ -12,7 +12,7 @@
 // rewritten when a chunk is appended, words_to_ranks_kernel; when a later chunk
 // brings new subjects the ranks of the records accumulated so far are renumbered,
 // ranks_renumber_kernel).  Pre-order ids turn find_lca into "lowest ancestor of
-// the smallest id whose subtree holds the largest" (DESIGN §2), ranks keep the
+// the smallest id whose subtree holds the largest" (DESIGN.md §2), ranks keep the
 // order of the ids, so a read needs the minimum and the maximum of its records'
 // ranks and nothing else — and the tables of the look-ups are indexed by rank
 // (round 3's records carried node ids: two gathers of rank blocks per read, two
@@ -41,7 +41,7 @@ constexpr uint32_t kFreeThreads = 1024;
 struct FreeArgs {
     const uint32_t* words;  // [n_records] feature | position << 23 | size << 27
     uint32_t n_records;
-    // the lowest common ancestor without a walk over the distinct
+    // the lowest common ancestor without a walk (DESIGN_HISTORY §3.1c) over the distinct
     // subject nodes d_0 < d_1 < ... in pre-order, which the records name by their
     // index: sparse[k][i] = the smallest among LCA(d_j, d_j+1), j in [i, i + 2^k);
     // parent_d[i] = parent of d_i, self_d[i] = d_i — all three as *result ids*: the
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(kLogThreads) free_log_kernel(FreeLogArgs a) {
 }
 
 // the dense counters + the shares of free_log_kernel -> the count table (weight L
-// per read); the dense counters are cleared on the way
+// per read, DESIGN_HISTORY §3.2); the dense counters are cleared on the way
 __global__ void __launch_bounds__(256) free_counts_kernel(uint32_t* __restrict__ dense, uint32_t n_results,
                                                           const int32_t* __restrict__ result_node, uint32_t job, uint32_t group,
                                                           const uint32_t* __restrict__ partial, const uint32_t* __restrict__ part_used,

@@ -11,9 +11,10 @@
 //       as 16-byte records; the other reads (several hits: their genes are a union over hits) are
 //       compacted, in order, into arrays of their own and go through wk_ordinal.hpp's kernels;
 //   stripe_match   a workgroup takes a piece of one stripe's hits, loads the stripe's gene records
-//       into LDS once, finds every hit's genes there (binary search over the genome's starts, walk
-//       back while an earlier gene still reaches the hit: the predicate of wk_ordinal.hpp) and adds
-//       1/n to the genes' bins in LDS; the bins go to the count table when the piece is done.
+//       and coordinate grids into LDS once, finds every hit's genes there (the grid cell of re - rel,
+//       then a walk back while an earlier gene still reaches the hit: the predicate of
+//       wk_ordinal.hpp, in 32-bit arithmetic) and counts them in LDS (reads with one gene / with
+//       two); the counts go to the count table as 1/n weights when the piece is done.
 //       No first2[], no log, no merge pass; a hit is read once (16 bytes).
 //   stripe_overflow   hits with more than two genes (nested genes) are listed and counted by a
 //       workgroup each, exactly (distinct features, any number up to the count key's 4095).
@@ -25,13 +26,15 @@
 
 namespace wk {
 
-constexpr uint32_t kStripeGenes = 3072;      // gene records of a stripe (48 KB of LDS) and as many 64-bit bins (24 KB)
+constexpr uint32_t kStripeGenes = 2048;      // gene records of a stripe (32 KB of LDS) and two 32-bit counters each (16 KB)
+constexpr uint32_t kStripeCells = 6144;      // cells of the stripe's coordinate grids (12 KB as 16-bit gene indices)
+constexpr uint32_t kStripeGenomes = 256;     // genomes of a stripe (4 KB of per-genome words)
 constexpr uint32_t kStripeMax = 1024;        // stripes a chunk can be sorted into (per-tile counters in LDS)
 constexpr uint32_t kStripeTileThreads = 256;
 constexpr uint32_t kStripeTileItems = 8;
 constexpr uint32_t kStripeTileReads = kStripeTileThreads * kStripeTileItems;  // reads per workgroup of the count / scatter passes
-constexpr uint32_t kStripeMatchThreads = 512;
-constexpr uint32_t kStripePiece = 32768;     // hits per workgroup of stripe_match
+constexpr uint32_t kStripeMatchThreads = 1024;
+constexpr uint32_t kStripePiece = 65536;     // hits per workgroup of stripe_match
 constexpr uint32_t kStripeStatBlocks = 4096; // (a part of the context's kStatBlocks pairs of statistics counters)
 
 struct StripeSortArgs {
@@ -210,12 +213,25 @@ struct StripeUnit {  // a piece of one stripe's hits
     uint32_t pad;
 };
 
+struct StripeInfo {  // a stripe: consecutive genomes, their genes and the cells of their coordinate grids
+    int32_t gene_lo, n_genes;
+    int32_t genome_lo, n_genomes;
+    int32_t cell_lo, n_cells;  // [cell_lo, cell_lo + n_cells) of the grid array (wk_set_genes), all genomes' cells + 1 each
+    int32_t pad0, pad1;
+};
+
 struct StripeMatchArgs {
     const int4* binned;
     const StripeUnit* units;
     const int4* gene4;         // wk_set_genes: {start0, end, largest end before the gene in its genome, feature}
     const int32_t* gene_off;   // [n_genomes + 1] genes of a genome
-    const int2* stripe_genes;  // [n_stripes] {first gene, number of genes}
+    const StripeInfo* stripes;
+    // the coordinate grids of wk_set_genes (wk_ordinal.hpp): per genome cells + 1 entries of grid, its smallest
+    // start, the offset of its cells, the cell width as a shift
+    const int32_t* grid;
+    const int32_t* gfirst;
+    const int32_t* goff;
+    const unsigned char* gshift;
     double th;
     int32_t n_jobs;
     int32_t job_index[WK_MAX_JOBS];
@@ -227,44 +243,54 @@ struct StripeMatchArgs {
     unsigned long long* stat_block;  // the context's (reads, records) counters, kStripeStatBlocks pairs
 };
 
+// A piece of one stripe's hits against the stripe's genes in LDS.  Per hit: the cell of re - rel in the
+// genome's grid (LDS) names the last gene that can start early enough; the walk back from there tests
+//     gene (gs, ge) matches hit (rs, re, rel)  <=>  min(ge, re) - max(gs, rs) >= rel
+//                                             <=>  ge - gs >= rel, ge >= rs + rel, gs <= re - rel  (and re - rs >= rel)
+// in 32-bit arithmetic (the three bounds are per hit), and ends where no earlier gene's end reaches rs + rel.
 __global__ void __launch_bounds__(kStripeMatchThreads) stripe_match_kernel(StripeMatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int4* const genes = reinterpret_cast<int4*>(smem);
-    unsigned long long* const bins = reinterpret_cast<unsigned long long*>(smem + (size_t)kStripeGenes * 16);
+    uint32_t* const c1 = reinterpret_cast<uint32_t*>(smem + (size_t)kStripeGenes * 16);     // reads whose only gene it is
+    uint32_t* const c2 = c1 + kStripeGenes;                                                   // reads with two genes
+    int4* const ginfo = reinterpret_cast<int4*>(c2 + kStripeGenes);                           // {first start, cell offset, cells, shift}
+    unsigned short* const lgrid = reinterpret_cast<unsigned short*>(ginfo + kStripeGenomes);  // [cells] gene index in the stripe
     __shared__ unsigned long long acc[2];
     const StripeUnit u = a.units[blockIdx.x];
-    const int2 sg = a.stripe_genes[u.stripe];
-    const int32_t g_lo = sg.x, n_g = sg.y;
-    for (int32_t i = threadIdx.x; i < n_g; i += blockDim.x) {
-        genes[i] = a.gene4[g_lo + i];
-        bins[i] = 0ull;
+    const StripeInfo si = a.stripes[u.stripe];
+    for (int32_t i = threadIdx.x; i < si.n_genes; i += blockDim.x) {
+        genes[i] = a.gene4[si.gene_lo + i];
+        c1[i] = 0u;
+        c2[i] = 0u;
+    }
+    for (int32_t i = threadIdx.x; i < si.n_cells; i += blockDim.x) lgrid[i] = (unsigned short)(a.grid[si.cell_lo + i] - si.gene_lo);
+    for (int32_t i = threadIdx.x; i < si.n_genomes; i += blockDim.x) {
+        const int32_t g = si.genome_lo + i;
+        const int32_t o0 = a.goff[g], o1 = a.goff[g + 1];
+        ginfo[i] = make_int4(a.gfirst[g], o0 - si.cell_lo, o1 - o0, (int32_t)a.gshift[g]);
     }
     if (threadIdx.x < 2) acc[threadIdx.x] = 0ull;
     __syncthreads();
-    unsigned long long my_reads = 0, my_pairs = 0;
+    uint32_t my_reads = 0, my_pairs = 0;
     for (uint32_t k = threadIdx.x; k < u.count; k += blockDim.x) {
         const int4 hit = a.binned[u.first + k];
-        const int64_t rs = hit.y, re = hit.z;
-        const int64_t rel = effective_len((uint32_t)hit.w, a.th);
-        // genes of the hit's genome, as indices into the stripe's records
-        const int32_t lo = a.gene_off[hit.x] - g_lo, hi = a.gene_off[hit.x + 1] - g_lo;
-        // the last gene that starts at or before re - rel (later ones cannot overlap by rel)
-        const int64_t t = re - rel;
-        int32_t l = lo, h = hi;  // first gene with start > t
-        while (l < h) {
-            const int32_t m = (l + h) >> 1;
-            if ((int64_t)genes[m].x <= t)
-                l = m + 1;
-            else
-                h = m;
-        }
+        const int32_t rs = hit.y, re = hit.z;
+        const int64_t rel64 = effective_len((uint32_t)hit.w, a.th);
+        const int64_t a64 = (int64_t)rs + rel64, b64 = (int64_t)re - rel64;
+        // (a hit shorter than rel, or bounds no 32-bit coordinate can meet: no gene)
+        if (rel64 > 0xFFFFFFFFll || (int64_t)re - (int64_t)rs < rel64 || a64 > 0x7FFFFFFFll || b64 < -0x80000000ll) continue;
+        const uint32_t rel = (uint32_t)rel64;
+        const int32_t end_min = (int32_t)a64, start_max = (int32_t)b64;
+        const int4 gi = ginfo[hit.x - si.genome_lo];
+        if (gi.z <= 1 || start_max < gi.x) continue;  // a genome without genes / every gene starts too late
+        uint32_t cell = (uint32_t)(start_max - gi.x) >> gi.w;
+        const uint32_t last = (uint32_t)gi.z - 2u;
+        cell = cell > last ? last : cell;
+        int32_t j = (int32_t)lgrid[gi.y + (int32_t)cell + 1] - 1;  // (>= the genome's first gene: its cell is <= start_max's)
         int32_t n = 0, fx = -1, fy = -1, ix = -1, iy = -1;
-        const int64_t min_end = rs + rel;
-        for (int32_t j = l - 1; j >= lo; --j) {
+        for (;; --j) {
             const int4 g = genes[j];
-            const int64_t gs = g.x, ge = g.y;
-            const int64_t ov = (ge < re ? ge : re) - (gs > rs ? gs : rs);
-            if (ov >= rel) {
+            if ((uint32_t)(g.y - g.x) >= rel && g.y >= end_min && g.x <= start_max) {
                 if (n == 0) {
                     fx = g.w;
                     ix = j;
@@ -274,7 +300,7 @@ __global__ void __launch_bounds__(kStripeMatchThreads) stripe_match_kernel(Strip
                 }
                 n += 1;
             }
-            if ((int64_t)g.z < min_end) break;  // nothing before j reaches the hit
+            if (g.z < end_min) break;  // nothing before j reaches the hit (first gene of a genome: INT32_MIN)
         }
         if (n == 0) continue;
         if (n > 2) {  // (nested genes: counted exactly by stripe_overflow_kernel)
@@ -282,22 +308,23 @@ __global__ void __launch_bounds__(kStripeMatchThreads) stripe_match_kernel(Strip
             if (at < a.overflow_cap) a.overflow[at] = u.first + k;
             continue;
         }
-        my_reads += 1;
-        my_pairs += (unsigned long long)n;
-        const bool two = n == 2 && fy != fx;  // (two rows of one gene id are one gene: ordinal.py:331-332 builds a set)
-        const unsigned long long w = (unsigned long long)weight_of(two ? 2u : 1u);
-        atomicAdd(&bins[ix], w);
-        if (two) atomicAdd(&bins[iy], w);
+        my_reads += 1u;
+        my_pairs += (uint32_t)n;
+        if (n == 2 && fy != fx) {  // (two rows of one gene id are one gene: ordinal.py:331-332 builds a set)
+            atomicAdd(&c2[ix], 1u);
+            atomicAdd(&c2[iy], 1u);
+        } else {
+            atomicAdd(&c1[ix], 1u);
+        }
     }
-    my_reads = wave_sum(my_reads);
-    my_pairs = wave_sum(my_pairs);
+    const unsigned long long w_reads = wave_sum((unsigned long long)my_reads), w_pairs = wave_sum((unsigned long long)my_pairs);
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        atomicAdd(&acc[0], my_reads);
-        atomicAdd(&acc[1], my_pairs);
+        atomicAdd(&acc[0], w_reads);
+        atomicAdd(&acc[1], w_pairs);
     }
     __syncthreads();
-    for (int32_t i = threadIdx.x; i < n_g; i += blockDim.x) {
-        const unsigned long long w = bins[i];
+    for (int32_t i = threadIdx.x; i < si.n_genes; i += blockDim.x) {
+        const unsigned long long w = (unsigned long long)c1[i] * weight_of(1u) + (unsigned long long)c2[i] * weight_of(2u);
         if (!w) continue;
         const uint32_t feature = (uint32_t)genes[i].w;
         for (int32_t jb = 0; jb < a.n_jobs; ++jb) table_add(a.table, make_key((uint32_t)a.job_index[jb], 0u, (uint32_t)a.group, feature), w);
@@ -311,6 +338,8 @@ __global__ void __launch_bounds__(kStripeMatchThreads) stripe_match_kernel(Strip
         if (acc[1]) atomicAdd(&a.stat_block[2 * sb + 1], acc[1]);
     }
 }
+
+constexpr size_t kStripeMatchLds = (size_t)kStripeGenes * 16 + (size_t)kStripeGenes * 8 + (size_t)kStripeGenomes * 16 + (size_t)kStripeCells * 2 + 64;
 
 // A hit with more than two genes: a wave collects them all, keeps the distinct features and adds 1/n to each
 // (n <= 16: in units of 1/L like everything else; beyond: under the key's k, which classify.counter's

@@ -166,8 +166,9 @@ struct wk_ctx {
     double th = 0.8;
     bool ord_valid = false;
     // hits binned by genome stripe (wk_stripe.hpp): the stripes of the gene tables, the sorted chunk
-    DevBuf g_gene_off, g_stripe_of, g_stripe_genes;
-    std::vector<int2> stripe_genes_host;
+    DevBuf g_gene_off, g_stripe_of, g_stripes;
+    std::vector<StripeInfo> stripes_host;
+    bool stripes_usable = false;
     int use_stripes = 1;       // (0: the gather kernels of wk_ordinal.hpp for every read; measurement)
     DevBuf sb_cnt, sb_tot, sb_base, sb_binned, sb_units, sb_over, sb_stat;
     DevBuf r_genome, r_beg, r_end, r_len, r_hoff;
@@ -247,7 +248,7 @@ struct wk_ctx {
     std::vector<HostReg> regs;
     int w_mode = 0;  // 0: subject indices for the weighted histogram; the stream of wk_free.hpp: 1: feature ids (one free-rank job), 2: ancestors at the job's rank (one rank job under --uniq / --above / --major), 3: subject indices, rewritten per job when the sample is classified (several such jobs)
     int rank_serial = 0;              // bumped by wk_build_rank_table
-    int free_per_cu = 2, free_threads = 1024, free_slots = 4096;  // launch shape of the free-rank stream (measurement knobs)  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
+    int free_per_cu = 2, free_threads = 1024, free_slots = 4096;  // launch shape of the free-rank stream (measurement knobs; DESIGN_HISTORY §3.1d)  // measurement knobs of the free-rank stream: workgroups per CU, windows in flight per wave
     int32_t max_gene_feature = 0;
     int use_range_log = 1;  // (0: the hashed miss log for the gene tally too; measurement)
     int words_keep = 0;  // measurement: wk_words_flush leaves the accumulated records in place
@@ -802,7 +803,9 @@ int wk_create(int device, wk_ctx** out) {
     }
     // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
     // (160 KiB per CU minus the kernels' few bytes of static LDS)
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<false>),
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stripe_match_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripeMatchLds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
@@ -1214,31 +1217,39 @@ int wk_set_genes(wk_ctx* c, const int32_t* genome_off, int32_t n_genomes, const 
     if ((rc = upload(c, c->g_goff, goff.data(), goff.size() * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->g_shift, shift.data(), shift.size()))) return rc;
     if ((rc = upload(c, c->g_feature, gene_feature, (size_t)n_genes * 4))) return rc;
-    // genome stripes for the sorted coord-match (wk_stripe.hpp): consecutive genomes while their genes fit
-    // the LDS; a genome with more genes than that has no stripe (its hits keep the gather kernels)
+    // genome stripes for the sorted coord-match (wk_stripe.hpp): consecutive genomes while their genes, the
+    // cells of their grids and their per-genome words fit the LDS; a genome that does not fit alone has no
+    // stripe (its hits keep the gather kernels)
     {
         std::vector<int32_t> stripe_of((size_t)std::max(n_genomes, 1), -1);
-        c->stripe_genes_host.clear();
+        c->stripes_host.clear();
+        auto genes_of = [&](int32_t g) { return genome_off[g + 1] - genome_off[g]; };
+        auto cells_of = [&](int32_t g) { return goff[g + 1] - goff[g]; };
         int32_t g = 0;
         while (g < n_genomes) {
-            const int32_t n_g = genome_off[g + 1] - genome_off[g];
-            if ((uint32_t)n_g > kStripeGenes) {
+            if ((uint32_t)genes_of(g) > kStripeGenes || (uint32_t)cells_of(g) > kStripeCells) {
                 ++g;
                 continue;
             }
-            const int32_t first_gene = genome_off[g];
-            int32_t count = 0;
-            const int32_t sid = (int32_t)c->stripe_genes_host.size();
-            while (g < n_genomes && (uint32_t)(count + genome_off[g + 1] - genome_off[g]) <= kStripeGenes) {
-                count += genome_off[g + 1] - genome_off[g];
+            StripeInfo si{};
+            si.gene_lo = genome_off[g];
+            si.genome_lo = g;
+            si.cell_lo = goff[g];
+            const int32_t sid = (int32_t)c->stripes_host.size();
+            while (g < n_genomes && (uint32_t)(si.n_genes + genes_of(g)) <= kStripeGenes && (uint32_t)(si.n_cells + cells_of(g)) <= kStripeCells &&
+                   (uint32_t)si.n_genomes < kStripeGenomes) {
+                si.n_genes += genes_of(g);
+                si.n_cells += cells_of(g);
+                si.n_genomes += 1;
                 stripe_of[g] = sid;
                 ++g;
             }
-            c->stripe_genes_host.push_back(make_int2(first_gene, count));
+            c->stripes_host.push_back(si);
         }
-        if (c->stripe_genes_host.empty()) c->stripe_genes_host.push_back(make_int2(0, 0));
+        c->stripes_usable = !c->stripes_host.empty() && n_genes > 0;
+        if (c->stripes_host.empty()) c->stripes_host.push_back(StripeInfo{});
         if ((rc = upload(c, c->g_stripe_of, stripe_of.data(), stripe_of.size() * 4))) return rc;
-        if ((rc = upload(c, c->g_stripe_genes, c->stripe_genes_host.data(), c->stripe_genes_host.size() * sizeof(int2)))) return rc;
+        if ((rc = upload(c, c->g_stripes, c->stripes_host.data(), c->stripes_host.size() * sizeof(StripeInfo)))) return rc;
         if ((rc = upload(c, c->g_gene_off, genome_off, ((size_t)n_genomes + 1) * 4))) return rc;
     }
     c->genes_by_index = c->gene_index_opt != 0;
@@ -3598,7 +3609,7 @@ static StripeSortArgs stripe_sort_args(wk_ctx* c, uint32_t n_tiles) {
     a.n_reads = c->o_reads;
     a.stripe_of = c->g_stripe_of.as<int32_t>();
     a.n_genomes = c->n_genomes;
-    a.n_stripes = (uint32_t)c->stripe_genes_host.size();
+    a.n_stripes = (uint32_t)c->stripes_host.size();
     a.n_tiles = n_tiles;
     a.cnt = c->sb_cnt.as<uint32_t>();
     a.row_base = c->sb_base.as<unsigned long long>();
@@ -3614,7 +3625,7 @@ static StripeSortArgs stripe_sort_args(wk_ctx* c, uint32_t n_tiles) {
 // The staged chunk sorted: reads of one hit by genome stripe, the others compacted (once per staged chunk).
 static int stripe_sort(wk_ctx* c) {
     if (c->sb_valid) return WK_OK;
-    const uint32_t n_stripes = (uint32_t)c->stripe_genes_host.size();
+    const uint32_t n_stripes = (uint32_t)c->stripes_host.size();
     const uint32_t n_tiles = (uint32_t)((c->o_reads + kStripeTileReads - 1) / kStripeTileReads);
     const size_t rows = (size_t)n_stripes + 2;
     HIP_TRY(c, c->sb_cnt.reserve(rows * n_tiles * 4));
@@ -3673,7 +3684,11 @@ static int stripe_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     m.units = c->sb_units.as<StripeUnit>();
     m.gene4 = c->gene4.as<int4>();
     m.gene_off = c->g_gene_off.as<int32_t>();
-    m.stripe_genes = c->g_stripe_genes.as<int2>();
+    m.stripes = c->g_stripes.as<StripeInfo>();
+    m.grid = c->g_grid.as<int32_t>();
+    m.gfirst = c->g_first.as<int32_t>();
+    m.goff = c->g_goff.as<int32_t>();
+    m.gshift = c->g_shift.as<unsigned char>();
     m.th = c->th;
     m.n_jobs = n_jobs;
     for (int j = 0; j < n_jobs; ++j) m.job_index[j] = j;
@@ -3687,7 +3702,7 @@ static int stripe_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     m.stat_block = c->stat_block.as<unsigned long long>();
     if (c->sb_n_units) {
         KernelTimer* kt = ktimer_begin(c, "stripe_match");
-        hipLaunchKernelGGL(stripe_match_kernel, dim3(c->sb_n_units), dim3(kStripeMatchThreads), (size_t)kStripeGenes * 24, c->stream, m);
+        hipLaunchKernelGGL(stripe_match_kernel, dim3(c->sb_n_units), dim3(kStripeMatchThreads), kStripeMatchLds, c->stream, m);
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
     }
@@ -3737,8 +3752,7 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     }
     DeviceGuard guard(c->device);
     KtScope kt_scope(c);
-    const size_t n_stripes = c->stripe_genes_host.size();
-    if (c->use_stripes && n_stripes >= 1 && n_stripes <= kStripeMax && c->stripe_genes_host[0].y > 0) return stripe_count(c, jobs, n_jobs);
+    if (c->use_stripes && c->stripes_usable && c->stripes_host.size() <= kStripeMax) return stripe_count(c, jobs, n_jobs);
     return tally_count(c, jobs, n_jobs);
 }
 
