@@ -73,6 +73,31 @@ __device__ __forceinline__ uint32_t stripe_class(const StripeSortArgs& a, int64_
     return s < 0 ? a.n_stripes : (uint32_t)s;
 }
 
+// The lanes of a wave that name the same counter share ONE LDS atomic (a Zipf sample sends half of a
+// wave's reads to the same stripe: 64 atomics on one LDS word serialise).  Returns the lane's place among
+// all adds to that counter (the counter's old value + its rank among the lanes that share it).
+__device__ __forceinline__ uint32_t wave_shared_add(uint32_t* counters, uint32_t which, bool valid) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    unsigned long long todo = __ballot(valid);
+    uint32_t place = 0;
+    for (int round = 0; todo && round < 12; ++round) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t c = (uint32_t)__shfl((int)which, leader, kWave);
+        const bool mine = valid && which == c;
+        const unsigned long long same = __ballot(mine);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counters[c], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, kWave);
+        if (mine) {
+            place = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            valid = false;
+        }
+        todo &= ~same;
+    }
+    if (valid) place = atomicAdd(&counters[which], 1u);  // (a wave spread over many counters: the rest one by one)
+    return place;
+}
+
 // pass 1: per tile of reads, how many go where
 __global__ void __launch_bounds__(kStripeTileThreads) stripe_count_kernel(StripeSortArgs a) {
     __shared__ uint32_t cnt[kStripeMax + 2];
@@ -82,14 +107,11 @@ __global__ void __launch_bounds__(kStripeTileThreads) stripe_count_kernel(Stripe
 #pragma unroll
     for (uint32_t it = 0; it < kStripeTileItems; ++it) {
         const int64_t r = base + it * kStripeTileThreads + threadIdx.x;
-        if (r < a.n_reads) {
-            int32_t h0, nh;
-            const uint32_t cls = stripe_class(a, r, &h0, &nh);
-            if (cls != 0xFFFFFFFFu) {
-                atomicAdd(&cnt[cls], 1u);
-                if (cls == a.n_stripes) atomicAdd(&cnt[a.n_stripes + 1u], (uint32_t)nh);
-            }
-        }
+        int32_t h0 = 0, nh = 0;
+        uint32_t cls = 0xFFFFFFFFu;
+        if (r < a.n_reads) cls = stripe_class(a, r, &h0, &nh);
+        (void)wave_shared_add(cnt, cls, cls != 0xFFFFFFFFu);
+        if (cls == a.n_stripes) atomicAdd(&cnt[a.n_stripes + 1u], (uint32_t)nh);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < a.n_stripes + 2u; i += blockDim.x) a.cnt[(size_t)i * a.n_tiles + blockIdx.x] = cnt[i];
@@ -199,8 +221,15 @@ __global__ void __launch_bounds__(kStripeTileThreads) stripe_scatter_kernel(Stri
                 a.r_len[rh] = a.len[h];
                 ++rh;
             }
-        } else {
-            const uint32_t at = atomicAdd(&cur[cls[it]], 1u);
+        }
+    }
+    // the reads of one hit: a place in their stripe's run of this tile (lanes of a wave that share a stripe
+    // share the reservation)
+#pragma unroll
+    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
+        const bool one = cls[it] < a.n_stripes;
+        const uint32_t at = wave_shared_add(cur, one ? cls[it] : 0u, one);
+        if (one) {
             const int32_t h = h0[it];
             a.binned[a.row_base[cls[it]] + at] = make_int4(a.genome[h], a.beg[h], a.end[h], (int32_t)a.len[h]);
         }
