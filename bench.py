@@ -678,18 +678,27 @@ class TextLcaWorkload:
             raise RuntimeError(f'{reads} reads emitted, {self.reads} expected')
 
     def profile_step(self):
-        """One block (the largest) scanned + emitted, then flushed: the
-        brackets of the three tokenizer families are those of one block."""
+        """One block (the largest) scanned + emitted; its words are flushed at
+        the start of the next call, so that the event brackets that are read
+        after this one are those of the block's kernels (a later call of the
+        library re-records the event they start from)."""
         ctx = self.ctx
+        self._flush_probe()
         view, begin, stop, hdr = self.blocks[self._probe]
         ctx.words_begin(self.jobs, 0)
         ctx.dtok_scan_emit(self.tok, view, begin, stop)
-        ctx.words_flush()
+        self._probe_pending = True
+
+    def _flush_probe(self):
+        if getattr(self, '_probe_pending', False):
+            self.ctx.words_flush()
+            self._probe_pending = False
 
     def family_bytes(self, family):
         return self.launch_bytes
 
     def sync(self):
+        self._flush_probe()
         self.ctx.sync()
 
     def close(self):

@@ -26,8 +26,11 @@ def test_the_stub_of_integration_md_runs_as_written(monkeypatch):
     assert 'wk_classify_chunk' in code and 'wk_counts_fetch' in code
     monkeypatch.setenv('WOLTKA_HIP_LIB', nat.LIB_PATH)
     rng = np.random.default_rng(5)
-    prob = synth.lca_problem(rng, n_nodes=3000, n_subjects=300, n_reads=5000,
-                             dup_frac=0.05, offtree_frac=0.0)
+    # (reads are sets of subjects, as the mapper yields them: the stub passes
+    # WK_SUBJ_IS_SET)
+    prob = synth.as_sets(synth.lca_problem(rng, n_nodes=3000, n_subjects=300,
+                                           n_reads=5000, dup_frac=0.0,
+                                           offtree_frac=0.0))
     h = prob['hier']
     env = dict(parent=h.parent, last=h.last, rank_code=h.rank_code,
                n_nodes=h.n_nodes, code_of=dict(h.rank_codes),

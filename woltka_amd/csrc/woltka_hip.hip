@@ -193,6 +193,9 @@ struct wk_ctx {
     hipEvent_t kt_tail = nullptr;   // last event of the chain
     int kt_depth = 0;
     double lap_s[4] = {0, 0, 0, 0};   // (wk_tune "lap_print") seconds inside wk_dtok_copy / scan / waits of scan / emit
+    double lap_copy_ms = 0;           // ... and the copies' own durations (events around each on the copy stream)
+    int64_t lap_copy_bytes = 0;
+    hipEvent_t copy_ev0[4] = {};      // (kTextBufs) start of a block's copy
 
     int lds_slots = 8192;  // LDS front-cache slots per workgroup (16 B each = 128 KiB)
     int threads = 1024;    // workgroup size of the direct classify kernel
@@ -910,6 +913,8 @@ void wk_destroy(wk_ctx* c) {
     c->regs.clear();
     for (hipEvent_t ev : c->copy_ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->copy_ev0)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -1044,7 +1049,12 @@ int wk_tune(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "lap_print")) {
         fprintf(stderr, "[wk] seconds inside wk_dtok_copy %.3f, wk_dtok_scan(_emit) %.3f of which waiting for the stream %.3f, for the copy %.3f\n", c->lap_s[0],
                 c->lap_s[1], c->lap_s[2], c->lap_s[3]);
+        if (c->lap_copy_ms > 0)
+            fprintf(stderr, "[wk] the copies themselves: %.1f ms for %.2f GB = %.1f GB/s (events around each copy + newline count on the copy stream)\n",
+                    c->lap_copy_ms, (double)c->lap_copy_bytes / 1e9, (double)c->lap_copy_bytes / 1e6 / c->lap_copy_ms);
         c->lap_s[0] = c->lap_s[1] = c->lap_s[2] = c->lap_s[3] = 0;
+        c->lap_copy_ms = 0;
+        c->lap_copy_bytes = 0;
         return WK_OK;
     }
     if (!strcmp(name, "range_parts")) {  // partitions of the dense gene log (a power of two; 0 = auto)
@@ -2541,7 +2551,8 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     DeviceGuard guard(c->device);
     if (!c->copy_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (hipEvent_t& ev : c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (hipEvent_t& ev : c->copy_ev) HIP_TRY(c, hipEventCreate(&ev));
+        for (hipEvent_t& ev : c->copy_ev0) HIP_TRY(c, hipEventCreate(&ev));
     }
     int k = -1;
     {
@@ -2558,7 +2569,10 @@ int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
     }
     if (k < 0) return fail(c, WK_E_STATE, "more than %d blocks copied ahead of the scan", wk_ctx::kTextBufs - 1);
     const uint32_t n = (uint32_t)n64;
-    HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
+    // (at least a full block's worth from the start: a file's first blocks are small, and growing a buffer
+    // three times means three hipFree / hipMalloc pairs per buffer while the dictionary is cold)
+    HIP_TRY(c, c->d_textbuf[k].reserve(std::max<size_t>((size_t)n + 64, ((size_t)66 << 20) + 64)));
+    HIP_TRY(c, hipEventRecord(c->copy_ev0[k], c->copy_stream));
     // (only the copy on this stream: the 64 zero bytes behind the text are a fill
     // kernel, which wk_dtok_scan launches on its own stream behind the copy's event)
     HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, text + begin, (size_t)n, c->copy_stream));
@@ -2756,7 +2770,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));  // (the pad: zeroed by the count behind the copy)
     } else {
         k = -1 - k;
-        HIP_TRY(c, c->d_textbuf[k].reserve((size_t)n + 64));
+        HIP_TRY(c, c->d_textbuf[k].reserve(std::max<size_t>((size_t)n + 64, ((size_t)66 << 20) + 64)));
         HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));  // (the pad: zeroed by the count below)
     }
     if (!resident) c->dt_cur = k;
@@ -2783,6 +2797,15 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             Lap wait(&c->lap_s[3]);
             HIP_TRY(c, hipEventSynchronize(c->copy_ev[k]));
         }
+        {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->copy_ev0[k], c->copy_ev[k]) == hipSuccess) {
+                c->lap_copy_ms += ms;
+                c->lap_copy_bytes += n;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         n_newlines = c->copy_newlines[k];
         tile_off = c->d_tile_off_k[k].as<unsigned long long>();
     } else {
@@ -2798,16 +2821,19 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     }
     const bool open_end = src[n - 1] != '\n';  // a last line without newline
     const uint32_t lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
-    HIP_TRY(c, c->d_lines.reserve(((size_t)lines + 2) * 4));
-    HIP_TRY(c, c->d_lsubj.reserve(((size_t)lines + 1) * 4));
-    HIP_TRY(c, c->d_lmeta.reserve(((size_t)lines + 1) * 4));
-    HIP_TRY(c, c->d_start.reserve((size_t)lines + 64));
-    HIP_TRY(c, c->d_first.reserve((size_t)lines + 64));
+    // (sized for a full block of short lines from the first block on: a file's first blocks are small, and
+    // every growth is a hipFree -- which waits for the device -- and a hipMalloc per array)
+    const size_t cap_lines = std::max<size_t>(lines, (size_t)1 << 21);
+    HIP_TRY(c, c->d_lines.reserve((cap_lines + 2) * 4));
+    HIP_TRY(c, c->d_lsubj.reserve((cap_lines + 1) * 4));
+    HIP_TRY(c, c->d_lmeta.reserve((cap_lines + 1) * 4));
+    HIP_TRY(c, c->d_start.reserve(cap_lines + 64));
+    HIP_TRY(c, c->d_first.reserve(cap_lines + 64));
     if (extra) {
-        HIP_TRY(c, c->d_lbeg.reserve(((size_t)lines + 1) * 4));
-        HIP_TRY(c, c->d_lend.reserve(((size_t)lines + 1) * 4));
-        HIP_TRY(c, c->d_llen.reserve(((size_t)lines + 1) * 4));
-        HIP_TRY(c, c->d_lscan.reserve(((size_t)lines + 1) * 8));
+        HIP_TRY(c, c->d_lbeg.reserve((cap_lines + 1) * 4));
+        HIP_TRY(c, c->d_lend.reserve((cap_lines + 1) * 4));
+        HIP_TRY(c, c->d_llen.reserve((cap_lines + 1) * 4));
+        HIP_TRY(c, c->d_lscan.reserve((cap_lines + 1) * 8));
     }
     if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
     // (line 0 and the block's scalars are written by the lines kernel itself)

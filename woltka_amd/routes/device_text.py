@@ -15,6 +15,9 @@ from ..hostio import (MAX_GROUPS, ROUTES, MapWriter, StageRing, _prefetch,
                       tokenizer_threads)
 
 
+_HOSTREG_SLOW = {}     # st_dev -> pinning that file system's pages in place is slower than reading them
+
+
 class DeviceTextRoute:
     """(mixin of classify.Engine)"""
 
@@ -472,6 +475,14 @@ class DeviceTextRoute:
             mapping, the runtime refuses: the pread route then)."""
             if size < self.HOSTREG_MIN or os.environ.get('WOLTKA_NO_HOSTREG'):
                 return None
+            # (what the first file on a file system showed holds for the next:
+            # the probe below pins and unpins 256 MB, ~40 ms on tmpfs)
+            try:
+                dev_id = os.fstat(fd).st_dev
+            except OSError:
+                dev_id = None
+            if _HOSTREG_SLOW.get(dev_id) and not os.environ.get('WOLTKA_HOSTREG'):
+                return None
             import mmap
             try:
                 mm = mmap.mmap(fd, size, flags=mmap.MAP_SHARED,
@@ -498,6 +509,7 @@ class DeviceTextRoute:
                     not os.environ.get('WOLTKA_HOSTREG'):
                 self.ctx.host_unregister(mapped['base'])
                 mapped['reg'] = []
+                _HOSTREG_SLOW[dev_id] = True
                 return None
             return arr
 
