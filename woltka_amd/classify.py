@@ -20,7 +20,8 @@ from .hierarchy import FeatureIndex, flatten_hierarchy
 from .hostio import (MAX_GROUPS, ROUTES, MapWriter, StageRing,  # noqa: F401
                      _NO_TREE_ROOT, _BySubject, _Staged, _prefetch,
                      _take_context, cpu_budget, drop_context_ahead,
-                     open_context_ahead, tokenizer_threads)
+                     open_context_ahead, take_warm_tokenizer,
+                     tokenizer_threads, warm_tokenizer_ahead)
 from .routes.coords import CoordMatchRoute
 from .routes.device_text import DeviceTextRoute
 from .routes.fold import Folding, exact_to_numbers  # noqa: F401
@@ -304,7 +305,13 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         them)."""
         from .align import native_sam_blocks
         if self.tok is None:
-            self.tok = nat.Tokenizer(tokenizer_threads(), exclude)
+            # (a tokenizer whose dictionary was filled from this file's first
+            # bytes while the hierarchy was read: hostio.warm_tokenizer_ahead)
+            warm = take_warm_tokenizer(getattr(stream, 'name', None))
+            if warm is not None and exclude:
+                warm.close()
+                warm = None
+            self.tok = warm or nat.Tokenizer(tokenizer_threads(), exclude)
         tok = self.tok
         device_ex = ordinal and cover is None and not want_names and \
             (not want_groups or self._dstrata is not None) and \

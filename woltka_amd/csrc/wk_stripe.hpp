@@ -31,7 +31,7 @@ constexpr uint32_t kStripeCells = 6144;      // cells of the stripe's coordinate
 constexpr uint32_t kStripeGenomes = 256;     // genomes of a stripe (4 KB of per-genome words)
 constexpr uint32_t kStripeMax = 1024;        // stripes a chunk can be sorted into (per-tile counters in LDS)
 constexpr uint32_t kStripeTileThreads = 256;
-constexpr uint32_t kStripeTileItems = 8;
+constexpr uint32_t kStripeTileItems = 32;
 constexpr uint32_t kStripeTileReads = kStripeTileThreads * kStripeTileItems;  // reads per workgroup of the count / scatter passes
 constexpr uint32_t kStripeMatchThreads = 1024;
 constexpr uint32_t kStripePiece = 65536;     // hits per workgroup of stripe_match
@@ -98,21 +98,24 @@ __device__ __forceinline__ uint32_t wave_shared_add(uint32_t* counters, uint32_t
     return place;
 }
 
-// pass 1: per tile of reads, how many go where
+// pass 1: per tile of reads, how many go where.  (A tile is kStripeTileReads = 8192 reads: the count matrix
+// -- rows x tiles, written and read with a stride of one row -- stays small against the hits themselves.)
 __global__ void __launch_bounds__(kStripeTileThreads) stripe_count_kernel(StripeSortArgs a) {
     __shared__ uint32_t cnt[kStripeMax + 2];
     for (uint32_t i = threadIdx.x; i < a.n_stripes + 2u; i += blockDim.x) cnt[i] = 0u;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kStripeTileReads;
-#pragma unroll
+    unsigned long long rest_hits = 0;
     for (uint32_t it = 0; it < kStripeTileItems; ++it) {
         const int64_t r = base + it * kStripeTileThreads + threadIdx.x;
         int32_t h0 = 0, nh = 0;
         uint32_t cls = 0xFFFFFFFFu;
         if (r < a.n_reads) cls = stripe_class(a, r, &h0, &nh);
         (void)wave_shared_add(cnt, cls, cls != 0xFFFFFFFFu);
-        if (cls == a.n_stripes) atomicAdd(&cnt[a.n_stripes + 1u], (uint32_t)nh);
+        if (cls == a.n_stripes) rest_hits += (unsigned long long)nh;
     }
+    rest_hits = wave_sum(rest_hits);
+    if ((threadIdx.x & (kWave - 1)) == 0 && rest_hits) atomicAdd(&cnt[a.n_stripes + 1u], (uint32_t)rest_hits);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < a.n_stripes + 2u; i += blockDim.x) a.cnt[(size_t)i * a.n_tiles + blockIdx.x] = cnt[i];
 }
@@ -172,49 +175,54 @@ __global__ void __launch_bounds__(64) stripe_bases_kernel(const unsigned long lo
     }
 }
 
-// pass 3: the hits to their places
+// pass 3: the hits to their places.  Reads are taken in rounds of 256 consecutive ones (coalesced loads); the
+// reads of several hits keep their order: a scan over the workgroup per round places them.
 __global__ void __launch_bounds__(kStripeTileThreads) stripe_scatter_kernel(StripeSortArgs a) {
     __shared__ uint32_t cur[kStripeMax];  // next place of a stripe's hits of this tile, inside the row
     __shared__ unsigned long long wtot[kStripeTileThreads / kWave];
+    __shared__ unsigned long long run_base;  // (reads | hits << 32) of the other reads placed by the rounds before
     const uint32_t tile = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < a.n_stripes; i += blockDim.x) cur[i] = a.cnt[(size_t)i * a.n_tiles + tile];
+    if (threadIdx.x == 0)
+        run_base = (unsigned long long)a.cnt[(size_t)a.n_stripes * a.n_tiles + tile] |
+                   ((unsigned long long)a.cnt[(size_t)(a.n_stripes + 1u) * a.n_tiles + tile] << 32);
     __syncthreads();
     const int64_t base = (int64_t)tile * kStripeTileReads;
-    // the other reads keep their order: thread t owns the reads base + t * items .. (consecutive), an
-    // exclusive scan of (reads | hits << 32) over the threads places them
-    int32_t h0[kStripeTileItems], nh[kStripeTileItems];
-    uint32_t cls[kStripeTileItems];
-    unsigned long long mine = 0;
-#pragma unroll
-    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
-        const int64_t r = base + (int64_t)threadIdx.x * kStripeTileItems + it;
-        cls[it] = 0xFFFFFFFFu;
-        h0[it] = nh[it] = 0;
-        if (r < a.n_reads) cls[it] = stripe_class(a, r, &h0[it], &nh[it]);
-        if (cls[it] == a.n_stripes) mine += 1ull | ((unsigned long long)(uint32_t)nh[it] << 32);
-    }
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    unsigned long long inc = mine;
-#pragma unroll
-    for (uint32_t d = 1; d < kWave; d <<= 1) {
-        const unsigned long long up = __shfl_up(inc, d, kWave);
-        if (lane >= d) inc += up;
-    }
-    if (lane == kWave - 1) wtot[wave] = inc;
-    __syncthreads();
-    unsigned long long before = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kStripeTileThreads / kWave; ++w) before += w < wave ? wtot[w] : 0ull;
-    unsigned long long run = before + inc - mine;
-    uint32_t rr = a.cnt[(size_t)a.n_stripes * a.n_tiles + tile] + (uint32_t)(run & 0xFFFFFFFFull);
-    uint32_t rh = a.cnt[(size_t)(a.n_stripes + 1u) * a.n_tiles + tile] + (uint32_t)(run >> 32);
-#pragma unroll
     for (uint32_t it = 0; it < kStripeTileItems; ++it) {
-        if (cls[it] == 0xFFFFFFFFu) continue;
-        if (cls[it] == a.n_stripes) {
-            a.r_hoff[rr++] = (int32_t)rh;
-            for (int32_t k = 0; k < nh[it]; ++k) {
-                const int32_t h = h0[it] + k;
+        const int64_t r = base + it * kStripeTileThreads + threadIdx.x;
+        int32_t h0 = 0, nh = 0;
+        uint32_t cls = 0xFFFFFFFFu;
+        if (r < a.n_reads) cls = stripe_class(a, r, &h0, &nh);
+        // the reads of one hit: a place in their stripe's run of this tile (lanes that share a stripe share the reservation)
+        const bool one = cls < a.n_stripes;
+        const uint32_t at = wave_shared_add(cur, one ? cls : 0u, one);
+        if (one) a.binned[a.row_base[cls] + at] = make_int4(a.genome[h0], a.beg[h0], a.end[h0], (int32_t)a.len[h0]);
+        // the others, in order
+        const bool rest = cls == a.n_stripes;
+        const unsigned long long any = __ballot(rest);
+        const unsigned long long mine = rest ? (1ull | ((unsigned long long)(uint32_t)nh << 32)) : 0ull;
+        unsigned long long inc = mine;
+#pragma unroll
+        for (uint32_t d = 1; d < kWave; d <<= 1) {
+            const unsigned long long up = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += up;
+        }
+        if (lane == kWave - 1) wtot[wave] = inc;
+        (void)any;
+        __syncthreads();
+        unsigned long long before = run_base, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kStripeTileThreads / kWave; ++w) {
+            before += w < wave ? wtot[w] : 0ull;
+            total += wtot[w];
+        }
+        if (rest) {
+            const unsigned long long me = before + inc - mine;
+            uint32_t rh = (uint32_t)(me >> 32);
+            a.r_hoff[(uint32_t)(me & 0xFFFFFFFFull)] = (int32_t)rh;
+            for (int32_t k = 0; k < nh; ++k) {
+                const int32_t h = h0 + k;
                 a.r_genome[rh] = a.genome[h];
                 a.r_beg[rh] = a.beg[h];
                 a.r_end[rh] = a.end[h];
@@ -222,17 +230,9 @@ __global__ void __launch_bounds__(kStripeTileThreads) stripe_scatter_kernel(Stri
                 ++rh;
             }
         }
-    }
-    // the reads of one hit: a place in their stripe's run of this tile (lanes of a wave that share a stripe
-    // share the reservation)
-#pragma unroll
-    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
-        const bool one = cls[it] < a.n_stripes;
-        const uint32_t at = wave_shared_add(cur, one ? cls[it] : 0u, one);
-        if (one) {
-            const int32_t h = h0[it];
-            a.binned[a.row_base[cls[it]] + at] = make_int4(a.genome[h], a.beg[h], a.end[h], (int32_t)a.len[h]);
-        }
+        __syncthreads();
+        if (threadIdx.x == 0) run_base += total;
+        // (the next round's barrier orders this write before its reads)
     }
 }
 

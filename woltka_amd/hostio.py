@@ -307,6 +307,83 @@ def _take_context(device):
     return box['ctx']
 
 
+_warm = {}
+
+
+def warm_tokenizer_ahead(path, fmt, span=256 << 20):
+    """On a thread, while the hierarchy / the gene coordinates are read: a
+    tokenizer whose dictionary already holds the subjects of the first `span`
+    bytes of `path` -- interned by the host tokenizer in text order, i.e. under
+    the indices the device route would give them.  The route then starts with
+    full blocks instead of a ramp of small ones, and its first blocks meet
+    (next to) no unknown subject.  ``take_warm_tokenizer(path)`` hands it to
+    the engine; anything that goes wrong just means no warm tokenizer."""
+    import threading
+    if _warm:
+        return
+    box = {'path': path}
+
+    def work():
+        tok = None
+        try:
+            size = os.path.getsize(path)
+            n = min(size, span)
+            if n < (8 << 20):
+                return
+            tok = nat.Tokenizer(tokenizer_threads())
+            buf = np.empty(n, dtype=np.uint8)
+            with open(path, 'rb') as f:
+                got = tok.read_into(f.fileno(), 0, memoryview(buf))
+            raw = buf[:got]
+            head = bytes(raw[:1 << 16])
+            use_fmt = fmt
+            if not use_fmt:
+                from .align import infer_align_format
+                line = head.split(b'\n', 1)[0] + b'\n'
+                use_fmt = infer_align_format(iter([line.decode()]))[0]
+            if use_fmt not in ('sam', 'b6o', 'paf', 'map'):
+                tok.close()
+                return
+            # (whole lines only; the last run need not be whole: nothing of
+            # this parse but the dictionary is kept)
+            if got == size:
+                end = got
+            else:
+                tail = raw[max(0, got - (1 << 20)):]
+                nl = np.flatnonzero(tail == 10)
+                end = got - tail.size + int(nl[-1]) + 1 if nl.size else 0
+            if end <= 0:
+                tok.close()
+                return
+            tok.parse(memoryview(buf)[:end], first=True, final=True,
+                      fmt=use_fmt)
+            tok.warm = True
+            box['tok'], box['fmt'] = tok, use_fmt
+        except Exception:       # noqa: BLE001 - best effort
+            if tok is not None:
+                try:
+                    tok.close()
+                except Exception:   # noqa: BLE001
+                    pass
+    th = threading.Thread(target=work, name='wk-warm', daemon=True)
+    _warm['x'] = (th, box)
+    th.start()
+
+
+def take_warm_tokenizer(path=None):
+    """The tokenizer `warm_tokenizer_ahead` prepared (None if there is none,
+    or it was made for another file)."""
+    th, box = _warm.pop('x', (None, None))
+    if th is None:
+        return None
+    th.join()
+    tok = box.get('tok')
+    if tok is not None and path is not None and box['path'] != path:
+        tok.close()
+        return None
+    return tok
+
+
 def drop_context_ahead():
     """Close contexts opened ahead that no engine took (an error on the way)."""
     for device in list(_ahead):
@@ -314,3 +391,6 @@ def drop_context_ahead():
             _take_context(device).close()
         except Exception:
             pass
+    tok = take_warm_tokenizer()
+    if tok is not None:
+        tok.close()

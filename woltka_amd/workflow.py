@@ -204,6 +204,21 @@ def _workflow_with_context(
         coords_fp, overlap, sizes, frac, scale, digits, output_fmt,
         unassigned, name_as_id, add_rank, add_lineage, outmap_dir, outmap_zip,
         outcov_dir, outcov_fmt, chunk, cache, device, comm=None):
+    # (while the hierarchy and the gene coordinates are read: the subjects of
+    # the first alignment file's first bytes into the tokenizer's dictionary,
+    # so that the device text route starts with full blocks and few unknowns)
+    if files and not exclude and (comm is None or comm.world == 1) and \
+            not os.environ.get('WOLTKA_NO_WARM'):
+        from .shard import file_key, file_path, FilePart
+        from .file import ZIP_BY_EXT
+        from os.path import isfile, splitext
+        first = sorted(files, key=file_key)[0]
+        fp0 = file_path(first)
+        if not isinstance(first, FilePart) and fp0 != '-' and isfile(fp0) \
+                and ZIP_BY_EXT.get(splitext(fp0)[1]) is None and \
+                input_fmt in (None, 'sam', 'b6o', 'paf', 'map'):
+            from . import classify as _classify
+            _classify.warm_tokenizer_ahead(fp0, input_fmt)
     tree, rankdic, namedic, root = build_hierarchy(
         names_fps, nodes_fps, newick_fps, lineage_fps, columns_fps, map_fps,
         map_rank, zippers)
