@@ -296,3 +296,28 @@ def test_rank_zero_failing_before_the_gather_ends_the_ranks():
     shard.stop_local_world(comm, procs, failed=True, grace=3.0)
     assert time.time() - t0 < 30
     assert not any(p.is_alive() for p in procs)
+
+
+@pytest.mark.timeout(300)
+def test_local_world_of_eight_one_sample_each(tmp_path):
+    """`woltka classify --gpus 8` without a GPU: eight sample files of uneven
+    sizes on eight ranks (the shape of BASELINE config 5 on one node: samples
+    shard, nothing is exchanged between ranks but the finished profiles) --
+    every rank gets work, rank 0 gathers what one process counts."""
+    files = {}
+    for i, n in enumerate((900, 120, 2400, 60, 700, 1500, 300, 1100)):
+        name = f'S{i + 1:02d}'
+        fp = tmp_path / f'{name}.sam'
+        fp.write_text(_mux_text(n, [name]).replace(f'{name}_', 'r'))
+        files[str(fp)] = name
+    shares = shard.partition_files(files, 8)
+    assert all(len(sh) == 1 for sh in shares)
+    comm, procs = shard.start_local_world(8, _local_entry, {'files': files})
+    out = {}
+    try:
+        _local_entry(comm=comm, files=files, out=out)
+    finally:
+        shard.stop_local_world(comm, procs, failed=not out)
+    assert all(p.exitcode == 0 for p in procs)
+    assert out == _count_share(files)
+    assert sorted(out['none']) == sorted(files.values())
