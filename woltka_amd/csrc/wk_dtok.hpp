@@ -752,6 +752,116 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_emit_kernel(DtokArgs a) {
     scatter_by_slice_n<kDtokThreads, kScatterItems>(a.streams, rec, word);
 }
 
+// dtok_first + dtok_emit in one kernel (the unordered emission: records for the weighted histogram).  A
+// workgroup takes kScatterItems x 256 consecutive lines; what the walks along a run read -- does the line
+// start a run, its mate, its subject -- sits in LDS for those lines and kFeHalo lines on either side, the
+// first-line flags are worked out there (no is_first[] round trip through HBM) and the walks for position
+// and size run in LDS too.  A walk that leaves the staged window (a run of more than kFeHalo lines across
+// the tile's edge) reads the global arrays and works the flag of a line out on the spot: same result, slower.
+constexpr uint32_t kFeHalo = 96;
+constexpr uint32_t kFeTile = kDtokThreads * kScatterItems;
+constexpr uint32_t kFeWindow = kFeTile + 2 * kFeHalo;
+
+struct RunView {
+    const DtokArgs& a;
+    const unsigned char* pk;  // per staged line: bit 0 starts a run, bit 1 first line of its read with its subject, bits 2-3 mate
+    const int32_t* sj;        // per staged line: subject
+    uint32_t w0, w1;          // staged lines [w0, w1)
+    __device__ __forceinline__ bool in(uint32_t j) const { return j >= w0 && j < w1; }
+    __device__ __forceinline__ bool start(uint32_t j) const { return in(j) ? (pk[j - w0] & 1u) != 0u : a.is_start[j] != 0; }
+    __device__ __forceinline__ uint32_t mate(uint32_t j) const { return in(j) ? (uint32_t)(pk[j - w0] >> 2) & 3u : a.lmeta[j] >> 28; }
+    __device__ __forceinline__ int32_t subj(uint32_t j) const { return in(j) ? sj[j - w0] : a.lsubj[j]; }
+    // (dtok_first_kernel's rule) the first line of its run and mate that names its subject
+    __device__ __forceinline__ bool first_slow(uint32_t j) const {
+        const int32_t s = subj(j);
+        if (s < 0) return false;
+        if (start(j)) return true;
+        const uint32_t m = mate(j);
+        uint32_t k = j;
+        do {
+            --k;
+            if (subj(k) == s && mate(k) == m) return false;
+        } while (!start(k));  // (a mapped line before j starts the run: k never passes 0)
+        return true;
+    }
+    __device__ __forceinline__ bool first(uint32_t j) const { return in(j) ? (pk[j - w0] & 2u) != 0u : first_slow(j); }
+};
+
+__global__ void __launch_bounds__(kDtokThreads) dtok_first_emit_kernel(DtokArgs a) {
+    __shared__ unsigned char pk[kFeWindow];
+    __shared__ int32_t sj[kFeWindow];
+    const uint32_t l0 = blockIdx.x * kFeTile;
+    const uint32_t w0 = l0 > kFeHalo ? l0 - kFeHalo : 0u;
+    const uint32_t w1 = min(a.n_lines, l0 + kFeTile + kFeHalo);
+    for (uint32_t j = w0 + threadIdx.x; j < w1; j += kDtokThreads) {
+        pk[j - w0] = (unsigned char)((a.is_start[j] ? 1u : 0u) | ((a.lmeta[j] >> 28) << 2));
+        sj[j - w0] = a.lsubj[j];
+    }
+    __syncthreads();
+    const RunView v{a, pk, sj, w0, w1};
+    // the first-line flags of the staged lines (a thread writes its own lines' bytes only)
+    static_assert((kFeWindow + kDtokThreads - 1) / kDtokThreads <= 32, "a thread's flags fit one word");
+    uint32_t fmask = 0;
+    {
+        uint32_t q = 0;
+        for (uint32_t j = w0 + threadIdx.x; j < w1; j += kDtokThreads, ++q) fmask |= v.first_slow(j) ? 1u << q : 0u;
+    }
+    __syncthreads();  // (every walk has read the bytes as they were)
+    {
+        uint32_t q = 0;
+        for (uint32_t j = w0 + threadIdx.x; j < w1; j += kDtokThreads, ++q)
+            if (fmask >> q & 1u) pk[j - w0] |= 2u;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    bool rec[kScatterItems];
+    uint32_t word[kScatterItems];
+    bool big = false;
+    uint32_t n_rec = 0, n_reads = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kScatterItems; ++r) {
+        const uint32_t i = l0 + r * kDtokThreads + threadIdx.x;
+        rec[r] = false;
+        word[r] = 0;
+        uint32_t pos = 0;
+        if (i < a.n_lines && v.first(i)) {
+            rec[r] = true;
+            const uint32_t m = v.mate(i);
+            if (!v.start(i)) {
+                uint32_t j = i;
+                do {
+                    --j;
+                    pos += (v.first(j) && v.mate(j) == m) ? 1u : 0u;
+                } while (!v.start(j));
+            }
+            uint32_t size = pos + 1u;
+            for (uint32_t j = i + 1u; j < a.n_lines && !v.start(j); ++j) size += (v.first(j) && v.mate(j) == m) ? 1u : 0u;
+            big |= size > (uint32_t)WK_WEIGHT_MAX_K;
+            word[r] = (uint32_t)v.subj(i) | ((pos & 15u) << kWordSubjBits) | ((size & 31u) << kWordSizeShift);
+        }
+        n_rec += (uint32_t)__popcll(__ballot(rec[r]));
+        n_reads += (uint32_t)__popcll(__ballot(rec[r] && pos == 0u));
+    }
+    if (big) atomicOr(&a.state->flags, kDtokBigRead);
+    __shared__ uint32_t w_rec[kDtokThreads / kWave], w_reads[kDtokThreads / kWave];
+    const uint32_t wave = threadIdx.x / kWave;
+    if (lane == 0) {
+        w_rec[wave] = n_rec;
+        w_reads[wave] = n_reads;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0, q = 0;
+        for (uint32_t w = 0; w < kDtokThreads / kWave; ++w) {
+            n += w_rec[w];
+            q += w_reads[w];
+        }
+        if (n) atomicAdd(&a.state->n_out, (unsigned long long)n);
+        if (q) atomicAdd(&a.state->n_reads, (unsigned long long)q);
+    }
+    scatter_by_slice_n<kDtokThreads, kScatterItems>(a.streams, rec, word);
+}
+
 // Plain flavour, ordered emission: the records of a read contiguous and in
 // position order (what the free-rank stream needs, wk_free.hpp) — placed like the
 // hits above: records before the run + records of lower mates in the run + the

@@ -2935,10 +2935,10 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
     const dim3 emit_grid((c->dt_lines + kDtokThreads * kScatterItems - 1) / (kDtokThreads * kScatterItems));
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
-    hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     const bool ordered = c->w_mode != 0 || c->dt_keep_reads;
     *ordered_out = ordered;
     c->dt_emitted = false;
+    if (ordered) hipLaunchKernelGGL(dtok_first_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     if (ordered) {
         // the per-read stream wants the records of a read next to each other, in
         // position order: placed by prefix sums instead of appended wave by wave
@@ -2958,7 +2958,8 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
             hipLaunchKernelGGL(dtok_place_words_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
         HIP_TRY(c, hipMemcpyAsync(totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
     } else {
-        hipLaunchKernelGGL(dtok_emit_kernel, emit_grid, dim3(kDtokThreads), 0, c->stream, a);
+        // (first-line flags and emission in one kernel, the runs' lines staged in LDS)
+        hipLaunchKernelGGL(dtok_first_emit_kernel, emit_grid, dim3(kDtokThreads), 0, c->stream, a);
     }
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
