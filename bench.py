@@ -556,8 +556,8 @@ class TextLcaWorkload:
     symbols = {'dtok_lines': 'wk::dtok_count_kernel + wk::tile_scan_kernel + '
                              'wk::dtok_lines_kernel',
                'dtok_parse': 'wk::dtok_parse_kernel<false>',
-               'dtok_emit': 'wk::dtok_runs_kernel + wk::dtok_first_kernel + '
-                            'wk::dtok_emit_kernel',
+               'dtok_emit': 'wk::dtok_runs_kernel + '
+                            'wk::dtok_first_emit_kernel',
                'classify': 'wk::weigh_streams_kernel<4>'}
     ranks = ('phylum', 'genus', 'species')
     BLOCK = 1 << 26

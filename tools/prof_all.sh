@@ -3,12 +3,13 @@
 # workload; results under gpurun_out/<tag>_<workload>/
 #   tools/prof_all.sh <tag> [workloads...]
 tag=${1:-r03prof}; shift
-wls=${*:-"lca lca_free lca_above lca_major lca_uniq ordinal flat"}
+wls=${*:-"lca_text lca lca_free lca_above lca_major lca_uniq ordinal flat"}
 for wl in $wls; do
   case $wl in
+    lca_text) kern=dtok_first_emit ;;
     lca) kern=weigh_streams ;;
     lca_free|lca_above|lca_major|lca_uniq) kern=free_stream ;;
-    ordinal) kern=match_hits ;;
+    ordinal) kern=stripe_match ;;
     flat) kern=count_subjects ;;
   esac
   # (FULL="lca ordinal": every PMC set for these, the two traffic passes only for the others)
