@@ -48,7 +48,10 @@ extern "C" {
  * subjects instead of walking up the tree).
  * "streams" (0: the packed records of all slices of the subject table in one
  * stream, round 3's team kernel), "range_parts" (partitions of the dense gene
- * log; 0 = as few as the merge's LDS array allows). */
+ * log; 0 = as few as the merge's LDS array allows), "stripes" (0: the
+ * coord-match tally never sorts the hits by genome stripe, csrc/wk_stripe.hpp)
+ * and "stripes_min" (chunks of fewer hits keep the gather kernels; default
+ * 4,000,000). */
 int wk_tune(wk_ctx* ctx, const char* name, int64_t value);
 
 /* ---- measurement ------------------------------------------------------- */

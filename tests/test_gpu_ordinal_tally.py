@@ -23,9 +23,14 @@ from woltka_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def ctx():
+@pytest.fixture(params=['stripes', 'gather'])
+def ctx(request):
+    """Both ways of the direct path: the sorted match for every chunk size
+    (`stripes_min` 0; the product sorts chunks of >= 4 M hits) and the gather
+    kernels alone."""
     c = nat.Context(0)
+    c.tune('stripes_min', 0)
+    c.tune('stripes', 1 if request.param == 'stripes' else 0)
     yield c
     c.close()
 

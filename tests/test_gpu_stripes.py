@@ -32,6 +32,7 @@ def ctx():
 def count(ctx, p, th, stripes, jobs=None, group=3, twice=False):
     jobs = jobs or [nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)]
     ctx.tune('stripes', stripes)
+    ctx.tune('stripes_min', 0)          # (the product sorts chunks of >= 4 M hits only)
     ctx.counts_clear()
     ctx.reset_stats()
     ctx.ordinal_stage(p['genome'], p['beg'], p['end'], p['length'], p['hoff'],

@@ -134,9 +134,14 @@ __global__ void __launch_bounds__(kStrataThreads) strata_parse_kernel(StrataArgs
     s.line_vlen[i] = ve - (tab + 1u);
     s.line_hash[i] = hk;
     // label
+    // (a map of 20 M reads names a few thousand labels: once a label sits in its slot every later line
+    // finds it with a plain load -- a compare-and-swap per line on the slot of a common label, a
+    // running minimum per line on its representative and one add per line to the pair counter were
+    // 47 ms per map of config 5, profiles/r05_e2e_twopass2_kernel_stats.csv)
     uint32_t q = (uint32_t)hl & (kStrataLabelSlots - 1u);
     for (uint32_t tries = 0;; ++tries) {
-        const unsigned long long old = atomicCAS(&s.labels[q].hash, kLabelEmpty, hl);
+        unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(&s.labels[q].hash);
+        if (old == kLabelEmpty) old = atomicCAS(&s.labels[q].hash, kLabelEmpty, hl);
         if (old == kLabelEmpty) {
             if (atomicAdd(&s.state[2], 1u) >= kStrataLabelSlots / 2u) atomicOr(&s.state[0], kStrataLabelsFull);
             break;
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(kStrataThreads) strata_parse_kernel(StrataArgs
         }
         q = (q + 1u) & (kStrataLabelSlots - 1u);
     }
-    atomicMin(&s.labels[q].rep, i);
+    if (*reinterpret_cast<volatile uint32_t*>(&s.labels[q].rep) > i) atomicMin(&s.labels[q].rep, i);
     s.line_label[i] = q;
     // key: the last line wins (dict())
     uint32_t h = (uint32_t)(hk ^ (hk >> 32)) & s.mask;
@@ -158,7 +163,9 @@ __global__ void __launch_bounds__(kStrataThreads) strata_parse_kernel(StrataArgs
         h = (h + 1u) & s.mask;
     }
     atomicMax(&s.slots[h].line1, i + 1u);
-    atomicAdd(&s.state[1], 1u);
+    // the pairs of the map: one add per wave
+    const unsigned long long pairs = __ballot(true);
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)pairs) - 1)) atomicAdd(&s.state[1], (uint32_t)__popcll(pairs));
 }
 
 __device__ __forceinline__ bool same_bytes(const unsigned char* a, const unsigned char* b, uint32_t n) {

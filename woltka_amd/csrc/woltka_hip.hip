@@ -170,6 +170,7 @@ struct wk_ctx {
     std::vector<StripeInfo> stripes_host;
     bool stripes_usable = false;
     int use_stripes = 1;       // (0: the gather kernels of wk_ordinal.hpp for every read; measurement)
+    int64_t stripes_min_hits = 4000000;  // chunks below this keep the gather kernels (wk_tune "stripes_min")
     DevBuf sb_cnt, sb_tot, sb_base, sb_binned, sb_units, sb_over, sb_stat;
     DevBuf r_genome, r_beg, r_end, r_len, r_hoff;
     bool sb_valid = false;     // the staged chunk has been sorted
@@ -986,6 +987,11 @@ int wk_tune(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "tally_slots")) {
         if (value < 256 || value > 4096 || (value & (value - 1))) return fail(c, WK_E_ARG, "tally_slots must be a power of two in [256, 4096]");
         c->tally_slots = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "stripes_min")) {
+        if (value < 0) return fail(c, WK_E_ARG, "stripes_min must be >= 0");
+        c->stripes_min_hits = value;
         return WK_OK;
     }
     if (!strcmp(name, "stripes")) {
@@ -3779,7 +3785,12 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     }
     DeviceGuard guard(c->device);
     KtScope kt_scope(c);
-    if (c->use_stripes && c->stripes_usable && c->stripes_host.size() <= kStripeMax) return stripe_count(c, jobs, n_jobs);
+    // The sorted match pays for chunks that are large against its fixed costs (a scan over stripes x tiles, a
+    // unit per stripe that loads the stripe's genes into LDS, one more read-back): from a few million hits on.
+    // The text route stages a block's hits at a time (~1.6 M): those keep the gather kernels, at 80 us per
+    // block against 370 (profiles/r05_e2e_ordinal_kernel_stats.csv).
+    if (c->use_stripes && c->stripes_usable && c->stripes_host.size() <= kStripeMax && c->n_hits >= c->stripes_min_hits)
+        return stripe_count(c, jobs, n_jobs);
     return tally_count(c, jobs, n_jobs);
 }
 
