@@ -143,6 +143,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         self._exclude = None
         self._gmap_key, self._gmap = None, None
         self._epoch = 0
+        self._used_bound, self._used_epoch = (0, None), -1
         self._units, self._big = {}, {}     # folded counts until `finish`
         self._tok_map = np.empty(0, dtype=np.int32)
         self._tok_identity = True
@@ -227,11 +228,25 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
             * n_jobs
         if 2 * most <= self.slots_reserved:
             return
+        # (asking counts the table's keys on the device and waits: 0.5 ms per
+        # block of a stratified run.  The keys in use are at most those counted
+        # last plus what the chunks since then could have added: only when that
+        # bound is too large is the table asked again)
+        known, table = getattr(self, '_used_bound', (0, None))
+        if table != self.slots_reserved or self._used_epoch != self._epoch:
+            known = None
+        if known is not None and 2 * (known + need) <= self.slots_reserved \
+                and 4 * known <= self.slots_reserved:
+            self._used_bound = (known + need, self.slots_reserved)
+            return
         used = self.ctx.stats()['table_used']
+        self._used_epoch = self._epoch
         if 2 * (used + need) <= self.slots_reserved and \
                 4 * used <= self.slots_reserved:
+            self._used_bound = (used + need, self.slots_reserved)
             return
         self.collect(data)
+        self._used_bound = (need, None)     # (asked again next time)
         if 2 * need > self.slots_reserved and not self._table_fixed:
             self._reserve(4 * need)
 
