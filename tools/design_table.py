@@ -18,7 +18,11 @@ def g(x, *keys, default=None):
 
 
 def rate(v):
-    return '—' if v is None else f'{v / 1e6:.0f} M' if v < 1e10 else f'{v / 1e9:.2f} G'
+    if v is None:
+        return '—'
+    if v < 1e6:
+        return f'{v / 1e6:.2f} M'
+    return f'{v / 1e6:.0f} M' if v < 1e10 else f'{v / 1e9:.0f} G'
 
 
 rows = []

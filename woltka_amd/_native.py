@@ -320,6 +320,9 @@ class Context:
         self._h = h
         self.device = device
         self.n_nodes = 0
+        import threading
+        self._pin_lock = threading.Lock()   # (see host_alloc)
+        self._copied_once = False
 
     # -- plumbing ---------------------------------------------------------
     def _check(self, rc):
@@ -334,6 +337,12 @@ class Context:
 
     def close(self):
         if getattr(self, '_h', None):
+            # (a thread that pins buffers ahead, hostio.open_context_ahead)
+            th = getattr(self, '_ring_thread', None)
+            if th is not None:
+                self._ring_stop = True
+                th.join()
+                self._ring_thread = None
             self._lib.wk_destroy(self._h)
             self._h = None
 
@@ -511,11 +520,15 @@ class Context:
     STAGE_SLOTS = 8
 
     def host_alloc(self, n, dtype=np.uint32):
-        """A pinned host array of ``n`` elements (owned by the context)."""
+        """A pinned host array of ``n`` elements (owned by the context).
+        (Calls are serialised: the library keeps one list of its pinned
+        blocks, and the host layer pins buffers ahead on a thread of its
+        own, hostio.open_context_ahead.)"""
         dt = np.dtype(dtype)
         out = C.c_void_p()
-        self._check(self._lib.wk_host_alloc(self._h, int(n) * dt.itemsize,
-                                            C.byref(out)))
+        with self._pin_lock:
+            self._check(self._lib.wk_host_alloc(self._h, int(n) * dt.itemsize,
+                                                C.byref(out)))
         buf = (C.c_char * (int(n) * dt.itemsize)).from_address(out.value)
         arr = np.frombuffer(buf, dtype=dt, count=int(n))
         return arr
@@ -561,6 +574,14 @@ class Context:
         ``dtok_scan`` of the same block finds it there."""
         raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
         if raw.size:
+            if not self._copied_once:
+                # (the first copy pins a few bytes for the newline counts)
+                with self._pin_lock:
+                    self._check(self._lib.wk_dtok_copy(
+                        self._h, C.c_void_p(raw.ctypes.data), int(begin),
+                        int(stop)))
+                self._copied_once = True
+                return
             self._check(self._lib.wk_dtok_copy(
                 self._h, C.c_void_p(raw.ctypes.data), int(begin), int(stop)))
 

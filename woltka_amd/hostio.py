@@ -233,10 +233,14 @@ class StageRing:
     ``take()`` hands the current one to a block, the consumer gives it back
     with ``release()`` once the device has it."""
 
-    def __init__(self, ctx, slots, layout):
+    def __init__(self, ctx, slots, layout, ready=None):
         import queue
         self._ctx, self.layout = ctx, dict(layout)
         self._bufs = [None] * slots         # allocated on first use
+        # (`ready`: a list that another thread fills with sets allocated
+        # ahead -- pinning 65 MB takes ~12 ms, which the reader thread would
+        # otherwise spend between its first blocks)
+        self._ready = ready
         self._free = queue.Queue()
         for i in range(slots):
             self._free.put(i)
@@ -247,8 +251,18 @@ class StageRing:
             self._cur = self._free.get()
         i = self._cur
         if self._bufs[i] is None:
-            self._bufs[i] = {k: self._ctx.host_alloc(n, dt)
-                             for k, (dt, n) in self.layout.items()}
+            bufs = None
+            if self._ready:
+                try:
+                    bufs = self._ready.pop()
+                except IndexError:
+                    bufs = None
+                if bufs is not None and not all(
+                        k in bufs and bufs[k].size >= n
+                        for k, (dt, n) in self.layout.items()):
+                    bufs = None
+            self._bufs[i] = bufs or {k: self._ctx.host_alloc(n, dt)
+                                     for k, (dt, n) in self.layout.items()}
         return self._bufs[i]
 
     def try_current(self):
@@ -279,9 +293,11 @@ MAX_GROUPS = 1 << nat.KEY_GROUP_BITS
 _ahead = {}
 
 
-def open_context_ahead(device):
+def open_context_ahead(device, text_ring=None):
     """Create the device context of `device` on a thread; ``Engine`` takes it.
-    Errors surface where the engine would have met them."""
+    Errors surface where the engine would have met them.  ``text_ring`` =
+    (slots, bytes): pinned buffers for the device text route allocated on the
+    same thread."""
     import threading
     if device in _ahead:
         return
@@ -292,6 +308,29 @@ def open_context_ahead(device):
             box['ctx'] = nat.Context(device)
         except Exception as e:          # raised again by _take_context
             box['err'] = e
+            return
+        # the pinned buffers the device text route reads its blocks into
+        # (`Engine._device_chunks`' ring), on a thread of their own while the
+        # hierarchy is read: nobody waits for them -- the ring takes what is
+        # there when it needs a buffer and allocates the rest itself
+        if text_ring:
+            ctx = box['ctx']
+            ctx._text_ring_ready = []
+            ctx._ring_stop = False
+
+            def pin():
+                n, nbytes = text_ring
+                try:
+                    for _ in range(n):
+                        if ctx._ring_stop:
+                            return
+                        buf = {'text': ctx.host_alloc(nbytes, np.uint8)}
+                        ctx._text_ring_ready.append(buf)    # (atomic under the GIL)
+                except Exception:       # noqa: BLE001 - allocated on use then
+                    pass
+            ctx._ring_thread = threading.Thread(target=pin, name='wk-pin',
+                                                daemon=True)
+            ctx._ring_thread.start()
     th = threading.Thread(target=work, name='wk-context', daemon=True)
     _ahead[device] = (th, box)
     th.start()

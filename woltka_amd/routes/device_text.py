@@ -198,7 +198,8 @@ class DeviceTextRoute:
         block = self.DTOK_BLOCK
         if self._tring is None:
             self._tring = StageRing(self.ctx, 8, {
-                'text': (np.uint8, block + self.DTOK_HEADROOM)})
+                'text': (np.uint8, block + self.DTOK_HEADROOM)},
+                ready=getattr(self.ctx, '_text_ring_ready', None))
         ring = self._tring
         free = queue.Queue()
 

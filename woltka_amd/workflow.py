@@ -165,7 +165,13 @@ def _workflow_ranked(input_fp, output_fp, input_fmt, input_ext, samples, demux,
     from . import classify as _classify
     restore = None
     if comm is None:
-        _classify.open_context_ahead(device)
+        # (with the pinned buffers of the device text route, when the input
+        # can take it: plain / gzip text without an exclusion set)
+        ring = None
+        if not exclude and not os.environ.get('WOLTKA_NO_DTOK'):
+            from .routes.device_text import DeviceTextRoute as _R
+            ring = (8, _R.DTOK_BLOCK + _R.DTOK_HEADROOM)
+        _classify.open_context_ahead(device, ring)
     elif comm.kind == 'local':
         # the ranks share this node's CPUs (classify.tokenizer_threads) and
         # each keeps to the NUMA node of its GPU
