@@ -168,9 +168,18 @@ def _workflow_ranked(input_fp, output_fp, input_fmt, input_ext, samples, demux,
         # (with the pinned buffers of the device text route, when the input
         # can take it: plain / gzip text without an exclusion set)
         ring = None
-        if not exclude and not os.environ.get('WOLTKA_NO_DTOK'):
-            from .routes.device_text import DeviceTextRoute as _R
-            ring = (8, _R.DTOK_BLOCK + _R.DTOK_HEADROOM)
+        if not exclude and not os.environ.get('WOLTKA_NO_DTOK') and \
+                not os.environ.get('WOLTKA_NO_PIN_AHEAD'):
+            # (only for inputs that will use all of them: a run of a few
+            # hundred MB is over before eight buffers are pinned)
+            try:
+                total = sum(os.path.getsize(file_path(x)) for x in files
+                            if file_path(x) != '-')
+            except OSError:
+                total = 0
+            if total >= (2 << 30):
+                from .routes.device_text import DeviceTextRoute as _R
+                ring = (8, _R.DTOK_BLOCK + _R.DTOK_HEADROOM)
         _classify.open_context_ahead(device, ring)
     elif comm.kind == 'local':
         # the ranks share this node's CPUs (classify.tokenizer_threads) and
