@@ -353,11 +353,27 @@ class LcaOptionWorkload(LcaWorkload):
                                        f'rank genus --{option}')
         h = self.prob['hier']
         ctx.build_rank_table(1, h.rank_codes['genus'])
-        flags = {'above': nat.F_ABOVE, 'uniq': nat.F_UNIQ, 'major': 0}[option]
-        self.jobs = [nat.Job(nat.MODE_RANK, 1, flags, 0,
-                             0.8 if option == 'major' else 0.0)]
-        self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
-                          8 * h.n_nodes + 4 * h.n_nodes)
+        if option == 'above3':
+            # `--rank phylum,genus,species --above`: three whole-read jobs over
+            # the same records -- one route, the stream runs once per job
+            # (the records are rewritten per job: words_to_ranks_kernel)
+            self.name = share.name.replace('ranks phylum,genus,species',
+                                           'ranks phylum,genus,species '
+                                           '--above')
+            self.jobs = []
+            for slot, rank in enumerate(('phylum', 'genus', 'species')):
+                ctx.build_rank_table(slot, h.rank_codes[rank])
+                self.jobs.append(nat.Job(nat.MODE_RANK, slot, nat.F_ABOVE, 0,
+                                         0.0))
+            self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
+                              8 * h.n_nodes + 3 * 4 * h.n_nodes)
+        else:
+            flags = {'above': nat.F_ABOVE, 'uniq': nat.F_UNIQ,
+                     'major': 0}[option]
+            self.jobs = [nat.Job(nat.MODE_RANK, 1, flags, 0,
+                                 0.8 if option == 'major' else 0.0)]
+            self.alg_bytes = (4 * self.records + 4 * (self.reads + 1) +
+                              8 * h.n_nodes + 4 * h.n_nodes)
         self.launch_bytes = self.alg_bytes
         sidx = subject_indices(self.prob)[1]
         words = packed_words(sidx, self.prob['qoff'])
@@ -2052,7 +2068,7 @@ def side_blocks(a, line, wl, ctx, dev):
             ctx.counts_clear()
         except Exception as e:      # a side block must not cost the headline
             configs['lca_free'] = {'error': repr(e)}
-        for option in ('above', 'major', 'uniq'):
+        for option in ('above', 'major', 'uniq', 'above3'):
             try:
                 opt = LcaOptionWorkload(ctx, option, wl)
                 p2 = passes_for(opt, a.steps, 0.5)

@@ -34,6 +34,7 @@ rows.append(('**headline** (`value`): device side of R1, config 3, text resident
 for key, label in (('lca', 'histogram alone (`configs.lca`, resident sliced records)'),
                    ('lca_free', '`--rank free`'), ('lca_above', '`--above`'),
                    ('lca_major', '`--major 80`'), ('lca_uniq', '`--uniq`'),
+                   ('lca_above3', '`--rank phylum,genus,species --above` (one route, a stream pass per rank)'),
                    ('ordinal', 'coord-match (`configs.ordinal`, 107.5 M hits staged)'),
                    ('flat', 'config 2 (`configs.flat`, 8 x 10 M records)')):
     c = g(d, 'configs', key)
