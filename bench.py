@@ -1046,6 +1046,7 @@ def e2e_twopass(device, n_samples=8, n_reads=20_000_000, workdir=None, reps=1,
             for key, kw in (('pass1', kw1), ('pass2', kw2)):
                 ph = Phases()
                 try:
+                    wait_closed()
                     t0 = time.perf_counter()
                     quiet(workflow.workflow, device=device, **kw)
                     dt = time.perf_counter() - t0
@@ -1279,6 +1280,17 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
+def wait_closed():
+    """The engine of the call before gives its device memory back on a thread
+    of its own (`Engine.close_later`, next to the writing of the tables); a
+    repetition's clock starts once that is over -- a command has no
+    predecessor."""
+    import threading
+    for th in threading.enumerate():
+        if th.name == 'wk-close':
+            th.join()
+
+
 class Phases:
     """Wall time of the parts of one `workflow.workflow` call: hierarchy /
     coordinate files read, device tables built (Engine setup), records
@@ -1420,6 +1432,7 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
             best = None
             for rep in range(reps):
                 ph.t = {}
+                wait_closed()
                 if sync is not None:
                     sync.barrier()
                 t0 = time.perf_counter()
@@ -1539,6 +1552,7 @@ def e2e_kind(kind, device, workdir=None, reads=0, reps=3, prob=None):
                 out = kw['output_fp']
                 if os.path.isdir(out):
                     shutil.rmtree(out)
+                wait_closed()
                 t0 = time.perf_counter()
                 quiet(workflow.workflow, device=device, **kw)
                 dt = time.perf_counter() - t0

@@ -285,8 +285,27 @@ int wk_words_pending(wk_ctx* ctx, int64_t* n_records, int64_t* n_reads);
  * was appended, the host tokenizer takes the block. */
 /* Start the copy of a block's text on a copy stream (pinned `text`): the
  * wk_dtok_scan of the same block then only waits for it, and the copy of block
- * i + 1 overlaps the kernels of block i.  One block ahead at most. */
+ * i + 1 overlaps the kernels of block i. */
 int wk_dtok_copy(wk_ctx* ctx, const char* text, int64_t begin, int64_t stop);
+/* The same copy for a reader that runs ahead of the scans and does not keep
+ * the host bytes until then (up to 191 blocks: the reader may start while the
+ * hierarchy is still being read — workflow.py:84-95 reads it before the first
+ * alignment — and HBM holds what it copied meanwhile).  *ticket names the copy:
+ * after wk_dtok_copy_wait(ticket) text[begin, stop) may be overwritten.  The
+ * block is scanned with the same (text, begin, stop), which is only its tag
+ * then; blocks are scanned in the order they were copied.  wk_dtok_text_back
+ * copies the text of the block scanned last back to the host (n = stop -
+ * begin): what the host tokenizer is given when *status = 1.
+ * wk_dtok_copy_drop forgets the blocks copied ahead that no scan asked for. */
+int wk_dtok_copy_ahead(wk_ctx* ctx, const char* text, int64_t begin,
+                       int64_t stop, int32_t* ticket);
+int wk_dtok_copy_wait(wk_ctx* ctx, int32_t ticket);
+int wk_dtok_copy_drop(wk_ctx* ctx);
+int wk_dtok_text_back(wk_ctx* ctx, char* out, int64_t n);
+/* A hint: the blocks scanned from now on are `text_bytes` bytes of one sample
+ * in all (0 = unknown again).  The sample's record buffers are then sized once,
+ * from the first block's lines per byte, instead of grown as they fill. */
+int wk_dtok_expect(wk_ctx* ctx, int64_t text_bytes);
 int wk_dtok_scan(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
                  int64_t stop, int extra, int64_t* n_lines, int* status);
 /* The format of the blocks wk_dtok_scan is given from now on: WK_FMT_SAM

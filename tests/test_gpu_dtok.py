@@ -629,3 +629,135 @@ def test_gzip_files_take_the_device_route(tmp_path, monkeypatch, ordinal,
     host, _ = _run(tmp_path, 'zh', True, input_fp=str(zipped),
                    input_fmt='sam', **extra)
     assert host == want
+
+
+@pytest.mark.parametrize('ordinal', [False, True])
+@pytest.mark.parametrize('block', [1 << 26, 1 << 16])
+def test_reader_started_before_the_hierarchy(tmp_path, monkeypatch, ordinal,
+                                             block):
+    """`workflow` starts the first file's reader next to the context, before
+    it reads the hierarchy (routes.device_text.start_text_ahead): blocks are
+    copied detached (wk_dtok_copy_ahead), their pinned buffers reused at once,
+    and the engine takes the reader over.  Same tables and log as without."""
+    from woltka_amd import classify as C
+    from woltka_amd.routes import device_text as D
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    monkeypatch.setattr(D, 'TEXT_AHEAD_MIN', 0)
+    rng = random.Random(77 + ordinal)
+    if ordinal:
+        coords, text = _random_coords_sam(rng, 5000)
+        (tmp_path / 'coords.txt').write_text(coords)
+        extra = dict(coords_fp=str(tmp_path / 'coords.txt'))
+    else:
+        tax = os.path.join(ROOT, 'tests', 'golden', 'data', 'taxonomy')
+        with open(os.path.join(tax, 'taxid.map')) as f:
+            subjects = [ln.split('\t')[0] for ln in f][:80]
+        text = _random_sam(rng, 5000, subjects, True, True, True, big=True)
+        extra = dict(nodes_fps=[os.path.join(tax, 'nodes.dmp')],
+                     map_fps=[os.path.join(tax, 'taxid.map')],
+                     ranks='none,phylum,genus')
+    d = tmp_path / 'in'
+    d.mkdir()
+    (d / 'S1.sam').write_text(text)
+    (d / 'S2.sam').write_text(text[:text.index('\n', len(text) // 3) + 1])
+    monkeypatch.setenv('WOLTKA_NO_TEXT_AHEAD', '1')
+    want, want_log = _run(tmp_path, 'w', False, input_fp=str(d),
+                          input_fmt='sam', **extra)
+    monkeypatch.delenv('WOLTKA_NO_TEXT_AHEAD')
+    for fmt in ('sam', None):
+        C.ROUTES.clear()
+        got, log = _run(tmp_path, f'a{fmt}', False, input_fp=str(d),
+                        input_fmt=fmt, **extra)
+        assert C.ROUTES.get('text_ahead', 0) == 1, dict(C.ROUTES)
+        assert C.ROUTES.get('dhits' if ordinal else 'dtok', 0) > 0
+        assert got == want
+        if fmt:
+            assert log == want_log
+    host, _ = _run(tmp_path, 'h', True, input_fp=str(d), input_fmt='sam',
+                   **extra)
+    assert host == want
+    assert not D._text_ahead
+
+
+def test_reader_started_ahead_is_dropped_when_the_file_goes_another_way(
+        tmp_path, monkeypatch):
+    """A reader started for a file that the host tokenizer reads after all
+    (`--trim-sub`: names are rewritten on the host): stopped, its copies
+    forgotten, the tables those of the host route."""
+    from woltka_amd import classify as C
+    from woltka_amd.routes import device_text as D
+    monkeypatch.setattr(D, 'TEXT_AHEAD_MIN', 0)
+    rng = random.Random(5)
+    subjects = [f'G{i:04d}_{i % 3}' for i in range(100)]
+    text = _random_sam(rng, 3000, subjects, True, False, False)
+    d = tmp_path / 'in'
+    d.mkdir()
+    (d / 'S1.sam').write_text(text)
+    C.ROUTES.clear()
+    got, _ = _run(tmp_path, 'a', False, input_fp=str(d), input_fmt='sam',
+                  trimsub='_')
+    assert C.ROUTES.get('text_ahead', 0) == 0
+    assert not D._text_ahead
+    host, _ = _run(tmp_path, 'h', True, input_fp=str(d), input_fmt='sam',
+                   trimsub='_')
+    assert got == host
+
+
+@pytest.mark.parametrize('block', [1 << 26, 1 << 13])
+def test_refused_block_of_a_reader_ahead_comes_back_from_the_device(
+        tmp_path, monkeypatch, block):
+    """Blocks copied detached whose kernels leave them to the host tokenizer
+    (subjects that `str.rstrip()` would shorten): the host parses the text as
+    the device holds it (wk_dtok_text_back), with the ends the reader kept."""
+    from woltka_amd import classify as C
+    from woltka_amd.routes import device_text as D
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    monkeypatch.setattr(D, 'TEXT_AHEAD_MIN', 0)
+    tails = ['', '', '', '\x1c', '\xa0', '']
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    rows = [f'r{q // 3}\tG{q % 11}{tails[q % len(tails)]}\n'
+            for q in range(3000)]
+    (indir / 'S1.map').write_text(''.join(rows))
+    kw = dict(input_fp=str(indir), input_fmt='map')
+    C.ROUTES.clear()
+    a, _ = _run(tmp_path, 'd', False, **kw)
+    assert C.ROUTES.get('text_ahead', 0) == 1, dict(C.ROUTES)
+    assert C.ROUTES.get('host_block', 0) > 0
+    b, _ = _run(tmp_path, 'h', True, **kw)
+    assert a == b
+
+
+def test_text_back_returns_the_bytes_of_the_block_scanned_last():
+    from woltka_amd import _native as nat
+    ctx = nat.Context(0)
+    tok = nat.Tokenizer(2)
+    try:
+        ctx.dtok_format('sam')
+        pinned = ctx.host_alloc(1 << 16, np.uint8)
+        texts = [b''.join(b'q%d\t0\tS%d\t1\t1\t5M\t*\t0\t0\t*\t*\n' % (i, i % 7)
+                          for i in range(k * 100, k * 100 + 90))
+                 for k in range(3)]
+        tickets = []
+        for t in texts:             # one pinned buffer, reused for every block
+            pinned[:len(t)] = np.frombuffer(t, dtype=np.uint8)
+            tk = ctx.dtok_copy_ahead(pinned, 0, len(t))
+            ctx.dtok_copy_wait(tk)
+            tickets.append(tk)
+        assert len(set(tickets)) == 3
+        pinned[:] = 0
+        for t in texts:             # scanned in the order they were copied
+            status, n_lines = ctx.dtok_scan(tok, pinned, 0, len(t))
+            assert (status, n_lines) == (0, 90)
+            assert ctx.dtok_text_back(len(t)).tobytes() == t
+        assert len(tok.new_subjects()) == 7
+        # copies nobody scans are forgotten
+        pinned[:len(texts[0])] = np.frombuffer(texts[0], dtype=np.uint8)
+        ctx.dtok_copy_wait(ctx.dtok_copy_ahead(pinned, 0, len(texts[0])))
+        ctx.dtok_copy_drop()
+        pinned[:len(texts[1])] = np.frombuffer(texts[1], dtype=np.uint8)
+        status, n_lines = ctx.dtok_scan(tok, pinned, 0, len(texts[1]))
+        assert ctx.dtok_text_back(len(texts[1])).tobytes() == texts[1]
+    finally:
+        tok.close()
+        ctx.close()

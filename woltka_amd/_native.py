@@ -53,7 +53,8 @@ SYMBOLS = (
     'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
     'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
     'wk_dtok_format',
-    'wk_dtok_copy', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
+    'wk_dtok_copy', 'wk_dtok_copy_ahead', 'wk_dtok_copy_wait',
+    'wk_dtok_copy_drop', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
     'wk_dtok_scan_emit', 'wk_dtok_keep_reads', 'wk_readmap_tables',
     'wk_dtok_readmap',
     'wk_dtok_readmap_fetch', 'wk_strata_load', 'wk_strata_labels',
@@ -191,6 +192,12 @@ def load_library():
         'wk_dtok_format': (C.c_int, [p, C.c_int]),
         'wk_tok_set_header_state': (C.c_int, [p, C.c_int]),
         'wk_dtok_copy': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64]),
+        'wk_dtok_copy_ahead': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64,
+                                         C.POINTER(C.c_int32)]),
+        'wk_dtok_copy_wait': (C.c_int, [p, C.c_int32]),
+        'wk_dtok_copy_drop': (C.c_int, [p]),
+        'wk_dtok_text_back': (C.c_int, [p, C.c_void_p, C.c_int64]),
+        'wk_dtok_expect': (C.c_int, [p, C.c_int64]),
         'wk_dtok_scan': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_int, i64p, C.POINTER(C.c_int)]),
         'wk_dtok_stage_hits': (C.c_int, [p, i32p, C.c_int32, C.c_double, i64p,
@@ -320,9 +327,6 @@ class Context:
         self._h = h
         self.device = device
         self.n_nodes = 0
-        import threading
-        self._pin_lock = threading.Lock()   # (see host_alloc)
-        self._copied_once = False
 
     # -- plumbing ---------------------------------------------------------
     def _check(self, rc):
@@ -520,15 +524,13 @@ class Context:
     STAGE_SLOTS = 8
 
     def host_alloc(self, n, dtype=np.uint32):
-        """A pinned host array of ``n`` elements (owned by the context).
-        (Calls are serialised: the library keeps one list of its pinned
-        blocks, and the host layer pins buffers ahead on a thread of its
-        own, hostio.open_context_ahead.)"""
+        """A pinned host array of ``n`` elements (owned by the context; may
+        be called from several threads: the host layer pins buffers ahead on
+        a thread of its own, hostio.open_context_ahead)."""
         dt = np.dtype(dtype)
         out = C.c_void_p()
-        with self._pin_lock:
-            self._check(self._lib.wk_host_alloc(self._h, int(n) * dt.itemsize,
-                                                C.byref(out)))
+        self._check(self._lib.wk_host_alloc(self._h, int(n) * dt.itemsize,
+                                            C.byref(out)))
         buf = (C.c_char * (int(n) * dt.itemsize)).from_address(out.value)
         arr = np.frombuffer(buf, dtype=dt, count=int(n))
         return arr
@@ -574,16 +576,41 @@ class Context:
         ``dtok_scan`` of the same block finds it there."""
         raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
         if raw.size:
-            if not self._copied_once:
-                # (the first copy pins a few bytes for the newline counts)
-                with self._pin_lock:
-                    self._check(self._lib.wk_dtok_copy(
-                        self._h, C.c_void_p(raw.ctypes.data), int(begin),
-                        int(stop)))
-                self._copied_once = True
-                return
             self._check(self._lib.wk_dtok_copy(
                 self._h, C.c_void_p(raw.ctypes.data), int(begin), int(stop)))
+
+    def dtok_copy_ahead(self, buf, begin, stop):
+        """``dtok_copy`` for a reader that reuses ``buf`` before the block is
+        scanned: returns the copy's ticket; after ``dtok_copy_wait(ticket)``
+        the bytes may be overwritten."""
+        raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+        ticket = C.c_int32(-1)
+        if raw.size:
+            args = (self._h, C.c_void_p(raw.ctypes.data), int(begin),
+                    int(stop), C.byref(ticket))
+            self._check(self._lib.wk_dtok_copy_ahead(*args))
+        return ticket.value
+
+    def dtok_copy_wait(self, ticket):
+        self._check(self._lib.wk_dtok_copy_wait(self._h, int(ticket)))
+
+    def dtok_copy_drop(self):
+        """Forget the blocks copied ahead that no scan has asked for."""
+        self._check(self._lib.wk_dtok_copy_drop(self._h))
+
+    def dtok_expect(self, text_bytes):
+        """The blocks scanned from now on are ``text_bytes`` bytes of one
+        sample in all (0: unknown): its record buffers are sized once."""
+        self._check(self._lib.wk_dtok_expect(self._h, int(text_bytes)))
+
+    def dtok_text_back(self, n):
+        """The text of the block scanned last (``n`` = its length) as the
+        device holds it."""
+        out = np.empty(int(n), dtype=np.uint8)
+        if out.size:
+            self._check(self._lib.wk_dtok_text_back(
+                self._h, C.c_void_p(out.ctypes.data), int(n)))
+        return out
 
     def dtok_stage_hits(self, genome_of_subject, th):
         """The scanned block's hits ("ex" flavour) as the staged coord-match

@@ -156,6 +156,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         # read maps formatted on the device (csrc/wk_readmap.hpp)
         self._dmaps = None          # (rank2dir, outzip, namedic) while a file is read that way
         self._dfmt = 'sam'          # format of the file the device tokenises
+        self._dpath = None          # ... and its path
         self._dmaps_n = -1          # subjects the device's read-map tables cover
         self._dmaps_ok = False
         self._mring = None          # pinned buffers the map text is fetched into
@@ -189,6 +190,10 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
             if self._strata_ahead is not None:
                 self._strata_ahead[0].join()
                 self._strata_ahead = None
+            # (a reader started ahead that no file of this run took over: it
+            # copies into this context)
+            from .routes.device_text import drop_text_ahead
+            drop_text_ahead()
             if self._read_pool is not None:
                 self._read_pool.shutdown(wait=True)
                 self._read_pool = None
@@ -356,6 +361,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
                 self._dmaps = dmaps if not (words or device_ex) else None
                 self.ctx.dtok_keep_reads(self._dmaps is not None)
                 self._dfmt = fmt
+                self._dpath = getattr(stream, 'name', None)
                 self.ctx.dtok_format(fmt)
                 try:
                     yield from self._device_chunks(reader, block_bytes,
@@ -365,6 +371,8 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
                     if getattr(self.ctx, '_h', None):   # (still open)
                         self.ctx.dtok_keep_reads(False)
                 return
+        from .routes.device_text import drop_text_ahead
+        drop_text_ahead()       # (a reader started for the device route)
         if want_groups and self._dstrata is not None:
             # (the device holds the join table but this file is tokenised on
             # the host after all)

@@ -194,9 +194,11 @@ struct wk_ctx {
     hipEvent_t kt_tail = nullptr;   // last event of the chain
     int kt_depth = 0;
     double lap_s[4] = {0, 0, 0, 0};   // (wk_tune "lap_print") seconds inside wk_dtok_copy / scan / waits of scan / emit
+    double lap_x[6] = {0, 0, 0, 0, 0, 0};  // ... of the scan: until the buffer is claimed / line starts queued / parse queued / emission queued / finish / names
     double lap_copy_ms = 0;           // ... and the copies' own durations (events around each on the copy stream)
     int64_t lap_copy_bytes = 0;
-    hipEvent_t copy_ev0[4] = {};      // (kTextBufs) start of a block's copy
+    hipEvent_t copy_ev0[192] = {};    // (kTextBufs) start of a block's copy
+    hipEvent_t copy_evm[192] = {};    // ... its end (the newline count behind it runs on a stream of its own)
 
     int lds_slots = 8192;  // LDS front-cache slots per workgroup (16 B each = 128 KiB)
     int threads = 1024;    // workgroup size of the direct classify kernel
@@ -259,9 +261,22 @@ struct wk_ctx {
     static constexpr int kStageSlots = 8;
     hipEvent_t slot_ev[kStageSlots] = {};
     bool slot_busy[kStageSlots] = {};
-    std::vector<void*> host_blocks;      // wk_host_alloc
+    std::vector<void*> host_blocks;      // wk_host_alloc (guarded by host_mu: the host layer pins buffers on several threads)
+    std::mutex host_mu;
     // device tokenizer (wk_dtok.hpp): the block scanned last and the dictionary mirror
-    static constexpr int kTextBufs = 4;   // the block being scanned + three copied ahead
+    // the block being scanned + the blocks copied ahead of it.  Three are enough while the scans keep up with
+    // the link; the host layer's reader may start before anything can be scanned (the hierarchy is still
+    // being read) and then runs as far ahead as it likes -- HBM is what a 288 GB device has to spare; the
+    // buffers are allocated as they are first used, the lowest free one first
+    static constexpr int kTextBufs = 192;
+    static_assert(sizeof(copy_ev0) / sizeof(copy_ev0[0]) == kTextBufs, "copy_ev0 has kTextBufs entries");
+    // (text buffers are cut from slabs of kSlabBufs: one hipMalloc per GB instead of one per block while the reader
+    // runs ahead -- every allocation holds the runtime's lock against the launches of the scans; a block larger than a
+    // slab's share gets a buffer of its own, d_textbuf[k])
+    static constexpr int kSlabBufs = 16;
+    static constexpr size_t kTextStride = ((size_t)66 << 20) + 256;
+    DevBuf d_textslab[kTextBufs / kSlabBufs];
+    unsigned char* d_textptr[kTextBufs] = {};
     DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
@@ -283,14 +298,29 @@ struct wk_ctx {
     bool dt_ready = false;
     // the text of a block is copied on a stream of its own into one of two
     // buffers while the kernels work on the other (wk_dtok_copy)
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, count_stream = nullptr;
     hipEvent_t copy_ev[kTextBufs] = {};
     const char* copy_src[kTextBufs] = {};
     DevBuf d_tiles_k[kTextBufs], d_tile_off_k[kTextBufs];          // newlines per tile of a block copied ahead, counted behind its copy
     unsigned long long* copy_newlines = nullptr;   // [kTextBufs] pinned: their totals
     bool copy_counted[kTextBufs] = {};
     uint32_t copy_n[kTextBufs] = {};
-    int copy_next = 0, dt_cur = 0;
+    int dt_cur = 0;
+    // blocks are scanned in the order they were copied: a copy's number tells two buffers with the same tag apart
+    unsigned long long copy_seq[kTextBufs] = {}, copy_seq_next = 1;
+    // a block copied by wk_dtok_copy_ahead: the host bytes are not kept until the scan (the reader reuses its pinned
+    // buffer once the copy is through); what the scan wants from them comes back from the device when it does
+    bool copy_detached[kTextBufs] = {};
+    char copy_last[kTextBufs] = {};   // the block's last byte (a last line without newline)
+    bool dt_detached = false;         // the block scanned last: its host bytes are gone
+    // (wk_dtok_expect) bytes of text the open sample will have brought in all; the records that makes, told from
+    // the first block's lines per byte: the sample's record buffers are sized once instead of doubled eight times
+    int64_t dt_expect_bytes = 0, w_expect = 0;
+    // Small results of a block (its DtokState, totals) come back through pinned memory that a one-wave kernel
+    // writes (small_back): a hipMemcpyAsync of a few bytes queues on the DMA engine behind the 64 MB text copy
+    // that is under way there, and the scan loop then runs at the pace of the link instead of the kernels'
+    unsigned char* host_back = nullptr;   // [kBackSlots][kBackBytes] pinned, then copy_newlines[kTextBufs]
+    static constexpr int kBackSlots = 4, kBackBytes = 256;
     // A text buffer is free, holds a block copied ahead (tagged by copy_src / copy_n), or is the one the
     // kernels of the block scanned last read (until the next scan begins).  wk_dtok_copy may be called
     // from another thread than the scans (the host layer's reader thread issues the copies as soon as a
@@ -298,6 +328,7 @@ struct wk_ctx {
     enum : unsigned char { kBufFree = 0, kBufCopied = 1, kBufScanning = 2 };
     unsigned char buf_state[kTextBufs] = {};
     std::mutex copy_mu;
+    std::mutex slab_mu;   // a slab is allocated by whoever needs one of its buffers first
     // read maps formatted on the device (wk_readmap.hpp): per job the taxon slot of every subject, the slots' order
     // and shown text; per block the reads' leader lines, line lengths / offsets and the text itself
     struct MapTables {
@@ -356,6 +387,43 @@ constexpr int kStatBlocks = 16384;  // >= the largest classify grid (256 CUs x 3
 
 unsigned long long* scalar_u64(wk_ctx* c, int idx) { return c->scalars.as<unsigned long long>() + idx; }
 int* scalar_err(wk_ctx* c) { return c->scalars.as<int>(); }
+
+// Device memory for text buffer k, at least `need` bytes.
+hipError_t text_buffer(wk_ctx* c, int k, size_t need) {
+    if (need <= wk_ctx::kTextStride) {
+        DevBuf& slab = c->d_textslab[k / wk_ctx::kSlabBufs];
+        std::lock_guard<std::mutex> lock(c->slab_mu);
+        if (!slab.p) {
+            const hipError_t e = slab.reserve(wk_ctx::kTextStride * wk_ctx::kSlabBufs);
+            if (e != hipSuccess) return e;
+        }
+        c->d_textptr[k] = slab.as<unsigned char>() + (size_t)(k % wk_ctx::kSlabBufs) * wk_ctx::kTextStride;
+        return hipSuccess;
+    }
+    const hipError_t e = c->d_textbuf[k].reserve(need);
+    if (e == hipSuccess) c->d_textptr[k] = c->d_textbuf[k].as<unsigned char>();
+    return e;
+}
+
+// `bytes` (<= 256, a multiple of 4) from device memory to pinned host memory, by the device itself
+__global__ void small_back_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ host, uint32_t words) {
+    if (threadIdx.x < words) host[threadIdx.x] = src[threadIdx.x];
+}
+
+// (one word to device memory without a trip through the DMA queue)
+__global__ void store_u32_kernel(uint32_t* dst, uint32_t value) { *dst = value; }
+
+// Queue the copy of a small result into slot `slot` of the pinned scratch; read it with small_back_get once the
+// stream has been waited for.
+hipError_t small_back(wk_ctx* c, int slot, const void* dev, size_t bytes) {
+    if (!c->host_back || slot < 0 || slot >= wk_ctx::kBackSlots || bytes > (size_t)wk_ctx::kBackBytes || (bytes & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(small_back_kernel, dim3(1), dim3(64), 0, c->stream, static_cast<const uint32_t*>(dev),
+                       reinterpret_cast<uint32_t*>(c->host_back + (size_t)slot * wk_ctx::kBackBytes), (uint32_t)(bytes / 4));
+    return hipGetLastError();
+}
+void small_back_get(wk_ctx* c, int slot, void* out, size_t bytes) {
+    std::memcpy(out, c->host_back + (size_t)slot * wk_ctx::kBackBytes, bytes);
+}
 
 struct Lap {
     double* acc;
@@ -746,6 +814,7 @@ static int streams_needed(const wk_ctx* c) { return std::max(1, (int)(((int64_t)
 // the accumulation is empty again
 static int words_reset(wk_ctx* c) {
     c->w_records = c->w_reads = 0;
+    c->w_expect = 0;
     c->w_open = false;
     c->w_counts_known = false;
     if (c->w_cursor.p) HIP_TRY(c, hipMemsetAsync(c->w_cursor.p, 0, kMaxStreams * 8, c->stream));
@@ -797,6 +866,9 @@ int wk_create(int device, wk_ctx** out) {
     if ((e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->host_back),
+                           (size_t)wk_ctx::kBackSlots * wk_ctx::kBackBytes + (size_t)wk_ctx::kTextBufs * 8,
+                           hipHostMallocDefault)) != hipSuccess ||
         (e = c->scalars.reserve(128)) != hipSuccess ||
         (e = hipMemsetAsync(c->scalars.p, 0, 128, c->stream)) != hipSuccess ||
         (e = c->stat_block.reserve((size_t)kStatBlocks * 16)) != hipSuccess ||
@@ -805,6 +877,7 @@ int wk_create(int device, wk_ctx** out) {
         wk_destroy(c);
         return rc;
     }
+    c->copy_newlines = reinterpret_cast<unsigned long long*>(c->host_back + (size_t)wk_ctx::kBackSlots * wk_ctx::kBackBytes);
     // the LDS front cache needs more than the default 64 KiB dynamic LDS limit
     // (160 KiB per CU minus the kernels' few bytes of static LDS)
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stripe_match_kernel),
@@ -900,6 +973,7 @@ void wk_destroy(wk_ctx* c) {
         c->d_tiles_k[q].release();
         c->d_tile_off_k[q].release();
         c->d_textbuf[q].release();
+        if (q % wk_ctx::kSlabBufs == 0) c->d_textslab[q / wk_ctx::kSlabBufs].release();
     }
     for (DevBuf* b : {&c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
                       &c->d_state, &c->d_dict, &c->d_arena})
@@ -910,13 +984,17 @@ void wk_destroy(wk_ctx* c) {
     }
     c->resident.clear();
     for (void* hp : c->host_blocks) (void)hipHostFree(hp);
+    if (c->host_back) (void)hipHostFree(c->host_back);
     for (const wk_ctx::HostReg& r : c->regs) (void)hipHostUnregister(const_cast<char*>(r.p));
     c->regs.clear();
     for (hipEvent_t ev : c->copy_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->copy_ev0)
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->copy_evm)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->count_stream) (void)hipStreamDestroy(c->count_stream);
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (DevBuf& b : c->rank_tab) b.release();
@@ -1058,6 +1136,9 @@ int wk_tune(wk_ctx* c, const char* name, int64_t value) {
         if (c->lap_copy_ms > 0)
             fprintf(stderr, "[wk] the copies themselves: %.1f ms for %.2f GB = %.1f GB/s (events around each copy + newline count on the copy stream)\n",
                     c->lap_copy_ms, (double)c->lap_copy_bytes / 1e9, (double)c->lap_copy_bytes / 1e6 / c->lap_copy_ms);
+        fprintf(stderr, "[wk] scan, host side: claim %.3f, line starts queued %.3f, parse queued %.3f, emission queued %.3f, finish %.3f, names %.3f\n",
+                c->lap_x[0], c->lap_x[1], c->lap_x[2], c->lap_x[3], c->lap_x[4], c->lap_x[5]);
+        for (double& x : c->lap_x) x = 0;
         c->lap_s[0] = c->lap_s[1] = c->lap_s[2] = c->lap_s[3] = 0;
         c->lap_copy_ms = 0;
         c->lap_copy_bytes = 0;
@@ -1922,18 +2003,24 @@ int wk_host_alloc(wk_ctx* c, size_t bytes, void** out) {
     DeviceGuard guard(c->device);
     void* p = nullptr;
     HIP_TRY(c, hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
-    c->host_blocks.push_back(p);
+    {
+        std::lock_guard<std::mutex> lock(c->host_mu);
+        c->host_blocks.push_back(p);
+    }
     *out = p;
     return WK_OK;
 }
 
 int wk_host_free(wk_ctx* c, void* p) {
     if (!c || !p) return WK_E_ARG;
-    auto it = std::find(c->host_blocks.begin(), c->host_blocks.end(), p);
-    if (it == c->host_blocks.end()) return fail(c, WK_E_ARG, "not a block of wk_host_alloc");
+    {
+        std::lock_guard<std::mutex> lock(c->host_mu);
+        auto it = std::find(c->host_blocks.begin(), c->host_blocks.end(), p);
+        if (it == c->host_blocks.end()) return fail(c, WK_E_ARG, "not a block of wk_host_alloc");
+        c->host_blocks.erase(it);
+    }
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->host_blocks.erase(it);
     HIP_TRY(c, hipHostFree(p));
     return WK_OK;
 }
@@ -2343,11 +2430,12 @@ static int words_room(wk_ctx* c, int64_t n_more) {
         const int want = c->w_sliced ? streams_needed(c) : 1;
         c->w_streams = std::max(c->w_streams, want);
         const size_t need = (size_t)(c->w_records + n_more) * 4 + 64;
+        const size_t room = std::max(need * 2, (size_t)std::max<int64_t>(c->w_expect, 0) * 4 + 64);
         for (int k = 0; k < c->w_streams; ++k) {
             DevBuf& b = c->w_stream[k];
             if (need <= b.cap) continue;
             DevBuf bigger;
-            HIP_TRY(c, bigger.reserve(need * 2));
+            HIP_TRY(c, bigger.reserve(room));
             const size_t keep = std::min((size_t)c->w_records * 4, b.cap);
             if (keep > 0) HIP_TRY(c, hipMemcpyAsync(bigger.p, b.p, keep, hipMemcpyDeviceToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2358,9 +2446,9 @@ static int words_room(wk_ctx* c, int64_t n_more) {
     }
     const size_t need = (size_t)(c->w_records + n_more) * 4 + 64;
     if (need <= c->c_words.cap) return WK_OK;
-    // grow: a new buffer (twice the need) takes over what is there
+    // grow: a new buffer (twice the need, or what the sample is expected to bring) takes over what is there
     DevBuf bigger;
-    HIP_TRY(c, bigger.reserve(need * 2));
+    HIP_TRY(c, bigger.reserve(std::max(need * 2, (size_t)std::max<int64_t>(c->w_expect, 0) * 4 + 64)));
     if (c->w_records > 0) HIP_TRY(c, hipMemcpyAsync(bigger.p, c->c_words.p, (size_t)c->w_records * 4, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->c_words.release();
@@ -2549,65 +2637,121 @@ int wk_host_unregister(wk_ctx* c, const void* p) {
     return WK_OK;
 }
 
-int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
+static int dtok_copy_impl(wk_ctx* c, const char* text, int64_t begin, int64_t stop, bool detached, int32_t* ticket) {
     if (!c || !text || begin < 0 || stop < begin) return WK_E_ARG;
+    if (ticket) *ticket = -1;
     Lap lap(&c->lap_s[0]);
     const int64_t n64 = stop - begin;
     if (n64 == 0 || n64 >= (1ll << 31) - 64) return WK_OK;
     DeviceGuard guard(c->device);
-    if (!c->copy_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (hipEvent_t& ev : c->copy_ev) HIP_TRY(c, hipEventCreate(&ev));
-        for (hipEvent_t& ev : c->copy_ev0) HIP_TRY(c, hipEventCreate(&ev));
-    }
     int k = -1;
     {
         std::lock_guard<std::mutex> lock(c->copy_mu);
-        for (int q = 0; q < wk_ctx::kTextBufs && k < 0; ++q) {
-            const int cand = (c->copy_next + q) % wk_ctx::kTextBufs;
-            if (c->buf_state[cand] == wk_ctx::kBufFree) k = cand;
-        }
+        if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->count_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->count_stream, hipStreamNonBlocking));
+        for (int q = 0; q < wk_ctx::kTextBufs && k < 0; ++q)
+            if (c->buf_state[q] == wk_ctx::kBufFree) k = q;
         if (k >= 0) {
             c->buf_state[k] = wk_ctx::kBufCopied;
             c->copy_src[k] = nullptr;  // (tagged below, once the copy is queued)
-            c->copy_next = (k + 1) % wk_ctx::kTextBufs;
+            c->copy_seq[k] = c->copy_seq_next++;
         }
     }
     if (k < 0) return fail(c, WK_E_STATE, "more than %d blocks copied ahead of the scan", wk_ctx::kTextBufs - 1);
+    if (!c->copy_ev[k]) HIP_TRY(c, hipEventCreate(&c->copy_ev[k]));
+    if (!c->copy_ev0[k]) HIP_TRY(c, hipEventCreate(&c->copy_ev0[k]));
+    if (!c->copy_evm[k]) HIP_TRY(c, hipEventCreate(&c->copy_evm[k]));
     const uint32_t n = (uint32_t)n64;
     // (at least a full block's worth from the start: a file's first blocks are small, and growing a buffer
     // three times means three hipFree / hipMalloc pairs per buffer while the dictionary is cold)
-    HIP_TRY(c, c->d_textbuf[k].reserve(std::max<size_t>((size_t)n + 64, ((size_t)66 << 20) + 64)));
+    HIP_TRY(c, text_buffer(c, k, (size_t)n + 64));
     HIP_TRY(c, hipEventRecord(c->copy_ev0[k], c->copy_stream));
     // (only the copy on this stream: the 64 zero bytes behind the text are a fill
     // kernel, which wk_dtok_scan launches on its own stream behind the copy's event)
-    HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, text + begin, (size_t)n, c->copy_stream));
-    // ... and, behind the copy on its stream, the count of the block's newlines:
-    // wk_dtok_scan finds the number on the host instead of waiting for it
+    HIP_TRY(c, copy_text_async(c, c->d_textptr[k], text + begin, (size_t)n, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->copy_evm[k], c->copy_stream));
+    // ... and, behind the copy, the count of the block's newlines -- on a stream of its own, so that the next
+    // block's copy follows this one without a gap; the total lands in pinned memory (written by the kernel: no
+    // trip through the DMA queue): wk_dtok_scan finds the number on the host instead of waiting for it
     {
-        if (!c->copy_newlines) {
-            void* hp = nullptr;
-            HIP_TRY(c, hipHostMalloc(&hp, 64, hipHostMallocDefault));
-            c->host_blocks.push_back(hp);
-            c->copy_newlines = static_cast<unsigned long long*>(hp);
-        }
         const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
         HIP_TRY(c, c->d_tiles_k[k].reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off_k[k].reserve((size_t)n_tiles * 8));
-        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->copy_stream, c->d_textbuf[k].as<unsigned char>(), n,
+        HIP_TRY(c, hipStreamWaitEvent(c->count_stream, c->copy_evm[k], 0));
+        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->count_stream, c->d_textptr[k], n,
                            c->d_tiles_k[k].as<unsigned long long>());
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->copy_stream, c->d_tiles_k[k].as<unsigned long long>(),
-                           c->d_tile_off_k[k].as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 10 + k));
-        HIP_TRY(c, hipMemcpyAsync(&c->copy_newlines[k], scalar_u64(c, 10 + k), 8, hipMemcpyDeviceToHost, c->copy_stream));
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->count_stream, c->d_tiles_k[k].as<unsigned long long>(),
+                           c->d_tile_off_k[k].as<unsigned long long>(), (int64_t)n_tiles, &c->copy_newlines[k]);
         HIP_TRY(c, hipGetLastError());
         c->copy_counted[k] = true;
     }
-    HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->count_stream));
     {
         std::lock_guard<std::mutex> lock(c->copy_mu);
         c->copy_n[k] = n;
+        c->copy_last[k] = text[stop - 1];
+        c->copy_detached[k] = detached;
         c->copy_src[k] = text + begin;
     }
+    if (ticket) *ticket = k;
+    return WK_OK;
+}
+
+int wk_dtok_copy(wk_ctx* c, const char* text, int64_t begin, int64_t stop) {
+    return dtok_copy_impl(c, text, begin, stop, false, nullptr);
+}
+
+// The same copy for a reader that does not keep the host bytes until the block is scanned: `ticket` names the copy for
+// wk_dtok_copy_wait, after which text[begin, stop) may be overwritten.  The scan of the block is called with the same
+// (text, begin, stop) as ever -- the pointer is only the block's tag then; where it wants the bytes themselves (names
+// of subjects the dictionary does not hold) they are fetched from the device, and wk_dtok_text_back hands the host
+// layer the block's text when the kernels leave the block to the host tokenizer.
+int wk_dtok_copy_ahead(wk_ctx* c, const char* text, int64_t begin, int64_t stop, int32_t* ticket) {
+    if (!ticket) return WK_E_ARG;
+    return dtok_copy_impl(c, text, begin, stop, true, ticket);
+}
+
+int wk_dtok_copy_wait(wk_ctx* c, int32_t ticket) {
+    if (!c) return WK_E_ARG;
+    if (ticket < 0) return WK_OK;  // (an empty block: nothing was copied)
+    if (ticket >= wk_ctx::kTextBufs || !c->copy_evm[ticket]) return fail(c, WK_E_ARG, "not a ticket of wk_dtok_copy_ahead");
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipEventSynchronize(c->copy_evm[ticket]));
+    return WK_OK;
+}
+
+// The text blocks scanned from now on belong to `text_bytes` bytes of one sample (0: unknown again): the buffers of its
+// records are sized for all of them when the first block is emitted.
+int wk_dtok_expect(wk_ctx* c, int64_t text_bytes) {
+    if (!c || text_bytes < 0) return WK_E_ARG;
+    c->dt_expect_bytes = text_bytes;
+    c->w_expect = 0;
+    return WK_OK;
+}
+
+// Forget the blocks copied ahead that no scan has asked for (the file goes another way after all).
+int wk_dtok_copy_drop(wk_ctx* c) {
+    if (!c) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    if (c->count_stream) HIP_TRY(c, hipStreamSynchronize(c->count_stream));
+    std::lock_guard<std::mutex> lock(c->copy_mu);
+    for (int q = 0; q < wk_ctx::kTextBufs; ++q)
+        if (c->buf_state[q] == wk_ctx::kBufCopied) {
+            c->buf_state[q] = wk_ctx::kBufFree;
+            c->copy_src[q] = nullptr;
+            c->copy_counted[q] = false;
+        }
+    return WK_OK;
+}
+
+// The text of the block scanned last, as the device holds it: n = stop - begin bytes into `out`.
+int wk_dtok_text_back(wk_ctx* c, char* out, int64_t n) {
+    if (!c || !out || n < 0) return WK_E_ARG;
+    if (!c->dt_text || (int64_t)c->dt_n != n) return fail(c, WK_E_STATE, "no scanned block of %lld bytes on the device", (long long)n);
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipMemcpyAsync(out, c->dt_text, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return WK_OK;
 }
 
@@ -2744,25 +2888,35 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             res = &r;
         }
     bool counted = false;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap_mark = [&](int i) {
+        const auto now = std::chrono::steady_clock::now();
+        c->lap_x[i] += std::chrono::duration<double>(now - lap_t).count();
+        lap_t = now;
+    };
     {
         std::lock_guard<std::mutex> lock(c->copy_mu);
         // (the buffer of the block scanned before is free from here on: its kernels have been waited for)
         for (int q = 0; q < wk_ctx::kTextBufs; ++q)
             if (c->buf_state[q] == wk_ctx::kBufScanning) c->buf_state[q] = wk_ctx::kBufFree;
+        // (the oldest copy with this tag: a reader that reuses its pinned buffers may have copied two blocks
+        // of one length from one address)
         for (int q = 0; q < wk_ctx::kTextBufs && !resident; ++q)
-            if (c->buf_state[q] == wk_ctx::kBufCopied && c->copy_src[q] == src && c->copy_n[q] == n) k = q;
+            if (c->buf_state[q] == wk_ctx::kBufCopied && c->copy_src[q] == src && c->copy_n[q] == n &&
+                (k < 0 || c->copy_seq[q] < c->copy_seq[k]))
+                k = q;
         if (!resident && k < 0) {  // not copied ahead: a free buffer, copied into below
-            for (int q = 0; q < wk_ctx::kTextBufs && k < 0; ++q) {
-                const int cand = (c->copy_next + q) % wk_ctx::kTextBufs;
-                if (c->buf_state[cand] == wk_ctx::kBufFree) k = cand;
-            }
+            for (int q = 0; q < wk_ctx::kTextBufs && k < 0; ++q)
+                if (c->buf_state[q] == wk_ctx::kBufFree) k = q;
             if (k < 0) return fail(c, WK_E_STATE, "every text buffer holds a block copied ahead");
             c->copy_counted[k] = false;
             c->copy_src[k] = nullptr;
+            c->copy_detached[k] = false;
             k = -1 - k;  // (marks "copy now")
         } else if (!resident) {
             counted = c->copy_counted[k];
         }
+        c->dt_detached = !resident && k >= 0 && c->copy_detached[k];
         if (!resident) {
             const int kk = k >= 0 ? k : -1 - k;
             c->buf_state[kk] = wk_ctx::kBufScanning;
@@ -2776,11 +2930,12 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));  // (the pad: zeroed by the count behind the copy)
     } else {
         k = -1 - k;
-        HIP_TRY(c, c->d_textbuf[k].reserve(std::max<size_t>((size_t)n + 64, ((size_t)66 << 20) + 64)));
-        HIP_TRY(c, copy_text_async(c, c->d_textbuf[k].p, src, n, c->stream));  // (the pad: zeroed by the count below)
+        HIP_TRY(c, text_buffer(c, k, (size_t)n + 64));
+        HIP_TRY(c, copy_text_async(c, c->d_textptr[k], src, n, c->stream));  // (the pad: zeroed by the count below)
     }
     if (!resident) c->dt_cur = k;
-    c->dt_text = resident ? resident : c->d_textbuf[k].as<unsigned char>();
+    lap_mark(0);
+    c->dt_text = resident ? resident : c->d_textptr[k];
     // line starts: newlines per tile -> offsets -> positions
     const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
     HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
@@ -2805,7 +2960,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         }
         {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->copy_ev0[k], c->copy_ev[k]) == hipSuccess) {
+            if (hipEventElapsedTime(&ms, c->copy_ev0[k], c->copy_evm[k]) == hipSuccess) {
                 c->lap_copy_ms += ms;
                 c->lap_copy_bytes += n;
             } else {
@@ -2825,7 +2980,9 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         tile_off = c->d_tile_off.as<unsigned long long>();
     }
-    const bool open_end = src[n - 1] != '\n';  // a last line without newline
+    // a last line without newline (the byte was noted when the block was copied ahead: the host bytes of such a
+    // block may be gone)
+    const bool open_end = (!resident && counted ? c->copy_last[k] : src[n - 1]) != '\n';
     const uint32_t lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
     // (sized for a full block of short lines from the first block on: a file's first blocks are small, and
     // every growth is a hipFree -- which waits for the device -- and a hipMalloc per array)
@@ -2852,6 +3009,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     ktimer_end(c, kt);
     HIP_TRY(c, hipGetLastError());
     c->dt_lines = lines;
+    lap_mark(1);
     // parse; subjects the dictionary does not know are interned in text order, then once more
     for (int round = 0; round < 3; ++round) {
         int rc = dtok_mirror_dict(c, tok);
@@ -2865,20 +3023,27 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             hipLaunchKernelGGL(dtok_parse_kernel<false>, dim3((lines + kDtokThreads - 1) / kDtokThreads), dim3(kDtokThreads), 0, c->stream, a);
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
+        lap_mark(2);
         const bool speculate = emit && round == 0 && !extra && c->w_open && lines > 0;
         bool ordered = false;
         unsigned long long totals = 0;
         if (speculate && (rc = dtok_emit_launch(c, &ordered, &totals))) return rc;
+        lap_mark(3);
         DtokState st{};
-        HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        static_assert(sizeof(DtokState) <= (size_t)wk_ctx::kBackBytes && sizeof(DtokState) % 4 == 0, "DtokState fits a slot");
+        HIP_TRY(c, small_back(c, 0, c->d_state.p, sizeof st));
         {
             Lap wait(&c->lap_s[2]);
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
+        small_back_get(c, 0, &st, sizeof st);
+        if (speculate && ordered) small_back_get(c, 1, &totals, 8);
+        lap_t = std::chrono::steady_clock::now();
         if (speculate) {
             const bool keep = st.flags == 0 && st.n_unknown == 0;
             int64_t nr = 0, nrec = 0;
             if ((rc = dtok_emit_finish(c, keep, ordered, st, totals, &nr, &nrec))) return rc;
+            lap_mark(4);
             if (keep) {
                 *status = 0;
                 *n_lines = lines;
@@ -2896,11 +3061,36 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             c->dt_ready = true;
             return WK_OK;
         }
+        lap_t = std::chrono::steady_clock::now();
         std::vector<uint2> unk(st.n_unknown);
         HIP_TRY(c, hipMemcpyAsync(unk.data(), c->d_unknown.p, (size_t)st.n_unknown * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         std::sort(unk.begin(), unk.end(), [](const uint2& x, const uint2& y) { return x.x < y.x; });
-        for (const uint2& u : unk) (void)wkx_tok_intern(tok, src + u.x, u.y);
+        if (!c->dt_detached) {
+            for (const uint2& u : unk) (void)wkx_tok_intern(tok, src + u.x, u.y);
+        } else {
+            // the names come back from the device: one by one while they are few, with the whole block otherwise
+            const bool whole = unk.size() > 128;
+            size_t need = 0;
+            for (const uint2& u : unk) need += u.y;
+            std::vector<char> back(whole ? (size_t)n : need);
+            if (whole) {
+                HIP_TRY(c, hipMemcpyAsync(back.data(), c->dt_text, n, hipMemcpyDeviceToHost, c->stream));
+            } else {
+                size_t at = 0;
+                for (const uint2& u : unk) {
+                    if (u.y) HIP_TRY(c, hipMemcpyAsync(back.data() + at, c->dt_text + u.x, u.y, hipMemcpyDeviceToHost, c->stream));
+                    at += u.y;
+                }
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            size_t at = 0;
+            for (const uint2& u : unk) {
+                (void)wkx_tok_intern(tok, back.data() + (whole ? (size_t)u.x : at), u.y);
+                at += u.y;
+            }
+        }
+        lap_mark(5);
     }
     return fail(c, WK_E_STATE, "device tokenizer: subjects still unknown after interning them");
 }
@@ -2923,6 +3113,11 @@ int wk_dtok_scan_emit(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, i
 // waiting in between: `launch` queues the kernels (and, where the records are placed by prefix sums, the copy of their
 // totals), `finish` — once the stream has been waited for — accepts or discards what they wrote.
 static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* totals) {
+    if (c->dt_expect_bytes > 0 && c->w_expect == 0 && c->dt_n > 0) {
+        // (a record per line at most; 8 % on top of the first block's rate, never more than the 2^30 a pass holds)
+        const double lines = (double)c->dt_expect_bytes * ((double)c->dt_lines / (double)c->dt_n) * 1.08 + (double)c->dt_lines;
+        c->w_expect = (int64_t)std::min(lines, (double)(1ll << 30));
+    }
     int rc = words_roll(c, c->dt_lines);
     if (rc) return rc;
     if ((rc = words_room(c, c->dt_lines))) return rc;
@@ -2962,7 +3157,8 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
             hipLaunchKernelGGL(dtok_emit_kernel, emit_grid, dim3(kDtokThreads), 0, c->stream, a);
         else
             hipLaunchKernelGGL(dtok_place_words_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
-        HIP_TRY(c, hipMemcpyAsync(totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+        (void)totals;  // (slot 1 of the pinned scratch: read by the caller once the stream has been waited for)
+        HIP_TRY(c, small_back(c, 1, scalar_u64(c, 3), 8));
     } else {
         // (first-line flags and emission in one kernel, the runs' lines staged in LDS)
         hipLaunchKernelGGL(dtok_first_emit_kernel, emit_grid, dim3(kDtokThreads), 0, c->stream, a);
@@ -3015,8 +3211,10 @@ int wk_dtok_emit(wk_ctx* c, int64_t* n_reads, int64_t* n_records, int* status) {
     int rc = dtok_emit_launch(c, &ordered, &totals);
     if (rc) return rc;
     DtokState st{};
-    HIP_TRY(c, hipMemcpyAsync(&st, c->d_state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, small_back(c, 0, c->d_state.p, sizeof st));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    small_back_get(c, 0, &st, sizeof st);
+    if (ordered) small_back_get(c, 1, &totals, 8);
     // (a read of more than 16 subjects: nothing counts as appended)
     if ((rc = dtok_emit_finish(c, st.flags == 0, ordered, st, totals, n_reads, n_records))) return rc;
     if (st.flags == 0) *status = 0;
@@ -3319,13 +3517,14 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
         }
         ktimer_end(c, kt);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(&totals, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, small_back(c, 1, scalar_u64(c, 3), 8));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        small_back_get(c, 1, &totals, 8);
     }
     const int64_t hits = (int64_t)(totals & 0xFFFFFFFFull), reads = (int64_t)(totals >> 32);
-    const int32_t end = (int32_t)hits;
-    HIP_TRY(c, hipMemcpyAsync(c->o_hoff.as<int32_t>() + reads, &end, 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // (the offsets' last entry; the stream orders it in front of whatever reads them)
+    hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, c->stream, c->o_hoff.as<uint32_t>() + reads, (uint32_t)hits);
+    HIP_TRY(c, hipGetLastError());
     c->n_hits = hits;
     c->o_reads = reads;
     c->th = th;

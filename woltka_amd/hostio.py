@@ -336,6 +336,17 @@ def open_context_ahead(device, text_ring=None):
     th.start()
 
 
+def peek_context(device, timeout=None):
+    """The context `open_context_ahead` is creating for `device`, once it is
+    there (None: there is none, or it failed -- the engine will say why); it
+    stays the engine's to take."""
+    th, box = _ahead.get(device, (None, None))
+    if th is None:
+        return None
+    th.join(timeout)
+    return box.get('ctx')
+
+
 def _take_context(device):
     th, box = _ahead.pop(device, (None, None))
     if th is None:
@@ -349,7 +360,8 @@ def _take_context(device):
 _warm = {}
 
 
-def warm_tokenizer_ahead(path, fmt, span=256 << 20):
+def warm_tokenizer_ahead(path, fmt, span=int(os.environ.get('WOLTKA_WARM_SPAN', 256 << 20)),
+                         threads=int(os.environ.get('WOLTKA_WARM_THREADS', 0))):
     """On a thread, while the hierarchy / the gene coordinates are read: a
     tokenizer whose dictionary already holds the subjects of the first `span`
     bytes of `path` -- interned by the host tokenizer in text order, i.e. under
@@ -369,7 +381,7 @@ def warm_tokenizer_ahead(path, fmt, span=256 << 20):
             n = min(size, span)
             if n < (8 << 20):
                 return
-            tok = nat.Tokenizer(tokenizer_threads())
+            tok = nat.Tokenizer(threads or tokenizer_threads())
             buf = np.empty(n, dtype=np.uint8)
             with open(path, 'rb') as f:
                 got = tok.read_into(f.fileno(), 0, memoryview(buf))
@@ -425,6 +437,11 @@ def take_warm_tokenizer(path=None):
 
 def drop_context_ahead():
     """Close contexts opened ahead that no engine took (an error on the way)."""
+    try:                                # (its reader first: it copies into one)
+        from .routes.device_text import drop_text_ahead
+        drop_text_ahead()
+    except Exception:
+        pass
     for device in list(_ahead):
         try:
             _take_context(device).close()

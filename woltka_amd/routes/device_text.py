@@ -12,10 +12,325 @@ import numpy as np
 
 from .. import _native as nat
 from ..hostio import (MAX_GROUPS, ROUTES, MapWriter, StageRing, _prefetch,
-                      tokenizer_threads)
+                      peek_context, tokenizer_threads)
 
 
 _HOSTREG_SLOW = {}     # st_dev -> pinning that file system's pages in place is slower than reading them
+
+
+def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE):
+    """Blocks of a plain file for the device tokenizer: [slot, bytes, fill,
+    begin, stop, first, final, header state in, header state out] per block,
+    cut where the last run of equal query ids starts (`tok`: whoever carries
+    the `warm` flag of the dictionary)."""
+    # A slot holds [headroom | file bytes]: the bytes of a block go to
+    # a fixed place, so the reads of the next blocks can be under way
+    # (8 MB pieces on a pool of threads: ~100 GB/s from the page cache
+    # with 16 of them, tools/ubench/pread_scaling.py; one 64 MB call at
+    # a time cut among the tokenizer's threads gave 15-40) while this
+    # one is cut; the unfinished last run of the block before (the
+    # carry) is copied in front of them.
+    from collections import deque
+    pending = deque()       # (slot, buf, futures, want, file position)
+    state = {'next': 0}
+
+    def issue(span, wait):
+        want = min(span, size - state['next'])
+        if want <= 0:
+            return False
+        bufs = ring.current() if wait else ring.try_current()
+        if bufs is None:
+            return False
+        buf, slot = bufs['text'], ring.take()
+        mv = memoryview(buf).cast('B')
+        p0 = state['next']
+        futs = [pool.submit(os.preadv, fd,
+                            [mv[H + o:H + min(o + PIECE, want)]], p0 + o)
+                for o in range(0, want, PIECE)]
+        pending.append((slot, buf, futs, want, p0))
+        state['next'] = p0 + want
+        return True
+
+    carry, in_header, first = b'', True, True
+    # small blocks first while the dictionary is cold: a block's
+    # unknown subjects are listed per record and interned on the host
+    ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
+    span = ramp or block
+    try:
+        while True:
+            if not pending and not issue(min(span, block), True):
+                break
+            while ramp is None and span <= block and len(pending) < 3 \
+                    and issue(block, False):
+                pass
+            slot, buf, futs, want, p0 = pending.popleft()
+            t0 = time.perf_counter()
+            got = sum(f.result() for f in futs)
+            lap['read'] += time.perf_counter() - t0
+            final = p0 + got >= size or got < want
+            if len(carry) > H or span > block:
+                # a run longer than the headroom / a block: the plain way
+                ring.release(slot)
+                while pending:      # (read again from here)
+                    s2, _, f2, _, _ = pending.popleft()
+                    for f in f2:
+                        f.result()
+                    ring.release(s2)
+                want = min(span, size - p0)
+                whole = np.empty(len(carry) + want, dtype=np.uint8)
+                view = memoryview(whole).cast('B')
+                view[:len(carry)] = carry
+                got = rd.read_into(fd, p0, view[len(carry):]) \
+                    if want else 0
+                state['next'] = p0 + got
+                final = p0 + got >= size or got < want
+                slot, out = None, whole[:len(carry) + got]
+            else:
+                start = H - len(carry)
+                if carry:
+                    memoryview(buf).cast('B')[start:H] = carry
+                out = buf[start:H + got]
+            fill = out.size
+            t0 = time.perf_counter()
+            ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                out, final, in_header, fmt)
+            lap['span'] += time.perf_counter() - t0
+            if not ok and not final:    # no complete run yet: read more
+                carry = out.tobytes()
+                span *= 2
+                if slot is not None:
+                    ring.release(slot)
+                continue
+            if ramp is not None:
+                ramp = min(block, ramp * 4)
+                if ramp == block:
+                    tok.warm, ramp = True, None
+            span = ramp or block
+            carry = b'' if final else out[stop:].tobytes()
+            yield slot, out, fill, begin, stop, first, final, \
+                in_header, hdr
+            in_header, first = hdr, False
+            if final:
+                return
+    finally:
+        while pending:
+            s2, _, f2, _, _ = pending.popleft()
+            for f in f2:
+                f.result()
+            ring.release(s2)
+
+
+class _BlockText:
+    """The bytes of a block whose pinned buffer the reader has taken back
+    (`_TextAhead`): `view` still names the place they were copied from -- the
+    block's tag for the scan -- and `get()` puts them together again from what
+    the device holds (the block scanned last) and the ends the reader kept."""
+    __slots__ = ('ctx', 'view', 'n', 'head', 'tail', 'serial', 'now')
+
+    def __init__(self, ctx, view, n, head, tail, serial, now):
+        self.ctx, self.view, self.n = ctx, view, n
+        self.head, self.tail, self.serial, self.now = head, tail, serial, now
+
+    def get(self):
+        if self.now[0] != self.serial:
+            raise RuntimeError('the text of a block was asked for after the '
+                               'next block had been scanned')
+        mid = self.ctx.dtok_text_back(self.n)
+        if not self.head and not self.tail:
+            return mid
+        return np.concatenate([np.frombuffer(self.head, dtype=np.uint8), mid,
+                               np.frombuffer(self.tail, dtype=np.uint8)])
+
+
+class _TextAhead:
+    """The reader thread of the device text route: takes the blocks a
+    generator cuts, starts their copies to the device and hands them on.  A
+    block in a pinned ring buffer is copied *detached* (`wk_dtok_copy_ahead`):
+    the buffer goes back to the ring as soon as the copy is through, not when
+    the block has been scanned -- so the reader runs as far ahead of the scans
+    as the device has text buffers (`depth`).  That is what lets it start
+    before anything can be scanned at all: while the hierarchy is still being
+    read the link is otherwise idle, and most of a 10 GB file is in HBM by the
+    time the first block is looked at."""
+    IN_FLIGHT = 2       # copies under way before the reader waits for the oldest
+
+    def __init__(self, ctx, gen, ring, depth, lap):
+        import queue
+        import threading
+        self.ctx, self.ring, self.lap = ctx, ring, lap
+        self.q = queue.Queue()          # (bounded by `free_bufs`)
+        self.free_bufs = threading.Semaphore(depth)
+        self.stop = threading.Event()
+        self.first = None               # (timing) the first copy: begun, issued
+        self.th = threading.Thread(target=self._work, args=(gen,),
+                                   name='wk-text', daemon=True)
+        self.th.start()
+
+    def _work(self, gen):
+        from collections import deque
+        ctx, ring, lap = self.ctx, self.ring, self.lap
+        inflight = deque()              # (ticket, ring slot)
+        try:
+            for item in gen:
+                slot = item[0]
+                if slot is not None:
+                    while not self.free_bufs.acquire(timeout=0.05):
+                        if self.stop.is_set():
+                            if isinstance(slot, int):
+                                ring.release(slot)
+                            return
+                    t0 = time.perf_counter()
+                    out, fill, begin, stop = item[1:5]
+                    if isinstance(slot, int):
+                        if self.first is None:
+                            self.first = [t0]
+                        ticket = ctx.dtok_copy_ahead(out, begin, stop)
+                        if len(self.first) == 1:
+                            self.first.append(time.perf_counter())
+                        inflight.append((ticket, slot))
+                        item = (('det', out[:begin].tobytes(),
+                                 out[stop:fill].tobytes()),) + tuple(item[1:])
+                        while len(inflight) > self.IN_FLIGHT:
+                            t, s2 = inflight.popleft()
+                            ctx.dtok_copy_wait(t)
+                            ring.release(s2)
+                    else:               # (a file pinned in place: it stays)
+                        ctx.dtok_copy(out, begin, stop)
+                    lap['copy'] += time.perf_counter() - t0
+                self.q.put(item)
+            self.q.put(None)
+        except BaseException as e:      # noqa: BLE001 - raised again by `get`
+            self.q.put(e)
+        finally:
+            try:
+                while inflight:
+                    t, s2 = inflight.popleft()
+                    ctx.dtok_copy_wait(t)
+                    ring.release(s2)
+            except Exception:           # noqa: BLE001 - on its way out
+                pass
+            gen.close()
+
+    def get(self):
+        item = self.q.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def done(self, item):
+        """The block has been scanned: its text buffer on the device is free."""
+        if item[0] is not None:
+            self.free_bufs.release()
+
+    def close(self):
+        """Stop the reader; blocks copied ahead that nobody scanned are
+        forgotten."""
+        self.stop.set()
+        self.th.join()
+        self.ctx.dtok_copy_drop()
+
+
+# A reader started before the engine exists (`workflow` calls this next to
+# `open_context_ahead`, before it reads the hierarchy): the first alignment
+# file's blocks are cut and copied to the device while the taxonomy is parsed.
+# `Engine._device_chunks` takes the reader over when it reaches that file; if
+# the file goes another way after all (`drop_text_ahead`), what was copied is
+# forgotten.
+_text_ahead = {}
+AHEAD_READ_THREADS = int(os.environ.get('WOLTKA_AHEAD_READ_THREADS', 16))
+TEXT_AHEAD_MIN = int(os.environ.get('WOLTKA_TEXT_AHEAD_MIN', 256 << 20))     # smaller files are read when their turn comes
+
+
+def start_text_ahead(path, fmt, device, warm=True):
+    """`path`: a plain (uncompressed, regular) alignment file that will be the
+    first to be read; `fmt`: its format if the caller knows it; `warm`: a
+    tokenizer with the file's first subjects is being prepared
+    (`hostio.warm_tokenizer_ahead`), so that full blocks can be cut from the
+    start.  Anything that goes wrong just means no reader ahead."""
+    import threading
+    if _text_ahead or os.environ.get('WOLTKA_NO_TEXT_AHEAD'):
+        return
+    box = {'path': path}
+
+    def work():
+        ahead = fd = None
+        marks = box['marks'] = [('start', time.perf_counter())]
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            from types import SimpleNamespace
+            size = os.path.getsize(path)
+            if size < TEXT_AHEAD_MIN:
+                return
+            use_fmt = fmt
+            if not use_fmt:
+                from ..align import infer_align_format
+                with open(path, 'rb') as f:
+                    line = f.readline(1 << 16)
+                use_fmt = infer_align_format(iter([line.decode()]))[0]
+            if use_fmt not in ('sam', 'b6o', 'paf', 'map'):
+                return
+            marks.append(('sniffed', time.perf_counter()))
+            ctx = peek_context(device)
+            if ctx is None:
+                return
+            marks.append(('context', time.perf_counter()))
+            R = DeviceTextRoute
+            ring = StageRing(ctx, 8, {
+                'text': (np.uint8, R.DTOK_BLOCK + R.DTOK_HEADROOM)},
+                ready=getattr(ctx, '_text_ring_ready', None))
+            # (4 threads were too few for the link, 6 and 16 did not differ
+            # beside the hierarchy's threads under a cap of 16 CPUs:
+            # tools/ab_text_ahead.sh)
+            n_thr = max(2, min(AHEAD_READ_THREADS, tokenizer_threads() // 2))
+            pool = ThreadPoolExecutor(max_workers=n_thr)
+            rd = nat.Tokenizer(n_thr)
+            fd = os.open(path, os.O_RDONLY)
+            marks.append(('ring, pool, reader', time.perf_counter()))
+            lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0,
+                   'read': 0.0, 'span': 0.0, 'blocks': 0}
+            gen = _pread_blocks(ring, pool, rd, fd, size, use_fmt,
+                                SimpleNamespace(warm=bool(warm)), lap,
+                                R.DTOK_BLOCK, R.DTOK_HEADROOM,
+                                R.DTOK_READ_PIECE)
+            ahead = _TextAhead(ctx, gen, ring, R.DTOK_AHEAD, lap)
+            ahead.fmt, ahead.pool, ahead.rd, ahead.fd = use_fmt, pool, rd, fd
+            ahead.marks = marks
+            marks.append(('thread', time.perf_counter()))
+            box['ahead'] = ahead
+        except Exception:       # noqa: BLE001 - best effort
+            if fd is not None and ahead is None:
+                os.close(fd)
+
+    th = threading.Thread(target=work, name='wk-text-start', daemon=True)
+    _text_ahead['x'] = (th, box)
+    th.start()
+
+
+def take_text_ahead(path=None, fmt=None, ctx=None):
+    """The reader `start_text_ahead` started, if it reads `path` as `fmt` for
+    the context `ctx`; a reader of something else is stopped (None then)."""
+    th, box = _text_ahead.pop('x', (None, None))
+    if th is None:
+        return None
+    th.join()
+    ahead = box.get('ahead')
+    if ahead is None:
+        return None
+    if path is None or box['path'] != path or ahead.fmt != fmt or \
+            ahead.ctx is not ctx:
+        try:
+            ahead.close()
+        finally:
+            ahead.pool.shutdown(wait=True)
+            ahead.rd.close()
+            os.close(ahead.fd)
+        return None
+    return ahead
+
+
+def drop_text_ahead():
+    """Stop a reader nobody took (the first file went another way)."""
+    take_text_ahead()
 
 
 class DeviceTextRoute:
@@ -170,7 +485,7 @@ class DeviceTextRoute:
 
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
     DTOK_READ_PIECE = int(os.environ.get('WOLTKA_READ_PIECE', 8 << 20))   # bytes per pread of the block reader's threads
-    DTOK_AHEAD = 3              # blocks copied to the device ahead of the one being scanned (wk_ctx::kTextBufs - 1)
+    DTOK_AHEAD = int(os.environ.get('WOLTKA_TEXT_AHEAD', 160))     # blocks copied to the device ahead of the one being scanned (at most wk_ctx::kTextBufs - 1)
     DTOK_HEADROOM = 1 << 20     # room in front of a block's bytes for the run the block before left unfinished
     HOSTREG_PIECE = 256 << 20   # a file is pinned in place in pieces of this size (a multiple of the page size)
     HOSTREG_MIN = 64 << 20      # smaller files are read into pinned buffers
@@ -192,6 +507,31 @@ class DeviceTextRoute:
         else:
             source, fd, size = reader, -1, 0
         tok = self.tok
+        # (a reader that has been at this file since before the hierarchy was
+        # read: workflow -> start_text_ahead)
+        taken = None
+        if _text_ahead:
+            if source is None and self._tring is None:
+                taken = take_text_ahead(self._dpath, self._dfmt, self.ctx)
+            else:
+                drop_text_ahead()
+        if taken is not None:
+            ROUTES['text_ahead'] += 1
+            if os.environ.get('WOLTKA_DTOK_TIMING'):
+                import sys
+                t_ref = taken.marks[0][1]
+                print('[dtok] reader ahead: ' + ', '.join(
+                    '%s +%.3f' % (k, v - t_ref) for k, v in taken.marks[1:]) +
+                    '; first copy begun +%.3f, issued +%.3f; taken over +%.3f'
+                    % ((taken.first or [t_ref])[0] - t_ref,
+                       (taken.first or [t_ref, t_ref])[-1] - t_ref,
+                       time.perf_counter() - t_ref), file=sys.stderr)
+            self._tring = taken.ring
+            if self._reader is None:
+                self._reader = taken.rd
+            if self._read_pool is None:
+                self._read_pool = taken.pool
+            tok.warm = True
         if self._reader is None:
             self._reader = nat.Tokenizer(max(2, tokenizer_threads() // 2))
         rd = self._reader
@@ -202,110 +542,6 @@ class DeviceTextRoute:
                 ready=getattr(self.ctx, '_text_ring_ready', None))
         ring = self._tring
         free = queue.Queue()
-
-        def blocks():
-            # A slot holds [headroom | file bytes]: the bytes of a block go to
-            # a fixed place, so the reads of the next blocks can be under way
-            # (8 MB pieces on a pool of threads: ~100 GB/s from the page cache
-            # with 16 of them, tools/ubench/pread_scaling.py; one 64 MB call at
-            # a time cut among the tokenizer's threads gave 15-40) while this
-            # one is cut; the unfinished last run of the block before (the
-            # carry) is copied in front of them.
-            from collections import deque
-            from concurrent.futures import ThreadPoolExecutor
-            H = self.DTOK_HEADROOM
-            PIECE = self.DTOK_READ_PIECE
-            if self._read_pool is None:
-                self._read_pool = ThreadPoolExecutor(
-                    max_workers=max(2, tokenizer_threads() // 2))
-            pool = self._read_pool
-            pending = deque()       # (slot, buf, futures, want, file position)
-            state = {'next': 0}
-
-            def issue(span, wait):
-                want = min(span, size - state['next'])
-                if want <= 0:
-                    return False
-                bufs = ring.current() if wait else ring.try_current()
-                if bufs is None:
-                    return False
-                buf, slot = bufs['text'], ring.take()
-                mv = memoryview(buf).cast('B')
-                p0 = state['next']
-                futs = [pool.submit(os.preadv, fd,
-                                    [mv[H + o:H + min(o + PIECE, want)]], p0 + o)
-                        for o in range(0, want, PIECE)]
-                pending.append((slot, buf, futs, want, p0))
-                state['next'] = p0 + want
-                return True
-
-            carry, in_header, first = b'', True, True
-            # small blocks first while the dictionary is cold: a block's
-            # unknown subjects are listed per record and interned on the host
-            ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
-            span = ramp or block
-            try:
-                while True:
-                    if not pending and not issue(min(span, block), True):
-                        break
-                    while ramp is None and span <= block and len(pending) < 3 \
-                            and issue(block, False):
-                        pass
-                    slot, buf, futs, want, p0 = pending.popleft()
-                    t0 = time.perf_counter()
-                    got = sum(f.result() for f in futs)
-                    lap['read'] += time.perf_counter() - t0
-                    final = p0 + got >= size or got < want
-                    if len(carry) > H or span > block:
-                        # a run longer than the headroom / a block: the plain way
-                        ring.release(slot)
-                        while pending:      # (read again from here)
-                            s2, _, f2, _, _ = pending.popleft()
-                            for f in f2:
-                                f.result()
-                            ring.release(s2)
-                        want = min(span, size - p0)
-                        whole = np.empty(len(carry) + want, dtype=np.uint8)
-                        view = memoryview(whole).cast('B')
-                        view[:len(carry)] = carry
-                        got = rd.read_into(fd, p0, view[len(carry):]) \
-                            if want else 0
-                        state['next'] = p0 + got
-                        final = p0 + got >= size or got < want
-                        slot, out = None, whole[:len(carry) + got]
-                    else:
-                        start = H - len(carry)
-                        if carry:
-                            memoryview(buf).cast('B')[start:H] = carry
-                        out = buf[start:H + got]
-                    fill = out.size
-                    t0 = time.perf_counter()
-                    ok, begin, stop, hdr = nat.Tokenizer.sam_span(
-                        out, final, in_header, self._dfmt)
-                    lap['span'] += time.perf_counter() - t0
-                    if not ok and not final:    # no complete run yet: read more
-                        carry = out.tobytes()
-                        span *= 2
-                        if slot is not None:
-                            ring.release(slot)
-                        continue
-                    if ramp is not None:
-                        ramp = min(block, ramp * 4)
-                        if ramp == block:
-                            tok.warm, ramp = True, None
-                    span = ramp or block
-                    carry = b'' if final else out[stop:].tobytes()
-                    yield slot, out, fill, begin, stop, first, final, \
-                        in_header, hdr
-                    in_header, first = hdr, False
-                    if final:
-                        return
-            finally:
-                while pending:
-                    s2, _, f2, _, _ = pending.popleft()
-                    for f in f2:
-                        f.result()
-                    ring.release(s2)
 
         def blocks_stream():
             # The same cut for text that arrives in order from a stream (a gzip
@@ -514,13 +750,21 @@ class DeviceTextRoute:
                 return None
             return arr
 
-        import time
-        lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0, 'read': 0.0,
-               'span': 0.0, 'blocks': 0}
+        lap = taken.lap if taken is not None else {
+            'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0, 'read': 0.0,
+            'span': 0.0, 'blocks': 0}
+        serial = [0]                # number of the detached block scanned last
         timing = bool(os.environ.get('WOLTKA_DTOK_TIMING'))
 
         def one(item):
             slot, buf, fill, begin, stop, first, final, hdr_in, hdr = item
+            # (`buf` names the block for the scan; `text` is what the host
+            # tokenizer reads if the kernels leave the block to it)
+            text = buf
+            if isinstance(slot, tuple) and slot[0] == 'det':
+                serial[0] += 1
+                text = _BlockText(self.ctx, buf, stop - begin, slot[1],
+                                  slot[2], serial[0], serial)
             try:
                 t0 = time.perf_counter()
                 done = None
@@ -549,13 +793,13 @@ class DeviceTextRoute:
                                         np.int32, len(fresh))])
                     if status == 0:
                         if n_lines:
-                            yield None, ('dhits', (buf, fill, first, final,
+                            yield None, ('dhits', (text, fill, first, final,
                                                    hdr_in, hdr)), \
                                 None, None, None, None
                         tok.set_header_state(hdr)
                     else:
                         yield from self._host_block(
-                            buf, fill, first, final, hdr_in, True,
+                            text, fill, first, final, hdr_in, True,
                             groups=self._dstrata is not None)
                     return
                 if fresh:
@@ -568,61 +812,69 @@ class DeviceTextRoute:
                     self._tok_map = np.concatenate([self._tok_map, ids])
                 if status == 0 and self._tok_identity:
                     if n_lines:
-                        yield None, ('dtok', (buf, fill, first, final, hdr_in,
+                        yield None, ('dtok', (text, fill, first, final, hdr_in,
                                               hdr, done)), None, None, None, \
                             None
                     tok.set_header_state(hdr)
                 else:
                     self._spec = False
-                    yield from self._host_block(buf, fill, first, final,
+                    yield from self._host_block(text, fill, first, final,
                                                 hdr_in,
                                                 names=self._dmaps is not None)
             finally:
-                if isinstance(slot, tuple):     # (mapped: copied up to here)
-                    mapped['done'] = max(mapped['done'], slot[1])
-                elif slot is not None:
-                    ring.release(slot)
+                # (a block in a ring buffer: the reader took the buffer back
+                # when its copy was through)
+                if isinstance(slot, tuple) and slot[0] == 'map':
+                    mapped['done'] = max(mapped['done'], slot[1])   # copied up to here
 
         # The copy of a block's text to the device is issued by the reader
-        # thread itself, as soon as the block is cut (`wk_dtok_copy` may be
+        # thread itself, as soon as the block is cut (`wk_dtok_copy*` may be
         # called beside the scans): the link never waits for this thread --
         # issuing a copy between two scans left it idle for a third of a
         # block's time.  Up to DTOK_AHEAD blocks are on their way or waiting on
-        # the device (wk_ctx::kTextBufs - 1); a block's buffer there is free
-        # again when the loop comes back for the next one.
-        import threading
-        free_bufs = threading.Semaphore(self.DTOK_AHEAD)
-        stop = threading.Event()
-
-        def copied(gen):
-            for item in gen:
-                if item[0] is not None:         # (pinned: an asynchronous copy)
-                    while not free_bufs.acquire(timeout=0.05):
-                        if stop.is_set():
-                            return
-                    t0 = time.perf_counter()
-                    self.ctx.dtok_copy(item[1], item[3], item[4])
-                    lap['copy'] += time.perf_counter() - t0
-                yield item
-
+        # the device; a block's buffer there is free again when the loop comes
+        # back for the next one.  (`_TextAhead`: a reader that was started
+        # before the engine existed is taken over here.)
         t_all = time.perf_counter()
-        whole = open_mapped() if source is None else None
-        it = _prefetch(copied(blocks_stream() if source is not None else
-                              blocks() if whole is None
-                              else blocks_mapped(whole)),
-                       depth=self.DTOK_AHEAD)
+        ahead, whole = taken, None
+        if ahead is None:
+            whole = open_mapped() if source is None else None
+            if source is not None:
+                gen = blocks_stream()
+            elif whole is not None:
+                gen = blocks_mapped(whole)
+            else:
+                if self._read_pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._read_pool = ThreadPoolExecutor(
+                        max_workers=max(2, tokenizer_threads() // 2))
+                gen = _pread_blocks(ring, self._read_pool, rd, fd, size,
+                                    self._dfmt, tok, lap, block,
+                                    self.DTOK_HEADROOM, self.DTOK_READ_PIECE)
+            ahead = _TextAhead(self.ctx, gen, ring,
+                               3 if whole is not None else self.DTOK_AHEAD,
+                               lap)
+        # (a plain file's size tells how many records its sample will hold)
+        self.ctx.dtok_expect(size if source is None else 0)
         try:
             while True:
                 t0 = time.perf_counter()
-                item = next(it, None)
+                item = ahead.get()
                 lap['wait'] += time.perf_counter() - t0
                 if item is None:
                     break
                 yield from one(item)
-                if item[0] is not None:
-                    free_bufs.release()
+                ahead.done(item)
         finally:
-            stop.set()
+            ahead.close()
+            if getattr(self.ctx, '_h', None):   # (still open)
+                self.ctx.dtok_expect(0)
+            if taken is not None:
+                os.close(taken.fd)
+                if taken.rd is not self._reader:
+                    taken.rd.close()
+                if taken.pool is not self._read_pool:
+                    taken.pool.shutdown(wait=True)
             if whole is not None:
                 # (every copy has been waited for by the kernels of its block;
                 # a consumer that stopped early may have left one in flight)
@@ -659,6 +911,8 @@ class DeviceTextRoute:
         all (the general arrays; ``names``: with the descriptors of the query
         names, for the read maps)."""
         ROUTES['host_block'] += 1
+        if isinstance(buf, _BlockText):     # (the bytes come back from the device)
+            buf = buf.get()
         tok = self.tok
         tok.set_header_state(hdr_in)
         if ordinal:

@@ -234,6 +234,11 @@ def _workflow_with_context(
                 input_fmt in (None, 'sam', 'b6o', 'paf', 'map'):
             from . import classify as _classify
             _classify.warm_tokenizer_ahead(fp0, input_fmt)
+            # ... and the file's blocks on their way to the device (the
+            # context is being created on its thread: open_context_ahead)
+            if comm is None and not os.environ.get('WOLTKA_NO_DTOK'):
+                from .routes.device_text import start_text_ahead
+                start_text_ahead(fp0, input_fmt, device)
     tree, rankdic, namedic, root = build_hierarchy(
         names_fps, nodes_fps, newick_fps, lineage_fps, columns_fps, map_fps,
         map_rank, zippers)
