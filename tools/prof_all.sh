@@ -8,7 +8,7 @@ for wl in $wls; do
   case $wl in
     lca_text) kern=dtok_first_emit ;;
     lca) kern=weigh_streams ;;
-    lca_free|lca_above|lca_major|lca_uniq) kern=free_stream ;;
+    lca_free|lca_above|lca_major|lca_uniq|lca_above3) kern=free_stream ;;
     ordinal) kern=stripe_match ;;
     flat) kern=count_subjects ;;
   esac

@@ -66,6 +66,11 @@ struct FreeArgs {
     uint32_t* log;
     uint32_t* log_cnt;
     uint32_t log_cap;
+    // (free_stream_kernel<., true>: several jobs over one accumulation) the records hold subject indices, which
+    // this job reads through its own table: rank_of_subject[s] < 0 = the subject has no node (at the rank)
+    const int32_t* rank_of_subject;
+    uint32_t n_subjects;
+    int* err;
 };
 
 constexpr uint32_t kFreeMiss = 128;     // per-wave ring of results on their way to the log: < 64 left over + <= 64 new
@@ -94,7 +99,7 @@ __host__ __device__ constexpr uint32_t free_wave_lds() { return kFreeQueue * 8 +
 //      gathers of the reads' records.
 // kMajor: the instance for a rank job under --major (the vote along the records;
 // the look-up is the value's own node or nothing).
-template <bool kMajor>
+template <bool kMajor, bool kTranslate = false>
 __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) free_stream_kernel(FreeArgs a, uint32_t lds_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long acc[2];
@@ -248,11 +253,41 @@ __global__ void __launch_bounds__(kFreeThreads) __attribute__((amdgpu_waves_per_
         v.w = left > 3u ? v.w : 0u;
         return v;
     };
+    // (kTranslate) subject indices -> this job's ranks, what words_to_ranks_kernel writes for a single job: the
+    // table (4 bytes per subject) stays in the caches; the look-ups of a block are issued one block ahead of its
+    // use and its words two blocks ahead, so that neither wait is on the wave's path
+    auto translate_word = [&](uint32_t w) -> uint32_t {
+        if ((w >> kWordSizeShift) == 0u) return w;  // (masked out: no record)
+        const uint32_t sidx = w & kWordSubjMask;
+        uint32_t f = kFreeMissing;
+        if (sidx < a.n_subjects) {
+            const int32_t x = a.rank_of_subject[sidx];
+            f = x >= 0 ? (uint32_t)x : kFreeMissing;
+        } else {
+            atomicOr(a.err, kErrFeatureRange);
+        }
+        return (w & ~kWordSubjMask) | f;
+    };
+    auto translate = [&](uint4 v) -> uint4 {
+        return make_uint4(translate_word(v.x), translate_word(v.y), translate_word(v.z), translate_word(v.w));
+    };
     uint32_t my_records = 0;      // (wave-uniform, as are these: a wave's share of < 2^32 records)
     uint32_t head = 0, tail = 0;  // (tail: the reads met so far)
     uint4 cur = load_block(wave0);
+    uint4 raw = make_uint4(0u, 0u, 0u, 0u);  // (kTranslate) the next block's words as they are
+    if constexpr (kTranslate) {
+        cur = translate(cur);
+        raw = load_block(wave0 + waves);
+    }
     for (uint32_t b = wave0; b < n_blocks; b += waves) {
-        const uint4 nxt = load_block(b + waves);
+        uint4 nxt;
+        if constexpr (kTranslate) {
+            const uint4 raw2 = load_block(b + 2u * waves);
+            nxt = translate(raw);
+            raw = raw2;
+        } else {
+            nxt = load_block(b + waves);
+        }
         // 1. a lane's own four records: ids, places in their reads
         const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
         uint32_t f[4], pos[4], size[4];

@@ -119,7 +119,7 @@ struct wk_ctx {
         int kind = -1, slot = -1, tree = -1, subj = -1, rank = -1;  // what the tables were made for
     };
     StreamTables st[WK_MAX_JOBS];
-    DevBuf w_tmp;  // several stream jobs: the records with the subject field rewritten for one job
+    DevBuf w_tmp;  // (unused since the stream translates subject indices itself: free_stream_kernel<., true>)
     DevBuf w_renum;  // old rank -> new rank when the subject table grows under accumulated records
     DevBuf f_dense;  // reads per result node of the free-rank stream
     DevBuf f_log, f_log_cnt, f_partial, f_part_used;  // results the stream's LDS caches had no room for, per wave; their counts per share (free_log_kernel)
@@ -885,6 +885,10 @@ int wk_create(int device, wk_ctx** out) {
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_stream_kernel<true, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(&free_log_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLogBins * 4))) != hipSuccess ||
@@ -2106,10 +2110,9 @@ int wk_words_flush(wk_ctx* c) {
     if (c->w_mode != 0) {
         // ---- free-rank jobs and rank jobs that look at whole reads: per job, the stream over node ids, then its dense
         // counters into the count table.  One job: the records hold its node ids since they were appended; several:
-        // they hold subject indices and are rewritten for one job at a time into a second buffer.
+        // they hold subject indices, which the stream reads through the job's table (free_stream_kernel<., true>).
         const int blocks = std::min(kStatBlocks, c->prop.multiProcessorCount * c->free_per_cu);
         const CountTable table{c->tkeys.as<unsigned long long>(), c->tvals.as<unsigned long long>(), c->slots - 1, scalar_err(c)};
-        if (c->w_mode == 3) HIP_TRY(c, c->w_tmp.reserve((size_t)c->w_records * 4 + 64));
         if (c->w_mode != 3) {  // (subjects registered since the last chunk was appended)
             const int rcr = refresh_word_ranks(c, c->w_records);
             if (rcr) return rcr;
@@ -2124,12 +2127,10 @@ int wk_words_flush(wk_ctx* c) {
             }
             FreeArgs fa{};
             fa.words = c->c_words.as<uint32_t>();
-            if (c->w_mode == 3) {
-                hipLaunchKernelGGL(words_to_ranks_kernel, dim3((unsigned)((c->w_records + 255) / 256)), dim3(256), 0, c->stream,
-                                   c->c_words.as<uint32_t>(), c->w_tmp.as<uint32_t>(), (uint32_t)c->w_records, T.subj_rank.as<int32_t>(),
-                                   (uint32_t)c->n_subjects, scalar_err(c));
-                fa.words = c->w_tmp.as<uint32_t>();
-            }
+            const bool translate = c->w_mode == 3;  // (several jobs: the records hold subject indices, read through this job's table)
+            fa.rank_of_subject = translate ? T.subj_rank.as<int32_t>() : nullptr;
+            fa.n_subjects = (uint32_t)c->n_subjects;
+            fa.err = scalar_err(c);
             fa.sparse = T.dsparse.as<int32_t>();
             fa.parent_d = T.dparent.as<int32_t>();
             fa.self_d = T.dself.as<int32_t>();
@@ -2169,10 +2170,14 @@ int wk_words_flush(wk_ctx* c) {
             fa.log = c->f_log.as<uint32_t>();
             fa.log_cnt = c->f_log_cnt.as<uint32_t>();
             KernelTimer* kt = ktimer_begin(c, "classify");
-            if (fa.major > 0.0)
-                hipLaunchKernelGGL(free_stream_kernel<true>, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
+            if (fa.major > 0.0 && translate)
+                hipLaunchKernelGGL((free_stream_kernel<true, true>), dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
+            else if (fa.major > 0.0)
+                hipLaunchKernelGGL((free_stream_kernel<true, false>), dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
+            else if (translate)
+                hipLaunchKernelGGL((free_stream_kernel<false, true>), dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
             else
-                hipLaunchKernelGGL(free_stream_kernel<false>, dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
+                hipLaunchKernelGGL((free_stream_kernel<false, false>), dim3(blocks), dim3(c->free_threads), lds, c->stream, fa, slots);
             ktimer_end(c, kt);
             FreeLogArgs la{};
             la.log = fa.log;

@@ -239,9 +239,14 @@ def _workflow_with_context(
             if comm is None and not os.environ.get('WOLTKA_NO_DTOK'):
                 from .routes.device_text import start_text_ahead
                 start_text_ahead(fp0, input_fmt, device)
-    tree, rankdic, namedic, root = build_hierarchy(
-        names_fps, nodes_fps, newick_fps, lineage_fps, columns_fps, map_fps,
-        map_rank, zippers)
+    start_coords_ahead(coords_fp, zippers)
+    try:
+        tree, rankdic, namedic, root = build_hierarchy(
+            names_fps, nodes_fps, newick_fps, lineage_fps, columns_fps,
+            map_fps, map_rank, zippers)
+    except BaseException:
+        _coords_ahead.clear()
+        raise
     mapper, chunk = build_mapper(coords_fp, outcov_dir, overlap, chunk,
                                  zippers)
     sizes = parse_sizes(sizes, mapper, zippers)
@@ -771,6 +776,43 @@ def parse_strata(fp=None, samples=None):
     return {sample: join(fp, name) for sample, name in found.items()}
 
 
+# The gene coordinates are read on a thread while the hierarchy is (`workflow`
+# starts it; the parser is native and holds no interpreter lock): build_mapper
+# picks the table up -- or the error, which surfaces where it always did.
+_coords_ahead = {}
+
+
+def start_coords_ahead(coords_fp, zippers=None):
+    import threading
+    if _coords_ahead or not coords_fp:
+        return
+    box = {'fp': coords_fp}
+
+    def work():
+        try:
+            table = load_gene_coords_file(coords_fp, zippers)
+            table.names
+            box['table'] = table
+        except BaseException as e:     # noqa: BLE001 - raised by build_mapper
+            box['err'] = e
+    th = threading.Thread(target=work, name='wk-coords', daemon=True)
+    _coords_ahead['x'] = (th, box)
+    th.start()
+
+
+def _coords_table(coords_fp, zippers):
+    th, box = _coords_ahead.pop('x', (None, None))
+    if th is not None:
+        th.join()
+        if box['fp'] == coords_fp:
+            if 'err' in box:
+                raise box['err']
+            return box['table']
+    table = load_gene_coords_file(coords_fp, zippers)
+    table.names     # (as Python strings now, while the device context opens on its thread)
+    return table
+
+
 def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
                  zippers=None):
     """Plain mapper, or coord-match mapper when gene coordinates are given
@@ -778,8 +820,7 @@ def build_mapper(coords_fp=None, outcov_dir=None, overlap=None, chunk=None,
     unless the user set it (the device default is chosen in ``classify``)."""
     if coords_fp:
         click.echo('Reading gene coordinates...', nl=False)
-        table = load_gene_coords_file(coords_fp, zippers)
-        table.names     # (as Python strings now, while the device context opens on its thread)
+        table = _coords_table(coords_fp, zippers)
         click.echo(' Done.')
         click.echo(f'  Total number of host sequences: {len(table)}.')
         return OrdinalMapper(table, th=overlap and overlap / 100), chunk
