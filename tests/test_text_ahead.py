@@ -1,0 +1,161 @@
+"""The reader thread of the device text route (routes/device_text.py:
+`_pread_blocks`, `_TextAhead`, `_BlockText`) against a stand-in for the device
+context: blocks are cut at run boundaries, copied *detached* -- the pinned
+buffer goes back to the ring when the copy is through -- and what the device
+was given, with the ends the reader kept, is the file again.  (The real copies
+and scans: tests/test_gpu_dtok.py.)"""
+import os
+import sys
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from woltka_amd import _native as nat                       # noqa: E402
+from woltka_amd.hostio import StageRing                     # noqa: E402
+from woltka_amd.routes import device_text as D              # noqa: E402
+
+
+class FakeContext:
+    """Keeps what `dtok_copy_ahead` was handed, like device memory would."""
+
+    def __init__(self):
+        self.copies, self.waited, self.dropped = [], [], 0
+        self.scanned = -1
+        self.lock = threading.Lock()
+
+    def host_alloc(self, n, dtype=np.uint8):
+        return np.zeros(n, dtype=dtype)
+
+    def dtok_copy_ahead(self, buf, begin, stop):
+        with self.lock:
+            self.copies.append(bytes(memoryview(buf)[begin:stop]))
+            return len(self.copies) - 1
+
+    def dtok_copy_wait(self, ticket):
+        self.waited.append(ticket)
+
+    def dtok_copy_drop(self):
+        self.dropped += 1
+
+    def dtok_text_back(self, n):
+        out = np.frombuffer(self.copies[self.scanned], dtype=np.uint8)
+        assert out.size == n
+        return out
+
+
+def sam_text(n_queries, header=True):
+    lines = ['@HD\tVN:1.0', '@SQ\tSN:x\tLN:5'] if header else []
+    for q in range(n_queries):
+        for k in range(1 + q % 4):
+            lines.append(f'read{q:05d}\t0\tS{(q * 7 + k) % 31}\t1\t1\t5M\t*\t0\t0\t*\t*')
+    return ('\n'.join(lines) + '\n').encode()
+
+
+def reader(tmp_path, text, ctx, block, depth, slots=4):
+    fp = tmp_path / 'a.sam'
+    fp.write_bytes(text)
+    H = 1 << 12
+    ring = StageRing(ctx, slots, {'text': (np.uint8, block + H)})
+    pool = ThreadPoolExecutor(max_workers=3)
+    rd = nat.Tokenizer(2)
+    fd = os.open(fp, os.O_RDONLY)
+    lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0, 'read': 0.0,
+           'span': 0.0, 'blocks': 0}
+
+    class Flag:
+        warm = True
+    gen = D._pread_blocks(ring, pool, rd, fd, len(text), 'sam', Flag, lap,
+                          block, H, 1 << 10)
+    ahead = D._TextAhead(ctx, gen, ring, depth, lap)
+
+    def finish():
+        ahead.close()
+        pool.shutdown(wait=True)
+        rd.close()
+        os.close(fd)
+    return ahead, ring, finish
+
+
+@pytest.mark.parametrize('block', [1 << 11, 1 << 13, 1 << 20])
+@pytest.mark.parametrize('header', [True, False])
+def test_detached_blocks_are_the_file_again(tmp_path, block, header):
+    text = sam_text(3000, header)
+    ctx = FakeContext()
+    ahead, ring, finish = reader(tmp_path, text, ctx, block, depth=3)
+    try:
+        rebuilt, n, serial = [], 0, [0]
+        while True:
+            item = ahead.get()
+            if item is None:
+                break
+            slot, out, fill, begin, stop, first, final, hdr_in, hdr = item
+            assert slot[0] == 'det'
+            ctx.scanned = n
+            serial[0] += 1
+            whole = D._BlockText(ctx, out, stop - begin, slot[1], slot[2],
+                                 serial[0], serial).get().tobytes()
+            assert len(whole) == fill
+            # the bytes in front of `begin` are header lines, those behind
+            # `stop` the unfinished run the next block starts with
+            assert all(ln.startswith(b'@') for ln in slot[1].splitlines())
+            rebuilt.append(whole[:stop])
+            assert first == (n == 0)
+            n += 1
+            ahead.done(item)
+        assert final
+        assert b''.join(rebuilt) == text
+        # every run of equal query names lies inside one block
+        for piece in ctx.copies:
+            assert piece.endswith(b'\n')
+        names = [[ln.split(b'\t', 1)[0] for ln in piece.splitlines()]
+                 for piece in ctx.copies]
+        for a, b in zip(names, names[1:]):
+            assert a[-1] != b[0]
+        assert n > 1 or block >= len(text)
+        # all pinned buffers are back in the ring
+        assert sorted(ctx.waited) == list(range(len(ctx.copies)))
+        assert ring._free.qsize() + (ring._cur is not None) == 4
+    finally:
+        finish()
+    assert ctx.dropped == 1
+
+
+def test_the_reader_runs_as_far_ahead_as_it_is_allowed(tmp_path):
+    text = sam_text(4000)
+    ctx = FakeContext()
+    ahead, ring, finish = reader(tmp_path, text, ctx, 1 << 11, depth=5)
+    try:
+        import time
+        for _ in range(200):            # (nothing is scanned meanwhile)
+            if len(ctx.copies) >= 5:
+                break
+            time.sleep(0.01)
+        time.sleep(0.05)
+        assert len(ctx.copies) == 5     # four ring buffers, five blocks ahead
+        item = ahead.get()
+        ahead.done(item)
+        for _ in range(200):
+            if len(ctx.copies) >= 6:
+                break
+            time.sleep(0.01)
+        assert len(ctx.copies) == 6
+    finally:
+        finish()                        # (stops a reader that is waiting)
+    assert ctx.dropped == 1
+
+
+def test_block_text_is_only_good_until_the_next_scan(tmp_path):
+    ctx = FakeContext()
+    ctx.copies = [b'abc\n', b'defg\n']
+    serial = [1]
+    one = D._BlockText(ctx, None, 4, b'', b'', 1, serial)
+    ctx.scanned = 0
+    assert one.get().tobytes() == b'abc\n'
+    serial[0] = 2
+    with pytest.raises(RuntimeError):
+        one.get()
