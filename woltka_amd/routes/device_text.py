@@ -486,7 +486,7 @@ class DeviceTextRoute:
     DTOK_BLOCK = int(os.environ.get('WOLTKA_DTOK_BLOCK', 1 << 26))
     DTOK_READ_PIECE = int(os.environ.get('WOLTKA_READ_PIECE', 8 << 20))   # bytes per pread of the block reader's threads
     DTOK_AHEAD = int(os.environ.get('WOLTKA_TEXT_AHEAD', 160))     # blocks copied to the device ahead of the one being scanned (at most wk_ctx::kTextBufs - 1) by the reader that starts before the hierarchy is read
-    DTOK_DEPTH = int(os.environ.get('WOLTKA_TEXT_DEPTH', 160))     # ... by a reader the engine starts when a file's turn comes
+    DTOK_DEPTH = int(os.environ.get('WOLTKA_TEXT_DEPTH', 6))       # ... by a reader the engine starts when a file's turn comes: the scans follow at once, a deeper queue only takes the CPUs from whoever else works (config 5's second call: 2.11 s with 3, 2.17 with 160, tools/ab_text_ahead.sh)
     DTOK_HEADROOM = 1 << 20     # room in front of a block's bytes for the run the block before left unfinished
     HOSTREG_PIECE = 256 << 20   # a file is pinned in place in pieces of this size (a multiple of the page size)
     HOSTREG_MIN = 64 << 20      # smaller files are read into pinned buffers

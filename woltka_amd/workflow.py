@@ -236,7 +236,11 @@ def _workflow_with_context(
             _classify.warm_tokenizer_ahead(fp0, input_fmt)
             # ... and the file's blocks on their way to the device (the
             # context is being created on its thread: open_context_ahead)
-            if comm is None and not os.environ.get('WOLTKA_NO_DTOK'):
+            # (not under --stratify: reading and joining the first sample's
+            # read map wants the CPUs the reader would take -- config 5's
+            # second call lost 0.25 s of 2.15 to it)
+            if comm is None and not stratmap and \
+                    not os.environ.get('WOLTKA_NO_DTOK'):
                 from .routes.device_text import start_text_ahead
                 start_text_ahead(fp0, input_fmt, device)
     start_coords_ahead(coords_fp, zippers)
