@@ -293,11 +293,14 @@ MAX_GROUPS = 1 << nat.KEY_GROUP_BITS
 _ahead = {}
 
 
-def open_context_ahead(device, text_ring=None):
+def open_context_ahead(device, text_ring=None, strata_bytes=0):
     """Create the device context of `device` on a thread; ``Engine`` takes it.
     Errors surface where the engine would have met them.  ``text_ring`` =
-    (slots, bytes): pinned buffers for the device text route allocated on the
-    same thread."""
+    (slots, bytes): pinned buffers for the device text route allocated on a
+    thread of their own; ``strata_bytes``: two pinned buffers of that size for
+    the text of the strata maps (`--stratify`: pinning half a GB takes 0.1 s,
+    which the first sample would otherwise wait for), handed out as futures
+    in ``ctx._strata_ready``."""
     import threading
     if device in _ahead:
         return
@@ -313,13 +316,22 @@ def open_context_ahead(device, text_ring=None):
         # (`Engine._device_chunks`' ring), on a thread of their own while the
         # hierarchy is read: nobody waits for them -- the ring takes what is
         # there when it needs a buffer and allocates the rest itself
-        if text_ring:
+        if text_ring or strata_bytes:
+            from concurrent.futures import Future
             ctx = box['ctx']
             ctx._text_ring_ready = []
             ctx._ring_stop = False
+            ctx._strata_ready = [Future(), Future()] if strata_bytes else []
+            futs = list(ctx._strata_ready)
 
             def pin():
-                n, nbytes = text_ring
+                for fut in futs:        # (wanted first: before the first block)
+                    try:
+                        fut.set_result(None if ctx._ring_stop else
+                                       ctx.host_alloc(strata_bytes, np.uint8))
+                    except Exception:   # noqa: BLE001 - allocated on use then
+                        fut.set_result(None)
+                n, nbytes = text_ring or (0, 0)
                 try:
                     for _ in range(n):
                         if ctx._ring_stop:

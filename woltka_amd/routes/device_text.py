@@ -421,6 +421,11 @@ class DeviceTextRoute:
         i = self._sbuf_next
         self._sbuf_next ^= 1
         buf = self._sbuf[i]
+        ready = getattr(self.ctx, '_strata_ready', None)
+        if buf is None and ready:
+            # (pinned on a thread while the hierarchy was read:
+            # hostio.open_context_ahead)
+            buf = self._sbuf[i] = ready.pop(0).result()
         if buf is None or buf.size < need:
             try:
                 buf = self.ctx.host_alloc(int(need * 1.25) + (1 << 20), np.uint8)

@@ -180,7 +180,25 @@ def _workflow_ranked(input_fp, output_fp, input_fmt, input_ext, samples, demux,
             if total >= (2 << 30):
                 from .routes.device_text import DeviceTextRoute as _R
                 ring = (8, _R.DTOK_BLOCK + _R.DTOK_HEADROOM)
-        _classify.open_context_ahead(device, ring)
+        # (--stratify: two pinned buffers for the text of the samples' read
+        # maps, sized for the largest)
+        strata_bytes = 0
+        if stratmap and not os.environ.get('WOLTKA_NO_DTOK') and \
+                not os.environ.get('WOLTKA_NO_PIN_AHEAD'):
+            from .routes.device_text import DeviceTextRoute as _R
+            try:
+                for fp in stratmap.values():
+                    need = os.path.getsize(fp)
+                    if fp.endswith('.gz'):
+                        need = _R._inflated_size(fp) or need * 8
+                    strata_bytes = max(strata_bytes, need)
+            except OSError:
+                strata_bytes = 0
+            if strata_bytes:
+                strata_bytes = int(strata_bytes * 1.25) + (1 << 20)
+            if strata_bytes > (8 << 30):
+                strata_bytes = 0
+        _classify.open_context_ahead(device, ring, strata_bytes)
     elif comm.kind == 'local':
         # the ranks share this node's CPUs (classify.tokenizer_threads) and
         # each keeps to the NUMA node of its GPU
