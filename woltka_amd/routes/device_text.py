@@ -11,8 +11,8 @@ from os.path import join
 import numpy as np
 
 from .. import _native as nat
-from ..hostio import (MAX_GROUPS, ROUTES, MapWriter, StageRing, _prefetch,
-                      peek_context, tokenizer_threads)
+from ..hostio import (MAX_GROUPS, ROUTES, MapWriter, StageRing, peek_context,
+                      tokenizer_threads)
 
 
 _HOSTREG_SLOW = {}     # st_dev -> pinning that file system's pages in place is slower than reading them
@@ -506,7 +506,6 @@ class DeviceTextRoute:
         Blocks the kernels leave to the host tokenizer (malformed lines, both
         mate bits, reads of more than 16 subjects) are tokenised on the host
         as before.  Yields what `native_chunks` yields."""
-        import queue
         source = None               # a stream (inflated text) instead of a file
         if isinstance(reader, tuple):
             fd, size = reader
@@ -547,7 +546,6 @@ class DeviceTextRoute:
                 'text': (np.uint8, block + self.DTOK_HEADROOM)},
                 ready=getattr(self.ctx, '_text_ring_ready', None))
         ring = self._tring
-        free = queue.Queue()
 
         def blocks_stream():
             # The same cut for text that arrives in order from a stream (a gzip
