@@ -159,3 +159,57 @@ def test_block_text_is_only_good_until_the_next_scan(tmp_path):
     serial[0] = 2
     with pytest.raises(RuntimeError):
         one.get()
+
+
+def test_table_rows_ranks_many_names_on_threads():
+    """`wk_table_rows` sorts more than 2^16 names in parts on threads of their
+    own and merges them: the order is Python's order of the UTF-8 bytes, also
+    among names that share their first eight bytes, are prefixes of each
+    other, or are shorter than eight bytes."""
+    import random
+    rng = random.Random(11)
+    names = set()
+    while len(names) < 90_000:
+        kind = rng.randrange(4)
+        if kind == 0:
+            names.add(f'G{rng.randrange(10**7):07d}_{rng.randrange(3000)}')
+        elif kind == 1:
+            names.add('prefix__' + 'x' * rng.randrange(6) + str(rng.randrange(99)))
+        elif kind == 2:
+            names.add(''.join(rng.choice('abcé') for _ in range(rng.randrange(1, 7))))
+        else:
+            names.add(f'{rng.randrange(10**9)}')
+    names = list(names)
+    rng.shuffle(names)
+    n = len(names)
+    vals = np.arange(1, 2 * n + 1, dtype=np.int64).reshape(n, 2)
+    body, rows = nat.table_rows(None, names, None,
+                                np.arange(n, dtype=np.int32), vals)
+    order = sorted(range(n), key=lambda i: names[i].encode())
+    want = ''.join(f'{names[i]}\t{2 * i + 1}\t{2 * i + 2}\n' for i in order)
+    assert rows == n
+    assert bytes(body).decode() == want
+
+
+def test_coordinates_read_beside_the_hierarchy_raise_where_they_did(tmp_path):
+    """`workflow.start_coords_ahead` reads the gene coordinates on a thread;
+    `build_mapper` hands out the table -- or raises the reader's error."""
+    from woltka_amd import workflow as W
+    good = tmp_path / 'good.txt'
+    good.write_text('>G1\ng1\t5\t30\ng2\t40\t10\n>G2\ng3\t1\t9\n')
+    W._coords_ahead.clear()
+    W.start_coords_ahead(str(good))
+    mapper, chunk = W.build_mapper(str(good), None, 80, None, {})
+    assert len(mapper.table) == 2 and not W._coords_ahead
+    direct, _ = W.build_mapper(str(good), None, 80, None, {})
+    assert list(direct.table.names) == list(mapper.table.names)
+    bad = tmp_path / 'bad.txt'
+    bad.write_text('>G1\ng1\t5\n')
+    W.start_coords_ahead(str(bad))
+    with pytest.raises(ValueError, match='Cannot extract coordinates'):
+        W.build_mapper(str(bad), None, 80, None, {})
+    assert not W._coords_ahead
+    # a table read for another file is not handed out
+    W.start_coords_ahead(str(bad))
+    mapper, _ = W.build_mapper(str(good), None, 80, None, {})
+    assert len(mapper.table) == 2 and not W._coords_ahead
