@@ -1493,6 +1493,10 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
             if isinstance(cold, float) else None,
             'phases_s': {k: round(v, 3) for k, v in sorted(parts.items())},
             'streaming_s': round(stream, 3),
+            'phases_note': 'wall time of the named steps; the first file is '
+                           'read and copied to the device while the hierarchy '
+                           'is read, so streaming_s (the call minus the steps) '
+                           'is what the stream adds after them',
             'value_streaming': round(n_rec / max(stream, 1e-9), 1),
             'text_generated_s': round(t_gen, 1), 'table_rows': rows,
             'tables_vs_kernel_path': same,
