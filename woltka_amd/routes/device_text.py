@@ -43,6 +43,7 @@ def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE):
             return False
         buf, slot = bufs['text'], ring.take()
         mv = memoryview(buf).cast('B')
+        want = min(want, len(mv) - H)   # (never more than the buffer holds)
         p0 = state['next']
         futs = [pool.submit(os.preadv, fd,
                             [mv[H + o:H + min(o + PIECE, want)]], p0 + o)
@@ -288,10 +289,11 @@ def start_text_ahead(path, fmt, device, warm=True):
             marks.append(('ring, pool, reader', time.perf_counter()))
             lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0,
                    'read': 0.0, 'span': 0.0, 'blocks': 0}
+            # (blocks as large as the ring's buffers take them)
             gen = _pread_blocks(ring, pool, rd, fd, size, use_fmt,
                                 SimpleNamespace(warm=bool(warm)), lap,
-                                R.DTOK_BLOCK, R.DTOK_HEADROOM,
-                                R.DTOK_READ_PIECE)
+                                ring.layout['text'][1] - R.DTOK_HEADROOM,
+                                R.DTOK_HEADROOM, R.DTOK_READ_PIECE)
             ahead = _TextAhead(ctx, gen, ring, R.DTOK_AHEAD, lap)
             ahead.fmt, ahead.pool, ahead.rd, ahead.fd = use_fmt, pool, rd, fd
             ahead.marks = marks
