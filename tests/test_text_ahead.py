@@ -213,3 +213,65 @@ def test_coordinates_read_beside_the_hierarchy_raise_where_they_did(tmp_path):
     W.start_coords_ahead(str(bad))
     mapper, _ = W.build_mapper(str(good), None, 80, None, {})
     assert len(mapper.table) == 2 and not W._coords_ahead
+
+
+@pytest.mark.parametrize('seed', [154, 399, 605])
+def test_coord_match_blocks_are_cut_by_the_ex_parsers_rows(tmp_path, seed):
+    """A block the kernels leave to the host tokenizer is parsed there up to
+    the tokenizer's own cut: the start of the last run of *its* rows.  The
+    reader must cut where it would (`sam_span(..., extra=True)` on the
+    coord-match route): with the plain parsers' cut a PAF row whose MAPQ is no
+    number -- a row to them, none to `parse_paf_file_ex` -- behind the last
+    read makes the tokenizer hold that read back, and the next block begins
+    behind it.  (The seeds are inputs on which the device route lost a read
+    that way; tools/fuzz_paf_coords.py.)"""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location(
+        'gpu_dtok_rows', os.path.join(ROOT, 'tests', 'test_gpu_dtok.py'))
+    rows = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rows)
+    _, text = rows._random_coords_rows(random.Random(seed), 'paf', 4000, True)
+    text = text[:len(text) // 3].rsplit('\n', 1)[0].encode() + b'\n'
+    fp = tmp_path / 'S.paf'
+    fp.write_bytes(text)
+    lost = {}
+    for extra in (False, True):
+        ctx = FakeContext()
+        block, H = 1 << 15, 1 << 12
+        ring = StageRing(ctx, 8, {'text': (np.uint8, block + H)})
+        pool = ThreadPoolExecutor(max_workers=3)
+        rd = nat.Tokenizer(2)
+        fd = os.open(fp, os.O_RDONLY)
+        lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0,
+               'read': 0.0, 'span': 0.0, 'blocks': 0}
+
+        class Flag:
+            warm = False
+        as_fallback, exactly = nat.Tokenizer(2), nat.Tokenizer(2)
+        n, pos = 0, 0
+        try:
+            for item in D._pread_blocks(ring, pool, rd, fd, len(text), 'paf',
+                                        Flag, lap, block, H, 1 << 10,
+                                        extra=extra):
+                slot, out, fill, begin, stop, first, final = item[:7]
+                assert bytes(out[:stop]) == text[pos:pos + stop]
+                pos += stop
+                mv = memoryview(out).cast('B')
+                a = as_fallback.parse(mv[:fill], first=first, final=final,
+                                      extra=True, fmt='paf')
+                b = exactly.parse(mv[:stop], first=first, final=True,
+                                  extra=True, fmt='paf')
+                n += (a['off'].size, int(a['off'][-1])) != \
+                    (b['off'].size, int(b['off'][-1]))
+                if slot is not None:
+                    ring.release(slot)
+        finally:
+            os.close(fd)
+            pool.shutdown(wait=True)
+            for t in (rd, as_fallback, exactly):
+                t.close()
+        assert pos == len(text)
+        lost[extra] = n
+    assert lost[True] == 0
+    assert lost[False] > 0      # (what the old cut did to these inputs)

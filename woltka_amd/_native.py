@@ -1019,17 +1019,22 @@ class Tokenizer:
         return out.value
 
     @staticmethod
-    def sam_span(buf, final, in_header, fmt='sam'):
+    def sam_span(buf, final, in_header, fmt='sam', extra=False):
         """(ok, begin, stop, in_header_after) of a block of alignment text (SAM
         unless ``fmt`` says otherwise): the part that can be tokenised now
-        (``wk_tok_span``)."""
+        (``wk_tok_span``).  ``extra``: for the "ex" parsers, to which a line
+        is a row only if it has all their fields -- the last run of rows, where
+        the block is cut, is theirs then (a block cut by the plain rule and
+        handed to the "ex" tokenizer would lose the read in front of a line
+        that only the plain parser takes for a row)."""
         raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
         b, s, h = C.c_int64(0), C.c_int64(0), C.c_int(0)
         addr = C.c_void_p(raw.ctypes.data) if raw.size \
             else C.cast(C.c_char_p(b''), C.c_void_p)
         rc = load_library().wk_tok_span(
-            Tokenizer.FORMATS[fmt], 0, addr, raw.size, int(bool(final)),
-            int(bool(in_header)), C.byref(b), C.byref(s), C.byref(h))
+            Tokenizer.FORMATS[fmt], int(bool(extra)), addr, raw.size,
+            int(bool(final)), int(bool(in_header)), C.byref(b), C.byref(s),
+            C.byref(h))
         return rc == OK, b.value, s.value, bool(h.value)
 
     def set_header_state(self, in_header):

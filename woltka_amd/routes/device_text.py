@@ -18,11 +18,13 @@ from ..hostio import (MAX_GROUPS, ROUTES, MapWriter, StageRing, peek_context,
 _HOSTREG_SLOW = {}     # st_dev -> pinning that file system's pages in place is slower than reading them
 
 
-def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE):
+def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
+                  extra=False):
     """Blocks of a plain file for the device tokenizer: [slot, bytes, fill,
     begin, stop, first, final, header state in, header state out] per block,
-    cut where the last run of equal query ids starts (`tok`: whoever carries
-    the `warm` flag of the dictionary)."""
+    cut where the last run of equal query ids starts -- of the rows of the
+    "ex" parsers with `extra`, the coord-match (`tok`: whoever carries the
+    `warm` flag of the dictionary)."""
     # A slot holds [headroom | file bytes]: the bytes of a block go to
     # a fixed place, so the reads of the next blocks can be under way
     # (8 MB pieces on a pool of threads: ~100 GB/s from the page cache
@@ -94,7 +96,7 @@ def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE):
             fill = out.size
             t0 = time.perf_counter()
             ok, begin, stop, hdr = nat.Tokenizer.sam_span(
-                out, final, in_header, fmt)
+                out, final, in_header, fmt, extra)
             lap['span'] += time.perf_counter() - t0
             if not ok and not final:    # no complete run yet: read more
                 carry = out.tobytes()
@@ -242,12 +244,14 @@ AHEAD_READ_THREADS = int(os.environ.get('WOLTKA_AHEAD_READ_THREADS', 16))
 TEXT_AHEAD_MIN = int(os.environ.get('WOLTKA_TEXT_AHEAD_MIN', 256 << 20))     # smaller files are read when their turn comes
 
 
-def start_text_ahead(path, fmt, device, warm=True):
+def start_text_ahead(path, fmt, device, warm=True, extra=False):
     """`path`: a plain (uncompressed, regular) alignment file that will be the
     first to be read; `fmt`: its format if the caller knows it; `warm`: a
     tokenizer with the file's first subjects is being prepared
     (`hostio.warm_tokenizer_ahead`), so that full blocks can be cut from the
-    start.  Anything that goes wrong just means no reader ahead."""
+    start; `extra`: the run is a coord-match (the blocks are cut by the "ex"
+    parsers' idea of a row).  Anything that goes wrong just means no reader
+    ahead."""
     import threading
     if _text_ahead or os.environ.get('WOLTKA_NO_TEXT_AHEAD'):
         return
@@ -293,9 +297,11 @@ def start_text_ahead(path, fmt, device, warm=True):
             gen = _pread_blocks(ring, pool, rd, fd, size, use_fmt,
                                 SimpleNamespace(warm=bool(warm)), lap,
                                 ring.layout['text'][1] - R.DTOK_HEADROOM,
-                                R.DTOK_HEADROOM, R.DTOK_READ_PIECE)
+                                R.DTOK_HEADROOM, R.DTOK_READ_PIECE,
+                                extra=bool(extra))
             ahead = _TextAhead(ctx, gen, ring, R.DTOK_AHEAD, lap)
             ahead.fmt, ahead.pool, ahead.rd, ahead.fd = use_fmt, pool, rd, fd
+            ahead.extra = bool(extra)
             ahead.marks = marks
             marks.append(('thread', time.perf_counter()))
             box['ahead'] = ahead
@@ -308,9 +314,10 @@ def start_text_ahead(path, fmt, device, warm=True):
     th.start()
 
 
-def take_text_ahead(path=None, fmt=None, ctx=None):
-    """The reader `start_text_ahead` started, if it reads `path` as `fmt` for
-    the context `ctx`; a reader of something else is stopped (None then)."""
+def take_text_ahead(path=None, fmt=None, ctx=None, extra=False):
+    """The reader `start_text_ahead` started, if it reads `path` as `fmt` (cut
+    for the "ex" parsers or not: `extra`) for the context `ctx`; a reader of
+    something else is stopped (None then)."""
     th, box = _text_ahead.pop('x', (None, None))
     if th is None:
         return None
@@ -319,7 +326,7 @@ def take_text_ahead(path=None, fmt=None, ctx=None):
     if ahead is None:
         return None
     if path is None or box['path'] != path or ahead.fmt != fmt or \
-            ahead.ctx is not ctx:
+            ahead.ctx is not ctx or ahead.extra != bool(extra):
         try:
             ahead.close()
         finally:
@@ -519,7 +526,8 @@ class DeviceTextRoute:
         taken = None
         if _text_ahead:
             if source is None and self._tring is None:
-                taken = take_text_ahead(self._dpath, self._dfmt, self.ctx)
+                taken = take_text_ahead(self._dpath, self._dfmt, self.ctx,
+                                        ordinal)
             else:
                 drop_text_ahead()
         if taken is not None:
@@ -632,7 +640,7 @@ class DeviceTextRoute:
                     fill_n = out.size
                     t0 = time.perf_counter()
                     ok, begin, stop, hdr = nat.Tokenizer.sam_span(
-                        out, final, in_header, self._dfmt)
+                        out, final, in_header, self._dfmt, ordinal)
                     lap['span'] += time.perf_counter() - t0
                     if not ok and not final:    # no complete run yet: read more
                         carry = out.tobytes()
@@ -695,7 +703,8 @@ class DeviceTextRoute:
                 t0 = time.perf_counter()
                 ok, begin, stop, hdr = nat.Tokenizer.sam_span(view, final,
                                                               in_header,
-                                                              self._dfmt)
+                                                              self._dfmt,
+                                                              ordinal)
                 lap['span'] += time.perf_counter() - t0
                 if not ok and not final:    # no complete run yet: look further
                     span *= 2
@@ -856,7 +865,8 @@ class DeviceTextRoute:
                         max_workers=max(2, tokenizer_threads() // 2))
                 gen = _pread_blocks(ring, self._read_pool, rd, fd, size,
                                     self._dfmt, tok, lap, block,
-                                    self.DTOK_HEADROOM, self.DTOK_READ_PIECE)
+                                    self.DTOK_HEADROOM, self.DTOK_READ_PIECE,
+                                    extra=ordinal)
             ahead = _TextAhead(self.ctx, gen, ring,
                                3 if whole is not None else self.DTOK_DEPTH,
                                lap)

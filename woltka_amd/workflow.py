@@ -260,7 +260,8 @@ def _workflow_with_context(
             if comm is None and not stratmap and \
                     not os.environ.get('WOLTKA_NO_DTOK'):
                 from .routes.device_text import start_text_ahead
-                start_text_ahead(fp0, input_fmt, device)
+                start_text_ahead(fp0, input_fmt, device,
+                                 extra=bool(coords_fp))
     start_coords_ahead(coords_fp, zippers)
     try:
         tree, rankdic, namedic, root = build_hierarchy(
