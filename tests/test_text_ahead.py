@@ -275,3 +275,93 @@ def test_coord_match_blocks_are_cut_by_the_ex_parsers_rows(tmp_path, seed):
         lost[extra] = n
     assert lost[True] == 0
     assert lost[False] > 0      # (what the old cut did to these inputs)
+
+
+def _gpu_dtok_generators():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'gpu_dtok_rows', os.path.join(ROOT, 'tests', 'test_gpu_dtok.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_blocks_left_to_the_host_tokenizer_add_up_to_the_file(tmp_path, seed):
+    """Every block of the device text route may end up with the host
+    tokenizer (`_host_block`: the bytes up to the block's fill, not final),
+    which cuts for itself.  Whatever the format, the flavour and the block
+    size: the reads and records of the blocks, parsed that way one by one, are
+    those of the file parsed at once -- the reader's cut and the tokenizer's
+    are the same cut."""
+    import random
+    G = _gpu_dtok_generators()
+    rng = random.Random(seed)
+    subjects = [f'G{i:04d}' for i in range(60)]
+    cases = [
+        ('sam', False, G._random_sam(rng, 900, subjects, True, True, True)),
+        ('sam', False, G._random_sam(rng, 900, subjects, False, False, False,
+                                     header=False, newline_at_end=False)),
+        ('sam', True, G._random_coords_sam(rng, 900, weird=True)[1]),
+    ]
+    for fmt in ('b6o', 'paf', 'map'):
+        cases.append((fmt, False, G._random_rows(rng, fmt, 900, subjects)))
+    for fmt in ('b6o', 'paf'):
+        for extra in (True, False):
+            cases.append((fmt, extra,
+                          G._random_coords_rows(rng, fmt, 900, True)[1]))
+    pool = ThreadPoolExecutor(max_workers=3)
+    rd = nat.Tokenizer(2)
+    try:
+        for k, (fmt, extra, text) in enumerate(cases):
+            text = text.encode()
+            fp = tmp_path / f'c{k}.txt'
+            fp.write_bytes(text)
+            whole = nat.Tokenizer(2)
+            try:
+                res = whole.parse(text, first=True, final=True, extra=extra,
+                                  fmt=fmt)
+                want = (res['off'].size - 1, int(res['off'][-1]))
+            except (ValueError, IndexError) as e:
+                want = type(e)
+            whole.close()
+            for block in (1 << 13, 1 << 15):
+                ctx = FakeContext()
+                H = 1 << 12
+                ring = StageRing(ctx, 8, {'text': (np.uint8, block + H)})
+                fd = os.open(fp, os.O_RDONLY)
+                lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0,
+                       'read': 0.0, 'span': 0.0, 'blocks': 0}
+
+                class Flag:
+                    warm = False
+                tok = nat.Tokenizer(2)
+                reads = recs = pos = 0
+                try:
+                    for item in D._pread_blocks(ring, pool, rd, fd, len(text),
+                                                fmt, Flag, lap, block, H,
+                                                1 << 10, extra=extra):
+                        slot, out, fill, begin, stop, first, final, hin, hout \
+                            = item
+                        assert bytes(out[:stop]) == text[pos:pos + stop]
+                        pos += stop
+                        tok.set_header_state(hin)
+                        res = tok.parse(memoryview(out).cast('B')[:fill],
+                                        first=first, final=final, extra=extra,
+                                        fmt=fmt)
+                        reads += res['off'].size - 1
+                        recs += int(res['off'][-1])
+                        tok.set_header_state(hout)
+                        if slot is not None:
+                            ring.release(slot)
+                    got = (reads, recs)
+                    assert pos == len(text)
+                except (ValueError, IndexError) as e:
+                    got = type(e)
+                finally:
+                    os.close(fd)
+                    tok.close()
+                assert got == want, (fmt, extra, block, got, want)
+    finally:
+        pool.shutdown(wait=True)
+        rd.close()
