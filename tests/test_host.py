@@ -422,3 +422,33 @@ def test_hierarchy_and_coords_from_a_fifo(tmp_path):
     ref = ordinal.load_gene_coords_file(str(tmp_path / 'c.txt'))
     assert list(tab.genomes) == list(ref.genomes)
     assert np.array_equal(tab.start0, ref.start0)
+
+
+def test_gene_ids_seen_twice_are_told_like_the_references_set():
+    """`isdup` of the native coordinates reader (ordinal.py:413-417: a set of
+    the gene ids seen, over all nucleotides, replaced ones included) from ids
+    dealt into piles by their hashes: random small files against a Python
+    set, and one repeat among 300 000 ids."""
+    import random
+    from woltka_amd import _native as nat
+    rng = random.Random(7)
+    for _ in range(300):
+        lines, seen = [], []
+        for _g in range(rng.randrange(1, 8)):
+            lines.append(f'>N{rng.randrange(5)}')
+            for _k in range(rng.randrange(0, 6)):
+                name = f'g{rng.randrange(12)}' if rng.random() < 0.7 \
+                    else f'gene_long_name_{rng.randrange(10 ** 6)}'
+                seen.append(name)
+                lines.append(f'{name}\t{rng.randrange(1, 100)}\t'
+                             f'{rng.randrange(1, 100)}')
+        try:
+            res = nat.parse_gene_coords(('\n'.join(lines) + '\n').encode())
+        except ValueError:      # (no coordinate at all)
+            continue
+        assert res[5] == (len(set(seen)) != len(seen))
+    names = [f'G{i:07d}' for i in range(300_000)]
+    body = '>X\n' + ''.join(f'{n}\t1\t9\n' for n in names)
+    assert nat.parse_gene_coords(body.encode())[5] is False
+    body += f'>Y\n{names[123456]}\t3\t8\n'
+    assert nat.parse_gene_coords(body.encode())[5] is True

@@ -68,6 +68,46 @@ struct Nucl {
     std::vector<Gene> genes;
 };
 
+// Does some gene id occur twice among `ids` (ordinal.py:413-417 keeps a set of them while it reads)?  Half a
+// million ids through one hash table as they are read cost more than everything else the reader does (a random
+// access into megabytes per line).  Here the ids are dealt into a thousand piles by the top bits of their hashes
+// -- two passes over arrays, no random access -- and every pile gets a table of its own that stays in the cache.
+struct IdRef {
+    const char* p;
+    uint32_t n;
+    uint64_t h;  // hash_bytes(p, n), taken while the line is being read
+};
+bool any_id_twice(const std::vector<IdRef>& ids) {
+    const size_t n = ids.size();
+    if (n < 2) return false;
+    constexpr int kBits = 10;
+    constexpr size_t kPiles = (size_t)1 << kBits;
+    std::vector<uint32_t> first(kPiles + 1, 0);
+    for (size_t i = 0; i < n; ++i) first[(size_t)(ids[i].h >> (64 - kBits)) + 1] += 1;
+    for (size_t k = 0; k < kPiles; ++k) first[k + 1] += first[k];
+    std::vector<uint32_t> pile(n), at(first.begin(), first.end() - 1);
+    for (size_t i = 0; i < n; ++i) pile[at[(size_t)(ids[i].h >> (64 - kBits))]++] = (uint32_t)i;
+    std::vector<uint32_t> slots;  // id number + 1, 0 = free
+    for (size_t k = 0; k < kPiles; ++k) {
+        const uint32_t lo = first[k], hi = first[k + 1];
+        if (hi - lo < 2) continue;
+        size_t cap = 16;
+        while (cap < (size_t)(hi - lo) * 2) cap <<= 1;
+        slots.assign(cap, 0u);
+        for (uint32_t x = lo; x < hi; ++x) {
+            const uint32_t i = pile[x];
+            size_t s = (size_t)(ids[i].h >> 8) & (cap - 1);
+            while (slots[s]) {
+                const uint32_t j = slots[s] - 1u;
+                if (ids[j].h == ids[i].h && ids[j].n == ids[i].n && memcmp(ids[j].p, ids[i].p, ids[i].n) == 0) return true;
+                s = (s + 1) & (cap - 1);
+            }
+            slots[s] = i + 1u;
+        }
+    }
+    return false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -79,11 +119,9 @@ int wk_coords_parse(const char* buf, int64_t len, wk_coords** out) {
     *out = c;
     std::vector<Nucl> nucls;
     NameTable index;  // nucleotide name -> position in `nucls`
-    NameTable used;   // gene ids seen (until the first repeat)
-    // (a gene line is >= ~12 bytes: room for all of them, no rehash on the way)
-    used.reserve((size_t)len / 12 + 16, (size_t)len / 2 + 16);
+    std::vector<IdRef> ids;  // the gene ids of all lines, in text order (any_id_twice)
+    ids.reserve((size_t)len / 16 + 16);
     int cur = -1;
-    bool isdup = false;
     const char* p = buf;
     const char* e = buf + len;
     while (p < e) {
@@ -130,19 +168,26 @@ int wk_coords_parse(const char* buf, int64_t len, wk_coords** out) {
         long long b = 0, en = 0;
         if (!simple_int(t1 + 1, t2, b) || !simple_int(t2 + 1, re, en)) return WK_E_STATE;
         nucls[(size_t)cur].genes.push_back(Gene{line, (uint32_t)(t1 - line), std::min(b, en) - 1, std::max(b, en)});
-        if (!isdup) {
-            const uint64_t hv = hash_bytes(line, (size_t)(t1 - line));
-            if (used.find(line, (size_t)(t1 - line), hv) >= 0)
-                isdup = true;
-            else
-                used.add(line, (size_t)(t1 - line), hv);
-        }
+        ids.push_back(IdRef{line, (uint32_t)(t1 - line), hash_bytes(line, (size_t)(t1 - line))});
     }
     if (nucls.empty()) {
         c->err = "No coordinate was read from file.";
         return WK_E_ARG;
     }
-    c->isdup = isdup ? 1 : 0;
+    c->isdup = any_id_twice(ids) ? 1 : 0;
+    {
+        // (room for everything below in one go)
+        const size_t n_genes = ids.size();
+        c->start0.reserve(n_genes);
+        c->end.reserve(n_genes);
+        c->findex.reserve(n_genes);
+        c->gene_off.reserve(n_genes + 1);
+        c->goff.reserve(nucls.size() + 1);
+        c->genome_off.reserve(nucls.size() + 1);
+        size_t id_bytes = 0;
+        for (const IdRef& r : ids) id_bytes += r.n;
+        c->gene_blob.reserve(id_bytes);
+    }
     c->goff.push_back(0);
     c->genome_off.push_back(0);
     c->gene_off.push_back(0);
