@@ -452,3 +452,46 @@ def test_gene_ids_seen_twice_are_told_like_the_references_set():
     assert nat.parse_gene_coords(body.encode())[5] is False
     body += f'>Y\n{names[123456]}\t3\t8\n'
     assert nat.parse_gene_coords(body.encode())[5] is True
+
+
+def test_native_preorder_numbers_like_the_level_passes():
+    """`wk_preorder` (one walk, leaves numbered on the spot, 32-bit offsets)
+    against `hierarchy.preorder_numbering`'s level-by-level numpy passes on
+    random trees in arbitrary numbering: the same numbers, sizes and depths
+    (children in input order); two roots, a parent out of range and a cycle
+    beside the tree are told."""
+    from woltka_amd import _native as nat
+    from woltka_amd import hierarchy as H
+    rng = np.random.default_rng(5)
+    for n in [1, 2, 3] + [int(x) for x in rng.integers(4, 400, 120)] + [5000]:
+        par = np.zeros(n, dtype=np.int64)
+        order = rng.permutation(n)
+        par[order[0]] = order[0]
+        for k in range(1, n):
+            # (chains, bushes and stars)
+            back = 1 if rng.random() < 0.3 else int(rng.integers(1, k + 1))
+            par[order[k]] = order[k - back]
+        pre, size, depth = nat.preorder(par)
+        # (the numpy passes themselves: small trees take them inside
+        # preorder_numbering, larger ones would come back here)
+        kids = np.flatnonzero(par != np.arange(n))
+        want_depth = np.zeros(n, dtype=np.int64)
+        for v in order[1:]:
+            want_depth[v] = want_depth[par[v]] + 1
+        assert np.array_equal(depth, want_depth)
+        assert sorted(pre.tolist()) == list(range(n))
+        assert (pre[par[kids]] < pre[kids]).all()
+        assert (pre[kids] + size[kids] <=
+                pre[par[kids]] + size[par[kids]]).all()
+        assert int(size[order[0]]) == n
+        if n <= 400:
+            p2, s2, d2, r = H.preorder_numbering(par)
+            assert r == order[0]
+            assert np.array_equal(pre, p2) and np.array_equal(size, s2) \
+                and np.array_equal(depth, d2)
+    with pytest.raises(ValueError):
+        nat.preorder(np.array([0, 1], dtype=np.int64))
+    with pytest.raises(ValueError):
+        nat.preorder(np.array([0, 5], dtype=np.int64))
+    with pytest.raises(LookupError):
+        nat.preorder(np.array([0, 0, 3, 2], dtype=np.int64))
