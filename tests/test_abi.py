@@ -77,6 +77,21 @@ def test_product_does_not_import_oracle():
                     os.path.join(dirpath, fn))
 
 
+def test_product_does_not_import_torch():
+    """north_star: host code over a ctypes C ABI, no PyTorch -- not even an
+    optional launcher inside the package (tools/torch_world.py is the adapter
+    for ranks torch.distributed.run started)."""
+    import re
+    pkg = os.path.join(ROOT, 'woltka_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith('.py'):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert not re.search(r'^\s*(import|from)\s+torch\b', src,
+                                     re.M), os.path.join(dirpath, fn)
+
+
 def test_library_carries_the_digest_of_its_sources():
     """build() must have compiled the sources as they are now: the digest in
     the .so (wk_build_id) equals the digest of csrc/ + the header."""

@@ -37,7 +37,12 @@ def _worker(rank, world, port, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        data = shard.classify_sharded(_oracle_classify, _files(), rank, world)
+        def gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        data = shard.classify_sharded(_oracle_classify, _files(), rank, world,
+                                      gather=gather)
         dist.barrier()
         q.put((rank, data))
     finally:

@@ -9,9 +9,9 @@ over N GPUs of the node (one process each, started by this one).
 The options are kept as one table (flags, keyword arguments of
 ``click.option``) and attached in a loop.
 
-The table commands — ``collapse``, ``normalize``, ``filter``, ``merge``,
-``coverage`` — are declared the same way in ``cli_tables.py`` and registered
-on the same group.
+The reference's table commands (``collapse``, ``normalize``, ``filter``,
+``merge``, ``coverage``) are outside this path and not
+provided: use the reference's own for them.
 """
 import click
 
@@ -111,11 +111,6 @@ def _classify(**kwargs):
 for _flags, _kw in reversed(OPTIONS):
     _classify = click.option(*_flags, **_kw)(_classify)
 classify_cmd = cli.command('classify', **CMD_KA)(_classify)
-
-
-from .cli_tables import register as _register_table_commands  # noqa: E402
-collapse_cmd, normalize_cmd, filter_cmd, merge_cmd, coverage_cmd = \
-    _register_table_commands(cli, CMD_KA)
 
 
 if __name__ == '__main__':

@@ -437,37 +437,52 @@ def id2file_from_map(fp):
     return pairs or None
 
 
-def read_map_uniq(fh, sep='\t'):
-    """(key, value) of lines with exactly two columns."""
+def _map_rows(fh, sep):
+    """The lines of a mapping file as lists of columns (the last one
+    right-stripped, as every reader of the reference strips the text behind
+    its first separator, woltka/file.py:368-426); lines without a separator
+    are no rows."""
     for line in fh:
-        key, found, value = line.partition(sep)
-        if found and sep not in value:
-            yield key, value.rstrip()
+        at = line.find(sep)
+        if at >= 0:
+            yield [line[:at]] + line[at + len(sep):].rstrip().split(sep)
+
+
+def read_map_uniq(fh, sep='\t'):
+    """(key, value) of the lines with exactly one separator -- counted before
+    the value is stripped: trailing tabs make a line ambiguous
+    (woltka/file.py:368-385)."""
+    for line in fh:
+        cols = line.split(sep, 2)
+        if len(cols) == 2:
+            yield cols[0], cols[1].rstrip()
 
 
 def read_map_1st(fh, sep='\t'):
-    """(key, second column) of lines with at least two columns."""
+    """(key, second column) of every row (woltka/file.py:388-406: the second
+    column is stripped by itself there, which differs when blanks sit in
+    front of the next separator)."""
     for line in fh:
-        key, found, rest = line.partition(sep)
-        if found:
-            yield key, rest.partition(sep)[0].rstrip()
+        cols = line.split(sep, 2)
+        if len(cols) > 1:
+            yield cols[0], cols[1].rstrip()
 
 
 def read_map_all(fh, sep='\t'):
-    """(first column, [other columns]) of lines with at least two columns
+    """(first column, [other columns]) of every row
     (woltka/file.py:409-426)."""
-    for line in fh:
-        key, found, rest = line.partition(sep)
-        if found:
-            yield key, rest.rstrip().split(sep)
+    return ((row[0], row[1:]) for row in _map_rows(fh, sep))
 
 
 def read_map_many(fh, sep='\t'):
-    """{key: [values]} over all lines of a mapping file, one-to-many lines
-    and repeated keys alike (woltka/file.py:429-466)."""
+    """{key: [values]}: one-to-many rows and repeated keys alike add to the
+    key's list, in file order (woltka/file.py:429-466)."""
     res = {}
-    for key, values in read_map_all(fh, sep):
-        res.setdefault(key, []).extend(values)
+    for row in _map_rows(fh, sep):
+        if row[0] in res:
+            res[row[0]] += row[1:]
+        else:
+            res[row[0]] = row[1:]
     return res
 
 

@@ -9,11 +9,13 @@ the per-process profiles — disjoint sample sets, a few KB each — are gathere
 on rank 0 through the host.  There is no device-side collective: xGMI / RCCL
 are not involved in the data path.
 
-Two ways to get the processes: `woltka classify --gpus N` starts them itself
-(``LocalWorld``: multiprocessing, pipes to rank 0, every rank's threads pinned
-to the NUMA node of its GPU — no PyTorch anywhere), or a launcher that sets
-RANK / LOCAL_RANK / WORLD_SIZE (``torch.distributed.run``) does, and the
-profiles are gathered with gloo (``TorchWorld``).
+`woltka classify --gpus N` starts the processes itself (``LocalWorld``:
+multiprocessing, pipes to rank 0, every rank's threads pinned to the NUMA node
+of its GPU).  Ranks started by somebody else's launcher pass
+``workflow(comm=...)`` an object of the same shape (rank, local, world, kind,
+``gather(obj)``); ``tools/torch_world.py`` is one over gloo, for
+``torch.distributed.run`` -- outside the package: nothing in here imports
+PyTorch or reads a launcher's environment.
 """
 import os
 from os.path import isfile, splitext
@@ -108,35 +110,22 @@ def merge_profiles(parts):
     return out
 
 
-def env_rank():
-    """(rank, local_rank, world) from the torch.distributed launcher
-    environment; (0, 0, 1) when not launched by it."""
-    return (int(os.environ.get('RANK', '0')),
-            int(os.environ.get('LOCAL_RANK', '0')),
-            int(os.environ.get('WORLD_SIZE', '1')))
-
-
 def classify_sharded(classify_fn, files, rank, world, gather=None, split=True):
     """Run ``classify_fn(share)`` on this process's share of ``files`` and
-    merge all shares' results where they are gathered (every rank under
-    ``TorchWorld``, rank 0 under ``LocalWorld``; ``None`` elsewhere).
+    merge all shares' results where they are gathered (rank 0 under
+    ``LocalWorld``; wherever the caller's ``gather`` returns the list).
 
     ``classify_fn`` maps a files list/dict to a ``data`` dict (normally a
     ``functools.partial`` of ``workflow.classify`` bound to this process's
     device).  ``gather`` collects one Python object per process into a list
-    (default: ``torch.distributed.all_gather_object`` on the initialised
-    process group)."""
+    (in rank order; ``None`` on the ranks that do not get it)."""
     share = partition_files(files, world, split=split)[rank]
     mine = classify_fn(share) if share else {}
     if world == 1:
         return mine
     if gather is None:
-        import torch.distributed as dist
-
-        def gather(obj):
-            out = [None] * world
-            dist.all_gather_object(out, obj)
-            return out
+        raise ValueError('several ranks need a `gather` (LocalWorld.gather, '
+                         'or the launcher\'s own)')
     parts = gather(mine)
     return None if parts is None else merge_profiles(parts)
 
@@ -188,24 +177,6 @@ class LocalWorld:
                     conn.close()
                 except OSError:
                     pass
-
-
-class TorchWorld:
-    """Ranks started by ``torch.distributed.run`` (or any launcher that sets
-    RANK / LOCAL_RANK / WORLD_SIZE): profiles gathered with gloo on every
-    rank."""
-    kind = 'torch'
-
-    def __init__(self):
-        self.rank, self.local, self.world = env_rank()
-
-    def gather(self, obj):
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group('gloo')
-        out = [None] * dist.get_world_size()
-        dist.all_gather_object(out, obj)
-        return out
 
 
 def _local_rank_main(entry, kwargs, rank, world, conn):

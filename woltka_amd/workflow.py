@@ -30,7 +30,7 @@ from .file import (FilesAhead, id2file_from_dir, id2file_from_map, openzip, path
                    stem2rank, write_readmap)
 from .ordinal import load_gene_coords, load_gene_coords_file  # noqa: F401
 from .ranges import Coverage, range_mapper, write_coverage
-from .shard import (FilePart, classify_sharded, env_rank, file_key,
+from .shard import (FilePart, classify_sharded, file_key,
                     file_path)
 from .table import allkeys, prep_table, write_table
 from .tree import (fill_root, read_columns, read_lineage, read_names,
@@ -113,17 +113,15 @@ def _workflow(input_fp, output_fp, input_fmt, input_ext, samples, demux,
               add_lineage, outmap_dir, outmap_zip, outcov_dir, outcov_fmt,
               chunk, cache, no_exe, device, gpus=1, comm=None):
     # `--gpus N`: this process becomes rank 0 of N and starts the others
-    # (shard.LocalWorld: multiprocessing, no PyTorch); a launcher that set
-    # WORLD_SIZE (torch.distributed.run) is honoured as before
+    # (shard.LocalWorld: multiprocessing, no PyTorch).  Ranks somebody else
+    # started (mpirun, torch.distributed.run ...) hand in their own `comm`:
+    # any object with rank / local / world / kind and gather(obj) -- the
+    # package itself never looks at a launcher's environment
     procs = []
-    if comm is None and env_rank()[2] > 1:
-        from .shard import TorchWorld
-        comm = TorchWorld()
-    elif comm is None and gpus and gpus > 1:
+    if comm is None and gpus and gpus > 1:
         from .shard import start_local_world
         kw = {k: v for k, v in locals().items()
-              if k not in ('comm', 'procs', 'gpus', 'TorchWorld',
-                           'start_local_world')}
+              if k not in ('comm', 'procs', 'gpus', 'start_local_world')}
         comm, procs = start_local_world(gpus, _rank_entry, kw)
     failed = True
     try:
@@ -284,7 +282,7 @@ def _workflow_with_context(
             exact=exact,
             rounding=(digits, scale_factor(scale) if scale else None, frac))
 
-    # one process per GPU (`--gpus N`, or a launcher's RANK / WORLD_SIZE):
+    # one process per GPU (`--gpus N`, or ranks that came with their `comm`):
     # alignment files (samples) shard across processes, profiles merge on the
     # host
     if comm is not None and comm.world > 1:
