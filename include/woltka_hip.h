@@ -301,6 +301,10 @@ int wk_dtok_copy_ahead(wk_ctx* ctx, const char* text, int64_t begin,
                        int64_t stop, int32_t* ticket);
 int wk_dtok_copy_wait(wk_ctx* ctx, int32_t ticket);
 int wk_dtok_copy_drop(wk_ctx* ctx);
+/* How many blocks may be copied ahead on this device as it is now: half of its
+ * free memory in text buffers (a reader that starts before the hierarchy is
+ * read must not take the memory the count table and the records will want). */
+int wk_dtok_ahead_room(wk_ctx* ctx, int32_t* n_blocks);
 int wk_dtok_text_back(wk_ctx* ctx, char* out, int64_t n);
 /* A hint: the blocks scanned from now on are `text_bytes` bytes of one sample
  * in all (0 = unknown again).  The sample's record buffers are then sized once,

@@ -54,7 +54,7 @@ SYMBOLS = (
     'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
     'wk_dtok_format',
     'wk_dtok_copy', 'wk_dtok_copy_ahead', 'wk_dtok_copy_wait',
-    'wk_dtok_copy_drop', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
+    'wk_dtok_copy_drop', 'wk_dtok_ahead_room', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
     'wk_dtok_scan_emit', 'wk_dtok_keep_reads', 'wk_readmap_tables',
     'wk_dtok_readmap',
     'wk_dtok_readmap_fetch', 'wk_strata_load', 'wk_strata_labels',
@@ -196,6 +196,7 @@ def load_library():
                                          C.POINTER(C.c_int32)]),
         'wk_dtok_copy_wait': (C.c_int, [p, C.c_int32]),
         'wk_dtok_copy_drop': (C.c_int, [p]),
+        'wk_dtok_ahead_room': (C.c_int, [p, C.POINTER(C.c_int32)]),
         'wk_dtok_text_back': (C.c_int, [p, C.c_void_p, C.c_int64]),
         'wk_dtok_expect': (C.c_int, [p, C.c_int64]),
         'wk_dtok_scan': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
@@ -597,6 +598,13 @@ class Context:
     def dtok_copy_drop(self):
         """Forget the blocks copied ahead that no scan has asked for."""
         self._check(self._lib.wk_dtok_copy_drop(self._h))
+
+    def dtok_ahead_room(self):
+        """Blocks a reader may copy ahead of the scans: half of the device's
+        free memory in text buffers."""
+        n = C.c_int32(0)
+        self._check(self._lib.wk_dtok_ahead_room(self._h, C.byref(n)))
+        return n.value
 
     def dtok_expect(self, text_bytes):
         """The blocks scanned from now on are ``text_bytes`` bytes of one

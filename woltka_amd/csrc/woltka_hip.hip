@@ -2747,6 +2747,43 @@ int wk_dtok_copy_drop(wk_ctx* c) {
             c->copy_src[q] = nullptr;
             c->copy_counted[q] = false;
         }
+    // (the slabs a reader far ahead of the scans took -- up to 12 GB -- go back to the device once none of their
+    // buffers is in use: what follows the file, count tables and records, must not compete with parked text.
+    // The first slab stays: a reader that keeps close to the scans lives in it)
+    {
+        std::lock_guard<std::mutex> slabs(c->slab_mu);
+        for (int sl = 1; sl < wk_ctx::kTextBufs / wk_ctx::kSlabBufs; ++sl) {
+            if (!c->d_textslab[sl].p) continue;
+            bool idle = true;
+            for (int q = sl * wk_ctx::kSlabBufs; q < (sl + 1) * wk_ctx::kSlabBufs; ++q) idle = idle && c->buf_state[q] == wk_ctx::kBufFree;
+            if (!idle) continue;
+            HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the scan of a block that lived there)
+            for (int q = sl * wk_ctx::kSlabBufs; q < (sl + 1) * wk_ctx::kSlabBufs; ++q)
+                if (c->d_textptr[q] >= c->d_textslab[sl].as<unsigned char>() &&
+                    c->d_textptr[q] < c->d_textslab[sl].as<unsigned char>() + wk_ctx::kTextStride * wk_ctx::kSlabBufs)
+                    c->d_textptr[q] = nullptr;
+            if (c->dt_text >= c->d_textslab[sl].as<unsigned char>() && c->dt_text < c->d_textslab[sl].as<unsigned char>() + c->d_textslab[sl].cap)
+                c->dt_text = nullptr;  // (wk_dtok_text_back of that block: refused from now on)
+            c->d_textslab[sl].release();
+        }
+    }
+    return WK_OK;
+}
+
+// How many blocks a reader may copy ahead of the scans on this device as it is now: half of the memory that is free
+// (slabs already taken for text count as free: they are reused), in text buffers of one block each.
+int wk_dtok_ahead_room(wk_ctx* c, int32_t* n_blocks) {
+    if (!c || !n_blocks) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    size_t held = 0;
+    {
+        std::lock_guard<std::mutex> slabs(c->slab_mu);
+        for (const DevBuf& b : c->d_textslab) held += b.p ? b.cap : 0;
+    }
+    const size_t room = (free_b + held) / 2 / wk_ctx::kTextStride;
+    *n_blocks = (int32_t)std::min<size_t>(room, (size_t)wk_ctx::kTextBufs - 1);
     return WK_OK;
 }
 

@@ -162,6 +162,14 @@ class _TextAhead:
         import threading
         self.ctx, self.ring, self.lap = ctx, ring, lap
         self.q = queue.Queue()          # (bounded by `free_bufs`)
+        # (never more text parked on the device than half of what is free
+        # there now: the count table and the records come later and want
+        # their share; a shallow ring only means the reader waits for scans)
+        try:
+            depth = max(2, min(depth, ctx.dtok_ahead_room()))
+        except (AttributeError, RuntimeError):
+            pass
+        self.depth = depth
         self.free_bufs = threading.Semaphore(depth)
         self.stop = threading.Event()
         self.first = None               # (timing) the first copy: begun, issued
@@ -176,6 +184,10 @@ class _TextAhead:
         try:
             for item in gen:
                 slot = item[0]
+                if self.stop.is_set():      # (nobody will scan what follows)
+                    if isinstance(slot, int):
+                        ring.release(slot)
+                    return
                 if slot is not None:
                     while not self.free_bufs.acquire(timeout=0.05):
                         if self.stop.is_set():
