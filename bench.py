@@ -572,9 +572,14 @@ class TextLcaWorkload:
     64 MB, `wk_words_flush` per sample); only the host link is left out -- the
     blocks were uploaded before the clock starts (`wk_text_upload`)."""
     key = 'lca_text'
-    dominant = 'dtok_emit'
-    families = ('dtok_lines', 'dtok_parse', 'dtok_emit')
-    symbols = {'dtok_lines': 'wk::dtok_count_kernel + wk::tile_scan_kernel + '
+    dominant = 'dtok_fused'
+    # (a block the one-kernel tokenizer hands back -- none of the synthetic
+    # text's -- takes dtok_lines / dtok_parse / dtok_emit: WOLTKA_NO_FUSED=1
+    # times those)
+    families = ('dtok_fused', 'dtok_lines', 'dtok_parse', 'dtok_emit')
+    symbols = {'dtok_fused': 'wk::dtok_fused_begin_kernel + '
+                             'wk::dtok_fused_kernel',
+               'dtok_lines': 'wk::dtok_count_kernel + wk::tile_scan_kernel + '
                              'wk::dtok_lines_kernel',
                'dtok_parse': 'wk::dtok_parse_kernel<false>',
                'dtok_emit': 'wk::dtok_runs_kernel + '
@@ -682,6 +687,19 @@ class TextLcaWorkload:
         rec_per_byte = self.records / max(self.text_bytes, 1)
         self.launch_bytes = int(self.block_bytes[self._probe] *
                                 (1 + 4 * rec_per_byte))
+        # which kernels do the blocks of a step take?  (one pass, untimed)
+        before = ctx.dtok_fused_counts()
+        self.step()
+        after = ctx.dtok_fused_counts()
+        ctx.counts_clear()
+        self.fused_blocks = after[0] - before[0]
+        self.handed_back = after[1] - before[1]
+        if self.fused_blocks == len(self.blocks):
+            self.families = ('dtok_fused',)
+        else:
+            self.families = ('dtok_lines', 'dtok_parse', 'dtok_emit') + (
+                ('dtok_fused',) if self.fused_blocks else ())
+            self.dominant = 'dtok_emit'
 
     def step(self):
         ctx, tok = self.ctx, self.tok

@@ -75,6 +75,11 @@ int wk_last_kernel_ms(wk_ctx* ctx, const char* family, double* ms);
  * starts).  wk_text_clear frees the blocks. */
 int wk_text_upload(wk_ctx* ctx, const char* text, int64_t begin, int64_t stop);
 int wk_text_clear(wk_ctx* ctx);
+/* Blocks of plain SAM text the one-kernel tokenizer (csrc/wk_dtok_fused.hpp) did
+ * and blocks it handed back to the six kernels of csrc/wk_dtok.hpp, since the
+ * context was created.  wk_tune "dtok_fused" (0/1) switches it; results never
+ * depend on it ("dtok_fused_per_cu": its persistent workgroups per CU). */
+int wk_dtok_fused_counts(wk_ctx* ctx, int64_t* done, int64_t* handed_back);
 /* The rate (bytes/s) of `reps` pinned host -> device copies of `bytes` each,
  * back to back on a stream of their own: the bound of the end-to-end text
  * route on this box (bench.py's e2e rooflines are quoted against it). */

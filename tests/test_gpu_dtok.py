@@ -794,3 +794,80 @@ def test_rows_that_only_the_plain_parser_takes_for_rows(tmp_path, monkeypatch,
     assert C.ROUTES.get('dhits', 0) > 0 and C.ROUTES.get('host_block', 0) > 0
     b, log_b = _run(tmp_path, 'h', True, **kw)
     assert a == b and log_a == log_b
+
+
+def _fused_sam(rng, n_queries, subjects, shape):
+    """SAM text that puts the one-kernel tokenizer's tile logic to work: runs
+    of 1-16 hits (some longer than a tile's look-ahead with `long_runs`),
+    repeated subjects inside a read, mates, unmapped records between and inside
+    runs, lines with SEQ / QUAL so long that no line before a tile is in its
+    window (`long_lines`), lines as short as they get (`tiny`)."""
+    lines = ['@HD\tVN:1.0\tSO:unsorted', '@SQ\tSN:x\tLN:5']
+    for q in range(n_queries):
+        name = f'r{q}' if shape == 'tiny' else f'read{q:07d}'
+        k = rng.choice([1, 1, 1, 2, 3, 5, 9, 16])
+        if shape == 'long_runs' and q % 97 == 0:
+            k = 16
+        for i in range(k):
+            s = rng.choice(subjects)
+            flag = rng.choice([99, 147, 83, 163, 355, 403, 0, 16, 256])
+            if rng.random() < 0.04:
+                lines.append(f'{name}\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*')
+            tail = '1\t42\t50M\t*\t0\t0\t*\t*'
+            if shape == 'long_lines' and rng.random() < 0.3:
+                n = rng.choice([150, 900, 2500, 6000])
+                tail = f'1\t42\t{n}M\t*\t0\t0\t' + 'ACGT' * (n // 4) + '\t' + \
+                    'F' * n
+            elif shape == 'long_runs' and k == 16:
+                tail = '1\t42\t250M\t*\t0\t0\t' + 'A' * 250 + '\t' + 'F' * 250
+            elif shape == 'tiny':
+                tail = ''
+            lines.append(f'{name}\t{flag}\t{s}\t{tail}')
+    return '\n'.join(lines) + ('\n' if shape != 'open_end' else '')
+
+
+@pytest.mark.parametrize('shape', ['plain', 'long_runs', 'long_lines', 'tiny',
+                                   'open_end'])
+@pytest.mark.parametrize('block', [1 << 26, 1 << 18])
+def test_one_kernel_tokenizer_equals_the_six(tmp_path, monkeypatch, shape,
+                                             block):
+    """csrc/wk_dtok_fused.hpp against csrc/wk_dtok.hpp (WOLTKA_NO_FUSED) and
+    against the host tokenizer on the same files: same tables, same log --
+    and most blocks did go through the one kernel (runs longer than its window
+    and lines longer than its look-back are its stated limits: handed back or
+    looked up in global memory, never guessed)."""
+    from woltka_amd import classify as C
+    from woltka_amd.hostio import ROUTES
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    rng = random.Random(zlib.crc32(f'{shape}:{block}'.encode()))
+    tax = os.path.join(ROOT, 'tests', 'golden', 'data', 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        subjects = [ln.split('\t')[0] for ln in f][:90]
+    # (no strangers here: a subject without an ancestor at a rank sends the
+    # whole job set to the general route -- the test above has those)
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    n = {'long_lines': 6000, 'tiny': 60000}.get(shape, 25000)
+    for s in ('S1', 'S2'):
+        (indir / f'{s}.sam').write_text(_fused_sam(rng, n if s == 'S1' else 900,
+                                                   subjects, shape))
+    kw = dict(input_fp=str(indir), input_fmt='sam',
+              nodes_fps=[os.path.join(tax, 'nodes.dmp')],
+              map_fps=[os.path.join(tax, 'taxid.map')],
+              ranks='none,phylum,genus')
+    ROUTES.clear()
+    a, log_a = _run(tmp_path, 'fused', False, **kw)
+    fused, back = ROUTES['dtok_fused'], ROUTES['dtok_fused_back']
+    routes_a = dict(ROUTES)
+    monkeypatch.setenv('WOLTKA_NO_FUSED', '1')
+    ROUTES.clear()
+    b, log_b = _run(tmp_path, 'six', False, **kw)
+    assert ROUTES['dtok_fused'] == 0 and ROUTES['dtok'] > 0, dict(ROUTES)
+    monkeypatch.delenv('WOLTKA_NO_FUSED')
+    h, log_h = _run(tmp_path, 'host', True, **kw)
+    assert a == b == h
+    assert log_a == log_b == log_h
+    assert fused + back > 0, routes_a
+    if shape in ('plain', 'open_end'):
+        assert fused > 0
+        assert fused >= 4 * max(back, 1) or block == 1 << 26

@@ -72,7 +72,8 @@ SYMBOLS = (
     'wk_coords_fetch', 'wk_coords_free',
     'wk_gz_bound', 'wk_gz_member', 'wk_crc32', 'wk_gz_inflate_members',
     'wk_gunzip_open', 'wk_gunzip_read', 'wk_gunzip_error', 'wk_gunzip_close',
-    'wk_text_upload', 'wk_text_clear', 'wk_h2d_rate')
+    'wk_text_upload', 'wk_text_clear', 'wk_h2d_rate',
+    'wk_dtok_fused_counts')
 
 
 class Job(C.Structure):
@@ -273,6 +274,7 @@ def load_library():
         'wk_gunzip_close': (None, [p]),
         'wk_text_upload': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64]),
         'wk_text_clear': (C.c_int, [p]),
+        'wk_dtok_fused_counts': (C.c_int, [p, i64p, i64p]),
         'wk_h2d_rate': (C.c_int, [p, C.c_int64, C.c_int,
                                   C.POINTER(C.c_double)]),
     }
@@ -669,6 +671,14 @@ class Context:
 
     def text_clear(self):
         self._check(self._lib.wk_text_clear(self._h))
+
+    def dtok_fused_counts(self):
+        """(measurement) blocks the one-kernel tokenizer did, blocks it handed
+        back to the six kernels."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.wk_dtok_fused_counts(self._h, C.byref(a),
+                                                   C.byref(b)))
+        return a.value, b.value
 
     def h2d_rate(self, nbytes=64 << 20, reps=32):
         """(measurement) bytes/s of pinned host -> device copies of

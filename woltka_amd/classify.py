@@ -152,6 +152,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         self._ring, self._ring_prev = None, None    # packed-record staging
         self._oring = None                          # coord-match staging
         self._tring, self._reader = None, None      # device tokenizer: text staging, reader threads
+        self._fused_seen = (0, 0)                   # wk_dtok_fused_counts when the last file ended
         self._deferred_from = None                  # see take_deferred
         # read maps formatted on the device (csrc/wk_readmap.hpp)
         self._dmaps = None          # (rank2dir, outzip, namedic) while a file is read that way

@@ -52,6 +52,7 @@ struct DtokState {  // device scalars of one block
     uint32_t n_unknown;
     unsigned long long n_out;    // words emitted by dtok_emit
     unsigned long long n_reads;  // reads (non-empty mate groups) emitted
+    unsigned long long n_lines;  // (dtok_fused_kernel) newlines of the block
 };
 
 struct DictSlot {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +21,7 @@
 #include "wk_classify.hpp"
 #include "wk_device.hpp"
 #include "wk_dtok.hpp"
+#include "wk_dtok_fused.hpp"
 #include "wk_free.hpp"
 #include "wk_ordinal.hpp"
 #include "wk_stripe.hpp"
@@ -169,6 +171,13 @@ struct wk_ctx {
     DevBuf g_gene_off, g_stripe_of, g_stripes;
     std::vector<StripeInfo> stripes_host;
     bool stripes_usable = false;
+    int use_fused = 1;         // (0: every block through the six kernels of wk_dtok.hpp; wk_tune "dtok_fused")
+    uint32_t fused_ablate = 0; // (measurement, wk_tune "fz_ablate")
+    std::atomic<bool> fused_streak{false}; // the block scanned last went through the one kernel: copies are not followed by a newline count
+    double dt_lpb = 0.0;       // lines per byte of that block
+    int fused_per_cu = 3;      // persistent workgroups per CU of dtok_fused_kernel (wk_tune "dtok_fused_per_cu")
+    int64_t fused_blocks = 0, fused_fallbacks = 0;   // blocks the fused kernel did / handed back
+    hipEvent_t res_ev = nullptr;
     int use_stripes = 1;       // (0: the gather kernels of wk_ordinal.hpp for every read; measurement)
     int64_t stripes_min_hits = 4000000;  // chunks below this keep the gather kernels (wk_tune "stripes_min")
     DevBuf sb_cnt, sb_tot, sb_base, sb_binned, sb_units, sb_over, sb_stat;
@@ -277,7 +286,7 @@ struct wk_ctx {
     static constexpr size_t kTextStride = ((size_t)66 << 20) + 256;
     DevBuf d_textslab[kTextBufs / kSlabBufs];
     unsigned char* d_textptr[kTextBufs] = {};
-    DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_arena;
+    DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_dict2, d_names16, d_arena;
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
     // measurement (woltka_hip_measure.h): blocks of text that are resident on the device already
@@ -956,6 +965,9 @@ int wk_create(int device, wk_ctx** out) {
         wk_destroy(c);
         return rc;
     }
+    // (measurement: WOLTKA_NO_FUSED=1 keeps every block of the text route on the six kernels of wk_dtok.hpp, for
+    // whole `woltka classify` calls that cannot reach wk_tune)
+    if (const char* nf = getenv("WOLTKA_NO_FUSED")) c->use_fused = (nf[0] && nf[0] != '0') ? 0 : 1;
     *out = c;
     return WK_OK;
 }
@@ -980,7 +992,7 @@ void wk_destroy(wk_ctx* c) {
         if (q % wk_ctx::kSlabBufs == 0) c->d_textslab[q / wk_ctx::kSlabBufs].release();
     }
     for (DevBuf* b : {&c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
-                      &c->d_state, &c->d_dict, &c->d_arena})
+                      &c->d_state, &c->d_dict, &c->d_dict2, &c->d_names16, &c->d_arena})
         b->release();
     for (wk_ctx::ResidentText& r : c->resident) {
         (void)hipFree(r.dev);
@@ -999,6 +1011,7 @@ void wk_destroy(wk_ctx* c) {
         if (ev) (void)hipEventDestroy(ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->count_stream) (void)hipStreamDestroy(c->count_stream);
+    if (c->res_ev) (void)hipEventDestroy(c->res_ev);
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (DevBuf& b : c->rank_tab) b.release();
@@ -1021,6 +1034,7 @@ int wk_sync(wk_ctx* c) {
     if (!c) return WK_E_ARG;
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->count_stream) HIP_TRY(c, hipStreamSynchronize(c->count_stream));  // (newline counts behind copies / resident blocks)
     return WK_OK;
 }
 
@@ -1069,6 +1083,20 @@ int wk_tune(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "tally_slots")) {
         if (value < 256 || value > 4096 || (value & (value - 1))) return fail(c, WK_E_ARG, "tally_slots must be a power of two in [256, 4096]");
         c->tally_slots = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "dtok_fused")) {
+        if (value != 0 && value != 1) return fail(c, WK_E_ARG, "dtok_fused must be 0 or 1");
+        c->use_fused = (int)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "fz_ablate")) {
+        c->fused_ablate = (uint32_t)value;
+        return WK_OK;
+    }
+    if (!strcmp(name, "dtok_fused_per_cu")) {
+        if (value < 1 || value > 8) return fail(c, WK_E_ARG, "dtok_fused_per_cu must be in [1, 8]");
+        c->fused_per_cu = (int)value;
         return WK_OK;
     }
     if (!strcmp(name, "stripes_min")) {
@@ -2562,6 +2590,25 @@ static int dtok_mirror_dict(wk_ctx* c, const wk_tok* tok) {
     int rc;
     if ((rc = upload(c, c->d_dict, tab.data(), tab.size() * sizeof(DictSlot)))) return rc;
     if ((rc = upload(c, c->d_arena, arena.data(), arena.size()))) return rc;
+    // (the same table for dtok_fused_kernel: 8-byte slots, the names by id)
+    std::vector<DictSlot8> tab8(slots, DictSlot8{0u, -1});
+    std::vector<unsigned char> names16((size_t)std::max(n, 1) * 16, 0);
+    for (uint32_t h = 0; h < slots; ++h) {
+        if (tab[h].id < 0) continue;
+        tab8[h] = DictSlot8{(uint32_t)(tab[h].hash >> 32), tab[h].id};
+        uint32_t len;
+        std::memcpy(&len, arena.data() + tab[h].off, 4);
+        unsigned char* rec = names16.data() + (size_t)tab[h].id * 16;
+        if (len <= 15) {
+            std::memcpy(rec, arena.data() + tab[h].off + 4, len);
+            rec[15] = (unsigned char)len;
+        } else {
+            std::memcpy(rec, &tab[h].off, 4);
+            rec[15] = 0xFF;
+        }
+    }
+    if ((rc = upload(c, c->d_dict2, tab8.data(), tab8.size() * sizeof(DictSlot8)))) return rc;
+    if ((rc = upload(c, c->d_names16, names16.data(), names16.size()))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->dt_dict_mask = slots - 1;
     c->dt_dict_names = n;
@@ -2678,11 +2725,12 @@ static int dtok_copy_impl(wk_ctx* c, const char* text, int64_t begin, int64_t st
     // ... and, behind the copy, the count of the block's newlines -- on a stream of its own, so that the next
     // block's copy follows this one without a gap; the total lands in pinned memory (written by the kernel: no
     // trip through the DMA queue): wk_dtok_scan finds the number on the host instead of waiting for it
-    {
+    HIP_TRY(c, hipStreamWaitEvent(c->count_stream, c->copy_evm[k], 0));
+    c->copy_counted[k] = false;
+    if (!c->fused_streak) {  // (blocks that go through the one kernel need no count: wk_dtok_fused.hpp)
         const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
         HIP_TRY(c, c->d_tiles_k[k].reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off_k[k].reserve((size_t)n_tiles * 8));
-        HIP_TRY(c, hipStreamWaitEvent(c->count_stream, c->copy_evm[k], 0));
         hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->count_stream, c->d_textptr[k], n,
                            c->d_tiles_k[k].as<unsigned long long>());
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->count_stream, c->d_tiles_k[k].as<unsigned long long>(),
@@ -2869,6 +2917,14 @@ int wk_h2d_rate(wk_ctx* c, int64_t bytes, int reps, double* bytes_per_s) {
     return WK_OK;
 }
 
+// (measurement) blocks of the text route the fused kernel did / handed back to the six kernels since the context exists
+int wk_dtok_fused_counts(wk_ctx* c, int64_t* done, int64_t* handed_back) {
+    if (!c || !done || !handed_back) return WK_E_ARG;
+    *done = c->fused_blocks;
+    *handed_back = c->fused_fallbacks;
+    return WK_OK;
+}
+
 int wk_text_clear(wk_ctx* c) {
     if (!c) return WK_E_ARG;
     DeviceGuard guard(c->device);
@@ -2929,7 +2985,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             resident = r.dev;
             res = &r;
         }
-    bool counted = false;
+    bool counted = false, counted_or_ahead = false;
     auto lap_t = std::chrono::steady_clock::now();
     auto lap_mark = [&](int i) {
         const auto now = std::chrono::steady_clock::now();
@@ -2957,6 +3013,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             k = -1 - k;  // (marks "copy now")
         } else if (!resident) {
             counted = c->copy_counted[k];
+            counted_or_ahead = true;
         }
         c->dt_detached = !resident && k >= 0 && c->copy_detached[k];
         if (!resident) {
@@ -2981,20 +3038,46 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     // line starts: newlines per tile -> offsets -> positions
     const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
     HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
+    // (one kernel for the block, wk_dtok_fused.hpp: decided here, the words' mode checked again below)
+    const bool fuse = emit && !extra && c->use_fused && c->dt_fmt == WK_FMT_SAM && c->w_open && c->w_mode == 0 && !c->dt_keep_reads &&
+                      wkx_tok_n_names(tok) < (1 << 23) - 1;
+    // The six kernels need the block's newlines per tile before anything else; the one kernel counts its lines itself.
+    // A block copied ahead while blocks went through the one kernel (`fused_streak`) was not counted behind its copy:
+    // it is counted here only if it turns out to need the six kernels after all -- or if the sample's record buffers
+    // are still to be sized from its lines per byte (wk_dtok_expect).
+    const bool ahead = !resident && counted_or_ahead;
     KernelTimer* kt = ktimer_begin(c, "dtok_lines");
     unsigned long long n_newlines = 0;
     const unsigned long long* tile_off = nullptr;
-    if (res) {
-        // (the product counts a block's newlines behind its copy and never waits for them; here the
-        // same two kernels run in front of the scan, their result was taken at upload)
+    bool have_count = false;
+    auto count_now = [&]() -> int {
         HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
         hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
                            c->d_tiles.as<unsigned long long>());
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
                            c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+        HIP_TRY(c, hipMemcpyAsync(&n_newlines, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        tile_off = c->d_tile_off.as<unsigned long long>();
+        have_count = true;
+        return WK_OK;
+    };
+    const bool want_count = !fuse || (c->dt_expect_bytes > 0 && c->w_expect == 0);
+    if (res) {
+        // (the product counts a block's newlines behind its copy -- when the block is to take the six kernels -- and
+        // never waits for them; here the same two kernels run in front of the scan, their result was taken at upload)
+        if (!fuse) {
+            HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
+            HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
+            hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
+                               c->d_tiles.as<unsigned long long>());
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
+                               c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
+        }
         n_newlines = res->n_newlines;
         tile_off = res->tile_off;
+        have_count = true;
     } else if (counted) {  // (counted behind the copy: the number is on the host once the copy's event has passed)
         {
             Lap wait(&c->lap_s[3]);
@@ -3011,21 +3094,100 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         }
         n_newlines = c->copy_newlines[k];
         tile_off = c->d_tile_off_k[k].as<unsigned long long>();
-    } else {
-        HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
-        HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
-        hipLaunchKernelGGL(dtok_count_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
-                           c->d_tiles.as<unsigned long long>());
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tiles.as<unsigned long long>(),
-                           c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
-        HIP_TRY(c, hipMemcpyAsync(&n_newlines, scalar_u64(c, 3), 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        tile_off = c->d_tile_off.as<unsigned long long>();
+        have_count = true;
+    } else if (want_count) {
+        const int rc = count_now();
+        if (rc) return rc;
     }
     // a last line without newline (the byte was noted when the block was copied ahead: the host bytes of such a
     // block may be gone)
-    const bool open_end = (!resident && counted ? c->copy_last[k] : src[n - 1]) != '\n';
-    const uint32_t lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
+    const bool open_end = (ahead ? c->copy_last[k] : src[n - 1]) != '\n';
+    // (not counted: no more lines than bytes / 7 -- a mapped record is "q\tf\tr\t\n" at least -- and, once the
+    // sample has shown its lines per byte, a quarter more than that; the kernel reports records that find no room)
+    uint32_t lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
+    if (!have_count) {
+        double est = (double)n / 7.0 + 1.0;
+        if (c->dt_lpb > 0.0) est = std::min(est, (double)n * c->dt_lpb * 1.25 + 65536.0);
+        lines = (uint32_t)est;
+    }
+    if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
+    // The usual block of a sample whose words are open -- SAM text, records for the weighted histogram, every subject
+    // known -- goes through ONE kernel (wk_dtok_fused.hpp).  A block it hands back (a subject the dictionary does not
+    // hold, a line for the host tokenizer, a run or a line beyond its window) leaves the streams as they were and
+    // takes the six kernels below.
+    if (fuse) {
+        c->dt_lines = lines;
+        int rc = dtok_mirror_dict(c, tok);
+        if (rc) return rc;
+        if (c->dt_expect_bytes > 0 && c->w_expect == 0) {   // (have_count: see want_count)
+            const double expect = (double)c->dt_expect_bytes * ((double)lines / (double)n) * 1.08 + (double)lines;
+            c->w_expect = (int64_t)std::min(expect, (double)(1ll << 30));
+        }
+        if ((rc = words_roll(c, lines))) return rc;
+        if ((rc = words_room(c, lines))) return rc;
+        FusedArgs fa{};
+        fa.streams = stream_set(c);
+        if (c->w_mode == 0 && fa.streams.n_streams <= kFzStreams) {   // (words_roll may have reopened the job set)
+            fa.text = c->dt_text;
+            fa.n = n;
+            fa.open_end = open_end ? 1u : 0u;
+            fa.n_tiles = (n + kFzTile - 1) / kFzTile;
+            fa.dict8 = c->d_dict2.as<DictSlot8>();
+            fa.names16 = c->d_names16.as<uint4>();
+            fa.dict_mask = c->dt_dict_mask;
+            fa.arena = c->d_arena.as<unsigned char>();
+            fa.unknown = c->d_unknown.as<uint2>();
+            fa.unknown_cap = (uint32_t)(c->d_unknown.cap / 8);
+            fa.state = c->d_state.as<DtokState>();
+            fa.ablate = c->fused_ablate;
+            c->w_counts_known = false;
+            HIP_TRY(c, c->w_backup.reserve(kMaxStreams * 8));
+            if (res) ktimer_end(c, kt);   // (the count behind a resident block's "copy": its own family)
+            KernelTimer* kf = ktimer_begin(c, "dtok_fused");
+            hipLaunchKernelGGL(dtok_fused_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->w_backup.as<unsigned long long>(),
+                               (const unsigned long long*)fa.streams.cursor, fa.state);
+            const unsigned grid = std::min<unsigned>(fa.n_tiles, (unsigned)(c->prop.multiProcessorCount * c->fused_per_cu));
+            hipLaunchKernelGGL(dtok_fused_kernel, dim3(grid), dim3(kFzThreads), 0, c->stream, fa);
+            ktimer_end(c, kf);
+            HIP_TRY(c, hipGetLastError());
+            lap_mark(2);
+            DtokState st{};
+            HIP_TRY(c, small_back(c, 0, c->d_state.p, sizeof st));
+            {
+                Lap wait(&c->lap_s[2]);
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+            small_back_get(c, 0, &st, sizeof st);
+            lap_t = std::chrono::steady_clock::now();
+            const bool keep = st.flags == 0 && st.n_unknown == 0;
+            int64_t nr = 0, nrec = 0;
+            c->dt_emitted = false;
+            if ((rc = dtok_emit_finish(c, keep, false, st, 0, &nr, &nrec))) return rc;   // (not kept: the cursors go back)
+            lap_mark(4);
+            c->fused_streak = keep;
+            if (keep) {
+                ++c->fused_blocks;
+                lines = (uint32_t)st.n_lines + (open_end ? 1u : 0u);
+                c->dt_lines = lines;
+                c->dt_lpb = (double)lines / (double)n;
+                *status = 0;
+                *n_lines = lines;
+                *emit = 1;
+                emitted[0] = nr;
+                emitted[1] = nrec;
+                c->dt_ready = false;
+                return WK_OK;
+            }
+            ++c->fused_fallbacks;
+            kt = ktimer_begin(c, "dtok_lines");
+        }
+    }
+    if (!have_count) {  // (the six kernels after all)
+        const int rc = count_now();
+        if (rc) return rc;
+        lines = (uint32_t)n_newlines + (open_end ? 1u : 0u);
+    }
+    c->fused_streak = false;
     // (sized for a full block of short lines from the first block on: a file's first blocks are small, and
     // every growth is a hipFree -- which waits for the device -- and a hipMalloc per array)
     const size_t cap_lines = std::max<size_t>(lines, (size_t)1 << 21);
@@ -3040,7 +3202,6 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         HIP_TRY(c, c->d_llen.reserve((cap_lines + 1) * 4));
         HIP_TRY(c, c->d_lscan.reserve((cap_lines + 1) * 8));
     }
-    if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
     // (line 0 and the block's scalars are written by the lines kernel itself)
     hipLaunchKernelGGL(dtok_lines_kernel, dim3(n_tiles), dim3(kDtokThreads), 0, c->stream, c->dt_text, n,
                        tile_off, c->d_lines.as<uint32_t>(), c->d_state.as<DtokState>());

@@ -897,6 +897,12 @@ class DeviceTextRoute:
             ahead.close()
             if getattr(self.ctx, '_h', None):   # (still open)
                 self.ctx.dtok_expect(0)
+                # (blocks that went through the one-kernel tokenizer,
+                # csrc/wk_dtok_fused.hpp, and blocks it handed back)
+                fz = self.ctx.dtok_fused_counts()
+                ROUTES['dtok_fused'] += fz[0] - self._fused_seen[0]
+                ROUTES['dtok_fused_back'] += fz[1] - self._fused_seen[1]
+                self._fused_seen = fz
             if taken is not None:
                 os.close(taken.fd)
                 if taken.rd is not self._reader:
