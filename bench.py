@@ -1459,22 +1459,23 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
                 wait_closed()
                 if sync is not None:
                     sync.barrier()
-                t0 = time.perf_counter()
+                t0, c0 = time.perf_counter(), cpu_seconds()
                 try:
                     quiet(workflow.workflow, indir, out, input_fmt='sam',
                           output_fmt=False, device=device, **kw)
                     dt = time.perf_counter() - t0
                 except Exception as e:
                     failed, dt = e, inf
+                cpu, mine = cpu_seconds() - c0, dt
                 if sync is not None:
                     dt = sync.allmax(dt)
                 if dt == inf:
                     raise failed or RuntimeError('another rank failed')
                 if best is None or dt < best[0]:
-                    best = (dt, dict(ph.t))
+                    best = (dt, dict(ph.t), cpu, mine)
         finally:
             ph.close()
-        dt, parts = best
+        dt, parts, cpu, mine = best
         cold = None
         if sync is None:
             try:
@@ -1506,6 +1507,9 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
     return {'value': round(n_rec / dt, 1), 'unit': 'records/s',
             'records': n_rec, 'reads': n_reads, 'frac_of_config': frac,
             'text_bytes': n_bytes, 'seconds': round(dt, 3),
+            'seconds_this_rank': round(mine, 3),
+            'host_cpu_s': round(cpu, 3),
+            'host_cpu_s_per_gb': round(cpu / max(n_bytes / 1e9, 1e-9), 4),
             'cold_process_s': cold,
             'value_cold_process': round(n_rec / cold, 1)
             if isinstance(cold, float) else None,
@@ -1525,6 +1529,13 @@ def e2e_leg(kind, prob, reads, device, frac=1.0, workdir=None, reps=3,
                      f'to written tables, SAM text in the page cache: {what}; '
                      'everything inside `seconds` (best of '
                      f'{reps} runs)')}
+
+
+def cpu_seconds():
+    """User + system CPU seconds of this process (all its threads)."""
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)
+    return r.ru_utime + r.ru_stime
 
 
 H2D = {}
@@ -1581,11 +1592,11 @@ def e2e_kind(kind, device, workdir=None, reads=0, reps=3, prob=None):
                 if os.path.isdir(out):
                     shutil.rmtree(out)
                 wait_closed()
-                t0 = time.perf_counter()
+                t0, c0 = time.perf_counter(), cpu_seconds()
                 quiet(workflow.workflow, device=device, **kw)
-                dt = time.perf_counter() - t0
+                dt, cpu = time.perf_counter() - t0, cpu_seconds() - c0
                 if best is None or dt < best[0]:
-                    best = (dt, dict(ph.t))
+                    best = (dt, dict(ph.t), cpu)
         finally:
             ph.close()
         out = kw['output_fp']
@@ -1597,10 +1608,12 @@ def e2e_kind(kind, device, workdir=None, reads=0, reps=3, prob=None):
             with open(fp, 'rb') as f:
                 digest[os.path.basename(fp)] = hashlib.sha256(
                     f.read()).hexdigest()[:16]
-    dt, parts = best
+    dt, parts, cpu = best
     leg = {'value': round(meta['records'] / dt, 1), 'unit': 'records/s',
            'records': meta['records'], 'reads': meta['reads'],
            'text_bytes': meta['text_bytes'], 'seconds': round(dt, 3),
+           'host_cpu_s': round(cpu, 3),
+           'host_cpu_s_per_gb': round(cpu / max(meta['text_bytes'] / 1e9, 1e-9), 4),
            'phases_s': {k: round(v, 3) for k, v in sorted(parts.items())},
            'text_generated_s': round(t_gen, 1), 'tables_sha256_16': digest}
     if 'gz_bytes' in meta:
@@ -2044,6 +2057,7 @@ def run_rank(a, rank, world, local, sync):
                    'sharding': f'samples x {world} ranks on {n_distinct} '
                                'GPU(s), no collective'},
         'roofline': block['roofline'],
+        'roofline_step': block['roofline_step'],
         'device': ctx.device_name,
         'checksum': checksum,
     }
@@ -2251,12 +2265,33 @@ def e2e_ranks(a, line, wl, dev, world, sync):
         err = 0.0
     except Exception as e:
         leg, err = {'error': repr(e)}, 1.0
-    if sync.allmax(err) > 0:
+    failed = sync.allmax(err) > 0
+    # what each rank saw, so that a flat curve can be attributed: its own wall
+    # time for the call, the CPU seconds its process spent (reader, tokenizer
+    # threads, hierarchy), and the host -> device rate of its link with all
+    # ranks copying at once
+    mine = (leg.get('seconds_this_rank', 0.0), leg.get('host_cpu_s', 0.0))
+    per = {'seconds': sync.gather(mine[0]), 'host_cpu_s': sync.gather(mine[1])}
+    try:
+        sync.barrier()
+        rate = h2d_peak(dev) / 1e9
+    except Exception:       # noqa: BLE001 - a side figure
+        rate = 0.0
+    per['h2d_GBps_all_ranks_copying'] = [round(x, 1)
+                                         for x in sync.gather(rate)]
+    if failed:
         leg = leg if 'error' in leg else {'error': 'another rank failed'}
     elif line is not None:
         leg['value_per_rank'] = leg['value']
         leg['value'] = round(leg['value'] * world, 1)
         leg['ranks'] = world
+        leg['per_rank'] = per
+        try:
+            import psutil
+            leg['host'] = {'cpus_usable': len(os.sched_getaffinity(0)),
+                           'cpus': psutil.cpu_count()}
+        except Exception:   # noqa: BLE001
+            pass
     if line is not None:
         line['e2e'] = {'lca': leg}
         line['e2e_value'] = leg.get('value')
@@ -2365,6 +2400,87 @@ def parse_args(argv=None):
     return a
 
 
+def summarise(line):
+    """The figures the driver's record must not lose, inside `config` (which it
+    keeps): every configuration's pass and whole-step roofline, every
+    end-to-end leg's seconds / records per second / fraction of the measured
+    host link / host CPU seconds per GB."""
+    cfg = line.get('config', {})
+    dev = {}
+    for key, b in (line.get('configs') or {}).items():
+        if 'error' in b:
+            dev[key] = {'error': b['error'][:80]}
+            continue
+        d = {'ms_per_pass': b.get('ms_per_pass'),
+             'kernel': b.get('roofline', {}).get('kernel'),
+             'frac': b.get('roofline', {}).get('frac'),
+             'frac_step': b.get('roofline_step', {}).get('frac')}
+        if 'ms_per_pass_with_sort' in b:
+            d['ms_per_pass_with_sort'] = b['ms_per_pass_with_sort']
+            d['frac_step_with_sort'] = b.get(
+                'roofline_step_with_sort', {}).get('frac')
+        dev[key] = d
+    if dev:
+        cfg['device_side'] = dev
+    legs = {}
+
+    def leg_of(x):
+        if 'error' in x:
+            return {'error': x['error'][:80]}
+        d = {'s': x.get('seconds'),
+             'M_rec_per_s': round(x['value'] / 1e6, 1) if x.get('value')
+             else None,
+             'frac_h2d': x.get('roofline', {}).get('frac'),
+             'cpu_s_per_gb': x.get('host_cpu_s_per_gb')}
+        for k in ('cold_process_s', 'ranks', 'per_rank', 'host'):
+            if x.get(k) is not None:
+                d[k] = x[k]
+        return d
+    for key, x in (line.get('e2e') or {}).items():
+        if key == 'twopass' and 'error' not in x:
+            for k2 in ('pass1', 'pass2'):
+                if k2 in x:
+                    legs[f'twopass.{k2}'] = leg_of(x[k2])
+        else:
+            legs[key] = leg_of(x)
+    if legs:
+        cfg['e2e'] = legs
+        cfg['e2e_note'] = ('whole `woltka classify` calls, file paths to '
+                           'written tables (PCIe inclusive); `value` above is '
+                           'the device side only')
+    line['config'] = cfg
+    return line
+
+
+COMPACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'ranks', 'rank_devices',
+                'oversubscribed', 'steps', 'warmup', 'ms_per_step',
+                'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+                'config', 'roofline', 'roofline_step', 'cpu_baseline',
+                'e2e_value', 'e2e_ordinal_value', 'e2e_twopass_values',
+                'device', 'checksum', 'cells_equal_words_route')
+
+
+def emit(line):
+    """The long line (every block in full) to stderr and, when
+    WOLTKA_BENCH_FULL names a file, there; ONE compact line -- the contract's
+    keys, `config` with the summaries, `roofline`, `cpu_baseline` -- to
+    stdout, last, where a tail cannot cut it."""
+    line = summarise(line)
+    full = json.dumps(line)
+    fp = os.environ.get('WOLTKA_BENCH_FULL')
+    if fp:
+        with open(fp, 'w') as f:
+            f.write(full + '\n')
+    print(full, file=sys.stderr, flush=True)
+    compact = {k: line[k] for k in COMPACT_KEYS if k in line}
+    cb = compact.get('cpu_baseline')
+    if isinstance(cb, dict):
+        compact['cpu_baseline'] = {
+            k: (v if not isinstance(v, str) else v[:160])
+            for k, v in cb.items() if not isinstance(v, dict)}
+    print(json.dumps(compact), flush=True)
+
+
 def main():
     a = parse_args()
     if 'WORLD_SIZE' in os.environ:      # launched by torch.distributed.run
@@ -2379,7 +2495,7 @@ def main():
     else:
         line = run_rank(a, 0, 1, 0, NoSync())
     if line is not None:
-        print(json.dumps(line))
+        emit(line)
 
 
 if __name__ == '__main__':

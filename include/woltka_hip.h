@@ -541,6 +541,20 @@ int wk_tok_set_header_state(wk_tok* tok, int in_header);
  * all tokenizer threads (pread on slices); short only at the end of the file. */
 int wk_tok_read(wk_tok* tok, int fd, int64_t offset, char* dst, int64_t len,
                 int64_t* got);
+/* The column trim between the page cache and pinned memory: SAM text
+ * [begin, begin + want) -- begin a line start -- of src (memory all threads
+ * see, e.g. the mapped file) or, src NULL, of the open file fd, which the
+ * threads read piece by piece (src_len: the length of either), with every line
+ * cut behind its tab number keep_tabs (3:
+ * QNAME, FLAG, RNAME, all `line.split('\t', 3)` looks at, align.py:313; 6 for the
+ * coord-match, align.py:376; doc/perform.md:122-128 asks the user to do this
+ * beforehand), written to dst by all tokenizer threads.  Lines of fewer tabs and
+ * lines that hold a carriage return leave whole.  Whole lines only: *consumed =
+ * input bytes taken (short when the range ends inside a line, unless it ends src;
+ * or when `cap` is reached), *got = bytes written. */
+int wk_tok_trim(wk_tok* tok, const char* src, int fd, int64_t src_len,
+                int64_t begin, int64_t want, int keep_tabs, char* dst,
+                int64_t cap, int64_t* consumed, int64_t* got);
 /* Translate subject indices on their way out (wk_tok_fetch's `subj`):
  * subj[i] = map[dictionary id], -1 for ids >= n.  The coord-match stages genome
  * indices of the gene tables (wk_ordinal_stage), which the host derives from the

@@ -365,3 +365,94 @@ def test_blocks_left_to_the_host_tokenizer_add_up_to_the_file(tmp_path, seed):
     finally:
         pool.shutdown(wait=True)
         rd.close()
+
+
+def _trimmed(text, keep):
+    """What csrc/wk_trim.inc makes of SAM text: lines of at least ``keep``
+    tabs (and no carriage return) cut behind tab number ``keep``."""
+    out = []
+    for ln in text.split(b'\n')[:-1] if text.endswith(b'\n') \
+            else text.split(b'\n'):
+        if b'\r' in ln or ln.count(b'\t') < keep:
+            out.append(ln)
+        else:
+            out.append(b'\t'.join(ln.split(b'\t', keep)[:keep]) + b'\t')
+    return b'\n'.join(out) + (b'\n' if text.endswith(b'\n') else b'')
+
+
+def _seqqual_text(n_queries, rng, newline_at_end=True, long_run_at=None):
+    lines = ['@HD\tVN:1.0', '@SQ\tSN:x\tLN:5\tM5:abc\tUR:file', '@PG\tID:t']
+    for q in range(n_queries):
+        k = 1 + q % 5
+        if q == long_run_at:
+            k = 400
+        for i in range(k):
+            n = rng.choice([20, 150, 251])
+            tail = '\t'.join(['*', '0', '0', 'ACGT' * (n // 4), 'F' * n,
+                              'AS:i:-3'])
+            if rng.random() < 0.02:
+                lines.append(f'read{q:05d}\t4\t*\t0\t0\t*\t{tail}')
+            if rng.random() < 0.01:
+                tail = tail.replace('ACGT', 'AC\rGT', 1)
+            lines.append(f'read{q:05d}\t{rng.choice([0, 16, 99, 147])}\t'
+                         f'S{(q * 7 + i) % 31}\t{1 + i}\t42\t{n}M\t{tail}')
+    return ('\n'.join(lines) + ('\n' if newline_at_end else '')).encode()
+
+
+@pytest.mark.parametrize('block', [1 << 12, 1 << 14, 1 << 20])
+@pytest.mark.parametrize('extra', [False, True])
+@pytest.mark.parametrize('newline_at_end', [True, False])
+def test_trimmed_blocks_are_the_trimmed_file(tmp_path, block, extra,
+                                             newline_at_end):
+    """`_trim_blocks`: what the blocks hold is the file with every line cut
+    behind RNAME (CIGAR for the coord-match) -- lines with a carriage return
+    and lines of fewer fields whole --, blocks end where a run of equal query
+    names starts, and a run longer than the headroom hands the rest of the file
+    to the plain reader (whose blocks hold the lines as they are)."""
+    import random
+    rng = random.Random(block + extra)
+    text = _seqqual_text(1500, rng, newline_at_end,
+                         long_run_at=900 if block == 1 << 12 else None)
+    fp = tmp_path / 'a.sam'
+    fp.write_bytes(text)
+    ctx = FakeContext()
+    H = 1 << 12
+    ring = StageRing(ctx, 4, {'text': (np.uint8, block + H)})
+    pool = ThreadPoolExecutor(max_workers=3)
+    rd = nat.Tokenizer(3)
+    fd = os.open(fp, os.O_RDONLY)
+    lap = {'read': 0.0, 'span': 0.0}
+
+    class Flag:
+        warm = True
+    keep = 6 if extra else 3
+    got, plain_from = [], None
+    try:
+        n = 0
+        for item in D._trim_blocks(ring, pool, rd, fd, len(text), 'sam', Flag,
+                                   lap, block, H, 1 << 10, extra=extra):
+            slot, out, fill, begin, stop, first, final, hdr_in, hdr = item
+            piece = bytes(out[:stop]) if not final else bytes(out[:fill])
+            got.append(piece)
+            assert first == (n == 0)
+            n += 1
+            if slot is not None:
+                ring.release(slot)
+        assert final
+    finally:
+        pool.shutdown(wait=True)
+        rd.close()
+        os.close(fd)
+    whole = b''.join(got)
+    want = _trimmed(text, keep)
+    if block == 1 << 12:
+        # up to the hand-over the trimmed text, behind it the lines as they are
+        common = os.path.commonprefix([whole, want])
+        at = common.rfind(b'\n') + 1
+        rest = whole[at:]
+        assert text.endswith(rest) and len(rest) > 0
+        assert _trimmed(rest, keep) == want[at:]
+    else:
+        assert whole == want
+    assert n > 1
+    assert ring._free.qsize() + (ring._cur is not None) == 4

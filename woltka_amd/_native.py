@@ -51,7 +51,7 @@ SYMBOLS = (
     'wk_tok_set_exclude', 'wk_tok_sam_tail', 'wk_tok_sam', 'wk_tok_text',
     'wk_tok_boundary',
     'wk_tok_fetch', 'wk_tok_fetch_packed', 'wk_tok_set_subject_map',
-    'wk_tok_read', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
+    'wk_tok_read', 'wk_tok_trim', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
     'wk_dtok_format',
     'wk_dtok_copy', 'wk_dtok_copy_ahead', 'wk_dtok_copy_wait',
     'wk_dtok_copy_drop', 'wk_dtok_ahead_room', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
@@ -185,6 +185,9 @@ def load_library():
         'wk_tok_set_subject_map': (C.c_int, [p, i32p, C.c_int32]),
         'wk_tok_read': (C.c_int, [p, C.c_int, C.c_int64, C.c_void_p, C.c_int64,
                                   i64p]),
+        'wk_tok_trim': (C.c_int, [p, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                                  C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                  i64p, i64p]),
         'wk_tok_sam_span': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       i64p, i64p, C.POINTER(C.c_int)]),
         'wk_tok_span': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64,
@@ -1077,6 +1080,27 @@ class Tokenizer:
             del raw
             mv.release()
         return got.value
+
+    def trim(self, src, begin, want, keep_tabs, dst, size=None):
+        """SAM text ``[begin, begin + want)`` (``begin`` a line start) of
+        ``src`` -- a uint8 array (the file, mapped) or an open file descriptor
+        with its ``size`` -- cut to its first ``keep_tabs`` columns into
+        ``dst`` by all tokenizer threads (``wk_tok_trim``).  Returns (input
+        bytes taken, bytes written): whole lines only."""
+        raw = np.frombuffer(memoryview(dst), dtype=np.uint8)
+        consumed, got = C.c_int64(0), C.c_int64(0)
+        if isinstance(src, int):
+            mem, fd, n = None, src, int(size)
+        else:
+            mem, fd, n = C.c_void_p(src.ctypes.data), -1, int(src.size)
+        try:
+            self._check(self._lib.wk_tok_trim(
+                self._h, mem, fd, n, int(begin), int(want), int(keep_tabs),
+                C.c_void_p(raw.ctypes.data), int(raw.size), C.byref(consumed),
+                C.byref(got)))
+        finally:
+            del raw
+        return consumed.value, got.value
 
     def set_subject_map(self, table):
         """Translate subject ids at fetch time: ``subj`` comes out as

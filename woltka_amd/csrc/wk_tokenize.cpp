@@ -666,6 +666,22 @@ namespace {
 #undef WK_SCAN_NAME
 #undef WK_SCAN_ATTR
 
+// the column trim of SAM text (wk_trim.inc), one per instruction set
+#define WK_TRIM_W 16
+#define WK_TRIM_NAME trim_sam_sse2
+#define WK_TRIM_ATTR
+#include "wk_trim.inc"
+#undef WK_TRIM_W
+#undef WK_TRIM_NAME
+#undef WK_TRIM_ATTR
+#define WK_TRIM_W 32
+#define WK_TRIM_NAME trim_sam_avx2
+#define WK_TRIM_ATTR __attribute__((target("avx2")))
+#include "wk_trim.inc"
+#undef WK_TRIM_W
+#undef WK_TRIM_NAME
+#undef WK_TRIM_ATTR
+
 // Lines of any format through the memchr parsers (parse_row): what the vector
 // scanner leaves over at the end of a range, and every format but SAM.
 int produce_rows(int fmt, const char*& pos, const char* e, bool extra, const FastDict& dict, Line* out, int max) {
@@ -1182,12 +1198,18 @@ int wk_tok_text(wk_tok* t, int fmt, const char* buf, int64_t len, int first_bloc
     lap(LAP_TOKENIZE);
     for (int i = 0; i < T; ++i)
         if (loc[i].error) {
-            char msg[160];
+            // (the line is named by its query: where it lies in the block says nothing to the user, and differs
+            // with the way the blocks are cut and trimmed)
+            const char* ln = buf + loc[i].error_at;
+            const char* le = buf + len;
+            int qn = 0;
+            while (ln + qn < le && qn < 80 && ln[qn] != '\t' && ln[qn] != '\n') ++qn;
+            char msg[240];
             snprintf(msg, sizeof msg,
-                     loc[i].error == 1   ? "SAM flag with both mate bits set at byte %zu"
-                     : loc[i].error == 3 ? "coordinate wider than 32 bits at byte %zu"
-                                         : "malformed alignment line at byte %zu",
-                     loc[i].error_at);
+                     loc[i].error == 1   ? "SAM flag with both mate bits set in a line of query '%.*s'"
+                     : loc[i].error == 3 ? "coordinate wider than 32 bits in a line of query '%.*s'"
+                                         : "malformed alignment line of query '%.*s'",
+                     qn, ln);
             t->err = msg;
             t->n_loc = 0;
             t->tot_reads = t->tot_rec = t->tot_big = 0;
@@ -1371,6 +1393,138 @@ int wk_tok_read(wk_tok* t, int fd, int64_t offset, char* dst, int64_t len, int64
     }
     *got = total;
     return WK_OK;
+}
+
+// SAM text [begin, begin + want) of a source -- `begin` a line start; the source: memory all threads see (a mapped
+// file) or an open file, read by the threads piece by piece (pread into a buffer of a piece's size that stays in the
+// thread's cache: no page of the file is mapped, and the bytes cross the memory bus once) -- trimmed to its first
+// `keep` columns (wk_trim.inc) into dst by all tokenizer threads: pieces of 1 MB, each trimmed into its thread's
+// scratch (a tenth of the piece, as a rule) and copied to its place behind the piece before it, whose length it waits
+// for -- not for its copy.  Whole lines only: *consumed = bytes of input taken (up to the start of the first line
+// without a newline in the range, or -- the source ends with the range -- all of it), *got = bytes written.  A piece
+// that would pass `cap` ends the call early the same way.
+static int trim_pieces(wk_tok* t, const char* mem, int fd, int64_t src_len, int64_t begin, int64_t want, int keep_tabs, char* dst, int64_t cap,
+                       int64_t* consumed, int64_t* got) {
+    *consumed = *got = 0;
+    if (want == 0) return WK_OK;
+    typedef size_t (*trim_fn)(const char*, const char*, const char*, int, bool, char*, const char*, const char**, bool*);
+    static const trim_fn trim = __builtin_cpu_supports("avx2") ? trim_sam_avx2 : trim_sam_sse2;
+    const int64_t piece = 1ll << 20;
+    const int n = (int)((want + piece - 1) / piece);
+    const int64_t limit = begin + want;   // (absolute positions from here on)
+    const bool at_eof = limit == src_len;
+    // off[j]: where piece j's bytes go (-1: not known yet, -2: no room for a piece before it)
+    std::vector<std::atomic<int64_t>> off((size_t)n + 1);
+    for (auto& x : off) x.store(-1, std::memory_order_relaxed);
+    off[0].store(0, std::memory_order_relaxed);
+    std::vector<int64_t> stop((size_t)n, 0);   // where piece j ended: the start of the first line it did not take
+    std::vector<char> done((size_t)n, 0);      // piece j took every line that starts in it
+    std::atomic<int> failed{0};
+    const std::function<void(int)> work = [&](int j) {
+        static thread_local std::vector<char> scratch, inbuf;
+        const int64_t pb = begin + (int64_t)j * piece, pe = std::min(limit, pb + piece);
+        // the bytes [lo, hi) at hand: all of a mapped source; of a file what was read (the piece, the byte in front
+        // of it and some more for the line that runs behind it; read again, larger, when that line is longer)
+        int64_t lo = mem ? begin : (j > 0 ? pb - 1 : pb), hi = mem ? limit : std::min(limit, pe + (64 << 10));
+        const char* base = mem ? mem + lo : nullptr;
+        auto read_window = [&]() -> bool {
+            if (mem) return true;
+            inbuf.resize((size_t)(hi - lo) + 64);
+            int64_t at = 0;
+            while (at < hi - lo) {
+                const ssize_t r = pread(fd, inbuf.data() + at, (size_t)(hi - lo - at), (off_t)(lo + at));
+                if (r <= 0) return false;
+                at += r;
+            }
+            base = inbuf.data();
+            return true;
+        };
+        if (!read_window()) {
+            failed.store(1);
+            hi = lo;
+        }
+        // the first line that starts in the piece
+        int64_t s = pb;
+        if (j > 0 && hi > lo) {
+            for (;;) {
+                const char* nl = (const char*)memchr(base + (pb - 1 - lo), '\n', (size_t)(hi - (pb - 1)));
+                if (nl) {
+                    s = lo + (nl - base) + 1;
+                    break;
+                }
+                if (hi >= limit) {
+                    s = limit;
+                    break;
+                }
+                hi = std::min(limit, hi + (hi - lo));   // (a line longer than the window: look further)
+                if (!read_window()) {
+                    failed.store(1);
+                    s = limit;
+                    break;
+                }
+            }
+        }
+        size_t len = 0;
+        int64_t next = s;
+        if (s < pe && hi > lo) {
+            if (scratch.size() < (size_t)piece + 4096) scratch.resize((size_t)piece + 4096);
+            for (;;) {
+                bool full = false;
+                const char* nx = nullptr;
+                // lines that start in [next, pe): each to its newline, wherever in front of `hi` that is
+                len += trim(base + (next - lo), base + (pe - lo), base + (hi - lo), keep_tabs, at_eof && hi == limit, scratch.data() + len,
+                            scratch.data() + scratch.size(), &nx, &full);
+                next = lo + (nx - base);
+                if (full) {  // (a line that leaves whole and is longer than the scratch: room for it)
+                    scratch.resize(scratch.size() * 2);
+                    continue;
+                }
+                if (next >= pe || hi >= limit) break;
+                hi = std::min(limit, hi + std::max<int64_t>(hi - lo, 1 << 20));   // (the line runs behind the window)
+                if (!read_window()) {
+                    failed.store(1);
+                    break;
+                }
+            }
+        }
+        stop[(size_t)j] = next;
+        done[(size_t)j] = (next >= pe || (at_eof && next >= limit)) ? 1 : 0;
+        // my place: behind the piece before me
+        int64_t at;
+        while ((at = off[(size_t)j].load(std::memory_order_acquire)) == -1) std::this_thread::yield();
+        if (at == -2 || at + (int64_t)len > cap) {
+            off[(size_t)j + 1].store(-2, std::memory_order_release);
+            return;
+        }
+        off[(size_t)j + 1].store(at + (int64_t)len, std::memory_order_release);
+        if (len) memcpy(dst + at, scratch.data(), len);
+    };
+    t->pool->run(n, work);
+    if (failed.load()) {
+        t->err = "reading the alignment file failed";
+        return WK_E_ARG;
+    }
+    // what was taken: pieces in order, up to the first that did not take all its lines (a line without newline in the
+    // range) or found no room
+    int64_t out_len = 0, upto = begin;
+    for (int j = 0; j < n; ++j) {
+        const int64_t nxt = off[(size_t)j + 1].load(std::memory_order_relaxed);
+        if (nxt == -2) break;  // no room for piece j (or one before it)
+        out_len = nxt;
+        upto = stop[(size_t)j];
+        if (!done[(size_t)j]) break;
+    }
+    *consumed = upto - begin;
+    *got = out_len;
+    return WK_OK;
+}
+
+int wk_tok_trim(wk_tok* t, const char* src, int fd, int64_t src_len, int64_t begin, int64_t want, int keep_tabs, char* dst, int64_t cap,
+                int64_t* consumed, int64_t* got) {
+    if (!t || (!src && fd < 0) || src_len < 0 || begin < 0 || want < 0 || begin + want > src_len || keep_tabs < 1 || keep_tabs > 32 || !dst ||
+        cap < 0 || !consumed || !got)
+        return WK_E_ARG;
+    return trim_pieces(t, src, fd, src_len, begin, want, keep_tabs, dst, cap, consumed, got);
 }
 
 int wk_tok_set_subject_map(wk_tok* t, const int32_t* map, int32_t n) {

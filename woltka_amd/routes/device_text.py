@@ -19,7 +19,7 @@ _HOSTREG_SLOW = {}     # st_dev -> pinning that file system's pages in place is 
 
 
 def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
-                  extra=False):
+                  extra=False, resume=None):
     """Blocks of a plain file for the device tokenizer: [slot, bytes, fill,
     begin, stop, first, final, header state in, header state out] per block,
     cut where the last run of equal query ids starts -- of the rows of the
@@ -55,6 +55,8 @@ def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
         return True
 
     carry, in_header, first = b'', True, True
+    if resume is not None:      # (`_trim_blocks` hands the rest of a file over)
+        state['next'], carry, in_header, first = resume
     # small blocks first while the dictionary is cold: a block's
     # unknown subjects are listed per record and interned on the host
     ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
@@ -62,6 +64,12 @@ def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
     try:
         while True:
             if not pending and not issue(min(span, block), True):
+                if carry:       # (a resumed reader with nothing left to read)
+                    out = np.frombuffer(carry, dtype=np.uint8)
+                    ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                        out, True, in_header, fmt, extra)
+                    yield None, out, out.size, begin, stop, first, True, \
+                        in_header, hdr
                 break
             while ramp is None and span <= block and len(pending) < 3 \
                     and issue(block, False):
@@ -121,6 +129,144 @@ def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
             for f in f2:
                 f.result()
             ring.release(s2)
+
+
+TRIM = not os.environ.get('WOLTKA_NO_TRIM')
+TRIM_MAPPED = bool(os.environ.get('WOLTKA_TRIM_MAPPED'))   # (measurement: scan the mapped file instead of reading it piece by piece)
+TRIM_SPAN_MAX = 1 << 30         # bytes of a file trimmed into one block at most
+TRIM_MIN_GAIN = float(os.environ.get('WOLTKA_TRIM_MIN_GAIN', 0.5))  # lines that keep more than this of their bytes are copied whole: scanning short lines costs the CPUs more than the bytes saved cost the link (config 3's 42-byte lines: 0.47 s trimmed, 0.43 s whole)
+
+
+def _trim_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
+                 extra=False):
+    """`_pread_blocks` for SAM text with the column trim between the page
+    cache and the pinned block (csrc/wk_trim.inc): what goes into a slot, over
+    the link and through the device tokenizer is QNAME / FLAG / RNAME (and POS,
+    MAPQ, CIGAR with `extra`) of every line -- all that the parsers look at
+    (align.py:313, 376; the trimming doc/perform.md:122-128 asks the user for)
+    -- 25-45 bytes of a line that an aligner wrote a few hundred of.  A block
+    is what `block` bytes of *trimmed* text hold: the span of the file that goes
+    into one follows the ratio the blocks before it showed.  The same tuples as
+    `_pread_blocks`; anything out of the ordinary (a run longer than the
+    headroom, no run boundary in a span) hands the rest of the file to it."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    keep = 6 if extra else 3
+    src = fd
+    mm = None
+    if TRIM_MAPPED:
+        import mmap
+        mm = mmap.mmap(fd, size, flags=mmap.MAP_SHARED, prot=mmap.PROT_READ)
+        src = np.frombuffer(mm, dtype=np.uint8)
+    # (one block is trimmed at a time, by all of `rd`'s threads; the next
+    # one's trim is under way while this thread cuts and copies)
+    seq = ThreadPoolExecutor(max_workers=1)
+    pending = deque()
+    state = {'next': 0, 'ratio': 1.0, 'grow': 1, 'cpu': 0.0}
+
+    def task(mv, cap):
+        p0 = state['next']
+        if p0 >= size:
+            return p0, 0, 0
+        want = int(min(max(cap / max(state['ratio'], 0.02) * 0.9, cap),
+                       TRIM_SPAN_MAX) * state['grow'])
+        want = min(want, size - p0)
+        took, got = rd.trim(src, p0, want, keep, mv[H:H + cap], size=size)
+        if took:
+            state['next'] = p0 + took
+            state['ratio'] = 0.5 * (state['ratio'] + got / took)
+            state['grow'] = 1
+        elif p0 + want < size:
+            state['grow'] *= 2      # (no whole line, or no room: a wider span / the plain way)
+        return p0, took, got
+
+    def issue(cap, wait):
+        bufs = ring.current() if wait else ring.try_current()
+        if bufs is None:
+            return False
+        buf, slot = bufs['text'], ring.take()
+        mv = memoryview(buf).cast('B')
+        cap = min(cap, len(mv) - H)
+        pending.append((slot, buf, seq.submit(task, mv, cap)))
+        return True
+
+    carry, in_header, first = b'', True, True
+    ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
+    hand_over = None
+    try:
+        while True:
+            if not pending and not issue(ramp or block, True):
+                break
+            while ramp is None and len(pending) < 2 and issue(block, False):
+                pass
+            slot, buf, fut = pending.popleft()
+            t0 = time.perf_counter()
+            p0, took, got = fut.result()
+            lap['read'] += time.perf_counter() - t0
+            if p0 >= size and not carry:
+                ring.release(slot)
+                break
+            final = p0 + took >= size
+            if len(carry) > H or (took == 0 and not final):
+                # (a run longer than the headroom, a line longer than the
+                # span: the plain reader from here)
+                ring.release(slot)
+                hand_over = (p0, carry, in_header, first)
+                break
+            start = H - len(carry)
+            if carry:
+                memoryview(buf).cast('B')[start:H] = carry
+            out = buf[start:H + got]
+            fill = out.size
+            t0 = time.perf_counter()
+            ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                out, final, in_header, fmt, extra)
+            lap['span'] += time.perf_counter() - t0
+            if not ok and not final:    # no complete run in a whole block
+                ring.release(slot)
+                hand_over = (p0, carry, in_header, first)
+                break
+            if ramp is not None:
+                ramp = min(block, ramp * 4)
+                if ramp == block:
+                    tok.warm, ramp = True, None
+            carry = b'' if final else out[stop:].tobytes()
+            yield slot, out, fill, begin, stop, first, final, in_header, hdr
+            in_header, first = hdr, False
+            if final:
+                return
+            if took >= (1 << 20) and got > TRIM_MIN_GAIN * took:
+                # (lines that are short already: the rest of the file as it is)
+                hand_over = (p0 + took, carry, in_header, first)
+                break
+    finally:
+        while pending:
+            s2, _, f2 = pending.popleft()
+            try:
+                f2.result()
+            except Exception:   # noqa: BLE001 - already on its way out
+                pass
+            ring.release(s2)
+        seq.shutdown(wait=True)
+        if mm is not None:
+            del src
+            mm.close()
+    if hand_over is not None:
+        yield from _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap,
+                                 block, H, PIECE, extra=extra,
+                                 resume=hand_over)
+
+
+def text_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
+                extra=False):
+    """The blocks of a plain file for the device tokenizer: SAM text trimmed
+    to the columns the parsers read on its way into pinned memory
+    (`_trim_blocks`; WOLTKA_NO_TRIM=1: as it is), any other format as it is."""
+    if TRIM and fmt == 'sam':
+        return _trim_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H,
+                            PIECE, extra=extra)
+    return _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H,
+                         PIECE, extra=extra)
 
 
 class _BlockText:
@@ -306,11 +452,11 @@ def start_text_ahead(path, fmt, device, warm=True, extra=False):
             lap = {'wait': 0.0, 'copy': 0.0, 'scan': 0.0, 'rest': 0.0,
                    'read': 0.0, 'span': 0.0, 'blocks': 0}
             # (blocks as large as the ring's buffers take them)
-            gen = _pread_blocks(ring, pool, rd, fd, size, use_fmt,
-                                SimpleNamespace(warm=bool(warm)), lap,
-                                ring.layout['text'][1] - R.DTOK_HEADROOM,
-                                R.DTOK_HEADROOM, R.DTOK_READ_PIECE,
-                                extra=bool(extra))
+            gen = text_blocks(ring, pool, rd, fd, size, use_fmt,
+                              SimpleNamespace(warm=bool(warm)), lap,
+                              ring.layout['text'][1] - R.DTOK_HEADROOM,
+                              R.DTOK_HEADROOM, R.DTOK_READ_PIECE,
+                              extra=bool(extra))
             ahead = _TextAhead(ctx, gen, ring, R.DTOK_AHEAD, lap)
             ahead.fmt, ahead.pool, ahead.rd, ahead.fd = use_fmt, pool, rd, fd
             ahead.extra = bool(extra)
@@ -875,10 +1021,10 @@ class DeviceTextRoute:
                     from concurrent.futures import ThreadPoolExecutor
                     self._read_pool = ThreadPoolExecutor(
                         max_workers=max(2, tokenizer_threads() // 2))
-                gen = _pread_blocks(ring, self._read_pool, rd, fd, size,
-                                    self._dfmt, tok, lap, block,
-                                    self.DTOK_HEADROOM, self.DTOK_READ_PIECE,
-                                    extra=ordinal)
+                gen = text_blocks(ring, self._read_pool, rd, fd, size,
+                                  self._dfmt, tok, lap, block,
+                                  self.DTOK_HEADROOM, self.DTOK_READ_PIECE,
+                                  extra=ordinal)
             ahead = _TextAhead(self.ctx, gen, ring,
                                3 if whole is not None else self.DTOK_DEPTH,
                                lap)
