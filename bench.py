@@ -2167,9 +2167,10 @@ def side_blocks(a, line, wl, ctx, dev):
                         1, a.e2e_frac, workdir=a.tmp,
                         per_rank_bytes=95e9 if kind == 'lca_seqqual' else 14e9)
                     n = max(1000, int(wl.reads * frac))
-                    if kind == 'lca_seqqual':
-                        # (350 B per line: a fifth of the reads is 17 GB of text)
-                        n = min(n, max(1000, wl.reads // 5))
+                    # (lca_seqqual: 340 B per line, 85 GB of text for the
+                    # whole configuration -- all of it, memory permitting:
+                    # the call's fixed parts, the hierarchy first of all,
+                    # are a third of a second whatever the sample's size)
                     e2e[kind] = e2e_kind(kind, dev, a.tmp, reads=n,
                                          prob=wl.prob, **kw)
                     e2e[kind]['frac_of_config'] = frac

@@ -955,3 +955,69 @@ def test_trimmed_reader_gives_the_tables_of_the_untrimmed_one(
     h, log_h = _run(tmp_path, 'host', True, **kw)
     assert a == b == h
     assert log_a == log_b == log_h
+
+
+class _SeqComm:
+    """Ranks of one `--gpus N` run, one after the other in this process: what
+    rank r hands to `gather` is kept; rank 0, run last, gets all of it."""
+    kind = 'test'
+
+    def __init__(self, rank, world, store):
+        self.rank, self.local, self.world, self.store = rank, 0, world, store
+
+    def gather(self, obj):
+        self.store[self.rank] = obj
+        if self.rank:
+            return None
+        return [self.store[r] for r in range(self.world)]
+
+
+@pytest.mark.parametrize('fmt', ['sam', 'paf'])
+@pytest.mark.parametrize('ordinal', [False, True])
+def test_byte_range_parts_equal_whole_file(tmp_path, monkeypatch, fmt,
+                                           ordinal):
+    """One large file under `--gpus 3` (shard.FilePart: byte ranges cut where
+    runs of equal query ids start) -- every range goes through the DEVICE text
+    route, and the merged tables are those of the file read whole."""
+    from woltka_amd import classify as C
+    from woltka_amd import workflow
+    from woltka_amd.hostio import ROUTES
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', 1 << 17)
+    rng = random.Random(zlib.crc32(f'{fmt}{ordinal}'.encode()))
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    coords, sam = _random_coords_sam(rng, 12000)
+    if fmt == 'sam':
+        text = _with_seq_qual(sam, rng, crs=False)
+    else:
+        rows = []
+        for ln in sam.split('\n'):
+            c = ln.split('\t')
+            if len(c) < 6 or ln.startswith('@'):
+                continue
+            beg = int(c[3])
+            rows.append('\t'.join([c[0], '150', '0', '100', '+', c[2], '5000',
+                                   str(beg), str(beg + 100), '90', '100',
+                                   '42']))
+        text = '\n'.join(rows) + '\n'
+    fp = indir / f'S1.{fmt}'
+    fp.write_text(text)
+    assert fp.stat().st_size > (1 << 20)
+    kw = dict(input_fp=str(indir), input_fmt=fmt)
+    if ordinal:
+        cfp = tmp_path / 'coords.txt'
+        cfp.write_text(coords)
+        kw.update(coords_fp=str(cfp), overlap=60)
+    whole, log = _run(tmp_path, 'whole', False, **kw)
+    store, world = {}, 3
+    for rank in (2, 1, 0):
+        ROUTES.clear()
+        out = str(tmp_path / f'parts{rank}')
+        with contextlib.redirect_stdout(io.StringIO()):
+            workflow.workflow(output_fp=out, output_fmt=False,
+                              comm=_SeqComm(rank, world, store), **kw)
+        route = 'dhits' if ordinal else 'dtok'
+        assert ROUTES[route] > 1, (rank, dict(ROUTES))
+        assert ROUTES['host_block'] == 0, (rank, dict(ROUTES))
+    with open(out, 'rb') as f:
+        assert {'table': f.read()} == whole

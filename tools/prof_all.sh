@@ -6,7 +6,7 @@ tag=${1:-r03prof}; shift
 wls=${*:-"lca_text lca lca_free lca_above lca_major lca_uniq ordinal flat"}
 for wl in $wls; do
   case $wl in
-    lca_text) kern=dtok_first_emit ;;
+    lca_text) kern=dtok_fused_kernel ;;
     lca) kern=weigh_streams ;;
     lca_free|lca_above|lca_major|lca_uniq|lca_above3) kern=free_stream ;;
     ordinal) kern=stripe_match ;;

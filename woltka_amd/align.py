@@ -476,6 +476,28 @@ def _parallel_reader(stream, tok, part):
         return None
 
 
+def part_range(reader, part, fmt, extra):
+    """(fd, end, start) of the ``part``-th byte range of the regular file
+    ``reader`` = (fd, size) names: cut where `_blocks_mmap` cuts -- every
+    process finds the same places, where a new run of equal query ids starts
+    -- by looking at the file around the two cuts only."""
+    import mmap
+    from ._native import Tokenizer
+    fd, size = reader
+    i, n = part
+    mm = mmap.mmap(fd, size, access=mmap.ACCESS_READ)
+    try:
+        view = memoryview(mm)
+        try:
+            start = Tokenizer.boundary(view, size * i // n, fmt, extra)
+            end = Tokenizer.boundary(view, size * (i + 1) // n, fmt, extra)
+        finally:
+            view.release()
+    finally:
+        mm.close()
+    return fd, end, start
+
+
 def _blocks_pread(reader, tok, block_bytes, extra, want_names, want_groups,
                   want_samples, fmt, exclude, sink, start):
     """Tokenise a regular file block by block through buffers filled by all

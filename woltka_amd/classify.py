@@ -343,11 +343,17 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         if (words or device_ex or dmaps) and (
                 fmt in ('sam', 'b6o', 'paf') or (fmt == 'map' and
                                                  not ordinal)) and \
-                not exclude and part is None and \
+                not exclude and \
                 not os.environ.get('WOLTKA_NO_DTOK'):
-            from .align import _parallel_reader
+            from .align import _parallel_reader, part_range
             from .file import GunzipStream
             reader = _parallel_reader(stream, tok, None)
+            if part is not None:
+                # one of several byte ranges of a large plain file (`--gpus N`
+                # on a single file, shard.FilePart): the range's text through
+                # the device like a file that begins and ends there
+                reader = part_range(reader, part, fmt, bool(ordinal)) \
+                    if reader is not None else None
             if reader is None and isinstance(stream, GunzipStream):
                 # a gzip file inflated by this package's own decoder: its
                 # blocks go from the inflater's threads straight into the

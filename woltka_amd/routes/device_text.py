@@ -19,7 +19,7 @@ _HOSTREG_SLOW = {}     # st_dev -> pinning that file system's pages in place is 
 
 
 def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
-                  extra=False, resume=None):
+                  extra=False, resume=None, start=0):
     """Blocks of a plain file for the device tokenizer: [slot, bytes, fill,
     begin, stop, first, final, header state in, header state out] per block,
     cut where the last run of equal query ids starts -- of the rows of the
@@ -33,8 +33,11 @@ def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
     # one is cut; the unfinished last run of the block before (the
     # carry) is copied in front of them.
     from collections import deque
+    # (`start` .. `size`: a byte range of the file -- shard.FilePart, cut where
+    # runs of equal query ids start -- is read like a file that begins and
+    # ends there; only the file's own beginning can be inside header lines)
     pending = deque()       # (slot, buf, futures, want, file position)
-    state = {'next': 0}
+    state = {'next': start}
 
     def issue(span, wait):
         want = min(span, size - state['next'])
@@ -54,7 +57,7 @@ def _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
         state['next'] = p0 + want
         return True
 
-    carry, in_header, first = b'', True, True
+    carry, in_header, first = b'', start == 0, start == 0
     if resume is not None:      # (`_trim_blocks` hands the rest of a file over)
         state['next'], carry, in_header, first = resume
     # small blocks first while the dictionary is cold: a block's
@@ -138,7 +141,7 @@ TRIM_MIN_GAIN = float(os.environ.get('WOLTKA_TRIM_MIN_GAIN', 0.5))  # lines that
 
 
 def _trim_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
-                 extra=False):
+                 extra=False, start=0):
     """`_pread_blocks` for SAM text with the column trim between the page
     cache and the pinned block (csrc/wk_trim.inc): what goes into a slot, over
     the link and through the device tokenizer is QNAME / FLAG / RNAME (and POS,
@@ -156,13 +159,14 @@ def _trim_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
     mm = None
     if TRIM_MAPPED:
         import mmap
-        mm = mmap.mmap(fd, size, flags=mmap.MAP_SHARED, prot=mmap.PROT_READ)
+        mm = mmap.mmap(fd, os.fstat(fd).st_size, flags=mmap.MAP_SHARED,
+                       prot=mmap.PROT_READ)
         src = np.frombuffer(mm, dtype=np.uint8)
     # (one block is trimmed at a time, by all of `rd`'s threads; the next
     # one's trim is under way while this thread cuts and copies)
     seq = ThreadPoolExecutor(max_workers=1)
     pending = deque()
-    state = {'next': 0, 'ratio': 1.0, 'grow': 1, 'cpu': 0.0}
+    state = {'next': start, 'ratio': 1.0, 'grow': 1, 'cpu': 0.0}
 
     def task(mv, cap):
         p0 = state['next']
@@ -190,7 +194,7 @@ def _trim_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
         pending.append((slot, buf, seq.submit(task, mv, cap)))
         return True
 
-    carry, in_header, first = b'', True, True
+    carry, in_header, first = b'', start == 0, start == 0
     ramp = None if getattr(tok, 'warm', False) else min(block, 1 << 20)
     hand_over = None
     try:
@@ -258,15 +262,15 @@ def _trim_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
 
 
 def text_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H, PIECE,
-                extra=False):
+                extra=False, start=0):
     """The blocks of a plain file for the device tokenizer: SAM text trimmed
     to the columns the parsers read on its way into pinned memory
     (`_trim_blocks`; WOLTKA_NO_TRIM=1: as it is), any other format as it is."""
     if TRIM and fmt == 'sam':
         return _trim_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H,
-                            PIECE, extra=extra)
+                            PIECE, extra=extra, start=start)
     return _pread_blocks(ring, pool, rd, fd, size, fmt, tok, lap, block, H,
-                         PIECE, extra=extra)
+                         PIECE, extra=extra, start=start)
 
 
 class _BlockText:
@@ -674,8 +678,10 @@ class DeviceTextRoute:
         mate bits, reads of more than 16 subjects) are tokenised on the host
         as before.  Yields what `native_chunks` yields."""
         source = None               # a stream (inflated text) instead of a file
+        start = 0                   # (a byte range of a file: [start, size))
         if isinstance(reader, tuple):
-            fd, size = reader
+            fd, size = reader[:2]
+            start = reader[2] if len(reader) > 2 else 0
         else:
             source, fd, size = reader, -1, 0
         tok = self.tok
@@ -883,7 +889,8 @@ class DeviceTextRoute:
         def open_mapped():
             """The file as a pinned read-only array, or None (small file, no
             mapping, the runtime refuses: the pread route then)."""
-            if size < self.HOSTREG_MIN or os.environ.get('WOLTKA_NO_HOSTREG'):
+            if size < self.HOSTREG_MIN or start or \
+                    os.environ.get('WOLTKA_NO_HOSTREG'):
                 return None
             # (what the first file on a file system showed holds for the next:
             # the probe below pins and unpins 256 MB, ~40 ms on tmpfs)
@@ -1024,12 +1031,12 @@ class DeviceTextRoute:
                 gen = text_blocks(ring, self._read_pool, rd, fd, size,
                                   self._dfmt, tok, lap, block,
                                   self.DTOK_HEADROOM, self.DTOK_READ_PIECE,
-                                  extra=ordinal)
+                                  extra=ordinal, start=start)
             ahead = _TextAhead(self.ctx, gen, ring,
                                3 if whole is not None else self.DTOK_DEPTH,
                                lap)
         # (a plain file's size tells how many records its sample will hold)
-        self.ctx.dtok_expect(size if source is None else 0)
+        self.ctx.dtok_expect(size - start if source is None else 0)
         try:
             while True:
                 t0 = time.perf_counter()
