@@ -301,6 +301,11 @@ int wk_dtok_copy_ahead(wk_ctx* ctx, const char* text, int64_t begin,
                        int64_t stop, int32_t* ticket);
 int wk_dtok_copy_wait(wk_ctx* ctx, int32_t ticket);
 int wk_dtok_copy_drop(wk_ctx* ctx);
+/* `--trim-sub` (workflow.py:840-841: `x.rsplit(sep, 1)[0]`, then a set again):
+ * the names the tokenizer meets are not the subjects; map[id of a name] = index
+ * of its subject (wk_set_subjects).  The plain flavour's kernels translate a
+ * block's lines before they group them into reads.  n = 0: no map. */
+int wk_dtok_subject_map(wk_ctx* ctx, const int32_t* map, int32_t n);
 /* How many blocks may be copied ahead on this device as it is now: half of its
  * free memory in text buffers (a reader that starts before the hierarchy is
  * read must not take the memory the count table and the records will want). */

@@ -685,8 +685,8 @@ def test_reader_started_before_the_hierarchy(tmp_path, monkeypatch, ordinal,
 def test_reader_started_ahead_is_dropped_when_the_file_goes_another_way(
         tmp_path, monkeypatch):
     """A reader started for a file that the host tokenizer reads after all
-    (`--trim-sub`: names are rewritten on the host): stopped, its copies
-    forgotten, the tables those of the host route."""
+    (`--demux`: the samples come from the read ids, on the host): stopped, its
+    copies forgotten, the tables those of the host route."""
     from woltka_amd import classify as C
     from woltka_amd.routes import device_text as D
     monkeypatch.setattr(D, 'TEXT_AHEAD_MIN', 0)
@@ -698,11 +698,11 @@ def test_reader_started_ahead_is_dropped_when_the_file_goes_another_way(
     (d / 'S1.sam').write_text(text)
     C.ROUTES.clear()
     got, _ = _run(tmp_path, 'a', False, input_fp=str(d), input_fmt='sam',
-                  trimsub='_')
+                  demux=True)
     assert C.ROUTES.get('text_ahead', 0) == 0
     assert not D._text_ahead
     host, _ = _run(tmp_path, 'h', True, input_fp=str(d), input_fmt='sam',
-                   trimsub='_')
+                   demux=True)
     assert got == host
 
 
@@ -1021,3 +1021,55 @@ def test_byte_range_parts_equal_whole_file(tmp_path, monkeypatch, fmt,
         assert ROUTES['host_block'] == 0, (rank, dict(ROUTES))
     with open(out, 'rb') as f:
         assert {'table': f.read()} == whole
+
+
+@pytest.mark.parametrize('block', [1 << 26, 1 << 16])
+def test_trim_sub_on_the_device_route(tmp_path, monkeypatch, block):
+    """`--trim-sub _` (workflow.py:840-841): gene ids like G000006605_17 are
+    trimmed to their genome *after* the reads' subject sets are made, and made
+    sets again -- on the device text route the kernels translate the ids of the
+    names they meet (wk_dtok_subject_map) before they group the lines; tables
+    and log equal the host tokenizer's, and the device route was taken."""
+    from woltka_amd import classify as C
+    from woltka_amd.hostio import ROUTES
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    rng = random.Random(block + 11)
+    tax = os.path.join(ROOT, 'tests', 'golden', 'data', 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        genomes = [ln.split('\t')[0] for ln in f][:60]
+    # (names with and without the separator, ending in it; with two of them --
+    # trimmed once, to a name no taxonomy holds -- under `--rank none` only:
+    # a subject without a genus sends the job set to the general route)
+    subjects = [f'{g}_{k}' for g in genomes for k in (1, 2, 17)] + \
+        genomes[:10] + [f'{genomes[0]}_']
+    twice = [f'{g}_x_y' for g in genomes[:5]]
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    for s in ('S1', 'S2'):
+        (indir / f'{s}.sam').write_text(_random_sam(
+            rng, 5000 if s == 'S1' else 800, subjects, paired=True,
+            unmapped=True, long_names=False))
+    odd = tmp_path / 'odd'
+    odd.mkdir()
+    (odd / 'S3.sam').write_text(_random_sam(
+        rng, 3000, subjects + twice, paired=True, unmapped=False,
+        long_names=False))
+    ROUTES.clear()
+    a, log_a = _run(tmp_path, 'dodd', False, input_fp=str(odd),
+                    input_fmt='sam', trimsub='_')
+    assert ROUTES['dtok'] > 0, dict(ROUTES)
+    b, log_b = _run(tmp_path, 'hodd', True, input_fp=str(odd),
+                    input_fmt='sam', trimsub='_')
+    assert a == b and log_a == log_b
+    kw = dict(input_fp=str(indir), input_fmt='sam', trimsub='_',
+              nodes_fps=[os.path.join(tax, 'nodes.dmp')],
+              map_fps=[os.path.join(tax, 'taxid.map')])
+    for i, ranks in enumerate(('none', 'none,phylum,genus', 'free')):
+        ROUTES.clear()
+        a, log_a = _run(tmp_path, f'd{i}', False, ranks=ranks, **kw)
+        routes = dict(ROUTES)
+        b, log_b = _run(tmp_path, f'h{i}', True, ranks=ranks, **kw)
+        assert a == b and log_a == log_b, ranks
+        assert routes.get('dtok', 0) > 0, (ranks, routes)
+        if block == 1 << 16:
+            assert routes.get('host_block', 0) == 0, (ranks, routes)

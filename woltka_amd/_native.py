@@ -54,7 +54,7 @@ SYMBOLS = (
     'wk_tok_read', 'wk_tok_trim', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
     'wk_dtok_format',
     'wk_dtok_copy', 'wk_dtok_copy_ahead', 'wk_dtok_copy_wait',
-    'wk_dtok_copy_drop', 'wk_dtok_ahead_room', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
+    'wk_dtok_copy_drop', 'wk_dtok_subject_map', 'wk_dtok_ahead_room', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
     'wk_dtok_scan_emit', 'wk_dtok_keep_reads', 'wk_readmap_tables',
     'wk_dtok_readmap',
     'wk_dtok_readmap_fetch', 'wk_strata_load', 'wk_strata_labels',
@@ -200,6 +200,7 @@ def load_library():
                                          C.POINTER(C.c_int32)]),
         'wk_dtok_copy_wait': (C.c_int, [p, C.c_int32]),
         'wk_dtok_copy_drop': (C.c_int, [p]),
+        'wk_dtok_subject_map': (C.c_int, [p, i32p, C.c_int32]),
         'wk_dtok_ahead_room': (C.c_int, [p, C.POINTER(C.c_int32)]),
         'wk_dtok_text_back': (C.c_int, [p, C.c_void_p, C.c_int64]),
         'wk_dtok_expect': (C.c_int, [p, C.c_int64]),
@@ -603,6 +604,16 @@ class Context:
     def dtok_copy_drop(self):
         """Forget the blocks copied ahead that no scan has asked for."""
         self._check(self._lib.wk_dtok_copy_drop(self._h))
+
+    def dtok_subject_map(self, table):
+        """``table[id of a name the tokenizer met]`` = index of its subject
+        (`--trim-sub`); None / empty: the ids are the indices."""
+        if table is None or len(table) == 0:
+            self._check(self._lib.wk_dtok_subject_map(self._h, None, 0))
+            return
+        table = np.ascontiguousarray(table, dtype=np.int32)
+        self._check(self._lib.wk_dtok_subject_map(
+            self._h, _ptr(table, C.c_int32), table.size))
 
     def dtok_ahead_room(self):
         """Blocks a reader may copy ahead of the scans: half of the device's

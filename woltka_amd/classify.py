@@ -147,6 +147,8 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         self._units, self._big = {}, {}     # folded counts until `finish`
         self._tok_map = np.empty(0, dtype=np.int32)
         self._tok_identity = True
+        self._tok_map_sent = 0      # entries of _tok_map the device holds (wk_dtok_subject_map)
+        self._dtrimsub = None       # `--trim-sub` of the file on the device text route
         self._tok_genome = np.empty(0, dtype=np.int32)
         self._tok_cover = np.empty(0, dtype=np.int64)
         self._ring, self._ring_prev = None, None    # packed-record staging
@@ -314,7 +316,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
                       want_names, trimsub=None, want_groups=False,
                       want_strings=True, want_samples=False, cover=None,
                       fmt='sam', part=None, words=False, dmaps=None,
-                      keep_empty=False):
+                      keep_empty=False, words_dev=False):
         """SAM text -> packed chunks through the native tokenizer.  Yields
         (reads or None, packed, strata ids, name descriptors, sample ids,
         ranges) where packed = (subj, qoff) of subject indices, or for
@@ -340,7 +342,10 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         # (the device tokenises SAM, BLAST tabular text and PAF in both
         # flavours, simple maps in the plain one -- they have no other:
         # align.py:258-547, 621-674, 753-981, 984-1213)
-        if (words or device_ex or dmaps) and (
+        # (`words_dev`: plain assigners whose packed records only the device
+        # text route can make -- `--trim-sub`, where the tokenizer's names
+        # are not the subjects and the kernels translate)
+        if (words or words_dev or device_ex or dmaps) and (
                 fmt in ('sam', 'b6o', 'paf') or (fmt == 'map' and
                                                  not ordinal)) and \
                 not exclude and \
@@ -368,6 +373,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
                 self._dmaps = dmaps if not (words or device_ex) else None
                 self.ctx.dtok_keep_reads(self._dmaps is not None)
                 self._dfmt = fmt
+                self._dtrimsub = trimsub if not ordinal else None
                 self._dpath = getattr(stream, 'name', None)
                 self.ctx.dtok_format(fmt)
                 try:

@@ -41,6 +41,7 @@ constexpr uint32_t kDtokBothMates = 2;   // FLAG with both mate bits
 constexpr uint32_t kDtokBigRead = 4;     // a read of more than WK_WEIGHT_MAX_K subjects
 constexpr uint32_t kDtokUnknownFull = 8; // more unknown subjects than the list holds
 constexpr uint32_t kDtokLongName = 16;   // a QNAME longer than the per-line word can say
+constexpr uint32_t kDtokBadNumber = 32;  // POS / CIGAR text the kernels leave to the host's Python-exact parsers
 
 // per-line result of dtok_parse
 constexpr int32_t kLineUnknown = -1;   // subject not in the dictionary
@@ -94,9 +95,25 @@ struct DtokArgs {
     uint32_t* o_len;
     int32_t* o_hoff;                // ... and the reads' offsets
     int32_t* o_group;               // (with a strata map on the device) the reads' (sample, stratum) groups
+    // plain flavour: the tokenizer's ids -> the subject indices the records carry, when they differ (`--trim-sub`:
+    // several names, one subject; workflow.py:840-841)
+    const int32_t* submap;
+    uint32_t n_submap;
 };
 
-constexpr uint32_t kDtokBadNumber = 32;  // POS / CIGAR text the kernels leave to the host's Python-exact parsers
+// lsubj[i] = submap[lsubj[i]] for the mapped lines, in front of the kernels that look at the subjects (after the host
+// has seen the names the parse listed): a read's subjects are a set of what the names are trimmed to
+__global__ void __launch_bounds__(kDtokThreads) dtok_submap_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines) return;
+    const int32_t id = a.lsubj[i];
+    if (id < 0) return;
+    if ((uint32_t)id < a.n_submap)
+        a.lsubj[i] = a.submap[id];
+    else
+        atomicOr(&a.state->flags, kDtokBadNumber);  // (a name the host has not mapped: the host tokenizer's block)
+}
+
 
 __device__ __forceinline__ uint32_t count_newlines16(const uint4 v) {
     auto cnt = [](uint32_t w) {

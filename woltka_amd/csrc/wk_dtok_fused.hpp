@@ -68,6 +68,8 @@ struct FusedArgs {
     uint32_t unknown_cap;
     DtokState* state;
     StreamSet streams;
+    const int32_t* submap;      // tokenizer id -> subject index, when they differ (`--trim-sub`), or null
+    uint32_t n_submap;
     uint32_t ablate;            // (measurement, wk_tune "fz_ablate": phases left out -- results are wrong then)
 };
 
@@ -428,7 +430,15 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
                 start = true;
             else
                 start = fz_starts_run_slow(a.text, w0 + ls[first_line], txt + ls[k], f_qn[k]);
-            const int32_t sid = (a.ablate & 1u) ? (int32_t)(fz_load32(name + 4) % 1000u) : fz_probe_end(a, probe, name, rn, w0 + f_rb[k]);
+            int32_t sid = (a.ablate & 1u) ? (int32_t)(fz_load32(name + 4) % 1000u) : fz_probe_end(a, probe, name, rn, w0 + f_rb[k]);
+            if (a.submap && sid >= 0) {
+                if ((uint32_t)sid < a.n_submap) {
+                    sid = a.submap[sid];
+                } else {  // (a name the host has not mapped yet: the block is done again)
+                    my_flags |= kDtokSpill;
+                    sid = -1;
+                }
+            }
             // (this thread's own word; the others look at its mapped bit only)
             info[k] |= (start ? kFiStart : 0u) | (sid < 0 ? kFiSubj : ((uint32_t)sid & kFiSubj));
             if (start) atomicMin(&own[w0 + ls[k] < t1 ? 0 : 1], k);

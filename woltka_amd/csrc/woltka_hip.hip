@@ -286,7 +286,9 @@ struct wk_ctx {
     static constexpr size_t kTextStride = ((size_t)66 << 20) + 256;
     DevBuf d_textslab[kTextBufs / kSlabBufs];
     unsigned char* d_textptr[kTextBufs] = {};
-    DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_dict2, d_names16, d_arena;
+    DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_dict2, d_names16, d_arena, d_submap;
+    bool dt_mapped = false;       // the block scanned last has had its lines' ids translated (dtok_submap_kernel)
+    uint32_t dt_submap_n = 0;     // wk_dtok_subject_map (0: the tokenizer's ids are the subject indices)
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
     // measurement (woltka_hip_measure.h): blocks of text that are resident on the device already
@@ -992,7 +994,7 @@ void wk_destroy(wk_ctx* c) {
         if (q % wk_ctx::kSlabBufs == 0) c->d_textslab[q / wk_ctx::kSlabBufs].release();
     }
     for (DevBuf* b : {&c->d_tiles, &c->d_tile_off, &c->d_lines, &c->d_lsubj, &c->d_lmeta, &c->d_start, &c->d_first, &c->d_unknown, &c->d_lbeg, &c->d_lend, &c->d_llen, &c->d_lscan, &c->d_gmap,
-                      &c->d_state, &c->d_dict, &c->d_dict2, &c->d_names16, &c->d_arena})
+                      &c->d_state, &c->d_dict, &c->d_dict2, &c->d_names16, &c->d_arena, &c->d_submap})
         b->release();
     for (wk_ctx::ResidentText& r : c->resident) {
         (void)hipFree(r.dev);
@@ -2637,6 +2639,8 @@ static DtokArgs dtok_args(wk_ctx* c) {
     a.lend = c->d_lend.as<int32_t>();
     a.llen = c->d_llen.as<uint32_t>();
     a.line_scan = c->d_lscan.as<unsigned long long>();
+    a.submap = c->dt_submap_n ? c->d_submap.as<int32_t>() : nullptr;
+    a.n_submap = c->dt_submap_n;
     return a;
 }
 
@@ -2936,6 +2940,22 @@ int wk_text_clear(wk_ctx* c) {
     return WK_OK;
 }
 
+// The tokenizer's ids are not the subject indices of the records (wk_set_subjects): map[id] is (`--trim-sub`, where
+// several names are one subject).  n = 0: they are again.  Applies to the plain flavour's blocks from the next
+// wk_dtok_emit / wk_dtok_scan_emit on; a block that meets an id beyond the map is the host tokenizer's.
+int wk_dtok_subject_map(wk_ctx* c, const int32_t* map, int32_t n) {
+    if (!c || n < 0 || (n > 0 && !map)) return WK_E_ARG;
+    DeviceGuard guard(c->device);
+    if (n > 0) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // (a kernel may be reading the map that is there)
+        const int rc = upload(c, c->d_submap, map, (size_t)n * 4);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->dt_submap_n = (uint32_t)n;
+    return WK_OK;
+}
+
 int wk_dtok_format(wk_ctx* c, int fmt) {
     if (!c) return WK_E_ARG;
     if (fmt != WK_FMT_SAM && fmt != WK_FMT_MAP && fmt != WK_FMT_B6O && fmt != WK_FMT_PAF)
@@ -3140,6 +3160,8 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             fa.unknown_cap = (uint32_t)(c->d_unknown.cap / 8);
             fa.state = c->d_state.as<DtokState>();
             fa.ablate = c->fused_ablate;
+            fa.submap = c->dt_submap_n ? c->d_submap.as<int32_t>() : nullptr;
+            fa.n_submap = c->dt_submap_n;
             c->w_counts_known = false;
             HIP_TRY(c, c->w_backup.reserve(kMaxStreams * 8));
             if (res) ktimer_end(c, kt);   // (the count behind a resident block's "copy": its own family)
@@ -3219,6 +3241,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         if (rc) return rc;
         if (round > 0) HIP_TRY(c, hipMemsetAsync(c->d_state.p, 0, sizeof(DtokState), c->stream));  // (round 0: by dtok_lines_kernel)
         const DtokArgs a = dtok_args(c);
+        c->dt_mapped = false;
         kt = ktimer_begin(c, "dtok_parse");
         if (extra)
             hipLaunchKernelGGL(dtok_parse_kernel<true>, dim3((lines + kDtokThreads - 1) / kDtokThreads), dim3(kDtokThreads), 0, c->stream, a);
@@ -3338,6 +3361,10 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
     const dim3 grid((c->dt_lines + kDtokThreads - 1) / kDtokThreads);
     const dim3 emit_grid((c->dt_lines + kDtokThreads * kScatterItems - 1) / (kDtokThreads * kScatterItems));
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
+    if (a.submap && !c->dt_mapped) {  // (once per scanned block)
+        hipLaunchKernelGGL(dtok_submap_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        c->dt_mapped = true;
+    }
     hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     const bool ordered = c->w_mode != 0 || c->dt_keep_reads;
     *ordered_out = ordered;

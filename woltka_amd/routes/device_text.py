@@ -984,13 +984,21 @@ class DeviceTextRoute:
                     return
                 if fresh:
                     base = self._tok_map.size
+                    if self._dtrimsub:      # (workflow.py:840-841)
+                        fresh = [x.rsplit(self._dtrimsub, 1)[0] for x in fresh]
                     ids = np.asarray(self.subjects.intern_many(fresh),
                                      dtype=np.int32)
                     if self._tok_identity and not np.array_equal(
                             ids, np.arange(base, base + ids.size)):
                         self._tok_identity = False
                     self._tok_map = np.concatenate([self._tok_map, ids])
-                if status == 0 and self._tok_identity:
+                if not self._tok_identity and \
+                        self._tok_map_sent != self._tok_map.size:
+                    # names that are not subjects (`--trim-sub`: several
+                    # names, one subject): the kernels translate
+                    self.ctx.dtok_subject_map(self._tok_map)
+                    self._tok_map_sent = self._tok_map.size
+                if status == 0:
                     if n_lines:
                         yield None, ('dtok', (text, fill, first, final, hdr_in,
                                               hdr, done)), None, None, None, \
@@ -1131,7 +1139,13 @@ class DeviceTextRoute:
                         final=final, fmt=self._dfmt, want_names=names)
         fresh = tok.new_subjects()
         if fresh:
+            base = self._tok_map.size
+            if self._dtrimsub:
+                fresh = [x.rsplit(self._dtrimsub, 1)[0] for x in fresh]
             ids = np.asarray(self.subjects.intern_many(fresh), dtype=np.int32)
+            if self._tok_identity and not np.array_equal(
+                    ids, np.arange(base, base + ids.size)):
+                self._tok_identity = False
             self._tok_map = np.concatenate([self._tok_map, ids])
         if res['off'].size > 1:
             subj = res['subj'] if self._tok_identity \
@@ -1236,11 +1250,11 @@ class DeviceTextRoute:
                 n += self.run_chunk(data, None, None, sample, None, None,
                                     dmaps[0], dmaps[1], dmaps[2], False,
                                     packed=(subj, qoff), names=names,
-                                    packed_is_set=True)
+                                    packed_is_set=not self._dtrimsub)
                 continue
             n += self.run_chunk(data, None, None, sample, None, None, None,
                                 None, None, False, packed=(subj, qoff),
-                                packed_is_set=True)
+                                packed_is_set=not self._dtrimsub)
         self.tok.set_header_state(hdr)
         return n
 

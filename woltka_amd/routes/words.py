@@ -12,12 +12,15 @@ from ..hostio import MAX_GROUPS
 class WordsRoute:
     """(mixin of classify.Engine)"""
 
-    def words_eligible(self):
+    def words_eligible(self, identity=True):
         """Can chunks go to the device as packed words, accumulated per
         sample (``wk_words_*``)?  The plain assigners only — what
-        ``wk_words_begin`` checks once more against the subject table."""
+        ``wk_words_begin`` checks once more against the subject table.
+        ``identity``: the words come from the host tokenizer, whose ids must
+        be the subject indices (the device text route translates)."""
         if self.sizes or self._replay is not None or \
-                len(self.jobs) > nat.MAX_JOBS or not self._tok_identity or \
+                len(self.jobs) > nat.MAX_JOBS or \
+                (identity and not self._tok_identity) or \
                 os.environ.get('WOLTKA_NO_WORDS'):
             return False
         # jobs that look at whole reads — `--rank free`, a rank under --uniq /

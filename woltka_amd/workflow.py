@@ -459,10 +459,16 @@ def classify(
                         # plain assigners, one sample per file, nothing per
                         # read: the records cross as packed words and the
                         # sample is classified by one launch at its end
-                        words = not (ordinal or cover is not None or
+                        plain = not (ordinal or cover is not None or
                                      want_names or native_strata or demux or
-                                     trimsub or rank2dir is not None) and \
+                                     rank2dir is not None)
+                        words = plain and not trimsub and \
                             engine.words_eligible()
+                        # (`--trim-sub`: the device text route translates the
+                        # names it meets into subjects; the host tokenizer's
+                        # words cannot)
+                        words_dev = plain and bool(trimsub) and \
+                            engine.words_eligible(identity=False)
                         # read maps of plain assigners, one sample per file:
                         # the lines are formatted on the device next to the
                         # tokenised text (csrc/wk_readmap.hpp)
@@ -477,7 +483,7 @@ def classify(
                             want_names, trimsub, want_groups=native_strata,
                             want_strings=want_strings, want_samples=native_demux,
                             cover=cover, fmt=fmt_, part=part, words=words,
-                            dmaps=dmaps,
+                            words_dev=words_dev, dmaps=dmaps,
                             keep_empty=bool(ordinal and rank2dir is not None))
                         if ordinal and rank2dir is not None:
                             chunks = engine.regroup_hits(chunks, n)
