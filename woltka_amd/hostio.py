@@ -390,7 +390,11 @@ def warm_tokenizer_ahead(path, fmt, span=int(os.environ.get('WOLTKA_WARM_SPAN', 
         tok = None
         try:
             size = os.path.getsize(path)
-            n = min(size, span)
+            # (a sixteenth of the file at most: the subjects of a 400 MB file
+            # are met in its first megabytes, and parsing 256 MB of it on the
+            # host took the CPUs from the hierarchy and the reader for a
+            # fifth of config 2's whole call)
+            n = min(size, span, max(size // 16, 8 << 20))
             if n < (8 << 20):
                 return
             tok = nat.Tokenizer(threads or tokenizer_threads())
