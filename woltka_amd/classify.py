@@ -235,6 +235,9 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         most = (len(self.groups) + max(1, n_groups)) * (len(self.index) + 2) \
             * n_jobs
         if 2 * most <= self.slots_reserved:
+            # (keys added from here on are in no bound: the table is asked
+            # again before a bound is trusted)
+            self._used_bound = (0, None)
             return
         # (asking counts the table's keys on the device and waits: 0.5 ms per
         # block of a stratified run.  The keys in use are at most those counted
