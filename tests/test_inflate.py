@@ -129,6 +129,20 @@ def test_member_chains_bgzf_and_wk(tmp_path):
         read_all(fp, 4)
 
 
+def test_empty_members_inside_a_chain_do_not_end_the_text(tmp_path):
+    """A BGZF end-of-file block (an empty member) in the middle of a file --
+    `cat a.bgzf b.bgzf` -- followed by a member that does not fit what is left
+    of the read buffer: the call must not return 0 bytes, which the reader
+    takes for the end of the data."""
+    a, b = sam_text(40_000, 3), sam_text(40_000, 5)
+    blob = _bgzf(a, 60_000) + _bgzf(b, 60_000)     # (each ends with an empty member)
+    fp = tmp_path / 'cat.sam.gz'
+    fp.write_bytes(blob)
+    assert gzip.decompress(blob) == a + b
+    for threads, cap in ((1, 1 << 16), (4, 1 << 16), (4, 1 << 17), (3, 1 << 22)):
+        assert read_all(fp, threads, cap) == a + b
+
+
 def test_damage_is_reported(tmp_path):
     data = sam_text(120_000, 4)
     good = gzip.compress(data, 6)

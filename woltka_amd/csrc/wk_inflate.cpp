@@ -1055,7 +1055,7 @@ int64_t wk_gunzip_read(wk_gunzip* h, char* dst_c, int64_t cap) {
                 break;
             }
             if (hr == 2 || mh.stated < (int64_t)mh.size + 8 || at + (size_t)mh.stated > g.size) {
-                if (tasks.empty()) {
+                if (fill == 0) {  // (nothing to hand out but empty members: 0 bytes would read as the end of the data)
                     if (hr == 0 && mh.stated < 0) {
                         g.err = "a gzip member without a stated size inside a chain of members that state theirs";
                         return -1;
@@ -1068,7 +1068,7 @@ int64_t wk_gunzip_read(wk_gunzip* h, char* dst_c, int64_t cap) {
             uint32_t isize;
             std::memcpy(&isize, g.file + at + mh.stated - 4, 4);
             if (fill + isize > (size_t)cap) {
-                if (tasks.empty()) {
+                if (fill == 0) {
                     g.err = "a gzip member larger than the read buffer";
                     return -1;
                 }
