@@ -780,6 +780,141 @@ def gen_cli_random(seed=47, n_cases=56):
     dump('cli_random.json', cases)
 
 
+def gen_dtok_blocks(seed=131):
+    """The device text route's block cuts against the reference itself: files
+    of several hundred queries in every format x {plain, --coords}, with the
+    rows that only one of a format's two parsers takes for rows, unmapped
+    records between and inside runs, and lines that make the kernels hand a
+    block to the host tokenizer without the reference raising (a FLAG int()
+    reads but that is not plain digits, a read of more than 16 subjects, a '*'
+    CIGAR, a MAPQ that is no number).  tests/test_gpu_dtok_blocks.py runs every
+    case with blocks of 64 MB and of 16 KB and compares with what the reference
+    wrote here."""
+    import lzma
+    import tempfile
+    from woltka.workflow import workflow
+    rng = random.Random(seed)
+    tax = os.path.join(DATA, 'taxonomy')
+    fun = os.path.join(DATA, 'function')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        tax_genomes = [x.split('\t')[0] for x in f]
+    genes = {}
+    with lzma.open(os.path.join(fun, 'coords.txt.xz'), 'rt') as f:
+        for line in f:
+            if line.startswith('>'):
+                cur = genes.setdefault(line[1:].strip(), [])
+            else:
+                x = line.split('\t')
+                a, b = int(x[1]), int(x[2])
+                cur.append((min(a, b), max(a, b)))
+    gene_genomes = [g for g in genes if len(genes[g]) > 50]
+    ext = {'sam': 'sam', 'b6o': 'b6', 'paf': 'paf', 'map': 'map'}
+
+    def row(fmt, q, s, pos, ln, flag=0, cigar=None, mapq='60'):
+        if fmt == 'sam':
+            return (f'{q}\t{flag}\t{s}\t{pos}\t255\t{cigar or f"{ln}M"}\t=\t0\t0'
+                    '\t*\t*\n')
+        if fmt == 'b6o':
+            a, b = pos, pos + ln - 1
+            if rng.random() < 0.5:
+                a, b = b, a
+            return f'{q}\t{s}\t99.0\t{ln}\t0\t0\t1\t{ln}\t{a}\t{b}\t1e-9\t200\n'
+        if fmt == 'paf':
+            return (f'{q}\t{ln}\t0\t{ln}\t+\t{s}\t9999999\t{pos - 1}\t'
+                    f'{pos - 1 + ln}\t{ln}\t{ln}\t{mapq}\n')
+        return f'{q}\t{s}\n'
+
+    def text_of(fmt, coords, subjects, n_queries, odd):
+        lines = ['@HD\tVN:1.0\tSO:unsorted\n', '@SQ\tSN:x\tLN:5\n'] \
+            if fmt == 'sam' else []
+        for qi in range(n_queries):
+            q = f'q{qi:05d}'
+            paired = fmt == 'sam' and rng.random() < 0.4
+            n_hits = rng.choice([1, 1, 1, 2, 3, 5, 8])
+            if odd and not coords and rng.random() < 0.004:
+                n_hits = 19         # (more subjects than a packed read holds)
+            for h in range(n_hits):
+                s = rng.choice(subjects)
+                ln = rng.choice([75, 100, 150])
+                if coords:
+                    gs, ge = rng.choice(genes[s])
+                    pos = max(1, gs + rng.randint(-ln, ge - gs))
+                else:
+                    pos = rng.randrange(1, 1_000_000)
+                flag = (rng.choice([99, 147, 355, 403]) if paired
+                        else rng.choice([0, 16, 256]))
+                if fmt == 'sam' and rng.random() < 0.04:
+                    lines.append(f'{q}\t{flag | 4}\t*\t0\t0\t*\t*\t0\t0\t*\t*\n')
+                cigar, mapq = None, '60'
+                if odd and rng.random() < 0.01:
+                    if fmt == 'sam':
+                        if coords and rng.random() < 0.5:
+                            cigar = '*'
+                        else:
+                            flag = f' {flag}'       # int(' 16') == 16
+                    elif fmt == 'paf':
+                        mapq = 'na'     # a row to parse_paf_file, none to _ex
+                    elif fmt == 'b6o':
+                        lines.append(f'{q}\t{s}\t99.0\n')   # three fields
+                        continue
+                    else:
+                        lines.append(f'{q}\t{s}\textra\n')
+                        continue
+                lines.append(row(fmt, q, s, pos, ln, flag, cigar, mapq))
+            if fmt == 'b6o' and rng.random() < 0.02:
+                lines.append('# BLAST-style comment line\n')
+        return ''.join(lines)
+
+    cases = []
+    for fmt in ('sam', 'b6o', 'paf', 'map'):
+        for coords in (False, True):
+            if coords and fmt == 'map':
+                continue
+            for odd in (False, True):
+                subjects = rng.sample(gene_genomes if coords else tax_genomes,
+                                      8 if coords else 30)
+                files = {f'aln/S{i + 1}.{ext[fmt]}': text_of(
+                    fmt, coords, subjects, rng.randint(350, 550), odd)
+                    for i in range(2)}
+                kw = {'output_fmt': False, 'input_fp': 'aln', 'input_fmt': fmt}
+                if coords:
+                    kw['coords_fp'] = '$FUN/coords.txt.xz'
+                    kw['overlap'] = rng.choice([50, 80])
+                elif rng.random() < 0.5:
+                    kw['nodes_fps'] = ['$TAX/nodes.dmp']
+                    kw['map_fps'] = ['$TAX/taxid.map']
+                    kw['ranks'] = rng.choice(['genus', 'phylum,genus', 'free'])
+                with tempfile.TemporaryDirectory() as tmp:
+                    for rel, text in files.items():
+                        _write_case_file(os.path.join(tmp, rel), text)
+
+                    def real(v):
+                        if isinstance(v, list):
+                            return [real(x) for x in v]
+                        if isinstance(v, str) and v.startswith('$TAX/'):
+                            return os.path.join(tax, v[5:])
+                        if isinstance(v, str) and v.startswith('$FUN/'):
+                            return os.path.join(fun, v[5:])
+                        if v == 'aln':
+                            return os.path.join(tmp, v)
+                        return v
+                    args = {k: real(v) for k, v in kw.items()}
+                    args['output_fp'] = os.path.join(tmp, 'out')
+                    import contextlib
+                    import io
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        workflow(**args)
+                    if os.path.isdir(args['output_fp']):
+                        outs = {fn: open(os.path.join(args['output_fp'],
+                                                      fn)).read()
+                                for fn in sorted(os.listdir(args['output_fp']))}
+                    else:
+                        outs = {'out': open(args['output_fp']).read()}
+                cases.append(dict(files=files, kwargs=kw, odd=odd,
+                                  expect={'tables': outs}))
+    dump('dtok_blocks.json', cases)
+
+
 def gen_cli_coords_excl(seed=59, n_cases=16):
     """`--coords` together with `--exclude`: the "extra + exclude" parsers
     (align.py:481-547, 919-981, 1152-1213), with files whose last query names an
@@ -1677,7 +1812,7 @@ def main():
     gen_cli_strata()
     gen_cli_config5()
     gen_cli_medium()
-    gen_tools()
+    gen_dtok_blocks()
     gen_hierarchy_build()
 
 
