@@ -304,7 +304,11 @@ int wk_dtok_copy_drop(wk_ctx* ctx);
 /* `--trim-sub` (workflow.py:840-841: `x.rsplit(sep, 1)[0]`, then a set again):
  * the names the tokenizer meets are not the subjects; map[id of a name] = index
  * of its subject (wk_set_subjects).  The plain flavour's kernels translate a
- * block's lines before they group them into reads.  n = 0: no map. */
+ * block's lines before they group them into reads.  n = 0: no map.
+ * `--exclude` (align.py:47-115, 438-470: a query that hits a subject of the set
+ * is dropped whole, all its mates): map[id] = -4 for the names of the set; a
+ * tokenizer with an exclusion set is scanned on the device only under such a
+ * map (plain flavour; the "ex" parsers' exclusion stays on the host). */
 int wk_dtok_subject_map(wk_ctx* ctx, const int32_t* map, int32_t n);
 /* How many blocks may be copied ahead on this device as it is now: half of its
  * free memory in text buffers (a reader that starts before the hierarchy is

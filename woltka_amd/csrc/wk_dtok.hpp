@@ -47,6 +47,7 @@ constexpr uint32_t kDtokBadNumber = 32;  // POS / CIGAR text the kernels leave t
 constexpr int32_t kLineUnknown = -1;   // subject not in the dictionary
 constexpr int32_t kLineUnmapped = -2;  // RNAME "*"
 constexpr int32_t kLineBad = -3;
+constexpr int32_t kLineExcluded = -4;  // a subject of the exclusion set (the submap's value for its names): drops its whole run
 
 struct DtokState {  // device scalars of one block
     uint32_t flags;
@@ -112,6 +113,28 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_submap_kernel(DtokArgs a) {
         a.lsubj[i] = a.submap[id];
     else
         atomicOr(&a.state->flags, kDtokBadNumber);  // (a name the host has not mapped: the host tokenizer's block)
+}
+
+// `--exclude` (align.plain_mapper's `excl`, align.py:47-115, and the filtering parsers, align.py:438-470): a query that
+// hits a subject of the set is dropped whole, all its mates.  Behind dtok_runs (the runs were told with every mapped
+// line in place) and dtok_submap (the set's names carry kLineExcluded): a line of such a subject marks the line its
+// run starts with (is_first[], free until dtok_first), then every line of a marked run turns into a line without a
+// subject -- which the kernels behind skip, and which ends no run.
+__global__ void __launch_bounds__(kDtokThreads) dtok_excl_mark_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines || a.lsubj[i] != kLineExcluded) return;
+    uint32_t j = i;
+    while (!a.is_start[j]) --j;  // (a mapped line at or before i starts the run)
+    a.is_first[j] = 0xEE;
+}
+__global__ void __launch_bounds__(kDtokThreads) dtok_excl_drop_kernel(DtokArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_lines) return;
+    const int32_t s = a.lsubj[i];
+    if (s < 0 && s != kLineExcluded) return;
+    uint32_t j = i;
+    while (!a.is_start[j]) --j;
+    if (a.is_first[j] == 0xEE) a.lsubj[i] = kLineUnmapped;
 }
 
 

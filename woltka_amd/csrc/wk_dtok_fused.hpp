@@ -218,6 +218,8 @@ constexpr uint32_t kFiMateShift = 24;
 constexpr uint32_t kFiMapped = 1u << 26;
 constexpr uint32_t kFiStart = 1u << 27;          // starts a run of equal QNAMEs
 constexpr uint32_t kFiFirst = 1u << 28;          // first line of its read (run, mate) that names its subject
+constexpr uint32_t kFiExcl = 1u << 29;           // names a subject of the exclusion set
+constexpr uint32_t kFiDropped = 1u << 30;        // (on the line that starts a run) a line of the run does: the run is dropped whole
 constexpr uint32_t kFiRead = kFiMapped | (3u << kFiMateShift);          // same read of a run: same mate (and mapped)
 constexpr uint32_t kFiKey = kFiRead | kFiSubj;                          // ... and the same subject
 constexpr uint32_t kFzPad = 8;                   // words in front of / behind the lines' words (walks read eight at a time)
@@ -431,16 +433,21 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
             else
                 start = fz_starts_run_slow(a.text, w0 + ls[first_line], txt + ls[k], f_qn[k]);
             int32_t sid = (a.ablate & 1u) ? (int32_t)(fz_load32(name + 4) % 1000u) : fz_probe_end(a, probe, name, rn, w0 + f_rb[k]);
+            bool excluded = false;
             if (a.submap && sid >= 0) {
                 if ((uint32_t)sid < a.n_submap) {
                     sid = a.submap[sid];
+                    if (sid == kLineExcluded) {  // (`--exclude`: the run goes, all its mates; align.py:47-115)
+                        excluded = true;
+                        sid = 0;
+                    }
                 } else {  // (a name the host has not mapped yet: the block is done again)
                     my_flags |= kDtokSpill;
                     sid = -1;
                 }
             }
             // (this thread's own word; the others look at its mapped bit only)
-            info[k] |= (start ? kFiStart : 0u) | (sid < 0 ? kFiSubj : ((uint32_t)sid & kFiSubj));
+            info[k] |= (start ? kFiStart : 0u) | (excluded ? kFiExcl : 0u) | (sid < 0 ? kFiSubj : ((uint32_t)sid & kFiSubj));
             if (start) atomicMin(&own[w0 + ls[k] < t1 ? 0 : 1], k);
         }
         __syncthreads();
@@ -461,6 +468,12 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
         for (uint32_t k = ka + tid; k < kb; k += kFzThreads) {
             const uint32_t mk = info[k];
             if (!(mk & kFiMapped)) continue;
+            if (mk & kFiExcl) {  // the line its run starts with learns that the run is dropped (read behind the barrier)
+                uint32_t j = k;
+                while (!(info[j] & kFiStart)) --j;
+                atomicOr(&info[j], kFiDropped);
+                continue;
+            }
             bool dup = false;
             if (!(mk & kFiStart) && !(a.ablate & 2u)) {
                 bool done = false;
@@ -476,7 +489,7 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
                 }
             }
             // (bit 28 of this thread's own word; the walks above look at the other bits of other lines' words)
-            if (!dup) info[k] = mk | kFiFirst;
+            if (!dup) atomicOr(&info[k], kFiFirst);  // (an atomic: a line of an excluded subject may be marking this word as its run's start)
         }
         __syncthreads();
         // ---- records: position and size inside the read ----
@@ -487,6 +500,7 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
             if (k < kb && (info[k] & kFiFirst) && !(a.ablate & 4u)) {
                 const uint32_t mk = info[k];
                 uint32_t pos = 0, size = 1;
+                bool dropped = (mk & kFiStart) && (mk & kFiDropped);
                 if (!(a.ablate & (2u | 128u))) {
                     if (!(mk & kFiStart)) {
                         bool done = false;
@@ -497,6 +511,7 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                             for (uint32_t i = 0; i < 8; ++i) {
                                 pos += (!done && (w[i] & kFiFirst) && ((w[i] ^ mk) & kFiRead) == 0u) ? 1u : 0u;
+                                dropped |= !done && (w[i] & kFiStart) && (w[i] & kFiDropped);
                                 done |= (w[i] & kFiStart) != 0u;
                             }
                         }
@@ -516,7 +531,7 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
                 }
                 if (size > (uint32_t)WK_WEIGHT_MAX_K) my_flags |= kDtokBigRead;
                 const uint32_t s = mk & kFiSubj;
-                if (s != kFiSubj) {  // (else: a subject the dictionary does not know -- the block is done again anyway)
+                if (s != kFiSubj && !dropped) {  // (kFiSubj: a subject the dictionary does not know -- the block is done again anyway)
                     rec = true;
                     word = s | ((pos & 15u) << kWordSubjBits) | ((size & 31u) << kWordSizeShift);
                     sl = s / kSliceBins;

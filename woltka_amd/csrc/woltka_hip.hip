@@ -288,6 +288,7 @@ struct wk_ctx {
     unsigned char* d_textptr[kTextBufs] = {};
     DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_dict2, d_names16, d_arena, d_submap;
     bool dt_mapped = false;       // the block scanned last has had its lines' ids translated (dtok_submap_kernel)
+    bool dt_has_excl = false;     // the map holds kLineExcluded: `--exclude` on the device text route
     uint32_t dt_submap_n = 0;     // wk_dtok_subject_map (0: the tokenizer's ids are the subject indices)
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
     bool dt_extra = false;
@@ -2946,13 +2947,21 @@ int wk_text_clear(wk_ctx* c) {
 int wk_dtok_subject_map(wk_ctx* c, const int32_t* map, int32_t n) {
     if (!c || n < 0 || (n > 0 && !map)) return WK_E_ARG;
     DeviceGuard guard(c->device);
+    bool excl = false;
     if (n > 0) {
+        for (int32_t i = 0; i < n; ++i) {
+            if (map[i] == kLineExcluded)
+                excl = true;
+            else if (map[i] < 0)
+                return fail(c, WK_E_ARG, "a subject map holds subject indices (or -4: excluded)");
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // (a kernel may be reading the map that is there)
         const int rc = upload(c, c->d_submap, map, (size_t)n * 4);
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->dt_submap_n = (uint32_t)n;
+    c->dt_has_excl = excl;
     return WK_OK;
 }
 
@@ -2980,7 +2989,9 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     *n_lines = 0;
     c->dt_ready = false;
     c->dt_extra = extra != 0;
-    if (!wkx_tok_device_ok(tok)) return WK_OK;  // an exclusion set: the host tokenizer's business
+    // (an exclusion set: the plain flavour takes it as kLineExcluded entries of the subject map, wk_dtok_subject_map;
+    // the "ex" parsers' way with it -- align.py:481-547 yields a stale pool at the end of a file -- stays the host's)
+    if (!wkx_tok_device_ok(tok) && (extra || c->dt_submap_n == 0)) return WK_OK;
     if (extra && c->dt_fmt == WK_FMT_MAP) return WK_OK;  // (a simple map has no "ex" flavour, align.py:236)
     const int64_t n64 = stop - begin;
     if (n64 >= (1ll << 31) - 64) return WK_OK;
@@ -3361,11 +3372,16 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
     const dim3 grid((c->dt_lines + kDtokThreads - 1) / kDtokThreads);
     const dim3 emit_grid((c->dt_lines + kDtokThreads * kScatterItems - 1) / (kDtokThreads * kScatterItems));
     KernelTimer* kt = ktimer_begin(c, "dtok_emit");
-    if (a.submap && !c->dt_mapped) {  // (once per scanned block)
+    hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+    if (a.submap && !c->dt_mapped) {  // (once per scanned block; behind the runs: a line of an excluded subject starts and continues runs like any other)
         hipLaunchKernelGGL(dtok_submap_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        if (c->dt_has_excl) {
+            HIP_TRY(c, hipMemsetAsync(c->d_first.p, 0, c->dt_lines, c->stream));
+            hipLaunchKernelGGL(dtok_excl_mark_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+            hipLaunchKernelGGL(dtok_excl_drop_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
+        }
         c->dt_mapped = true;
     }
-    hipLaunchKernelGGL(dtok_runs_kernel, grid, dim3(kDtokThreads), 0, c->stream, a);
     const bool ordered = c->w_mode != 0 || c->dt_keep_reads;
     *ordered_out = ordered;
     c->dt_emitted = false;
