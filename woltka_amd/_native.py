@@ -607,11 +607,17 @@ class Context:
 
     def dtok_subject_map(self, table):
         """``table[id of a name the tokenizer met]`` = index of its subject
-        (`--trim-sub`); None / empty: the ids are the indices."""
-        if table is None or len(table) == 0:
+        (`--trim-sub`), -4 for a name of the `--exclude` set; None: the ids
+        are the indices."""
+        if table is None:
             self._check(self._lib.wk_dtok_subject_map(self._h, None, 0))
             return
         table = np.ascontiguousarray(table, dtype=np.int32)
+        if table.size == 0:     # (a map that no name has entered yet)
+            one = np.zeros(1, dtype=np.int32)
+            self._check(self._lib.wk_dtok_subject_map(
+                self._h, _ptr(one, C.c_int32), 0))
+            return
         self._check(self._lib.wk_dtok_subject_map(
             self._h, _ptr(table, C.c_int32), table.size))
 

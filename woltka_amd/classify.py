@@ -149,6 +149,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         self._tok_identity = True
         self._tok_map_sent = 0      # entries of _tok_map the device holds (wk_dtok_subject_map)
         self._dtrimsub = None       # `--trim-sub` of the file on the device text route
+        self._dexclude = None       # ... and its `--exclude` set
         self._tok_genome = np.empty(0, dtype=np.int32)
         self._tok_cover = np.empty(0, dtype=np.int64)
         self._ring, self._ring_prev = None, None    # packed-record staging
@@ -348,10 +349,12 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         # (`words_dev`: plain assigners whose packed records only the device
         # text route can make -- `--trim-sub`, where the tokenizer's names
         # are not the subjects and the kernels translate)
+        # (`--exclude`: the plain flavour's kernels drop the runs that hit a
+        # name of the set; not with read maps, not the "ex" parsers' way)
         if (words or words_dev or device_ex or dmaps) and (
                 fmt in ('sam', 'b6o', 'paf') or (fmt == 'map' and
                                                  not ordinal)) and \
-                not exclude and \
+                (not exclude or ((words or words_dev) and not dmaps)) and \
                 not os.environ.get('WOLTKA_NO_DTOK'):
             from .align import _parallel_reader, part_range
             from .file import GunzipStream
@@ -377,6 +380,16 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
                 self.ctx.dtok_keep_reads(self._dmaps is not None)
                 self._dfmt = fmt
                 self._dtrimsub = trimsub if not ordinal else None
+                self._dexclude = set(exclude) if exclude else None
+                if exclude:
+                    # (the tokenizer's ids are no subject indices from now
+                    # on: names of the set get none; the device is told
+                    # before its first scan that a map is coming)
+                    self._tok_identity = False
+                    if self._tok_map_sent != self._tok_map.size or \
+                            not self._tok_map.size:
+                        self.ctx.dtok_subject_map(self._tok_map)
+                        self._tok_map_sent = self._tok_map.size
                 self._dpath = getattr(stream, 'name', None)
                 self.ctx.dtok_format(fmt)
                 try:

@@ -288,6 +288,7 @@ struct wk_ctx {
     unsigned char* d_textptr[kTextBufs] = {};
     DevBuf d_textbuf[kTextBufs], d_tiles, d_tile_off, d_lines, d_lsubj, d_lmeta, d_start, d_first, d_unknown, d_state, d_dict, d_dict2, d_names16, d_arena, d_submap;
     bool dt_mapped = false;       // the block scanned last has had its lines' ids translated (dtok_submap_kernel)
+    bool dt_submap_on = false;    // a map has been given (it may be empty still)
     bool dt_has_excl = false;     // the map holds kLineExcluded: `--exclude` on the device text route
     uint32_t dt_submap_n = 0;     // wk_dtok_subject_map (0: the tokenizer's ids are the subject indices)
     DevBuf d_lbeg, d_lend, d_llen, d_lscan, d_gmap;  // "ex" flavour
@@ -2640,7 +2641,7 @@ static DtokArgs dtok_args(wk_ctx* c) {
     a.lend = c->d_lend.as<int32_t>();
     a.llen = c->d_llen.as<uint32_t>();
     a.line_scan = c->d_lscan.as<unsigned long long>();
-    a.submap = c->dt_submap_n ? c->d_submap.as<int32_t>() : nullptr;
+    a.submap = c->dt_submap_on ? c->d_submap.as<int32_t>() : nullptr;
     a.n_submap = c->dt_submap_n;
     return a;
 }
@@ -2947,6 +2948,8 @@ int wk_text_clear(wk_ctx* c) {
 int wk_dtok_subject_map(wk_ctx* c, const int32_t* map, int32_t n) {
     if (!c || n < 0 || (n > 0 && !map)) return WK_E_ARG;
     DeviceGuard guard(c->device);
+    c->dt_submap_on = map != nullptr;  // (an empty map that is there: no name has been met yet)
+    if (map && n == 0) HIP_TRY(c, c->d_submap.reserve(64));
     bool excl = false;
     if (n > 0) {
         for (int32_t i = 0; i < n; ++i) {
@@ -2991,7 +2994,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     c->dt_extra = extra != 0;
     // (an exclusion set: the plain flavour takes it as kLineExcluded entries of the subject map, wk_dtok_subject_map;
     // the "ex" parsers' way with it -- align.py:481-547 yields a stale pool at the end of a file -- stays the host's)
-    if (!wkx_tok_device_ok(tok) && (extra || c->dt_submap_n == 0)) return WK_OK;
+    if (!wkx_tok_device_ok(tok) && (extra || !c->dt_submap_on)) return WK_OK;
     if (extra && c->dt_fmt == WK_FMT_MAP) return WK_OK;  // (a simple map has no "ex" flavour, align.py:236)
     const int64_t n64 = stop - begin;
     if (n64 >= (1ll << 31) - 64) return WK_OK;
@@ -3171,7 +3174,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             fa.unknown_cap = (uint32_t)(c->d_unknown.cap / 8);
             fa.state = c->d_state.as<DtokState>();
             fa.ablate = c->fused_ablate;
-            fa.submap = c->dt_submap_n ? c->d_submap.as<int32_t>() : nullptr;
+            fa.submap = c->dt_submap_on ? c->d_submap.as<int32_t>() : nullptr;
             fa.n_submap = c->dt_submap_n;
             c->w_counts_known = false;
             HIP_TRY(c, c->w_backup.reserve(kMaxStreams * 8));

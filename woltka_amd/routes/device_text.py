@@ -983,15 +983,7 @@ class DeviceTextRoute:
                             groups=self._dstrata is not None)
                     return
                 if fresh:
-                    base = self._tok_map.size
-                    if self._dtrimsub:      # (workflow.py:840-841)
-                        fresh = [x.rsplit(self._dtrimsub, 1)[0] for x in fresh]
-                    ids = np.asarray(self.subjects.intern_many(fresh),
-                                     dtype=np.int32)
-                    if self._tok_identity and not np.array_equal(
-                            ids, np.arange(base, base + ids.size)):
-                        self._tok_identity = False
-                    self._tok_map = np.concatenate([self._tok_map, ids])
+                    self._map_fresh(fresh)
                 if not self._tok_identity and \
                         self._tok_map_sent != self._tok_map.size:
                     # names that are not subjects (`--trim-sub`: several
@@ -1100,6 +1092,32 @@ class DeviceTextRoute:
                 file=sys.stderr)
             self._dtok_lap = {}
 
+    EXCLUDED = -4       # (kLineExcluded, csrc/wk_dtok.hpp)
+
+    def _map_fresh(self, fresh):
+        """Names the tokenizer has met for the first time -> `_tok_map`: the
+        index of the subject each stands for (`--trim-sub`: the name cut at
+        its last separator, workflow.py:840-841), or EXCLUDED for a name of
+        the `--exclude` set (which never becomes a subject: a query that hits
+        it is dropped whole, align.py:47-115)."""
+        base = self._tok_map.size
+        excl = self._dexclude
+        if excl:
+            kept = [x for x in fresh if x not in excl]
+        else:
+            kept = fresh
+        names = [x.rsplit(self._dtrimsub, 1)[0] for x in kept] \
+            if self._dtrimsub else kept
+        ids = np.asarray(self.subjects.intern_many(names), dtype=np.int32)
+        if excl and len(kept) != len(fresh):
+            full = np.full(len(fresh), self.EXCLUDED, dtype=np.int32)
+            full[[i for i, x in enumerate(fresh) if x not in excl]] = ids
+            ids = full
+        if self._tok_identity and (excl or not np.array_equal(
+                ids, np.arange(base, base + ids.size))):
+            self._tok_identity = False
+        self._tok_map = np.concatenate([self._tok_map, ids])
+
     def _host_block(self, buf, fill, first, final, hdr_in, ordinal=False,
                     names=False, groups=False):
         """One block of the device route through the host tokenizer after
@@ -1139,14 +1157,7 @@ class DeviceTextRoute:
                         final=final, fmt=self._dfmt, want_names=names)
         fresh = tok.new_subjects()
         if fresh:
-            base = self._tok_map.size
-            if self._dtrimsub:
-                fresh = [x.rsplit(self._dtrimsub, 1)[0] for x in fresh]
-            ids = np.asarray(self.subjects.intern_many(fresh), dtype=np.int32)
-            if self._tok_identity and not np.array_equal(
-                    ids, np.arange(base, base + ids.size)):
-                self._tok_identity = False
-            self._tok_map = np.concatenate([self._tok_map, ids])
+            self._map_fresh(fresh)
         if res['off'].size > 1:
             subj = res['subj'] if self._tok_identity \
                 else self._tok_map[res['subj']]

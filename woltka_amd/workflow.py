@@ -467,7 +467,9 @@ def classify(
                         # (`--trim-sub`: the device text route translates the
                         # names it meets into subjects; the host tokenizer's
                         # words cannot)
-                        words_dev = plain and bool(trimsub) and \
+                        # (`--exclude`: the names of the set get no subject
+                        # index, so the tokenizer's ids are none either)
+                        words_dev = plain and bool(trimsub or exclude) and \
                             engine.words_eligible(identity=False)
                         # read maps of plain assigners, one sample per file:
                         # the lines are formatted on the device next to the
