@@ -55,6 +55,8 @@ struct DtokState {  // device scalars of one block
     unsigned long long n_out;    // words emitted by dtok_emit
     unsigned long long n_reads;  // reads (non-empty mate groups) emitted
     unsigned long long n_lines;  // (dtok_fused_kernel) newlines of the block
+    unsigned int done;           // (dtok_fused_kernel) workgroups through: the last one reports and clears
+    unsigned int pad_;
 };
 
 struct DictSlot {

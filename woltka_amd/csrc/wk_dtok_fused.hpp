@@ -11,7 +11,8 @@
 // 23 | size << 27, wk_weigh.hpp).  Per-line arrays never leave LDS; the text is
 // read from HBM once.
 //
-// Tiles and ownership.  The text of a block is cut into tiles of kFzTile bytes.  A
+// Tiles and ownership.  The text of a block is cut into tiles of at most kFzTile bytes
+// (so many that every workgroup gets the same number of them: FusedArgs::tile).  A
 // run of equal QNAMEs belongs to the tile its first line starts in; the workgroup
 // of a tile therefore looks kFzBack bytes back (the line before its first one:
 // does that one continue a run?) and kFzFwd bytes ahead (the rest of its last
@@ -60,6 +61,7 @@ struct FusedArgs {
     uint32_t n;
     uint32_t open_end;          // the text's last byte is no newline: a line ends at n
     uint32_t n_tiles;
+    uint32_t tile;              // bytes per tile (a multiple of 16, <= kFzTile): the block in equal shares of the workgroups' rounds
     const struct DictSlot8* dict8;
     const uint4* names16;       // by id
     uint32_t dict_mask;
@@ -67,6 +69,8 @@ struct FusedArgs {
     uint2* unknown;
     uint32_t unknown_cap;
     DtokState* state;
+    DtokState* host_state;               // pinned host memory: the block's scalars, written by the last workgroup
+    unsigned long long* backup_next;     // [kMaxStreams] the streams' cursors behind this block (= in front of the next)
     StreamSet streams;
     const int32_t* submap;      // tokenizer id -> subject index, when they differ (`--trim-sub`), or null
     uint32_t n_submap;
@@ -76,7 +80,7 @@ struct FusedArgs {
 // the streams' cursors put aside and the block's scalars cleared, in front of the fused kernel on its stream
 __global__ void dtok_fused_begin_kernel(unsigned long long* __restrict__ backup, const unsigned long long* __restrict__ cursor, DtokState* state) {
     if (threadIdx.x < (uint32_t)kMaxStreams) backup[threadIdx.x] = cursor[threadIdx.x];
-    if (threadIdx.x == 0) *state = DtokState{0u, 0u, 0ull, 0ull};
+    if (threadIdx.x == 0) *state = DtokState{0u, 0u, 0ull, 0ull, 0ull, 0u, 0u};
 }
 
 // 16 aligned bytes of the text, read once: kept out of the way of what the L2 should hold (the dictionary)
@@ -270,10 +274,10 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
     };
 
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint32_t t0 = tile * kFzTile;
-        const uint32_t t1 = min(t0 + kFzTile, a.n);
+        const uint32_t t0 = tile * a.tile;
+        const uint32_t t1 = min(t0 + a.tile, a.n);
         const uint32_t w0 = t0 >= kFzBack ? t0 - kFzBack : 0u;
-        const uint32_t w1 = min(w0 + kFzWin, text_end);     // text positions [w0, w1) are looked at
+        const uint32_t w1 = min(t0 + a.tile + kFzFwd, text_end);  // text positions [w0, w1) are looked at
         const bool to_end = w1 == text_end;                  // every line from here to the end of the text is whole
         __syncthreads();  // (the tile before is through with the arrays)
         if (tid < 2u) own[tid] = 0xFFFFFFFFu;
@@ -287,7 +291,7 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
             const uint32_t cw = r * kWave + lane;
             const uint32_t p = w0 + (wave * kFzChunksPerWave + cw) * 16u;
             v[r] = make_uint4(0u, 0u, 0u, 0u);
-            if (cw < kFzChunksPerWave && p < a.n) v[r] = fz_load_stream(a.text + p);  // (may pass n: the text's pad)
+            if (cw < kFzChunksPerWave && p < a.n && p < w1) v[r] = fz_load_stream(a.text + p);  // (may pass n: the text's pad)
         }
         uint32_t marks[kFzRounds];
         uint32_t nl_mine = 0;
@@ -591,6 +595,28 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
         if (nreads) atomicAdd(&a.state->n_reads, nreads);
         if (nlines) atomicAdd(&a.state->n_lines, nlines);
         if (wg_flags) atomicOr(&a.state->flags, wg_flags);
+        // The last workgroup through does what two more launches used to: the block's scalars to pinned host memory
+        // (the host reads them once the stream has been waited for), the streams' cursors put aside as the next
+        // block's "before", the scalars cleared for it.
+        __threadfence();
+        own[0] = atomicAdd(&a.state->done, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (own[0]) {
+        __threadfence();
+        if (tid < (uint32_t)kMaxStreams)
+            a.backup_next[tid] = __hip_atomic_load(&a.streams.cursor[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            DtokState st{};
+            st.flags = __hip_atomic_load(&a.state->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st.n_unknown = __hip_atomic_load(&a.state->n_unknown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st.n_out = __hip_atomic_load(&a.state->n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st.n_reads = __hip_atomic_load(&a.state->n_reads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st.n_lines = __hip_atomic_load(&a.state->n_lines, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *a.host_state = st;
+            *a.state = DtokState{0u, 0u, 0ull, 0ull, 0ull, 0u, 0u};
+            __threadfence_system();
+        }
     }
 }
 

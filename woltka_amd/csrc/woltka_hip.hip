@@ -245,7 +245,11 @@ struct wk_ctx {
     DevBuf c_words;   // (per-read stream, w_mode != 0: one buffer, reads contiguous)
     // weighted histogram (w_mode 0): the records by slice of the subject table (wk_weigh.hpp), appended through device
     // cursors; unsliced (more than kMaxStreams slices) = one stream for the team kernel
-    DevBuf w_stream[kMaxStreams], w_cursor, w_stage, w_backup;
+    DevBuf w_stream[kMaxStreams], w_cursor, w_stage, w_backup, w_backup2;
+    void* w_backup_cur = nullptr;   // the cursors in front of the block emitted last (what a block that is not kept restores)
+    bool fz_chain = false;          // the one-kernel tokenizer's last launch left the next block's "before" and cleared scalars behind
+    int fz_parity = 0;              // ... in w_backup (0) / w_backup2 (1)
+    bool fz_no_chain = false;       // (measurement, WOLTKA_FZ_NO_CHAIN=1: the small kernel in front of every block)
     int w_streams = 0;              // streams the open accumulation writes to
     bool w_sliced = false;
     bool w_counts_known = false;    // w_count holds the cursors' values
@@ -830,6 +834,7 @@ static int words_reset(wk_ctx* c) {
     c->w_expect = 0;
     c->w_open = false;
     c->w_counts_known = false;
+    c->fz_chain = false;
     if (c->w_cursor.p) HIP_TRY(c, hipMemsetAsync(c->w_cursor.p, 0, kMaxStreams * 8, c->stream));
     return WK_OK;
 }
@@ -972,6 +977,7 @@ int wk_create(int device, wk_ctx** out) {
     // (measurement: WOLTKA_NO_FUSED=1 keeps every block of the text route on the six kernels of wk_dtok.hpp, for
     // whole `woltka classify` calls that cannot reach wk_tune)
     if (const char* nf = getenv("WOLTKA_NO_FUSED")) c->use_fused = (nf[0] && nf[0] != '0') ? 0 : 1;
+    if (const char* nc = getenv("WOLTKA_FZ_NO_CHAIN")) c->fz_no_chain = nc[0] && nc[0] != '0';
     *out = c;
     return WK_OK;
 }
@@ -989,6 +995,7 @@ void wk_destroy(wk_ctx* c) {
         for (DevBuf* b : {&T.dsparse, &T.dparent, &T.dself, &T.rnode, &T.subj_node, &T.subj_rank}) b->release();
     c->c_words.release();
     for (DevBuf& b : c->w_stream) b.release();
+    c->w_backup2.release();
     for (int q = 0; q < wk_ctx::kTextBufs; ++q) {
         c->d_tiles_k[q].release();
         c->d_tile_off_k[q].release();
@@ -2513,6 +2520,7 @@ int wk_words_append(wk_ctx* c, const uint32_t* words, int64_t n_records, int64_t
     if (!c) return WK_E_ARG;
     if (n_records < 0 || n_reads < 0 || (n_records > 0 && !words)) return fail(c, WK_E_ARG, "bad packed record arguments");
     if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
+    c->fz_chain = false;
     if (slot < -1 || slot >= wk_ctx::kStageSlots) return fail(c, WK_E_ARG, "slot must be -1 or in [0, %d)", wk_ctx::kStageSlots);
     DeviceGuard guard(c->device);
     {
@@ -3165,7 +3173,17 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             fa.text = c->dt_text;
             fa.n = n;
             fa.open_end = open_end ? 1u : 0u;
-            fa.n_tiles = (n + kFzTile - 1) / kFzTile;
+            // (tiles of equal size, as many as make every workgroup's share the same number of rounds: 4096 tiles
+            // of 16 KB over 768 workgroups are 5.33 rounds paid as 6 -- 6 rounds of 14.2 KB tiles do the same work in
+            // 0.89 of the time)
+            const unsigned wgs = (unsigned)(c->prop.multiProcessorCount * c->fused_per_cu);
+            {
+                const uint32_t rounds = (uint32_t)(((uint64_t)n + (uint64_t)wgs * kFzTile - 1) / ((uint64_t)wgs * kFzTile));
+                uint32_t tile = (uint32_t)(((uint64_t)n + (uint64_t)wgs * rounds - 1) / ((uint64_t)wgs * rounds));
+                tile = (tile + 15u) & ~15u;
+                fa.tile = std::min<uint32_t>(kFzTile, std::max<uint32_t>(tile, 4096u));
+            }
+            fa.n_tiles = (n + fa.tile - 1) / fa.tile;
             fa.dict8 = c->d_dict2.as<DictSlot8>();
             fa.names16 = c->d_names16.as<uint4>();
             fa.dict_mask = c->dt_dict_mask;
@@ -3178,17 +3196,27 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             fa.n_submap = c->dt_submap_n;
             c->w_counts_known = false;
             HIP_TRY(c, c->w_backup.reserve(kMaxStreams * 8));
+            HIP_TRY(c, c->w_backup2.reserve(kMaxStreams * 8));
+            // ONE launch per block while blocks follow one another through this kernel: its last workgroup leaves the
+            // cursors as they are behind the block in the other of two buffers -- the next block's "before" --, the
+            // block's scalars in pinned memory and cleared ones on the device.  (Anything else that moves the cursors
+            // or the scalars in between breaks the chain: the small kernel in front, then.)
+            DevBuf& before = c->fz_parity ? c->w_backup2 : c->w_backup;
+            DevBuf& after = c->fz_parity ? c->w_backup : c->w_backup2;
+            fa.backup_next = after.as<unsigned long long>();
+            fa.host_state = reinterpret_cast<DtokState*>(c->host_back);   // (slot 0 of the pinned scratch)
+            c->w_backup_cur = before.p;
             if (res) ktimer_end(c, kt);   // (the count behind a resident block's "copy": its own family)
             KernelTimer* kf = ktimer_begin(c, "dtok_fused");
-            hipLaunchKernelGGL(dtok_fused_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->w_backup.as<unsigned long long>(),
-                               (const unsigned long long*)fa.streams.cursor, fa.state);
-            const unsigned grid = std::min<unsigned>(fa.n_tiles, (unsigned)(c->prop.multiProcessorCount * c->fused_per_cu));
+            if (!c->fz_chain || c->fz_no_chain)
+                hipLaunchKernelGGL(dtok_fused_begin_kernel, dim3(1), dim3(64), 0, c->stream, before.as<unsigned long long>(),
+                                   (const unsigned long long*)fa.streams.cursor, fa.state);
+            const unsigned grid = std::min<unsigned>(fa.n_tiles, wgs);
             hipLaunchKernelGGL(dtok_fused_kernel, dim3(grid), dim3(kFzThreads), 0, c->stream, fa);
             ktimer_end(c, kf);
             HIP_TRY(c, hipGetLastError());
             lap_mark(2);
             DtokState st{};
-            HIP_TRY(c, small_back(c, 0, c->d_state.p, sizeof st));
             {
                 Lap wait(&c->lap_s[2]);
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -3201,7 +3229,9 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             if ((rc = dtok_emit_finish(c, keep, false, st, 0, &nr, &nrec))) return rc;   // (not kept: the cursors go back)
             lap_mark(4);
             c->fused_streak = keep;
+            c->fz_chain = keep;   // (not kept: dtok_emit_finish has put the cursors back)
             if (keep) {
+                c->fz_parity ^= 1;
                 ++c->fused_blocks;
                 lines = (uint32_t)st.n_lines + (open_end ? 1u : 0u);
                 c->dt_lines = lines;
@@ -3353,6 +3383,7 @@ int wk_dtok_scan_emit(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, i
 // waiting in between: `launch` queues the kernels (and, where the records are placed by prefix sums, the copy of their
 // totals), `finish` — once the stream has been waited for — accepts or discards what they wrote.
 static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* totals) {
+    c->fz_chain = false;
     if (c->dt_expect_bytes > 0 && c->w_expect == 0 && c->dt_n > 0) {
         // (a record per line at most; 8 % on top of the first block's rate, never more than the 2^30 a pass holds)
         const double lines = (double)c->dt_expect_bytes * ((double)c->dt_lines / (double)c->dt_n) * 1.08 + (double)c->dt_lines;
@@ -3368,6 +3399,7 @@ static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* to
         // (a block the kernels give up on must leave the streams as they were)
         HIP_TRY(c, c->w_backup.reserve(kMaxStreams * 8));
         a.cursor_backup = c->w_backup.as<unsigned long long>();  // (copied by dtok_runs_kernel)
+        c->w_backup_cur = c->w_backup.p;
     } else {
         a.out = c->c_words.as<uint32_t>() + c->w_records;
         a.out_cap = c->dt_lines;
@@ -3426,7 +3458,8 @@ static int dtok_emit_finish(wk_ctx* c, bool keep, bool ordered, DtokState st, un
     }
     if (!keep) {
         if (c->w_mode == 0) {
-            HIP_TRY(c, hipMemcpyAsync(c->w_cursor.p, c->w_backup.p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
+            c->fz_chain = false;
+            HIP_TRY(c, hipMemcpyAsync(c->w_cursor.p, c->w_backup_cur, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
         return WK_OK;
