@@ -1567,6 +1567,15 @@ def e2e_roofline(leg, device, text_bytes=None):
                            'peak_source': 'wk_h2d_rate: pinned 64 MB copies '
                                           'back to back, this box, this run',
                            'floor_s': round(nbytes / peak, 3)}
+        if got > peak:
+            # (SAM lines with columns the parsers do not read are cut behind
+            # RNAME / CIGAR on the host, csrc/wk_trim.inc: the link carries a
+            # fraction of the file and does not bound the call -- the scan of
+            # the file out of the page cache does)
+            leg['roofline'].update(
+                bound='host_scan', frac=None, floor_s=None,
+                note='file text per second through the host\'s column trim; '
+                     'the link (peak) carried only the kept columns')
     except Exception as e:      # noqa: BLE001 - a side figure
         leg['roofline'] = {'error': repr(e)}
     return leg
