@@ -1,6 +1,6 @@
 #!/bin/bash
 # What a cold `woltka classify` process pays before its first alignment byte moves.
-t() { local s=$(date +%s.%N); "$@" > /dev/null 2>&1; local e=$(date +%s.%N); printf "%-70s %.3f s\n" "$*" $(echo "$e - $s" | bc); }
+t() { local s=$(date +%s%N); "$@" > /dev/null 2>&1; local e=$(date +%s%N); printf "%-86s %6d ms\n" "$*" $(( (e - s) / 1000000 )); }
 for i in 1 2; do
 t python -c "pass"
 t python -c "import numpy"
