@@ -65,6 +65,17 @@ struct DictSlot {
     uint32_t off;
 };
 
+// The same dictionary in a form that costs two requests per probe instead of fifteen: slots of 8 bytes {high half of
+// the name's hash, id}, and the names by id in 16-byte records (up to 15 bytes + the length in the last byte; longer
+// names: 0xFF there and their arena offset in the first word).  It matters when few subjects take most of the lines
+// (config 5: 5 000 genomes under a Zipf law): every wave then asks for the same few cache lines, which one L2
+// channel serves one request at a time -- with a byte-wise compare against the arena (a request per byte and wave)
+// dtok_parse took 330 us per block on such text against 80 us on config 3's.
+struct DictSlot8 {
+    uint32_t hash_hi;
+    int32_t id;  // -1 = empty
+};
+
 struct DtokArgs {
     const unsigned char* text;  // [n] + 64 readable bytes behind
     uint32_t n;
@@ -76,6 +87,8 @@ struct DtokArgs {
     const DictSlot* dict;
     uint32_t dict_mask;
     const unsigned char* arena;  // [len:4][bytes] per name
+    const DictSlot8* dict8;      // (the same slots, 8 bytes each)
+    const uint4* names16;        // by id
     uint2* unknown;              // (offset, length) of RNAMEs not in the dictionary
     uint32_t unknown_cap;
     unsigned char* is_start;     // [n_lines]
@@ -246,21 +259,45 @@ __device__ __forceinline__ unsigned long long dtok_hash(const unsigned char* p, 
     return h ^ (h >> 32);
 }
 
-// the subject text[rb, rb + rn) in the dictionary: its id, or kLineUnknown (and the name listed for the host)
+__device__ __forceinline__ unsigned long long dtok_load64(const unsigned char* p) {
+    unsigned long long w;
+    __builtin_memcpy(&w, p, 8);  // (gfx950: one load whatever the alignment, LDS or global)
+    return w;
+}
+__device__ __forceinline__ unsigned long long dtok_low_bytes(unsigned long long w, uint32_t k) {
+    return k >= 8u ? w : (w & ((1ull << (8u * k)) - 1ull));
+}
+
+// the subject text[rb, rb + rn) in the dictionary: its id, or kLineUnknown (and the name listed for the host).
+// (The text may be read up to 7 bytes past the name: a tab and the rest of its line follow, or the text's pad.)
 __device__ __forceinline__ int32_t dtok_subject(const DtokArgs& a, uint32_t rb, uint32_t rn) {
-    const unsigned long long hv = dtok_hash(a.text + rb, rn);
+    const unsigned char* name = a.text + rb;
+    const unsigned long long hv = dtok_hash(name, rn);
+    unsigned long long n0 = 0, n1 = 0;
+    if (rn <= 15u) {
+        n0 = dtok_low_bytes(dtok_load64(name), rn);
+        n1 = (rn > 8u ? dtok_low_bytes(dtok_load64(name + 8), rn - 8u) : 0ull) | ((unsigned long long)rn << 56);
+    }
     uint32_t h = (uint32_t)hv & a.dict_mask;
     int32_t id = kLineUnknown;
     for (;;) {
-        const DictSlot s = a.dict[h];
-        if (s.id < 0) break;
-        if (s.hash == hv) {
-            const unsigned char* nm = a.arena + s.off;
-            const uint32_t ln = (uint32_t)nm[0] | ((uint32_t)nm[1] << 8) | ((uint32_t)nm[2] << 16) | ((uint32_t)nm[3] << 24);
-            bool same = ln == rn;
-            for (uint32_t k = 0; same && k < rn; ++k) same = nm[4 + k] == a.text[rb + k];
+        const uint2 slot = reinterpret_cast<const uint2*>(a.dict8)[h];
+        if ((int32_t)slot.y < 0) break;
+        if (slot.x == (uint32_t)(hv >> 32)) {
+            const uint4 nm = a.names16[(int32_t)slot.y];
+            bool same;
+            if (rn <= 15u) {
+                same = ((((unsigned long long)nm.y << 32) | nm.x) == n0) && ((((unsigned long long)nm.w << 32) | nm.z) == n1);
+            } else {
+                same = (nm.w >> 24) == 0xFFu;
+                if (same) {
+                    const unsigned char* full = a.arena + nm.x;  // [len:4][bytes]
+                    same = ((uint32_t)full[0] | ((uint32_t)full[1] << 8) | ((uint32_t)full[2] << 16) | ((uint32_t)full[3] << 24)) == rn;
+                    for (uint32_t k = 0; same && k < rn; ++k) same = full[4 + k] == name[k];
+                }
+            }
             if (same) {
-                id = s.id;
+                id = (int32_t)slot.y;
                 break;
             }
         }

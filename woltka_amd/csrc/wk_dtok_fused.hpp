@@ -138,17 +138,10 @@ __device__ __forceinline__ bool fz_same(const unsigned char* x, const unsigned c
     return n == 0u || fz_low_bytes(fz_load64(x) ^ fz_load64(y), n) == 0ull;
 }
 
-// The dictionary as this kernel probes it.  A block makes 1.9 M probes; with 16- or 32-byte slots (4-8 MB for 100 k
-// subjects) next to 8 MB of text streaming through each XCD's 4 MB of L2 nearly every probe missed the L2 and moved a
-// 128-byte line -- 240 MB per 64 MB block, a quarter of the kernel's time.  So: slots of 8 bytes {high half of the
-// name's hash, id} (2 MB: they stay in the L2), the names by id in 16-byte records (up to 15 bytes + the length in
-// the last byte; longer names: 0xFF there and their arena offset in the first word), and the text loaded as
-// non-temporal, which it is.
-struct DictSlot8 {
-    uint32_t hash_hi;
-    int32_t id;  // -1 = empty
-};
-
+// The dictionary as this kernel probes it: DictSlot8 + the names by id (wk_dtok.hpp).  (On config 3's text, 100 k
+// subjects met evenly, the probe's time did not depend on the slots' size -- 16-byte slots + arena, 32-byte slots with
+// the name inside, 8-byte slots + names by id all gave 27 us of a block's 125: it is two dependent trips to the L2 /
+// the fabric either way.  The compact form is kept for text whose lines name few subjects, see there.)
 // The subject name[0, rn) (in LDS) in the dictionary: its id, or kLineUnknown and the name listed for the host.  In
 // two halves, so that the first slot's trip to memory is under way while the caller does something else.
 struct FzProbe {

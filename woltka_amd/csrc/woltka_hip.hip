@@ -2640,6 +2640,8 @@ static DtokArgs dtok_args(wk_ctx* c) {
     a.dict = c->d_dict.as<DictSlot>();
     a.dict_mask = c->dt_dict_mask;
     a.arena = c->d_arena.as<unsigned char>();
+    a.dict8 = c->d_dict2.as<DictSlot8>();
+    a.names16 = c->d_names16.as<uint4>();
     a.unknown = c->d_unknown.as<uint2>();
     a.unknown_cap = (uint32_t)(c->d_unknown.cap / 8);
     a.is_start = c->d_start.as<unsigned char>();
