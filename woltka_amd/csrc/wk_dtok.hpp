@@ -256,7 +256,9 @@ __device__ __forceinline__ unsigned long long dtok_hash(const unsigned char* p, 
     unsigned long long v = 0;
     for (uint32_t i = 0; i < n; ++i) v |= (unsigned long long)p[i] << (8 * i);
     h = (h ^ v) * 0x100000001b3ull;
-    return h ^ (h >> 32);
+    h ^= h >> 32;
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
 }
 
 __device__ __forceinline__ unsigned long long dtok_load64(const unsigned char* p) {

@@ -124,7 +124,9 @@ __device__ __forceinline__ unsigned long long fz_hash(const unsigned char* p, ui
     }
     const unsigned long long v = n ? fz_low_bytes(fz_load64(p), n) : 0ull;
     h = (h ^ v) * 0x100000001b3ull;
-    return h ^ (h >> 32);
+    h ^= h >> 32;
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
 }
 
 // are the n bytes at x and y equal?  (both readable 7 bytes past their ends)

@@ -21,7 +21,13 @@ inline uint64_t hash_bytes(const char* p, size_t n) {
     uint64_t v = 0;
     memcpy(&v, p, n);
     h = (h ^ v) * 0x100000001b3ull;
-    return h ^ (h >> 32);
+    // (an avalanche at the end: names shorter than eight bytes go through the one multiply above only, and the low
+    // bits of a product depend on the low bits of its factors alone -- 5 000 names "G000000" .. "G004999" had 500
+    // distinct home slots in a table of 16 384, 22 probes per look-up on average, 180 at most: the 4x slower
+    // dtok_parse on config 5's text that round 5 left "not understood".  With this: 1.2 probes, 10 at most.)
+    h ^= h >> 32;
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
 }
 
 // End of [b, e) after Python's str.rstrip() on the UTF-8 text: every character
