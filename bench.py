@@ -705,13 +705,34 @@ class TextLcaWorkload:
         ctx, tok = self.ctx, self.tok
         if not ctx.words_begin(self.jobs, 0):
             raise RuntimeError('words_begin refused')
-        reads = 0
+        # (as `Engine._device_chunks` does it: a block's verdict is read
+        # when the next block's kernel has been queued -- wk_dtok_scan_emit_
+        # begin / _end --, a block that way refuses goes the one-call way)
+        reads, lag = 0, []
+        lagging = not os.environ.get('WOLTKA_NO_LAG')
+
+        def settle(leave):
+            got = 0
+            while len(lag) > leave:
+                res = ctx.dtok_scan_emit_end()
+                if res is None:
+                    raise RuntimeError('a resident block was handed back')
+                got += res[1]
+                tok.set_header_state(lag.pop(0))
+            return got
+
         for view, begin, stop, hdr in self.blocks:
+            if lagging and ctx.dtok_scan_emit_begin(tok, view, begin, stop):
+                lag.append(hdr)
+                reads += settle(1)
+                continue
+            reads += settle(0)
             status, _, done = ctx.dtok_scan_emit(tok, view, begin, stop)
             if status != 0 or done is None:
                 raise RuntimeError('a resident block was refused')
             reads += done
             tok.set_header_state(hdr)
+        reads += settle(0)
         ctx.words_flush()
         if reads != self.reads:
             raise RuntimeError(f'{reads} reads emitted, {self.reads} expected')

@@ -344,6 +344,24 @@ int wk_dtok_emit(wk_ctx* ctx, int64_t* n_reads, int64_t* n_records,
 int wk_dtok_scan_emit(wk_ctx* ctx, wk_tok* tok, const char* text, int64_t begin,
                       int64_t stop, int64_t* n_lines, int* status, int* emitted,
                       int64_t* n_reads, int64_t* n_records);
+/* The same with the verdict read one block late, so that the device goes from
+ * one block's kernel to the next without waiting for the host (the reference
+ * has no counterpart: align.py:86-128 yields a chunk at a time).  _begin
+ * launches the block's one-kernel tokenizer and returns; *started = 0: the
+ * block is not one for this way right now (not copied ahead, not the plain
+ * SAM flavour, two blocks under way already, the sample's buffers to be grown
+ * or rolled first ...) and nothing has happened -- wk_dtok_scan_emit takes it
+ * once the blocks under way have been read.  _end waits for the OLDEST block
+ * under way.  *status 0: its records are appended (*n_lines, *n_reads,
+ * *n_records as wk_dtok_scan_emit reports them).  *status 2: the kernel handed
+ * the block back; neither it nor the block launched behind it has left a
+ * record, none is under way any more, and both are found by wk_dtok_scan_emit
+ * as blocks copied ahead.  wk_words_flush, wk_words_append and the scans
+ * refuse (WK_E_STATE) while a block is under way. */
+int wk_dtok_scan_emit_begin(wk_ctx* ctx, wk_tok* tok, const char* text,
+                            int64_t begin, int64_t stop, int* started);
+int wk_dtok_scan_emit_end(wk_ctx* ctx, int64_t* n_lines, int* status,
+                          int64_t* n_reads, int64_t* n_records);
 /* ---- strata map on the device (csrc/wk_strata.hpp) -------------------------
  * workflow.read_strata + the lookups of classify.counter_strat (workflow.py:
  * 912-938, file.py:368-385, classify.py:216-249) for samples the device

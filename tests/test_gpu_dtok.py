@@ -873,6 +873,55 @@ def test_one_kernel_tokenizer_equals_the_six(tmp_path, monkeypatch, shape,
             assert fused >= 4 * max(back, 1), routes_a
 
 
+@pytest.mark.parametrize('shape', ['plain', 'long_runs', 'late_subjects'])
+def test_verdicts_read_one_block_late(tmp_path, monkeypatch, shape):
+    """`wk_dtok_scan_emit_begin` / `_end`: a block's verdict is read when the
+    next block's kernel is queued.  Same tables and log as with every verdict
+    read at once (WOLTKA_NO_LAG) and as the host tokenizer's; a block handed
+    back with another one under way behind it (subjects that first appear late
+    in the file) takes that one along and both are done again in order."""
+    from woltka_amd import classify as C
+    from woltka_amd.hostio import ROUTES
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', 1 << 17)
+    rng = random.Random(zlib.crc32(f'lag:{shape}'.encode()))
+    tax = os.path.join(ROOT, 'tests', 'golden', 'data', 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        subjects = [ln.split('\t')[0] for ln in f][:90]
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    for s in ('S1', 'S2'):
+        n = 30000 if s == 'S1' else 5000
+        if shape == 'late_subjects':
+            text = _fused_sam(rng, n, subjects[:30], 'plain')
+            for lo in (30, 50, 70):
+                more = _fused_sam(rng, n // 3, subjects[:lo + 20], 'plain')
+                text += more.split('\n', 2)[2]
+        else:
+            text = _fused_sam(rng, n, subjects, shape)
+        (indir / f'{s}.sam').write_text(text)
+    kw = dict(input_fp=str(indir), input_fmt='sam',
+              nodes_fps=[os.path.join(tax, 'nodes.dmp')],
+              map_fps=[os.path.join(tax, 'taxid.map')],
+              ranks='none,phylum,genus')
+    ROUTES.clear()
+    a, log_a = _run(tmp_path, 'lag', False, **kw)
+    routes_a = dict(ROUTES)
+    monkeypatch.setenv('WOLTKA_NO_LAG', '1')
+    ROUTES.clear()
+    b, log_b = _run(tmp_path, 'nolag', False, **kw)
+    routes_b = dict(ROUTES)
+    monkeypatch.delenv('WOLTKA_NO_LAG')
+    h, log_h = _run(tmp_path, 'host', True, **kw)
+    assert a == b == h
+    assert log_a == log_b == log_h
+    assert routes_a.get('dtok_lag', 0) > 0, routes_a
+    assert routes_b.get('dtok_lag', 0) == 0, routes_b
+    if shape == 'late_subjects':
+        assert routes_a.get('dtok_lag_back', 0) > 0, routes_a
+    # (every block went one way or the other, as many as without the lag)
+    assert routes_a.get('dtok', 0) == routes_b.get('dtok', 0)
+
+
 def _with_seq_qual(sam_text, rng, crs=True):
     """Every alignment line of `sam_text` with SEQ / QUAL / tags as an aligner
     writes them (the '*' columns of the generators above filled in); a few

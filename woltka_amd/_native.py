@@ -55,7 +55,8 @@ SYMBOLS = (
     'wk_dtok_format',
     'wk_dtok_copy', 'wk_dtok_copy_ahead', 'wk_dtok_copy_wait',
     'wk_dtok_copy_drop', 'wk_dtok_subject_map', 'wk_dtok_ahead_room', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
-    'wk_dtok_scan_emit', 'wk_dtok_keep_reads', 'wk_readmap_tables',
+    'wk_dtok_scan_emit', 'wk_dtok_scan_emit_begin', 'wk_dtok_scan_emit_end',
+    'wk_dtok_keep_reads', 'wk_readmap_tables',
     'wk_dtok_readmap',
     'wk_dtok_readmap_fetch', 'wk_strata_load', 'wk_strata_labels',
     'wk_strata_groups', 'wk_strata_clear',
@@ -212,6 +213,10 @@ def load_library():
         'wk_dtok_scan_emit': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
                                         i64p, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), i64p, i64p]),
+        'wk_dtok_scan_emit_begin': (C.c_int, [p, p, C.c_void_p, C.c_int64,
+                                              C.c_int64, C.POINTER(C.c_int)]),
+        'wk_dtok_scan_emit_end': (C.c_int, [p, i64p, C.POINTER(C.c_int), i64p,
+                                            i64p]),
         'wk_dtok_keep_reads': (C.c_int, [p, C.c_int]),
         'wk_readmap_tables': (C.c_int, [p, C.c_int32, i32p, C.c_int32, i32p,
                                         u32p, C.c_char_p, C.c_int32]),
@@ -680,6 +685,30 @@ class Context:
             self._h, tok._h, addr, int(begin), int(stop), C.byref(n),
             C.byref(st), C.byref(em), C.byref(a), C.byref(b)))
         return st.value, n.value, (a.value if em.value else None)
+
+    def dtok_scan_emit_begin(self, tok, buf, begin, stop):
+        """Launch a block's one-kernel tokenizer without waiting for it
+        (``wk_dtok_scan_emit_begin``).  False: not a block for this way right
+        now, nothing has happened."""
+        raw = np.frombuffer(memoryview(buf), dtype=np.uint8)
+        if not raw.size:
+            return False
+        started = C.c_int(0)
+        self._check(self._lib.wk_dtok_scan_emit_begin(
+            self._h, tok._h, C.c_void_p(raw.ctypes.data), int(begin),
+            int(stop), C.byref(started)))
+        return bool(started.value)
+
+    def dtok_scan_emit_end(self):
+        """The verdict of the oldest block under way
+        (``wk_dtok_scan_emit_end``): (n_lines, n_reads) of an appended block,
+        ``None`` when the kernel handed it -- and the block behind it --
+        back."""
+        n, st = C.c_int64(0), C.c_int(1)
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.wk_dtok_scan_emit_end(
+            self._h, C.byref(n), C.byref(st), C.byref(a), C.byref(b)))
+        return (n.value, a.value) if st.value == 0 else None
 
     def text_upload(self, buf, begin, stop):
         """(measurement) ``buf[begin:stop]`` -- a block as the host cuts it --

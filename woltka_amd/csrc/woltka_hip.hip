@@ -248,7 +248,26 @@ struct wk_ctx {
     DevBuf w_stream[kMaxStreams], w_cursor, w_stage, w_backup, w_backup2;
     void* w_backup_cur = nullptr;   // the cursors in front of the block emitted last (what a block that is not kept restores)
     bool fz_chain = false;          // the one-kernel tokenizer's last launch left the next block's "before" and cleared scalars behind
-    int fz_parity = 0;              // ... in w_backup (0) / w_backup2 (1)
+    int fz_parity = 0;              // ... in w_backup (0) / w_backup2 (1) / w_backup3 (2): `fz_bk(i)`
+    DevBuf w_backup3;
+    // blocks of the one-kernel tokenizer whose verdict has not been read yet (wk_dtok_scan_emit_begin / _end): at most
+    // two, oldest first -- the second one's kernel is queued behind the first one's, so that the device never waits
+    // for the host between blocks
+    struct LagSlot {
+        int buf = -1;                // text buffer (-1: a resident block)
+        const char* src = nullptr;   // the block's tag (put back when the block is handed back)
+        uint32_t n = 0;
+        bool open_end = false;
+        int ring = 0;                // fz_bk(ring) = the cursors in front of the block
+        uint32_t lines_est = 0;
+        int host_slot = 0;           // slot of the pinned scratch its scalars land in
+        hipEvent_t ev = nullptr;
+    };
+    LagSlot lag[2];
+    int lag_count = 0;
+    hipEvent_t lag_ev[2] = {nullptr, nullptr};
+    int lag_next_ev = 0;
+    bool lag_enabled = true;        // (WOLTKA_NO_LAG=1: every block's verdict is read before the next is launched)
     bool fz_no_chain = false;       // (measurement, WOLTKA_FZ_NO_CHAIN=1: the small kernel in front of every block)
     int w_streams = 0;              // streams the open accumulation writes to
     bool w_sliced = false;
@@ -342,7 +361,7 @@ struct wk_ctx {
     // kernels of the block scanned last read (until the next scan begins).  wk_dtok_copy may be called
     // from another thread than the scans (the host layer's reader thread issues the copies as soon as a
     // block is cut): the states and tags are guarded by copy_mu.
-    enum : unsigned char { kBufFree = 0, kBufCopied = 1, kBufScanning = 2 };
+    enum : unsigned char { kBufFree = 0, kBufCopied = 1, kBufScanning = 2, kBufPending = 3 };
     unsigned char buf_state[kTextBufs] = {};
     std::mutex copy_mu;
     std::mutex slab_mu;   // a slab is allocated by whoever needs one of its buffers first
@@ -978,6 +997,7 @@ int wk_create(int device, wk_ctx** out) {
     // whole `woltka classify` calls that cannot reach wk_tune)
     if (const char* nf = getenv("WOLTKA_NO_FUSED")) c->use_fused = (nf[0] && nf[0] != '0') ? 0 : 1;
     if (const char* nc = getenv("WOLTKA_FZ_NO_CHAIN")) c->fz_no_chain = nc[0] && nc[0] != '0';
+    if (const char* nl = getenv("WOLTKA_NO_LAG")) c->lag_enabled = !(nl[0] && nl[0] != '0');
     *out = c;
     return WK_OK;
 }
@@ -996,6 +1016,9 @@ void wk_destroy(wk_ctx* c) {
     c->c_words.release();
     for (DevBuf& b : c->w_stream) b.release();
     c->w_backup2.release();
+    c->w_backup3.release();
+    for (hipEvent_t& e : c->lag_ev)
+        if (e) (void)hipEventDestroy(e);
     for (int q = 0; q < wk_ctx::kTextBufs; ++q) {
         c->d_tiles_k[q].release();
         c->d_tile_off_k[q].release();
@@ -2142,6 +2165,7 @@ static bool same_jobs(const std::vector<wk_job>& have, const wk_job* jobs, int32
 
 int wk_words_flush(wk_ctx* c) {
     if (!c) return WK_E_ARG;
+    if (c->lag_count) return fail(c, WK_E_STATE, "blocks whose verdict has not been read (wk_dtok_scan_emit_end)");
     if (!c->w_open || c->w_records == 0) return words_reset(c);
     if (!c->slots) return fail(c, WK_E_STATE, "count table not reserved (wk_counts_reserve)");
     DeviceGuard guard(c->device);
@@ -2520,6 +2544,7 @@ int wk_words_append(wk_ctx* c, const uint32_t* words, int64_t n_records, int64_t
     if (!c) return WK_E_ARG;
     if (n_records < 0 || n_reads < 0 || (n_records > 0 && !words)) return fail(c, WK_E_ARG, "bad packed record arguments");
     if (!c->w_open) return fail(c, WK_E_STATE, "wk_words_begin has not accepted a job set");
+    if (c->lag_count) return fail(c, WK_E_STATE, "blocks whose verdict has not been read (wk_dtok_scan_emit_end)");
     c->fz_chain = false;
     if (slot < -1 || slot >= wk_ctx::kStageSlots) return fail(c, WK_E_ARG, "slot must be -1 or in [0, %d)", wk_ctx::kStageSlots);
     DeviceGuard guard(c->device);
@@ -2986,6 +3011,8 @@ int wk_dtok_format(wk_ctx* c, int fmt) {
     return WK_OK;
 }
 
+static DevBuf& fz_bk(wk_ctx* c, int i) { return i == 0 ? c->w_backup : i == 1 ? c->w_backup2 : c->w_backup3; }
+
 static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* totals);
 static int dtok_emit_finish(wk_ctx* c, bool keep, bool ordered, DtokState st, unsigned long long totals, int64_t* n_reads,
                             int64_t* n_records);
@@ -2997,6 +3024,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
                           int* emit, int64_t* emitted) {
     if (!c || !tok || !text || begin < 0 || stop < begin || !n_lines || !status) return WK_E_ARG;
     if (emit) *emit = 0;
+    if (c->lag_count) return fail(c, WK_E_STATE, "blocks whose verdict has not been read (wk_dtok_scan_emit_end)");
     Lap lap(&c->lap_s[1]);
     *status = 1;
     *n_lines = 0;
@@ -3203,8 +3231,9 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             // cursors as they are behind the block in the other of two buffers -- the next block's "before" --, the
             // block's scalars in pinned memory and cleared ones on the device.  (Anything else that moves the cursors
             // or the scalars in between breaks the chain: the small kernel in front, then.)
-            DevBuf& before = c->fz_parity ? c->w_backup2 : c->w_backup;
-            DevBuf& after = c->fz_parity ? c->w_backup : c->w_backup2;
+            HIP_TRY(c, c->w_backup3.reserve(kMaxStreams * 8));
+            DevBuf& before = fz_bk(c, c->fz_parity);
+            DevBuf& after = fz_bk(c, (c->fz_parity + 1) % 3);
             fa.backup_next = after.as<unsigned long long>();
             fa.host_state = reinterpret_cast<DtokState*>(c->host_back);   // (slot 0 of the pinned scratch)
             c->w_backup_cur = before.p;
@@ -3233,7 +3262,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             c->fused_streak = keep;
             c->fz_chain = keep;   // (not kept: dtok_emit_finish has put the cursors back)
             if (keep) {
-                c->fz_parity ^= 1;
+                c->fz_parity = (c->fz_parity + 1) % 3;
                 ++c->fused_blocks;
                 lines = (uint32_t)st.n_lines + (open_end ? 1u : 0u);
                 c->dt_lines = lines;
@@ -3365,6 +3394,188 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
         lap_mark(5);
     }
     return fail(c, WK_E_STATE, "device tokenizer: subjects still unknown after interning them");
+}
+
+// ---- the verdict of a block read one block late ------------------------------------------------------------------
+// wk_dtok_scan_emit waits for a block's kernel before the next block's is launched: the device idles while the host
+// wakes up, reads the verdict and launches again (14 of a block's 138 us with the text resident).  _begin launches a
+// block's one-kernel tokenizer and returns; _end waits for the OLDEST block launched that way and says what became of
+// it.  With two blocks under way the second one's kernel starts the moment the first one's ends.  A block the kernel
+// hands back (*status = 2) has left no record -- nor has the block launched behind it, which is forgotten: the caller
+// scans both again the synchronous way (their text is where it was).
+int wk_dtok_scan_emit_begin(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int* started) {
+    if (!c || !tok || !text || begin < 0 || stop < begin || !started) return WK_E_ARG;
+    *started = 0;
+    const int64_t n64 = stop - begin;
+    if (!c->lag_enabled || !c->use_fused || c->lag_count >= 2 || c->dt_fmt != WK_FMT_SAM || !c->w_open || c->w_mode != 0 || c->dt_keep_reads ||
+        n64 <= 0 || n64 >= (1ll << 31) - 64 || wkx_tok_n_names(tok) >= (1 << 23) - 1)
+        return WK_OK;
+    if (!wkx_tok_device_ok(tok) && !c->dt_submap_on) return WK_OK;
+    if (c->dt_expect_bytes > 0 && c->w_expect == 0) return WK_OK;   // (the sample's buffers are sized from a counted block)
+    if (c->lag_count > 0 && !c->fz_chain) return WK_OK;
+    DeviceGuard guard(c->device);
+    const uint32_t n = (uint32_t)n64;
+    const char* src = text + begin;
+    const wk_ctx::ResidentText* res = nullptr;
+    for (const wk_ctx::ResidentText& r : c->resident)
+        if (r.host == src && r.n == n) res = &r;
+    int k = -1;
+    uint32_t lines = 0;
+    bool open_end;
+    {
+        std::lock_guard<std::mutex> lock(c->copy_mu);
+        if (c->lag_count == 0)
+            for (int q = 0; q < wk_ctx::kTextBufs; ++q)
+                if (c->buf_state[q] == wk_ctx::kBufScanning) c->buf_state[q] = wk_ctx::kBufFree;
+        if (!res) {
+            for (int q = 0; q < wk_ctx::kTextBufs; ++q)
+                if (c->buf_state[q] == wk_ctx::kBufCopied && c->copy_src[q] == src && c->copy_n[q] == n && (k < 0 || c->copy_seq[q] < c->copy_seq[k]))
+                    k = q;
+            if (k < 0) return WK_OK;   // (not copied ahead: the synchronous call copies it)
+        }
+    }
+    if (res) {
+        open_end = src[n - 1] != '\n';
+        lines = (uint32_t)res->n_newlines + (open_end ? 1u : 0u);
+    } else {
+        if (c->dt_lpb <= 0.0) return WK_OK;
+        open_end = c->copy_last[k] != '\n';
+        lines = (uint32_t)std::min((double)n / 7.0 + 1.0, (double)n * c->dt_lpb * 1.25 + 65536.0);
+    }
+    // room for the records of every block under way (none of them is in w_records yet); a buffer that would have to
+    // grow while a kernel appends to it, or a sample that would have to be rolled, waits for the verdicts
+    int64_t under_way = lines;
+    for (int i = 0; i < c->lag_count; ++i) under_way += c->lag[i].lines_est;
+    if (c->w_records + under_way >= (1ll << 30) - (1 << 20)) return WK_OK;
+    if (c->w_sliced && streams_needed(c) > kMaxStreams) return WK_OK;
+    if (c->lag_count == 0) {
+        const int rcw = words_room(c, under_way);
+        if (rcw) return rcw;
+    } else {
+        const int want = c->w_sliced ? streams_needed(c) : 1;
+        const size_t need = (size_t)(c->w_records + under_way) * 4 + 64;
+        bool fits = c->w_cursor.p != nullptr && c->w_streams >= want;
+        for (int q = 0; fits && q < c->w_streams; ++q) fits = need <= c->w_stream[q].cap;
+        if (!fits) return WK_OK;
+    }
+    int rc = dtok_mirror_dict(c, tok);
+    if (rc) return rc;
+    FusedArgs fa{};
+    fa.streams = stream_set(c);
+    if (fa.streams.n_streams > kFzStreams) return WK_OK;
+    if (!res) {
+        std::lock_guard<std::mutex> lock(c->copy_mu);
+        c->buf_state[k] = wk_ctx::kBufPending;
+        c->copy_src[k] = nullptr;
+        c->copy_counted[k] = false;
+    }
+    if (!res) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[k], 0));
+    HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
+    if (c->d_unknown.cap < (size_t)(1 << 20) * 8) HIP_TRY(c, c->d_unknown.reserve((size_t)(1 << 20) * 8));
+    for (int i = 0; i < 3; ++i) HIP_TRY(c, fz_bk(c, i).reserve(kMaxStreams * 8));
+    const unsigned wgs = (unsigned)(c->prop.multiProcessorCount * c->fused_per_cu);
+    fa.text = res ? res->dev : c->d_textptr[k];
+    fa.n = n;
+    fa.open_end = open_end ? 1u : 0u;
+    {
+        const uint32_t rounds = (uint32_t)(((uint64_t)n + (uint64_t)wgs * kFzTile - 1) / ((uint64_t)wgs * kFzTile));
+        uint32_t tile = (uint32_t)(((uint64_t)n + (uint64_t)wgs * rounds - 1) / ((uint64_t)wgs * rounds));
+        tile = (tile + 15u) & ~15u;
+        fa.tile = std::min<uint32_t>(kFzTile, std::max<uint32_t>(tile, 4096u));
+    }
+    fa.n_tiles = (n + fa.tile - 1) / fa.tile;
+    fa.dict8 = c->d_dict2.as<DictSlot8>();
+    fa.names16 = c->d_names16.as<uint4>();
+    fa.dict_mask = c->dt_dict_mask;
+    fa.arena = c->d_arena.as<unsigned char>();
+    fa.unknown = c->d_unknown.as<uint2>();
+    fa.unknown_cap = (uint32_t)(c->d_unknown.cap / 8);
+    fa.state = c->d_state.as<DtokState>();
+    fa.ablate = c->fused_ablate;
+    fa.submap = c->dt_submap_on ? c->d_submap.as<int32_t>() : nullptr;
+    fa.n_submap = c->dt_submap_n;
+    wk_ctx::LagSlot& L = c->lag[c->lag_count];
+    L.buf = res ? -1 : k;
+    L.src = src;
+    L.n = n;
+    L.open_end = open_end;
+    L.ring = c->fz_parity;
+    L.lines_est = lines;
+    L.host_slot = 2 + c->lag_next_ev;
+    if (!c->lag_ev[c->lag_next_ev]) HIP_TRY(c, hipEventCreateWithFlags(&c->lag_ev[c->lag_next_ev], hipEventDisableTiming));
+    L.ev = c->lag_ev[c->lag_next_ev];
+    c->lag_next_ev ^= 1;
+    fa.backup_next = fz_bk(c, (L.ring + 1) % 3).as<unsigned long long>();
+    fa.host_state = reinterpret_cast<DtokState*>(c->host_back + (size_t)L.host_slot * wk_ctx::kBackBytes);
+    c->w_counts_known = false;
+    if (!c->fz_chain || c->fz_no_chain)
+        hipLaunchKernelGGL(dtok_fused_begin_kernel, dim3(1), dim3(64), 0, c->stream, fz_bk(c, L.ring).as<unsigned long long>(),
+                           (const unsigned long long*)fa.streams.cursor, fa.state);
+    hipLaunchKernelGGL(dtok_fused_kernel, dim3(std::min<unsigned>(fa.n_tiles, wgs)), dim3(kFzThreads), 0, c->stream, fa);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(L.ev, c->stream));
+    // (the next block is launched as if this one will be kept: its kernel leaves what that needs behind)
+    c->fz_chain = true;
+    c->fz_parity = (c->fz_parity + 1) % 3;
+    ++c->lag_count;
+    *started = 1;
+    return WK_OK;
+}
+
+// *status: 0 = the oldest block under way has been appended (*n_reads, *n_records, *n_lines), 2 = the kernel handed it
+// back: no block under way has left a record, none is under way any more, and the synchronous calls find their text.
+int wk_dtok_scan_emit_end(wk_ctx* c, int64_t* n_lines, int* status, int64_t* n_reads, int64_t* n_records) {
+    if (!c || !n_lines || !status || !n_reads || !n_records) return WK_E_ARG;
+    if (c->lag_count == 0) return fail(c, WK_E_STATE, "no block under way (wk_dtok_scan_emit_begin)");
+    DeviceGuard guard(c->device);
+    const wk_ctx::LagSlot L = c->lag[0];
+    HIP_TRY(c, hipEventSynchronize(L.ev));
+    DtokState st{};
+    small_back_get(c, L.host_slot, &st, sizeof st);
+    const bool keep = st.flags == 0 && st.n_unknown == 0;
+    *n_lines = *n_reads = *n_records = 0;
+    if (keep) {
+        c->w_backup_cur = fz_bk(c, L.ring).p;
+        c->dt_emitted = false;
+        const int rc = dtok_emit_finish(c, true, false, st, 0, n_reads, n_records);
+        if (rc) return rc;
+        const uint32_t lines = (uint32_t)st.n_lines + (L.open_end ? 1u : 0u);
+        c->dt_lines = lines;
+        c->dt_lpb = (double)lines / (double)L.n;
+        c->fused_streak = true;
+        ++c->fused_blocks;
+        *n_lines = lines;
+        *status = 0;
+        if (L.buf >= 0) {
+            std::lock_guard<std::mutex> lock(c->copy_mu);
+            c->buf_state[L.buf] = wk_ctx::kBufFree;
+        }
+        c->lag[0] = c->lag[1];
+        --c->lag_count;
+        return WK_OK;
+    }
+    // handed back: every kernel under way through, the cursors as they were in front of this block -- which takes the
+    // records of the block behind it along --, the blocks' text findable again
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->w_cursor.p, fz_bk(c, L.ring).p, kMaxStreams * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    {
+        std::lock_guard<std::mutex> lock(c->copy_mu);
+        for (int i = 0; i < c->lag_count; ++i) {
+            const wk_ctx::LagSlot& X = c->lag[i];
+            if (X.buf < 0) continue;
+            c->buf_state[X.buf] = wk_ctx::kBufCopied;
+            c->copy_src[X.buf] = X.src;
+            c->copy_n[X.buf] = X.n;
+            c->copy_counted[X.buf] = false;
+        }
+    }
+    c->lag_count = 0;
+    c->fz_chain = false;
+    c->fused_streak = false;
+    ++c->fused_fallbacks;
+    *status = 2;
+    return WK_OK;
 }
 
 int wk_dtok_scan(wk_ctx* c, wk_tok* tok, const char* text, int64_t begin, int64_t stop, int extra, int64_t* n_lines, int* status) {

@@ -1037,6 +1037,41 @@ class DeviceTextRoute:
                                lap)
         # (a plain file's size tells how many records its sample will hold)
         self.ctx.dtok_expect(size - start if source is None else 0)
+        # While blocks go through the one-kernel tokenizer their verdicts are
+        # read one block late (`wk_dtok_scan_emit_begin` / `_end`): the next
+        # block's kernel is queued before this thread waits for the current
+        # one's, and the device goes from one to the other without the host in
+        # between.  `lag`: the blocks under way, oldest first.
+        from collections import deque
+        lag = deque()
+        may_lag = not ordinal and not os.environ.get('WOLTKA_NO_LAG')
+
+        def settle(leave):
+            """Read verdicts until `leave` blocks are under way.  A block the
+            kernel hands back takes the one behind it along: both go the way
+            of `one`, in order."""
+            while len(lag) > leave:
+                t0 = time.perf_counter()
+                res = self.ctx.dtok_scan_emit_end()
+                lap['scan'] += time.perf_counter() - t0
+                if res is None:
+                    ROUTES['dtok_lag_back'] += 1
+                    again = list(lag)
+                    lag.clear()
+                    for it in again:
+                        yield from one(it)
+                        ahead.done(it)
+                    return
+                it = lag.popleft()
+                lap['blocks'] += 1
+                ROUTES['dtok_lag'] += 1
+                if res[0]:
+                    yield None, ('dtok', (it[1], it[2], it[5], it[6], it[7],
+                                          it[8], res[1])), None, None, None, \
+                        None
+                tok.set_header_state(it[8])
+                ahead.done(it)
+
         try:
             while True:
                 t0 = time.perf_counter()
@@ -1044,9 +1079,31 @@ class DeviceTextRoute:
                 lap['wait'] += time.perf_counter() - t0
                 if item is None:
                     break
+                slot = item[0]
+                if may_lag and self._spec and self._dmaps is None and \
+                        isinstance(slot, tuple) and slot[0] == 'det':
+                    t0 = time.perf_counter()
+                    begun = self.ctx.dtok_scan_emit_begin(tok, item[1],
+                                                          item[3], item[4])
+                    lap['scan'] += time.perf_counter() - t0
+                    if begun:
+                        serial[0] += 1      # (the device's "current block" moved on)
+                        lag.append(item)
+                        yield from settle(1)
+                        continue
+                yield from settle(0)
                 yield from one(item)
                 ahead.done(item)
+            yield from settle(0)
         finally:
+            # (left early: what is under way is waited for, nothing more)
+            try:
+                while lag and getattr(self.ctx, '_h', None):
+                    lag.popleft()
+                    if self.ctx.dtok_scan_emit_end() is None:
+                        lag.clear()
+            except Exception:           # noqa: BLE001 - on its way out
+                pass
             ahead.close()
             if getattr(self.ctx, '_h', None):   # (still open)
                 self.ctx.dtok_expect(0)
