@@ -426,6 +426,21 @@ int wk_dtok_readmap_fetch(wk_ctx* ctx, char* out, int64_t cap);
 int wk_dtok_stage_hits(wk_ctx* ctx, const int32_t* genome_of_subject,
                        int32_t n_subjects, double th, int64_t* n_reads,
                        int64_t* n_hits, int* status);
+/* The same, the block's hits placed BEHIND those of the blocks staged this way
+ * since the last wk_ordinal_count / wk_ordinal_match: ordinal.py:243-335
+ * (flush_chunk) matches a chunk's reads one by one, so how many blocks make a
+ * chunk changes nothing -- and the match sorted by genome stripe (O4,
+ * csrc/wk_stripe.hpp) pays from a few million hits on, where a 64 MB block of
+ * text brings 1.5 M.  *may_wait = 1: `jobs` are of the kind that match serves
+ * and the pile is below what it wants (wk_tune "stripes_min"): the caller may
+ * stage the next block first; 0: count now.  The pile is one chunk, with one
+ * group for all of it (wk_set_uniform_group).  wk_ordinal_stage and
+ * wk_dtok_stage_hits refuse (WK_E_STATE) while a pile has not been counted. */
+int wk_dtok_stage_hits_append(wk_ctx* ctx, const int32_t* genome_of_subject,
+                              int32_t n_subjects, double th,
+                              const wk_job* jobs, int32_t n_jobs,
+                              int64_t* n_reads, int64_t* n_hits, int* status,
+                              int* may_wait);
 
 /* Convenience: stage + classify in one call from host buffers. */
 int wk_classify_chunk(wk_ctx* ctx, const wk_job* jobs, int32_t n_jobs,

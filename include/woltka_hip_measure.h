@@ -80,6 +80,11 @@ int wk_text_clear(wk_ctx* ctx);
  * context was created.  wk_tune "dtok_fused" (0/1) switches it; results never
  * depend on it ("dtok_fused_per_cu": its persistent workgroups per CU). */
 int wk_dtok_fused_counts(wk_ctx* ctx, int64_t* done, int64_t* handed_back);
+/* Chunks wk_ordinal_count matched sorted by genome stripe (csrc/wk_stripe.hpp)
+ * and chunks it matched with the gather kernels alone (csrc/wk_ordinal.hpp),
+ * since the context was created.  wk_tune "stripes_min" / WOLTKA_STRIPES_MIN:
+ * the hits from which a chunk is sorted; results never depend on it. */
+int wk_ordinal_chunk_counts(wk_ctx* ctx, int64_t* sorted, int64_t* gathered);
 /* The rate (bytes/s) of `reps` pinned host -> device copies of `bytes` each,
  * back to back on a stream of their own: the bound of the end-to-end text
  * route on this box (bench.py's e2e rooflines are quoted against it). */

@@ -263,7 +263,8 @@ def test_device_tokenizer_coord_match_equals_host(tmp_path, monkeypatch,
 
 
 def test_device_ex_really_runs(tmp_path):
-    """The coord-match run above must have gone through wk_dtok_stage_hits."""
+    """The coord-match run above must have gone through the device's staging
+    (wk_dtok_stage_hits_append: one sample, no strata)."""
     from woltka_amd import _native as nat
     rng = random.Random(9)
     coords, sam = _random_coords_sam(rng, 2000)
@@ -273,20 +274,76 @@ def test_device_ex_really_runs(tmp_path):
     cfp = tmp_path / 'coords.txt'
     cfp.write_text(coords)
     calls = []
-    orig = nat.Context.dtok_stage_hits
+    orig = nat.Context.dtok_stage_hits_append
 
     def spy(self, *a):
         res = orig(self, *a)
         calls.append(res)
         return res
-    nat.Context.dtok_stage_hits = spy
+    nat.Context.dtok_stage_hits_append = spy
     try:
         a, _ = _run(tmp_path, 'd', False, input_fp=str(indir),
                     input_fmt='sam', coords_fp=str(cfp))
     finally:
-        nat.Context.dtok_stage_hits = orig
-    assert calls and all(st == 0 for st, _, _ in calls)
-    assert sum(h for _, _, h in calls) > 3000
+        nat.Context.dtok_stage_hits_append = orig
+    assert calls and all(st == 0 for st, _, _, _ in calls)
+    assert sum(h for _, _, h, _ in calls) > 3000
+
+
+@pytest.mark.parametrize('block', [1 << 26, 1 << 15, 1 << 13])
+@pytest.mark.parametrize('stripes_min', [0, 2500, 4000000])
+def test_hits_of_several_blocks_pile_up_for_the_sorted_match(
+        tmp_path, monkeypatch, block, stripes_min):
+    """O4 on the product's route: the blocks' hits are staged one behind the
+    other (wk_dtok_stage_hits_append) until the match sorted by genome stripe
+    (csrc/wk_stripe.hpp) has `stripes_min` of them -- here a few thousand, in
+    the product 4 M; what is left at the end of a file is counted then.  Same
+    tables and log as with every block counted by itself (WOLTKA_NO_HIT_PILE)
+    and as the host tokenizer's; the sorted match did run."""
+    from woltka_amd import classify as C
+    from woltka_amd import _native as nat
+    from woltka_amd.hostio import ROUTES
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', block)
+    monkeypatch.setenv('WOLTKA_STRIPES_MIN', str(stripes_min))
+    rng = random.Random(zlib.crc32(f'pile:{block}:{stripes_min}'.encode()))
+    coords, sam = _random_coords_sam(rng, 4000)
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    (indir / 'S1.sam').write_text(sam)
+    (indir / 'S2.sam').write_text(sam[:len(sam) // 3].rsplit('\n', 1)[0] + '\n')
+    (indir / 'S3.sam').write_text('@HD\tVN:1.0\n')
+    cfp = tmp_path / 'coords.txt'
+    cfp.write_text(coords)
+    kw = dict(input_fp=str(indir), input_fmt='sam', coords_fp=str(cfp))
+    sorted_calls = []
+    orig = nat.Context.ordinal_count
+
+    def spy(self, jobs):
+        orig(self, jobs)
+        sorted_calls.append(self.ordinal_chunk_counts())
+    ROUTES.clear()
+    monkeypatch.setattr(nat.Context, 'ordinal_count', spy)
+    a, log_a = _run(tmp_path, 'pile', False, **kw)
+    monkeypatch.setattr(nat.Context, 'ordinal_count', orig)
+    routes_a = dict(ROUTES)
+    monkeypatch.setenv('WOLTKA_NO_HIT_PILE', '1')
+    ROUTES.clear()
+    b, log_b = _run(tmp_path, 'each', False, **kw)
+    routes_b = dict(ROUTES)
+    monkeypatch.delenv('WOLTKA_NO_HIT_PILE')
+    h, log_h = _run(tmp_path, 'host', True, **kw)
+    assert a == b == h
+    assert log_a == log_b == log_h
+    assert routes_a.get('dhits', 0) == routes_b.get('dhits', 0) > 0, routes_a
+    assert routes_b.get('dhits_piled', 0) == 0
+    if block < 1 << 26 and stripes_min:
+        assert routes_a.get('dhits_piled', 0) > 0, routes_a
+    # (chunks sorted, chunks gathered) as the context counted them
+    assert sorted_calls
+    if stripes_min < 4000000:
+        assert max(x[0] for x in sorted_calls) > 0, sorted_calls
+    else:
+        assert max(x[0] for x in sorted_calls) == 0, sorted_calls
 
 
 @pytest.mark.parametrize('bad', ['pairX\t99\tG001\tabc\t42\t50M\t=\t1\t0\t*\t*',

@@ -54,7 +54,7 @@ SYMBOLS = (
     'wk_tok_read', 'wk_tok_trim', 'wk_tok_sam_span', 'wk_tok_span', 'wk_tok_set_header_state',
     'wk_dtok_format',
     'wk_dtok_copy', 'wk_dtok_copy_ahead', 'wk_dtok_copy_wait',
-    'wk_dtok_copy_drop', 'wk_dtok_subject_map', 'wk_dtok_ahead_room', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits',
+    'wk_dtok_copy_drop', 'wk_dtok_subject_map', 'wk_dtok_ahead_room', 'wk_dtok_text_back', 'wk_dtok_expect', 'wk_dtok_scan', 'wk_dtok_emit', 'wk_dtok_stage_hits', 'wk_dtok_stage_hits_append',
     'wk_dtok_scan_emit', 'wk_dtok_scan_emit_begin', 'wk_dtok_scan_emit_end',
     'wk_dtok_keep_reads', 'wk_readmap_tables',
     'wk_dtok_readmap',
@@ -74,7 +74,7 @@ SYMBOLS = (
     'wk_gz_bound', 'wk_gz_member', 'wk_crc32', 'wk_gz_inflate_members',
     'wk_gunzip_open', 'wk_gunzip_read', 'wk_gunzip_error', 'wk_gunzip_close',
     'wk_text_upload', 'wk_text_clear', 'wk_h2d_rate',
-    'wk_dtok_fused_counts')
+    'wk_dtok_fused_counts', 'wk_ordinal_chunk_counts')
 
 
 class Job(C.Structure):
@@ -209,6 +209,10 @@ def load_library():
                                    C.c_int, i64p, C.POINTER(C.c_int)]),
         'wk_dtok_stage_hits': (C.c_int, [p, i32p, C.c_int32, C.c_double, i64p,
                                          i64p, C.POINTER(C.c_int)]),
+        'wk_dtok_stage_hits_append': (C.c_int, [p, i32p, C.c_int32, C.c_double,
+                                                C.POINTER(Job), C.c_int32, i64p,
+                                                i64p, C.POINTER(C.c_int),
+                                                C.POINTER(C.c_int)]),
         'wk_dtok_emit': (C.c_int, [p, i64p, i64p, C.POINTER(C.c_int)]),
         'wk_dtok_scan_emit': (C.c_int, [p, p, C.c_void_p, C.c_int64, C.c_int64,
                                         i64p, C.POINTER(C.c_int),
@@ -284,6 +288,7 @@ def load_library():
         'wk_text_upload': (C.c_int, [p, C.c_void_p, C.c_int64, C.c_int64]),
         'wk_text_clear': (C.c_int, [p]),
         'wk_dtok_fused_counts': (C.c_int, [p, i64p, i64p]),
+        'wk_ordinal_chunk_counts': (C.c_int, [p, i64p, i64p]),
         'wk_h2d_rate': (C.c_int, [p, C.c_int64, C.c_int,
                                   C.POINTER(C.c_double)]),
     }
@@ -657,6 +662,18 @@ class Context:
             C.byref(b), C.byref(st)))
         return st.value, a.value, b.value
 
+    def dtok_stage_hits_append(self, genome_of_subject, th, jobs):
+        """``dtok_stage_hits`` behind the hits of the blocks staged this way
+        since the last count (``wk_dtok_stage_hits_append``).  Returns
+        (status, reads, hits, may_wait): ``may_wait`` -- the next block may be
+        staged before ``ordinal_count``."""
+        g = _arr(genome_of_subject, np.int32)
+        a, b, st, w = C.c_int64(0), C.c_int64(0), C.c_int(1), C.c_int(0)
+        self._check(self._lib.wk_dtok_stage_hits_append(
+            self._h, _ptr(g, C.c_int32), g.size, float(th), self._jobs(jobs),
+            len(jobs), C.byref(a), C.byref(b), C.byref(st), C.byref(w)))
+        return st.value, a.value, b.value, bool(w.value)
+
     def dtok_scan(self, tok, buf, begin, stop, extra=False):
         """Copy and parse ``buf[begin:stop]`` (whole lines ending at a run
         boundary: ``Tokenizer.sam_span``) on the device.  Returns (status,
@@ -720,6 +737,14 @@ class Context:
 
     def text_clear(self):
         self._check(self._lib.wk_text_clear(self._h))
+
+    def ordinal_chunk_counts(self):
+        """(measurement) chunks ``ordinal_count`` matched sorted by genome
+        stripe, chunks it matched with the gather kernels alone."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.wk_ordinal_chunk_counts(self._h, C.byref(a),
+                                                      C.byref(b)))
+        return a.value, b.value
 
     def dtok_fused_counts(self):
         """(measurement) blocks the one-kernel tokenizer did, blocks it handed

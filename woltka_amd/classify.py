@@ -157,6 +157,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         self._tring, self._reader = None, None      # device tokenizer: text staging, reader threads
         self._fused_seen = (0, 0)                   # wk_dtok_fused_counts when the last file ended
         self._deferred_from = None                  # see take_deferred
+        self._hits_open = None                      # group of the hits piled up on the device (`_settle_hits`)
         # read maps formatted on the device (csrc/wk_readmap.hpp)
         self._dmaps = None          # (rank2dir, outzip, namedic) while a file is read that way
         self._dfmt = 'sam'          # format of the file the device tokenises
@@ -251,6 +252,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
                 and 4 * known <= self.slots_reserved:
             self._used_bound = (known + need, self.slots_reserved)
             return
+        self._settle_hits()     # (their keys are in the bound, not in the table yet)
         used = self.ctx.stats()['table_used']
         self._used_epoch = self._epoch
         if 2 * (used + need) <= self.slots_reserved and \
@@ -611,8 +613,11 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         the Python parsers, of the host tokenizer, anything that needs the
         assignments back on the host — takes the general route."""
         if packed is not None and isinstance(packed[0], str):
+            if packed[0] != 'dhits':
+                self._settle_hits()
             return getattr(self, self.ROUTE_OF[packed[0]])(data, packed,
                                                           sample_of)
+        self._settle_hits()
         return self._run_general(
             data, reads, subque, sample_of, strata_of, trimsub, rank2dir,
             outzip, namedic, ordinal, packed, strata_ids, strata_labels, names,
@@ -788,12 +793,26 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         """Queries classified since the last call that `run_chunk` has not
         reported yet (the coord-match tally route counts them on the
         device)."""
+        self._settle_hits()
         if self._deferred_from is None:
             return 0
         n = (self.ctx.stats()['n_reads'] - self._deferred_from) \
             // self._n_batches()
         self._deferred_from = None
         return n
+
+    def _settle_hits(self):
+        """Blocks of the device text route whose hits are piled up on the
+        device (`wk_dtok_stage_hits_append`: the match sorted by genome stripe
+        wants a few million hits, a block brings 1.5 M) are matched and
+        counted now.  Called in front of everything that looks at the counts
+        or stages another chunk."""
+        group = self._hits_open
+        if group is None:
+            return
+        self._hits_open = None
+        self.ctx.set_uniform_group(group)
+        self.ctx.ordinal_count(self.jobs)
 
     def _release_staged(self, packed):
         """The staging call has copied the block (it waits for its copies):

@@ -110,6 +110,7 @@ struct DtokArgs {
     int32_t* o_end;
     uint32_t* o_len;
     int32_t* o_hoff;                // ... and the reads' offsets
+    uint32_t o_hit_base;            // (hits staged in front of this block's, wk_dtok_stage_hits_append: o_* point behind them, the offsets count from them)
     int32_t* o_group;               // (with a strata map on the device) the reads' (sample, stratum) groups
     // plain flavour: the tokenizer's ids -> the subject indices the records carry, when they differ (`--trim-sub`:
     // several names, one subject; workflow.py:840-841)
@@ -708,7 +709,7 @@ __global__ void __launch_bounds__(kDtokThreads) dtok_place_kernel(DtokArgs a, St
     if (a.is_first[i] & 2u) {  // the read's first hit: its offset
         for (uint32_t q = 0; q < m && q < 3u; ++q) groups_before += seen[q] ? 1u : 0u;
         const uint32_t r = (uint32_t)(base >> 32) + groups_before;
-        a.o_hoff[r] = (int32_t)at;
+        a.o_hoff[r] = (int32_t)(at + a.o_hit_base);
         if constexpr (kStrata) a.o_group[r] = strata_lookup(strata, a.text + a.line_start[i], a.lmeta[i] & 0x0FFFFFFFu, m);
     }
 }

@@ -179,6 +179,8 @@ struct wk_ctx {
     int64_t fused_blocks = 0, fused_fallbacks = 0;   // blocks the fused kernel did / handed back
     hipEvent_t res_ev = nullptr;
     int use_stripes = 1;       // (0: the gather kernels of wk_ordinal.hpp for every read; measurement)
+    int64_t chunks_sorted = 0, chunks_gathered = 0;   // (measurement: wk_ordinal_chunk_counts)
+    bool acc_open = false;     // the staged hits are blocks piled up by wk_dtok_stage_hits_append, not counted yet
     int64_t stripes_min_hits = 4000000;  // chunks below this keep the gather kernels (wk_tune "stripes_min")
     DevBuf sb_cnt, sb_tot, sb_base, sb_binned, sb_units, sb_over, sb_stat;
     DevBuf r_genome, r_beg, r_end, r_len, r_hoff;
@@ -998,6 +1000,8 @@ int wk_create(int device, wk_ctx** out) {
     if (const char* nf = getenv("WOLTKA_NO_FUSED")) c->use_fused = (nf[0] && nf[0] != '0') ? 0 : 1;
     if (const char* nc = getenv("WOLTKA_FZ_NO_CHAIN")) c->fz_no_chain = nc[0] && nc[0] != '0';
     if (const char* nl = getenv("WOLTKA_NO_LAG")) c->lag_enabled = !(nl[0] && nl[0] != '0');
+    if (const char* sm = getenv("WOLTKA_STRIPES_MIN"))
+        if (sm[0]) c->stripes_min_hits = std::max<long long>(0, atoll(sm));
     *out = c;
     return WK_OK;
 }
@@ -2958,6 +2962,13 @@ int wk_h2d_rate(wk_ctx* c, int64_t bytes, int reps, double* bytes_per_s) {
     return WK_OK;
 }
 
+int wk_ordinal_chunk_counts(wk_ctx* c, int64_t* sorted, int64_t* gathered) {
+    if (!c || !sorted || !gathered) return WK_E_ARG;
+    *sorted = c->chunks_sorted;
+    *gathered = c->chunks_gathered;
+    return WK_OK;
+}
+
 // (measurement) blocks of the text route the fused kernel did / handed back to the six kernels since the context exists
 int wk_dtok_fused_counts(wk_ctx* c, int64_t* done, int64_t* handed_back) {
     if (!c || !done || !handed_back) return WK_E_ARG;
@@ -3963,35 +3974,57 @@ int wk_dtok_readmap_fetch(wk_ctx* c, char* out, int64_t cap) {
 }
 
 // The scanned block's hits ("ex" flavour) as the staged chunk of the coord-match:
-// what wk_ordinal_stage would have been given.
-int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_subjects, double th, int64_t* n_reads,
-                       int64_t* n_hits, int* status) {
+// what wk_ordinal_stage would have been given.  `append`: behind the hits staged by the calls before that
+// nothing has counted yet (a read's hits never span two blocks: the chunk of both is what wk_ordinal_stage
+// would have been given for their reads together).
+static hipError_t grow_keep(wk_ctx* c, DevBuf& b, size_t need, size_t keep) {
+    if (need <= b.cap) return hipSuccess;
+    if (keep == 0 || !b.p) return b.reserve(need);
+    DevBuf bigger;
+    hipError_t e = bigger.reserve(need * 2);
+    if (e != hipSuccess && (e = bigger.reserve(need)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(bigger.p, b.p, std::min(keep, b.cap), hipMemcpyDeviceToDevice, c->stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    b.release();
+    b = bigger;
+    return hipSuccess;
+}
+
+static int dtok_stage_impl(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_subjects, double th, bool append, int64_t* n_reads,
+                           int64_t* n_hits, int* status) {
     if (!c || !n_reads || !n_hits || !status || n_subjects < 0 || (n_subjects > 0 && !genome_of_subject)) return WK_E_ARG;
     *status = 1;
     *n_reads = *n_hits = 0;
     if (!c->dt_ready || !c->dt_extra) return fail(c, WK_E_STATE, "no block scanned for the \"ex\" flavour (wk_dtok_scan)");
     if (!(th > 0.0)) return fail(c, WK_E_ARG, "overlap threshold must be positive");
+    if (c->acc_open && !append) return fail(c, WK_E_STATE, "staged hits not counted yet (wk_ordinal_count)");
+    if (c->acc_open && th != c->th) return fail(c, WK_E_STATE, "staged hits of another overlap threshold not counted yet");
     c->dt_ready = false;
     DeviceGuard guard(c->device);
     KtScope kt_scope(c);
     const uint32_t lines = c->dt_lines;
+    const bool behind = append && c->acc_open && c->ord_valid;
+    const int64_t base_h = behind ? c->n_hits : 0, base_r = behind ? c->o_reads : 0;
+    if (base_h + (int64_t)lines >= (1ll << 31) - 64) return fail(c, WK_E_RANGE, "more than 2^31 hits staged");
     int rc;
     if ((rc = upload(c, c->d_gmap, genome_of_subject, (size_t)std::max(n_subjects, 1) * 4))) return rc;
-    HIP_TRY(c, c->o_genome.reserve(((size_t)lines + 1) * 4));
-    HIP_TRY(c, c->o_beg.reserve(((size_t)lines + 1) * 4));
-    HIP_TRY(c, c->o_end.reserve(((size_t)lines + 1) * 4));
-    HIP_TRY(c, c->o_len.reserve(((size_t)lines + 1) * 4));
-    HIP_TRY(c, c->o_hoff.reserve(((size_t)lines + 2) * 4));
+    const size_t cap_h = (size_t)base_h + lines + 1, keep_h = (size_t)base_h * 4;
+    HIP_TRY(c, grow_keep(c, c->o_genome, cap_h * 4, keep_h));
+    HIP_TRY(c, grow_keep(c, c->o_beg, cap_h * 4, keep_h));
+    HIP_TRY(c, grow_keep(c, c->o_end, cap_h * 4, keep_h));
+    HIP_TRY(c, grow_keep(c, c->o_len, cap_h * 4, keep_h));
+    HIP_TRY(c, grow_keep(c, c->o_hoff, ((size_t)base_r + lines + 2) * 4, (size_t)base_r * 4));
     unsigned long long totals = 0;
     if (lines > 0) {
         DtokArgs a = dtok_args(c);
         a.gmap = c->d_gmap.as<int32_t>();
         a.n_gmap = (uint32_t)n_subjects;
-        a.o_genome = c->o_genome.as<int32_t>();
-        a.o_beg = c->o_beg.as<int32_t>();
-        a.o_end = c->o_end.as<int32_t>();
-        a.o_len = c->o_len.as<uint32_t>();
-        a.o_hoff = c->o_hoff.as<int32_t>();
+        a.o_genome = c->o_genome.as<int32_t>() + base_h;
+        a.o_beg = c->o_beg.as<int32_t>() + base_h;
+        a.o_end = c->o_end.as<int32_t>() + base_h;
+        a.o_len = c->o_len.as<uint32_t>() + base_h;
+        a.o_hoff = c->o_hoff.as<int32_t>() + base_r;
+        a.o_hit_base = (uint32_t)base_h;
         const uint32_t n_tiles = (lines + kDtokThreads - 1) / kDtokThreads;
         HIP_TRY(c, c->d_tiles.reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off.reserve((size_t)n_tiles * 8));
@@ -4004,8 +4037,8 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
                            c->d_tile_off.as<unsigned long long>(), (int64_t)n_tiles, scalar_u64(c, 3));
         hipLaunchKernelGGL(dtok_scan_lines_kernel, grid, dim3(kDtokThreads), 0, c->stream, a, c->d_tile_off.as<unsigned long long>());
         if (c->s_use) {
-            HIP_TRY(c, c->c_group.reserve(((size_t)lines + 1) * 4));
-            a.o_group = c->c_group.as<int32_t>();
+            HIP_TRY(c, grow_keep(c, c->c_group, ((size_t)base_r + lines + 1) * 4, (size_t)base_r * 4));
+            a.o_group = c->c_group.as<int32_t>() + base_r;
             hipLaunchKernelGGL(dtok_place_kernel<true>, grid, dim3(kDtokThreads), 0, c->stream, a, strata_args(c));
         } else {
             hipLaunchKernelGGL(dtok_place_kernel<false>, grid, dim3(kDtokThreads), 0, c->stream, a, StrataArgs{});
@@ -4018,20 +4051,52 @@ int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_su
     }
     const int64_t hits = (int64_t)(totals & 0xFFFFFFFFull), reads = (int64_t)(totals >> 32);
     // (the offsets' last entry; the stream orders it in front of whatever reads them)
-    hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, c->stream, c->o_hoff.as<uint32_t>() + reads, (uint32_t)hits);
+    hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, c->stream, c->o_hoff.as<uint32_t>() + base_r + reads, (uint32_t)(base_h + hits));
     HIP_TRY(c, hipGetLastError());
-    c->n_hits = hits;
-    c->o_reads = reads;
+    c->n_hits = base_h + hits;
+    c->o_reads = base_r + reads;
     c->th = th;
-    c->has_group = c->s_use && lines > 0;
+    c->has_group = c->s_use && (lines > 0 || (behind && c->has_group));
     c->group_base = 0;
     c->rk_valid[0] = c->rk_valid[1] = false;
     c->ord_valid = true;
     c->sb_valid = false;
     c->chunk_valid = false;
+    c->acc_open = append;
     *n_reads = reads;
     *n_hits = hits;
     *status = 0;
+    return WK_OK;
+}
+
+int wk_dtok_stage_hits(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_subjects, double th, int64_t* n_reads,
+                       int64_t* n_hits, int* status) {
+    return dtok_stage_impl(c, genome_of_subject, n_subjects, th, false, n_reads, n_hits, status);
+}
+
+static bool ordinal_tally_jobs(const wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
+    bool tally = c->use_tally && !c->genes_by_index && c->slots > 0;
+    for (int j = 0; j < n_jobs && tally; ++j)
+        tally = jobs[j].mode == WK_MODE_NONE && !(jobs[j].flags & (WK_F_UNIQ | WK_F_SIZED));
+    return tally;
+}
+
+// wk_dtok_stage_hits, the block's hits placed BEHIND those of the blocks staged this way since the last count:
+// a 64 MB block of text brings 1.5 M hits, the sorted match (wk_stripe.hpp) pays from a few million on.
+// *may_wait = 1: the caller may stage the next block before it counts (`jobs` are of the kind the sorted match
+// serves, the pile is still below what it wants); 0: count now.  Whatever is piled up is one chunk for
+// wk_ordinal_count / wk_ordinal_match, with one group for all of it (wk_set_uniform_group) unless a strata map
+// on the device names the reads' groups.
+int wk_dtok_stage_hits_append(wk_ctx* c, const int32_t* genome_of_subject, int32_t n_subjects, double th, const wk_job* jobs,
+                              int32_t n_jobs, int64_t* n_reads, int64_t* n_hits, int* status, int* may_wait) {
+    if (!c || !may_wait || n_jobs < 0 || (n_jobs > 0 && !jobs)) return WK_E_ARG;
+    *may_wait = 0;
+    const int rc = dtok_stage_impl(c, genome_of_subject, n_subjects, th, true, n_reads, n_hits, status);
+    if (rc || *status != 0) return rc;
+    *may_wait = n_jobs > 0 && n_jobs <= WK_MAX_JOBS && !c->s_use && ordinal_tally_jobs(c, jobs, n_jobs) && c->use_stripes &&
+                        c->stripes_usable && c->stripes_host.size() <= kStripeMax && c->n_hits < c->stripes_min_hits
+                    ? 1
+                    : 0;
     return WK_OK;
 }
 
@@ -4045,6 +4110,7 @@ int wk_ordinal_stage(wk_ctx* c, const int32_t* genome, const int32_t* beg, const
     if (n_hits >= (1ll << 31)) return fail(c, WK_E_RANGE, "more than 2^31 hits in one chunk");
     if (hoff[0] != 0 || hoff[n_reads] != n_hits) return fail(c, WK_E_ARG, "hoff must run from 0 to n_hits");
     if (!(th > 0.0)) return fail(c, WK_E_ARG, "overlap threshold must be positive");
+    if (c->acc_open) return fail(c, WK_E_STATE, "staged hits not counted yet (wk_ordinal_count)");
     DeviceGuard guard(c->device);
     int rc;
     if ((rc = upload(c, c->o_genome, genome, (size_t)n_hits * 4))) return rc;
@@ -4199,6 +4265,7 @@ int wk_ordinal_match(wk_ctx* c) {
     if (!c->genes_set) return fail(c, WK_E_STATE, "no gene tables uploaded (wk_set_genes)");
     DeviceGuard guard(c->device);
     KtScope kt_scope(c);
+    c->acc_open = false;
     int rc = reserve_match_buffers(c);
     if (rc) return rc;
     if (c->n_hits > 0) {
@@ -4469,9 +4536,8 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     if (n_jobs < 1 || n_jobs > WK_MAX_JOBS || !jobs) return fail(c, WK_E_ARG, "n_jobs must be in [1, %d]", WK_MAX_JOBS);
     // the genes themselves are counted (rank none, one group, no size
     // normalisation): tallied per read straight from the matches
-    bool tally = c->use_tally && !c->has_group && !c->genes_by_index && c->slots > 0 && c->n_hits > 0 && c->o_reads > 0;
-    for (int j = 0; j < n_jobs && tally; ++j)
-        tally = jobs[j].mode == WK_MODE_NONE && !(jobs[j].flags & (WK_F_UNIQ | WK_F_SIZED));
+    const bool tally = ordinal_tally_jobs(c, jobs, n_jobs) && !c->has_group && c->n_hits > 0 && c->o_reads > 0;
+    c->acc_open = false;   // (whatever was piled up is counted by this call)
     if (!tally) {
         int rc = wk_ordinal_match(c);
         if (rc) return rc;
@@ -4483,8 +4549,11 @@ int wk_ordinal_count(wk_ctx* c, const wk_job* jobs, int32_t n_jobs) {
     // unit per stripe that loads the stripe's genes into LDS, one more read-back): from a few million hits on.
     // The text route stages a block's hits at a time (~1.6 M): those keep the gather kernels, at 80 us per
     // block against 370 (profiles/r05_e2e_ordinal_kernel_stats.csv).
-    if (c->use_stripes && c->stripes_usable && c->stripes_host.size() <= kStripeMax && c->n_hits >= c->stripes_min_hits)
+    if (c->use_stripes && c->stripes_usable && c->stripes_host.size() <= kStripeMax && c->n_hits >= c->stripes_min_hits) {
+        ++c->chunks_sorted;
         return stripe_count(c, jobs, n_jobs);
+    }
+    ++c->chunks_gathered;
     return tally_count(c, jobs, n_jobs);
 }
 

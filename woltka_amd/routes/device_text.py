@@ -1237,20 +1237,40 @@ class DeviceTextRoute:
             group = self._group_array(1, sample, None)
         for rank in self.ranks:
             data[rank].setdefault(sample, {})
+        # (one sample, no strata, no size log: the blocks' hits pile up on the
+        # device until the match sorted by genome stripe has enough of them,
+        # `_settle_hits`; a pile is one sample's)
+        pile = ds is None and not self.sizes and \
+            not os.environ.get('WOLTKA_NO_HIT_PILE')
+        if self._hits_open is not None and \
+                (not pile or self._hits_open != group):
+            self._settle_hits()
         if self._deferred_from is None:
             self._deferred_from = self.ctx.stats()['n_reads']
-        status, n_reads, _ = self.ctx.dtok_stage_hits(self._tok_genome,
-                                                      self._th)
+        wait = False
+        if pile:
+            status, n_reads, _, wait = self.ctx.dtok_stage_hits_append(
+                self._tok_genome, self._th, self.jobs)
+        else:
+            status, n_reads, _ = self.ctx.dtok_stage_hits(self._tok_genome,
+                                                          self._th)
         if status == 0:
             ROUTES['dhits_strata' if ds is not None else 'dhits'] += 1
             self._n_reads += n_reads
-            if n_reads:
+            if pile:
+                self._hits_open = group
+                if wait:
+                    ROUTES['dhits_piled'] += 1
+                else:
+                    self._settle_hits()
+            elif n_reads:
                 if ds is None:
                     self.ctx.set_uniform_group(group)
                 self.ctx.ordinal_count(self.jobs)
                 if self.sizes:
                     self._collect_log()
             return 0
+        self._settle_hits()
         n = 0
         for _, arrays, ids, *_ in self._host_block(
                 buf, fill, first, final, hdr_in, True, groups=ds is not None):

@@ -143,6 +143,7 @@ class Folding:
         ``Fraction``s (sum_k n_k / k, classify.py:167-170) and clear the
         device table.  ``keep_groups``: the (sample, stratum) group ids stay
         valid (the staged chunk is classified again under other jobs)."""
+        self._settle_hits()
         while True:
             try:
                 keys, vals = self.ctx.counts_fetch()
@@ -253,6 +254,7 @@ class Folding:
         rounded ``float`` division.  ``exact`` leaves the rationals in place
         (profiles of several processes are then added exactly and converted
         once, ``exact_to_numbers``)."""
+        self._settle_hits()
         self._maps_done()
         if self._writer is not None:
             self._writer.flush()
