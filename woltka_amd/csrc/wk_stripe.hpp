@@ -31,7 +31,7 @@ constexpr uint32_t kStripeCells = 6144;      // cells of the stripe's coordinate
 constexpr uint32_t kStripeGenomes = 256;     // genomes of a stripe (4 KB of per-genome words)
 constexpr uint32_t kStripeMax = 1024;        // stripes a chunk can be sorted into (per-tile counters in LDS)
 constexpr uint32_t kStripeTileThreads = 256;
-constexpr uint32_t kStripeTileItems = 32;
+constexpr uint32_t kStripeTileItems = 16;
 constexpr uint32_t kStripeTileReads = kStripeTileThreads * kStripeTileItems;  // reads per workgroup of the count / scatter passes
 constexpr uint32_t kStripeMatchThreads = 1024;
 constexpr uint32_t kStripePiece = 65536;     // hits per workgroup of stripe_match
@@ -59,19 +59,8 @@ struct StripeSortArgs {
     int32_t* r_hoff;           // ... and offsets [n_rest_reads + 1]
 };
 
-// the class of a read: its stripe (one hit on a genome of a stripe), n_stripes (anything else that has hits
+// the class of a read (stripe_classes below): its stripe (one hit on a genome of a stripe), n_stripes (anything else that has hits
 // worth matching), 0xFFFFFFFF (nothing to match: no hits, or one hit of length 0 / on an unknown genome)
-__device__ __forceinline__ uint32_t stripe_class(const StripeSortArgs& a, int64_t r, int32_t* h0_out, int32_t* nh_out) {
-    const int32_t h0 = a.hoff[r], nh = a.hoff[r + 1] - h0;
-    *h0_out = h0;
-    *nh_out = nh;
-    if (nh <= 0) return 0xFFFFFFFFu;
-    if (nh > 1) return a.n_stripes;
-    const int32_t g = a.genome[h0];
-    if (g < 0 || g >= a.n_genomes || a.len[h0] == 0u) return 0xFFFFFFFFu;  // ordinal.py:231, 294-297: matches nothing
-    const int32_t s = a.stripe_of[g];
-    return s < 0 ? a.n_stripes : (uint32_t)s;
-}
 
 // The lanes of a wave that name the same counter share ONE LDS atomic (a Zipf sample sends half of a
 // wave's reads to the same stripe: 64 atomics on one LDS word serialise).  Returns the lane's place among
@@ -98,21 +87,61 @@ __device__ __forceinline__ uint32_t wave_shared_add(uint32_t* counters, uint32_t
     return place;
 }
 
-// pass 1: per tile of reads, how many go where.  (A tile is kStripeTileReads = 8192 reads: the count matrix
+// The classes of a tile's reads, kStripeTileItems per thread (read = tile base + item * threads + thread: a wave's
+// loads are coalesced).  Three dependent loads lead to a class -- offsets, the hit's genome, the genome's stripe --:
+// each step is done for all of the thread's items before the next, so that a thread has kStripeTileItems loads
+// under way instead of one (the passes are latency-bound otherwise: a tile took as long as the whole kernel).
+__device__ __forceinline__ void stripe_classes(const StripeSortArgs& a, int64_t base, uint32_t (&cls)[kStripeTileItems],
+                                               int32_t (&h0)[kStripeTileItems], int32_t (&nh)[kStripeTileItems]) {
+#pragma unroll
+    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
+        const int64_t r = base + it * kStripeTileThreads + threadIdx.x;
+        h0[it] = 0;
+        nh[it] = 0;
+        if (r < a.n_reads) {
+            h0[it] = a.hoff[r];
+            nh[it] = a.hoff[r + 1] - h0[it];
+        }
+    }
+    int32_t g[kStripeTileItems];
+    uint32_t ln[kStripeTileItems];
+#pragma unroll
+    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
+        g[it] = -1;
+        ln[it] = 0u;
+        if (nh[it] == 1) {
+            g[it] = a.genome[h0[it]];
+            ln[it] = a.len[h0[it]];
+        }
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < kStripeTileItems; ++it) {
+        uint32_t c = 0xFFFFFFFFu;
+        if (nh[it] > 1) {
+            c = a.n_stripes;
+        } else if (nh[it] == 1 && g[it] >= 0 && g[it] < a.n_genomes && ln[it] != 0u) {  // (else: ordinal.py:231, 294-297, matches nothing)
+            const int32_t st = a.stripe_of[g[it]];
+            c = st < 0 ? a.n_stripes : (uint32_t)st;
+        }
+        cls[it] = c;
+    }
+}
+
+// pass 1: per tile of reads, how many go where.  (A tile is kStripeTileReads = 4096 reads: the count matrix
 // -- rows x tiles, written and read with a stride of one row -- stays small against the hits themselves.)
 __global__ void __launch_bounds__(kStripeTileThreads) stripe_count_kernel(StripeSortArgs a) {
     __shared__ uint32_t cnt[kStripeMax + 2];
     for (uint32_t i = threadIdx.x; i < a.n_stripes + 2u; i += blockDim.x) cnt[i] = 0u;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kStripeTileReads;
+    uint32_t cls[kStripeTileItems];
+    int32_t h0[kStripeTileItems], nh[kStripeTileItems];
+    stripe_classes(a, base, cls, h0, nh);
     unsigned long long rest_hits = 0;
+#pragma unroll
     for (uint32_t it = 0; it < kStripeTileItems; ++it) {
-        const int64_t r = base + it * kStripeTileThreads + threadIdx.x;
-        int32_t h0 = 0, nh = 0;
-        uint32_t cls = 0xFFFFFFFFu;
-        if (r < a.n_reads) cls = stripe_class(a, r, &h0, &nh);
-        (void)wave_shared_add(cnt, cls, cls != 0xFFFFFFFFu);
-        if (cls == a.n_stripes) rest_hits += (unsigned long long)nh;
+        (void)wave_shared_add(cnt, cls[it], cls[it] != 0xFFFFFFFFu);
+        if (cls[it] == a.n_stripes) rest_hits += (unsigned long long)nh[it];
     }
     rest_hits = wave_sum(rest_hits);
     if ((threadIdx.x & (kWave - 1)) == 0 && rest_hits) atomicAdd(&cnt[a.n_stripes + 1u], (uint32_t)rest_hits);
@@ -176,7 +205,22 @@ __global__ void __launch_bounds__(64) stripe_bases_kernel(const unsigned long lo
 }
 
 // pass 3: the hits to their places.  Reads are taken in rounds of 256 consecutive ones (coalesced loads); the
-// reads of several hits keep their order: a scan over the workgroup per round places them.
+// reads of several hits keep their order: a scan over the workgroup per round places them.  (Measured against a
+// version that classifies all of a thread's reads first, like pass 1, and scans them with two barriers per tile:
+// 240 VGPRs, 3.8-5.5 ms for 100 M reads where this one takes 2.3 -- tools/sort_probe.py.)
+__device__ __forceinline__ uint32_t stripe_class(const StripeSortArgs& a, int64_t r, int32_t* h0_out, int32_t* nh_out) {
+    const int32_t h0 = a.hoff[r], nh = a.hoff[r + 1] - h0;
+    *h0_out = h0;
+    *nh_out = nh;
+    if (nh <= 0) return 0xFFFFFFFFu;
+    if (nh > 1) return a.n_stripes;
+    const int32_t g = a.genome[h0];
+    if (g < 0 || g >= a.n_genomes || a.len[h0] == 0u) return 0xFFFFFFFFu;  // ordinal.py:231, 294-297: matches nothing
+    const int32_t s = a.stripe_of[g];
+    return s < 0 ? a.n_stripes : (uint32_t)s;
+}
+
+
 __global__ void __launch_bounds__(kStripeTileThreads) stripe_scatter_kernel(StripeSortArgs a) {
     __shared__ uint32_t cur[kStripeMax];  // next place of a stripe's hits of this tile, inside the row
     __shared__ unsigned long long wtot[kStripeTileThreads / kWave];
@@ -235,6 +279,7 @@ __global__ void __launch_bounds__(kStripeTileThreads) stripe_scatter_kernel(Stri
         // (the next round's barrier orders this write before its reads)
     }
 }
+
 
 struct StripeUnit {  // a piece of one stripe's hits
     uint32_t stripe;
