@@ -206,6 +206,7 @@ struct wk_ctx {
     int kt_depth = 0;
     double lap_s[4] = {0, 0, 0, 0};   // (wk_tune "lap_print") seconds inside wk_dtok_copy / scan / waits of scan / emit
     double lap_x[6] = {0, 0, 0, 0, 0, 0};  // ... of the scan: until the buffer is claimed / line starts queued / parse queued / emission queued / finish / names
+    double lap_c[5] = {0, 0, 0, 0, 0};  // ... of the copy: streams + events / device buffer / copy queued / count queued; [4] the longest device-buffer step
     double lap_copy_ms = 0;           // ... and the copies' own durations (events around each on the copy stream)
     int64_t lap_copy_bytes = 0;
     hipEvent_t copy_ev0[192] = {};    // (kTextBufs) start of a block's copy
@@ -1203,6 +1204,9 @@ int wk_tune(wk_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "lap_print")) {
         fprintf(stderr, "[wk] seconds inside wk_dtok_copy %.3f, wk_dtok_scan(_emit) %.3f of which waiting for the stream %.3f, for the copy %.3f\n", c->lap_s[0],
                 c->lap_s[1], c->lap_s[2], c->lap_s[3]);
+        fprintf(stderr, "[wk] copy calls, host side: streams + events %.3f, device buffer %.3f (longest %.3f), copy queued %.3f, count queued %.3f\n", c->lap_c[0],
+                c->lap_c[1], c->lap_c[4], c->lap_c[2], c->lap_c[3]);
+        for (double& x : c->lap_c) x = 0;
         if (c->lap_copy_ms > 0)
             fprintf(stderr, "[wk] the copies themselves: %.1f ms for %.2f GB = %.1f GB/s (events around each copy + newline count on the copy stream)\n",
                     c->lap_copy_ms, (double)c->lap_copy_bytes / 1e9, (double)c->lap_copy_bytes / 1e6 / c->lap_copy_ms);
@@ -2740,6 +2744,7 @@ static int dtok_copy_impl(wk_ctx* c, const char* text, int64_t begin, int64_t st
     Lap lap(&c->lap_s[0]);
     const int64_t n64 = stop - begin;
     if (n64 == 0 || n64 >= (1ll << 31) - 64) return WK_OK;
+    auto lap_t = std::chrono::steady_clock::now();
     DeviceGuard guard(c->device);
     int k = -1;
     {
@@ -2755,18 +2760,28 @@ static int dtok_copy_impl(wk_ctx* c, const char* text, int64_t begin, int64_t st
         }
     }
     if (k < 0) return fail(c, WK_E_STATE, "more than %d blocks copied ahead of the scan", wk_ctx::kTextBufs - 1);
+    auto lap_mark = [&](int i) {
+        const auto now = std::chrono::steady_clock::now();
+        const double dt = std::chrono::duration<double>(now - lap_t).count();
+        c->lap_c[i] += dt;
+        if (i == 1) c->lap_c[4] = std::max(c->lap_c[4], dt);
+        lap_t = now;
+    };
     if (!c->copy_ev[k]) HIP_TRY(c, hipEventCreate(&c->copy_ev[k]));
     if (!c->copy_ev0[k]) HIP_TRY(c, hipEventCreate(&c->copy_ev0[k]));
     if (!c->copy_evm[k]) HIP_TRY(c, hipEventCreate(&c->copy_evm[k]));
     const uint32_t n = (uint32_t)n64;
     // (at least a full block's worth from the start: a file's first blocks are small, and growing a buffer
     // three times means three hipFree / hipMalloc pairs per buffer while the dictionary is cold)
+    lap_mark(0);
     HIP_TRY(c, text_buffer(c, k, (size_t)n + 64));
+    lap_mark(1);
     HIP_TRY(c, hipEventRecord(c->copy_ev0[k], c->copy_stream));
     // (only the copy on this stream: the 64 zero bytes behind the text are a fill
     // kernel, which wk_dtok_scan launches on its own stream behind the copy's event)
     HIP_TRY(c, copy_text_async(c, c->d_textptr[k], text + begin, (size_t)n, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->copy_evm[k], c->copy_stream));
+    lap_mark(2);
     // ... and, behind the copy, the count of the block's newlines -- on a stream of its own, so that the next
     // block's copy follows this one without a gap; the total lands in pinned memory (written by the kernel: no
     // trip through the DMA queue): wk_dtok_scan finds the number on the host instead of waiting for it
@@ -2784,6 +2799,7 @@ static int dtok_copy_impl(wk_ctx* c, const char* text, int64_t begin, int64_t st
         c->copy_counted[k] = true;
     }
     HIP_TRY(c, hipEventRecord(c->copy_ev[k], c->count_stream));
+    lap_mark(3);
     {
         std::lock_guard<std::mutex> lock(c->copy_mu);
         c->copy_n[k] = n;
