@@ -71,6 +71,8 @@ struct FusedArgs {
     DtokState* state;
     DtokState* host_state;               // pinned host memory: the block's scalars, written by the last workgroup
     unsigned long long* backup_next;     // [kMaxStreams] the streams' cursors behind this block (= in front of the next)
+    uint32_t* host_seq;                  // pinned host memory or null: `seq` is stored there (system scope, release) once host_state is written
+    uint32_t seq;
     StreamSet streams;
     const int32_t* submap;      // tokenizer id -> subject index, when they differ (`--trim-sub`), or null
     uint32_t n_submap;
@@ -611,6 +613,7 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
             *a.host_state = st;
             *a.state = DtokState{0u, 0u, 0ull, 0ull, 0ull, 0u, 0u};
             __threadfence_system();
+            if (a.host_seq) __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <ctime>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -265,11 +266,14 @@ struct wk_ctx {
         uint32_t lines_est = 0;
         int host_slot = 0;           // slot of the pinned scratch its scalars land in
         hipEvent_t ev = nullptr;
+        uint32_t seq = 0;
     };
     LagSlot lag[2];
     int lag_count = 0;
     hipEvent_t lag_ev[2] = {nullptr, nullptr};
     int lag_next_ev = 0;
+    bool lag_poll = true;           // a block's end is seen in pinned memory instead of waited for through an event (WOLTKA_LAG_POLL=0: the event; 127.7 against 126.3 us per block, tools/lag_probe.py)
+    uint32_t lag_seq = 0;
     bool lag_enabled = true;        // (WOLTKA_NO_LAG=1: every block's verdict is read before the next is launched)
     bool fz_no_chain = false;       // (measurement, WOLTKA_FZ_NO_CHAIN=1: the small kernel in front of every block)
     int w_streams = 0;              // streams the open accumulation writes to
@@ -1001,6 +1005,7 @@ int wk_create(int device, wk_ctx** out) {
     if (const char* nf = getenv("WOLTKA_NO_FUSED")) c->use_fused = (nf[0] && nf[0] != '0') ? 0 : 1;
     if (const char* nc = getenv("WOLTKA_FZ_NO_CHAIN")) c->fz_no_chain = nc[0] && nc[0] != '0';
     if (const char* nl = getenv("WOLTKA_NO_LAG")) c->lag_enabled = !(nl[0] && nl[0] != '0');
+    if (const char* lp = getenv("WOLTKA_LAG_POLL")) c->lag_poll = lp[0] && lp[0] != '0';
     if (const char* sm = getenv("WOLTKA_STRIPES_MIN"))
         if (sm[0]) c->stripes_min_hits = std::max<long long>(0, atoll(sm));
     *out = c;
@@ -3534,13 +3539,20 @@ int wk_dtok_scan_emit_begin(wk_ctx* c, wk_tok* tok, const char* text, int64_t be
     c->lag_next_ev ^= 1;
     fa.backup_next = fz_bk(c, (L.ring + 1) % 3).as<unsigned long long>();
     fa.host_state = reinterpret_cast<DtokState*>(c->host_back + (size_t)L.host_slot * wk_ctx::kBackBytes);
+    static_assert(sizeof(DtokState) <= 128 && wk_ctx::kBackBytes >= 132, "the slot's second half holds the block's sequence number");
+    L.seq = 0;
+    if (c->lag_poll) {
+        L.seq = ++c->lag_seq ? c->lag_seq : ++c->lag_seq;
+        fa.host_seq = reinterpret_cast<uint32_t*>(c->host_back + (size_t)L.host_slot * wk_ctx::kBackBytes + 128);
+        fa.seq = L.seq;
+    }
     c->w_counts_known = false;
     if (!c->fz_chain || c->fz_no_chain)
         hipLaunchKernelGGL(dtok_fused_begin_kernel, dim3(1), dim3(64), 0, c->stream, fz_bk(c, L.ring).as<unsigned long long>(),
                            (const unsigned long long*)fa.streams.cursor, fa.state);
     hipLaunchKernelGGL(dtok_fused_kernel, dim3(std::min<unsigned>(fa.n_tiles, wgs)), dim3(kFzThreads), 0, c->stream, fa);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(L.ev, c->stream));
+    if (!c->lag_poll) HIP_TRY(c, hipEventRecord(L.ev, c->stream));
     // (the next block is launched as if this one will be kept: its kernel leaves what that needs behind)
     c->fz_chain = true;
     c->fz_parity = (c->fz_parity + 1) % 3;
@@ -3556,7 +3568,26 @@ int wk_dtok_scan_emit_end(wk_ctx* c, int64_t* n_lines, int* status, int64_t* n_r
     if (c->lag_count == 0) return fail(c, WK_E_STATE, "no block under way (wk_dtok_scan_emit_begin)");
     DeviceGuard guard(c->device);
     const wk_ctx::LagSlot L = c->lag[0];
-    HIP_TRY(c, hipEventSynchronize(L.ev));
+    if (L.seq) {
+        // (the kernel's last workgroup stores the number behind the block's scalars: looked for every few
+        // microseconds -- there is a whole kernel's time of slack --, the stream waited for if it does not show)
+        const volatile uint32_t* seen = reinterpret_cast<const volatile uint32_t*>(c->host_back + (size_t)L.host_slot * wk_ctx::kBackBytes + 128);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool there = false;
+        for (int spin = 0;; ++spin) {
+            if (__atomic_load_n(const_cast<const uint32_t*>(reinterpret_cast<const volatile uint32_t*>(seen)), __ATOMIC_ACQUIRE) == L.seq) {
+                there = true;
+                break;
+            }
+            if (spin < 64) continue;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.01) break;
+            struct timespec ts = {0, 5000};
+            nanosleep(&ts, nullptr);
+        }
+        if (!there) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        HIP_TRY(c, hipEventSynchronize(L.ev));
+    }
     DtokState st{};
     small_back_get(c, L.host_slot, &st, sizeof st);
     const bool keep = st.flags == 0 && st.n_unknown == 0;
