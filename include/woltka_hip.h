@@ -134,7 +134,12 @@ int wk_device_name(const wk_ctx* ctx, char* buf, size_t cap);
 int wk_sync(wk_ctx* ctx); /* wait for all work on the context's stream */
 /* Product options.  "gene_index_pairs" (0/1; takes effect at the next
  * wk_set_genes): the gene lists of wk_ordinal_match are kept by gene table index
- * as well (wk_ordinal_pair_genes).  Unknown names are an error. */
+ * as well (wk_ordinal_pair_genes).  "dtok_count_ahead" (0/1, default 1): 0 =
+ * the blocks copied from now on will be scanned for plain SAM records of the
+ * weighted histogram -- wk_dtok_copy* launches no newline count behind their
+ * copies (the one-kernel tokenizer needs none; a block that takes the six
+ * kernels after all is counted when it is scanned).  Results never depend on
+ * it.  Unknown names are an error. */
 int wk_set_option(wk_ctx* ctx, const char* name, int64_t value);
 
 /* (Measurement entry points -- launch-shape knobs, event timers, resident-text

@@ -272,6 +272,7 @@ struct wk_ctx {
     int lag_count = 0;
     hipEvent_t lag_ev[2] = {nullptr, nullptr};
     int lag_next_ev = 0;
+    bool count_ahead = true;        // wk_set_option "dtok_count_ahead"
     bool lag_poll = true;           // a block's end is seen in pinned memory instead of waited for through an event (WOLTKA_LAG_POLL=0: the event; 127.7 against 126.3 us per block, tools/lag_probe.py)
     uint32_t lag_seq = 0;
     bool lag_enabled = true;        // (WOLTKA_NO_LAG=1: every block's verdict is read before the next is launched)
@@ -1086,6 +1087,10 @@ int wk_set_option(wk_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return WK_E_ARG;
     if (!strcmp(name, "gene_index_pairs")) {  // the next wk_set_genes: gene lists by gene table index (wk_ordinal_pair_genes)
         c->gene_index_opt = value != 0;
+        return WK_OK;
+    }
+    if (!strcmp(name, "dtok_count_ahead")) {  // 0: no newline count behind the copies of blocks (wk_dtok_copy*): the scans count the blocks that need it
+        c->count_ahead = value != 0;
         return WK_OK;
     }
     return fail(c, WK_E_ARG, "unknown option '%s' (launch shapes and ablation switches: wk_tune)", name);
@@ -2792,7 +2797,7 @@ static int dtok_copy_impl(wk_ctx* c, const char* text, int64_t begin, int64_t st
     // trip through the DMA queue): wk_dtok_scan finds the number on the host instead of waiting for it
     HIP_TRY(c, hipStreamWaitEvent(c->count_stream, c->copy_evm[k], 0));
     c->copy_counted[k] = false;
-    if (!c->fused_streak) {  // (blocks that go through the one kernel need no count: wk_dtok_fused.hpp)
+    if (!c->fused_streak && c->count_ahead) {  // (blocks that go through the one kernel need no count: wk_dtok_fused.hpp)
         const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
         HIP_TRY(c, c->d_tiles_k[k].reserve((size_t)n_tiles * 8));
         HIP_TRY(c, c->d_tile_off_k[k].reserve((size_t)n_tiles * 8));

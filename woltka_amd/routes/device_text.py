@@ -406,7 +406,7 @@ AHEAD_READ_THREADS = int(os.environ.get('WOLTKA_AHEAD_READ_THREADS', 16))
 TEXT_AHEAD_MIN = int(os.environ.get('WOLTKA_TEXT_AHEAD_MIN', 256 << 20))     # smaller files are read when their turn comes
 
 
-def start_text_ahead(path, fmt, device, warm=True, extra=False):
+def start_text_ahead(path, fmt, device, warm=True, extra=False, ordered=False):
     """`path`: a plain (uncompressed, regular) alignment file that will be the
     first to be read; `fmt`: its format if the caller knows it; `warm`: a
     tokenizer with the file's first subjects is being prepared
@@ -441,6 +441,11 @@ def start_text_ahead(path, fmt, device, warm=True, extra=False):
             if ctx is None:
                 return
             marks.append(('context', time.perf_counter()))
+            # (`ordered`: the run writes read maps.  Plain SAM records for
+            # the weighted histogram go through the one-kernel tokenizer,
+            # which needs no newline count behind a block's copy)
+            ctx.set_option('dtok_count_ahead',
+                           int(bool(extra or ordered or use_fmt != 'sam')))
             R = DeviceTextRoute
             ring = StageRing(ctx, 8, {
                 'text': (np.uint8, R.DTOK_BLOCK + R.DTOK_HEADROOM)},
@@ -1016,6 +1021,11 @@ class DeviceTextRoute:
         # back for the next one.  (`_TextAhead`: a reader that was started
         # before the engine existed is taken over here.)
         t_all = time.perf_counter()
+        if taken is None:
+            # (plain SAM records for the weighted histogram go through the
+            # one-kernel tokenizer: no newline count behind a block's copy)
+            self.ctx.set_option('dtok_count_ahead', int(bool(
+                ordinal or self._dmaps is not None or self._dfmt != 'sam')))
         ahead, whole = taken, None
         if ahead is None:
             whole = open_mapped() if source is None else None
@@ -1037,6 +1047,7 @@ class DeviceTextRoute:
                                lap)
         # (a plain file's size tells how many records its sample will hold)
         self.ctx.dtok_expect(size - start if source is None else 0)
+
         # While blocks go through the one-kernel tokenizer their verdicts are
         # read one block late (`wk_dtok_scan_emit_begin` / `_end`): the next
         # block's kernel is queued before this thread waits for the current

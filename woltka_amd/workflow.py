@@ -259,7 +259,8 @@ def _workflow_with_context(
                     not os.environ.get('WOLTKA_NO_DTOK'):
                 from .routes.device_text import start_text_ahead
                 start_text_ahead(fp0, input_fmt, device,
-                                 extra=bool(coords_fp))
+                                 extra=bool(coords_fp),
+                                 ordered=bool(outmap_dir))
     start_coords_ahead(coords_fp, zippers)
     try:
         tree, rankdic, namedic, root = build_hierarchy(
