@@ -22,7 +22,8 @@ def rate(v):
         return '—'
     if v < 1e6:
         return f'{v / 1e6:.2f} M'
-    return f'{v / 1e6:.0f} M' if v < 1e10 else f'{v / 1e9:.0f} G'
+    return f'{v / 1e6:.0f} M' if v < 1e10 else (
+        f'{v / 1e9:.1f} G' if v < 1e11 else f'{v / 1e9:.0f} G')
 
 
 rows = []
@@ -51,16 +52,21 @@ for key, label in (('lca', 'histogram alone (`configs.lca`, resident sliced reco
 for key, label in (('lca', 'config 3, `woltka classify` end to end'),
                    ('lca_gz', 'the same text as one `.sam.gz`'),
                    ('lca_gz8', 'the same text as eight `.sam.gz`'),
-                   ('lca_seqqual', 'a fifth of the reads with 150-base SEQ / QUAL (17 GB)'),
+                   ('lca_seqqual', 'config 3 with 150-base SEQ / QUAL on every line (85 GB)'),
                    ('flat', 'config 2 end to end (10 M records, flat map)'),
                    ('ordinal', 'config 4 end to end')):
     e = g(d, 'e2e', key)
     if not e or 'error' in e:
         continue
     rf = e.get('roofline', {})
+    if rf.get('bound') == 'host_scan':
+        bound = (f"{rf.get('achieved', '—')} GB/s of file text, above the link's "
+                 f"{rf.get('peak', '—')} GB/s: the columns nobody reads are cut on the host (bound: the host's scan)")
+    else:
+        bound = f"{rf.get('achieved', '—')} of {rf.get('peak', '—')} GB/s measured H2D = {rf.get('frac', '—')}"
     rows.append((f'`e2e.{key}`: {label}',
                  f"{e['seconds']:.3f} s = **{rate(e['value'])} records/s**",
-                 f"{rf.get('achieved', '—')} of {rf.get('peak', '—')} GB/s measured H2D = {rf.get('frac', '—')}; phases {e.get('phases_s')}"))
+                 f"{bound}; phases {e.get('phases_s')}"))
 tp = g(d, 'e2e', 'twopass')
 if tp and 'error' not in tp:
     for k in ('pass1', 'pass2'):
