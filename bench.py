@@ -577,8 +577,7 @@ class TextLcaWorkload:
     # text's -- takes dtok_lines / dtok_parse / dtok_emit: WOLTKA_NO_FUSED=1
     # times those)
     families = ('dtok_fused', 'dtok_lines', 'dtok_parse', 'dtok_emit')
-    symbols = {'dtok_fused': 'wk::dtok_fused_begin_kernel + '
-                             'wk::dtok_fused_kernel',
+    symbols = {'dtok_fused': 'wk::dtok_fused_kernel',
                'dtok_lines': 'wk::dtok_count_kernel + wk::tile_scan_kernel + '
                              'wk::dtok_lines_kernel',
                'dtok_parse': 'wk::dtok_parse_kernel<false>',
@@ -746,7 +745,18 @@ class TextLcaWorkload:
         self._flush_probe()
         view, begin, stop, hdr = self.blocks[self._probe]
         ctx.words_begin(self.jobs, 0)
-        ctx.dtok_scan_emit(self.tok, view, begin, stop)
+        # (as in `step`: the block queued twice, the second time behind its
+        # own first kernel -- its bracket runs from that kernel's end to its
+        # own, which is how a block's kernel sits in the product's loop; a
+        # block scanned the one-call way starts from an idle stream and with
+        # the small kernel that opens a chain in front)
+        if not os.environ.get('WOLTKA_NO_LAG') and \
+                ctx.dtok_scan_emit_begin(self.tok, view, begin, stop):
+            if ctx.dtok_scan_emit_begin(self.tok, view, begin, stop):
+                ctx.dtok_scan_emit_end()
+            ctx.dtok_scan_emit_end()
+        else:
+            ctx.dtok_scan_emit(self.tok, view, begin, stop)
         self._probe_pending = True
 
     def _flush_probe(self):

@@ -3552,10 +3552,13 @@ int wk_dtok_scan_emit_begin(wk_ctx* c, wk_tok* tok, const char* text, int64_t be
         fa.seq = L.seq;
     }
     c->w_counts_known = false;
+    KtScope kt_scope(c);   // (wk_profile_kernels: a block queued behind another one is bracketed from that one's end to its own)
+    KernelTimer* kf = ktimer_begin(c, "dtok_fused");
     if (!c->fz_chain || c->fz_no_chain)
         hipLaunchKernelGGL(dtok_fused_begin_kernel, dim3(1), dim3(64), 0, c->stream, fz_bk(c, L.ring).as<unsigned long long>(),
                            (const unsigned long long*)fa.streams.cursor, fa.state);
     hipLaunchKernelGGL(dtok_fused_kernel, dim3(std::min<unsigned>(fa.n_tiles, wgs)), dim3(kFzThreads), 0, c->stream, fa);
+    ktimer_end(c, kf);
     HIP_TRY(c, hipGetLastError());
     if (!c->lag_poll) HIP_TRY(c, hipEventRecord(L.ev, c->stream));
     // (the next block is launched as if this one will be kept: its kernel leaves what that needs behind)
