@@ -12,18 +12,20 @@ from woltka_amd import _native as nat  # noqa: E402
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
 with nat.Context(0) as ctx:
     wl = bench.TextLcaWorkload(ctx, 1003, scale)
-    for _ in range(3):
-        wl.step()
-    ctx.sync()
-    best = None
-    for rep in range(5):
-        t0 = time.perf_counter()
-        for _ in range(8):
-            wl.step()
-        ctx.sync()
-        dt = (time.perf_counter() - t0) / 8
-        best = dt if best is None else min(best, dt)
-    print('%d blocks: %.3f ms per pass, %.1f us per block (NO_LAG=%s LAG_POLL=%s)' % (
-        len(wl.blocks), best * 1e3, best * 1e6 / len(wl.blocks),
-        os.environ.get('WOLTKA_NO_LAG'), os.environ.get('WOLTKA_LAG_POLL')))
+    for ab in [int(x, 0) for x in os.environ.get('FZ_ABLATE', '0').split(',')]:
+      ctx.tune('fz_ablate', ab)
+      for _ in range(3):
+          wl.step()
+      ctx.sync()
+      best = None
+      for rep in range(5):
+          t0 = time.perf_counter()
+          for _ in range(8):
+              wl.step()
+          ctx.sync()
+          dt = (time.perf_counter() - t0) / 8
+          best = dt if best is None else min(best, dt)
+      print('%d blocks: %.3f ms per pass, %.1f us per block (NO_LAG=%s LAG_POLL=%s)' % (
+          len(wl.blocks), best * 1e3, best * 1e6 / len(wl.blocks),
+          os.environ.get('WOLTKA_NO_LAG'), os.environ.get('WOLTKA_LAG_POLL')), 'fz_ablate', ab)
     wl.close()
