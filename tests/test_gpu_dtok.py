@@ -979,6 +979,150 @@ def test_verdicts_read_one_block_late(tmp_path, monkeypatch, shape):
     assert routes_a.get('dtok', 0) == routes_b.get('dtok', 0)
 
 
+def test_late_verdict_entry_points_keep_their_contract():
+    """`wk_dtok_scan_emit_begin` / `_end` by themselves (include/woltka_hip.h):
+    at most two blocks under way -- a third is declined and nothing happens --,
+    the other entry points that touch the sample's records refuse while one
+    is, `_end` without a block under way is an error, and a sample scanned
+    half this way and half the one-call way has the cells of the two-call
+    pass over the same text."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from woltka_amd import _native as nat
+
+    class Small(bench.TextLcaWorkload):
+        BLOCK = 1 << 18
+
+    with nat.Context(0) as ctx:
+        wl = Small(ctx, 7, scale=0.004)
+        b = blk = None
+        try:
+            assert len(wl.blocks) > 20 and wl.fused_blocks == len(wl.blocks)
+            ctx.counts_clear()
+            assert ctx.words_begin(wl.jobs, 0)
+            b = [x[:3] for x in wl.blocks]
+            assert ctx.dtok_scan_emit_begin(wl.tok, *b[0])
+            assert ctx.dtok_scan_emit_begin(wl.tok, *b[1])
+            assert not ctx.dtok_scan_emit_begin(wl.tok, *b[2])
+            with pytest.raises(RuntimeError, match='verdict'):
+                ctx.words_flush()
+            with pytest.raises(RuntimeError, match='verdict'):
+                ctx.dtok_scan_emit(wl.tok, *b[2])
+            first, second = ctx.dtok_scan_emit_end(), ctx.dtok_scan_emit_end()
+            assert first is not None and second is not None
+            with pytest.raises(RuntimeError, match='no block under way'):
+                ctx.dtok_scan_emit_end()
+            reads = first[1] + second[1]
+            for k, blk in enumerate(b[2:]):
+                if k % 3 == 0 and ctx.dtok_scan_emit_begin(wl.tok, *blk):
+                    reads += ctx.dtok_scan_emit_end()[1]
+                    continue
+                status, _, done = ctx.dtok_scan_emit(wl.tok, *blk)
+                assert status == 0 and done is not None
+                reads += done
+            ctx.words_flush()
+            assert reads == wl.reads
+            assert wl.cells_equal(*ctx.counts_fetch())
+        finally:
+            b = blk = None      # (views of the workload's mapped text)
+            wl.close()
+
+
+def test_piled_hits_entry_point_keeps_its_contract():
+    """`wk_dtok_stage_hits_append` by itself (include/woltka_hip.h): a pile that
+    has not been counted is staged over by nothing else (WK_E_STATE), a block
+    staged twice behind itself counts twice what it counts alone, and one
+    pile of two blocks counts what the two blocks count one by one."""
+    from woltka_amd import _native as nat
+    from woltka_amd import synth
+    rng = np.random.default_rng(11)
+    p = synth.ordinal_problem(rng, n_genomes=50, genes_per_genome=40,
+                              n_pairs=10)
+    py = random.Random(5)
+    lines = []
+    for q in range(6000):
+        g = py.randrange(50)
+        lo = int(p['gstart'][p['genome_off'][g]])
+        hi = int(p['gend'][p['genome_off'][g + 1] - 1])
+        for mate, flag in ((1, 99), (2, 147)):
+            pos = py.randrange(max(lo - 100, 1), hi)
+            lines.append(f'q{q}\t{flag}\tG{g:03d}\t{pos}\t42\t'
+                         f'{py.choice([100, 150, 60])}M\t=\t1\t0\t*\t*')
+    half = len(lines) // 2
+    texts = [np.frombuffer(('\n'.join(x) + '\n').encode(), dtype=np.uint8)
+             for x in (lines[:half], lines[half:])]
+    jobs = [nat.Job(nat.MODE_NONE, 0, 0, 0, 0.0)]
+
+    def fresh():
+        ctx = nat.Context(0)
+        ctx.set_genes(p['genome_off'], p['gstart'], p['gend'],
+                      p['gene_feature'])
+        ctx.counts_reserve(1 << 16)
+        ctx.dtok_format('sam')
+        return ctx, nat.Tokenizer(2)
+
+    def scan(ctx, tok, text, gmap):
+        status, n_lines = ctx.dtok_scan(tok, text, 0, text.size, extra=True)
+        assert status == 0 and n_lines > 0
+        gmap.extend(int(x[1:]) for x in tok.new_subjects())
+        return np.asarray(gmap, dtype=np.int32)
+
+    def cells(ctx):
+        keys, vals = ctx.counts_fetch()
+        o = np.argsort(keys, kind='stable')
+        return keys[o], vals[o]
+
+    # every block counted by itself
+    ctx, tok = fresh()
+    gmap = []
+    for text in texts:
+        g = scan(ctx, tok, text, gmap)
+        st, reads, hits = ctx.dtok_stage_hits(g, 0.8)
+        assert st == 0 and hits > 1000
+        ctx.set_uniform_group(3)
+        ctx.ordinal_count(jobs)
+    one_by_one = cells(ctx)
+    ctx.close()
+    # one pile of both
+    ctx, tok = fresh()
+    gmap = []
+    g = scan(ctx, tok, texts[0], gmap)
+    st, reads, hits, wait = ctx.dtok_stage_hits_append(g, 0.8, jobs)
+    assert st == 0 and wait          # (far below what the sorted match wants)
+    g = scan(ctx, tok, texts[1], gmap)
+    with pytest.raises(RuntimeError, match='not counted'):
+        ctx.dtok_stage_hits(g, 0.8)
+    with pytest.raises(RuntimeError, match='not counted'):
+        ctx.ordinal_stage(np.zeros(1, np.int32), np.zeros(1, np.int32),
+                          np.ones(1, np.int32), np.ones(1, np.uint32),
+                          np.asarray([0, 1], np.int32), 0.8)
+    g = scan(ctx, tok, texts[1], gmap)      # (the refused call used the scan up)
+    st, reads2, hits2, wait = ctx.dtok_stage_hits_append(g, 0.8, jobs)
+    assert st == 0 and wait
+    ctx.set_uniform_group(3)
+    ctx.ordinal_count(jobs)
+    piled = cells(ctx)
+    assert np.array_equal(piled[0], one_by_one[0])
+    assert np.array_equal(piled[1], one_by_one[1])
+    # a block behind itself
+    ctx.counts_clear()
+    for _ in range(2):
+        g = scan(ctx, tok, texts[0], gmap)
+        assert ctx.dtok_stage_hits_append(g, 0.8, jobs)[0] == 0
+    ctx.set_uniform_group(3)
+    ctx.ordinal_count(jobs)
+    twice = cells(ctx)
+    ctx.counts_clear()
+    g = scan(ctx, tok, texts[0], gmap)
+    assert ctx.dtok_stage_hits_append(g, 0.8, jobs)[0] == 0
+    ctx.set_uniform_group(3)
+    ctx.ordinal_count(jobs)
+    once = cells(ctx)
+    assert np.array_equal(twice[0], once[0])
+    assert np.array_equal(twice[1], 2 * once[1])
+    ctx.close()
+
+
 def _with_seq_qual(sam_text, rng, crs=True):
     """Every alignment line of `sam_text` with SEQ / QUAL / tags as an aligner
     writes them (the '*' columns of the generators above filled in); a few
