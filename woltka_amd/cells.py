@@ -199,10 +199,27 @@ def write_lazy_table(profile, columns, path, openzip):
         store.i[idx]
     if idx.size == 0:
         return None
-    uf = np.unique(f)
-    fi = np.searchsorted(uf, f)
-    # rows = distinct (stratum, feature)
-    rows, inv = np.unique((t + 1) * uf.size + fi, return_inverse=True)
+    # the features met and the rows = distinct (stratum, feature), in order:
+    # by marks in a table when the ids are small against the cells (no sort
+    # over millions of cells), by sorting otherwise
+    top = int(f.max()) + 1
+    if top <= 8 * f.size + (1 << 20):
+        seen = np.zeros(top, dtype=bool)
+        seen[f] = True
+        uf = np.flatnonzero(seen)
+        fi = (np.cumsum(seen) - 1)[f]
+    else:
+        uf = np.unique(f)
+        fi = np.searchsorted(uf, f)
+    key = (t + 1) * uf.size + fi
+    top = (int(t.max()) + 2) * uf.size
+    if top <= 8 * f.size + (1 << 20):
+        seen = np.zeros(top, dtype=bool)
+        seen[key] = True
+        rows = np.flatnonzero(seen)
+        inv = (np.cumsum(seen) - 1)[key]
+    else:
+        rows, inv = np.unique(key, return_inverse=True)
     mat = np.zeros((rows.size, len(samples)), dtype=np.int64)
     mat[inv, col] = val
     row_t = (rows // uf.size - 1).astype(np.int32)

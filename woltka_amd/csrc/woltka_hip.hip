@@ -910,6 +910,10 @@ int wk_create(int device, wk_ctx** out) {
     DeviceGuard guard(device);
     if ((e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        // (the text route's two streams with it: made by the first wk_dtok_copy they cost the reader 40 ms of a call's
+        // first 100 -- it runs beside the hierarchy's and the pread pool's threads by then --, here 6)
+        (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->count_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->host_back),
                            (size_t)wk_ctx::kBackSlots * wk_ctx::kBackBytes + (size_t)wk_ctx::kTextBufs * 8,

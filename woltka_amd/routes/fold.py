@@ -4,6 +4,7 @@ end (`finish`; large folds stay arrays, cells.py), the `--sizes` log, and the
 reads of more candidates than a count key can say."""
 import os
 from fractions import Fraction
+from math import gcd
 
 import numpy as np
 
@@ -186,7 +187,11 @@ class Folding:
                 g2s = np.empty(len(self.groups), dtype=np.int32)
                 g2t = np.empty(len(self.groups), dtype=np.int32)
                 sid, tid = self._lz_sample_ids, self._lz_strata_ids
-                for g in np.unique(np.concatenate((cg, grp[big]))).tolist():
+                # (the groups met, without a sort over millions of cells)
+                met = np.zeros(len(self.groups), dtype=bool)
+                met[cg] = True
+                met[grp[big]] = True
+                for g in np.flatnonzero(met).tolist():
                     sample, stratum = self.groups[g]
                     if sample not in sid:
                         sid[sample] = len(self._lz_samples)
@@ -348,7 +353,7 @@ class Folding:
             else np.zeros(0, dtype=np.int64)
         n_t = len(self._lz_strata) + 1
         allkey = (sm * n_t + (tt + 1)) * (nat.FEATURE_UNASSIGNED + 1) + ff
-        for job in np.unique(j).tolist():
+        for job in np.flatnonzero(np.bincount(j)).tolist():
             rank = self.ranks[job]
             m = np.flatnonzero(j == job)
             key = allkey[m]
@@ -376,7 +381,8 @@ class Folding:
                 np.add.at(tot, inv, bn[qs])
                 for c, t in zip(both.tolist(), tot.tolist()):
                     i, k = divmod(c, 4096)
-                    extra[i] = extra.get(i, 0) + Fraction(t, k)
+                    v = Fraction(t, k)
+                    extra[i] = extra[i] + v if i in extra else v
             cuts = np.flatnonzero(s_[1:] != s_[:-1]) + 1
             lo = [0] + cuts.tolist()
             hi = cuts.tolist() + [s_.size]
@@ -404,12 +410,17 @@ class Folding:
                             dstb[key_] = dstb.get(key_, 0) + v
                     continue
                 for i in mine:      # the exact value of these few cells
-                    v = Fraction(int(units[i]), L) + extra[i]
-                    if v.denominator == 1:
-                        store.w[i], store.i[i] = True, v.numerator
+                    # (units / L + extra as one reduced fraction of ints)
+                    e = extra[i]
+                    num = int(units[i]) * e.denominator + e.numerator * L
+                    den = L * e.denominator
+                    g = gcd(num, den)
+                    num, den = num // g, den // g
+                    if den == 1:
+                        store.w[i], store.i[i] = True, num
                     else:
                         store.w[i] = False
-                        store.x[i] = v.numerator / v.denominator
+                        store.x[i] = num / den
                 out[k] = (cells, big)
         return out
 
