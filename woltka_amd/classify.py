@@ -210,6 +210,7 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
 
     # ------------------------------------------------------------------
     MAX_SLOTS = 1 << 30
+    GROW_TO = 1 << 26       # slots (16 B each) a table grows to by itself when it keeps filling up
 
     def _reserve(self, slots):
         """(Re)allocate the device count table (cleared) with a power-of-two
@@ -263,6 +264,12 @@ class Engine(DeviceTextRoute, WordsRoute, CoordMatchRoute, ReadMaps, Replay,
         self._used_bound = (need, None)     # (asked again next time)
         if 2 * need > self.slots_reserved and not self._table_fixed:
             self._reserve(4 * need)
+        elif not self._table_fixed and self.slots_reserved < self.GROW_TO:
+            # a table that had to be folded because it filled up comes back
+            # four times the size (HBM is what this device has to spare): a
+            # stratified run folds once or twice instead of once per few
+            # blocks, and `finish` adds up that many copies of a cell less
+            self._reserve(min(4 * self.slots_reserved, self.GROW_TO))
 
     def load_strata(self, fp, zippers, then=None, device=False):
         """Read-to-stratum map of one sample into the native tokenizer;
