@@ -820,9 +820,13 @@ def start_coords_ahead(coords_fp, zippers=None):
 
     def work():
         try:
+            import time
+            t0 = time.perf_counter()
             table = load_gene_coords_file(coords_fp, zippers)
+            t1 = time.perf_counter()
             table.names
             box['table'] = table
+            box['laps'] = (t0, t1, time.perf_counter())
         except BaseException as e:     # noqa: BLE001 - raised by build_mapper
             box['err'] = e
     th = threading.Thread(target=work, name='wk-coords', daemon=True)
@@ -833,7 +837,16 @@ def start_coords_ahead(coords_fp, zippers=None):
 def _coords_table(coords_fp, zippers):
     th, box = _coords_ahead.pop('x', (None, None))
     if th is not None:
+        import time
+        t_join = time.perf_counter()
         th.join()
+        if os.environ.get('WOLTKA_DTOK_TIMING') and 'laps' in box:
+            import sys
+            t0, t1, t2 = box['laps']
+            print('[coords] reader ahead: read + parse %.3f s, names %.3f s; '
+                  'begun %.3f s before it was asked for, waited for %.3f s'
+                  % (t1 - t0, t2 - t1, t_join - t0,
+                     time.perf_counter() - t_join), file=sys.stderr)
         if box['fp'] == coords_fp:
             if 'err' in box:
                 raise box['err']
