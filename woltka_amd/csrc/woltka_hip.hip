@@ -272,6 +272,7 @@ struct wk_ctx {
     int lag_count = 0;
     hipEvent_t lag_ev[2] = {nullptr, nullptr};
     int lag_next_ev = 0;
+    int fz_back_streak = 0, fz_skip = 0;   // blocks in a row the one kernel handed back; blocks it is left out for
     bool count_ahead = true;        // wk_set_option "dtok_count_ahead"
     bool lag_poll = true;           // a block's end is seen in pinned memory instead of waited for through an event (WOLTKA_LAG_POLL=0: the event; 127.7 against 126.3 us per block, tools/lag_probe.py)
     uint32_t lag_seq = 0;
@@ -3052,6 +3053,12 @@ int wk_dtok_format(wk_ctx* c, int fmt) {
     return WK_OK;
 }
 
+// a block the one kernel handed back: see dtok_scan_impl
+static void fz_handed_back(wk_ctx* c) {
+    c->fz_back_streak = std::min(c->fz_back_streak + 1, 6);
+    if (c->fz_back_streak >= 2) c->fz_skip = 1 << (c->fz_back_streak - 1);
+}
+
 static DevBuf& fz_bk(wk_ctx* c, int i) { return i == 0 ? c->w_backup : i == 1 ? c->w_backup2 : c->w_backup3; }
 
 static int dtok_emit_launch(wk_ctx* c, bool* ordered_out, unsigned long long* totals);
@@ -3152,8 +3159,14 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
     const uint32_t n_tiles = (n + kDtokTile - 1) / kDtokTile;
     HIP_TRY(c, c->d_state.reserve(sizeof(DtokState) + 64));
     // (one kernel for the block, wk_dtok_fused.hpp: decided here, the words' mode checked again below)
-    const bool fuse = emit && !extra && c->use_fused && c->dt_fmt == WK_FMT_SAM && c->w_open && c->w_mode == 0 && !c->dt_keep_reads &&
-                      wkx_tok_n_names(tok) < (1 << 23) - 1;
+    bool fuse = emit && !extra && c->use_fused && c->dt_fmt == WK_FMT_SAM && c->w_open && c->w_mode == 0 && !c->dt_keep_reads &&
+                wkx_tok_n_names(tok) < (1 << 23) - 1;
+    // (text the one kernel keeps handing back -- runs longer than its window, say -- pays for both ways block after
+    // block: after two blocks in a row it is left out for 2, 4, ... 32 blocks before it is tried again)
+    if (fuse && c->fz_skip > 0) {
+        --c->fz_skip;
+        fuse = false;
+    }
     // The six kernels need the block's newlines per tile before anything else; the one kernel counts its lines itself.
     // A block copied ahead while blocks went through the one kernel (`fused_streak`) was not counted behind its copy:
     // it is counted here only if it turns out to need the six kernels after all -- or if the sample's record buffers
@@ -3304,6 +3317,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
             c->fz_chain = keep;   // (not kept: dtok_emit_finish has put the cursors back)
             if (keep) {
                 c->fz_parity = (c->fz_parity + 1) % 3;
+                c->fz_back_streak = 0;
                 ++c->fused_blocks;
                 lines = (uint32_t)st.n_lines + (open_end ? 1u : 0u);
                 c->dt_lines = lines;
@@ -3317,6 +3331,7 @@ static int dtok_scan_impl(wk_ctx* c, wk_tok* tok, const char* text, int64_t begi
                 return WK_OK;
             }
             ++c->fused_fallbacks;
+            fz_handed_back(c);
             kt = ktimer_begin(c, "dtok_lines");
         }
     }
@@ -3448,7 +3463,7 @@ int wk_dtok_scan_emit_begin(wk_ctx* c, wk_tok* tok, const char* text, int64_t be
     if (!c || !tok || !text || begin < 0 || stop < begin || !started) return WK_E_ARG;
     *started = 0;
     const int64_t n64 = stop - begin;
-    if (!c->lag_enabled || !c->use_fused || c->lag_count >= 2 || c->dt_fmt != WK_FMT_SAM || !c->w_open || c->w_mode != 0 || c->dt_keep_reads ||
+    if (!c->lag_enabled || !c->use_fused || c->lag_count >= 2 || c->fz_skip > 0 || c->dt_fmt != WK_FMT_SAM || !c->w_open || c->w_mode != 0 || c->dt_keep_reads ||
         n64 <= 0 || n64 >= (1ll << 31) - 64 || wkx_tok_n_names(tok) >= (1 << 23) - 1)
         return WK_OK;
     if (!wkx_tok_device_ok(tok) && !c->dt_submap_on) return WK_OK;
@@ -3613,6 +3628,7 @@ int wk_dtok_scan_emit_end(wk_ctx* c, int64_t* n_lines, int* status, int64_t* n_r
         c->dt_lines = lines;
         c->dt_lpb = (double)lines / (double)L.n;
         c->fused_streak = true;
+        c->fz_back_streak = 0;
         ++c->fused_blocks;
         *n_lines = lines;
         *status = 0;
@@ -3644,6 +3660,7 @@ int wk_dtok_scan_emit_end(wk_ctx* c, int64_t* n_lines, int* status, int64_t* n_r
     c->fz_chain = false;
     c->fused_streak = false;
     ++c->fused_fallbacks;
+    fz_handed_back(c);
     *status = 2;
     return WK_OK;
 }
