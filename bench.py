@@ -626,7 +626,7 @@ class TextLcaWorkload:
                 view = text[pos:end]
                 ok, begin, stop, hdr = nat.Tokenizer.sam_span(
                     view, end >= size, in_header, 'sam')
-                if ok or end >= size:
+                if (ok and stop > 0) or end >= size:
                     break
                 span *= 2
             self.blocks.append((view, begin, stop, hdr))

@@ -165,6 +165,59 @@ def test_mapped_route_is_taken(tmp_path, monkeypatch):
     assert a == b and log_a == log_b
 
 
+def test_mapped_route_with_runs_longer_than_a_block(tmp_path, monkeypatch):
+    """The file pinned in place, blocks of 32 KB, lines of up to 12 KB in runs
+    of up to 16: where a view holds one run from its first byte on, the cut
+    at 0 makes no progress -- the reader has to look further (it used to come
+    back with the same view for ever; found by tools/fuzz_text_routes.py)."""
+    from woltka_amd import classify as C
+    monkeypatch.setattr(C.Engine, 'DTOK_BLOCK', 1 << 15)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_MIN', 0)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_PIECE', 1 << 21)
+    monkeypatch.setattr(C.Engine, 'HOSTREG_RATE', 0.0)
+    monkeypatch.setenv('WOLTKA_HOSTREG', '1')
+    monkeypatch.setenv('WOLTKA_NO_TEXT_AHEAD', '1')
+    rng = random.Random(102)
+    tax = os.path.join(ROOT, 'tests', 'golden', 'data', 'taxonomy')
+    with open(os.path.join(tax, 'taxid.map')) as f:
+        subjects = [ln.split('\t')[0] for ln in f][:90]
+    indir = tmp_path / 'in'
+    indir.mkdir()
+    (indir / 'S1.sam').write_text(_fused_sam(rng, 1500, subjects, 'long_lines'))
+    kw = dict(input_fp=str(indir), input_fmt='sam',
+              nodes_fps=[os.path.join(tax, 'nodes.dmp')],
+              map_fps=[os.path.join(tax, 'taxid.map')], ranks='genus')
+    from woltka_amd.hostio import ROUTES
+    from woltka_amd import _native as nat
+    pinned = []
+    orig = nat.Context.host_register
+
+    def spy(self, address, n):
+        pinned.append(n)
+        return orig(self, address, n)
+    monkeypatch.setattr(nat.Context, 'host_register', spy)
+    ROUTES.clear()
+    a, log_a = _run(tmp_path, 'd', False, **kw)
+    assert ROUTES.get('dtok', 0) > 0 and pinned, (dict(ROUTES), pinned)
+    b, log_b = _run(tmp_path, 'h', True, **kw)
+    assert a == b and log_a == log_b
+
+
+@pytest.mark.parametrize('block', [1 << 15, 1 << 17])
+def test_one_kernel_tokenizer_on_lines_longer_than_its_window(block):
+    """SAM lines as an aligner writes them for long reads (SEQ / QUAL kept: up
+    to 12 KB a line) never reach the one kernel through the column trim, but
+    do when the file is pinned in place.  A line that starts in a tile and
+    does not end inside its window must send the block to the six kernels: the
+    kernel used to see no run start at all around such a line and dropped the
+    run without a word (found by tools/fuzz_text_routes.py).  Block by block,
+    the cells of the one kernel against those of the six."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import fused_vs_six_blocks
+    bad, n_blocks = fused_vs_six_blocks.compare(102, block, 1500, 'long_lines')
+    assert n_blocks > 50 and bad == 0
+
+
 def test_device_tokenizer_at_size(tmp_path):
     """1.2 M records of the config-3 shape: device vs host route, and the
     device route must really have been taken (records arrive packed)."""

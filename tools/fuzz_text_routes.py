@@ -21,6 +21,10 @@ import test_gpu_dtok as T  # noqa: E402
 
 
 def main():
+    if os.environ.get('FUZZ_DUMP_AFTER'):   # (where is a round stuck?)
+        import faulthandler
+        faulthandler.dump_traceback_later(
+            float(os.environ['FUZZ_DUMP_AFTER']), repeat=False, exit=True)
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     from woltka_amd import classify as C
@@ -71,7 +75,9 @@ def main():
                 if rng.random() < 0.25:
                     kw['trimsub'] = '_'
             ROUTES.clear()
+            print(f'seed {seed}: {kind}, block {block} ...', flush=True)
             a, log_a = T._run(tmp, 'dev', False, **kw)
+            print('  device route done', dict(ROUTES), flush=True)
             routes = dict(ROUTES)
             b, log_b = T._run(tmp, 'host', True, **kw)
             ok = a == b and log_a == log_b

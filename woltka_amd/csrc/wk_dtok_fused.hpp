@@ -16,10 +16,11 @@
 // run of equal QNAMEs belongs to the tile its first line starts in; the workgroup
 // of a tile therefore looks kFzBack bytes back (the line before its first one:
 // does that one continue a run?) and kFzFwd bytes ahead (the rest of its last
-// run).  A run that does not end inside the window, more than kFzLines lines in a
+// run).  A run that does not end inside the window, a line that starts in the tile
+// and does not end inside the window, more than kFzLines lines in a
 // window, or a line before the tile that cannot be found in the window's back
-// part is nothing this kernel guesses about: the first two set kDtokSpill (the
-// block is done again by the six kernels, which have no such limits), the third
+// part is nothing this kernel guesses about: the first three set kDtokSpill (the
+// block is done again by the six kernels, which have no such limits), the last
 // is looked up in global memory.
 //
 // Records.  Workgroups are persistent (a few per CU, tiles taken round-robin)
@@ -351,6 +352,13 @@ __global__ void __launch_bounds__(kFzThreads) __attribute__((amdgpu_waves_per_eu
             }
         }
         __syncthreads();
+        // A line that STARTS in this tile and does not end inside the window is a line nobody sees whole: its tile is
+        // the one that would own a run it starts, and the tiles behind it find no run start in it.  (Lines of more
+        // than kFzFwd bytes -- SEQ / QUAL of a long read kept; text that comes through the column trim has none.)
+        if (!too_many && (total_nl > 0u || w0 == 0u)) {
+            const uint32_t trail = w0 + (uint32_t)ls[total_nl];   // the first byte behind the window's last newline
+            if (trail >= t0 && trail < t1) my_flags |= kDtokSpill;
+        }
         const uint32_t first_line = w0 == 0u ? 0u : 1u;
         const uint32_t n_lines = too_many ? 0u : total_nl;  // whole lines: [first_line, n_lines)
         if (tid < kFzPad) info[n_lines + tid] = kFiStart;   // (a walk ahead stops behind the last whole line)

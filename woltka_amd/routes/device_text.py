@@ -875,7 +875,10 @@ class DeviceTextRoute:
                                                               self._dfmt,
                                                               ordinal)
                 lap['span'] += time.perf_counter() - t0
-                if not ok and not final:    # no complete run yet: look further
+                if (not ok or stop == 0) and not final:
+                    # no complete run yet -- or one run from the view's first
+                    # byte to its last line (a cut at 0 would come back here
+                    # with the same view for ever): look further
                     span *= 2
                     continue
                 if ramp is not None:
