@@ -456,3 +456,47 @@ def test_trimmed_blocks_are_the_trimmed_file(tmp_path, block, extra,
         assert whole == want
     assert n > 1
     assert ring._free.qsize() + (ring._cur is not None) == 4
+
+
+@pytest.mark.parametrize('block', [1 << 12, 1 << 15])
+def test_a_cut_at_zero_is_no_progress_for_a_reader_without_a_carry(block):
+    """`sam_span` answers ok with stop == 0 when ONE run fills a view from its
+    first byte to its last whole line (the next run starts nowhere in it).
+    The pread readers carry such text over and grow the view; a reader that
+    looks at the file in place (`blocks_mapped`, `bench.TextLcaWorkload`) has
+    to look further instead -- with the cut at 0 it would come back with the
+    same view for ever, which is what `tools/fuzz_text_routes.py` met.  The
+    loop those readers use, on text whose runs are longer than a block: it
+    ends, and its blocks are the text."""
+    import random
+    rng = random.Random(block)
+    lines = ['@HD\tVN:1.0']
+    for q in range(300):
+        k = rng.choice([1, 2, 16])
+        pad = 'A' * rng.choice([10, 400, 5000])
+        for i in range(k):
+            lines.append(f'read{q:05d}\t0\tG{rng.randrange(50):03d}\t1\t42\t'
+                         f'50M\t*\t0\t0\t{pad}\t{pad}')
+    text = np.frombuffer(('\n'.join(lines) + '\n').encode(), dtype=np.uint8)
+    size, pos, in_header, got, zero_cuts = text.size, 0, True, [], 0
+    for _ in range(100000):
+        span = block
+        while True:
+            end = min(size, pos + span)
+            view = text[pos:end]
+            ok, begin, stop, hdr = nat.Tokenizer.sam_span(
+                view, end >= size, in_header, 'sam')
+            zero_cuts += bool(ok and stop == 0 and end < size)
+            if (ok and stop > 0) or end >= size:
+                break
+            span *= 2
+        got.append(bytes(view[begin:stop]))
+        in_header = hdr
+        if end >= size:
+            break
+        pos += stop
+    else:
+        raise AssertionError('the reader does not end')
+    assert zero_cuts > 0                    # (the case is met)
+    body = bytes(text)
+    assert b''.join(got) == body[body.index(b'read00000'):]
