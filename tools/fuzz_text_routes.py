@@ -76,10 +76,16 @@ def main():
                     kw['trimsub'] = '_'
             ROUTES.clear()
             print(f'seed {seed}: {kind}, block {block} ...', flush=True)
-            a, log_a = T._run(tmp, 'dev', False, **kw)
+
+            def run(tag, host):
+                try:            # (an input both routes refuse: the same words)
+                    return T._run(tmp, tag, host, **kw)
+                except (ValueError, IndexError) as e:
+                    return {'error': type(e).__name__ + ': ' + str(e)}, ''
+            a, log_a = run('dev', False)
             print('  device route done', dict(ROUTES), flush=True)
             routes = dict(ROUTES)
-            b, log_b = T._run(tmp, 'host', True, **kw)
+            b, log_b = run('host', True)
             ok = a == b and log_a == log_b
             print(f'seed {seed}: {kind}, block {block}, '
                   f'{"same" if ok else "DIFFERENT"}; routes {routes}',
